@@ -1,0 +1,128 @@
+"""ctypes binding of oracle/liboracle.so (the C restatement of the reference's CPU path).
+
+TEST INFRASTRUCTURE ONLY: the product package `imageflow_amd` never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FILTER_IDS = {  # weights.rs:43-78
+    "RobidouxFast": 1, "Robidoux": 2, "RobidouxSharp": 3, "Ginseng": 4, "GinsengSharp": 5, "Lanczos": 6,
+    "LanczosSharp": 7, "Lanczos2": 8, "Lanczos2Sharp": 9, "CubicFast": 10, "Cubic": 11, "CubicSharp": 12,
+    "CatmullRom": 13, "Mitchell": 14, "CubicBSpline": 15, "Hermite": 16, "Jinc": 17, "RawLanczos3": 18,
+    "RawLanczos3Sharp": 19, "RawLanczos2": 20, "RawLanczos2Sharp": 21, "Triangle": 22, "Linear": 23, "Box": 24,
+    "CatmullRomFast": 25, "CatmullRomFastSharp": 26, "Fastest": 27, "MitchellFast": 28, "NCubic": 29,
+    "NCubicSharp": 30, "LegacyIDCTFilter": 31,
+}
+LOBE_NATURAL, LOBE_EXACT, LOBE_SHARPEN_PERCENT = 0, 1, 2
+REPLACE_SELF, BLEND_WITH_SELF, BLEND_WITH_MATTE = 0, 1, 2
+SRGB, LINEAR = 0, 1
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "--no-print-directory"], check=True, capture_output=True)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        u8p, f32p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+        L.ifo_weights_flat.argtypes = [C.c_int, C.c_int, C.c_float, C.c_double, C.c_uint32, C.c_uint32,
+                                       u32p, u32p, f32p, C.c_uint32, u32p]
+        L.ifo_natural_negative_ratio.restype = C.c_double
+        L.ifo_natural_negative_ratio.argtypes = [C.c_int]
+        L.ifo_table_s2l.restype = f32p
+        L.ifo_table_s2f.restype = f32p
+        L.ifo_table_l2s.restype = u8p
+        L.ifo_uchar_clamp_ff.restype = C.c_uint8
+        L.ifo_uchar_clamp_ff.argtypes = [C.c_float]
+        L.ifo_linear_to_srgb_lut.restype = C.c_uint8
+        L.ifo_linear_to_srgb_lut.argtypes = [C.c_float]
+        L.ifo_scale_and_render.argtypes = [
+            C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+            C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+            C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+            C.c_int, C.c_float, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
+        L.ifo_scale_and_render_batch.argtypes = [
+            C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+            C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+            C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+            C.c_int, C.c_float, C.c_int, C.c_int, C.c_uint32, C.c_int]
+        L.ifo_apply_matte.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
+        L.ifo_stride_for_width.restype = C.c_uint32
+        L.ifo_stride_for_width.argtypes = [C.c_uint32]
+        L.ifo_init_tables()
+        _LIB = L
+    return _LIB
+
+
+def weights(filter_id, out_size, in_size, lobe_mode=LOBE_NATURAL, lobe_value=0.0, kernel_width_scale=1.0):
+    """populate_weights -> (left[u], count[u], flat f32 weights)."""
+    L = lib()
+    cap = out_size * (int(2 * 7 * max(1.0, in_size / out_size)) + 8)
+    left = np.zeros(out_size, np.uint32)
+    count = np.zeros(out_size, np.uint32)
+    w = np.zeros(cap, np.float32)
+    n = C.c_uint32(0)
+    rc = L.ifo_weights_flat(filter_id, lobe_mode, lobe_value, kernel_width_scale, out_size, in_size,
+                            left.ctypes.data_as(C.POINTER(C.c_uint32)), count.ctypes.data_as(C.POINTER(C.c_uint32)),
+                            w.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n))
+    if rc:
+        raise RuntimeError(f"oracle weights rc={rc}")
+    return left, count, w[: n.value].copy()
+
+
+def stride_for_width(w):
+    return int(lib().ifo_stride_for_width(w))
+
+
+def tables():
+    L = lib()
+    s2l = np.ctypeslib.as_array(L.ifo_table_s2l(), (256,)).copy()
+    s2f = np.ctypeslib.as_array(L.ifo_table_s2f(), (256,)).copy()
+    l2s = np.ctypeslib.as_array(L.ifo_table_l2s(), (16384,)).copy()
+    return s2l, s2f, l2s
+
+
+def scale_and_render(inp, in_w, in_h, canvas, cw, ch, x, y, w, h, filter_id=2, sharpen=0.0, working_space=LINEAR,
+                     compositing=REPLACE_SELF, matte_bgra=0, alpha_meaningful=False, want_f32=False,
+                     in_stride=None, c_stride=None):
+    """inp/canvas: C-contiguous uint8 arrays of rows with stride bytes per row; canvas is modified in place."""
+    L = lib()
+    in_stride = in_stride or inp.strides[0]
+    c_stride = c_stride or canvas.strides[0]
+    f32 = np.zeros((h, w, 4), np.float32) if want_f32 else None
+    rc = L.ifo_scale_and_render(inp.ctypes.data, in_w, in_h, in_stride, int(alpha_meaningful),
+                                canvas.ctypes.data, cw, ch, c_stride, x, y, w, h,
+                                filter_id, sharpen, working_space, compositing, matte_bgra,
+                                f32.ctypes.data if want_f32 else None)
+    return rc, f32
+
+
+def scale_and_render_batch(inp, canvas, in_w, in_h, in_stride, cw, ch, c_stride, x, y, w, h, filter_id=2,
+                           sharpen=0.0, working_space=LINEAR, compositing=REPLACE_SELF, matte_bgra=0,
+                           alpha_meaningful=False, n_threads=1):
+    """inp: uint8 [n, in_h*in_stride]; canvas: uint8 [n, ch*c_stride]."""
+    L = lib()
+    n = inp.shape[0]
+    return L.ifo_scale_and_render_batch(inp.ctypes.data, inp.strides[0], n, in_w, in_h, in_stride, int(alpha_meaningful),
+                                        canvas.ctypes.data, canvas.strides[0], cw, ch, c_stride, x, y, w, h,
+                                        filter_id, sharpen, working_space, compositing, matte_bgra, n_threads)
+
+
+def apply_matte(bgra, w, h, stride, matte_bgra, alpha_meaningful=True):
+    return lib().ifo_apply_matte(bgra.ctypes.data, w, h, stride, int(alpha_meaningful), matte_bgra)
