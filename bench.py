@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- megapixels/s of the resample hot path (BASELINE.json metric) on N MI355X of one node.
+
+Workload (config.workload): BASELINE config 2 -- a batch of 256 synthetic 3840x2160 BGRA8 frames per GPU, device
+resident, each resized to 200x200 with Robidoux in linear light (ReplaceSelf canvas, alpha not meaningful, as after
+a JPEG decode).  One "step" = one pass of the fused kernel over the rank's whole batch.  Weak scaling: every rank owns
+its own 256 frames (independent images: no data-path collective); for N > 1 the 200x200 outputs of each step are
+gathered with one RCCL all_gather on a side stream, overlapped with the next step.
+
+Prints ONE JSON line (rank 0).  value = source megapixels resized per second over all ranks, inputs already in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+IN_W, IN_H, OUT_W, OUT_H = 3840, 2160, 200, 200
+FRAMES_PER_GPU = 256
+ALGO_BYTES_PER_FRAME = IN_W * IN_H * 4 + OUT_W * OUT_H * 4        # 33,337,600 B
+HBM_PEAK = 8.0e12                                                   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_frames(torch, n, rank, device, pattern):
+    """frame k pixel (x,y): B=(x+k)&255, G=(y+k)&255, R=(x+y+k)&255, A=255 (bench_graphics.rs:403-414 + offset);
+    the random half is uniform bytes (worst case for LUT bank conflicts and rounding)."""
+    from imageflow_amd.graphics.bitmaps import Bitmap, get_stride
+    stride = get_stride(IN_W)
+    data = torch.empty((n, IN_H, stride), dtype=torch.uint8, device=device)
+    x = torch.arange(IN_W, device=device, dtype=torch.int32)[None, :]
+    y = torch.arange(IN_H, device=device, dtype=torch.int32)[:, None]
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1000 + rank)
+    for i in range(n):
+        k = rank * n + i
+        use_random = pattern == "random" or (pattern == "mixed" and i >= n // 2)
+        if use_random:
+            data[i] = torch.randint(0, 256, (IN_H, stride), dtype=torch.uint8, device=device, generator=gen)
+            data[i, :, 3::4] = 255
+        else:
+            px = data[i, :, : IN_W * 4].view(IN_H, IN_W, 4)
+            px[..., 0] = ((x + k) & 255).to(torch.uint8)
+            px[..., 1] = ((y + k) & 255).to(torch.uint8).expand(IN_H, IN_W)
+            px[..., 2] = ((x + y + k) & 255).to(torch.uint8)
+            px[..., 3] = 255
+    return Bitmap(data.view(n, IN_H * stride), IN_W, IN_H, stride, alpha_meaningful=False)
+
+
+def cpu_baseline(sample_seconds=15.0):
+    """The oracle (our C port of the reference's CPU path; the Rust reference cannot be built here) timed on the
+    host cores on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import oracle as O
+    from tests import util as U
+    cores = os.cpu_count() or 1
+    fr = U.gradient_frames(1, IN_W, IN_H)
+    cst = U.stride_for(OUT_W)
+    can = np.zeros((1, OUT_H, cst), np.uint8)
+    t0 = time.perf_counter()
+    O.scale_and_render_batch(fr.reshape(1, -1), can.reshape(1, -1), IN_W, IN_H, fr.shape[2], OUT_W, OUT_H, cst,
+                             0, 0, OUT_W, OUT_H, n_threads=1)
+    t1 = time.perf_counter() - t0
+    n = int(max(cores, min(8 * cores, cores * max(1.0, sample_seconds / max(t1, 1e-3)))))
+    n = min(n, 96)
+    frames = np.concatenate([U.gradient_frames(n // 2, IN_W, IN_H), U.random_frames(n - n // 2, IN_W, IN_H, alpha=False)])
+    cans = np.zeros((n, OUT_H * cst), np.uint8)
+    flat = frames.reshape(n, -1)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        rc = O.scale_and_render_batch(flat, cans, IN_W, IN_H, frames.shape[2], OUT_W, OUT_H, cst, 0, 0, OUT_W, OUT_H,
+                                      n_threads=cores)
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        best = dt if best is None else min(best, dt)
+    mp = n * IN_W * IN_H / 1e6
+    return {"value": round(mp / best, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+            "single_thread_MPps": round(IN_W * IN_H / 1e6 / t1, 2),
+            "sample": f"{n} frames 3840x2160->200x200 Robidoux linear (half gradient, half random), "
+                      f"oracle/if_oracle.c -O3 x86-64-v3, {cores} OpenMP threads, best of 2"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (default 256 = BASELINE config 2)")
+    ap.add_argument("--pattern", default="mixed", choices=["mixed", "gradient", "random"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from imageflow_amd.graphics.bitmaps import Bitmap
+    from imageflow_amd.graphics.scaling import ScaleAndRenderParams, plan_for, scale_and_render, time_scale_and_render
+    from imageflow_amd.graphics.weights import Filter
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: imageflow_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.frames
+    inp = make_frames(torch, n, rank, dev, args.pattern)
+    canv = [Bitmap.create_u8(n, OUT_W, OUT_H, dev) for _ in range(2)]
+    info = ScaleAndRenderParams(0, 0, OUT_W, OUT_H, 0.0, Filter.Robidoux)
+    plan = plan_for(IN_W, IN_H, OUT_W, OUT_H, info.interpolation_filter, 0.0, dev)
+    gather = distributed and not args.no_gather and os.environ.get("IFHIP_BENCH_GATHER", "1") != "0"
+    gathered = [torch.empty((world,) + tuple(c.data.shape), dtype=torch.uint8, device=dev) for c in canv] if gather else None
+
+    def step(i, pending):
+        c = canv[i & 1]
+        if gather and pending[i & 1] is not None:
+            pending[i & 1].wait()                  # the buffer we are about to overwrite has been gathered
+            pending[i & 1] = None
+        scale_and_render(inp, c, info, plan=plan)
+        if gather:
+            pending[i & 1] = dist.all_gather_into_tensor(gathered[i & 1].view(-1), c.data.view(-1), async_op=True)
+
+    def sync_all(pending):
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+        torch.cuda.synchronize()
+
+    pending = [None, None]
+    for i in range(args.warmup):
+        step(i, pending)
+    sync_all(pending)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, pending)
+    sync_all(pending)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant-kernel duration: hipEvents on the launch stream around back-to-back launches of the same op
+    kernel_ms = time_scale_and_render(inp, canv[0], info, launches=max(5, min(args.steps, 50)), plan=plan)
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        mp_per_step = world * n * IN_W * IN_H / 1e6
+        value = mp_per_step * args.steps / elapsed
+        algo_bytes = n * ALGO_BYTES_PER_FRAME
+        achieved = algo_bytes / (kernel_ms * 1e-3)
+        out = {
+            "metric": "megapixels/sec resize (4K->200px Robidoux)", "value": round(value, 1), "unit": "MP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8 (f32 accumulate)", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 2: {n} x 3840x2160 BGRA8 frames per GPU -> 200x200 Robidoux, linear "
+                                   f"light, ReplaceSelf, device resident, pattern={args.pattern}",
+                       "frames_per_gpu": n, "kernel": "fused_resample_kernel" if plan.kernel_kind() == 0 else "generic",
+                       "gather": "rccl all_gather of outputs, overlapped" if gather else "none"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:   # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "MP/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

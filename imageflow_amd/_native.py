@@ -1,0 +1,60 @@
+"""ctypes binding of libimageflow_hip.so.  Fails loudly when the library is missing: there is no CPU path."""
+import ctypes as C
+import os
+
+from .errors import FlowError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libimageflow_hip.so")
+_lib = None
+
+u8p, u32p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -m imageflow_amd.build` (hipcc, gfx950). "
+                          "imageflow_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  -- load torch's HIP runtime first so both share one libamdhip64.so.7
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L.ifhip_last_error_message.restype = C.c_char_p
+    L.ifhip_version.restype = C.c_char_p
+    L.ifhip_stride_for_width.restype = C.c_uint32
+    L.ifhip_stride_for_width.argtypes = [C.c_uint32]
+    L.ifhip_populate_weights.argtypes = [C.c_int, C.c_int, C.c_float, C.c_double, C.c_uint32, C.c_uint32,
+                                         u32p, u32p, f32p, C.c_uint32, u32p]
+    L.ifhip_table_srgb_to_floatspace.argtypes = [C.c_int, f32p]
+    L.ifhip_table_linear_to_srgb.argtypes = [u8p]
+    L.ifhip_scale_and_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                         C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                         C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_int, C.c_float, C.c_int, C.c_int, C.c_uint32]
+    L.ifhip_resample_plan_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_int, C.c_float]
+    L.ifhip_resample_plan_destroy.argtypes = [C.c_void_p]
+    L.ifhip_resample_plan_destroy.restype = None
+    L.ifhip_resample_plan_kernel_kind.argtypes = [C.c_void_p, C.c_int]
+    _batch = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_uint32,
+              C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+              C.c_int, C.c_int, C.c_uint32]
+    L.ifhip_scale_and_render_batch_device.argtypes = _batch + [C.c_void_p, C.c_int, C.c_void_p]
+    L.ifhip_time_scale_and_render_batch_device.argtypes = _batch + [C.c_int, C.c_void_p, C.c_int, f32p]
+    L.ifhip_measure_copy_bandwidth.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    L.ifhip_apply_matte.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
+    L.ifhip_apply_matte_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 C.c_uint32, C.c_int, C.c_uint32, C.c_void_p]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().ifhip_last_error_message()
+        raise FlowError(rc, msg.decode("utf-8", "replace") if msg else "")
+    return rc

@@ -1,0 +1,565 @@
+// api.cpp -- the C ABI of libimageflow_hip.so (include/imageflow_hip.h) over the gfx950 kernels.
+//
+// Host responsibilities only: argument validation with the reference's error kinds (graphics/scaling.rs:24-48),
+// per-shape plan construction (weights, vertical schedule, column strips), HBM staging for the host-buffer
+// drop-in entry points, and launch geometry.  No pixel arithmetic happens on the host.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+
+#include "common.hpp"
+#include "device.hpp"
+
+namespace ifhip {
+hipError_t launch_fused(const ResampleArgs& a, int slots, bool alpha, uint32_t grid, uint32_t block, size_t lds,
+                        hipStream_t st);
+hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, uint32_t img0, uint32_t n_img,
+                          hipStream_t st);
+hipError_t launch_apply_matte(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w, uint32_t h,
+                              uint32_t stride, uint32_t matte, float mb, float mg, float mr, float ma,
+                              const float* s2l, const uint8_t* l2s, hipStream_t st);
+}  // namespace ifhip
+
+using namespace ifhip;
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(IFHIP_GPU_ERROR, "GpuError: %s failed: %s", #expr, hipGetErrorString(e__));     \
+    } while (0)
+
+namespace {
+
+constexpr size_t kLdsLimit = 160 * 1024;       // gfx950 LDS per CU == per-workgroup maximum
+constexpr uint32_t kMaxQuads = 1024;           // lanes per workgroup
+constexpr uint32_t kMaxStripOutputs = 2048;
+
+// ---- per-device colour tables -----------------------------------------------------------------------
+struct DeviceTables {
+    float* s2l = nullptr;
+    float* s2f = nullptr;
+    uint8_t* l2s = nullptr;
+};
+std::mutex g_dev_mu;
+std::map<int, DeviceTables> g_dev_tables;
+
+int device_tables(DeviceTables* out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0)
+        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device (hipGetDevice failed); this library has no CPU path");
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto it = g_dev_tables.find(dev);
+    if (it == g_dev_tables.end()) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: device %d is %s, this library is built for gfx950 only", dev, prop.gcnArchName);
+        const ColorTables& t = color_tables();
+        DeviceTables d;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.s2l), sizeof t.s2l));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.s2f), sizeof t.s2f));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.l2s), sizeof t.l2s));
+        HIP_TRY(hipMemcpy(d.s2l, t.s2l, sizeof t.s2l, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d.s2f, t.s2f, sizeof t.s2f, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d.l2s, t.l2s, sizeof t.l2s, hipMemcpyHostToDevice));
+        it = g_dev_tables.emplace(dev, d).first;
+    }
+    *out = it->second;
+    return IFHIP_OK;
+}
+
+template <typename T>
+int upload(const std::vector<T>& v, T** out) {
+    *out = nullptr;
+    if (v.empty()) return IFHIP_OK;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(out), v.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return IFHIP_OK;
+}
+
+struct ScheduleOnDevice {
+    VStep* steps = nullptr;
+    uint32_t* band_begin = nullptr;
+    uint32_t n_bands = 0;
+};
+
+}  // namespace
+
+// ---- plan ------------------------------------------------------------------------------------------------
+struct ifhip_resample_plan {
+    int device = -1;
+    uint32_t in_w = 0, in_h = 0, out_w = 0, out_h = 0;
+    AxisWeights wv, wh;
+    // device copies of the contribution tables
+    uint32_t *d_v_left = nullptr, *d_v_count = nullptr, *d_v_off = nullptr;
+    uint32_t *d_h_left = nullptr, *d_h_count = nullptr, *d_h_off = nullptr;
+    float *d_v_w = nullptr, *d_h_w = nullptr, *d_h_wT = nullptr;
+    // fused-kernel geometry
+    bool fused_possible = false;
+    int slots = 0;
+    std::vector<Strip> strips;
+    Strip* d_strips = nullptr;
+    uint32_t max_quads = 0;
+    // lazily built, guarded by mu
+    mutable std::mutex mu;
+    mutable std::map<uint32_t, ScheduleOnDevice> schedules;
+    mutable float4* scratch = nullptr;
+    mutable size_t scratch_bytes = 0;
+
+    ~ifhip_resample_plan() {
+        for (void* p : {(void*)d_v_left, (void*)d_v_count, (void*)d_v_off, (void*)d_h_left, (void*)d_h_count,
+                        (void*)d_h_off, (void*)d_v_w, (void*)d_h_w, (void*)d_h_wT, (void*)d_strips, (void*)scratch})
+            if (p) (void)hipFree(p);
+        for (auto& kv : schedules) {
+            if (kv.second.steps) (void)hipFree(kv.second.steps);
+            if (kv.second.band_begin) (void)hipFree(kv.second.band_begin);
+        }
+    }
+};
+
+namespace {
+
+size_t fused_lds_bytes(uint32_t n_u, uint32_t nquads, int channels) {
+    return 256 * sizeof(float) + static_cast<size_t>((n_u * 4u + 3u) & ~3u) * sizeof(float)
+           + static_cast<size_t>(nquads) * 4u * channels * sizeof(float);
+}
+
+// Split the output columns into strips whose staged source span fits one workgroup (<= 1024 lanes x 4 px)
+// and whose LDS footprint (with 4 channels, the worst case) fits the CU.
+bool plan_strips(const AxisWeights& wh, std::vector<Strip>* out, uint32_t* max_quads) {
+    for (uint32_t n = 1; n <= wh.n_out; ++n) {
+        std::vector<Strip> s;
+        bool ok = true;
+        uint32_t mq = 0;
+        for (uint32_t i = 0; i < n && ok; ++i) {
+            Strip t;
+            t.u0 = static_cast<uint32_t>(static_cast<uint64_t>(wh.n_out) * i / n);
+            t.u1 = static_cast<uint32_t>(static_cast<uint64_t>(wh.n_out) * (i + 1) / n);
+            if (t.u1 <= t.u0) { ok = false; break; }
+            uint32_t lo = wh.left[t.u0], hi = 0;
+            for (uint32_t u = t.u0; u < t.u1; ++u) {
+                lo = std::min(lo, wh.left[u]);
+                hi = std::max(hi, wh.left[u] + wh.count[u]);
+            }
+            t.cx0 = lo & ~3u;
+            t.nquads = (hi - t.cx0 + 3u) / 4u;
+            if (t.nquads > kMaxQuads || (t.u1 - t.u0) > kMaxStripOutputs) ok = false;
+            if (fused_lds_bytes(t.u1 - t.u0, t.nquads, 4) > kLdsLimit) ok = false;
+            mq = std::max(mq, t.nquads);
+            s.push_back(t);
+        }
+        if (ok) { *out = std::move(s); *max_quads = mq; return true; }
+        if (n > 4096) break;
+    }
+    return false;
+}
+
+int get_schedule(const ifhip_resample_plan* p, uint32_t n_bands, ScheduleOnDevice* out) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    auto it = p->schedules.find(n_bands);
+    if (it == p->schedules.end()) {
+        VSchedule s;
+        if (!build_vschedule(p->wv, static_cast<int>(n_bands), &s))
+            return fail(IFHIP_INVALID_STATE, "InvalidState: vertical schedule could not be built");
+        ScheduleOnDevice d;
+        d.n_bands = static_cast<uint32_t>(s.band_begin.size() - 1);
+        int rc = upload(s.steps, &d.steps);
+        if (rc) return rc;
+        rc = upload(s.band_begin, &d.band_begin);
+        if (rc) return rc;
+        it = p->schedules.emplace(n_bands, d).first;
+    }
+    *out = it->second;
+    return IFHIP_OK;
+}
+
+uint32_t choose_bands(const ifhip_resample_plan* p, uint32_t n_images) {
+    if (const char* e = std::getenv("IFHIP_BANDS")) {
+        const int v = std::atoi(e);
+        if (v >= 1) return std::min<uint32_t>(static_cast<uint32_t>(v), p->out_h);
+    }
+    // enough workgroups to cover 256 CUs twice over; a band re-reads its halo rows, so no more than needed
+    const uint64_t wgs = static_cast<uint64_t>(n_images) * p->strips.size();
+    uint32_t bands = 1;
+    if (wgs < 512) bands = static_cast<uint32_t>((512 + wgs - 1) / wgs);
+    const uint32_t max_bands = std::max<uint32_t>(1u, p->out_h / 4u);
+    return std::max<uint32_t>(1u, std::min(bands, max_bands));
+}
+
+bool fused_usable(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride) {
+    if (!p->fused_possible) return false;
+    if ((reinterpret_cast<uintptr_t>(d_in) & 15u) || (in_image_bytes & 15u) || (in_stride & 15u)) return false;
+    for (const Strip& s : p->strips)
+        if (static_cast<uint64_t>(s.cx0 + 4u * s.nquads) * 4u > in_stride) return false;   // 16-byte row reads stay inside the row
+    return true;
+}
+
+int validate_render(uint32_t in_w, uint32_t in_h, uint32_t in_stride, uint32_t cw, uint32_t ch, uint32_t c_stride,
+                    uint32_t x, uint32_t y, uint32_t w, uint32_t h, int working_space, int compositing) {
+    if (static_cast<uint64_t>(h) + y > ch || static_cast<uint64_t>(w) + x > cw)                 // scaling.rs:24-29
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: Destination rectangle for scale2d is out of bounds");
+    if (w == 0 || h == 0 || in_w == 0 || in_h == 0)                                              // bitmaps.rs:700-702
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: Bitmap dimensions cannot be zero");
+    if (static_cast<uint64_t>(in_w) * 4u > in_stride || static_cast<uint64_t>(cw) * 4u > c_stride)
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: stride smaller than a BGRA row");
+    if (c_stride & 3u)
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: canvas stride must be a multiple of 4 bytes");
+    if (working_space != IFHIP_SPACE_SRGB && working_space != IFHIP_SPACE_LINEAR)
+        return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: working floatspace %d", working_space);
+    if (compositing < IFHIP_REPLACE_SELF || compositing > IFHIP_BLEND_WITH_MATTE)
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: compositing mode %d", compositing);
+    return IFHIP_OK;
+}
+
+int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride,
+                  int alpha, uint32_t n_images, uint8_t* d_canvas, size_t canvas_image_bytes, uint32_t cw, uint32_t ch,
+                  uint32_t c_stride, uint32_t x, uint32_t y, int working_space, int compositing, uint32_t matte,
+                  float* d_f32, int force_kernel, hipStream_t st) {
+    if (!p) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null plan");
+    int rc = validate_render(p->in_w, p->in_h, in_stride, cw, ch, c_stride, x, y, p->out_w, p->out_h, working_space, compositing);
+    if (rc) return rc;
+    if (n_images == 0) return IFHIP_OK;
+    if (!d_in || !d_canvas) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null bitmap pointer");
+    if ((reinterpret_cast<uintptr_t>(d_canvas) & 3u) || (canvas_image_bytes & 3u))
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: canvas pixels must be 4-byte aligned");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != p->device) return fail(IFHIP_INVALID_STATE, "InvalidState: plan belongs to device %d, current device is %d", p->device, dev);
+    DeviceTables tb;
+    rc = device_tables(&tb);
+    if (rc) return rc;
+    const ColorTables& host_tb = color_tables();
+
+    ResampleArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = d_in; a.in_image_bytes = in_image_bytes; a.in_stride = in_stride; a.in_w = p->in_w; a.in_h = p->in_h;
+    a.canvas = d_canvas; a.canvas_image_bytes = canvas_image_bytes; a.c_stride = c_stride; a.x = x; a.y = y;
+    a.out_w = p->out_w; a.out_h = p->out_h; a.f32_dump = d_f32;
+    a.h_left = p->d_h_left; a.h_count = p->d_h_count; a.h_wT = p->d_h_wT; a.h_max_taps = p->wh.max_taps;
+    a.v_left = p->d_v_left; a.v_count = p->d_v_count; a.v_off = p->d_v_off; a.v_w = p->d_v_w;
+    a.h_off = p->d_h_off; a.h_w = p->d_h_w;
+    a.linear = working_space == IFHIP_SPACE_LINEAR;
+    a.lut_in = a.linear ? tb.s2l : tb.s2f;
+    a.l2s = tb.l2s;
+    a.mode = compositing;
+    const float* s2 = a.linear ? host_tb.s2l : host_tb.s2f;       // matte colour in working space, scaling.rs:141-143
+    a.m0 = s2[matte & 255u]; a.m1 = s2[(matte >> 8) & 255u]; a.m2 = s2[(matte >> 16) & 255u];
+    a.matte_a = static_cast<float>(matte >> 24) * (1.0f / 255.0f);
+    a.n_images = n_images;
+
+    bool fused = fused_usable(p, d_in, in_image_bytes, in_stride);
+    if (force_kernel == 0 && !fused)
+        return fail(IFHIP_INVALID_STATE, "InvalidState: fused kernel requested but its preconditions do not hold "
+                    "(live rows %d > %d, or rows not 16-byte aligned / padded)", p->slots, kMaxSlots);
+    if (force_kernel == 1) fused = false;
+
+    if (fused) {
+        const uint32_t want_bands = choose_bands(p, n_images);
+        ScheduleOnDevice sd;
+        rc = get_schedule(p, want_bands, &sd);
+        if (rc) return rc;
+        a.steps = sd.steps; a.band_begin = sd.band_begin; a.n_bands = sd.n_bands;
+        a.strips = p->d_strips; a.n_strips = static_cast<uint32_t>(p->strips.size());
+        const int channels = alpha ? 4 : 3;
+        size_t lds = 0;
+        for (const Strip& s : p->strips) lds = std::max(lds, fused_lds_bytes(s.u1 - s.u0, s.nquads, channels));
+        const uint32_t block = std::max<uint32_t>(64u, (p->max_quads + 63u) & ~63u);
+        const uint64_t grid = static_cast<uint64_t>(n_images) * sd.n_bands * a.n_strips;
+        if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
+        HIP_TRY(launch_fused(a, p->slots, alpha != 0, static_cast<uint32_t>(grid), block, lds, st));
+        return IFHIP_OK;
+    }
+
+    // generic two-pass path through an HBM scratch of [chunk][out_h][in_w] float4
+    if (p->out_h > 65535u) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: output taller than 65535 rows");
+    const size_t per_image = static_cast<size_t>(p->out_h) * p->in_w * sizeof(float4);
+    const size_t budget = static_cast<size_t>(1) << 30;
+    uint32_t chunk = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(n_images, budget / std::max<size_t>(per_image, 1))));
+    chunk = std::min<uint32_t>(chunk, 65535u);
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if (p->scratch_bytes < per_image * chunk) {
+            if (p->scratch) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(p->scratch); p->scratch = nullptr; p->scratch_bytes = 0; }
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->scratch), per_image * chunk));
+            p->scratch_bytes = per_image * chunk;
+        }
+    }
+    for (uint32_t i0 = 0; i0 < n_images; i0 += chunk) {
+        const uint32_t n = std::min(chunk, n_images - i0);
+        HIP_TRY(launch_generic(a, alpha != 0, p->scratch, i0, n, st));
+    }
+    return IFHIP_OK;
+}
+
+}  // namespace
+
+// ======================================================================================================
+// extern "C"
+// ======================================================================================================
+extern "C" {
+
+const char* ifhip_last_error_message(void) { return last_error(); }
+const char* ifhip_version(void) { return "imageflow_hip 0.1 (gfx950)"; }
+
+int ifhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int usable = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++usable;
+    }
+    return usable;
+}
+
+int ifhip_set_device(int ordinal) {
+    if (hipSetDevice(ordinal) != hipSuccess)
+        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: hipSetDevice(%d) failed", ordinal);
+    return IFHIP_OK;
+}
+
+uint32_t ifhip_stride_for_width(uint32_t w) {
+    const uint64_t row = static_cast<uint64_t>(w) * 4u;
+    return static_cast<uint32_t>((row + 63u) / 64u * 64u);
+}
+
+int ifhip_populate_weights(int filter, int lobe_mode, float lobe_value, double kernel_width_scale,
+                           uint32_t output_line_size, uint32_t input_line_size, uint32_t* left_pixel,
+                           uint32_t* tap_count, float* weights, uint32_t weights_capacity, uint32_t* n_weights) {
+    FilterSpec spec;
+    if (!filter_spec_for(filter, &spec)) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: unknown filter %d", filter);
+    spec.blur *= kernel_width_scale;                 // set_kernel_width_scale, weights.rs:155-157
+    spec.lobe_mode = lobe_mode; spec.lobe_value = lobe_value;
+    AxisWeights w;
+    int rc = build_axis_weights(spec, output_line_size, input_line_size, &w);
+    if (rc) return rc;
+    if (n_weights) *n_weights = static_cast<uint32_t>(w.w.size());
+    if (weights_capacity == 0) return IFHIP_OK;
+    if (w.w.size() > weights_capacity) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: weights_capacity too small");
+    if (left_pixel) std::memcpy(left_pixel, w.left.data(), w.left.size() * sizeof(uint32_t));
+    if (tap_count) std::memcpy(tap_count, w.count.data(), w.count.size() * sizeof(uint32_t));
+    if (weights) std::memcpy(weights, w.w.data(), w.w.size() * sizeof(float));
+    return IFHIP_OK;
+}
+
+int ifhip_table_srgb_to_floatspace(int working_space, float* out256) {
+    if (!out256) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null table pointer");
+    const ColorTables& t = color_tables();
+    if (working_space == IFHIP_SPACE_LINEAR) std::memcpy(out256, t.s2l, sizeof t.s2l);
+    else if (working_space == IFHIP_SPACE_SRGB) std::memcpy(out256, t.s2f, sizeof t.s2f);
+    else return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: working floatspace %d", working_space);
+    return IFHIP_OK;
+}
+
+int ifhip_table_linear_to_srgb(uint8_t* out16384) {
+    if (!out16384) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null table pointer");
+    std::memcpy(out16384, color_tables().l2s, 16384);
+    return IFHIP_OK;
+}
+
+int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32_t in_h, uint32_t w, uint32_t h,
+                               int filter, float sharpen_percent_goal) {
+    if (!plan) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null plan out-pointer");
+    *plan = nullptr;
+    if (w == 0 || h == 0 || in_w == 0 || in_h == 0)
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: Bitmap dimensions cannot be zero");
+    FilterSpec spec;
+    if (!filter_spec_for(filter, &spec)) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: unknown filter %d", filter);
+    if (sharpen_percent_goal > 0.0f) {               // scaling.rs:103-105 -> LobeRatio::SharpenPercent
+        spec.lobe_mode = IFHIP_LOBE_SHARPEN_PERCENT;
+        spec.lobe_value = sharpen_percent_goal;
+    }
+    DeviceTables tb;
+    int rc = device_tables(&tb);
+    if (rc) return rc;
+    std::unique_ptr<ifhip_resample_plan> p(new ifhip_resample_plan);
+    HIP_TRY(hipGetDevice(&p->device));
+    p->in_w = in_w; p->in_h = in_h; p->out_w = w; p->out_h = h;
+    rc = build_axis_weights(spec, h, in_h, &p->wv);
+    if (rc) return rc;
+    rc = build_axis_weights(spec, w, in_w, &p->wh);
+    if (rc) return rc;
+
+    // horizontal weights transposed to [tap][out_w] so that lanes walking adjacent outputs read adjacent floats
+    std::vector<float> wT(static_cast<size_t>(p->wh.max_taps) * w, 0.0f);
+    for (uint32_t u = 0; u < w; ++u)
+        for (uint32_t k = 0; k < p->wh.count[u]; ++k) wT[static_cast<size_t>(k) * w + u] = p->wh.w[p->wh.offset[u] + k];
+
+    if ((rc = upload(p->wv.left, &p->d_v_left)) || (rc = upload(p->wv.count, &p->d_v_count)) ||
+        (rc = upload(p->wv.offset, &p->d_v_off)) || (rc = upload(p->wv.w, &p->d_v_w)) ||
+        (rc = upload(p->wh.left, &p->d_h_left)) || (rc = upload(p->wh.count, &p->d_h_count)) ||
+        (rc = upload(p->wh.offset, &p->d_h_off)) || (rc = upload(p->wh.w, &p->d_h_w)) || (rc = upload(wT, &p->d_h_wT)))
+        return rc;
+
+    p->slots = max_live_rows(p->wv);
+    VSchedule probe;
+    p->fused_possible = p->slots <= kMaxSlots && build_vschedule(p->wv, 1, &probe) && plan_strips(p->wh, &p->strips, &p->max_quads);
+    if (p->fused_possible && (rc = upload(p->strips, &p->d_strips))) return rc;
+    *plan = p.release();
+    return IFHIP_OK;
+}
+
+void ifhip_resample_plan_destroy(ifhip_resample_plan* plan) { delete plan; }
+
+int ifhip_resample_plan_kernel_kind(const ifhip_resample_plan* plan, int /*in_alpha_meaningful*/) {
+    return (plan && plan->fused_possible) ? 0 : 1;
+}
+
+int ifhip_scale_and_render_batch_device(const ifhip_resample_plan* plan, const uint8_t* d_in, size_t in_image_bytes,
+                                        uint32_t in_stride, int in_alpha_meaningful, uint32_t n_images,
+                                        uint8_t* d_canvas, size_t canvas_image_bytes, uint32_t canvas_w,
+                                        uint32_t canvas_h, uint32_t canvas_stride, uint32_t x, uint32_t y,
+                                        int working_space, int compositing, uint32_t matte_bgra, float* d_f32_dump,
+                                        int force_kernel, void* hip_stream) {
+    return enqueue_batch(plan, d_in, in_image_bytes, in_stride, in_alpha_meaningful, n_images, d_canvas,
+                         canvas_image_bytes, canvas_w, canvas_h, canvas_stride, x, y, working_space, compositing,
+                         matte_bgra, d_f32_dump, force_kernel, static_cast<hipStream_t>(hip_stream));
+}
+
+int ifhip_time_scale_and_render_batch_device(const ifhip_resample_plan* plan, const uint8_t* d_in,
+                                             size_t in_image_bytes, uint32_t in_stride, int in_alpha_meaningful,
+                                             uint32_t n_images, uint8_t* d_canvas, size_t canvas_image_bytes,
+                                             uint32_t canvas_w, uint32_t canvas_h, uint32_t canvas_stride, uint32_t x,
+                                             uint32_t y, int working_space, int compositing, uint32_t matte_bgra,
+                                             int force_kernel, void* hip_stream, int launches,
+                                             float* avg_ms_per_launch) {
+    if (launches < 1 || !avg_ms_per_launch) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: launches/avg pointer");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, st));
+    int rc = IFHIP_OK;
+    for (int i = 0; i < launches && rc == IFHIP_OK; ++i)
+        rc = enqueue_batch(plan, d_in, in_image_bytes, in_stride, in_alpha_meaningful, n_images, d_canvas,
+                           canvas_image_bytes, canvas_w, canvas_h, canvas_stride, x, y, working_space, compositing,
+                           matte_bgra, nullptr, force_kernel, st);
+    hipError_t er = hipEventRecord(e1, st);
+    if (er == hipSuccess) er = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (er == hipSuccess) er = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    if (er != hipSuccess) return fail(IFHIP_GPU_ERROR, "GpuError: event timing failed: %s", hipGetErrorString(er));
+    *avg_ms_per_launch = ms / static_cast<float>(launches);
+    return IFHIP_OK;
+}
+
+int ifhip_measure_copy_bandwidth(size_t bytes, int iters, double* bytes_per_second) {
+    if (!bytes_per_second || iters < 1 || bytes == 0) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: copy bandwidth probe");
+    DeviceTables tb;
+    int rc = device_tables(&tb);
+    if (rc) return rc;
+    void *a = nullptr, *b = nullptr;
+    HIP_TRY(hipMalloc(&a, bytes));
+    HIP_TRY(hipMalloc(&b, bytes));
+    HIP_TRY(hipMemset(a, 1, bytes));
+    HIP_TRY(hipMemcpy(b, a, bytes, hipMemcpyDeviceToDevice));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) HIP_TRY(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, nullptr));
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b);
+    *bytes_per_second = 2.0 * static_cast<double>(bytes) * iters / (static_cast<double>(ms) * 1e-3);
+    return IFHIP_OK;
+}
+
+// ---- host-buffer drop-ins ---------------------------------------------------------------------------------
+int ifhip_scale_and_render(const uint8_t* in, uint32_t in_w, uint32_t in_h, uint32_t in_stride, int in_alpha_meaningful,
+                           uint8_t* canvas, uint32_t canvas_w, uint32_t canvas_h, uint32_t canvas_stride,
+                           int /*canvas_alpha_meaningful*/, uint32_t x, uint32_t y, uint32_t w, uint32_t h, int filter,
+                           float sharpen_percent_goal, int working_space, int compositing, uint32_t matte_bgra) {
+    int rc = validate_render(in_w, in_h, in_stride, canvas_w, canvas_h, canvas_stride, x, y, w, h, working_space, compositing);
+    if (rc) return rc;
+    if (!in || !canvas) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null bitmap pointer");
+    ifhip_resample_plan* plan = nullptr;
+    rc = ifhip_resample_plan_create(&plan, in_w, in_h, w, h, filter, sharpen_percent_goal);
+    if (rc) return rc;
+    std::unique_ptr<ifhip_resample_plan> guard(plan);
+    // stage: source rows as given; only the canvas rows the rect touches
+    const size_t in_bytes = (static_cast<size_t>(in_h) * in_stride + 15u) & ~static_cast<size_t>(15);
+    const size_t in_valid = static_cast<size_t>(in_h - 1) * in_stride + static_cast<size_t>(in_w) * 4u;
+    const size_t c_rows_bytes = static_cast<size_t>(h) * canvas_stride;
+    const size_t c_valid = static_cast<size_t>(h - 1) * canvas_stride + static_cast<size_t>(canvas_w) * 4u;
+    uint8_t *d_in = nullptr, *d_c = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), in_bytes + 64));
+    if (hipMalloc(reinterpret_cast<void**>(&d_c), c_rows_bytes + 64) != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: %zu bytes of HBM for the canvas", c_rows_bytes);
+    }
+    hipError_t e = hipMemset(d_in, 0, in_bytes + 64);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, in_valid, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_c, canvas + static_cast<size_t>(y) * canvas_stride, c_valid, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = enqueue_batch(plan, d_in, in_bytes, in_stride, in_alpha_meaningful, 1, d_c, (c_rows_bytes + 3u) & ~static_cast<size_t>(3),
+                           canvas_w, h, canvas_stride, x, 0, working_space, compositing, matte_bgra, nullptr, -1, nullptr);
+        if (rc == IFHIP_OK) {
+            e = hipStreamSynchronize(nullptr);
+            if (e == hipSuccess) e = hipMemcpy(canvas + static_cast<size_t>(y) * canvas_stride, d_c, c_valid, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_c);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(IFHIP_GPU_ERROR, "GpuError: staging failed: %s", hipGetErrorString(e));
+    return IFHIP_OK;
+}
+
+int ifhip_apply_matte_batch_device(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w, uint32_t h,
+                                   uint32_t stride, int alpha_meaningful, uint32_t matte_bgra, void* hip_stream) {
+    if (!alpha_meaningful) return IFHIP_OK;                       // blend.rs:11-13
+    if (w == 0 || h == 0 || n_images == 0) return IFHIP_OK;
+    if (!d_bgra) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null bitmap pointer");
+    if (static_cast<uint64_t>(w) * 4u > stride || (stride & 3u) || (image_bytes & 3u) || (reinterpret_cast<uintptr_t>(d_bgra) & 3u))
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: BGRA rows must be 4-byte aligned and stride >= 4*w");
+    if (h > 65535u || n_images > 65535u) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: more than 65535 rows/images per launch");
+    DeviceTables tb;
+    int rc = device_tables(&tb);
+    if (rc) return rc;
+    const ColorTables& t = color_tables();
+    HIP_TRY(launch_apply_matte(d_bgra, image_bytes, n_images, w, h, stride, matte_bgra, t.s2l[matte_bgra & 255u],
+                               t.s2l[(matte_bgra >> 8) & 255u], t.s2l[(matte_bgra >> 16) & 255u],
+                               static_cast<float>(matte_bgra >> 24) * (1.0f / 255.0f), tb.s2l, tb.l2s,
+                               static_cast<hipStream_t>(hip_stream)));
+    return IFHIP_OK;
+}
+
+int ifhip_apply_matte(uint8_t* bgra, uint32_t w, uint32_t h, uint32_t stride, int alpha_meaningful, uint32_t matte_bgra) {
+    if (!alpha_meaningful) return IFHIP_OK;
+    if (w == 0 || h == 0) return IFHIP_OK;
+    if (!bgra) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null bitmap pointer");
+    const size_t valid = static_cast<size_t>(h - 1) * stride + static_cast<size_t>(w) * 4u;
+    const size_t bytes = (static_cast<size_t>(h) * stride + 3u) & ~static_cast<size_t>(3);
+    uint8_t* d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    hipError_t e = hipMemcpy(d, bgra, valid, hipMemcpyHostToDevice);
+    int rc = IFHIP_OK;
+    if (e == hipSuccess) {
+        rc = ifhip_apply_matte_batch_device(d, bytes, 1, w, h, stride, 1, matte_bgra, nullptr);
+        if (rc == IFHIP_OK) {
+            e = hipStreamSynchronize(nullptr);
+            if (e == hipSuccess) e = hipMemcpy(bgra, d, valid, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(IFHIP_GPU_ERROR, "GpuError: staging failed: %s", hipGetErrorString(e));
+    return IFHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// common.hpp -- shared declarations for libimageflow_hip.so (host side).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/imageflow_hip.h"
+
+namespace ifhip {
+
+// thread-local last error (FlowError.message analogue)
+int fail(int status, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+const char* last_error();
+
+// ---------------------------------------------------------------------------------------------------
+// Interpolation kernels + per-axis contribution tables  (graphics/weights.rs)
+// ---------------------------------------------------------------------------------------------------
+enum class KernelShape : uint8_t { FlexCubic, CubicFast, Sinc, Box, Triangle, SincWindowed, Jinc, Ginseng };
+
+struct FilterSpec {            // InterpolationDetails (weights.rs:107-124) minus the fn pointer
+    double window = 2.0;
+    double blur = 1.0;
+    double p1 = 0, p2 = 1, p3 = 1, q1 = 0, q2 = 1, q3 = 1, q4 = 1;
+    KernelShape shape = KernelShape::Box;
+    int lobe_mode = IFHIP_LOBE_NATURAL;
+    float lobe_value = 0.f;
+
+    double eval(double x) const;                 // (self.filter)(self, x)
+    double natural_negative_ratio() const;       // calculate_percent_negative_weight, weights.rs:333-350
+};
+
+bool filter_spec_for(int filter, FilterSpec* out);     // InterpolationDetails::create, weights.rs:176-331
+
+struct AxisWeights {           // PixelRowWeights (weights.rs:521-571) in structure-of-arrays form
+    uint32_t n_out = 0, n_in = 0;
+    std::vector<uint32_t> left;     // left_pixel
+    std::vector<uint32_t> count;    // right_pixel - left_pixel + 1
+    std::vector<uint32_t> offset;   // left_weight
+    std::vector<float> w;
+    uint32_t max_taps = 0;
+};
+
+// populate_weights, weights.rs:681-788.  Returns IFHIP_OK or an error status (message set).
+int build_axis_weights(const FilterSpec& spec, uint32_t out_size, uint32_t in_size, AxisWeights* out);
+
+// ---------------------------------------------------------------------------------------------------
+// Colour tables  (graphics/color.rs, graphics/lut.rs)
+// ---------------------------------------------------------------------------------------------------
+struct ColorTables {
+    float s2l[256];        // ColorContext(LinearRGB).byte_to_float
+    float s2f[256];        // ColorContext(StandardRGB).byte_to_float
+    uint8_t l2s[16384];    // LINEAR_TO_SRGB_LUT
+};
+const ColorTables& color_tables();
+
+// ---------------------------------------------------------------------------------------------------
+// Vertical schedule for the fused kernel (our own construct; DESIGN.md "vertical schedule")
+// ---------------------------------------------------------------------------------------------------
+constexpr int kMaxSlots = 8;
+struct alignas(64) VStep {
+    int32_t y;            // source row to load and accumulate, or -1
+    uint32_t active;      // bit s set: ring slot s accumulates row y with weight w[s]
+    int32_t flush_slot;   // ring slot completed by this step (-1: none)
+    int32_t out_row;      // output row index held by flush_slot
+    float w[kMaxSlots];
+    int32_t pad[4];
+};
+static_assert(sizeof(VStep) == 64, "VStep must be one 64-byte scalar-load line");
+
+struct VSchedule {
+    int slots = 0;                       // ring size K = max simultaneously live output rows
+    std::vector<VStep> steps;            // concatenated over bands
+    std::vector<uint32_t> band_begin;    // n_bands + 1 offsets into steps
+};
+// Split out rows [0, n_out) into n_bands contiguous bands and emit the step list of each.
+// Returns false if more than kMaxSlots rows are live at once (caller uses the generic kernels).
+bool build_vschedule(const AxisWeights& wv, int n_bands, VSchedule* out);
+int max_live_rows(const AxisWeights& wv);
+
+}  // namespace ifhip

@@ -1,0 +1,158 @@
+/*
+ * imageflow_hip.h -- C ABI of libimageflow_hip.so: the MI355X (gfx950) implementation of imageflow's
+ * pixel hot path.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the imageflow tree).
+ * The Rust side binds these with an `extern "C"` block exactly like imageflow_core/src/ffi/c_interop.rs:115-213
+ * binds c_components today (binding source: INTEGRATION.md).
+ *
+ * Conventions (mirroring wrap_jpeg_* in c_components/lib/codec_jpeg_wrapper.c:187-233 and FlowError):
+ *   - functions return an ifhip_status (0 = ok); the message of the last failure on the calling thread is
+ *     available from ifhip_last_error_message();
+ *   - a bitmap is (pointer, w, h, stride-in-bytes), BGRA8, rows padded as graphics/bitmaps.rs:712-740;
+ *   - colours are Color32 0xAARRGGBB whose little-endian bytes are B,G,R,A (imageflow_helpers/src/colors.rs:77-117);
+ *   - `*_device` variants take pointers into HBM and a hipStream_t (as void*); they enqueue and return.
+ *     The non-device variants take host memory, are synchronous, and are the drop-in for the Rust callers.
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute entry point fails with
+ *     IFHIP_GPU_UNAVAILABLE.
+ */
+#ifndef IMAGEFLOW_HIP_H
+#define IMAGEFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IFHIP_API __attribute__((visibility("default")))
+
+/* Subset of imageflow_core::ErrorKind (errors.rs:158-248) that this path can raise. */
+typedef enum ifhip_status {
+    IFHIP_OK = 0,
+    IFHIP_INVALID_ARGUMENT = 1,        /* ErrorKind::InvalidArgument   (scaling.rs:24-29,40)   */
+    IFHIP_METHOD_NOT_IMPLEMENTED = 2,  /* ErrorKind::MethodNotImplemented (scaling.rs:43-48)   */
+    IFHIP_INVALID_STATE = 3,           /* ErrorKind::InvalidState      (scaling.rs:145,192)    */
+    IFHIP_ALLOCATION_FAILED = 4,       /* ErrorKind::AllocationFailed                           */
+    IFHIP_GPU_UNAVAILABLE = 5,         /* no gfx950 device / HIP runtime error                  */
+    IFHIP_GPU_ERROR = 6
+} ifhip_status;
+
+/* graphics/weights.rs:43-78 -- same discriminants. */
+typedef enum ifhip_filter {
+    IFHIP_FILTER_ROBIDOUX_FAST = 1, IFHIP_FILTER_ROBIDOUX = 2, IFHIP_FILTER_ROBIDOUX_SHARP = 3,
+    IFHIP_FILTER_GINSENG = 4, IFHIP_FILTER_GINSENG_SHARP = 5, IFHIP_FILTER_LANCZOS = 6,
+    IFHIP_FILTER_LANCZOS_SHARP = 7, IFHIP_FILTER_LANCZOS2 = 8, IFHIP_FILTER_LANCZOS2_SHARP = 9,
+    IFHIP_FILTER_CUBIC_FAST = 10, IFHIP_FILTER_CUBIC = 11, IFHIP_FILTER_CUBIC_SHARP = 12,
+    IFHIP_FILTER_CATMULL_ROM = 13, IFHIP_FILTER_MITCHELL = 14, IFHIP_FILTER_CUBIC_B_SPLINE = 15,
+    IFHIP_FILTER_HERMITE = 16, IFHIP_FILTER_JINC = 17, IFHIP_FILTER_RAW_LANCZOS3 = 18,
+    IFHIP_FILTER_RAW_LANCZOS3_SHARP = 19, IFHIP_FILTER_RAW_LANCZOS2 = 20, IFHIP_FILTER_RAW_LANCZOS2_SHARP = 21,
+    IFHIP_FILTER_TRIANGLE = 22, IFHIP_FILTER_LINEAR = 23, IFHIP_FILTER_BOX = 24,
+    IFHIP_FILTER_CATMULL_ROM_FAST = 25, IFHIP_FILTER_CATMULL_ROM_FAST_SHARP = 26, IFHIP_FILTER_FASTEST = 27,
+    IFHIP_FILTER_MITCHELL_FAST = 28, IFHIP_FILTER_N_CUBIC = 29, IFHIP_FILTER_N_CUBIC_SHARP = 30,
+    IFHIP_FILTER_LEGACY_IDCT = 31
+} ifhip_filter;
+
+/* graphics/color.rs:4-9 WorkingFloatspace (Gamma is not reachable from scale_render.rs:293-296). */
+typedef enum ifhip_working_space { IFHIP_SPACE_SRGB = 0, IFHIP_SPACE_LINEAR = 1 } ifhip_working_space;
+
+/* ffi/mod.rs:41-47 BitmapCompositingMode. */
+typedef enum ifhip_compositing {
+    IFHIP_REPLACE_SELF = 0, IFHIP_BLEND_WITH_SELF = 1, IFHIP_BLEND_WITH_MATTE = 2
+} ifhip_compositing;
+
+/* weights.rs:14-40 LobeRatio. */
+typedef enum ifhip_lobe_mode { IFHIP_LOBE_NATURAL = 0, IFHIP_LOBE_EXACT = 1, IFHIP_LOBE_SHARPEN_PERCENT = 2 } ifhip_lobe_mode;
+
+/* ---- library / device -------------------------------------------------------------------------------- */
+IFHIP_API const char* ifhip_last_error_message(void);
+IFHIP_API const char* ifhip_version(void);
+IFHIP_API int ifhip_device_count(void);            /* number of usable gfx950 devices (0 if none)          */
+IFHIP_API int ifhip_set_device(int ordinal);       /* one process per GPU: call once with LOCAL_RANK       */
+
+/* ---- host-side tables (no GPU needed) ---------------------------------------------------------------- */
+/* graphics/bitmaps.rs:712-740 Bitmap::get_stride::<u8>(w, h, 4, 64). */
+IFHIP_API uint32_t ifhip_stride_for_width(uint32_t w);
+/* graphics/weights.rs:681-788 populate_weights + PixelWeightIndexes (:555-571).  left[u]/count[u] give the first
+ * source pixel and tap count of output pixel u; weights are concatenated in output order.  Pass
+ * weights_capacity = 0 to query *n_weights.  kernel_width_scale = 1.0 unless set_kernel_width_scale is wanted. */
+IFHIP_API int ifhip_populate_weights(int filter, int lobe_mode, float lobe_value, double kernel_width_scale,
+                                     uint32_t output_line_size, uint32_t input_line_size,
+                                     uint32_t* left_pixel, uint32_t* tap_count,
+                                     float* weights, uint32_t weights_capacity, uint32_t* n_weights);
+/* graphics/color.rs:22-45 ColorContext::byte_to_float (space = working space), 256 floats. */
+IFHIP_API int ifhip_table_srgb_to_floatspace(int working_space, float* out256);
+/* graphics/lut.rs:14-271 LINEAR_TO_SRGB_LUT, 16384 bytes. */
+IFHIP_API int ifhip_table_linear_to_srgb(uint8_t* out16384);
+
+/* ---- Inner A: resample + render ---------------------------------------------------------------------- */
+/*
+ * Replaces imageflow_core::graphics::scaling::scale_and_render (graphics/scaling.rs:19-90) with
+ * ScaleAndRenderParams (:8-17).  Host buffers, synchronous: upload -> kernels -> download of the touched
+ * canvas rect.  in_alpha_meaningful = input.info().alpha_meaningful(); `compositing`/`matte_bgra` =
+ * canvas.info().compose().  Errors as the reference: rect outside the canvas -> IFHIP_INVALID_ARGUMENT.
+ */
+IFHIP_API int ifhip_scale_and_render(const uint8_t* in, uint32_t in_w, uint32_t in_h, uint32_t in_stride,
+                                     int in_alpha_meaningful,
+                                     uint8_t* canvas, uint32_t canvas_w, uint32_t canvas_h, uint32_t canvas_stride,
+                                     int canvas_alpha_meaningful,
+                                     uint32_t x, uint32_t y, uint32_t w, uint32_t h,
+                                     int filter, float sharpen_percent_goal, int working_space,
+                                     int compositing, uint32_t matte_bgra);
+
+/*
+ * Device-resident batch form: what a job that keeps frames in HBM calls.  A plan owns the per-shape tables
+ * (PixelRowWeights for both axes, the vertical schedule) for (in_w, in_h) -> (w, h); it is immutable and may be
+ * shared by any number of launches on the device it was created on.
+ */
+typedef struct ifhip_resample_plan ifhip_resample_plan;
+IFHIP_API int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32_t in_h,
+                                         uint32_t w, uint32_t h, int filter, float sharpen_percent_goal);
+IFHIP_API void ifhip_resample_plan_destroy(ifhip_resample_plan* plan);
+/* introspection for tests/bench: 0 = fused single-pass kernel, 1 = generic two-pass kernels */
+IFHIP_API int ifhip_resample_plan_kernel_kind(const ifhip_resample_plan* plan, int in_alpha_meaningful);
+
+/*
+ * n_images independent frames, image i at d_in + i*in_image_bytes / d_canvas + i*canvas_image_bytes.
+ * d_f32_dump (nullable): [n_images][h][w][4] premultiplied working-space floats (the f32 working buffer,
+ * what StreamingResize::next_output_row_f32 yields at scaling.rs:195).
+ * force_kernel: -1 auto, 0 fused, 1 generic (tests cross-check the two).
+ */
+IFHIP_API int ifhip_scale_and_render_batch_device(const ifhip_resample_plan* plan,
+                                                  const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride,
+                                                  int in_alpha_meaningful, uint32_t n_images,
+                                                  uint8_t* d_canvas, size_t canvas_image_bytes,
+                                                  uint32_t canvas_w, uint32_t canvas_h, uint32_t canvas_stride,
+                                                  uint32_t x, uint32_t y,
+                                                  int working_space, int compositing, uint32_t matte_bgra,
+                                                  float* d_f32_dump, int force_kernel, void* hip_stream);
+
+/* ---- Inner B: flatten --------------------------------------------------------------------------------- */
+/* Replaces graphics::blend::apply_matte (graphics/blend.rs:6-59) / Bitmap::apply_matte (bitmaps.rs:528-541).
+ * In place; no-op when !alpha_meaningful (blend.rs:11-13). */
+IFHIP_API int ifhip_apply_matte(uint8_t* bgra, uint32_t w, uint32_t h, uint32_t stride, int alpha_meaningful,
+                                uint32_t matte_bgra);
+IFHIP_API int ifhip_apply_matte_batch_device(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images,
+                                             uint32_t w, uint32_t h, uint32_t stride, int alpha_meaningful,
+                                             uint32_t matte_bgra, void* hip_stream);
+
+/* ---- measurement helpers (bench.py) -------------------------------------------------------------------- */
+/* Runs `launches` back-to-back launches of the batch op on `hip_stream` bracketed by hipEvents on that stream
+ * and returns the average milliseconds per launch. */
+IFHIP_API int ifhip_time_scale_and_render_batch_device(const ifhip_resample_plan* plan,
+                                                       const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride,
+                                                       int in_alpha_meaningful, uint32_t n_images,
+                                                       uint8_t* d_canvas, size_t canvas_image_bytes,
+                                                       uint32_t canvas_w, uint32_t canvas_h, uint32_t canvas_stride,
+                                                       uint32_t x, uint32_t y,
+                                                       int working_space, int compositing, uint32_t matte_bgra,
+                                                       int force_kernel, void* hip_stream, int launches,
+                                                       float* avg_ms_per_launch);
+/* device-to-device copy bandwidth probe (bytes read + bytes written per second), for the "measured roofline" note */
+IFHIP_API int ifhip_measure_copy_bandwidth(size_t bytes, int iters, double* bytes_per_second);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMAGEFLOW_HIP_H */

@@ -1,0 +1,207 @@
+"""Parity of the HIP resample/render path (through the C ABI) against the CPU oracle, bit for bit.
+
+BGRA8 surfaces: exact.  f32 working buffer: exact too (tolerance stated by north_star is 1 ULP; we assert 0).
+Cases follow SURVEY.md section 8: cfg2/cfg5-shaped resizes at reduced size, ragged widths, x/y sub-rect render,
+all three compositing modes, alpha meaningful or not, srgb/linear working space, sharpen, upscale (generic path),
+plus full-size 4K frames and size-independent properties.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from imageflow_amd.errors import ErrorKind, FlowError  # noqa: E402
+from imageflow_amd.graphics.bitmaps import Bitmap, BitmapCompositing  # noqa: E402
+from imageflow_amd.graphics.color import WorkingFloatspace  # noqa: E402
+from imageflow_amd.graphics.scaling import (ResamplePlan, ScaleAndRenderParams, scale_and_render,  # noqa: E402
+                                            scale_and_render_host)
+from imageflow_amd.graphics.weights import Filter  # noqa: E402
+from tests import util as U  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def run_case(in_w, in_h, out_w, out_h, *, n=2, filt=Filter.Robidoux, sharpen=0.0, space=WorkingFloatspace.LinearRGB,
+             compose=BitmapCompositing.ReplaceSelf, matte=0, alpha=False, x=0, y=0, cw=None, ch=None, force=-1,
+             frames=None, seed=0):
+    cw = cw or out_w + x
+    ch = ch or out_h + y
+    if frames is None:
+        frames = U.random_frames(n, in_w, in_h, seed0=1000 + seed, alpha=True)
+    n = frames.shape[0]
+    cst = U.stride_for(cw)
+    rng = np.random.default_rng(77 + seed)
+    canvas0 = rng.integers(0, 256, size=(n, ch, cst), dtype=np.uint8)
+    exp = canvas0.copy()
+    exp_f32 = U.oracle_render(frames, in_w, in_h, exp, cw, ch, x, y, out_w, out_h, filter_id=int(filt), sharpen=sharpen,
+                              working_space=int(space), compositing=int(compose), matte_bgra=matte,
+                              alpha_meaningful=alpha, want_f32=True)
+    inp = Bitmap.from_numpy(frames, in_w, in_h, frames.shape[2], DEV, alpha_meaningful=alpha)
+    can = Bitmap.from_numpy(canvas0.copy(), cw, ch, cst, DEV, compose=compose, matte=matte)
+    f32 = torch.zeros((n, out_h, out_w, 4), dtype=torch.float32, device=DEV)
+    info = ScaleAndRenderParams(x, y, out_w, out_h, sharpen, filt, space)
+    plan = scale_and_render(inp, can, info, f32_out=f32, force_kernel=force)
+    torch.cuda.synchronize()
+    got = can.to_numpy()
+    got_f32 = f32.cpu().numpy()
+    assert np.array_equal(got_f32.view(np.uint32), exp_f32.view(np.uint32)), \
+        f"f32 working buffer differs: max abs {np.abs(got_f32 - exp_f32).max()}"
+    if not np.array_equal(got, exp):
+        bad = np.argwhere(got != exp)
+        raise AssertionError(f"{len(bad)} bytes differ, first at {bad[0]}: got {got[tuple(bad[0])]} exp {exp[tuple(bad[0])]}")
+    return plan
+
+
+SHAPES = [
+    (384, 216, 20, 20),      # cfg2 ratio (19.2x / 10.8x)
+    (768, 432, 40, 23),      # cfg5-like ratio
+    (101, 67, 33, 21),       # ragged, ~3x
+    (37, 29, 5, 4),
+    (64, 64, 63, 63),        # nearly 1:1
+    (16, 16, 1, 1),
+    (4, 4, 2, 2),
+    (1000, 10, 100, 3),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("alpha", [False, True])
+def test_replace_self_linear_fused_and_generic(shape, alpha):
+    iw, ih, ow, oh = shape
+    p = run_case(iw, ih, ow, oh, alpha=alpha, force=-1)
+    run_case(iw, ih, ow, oh, alpha=alpha, force=1)
+    if p.kernel_kind() == 0:
+        run_case(iw, ih, ow, oh, alpha=alpha, force=0)
+
+
+@pytest.mark.parametrize("filt,sharpen", [(Filter.Lanczos, 15.0), (Filter.Ginseng, 0.0), (Filter.Hermite, 0.0),
+                                          (Filter.Box, 0.0), (Filter.Triangle, 0.0), (Filter.CatmullRom, 5.0),
+                                          (Filter.Mitchell, 0.0), (Filter.NCubic, 0.0), (Filter.Jinc, 0.0),
+                                          (Filter.Robidoux, 50.0), (Filter.Fastest, 0.0), (Filter.LanczosSharp, 0.0)])
+def test_filters(filt, sharpen):
+    run_case(300, 170, 31, 18, filt=filt, sharpen=sharpen, alpha=True)
+    run_case(300, 170, 31, 18, filt=filt, sharpen=sharpen, alpha=False, force=1)
+
+
+@pytest.mark.parametrize("space", [WorkingFloatspace.StandardRGB, WorkingFloatspace.LinearRGB])
+@pytest.mark.parametrize("compose", list(BitmapCompositing))
+@pytest.mark.parametrize("alpha", [False, True])
+def test_compositing_modes(space, compose, alpha):
+    for matte in (0xFFFFFFFF, 0x80FF2010):
+        run_case(200, 120, 23, 14, space=space, compose=compose, matte=matte, alpha=alpha)
+        run_case(200, 120, 23, 14, space=space, compose=compose, matte=matte, alpha=alpha, force=1)
+
+
+def test_subrect_render_leaves_rest_of_canvas_untouched():
+    run_case(320, 200, 30, 17, x=5, y=3, cw=50, ch=40, alpha=True, compose=BitmapCompositing.BlendWithSelf)
+    run_case(320, 200, 30, 17, x=5, y=3, cw=50, ch=40, alpha=False)
+    run_case(320, 200, 30, 17, x=20, y=23, cw=50, ch=40, alpha=True, compose=BitmapCompositing.BlendWithMatte,
+             matte=0xFF336699, force=1)
+
+
+def test_upscale_uses_generic_path():
+    p = run_case(20, 14, 57, 41, filt=Filter.Ginseng, alpha=True)
+    assert p.kernel_kind() == 1
+    run_case(64, 48, 128, 96, filt=Filter.Robidoux, alpha=False)
+    run_case(10, 10, 10, 30, filt=Filter.Lanczos, alpha=True)
+
+
+def test_alpha_edge_values():
+    fr = U.random_frames(2, 128, 96, seed0=5)
+    fr[0, :, 3::4] = 0                 # fully transparent frame
+    fr[1, :48, 3::4] = 255
+    fr[1, 48:, 3::4] = 0
+    for compose in BitmapCompositing:
+        run_case(128, 96, 16, 12, frames=fr, alpha=True, compose=compose, matte=0xFF102030)
+
+
+def test_constant_and_extreme_frames():
+    for val in (0, 255):
+        fr = np.full((1, 90, U.stride_for(160)), val, np.uint8)
+        run_case(160, 90, 16, 9, frames=fr, alpha=False)
+        run_case(160, 90, 16, 9, frames=fr, alpha=True, filt=Filter.Lanczos, sharpen=15.0)
+
+
+def test_batch_of_gradient_frames_cfg2_shape_reduced():
+    fr = U.gradient_frames(8, 960, 540)
+    run_case(960, 540, 50, 50, frames=fr, alpha=False)
+
+
+def test_full_size_4k_frame_bit_exact():
+    """BASELINE config 2 at full size: 3840x2160 -> 200x200 Robidoux linear, gradient + random frames."""
+    fr = np.concatenate([U.gradient_frames(1, 3840, 2160, k0=3), U.random_frames(1, 3840, 2160, seed0=1000, alpha=False)])
+    p = run_case(3840, 2160, 200, 200, frames=fr, alpha=False)
+    assert p.kernel_kind() == 0
+    fr = U.random_frames(1, 3840, 2160, seed0=1001, alpha=True)
+    run_case(3840, 2160, 200, 113, frames=fr, alpha=True, compose=BitmapCompositing.BlendWithMatte, matte=0xFFFFFFFF)
+
+
+def test_full_size_fused_equals_generic_checksum():
+    """Size-independent property at BASELINE sizes: two independent kernel families agree on every byte."""
+    n = 4
+    fr = U.random_frames(n, 3840, 2160, seed0=2000, alpha=True)
+    inp = Bitmap.from_numpy(fr, 3840, 2160, fr.shape[2], DEV, alpha_meaningful=True)
+    info = ScaleAndRenderParams(0, 0, 200, 200)
+    outs = []
+    for force in (0, 1):
+        can = Bitmap.create_u8(n, 200, 200, DEV)
+        f32 = torch.zeros((n, 200, 200, 4), dtype=torch.float32, device=DEV)
+        scale_and_render(inp, can, info, f32_out=f32, force_kernel=force)
+        torch.cuda.synchronize()
+        outs.append((can.to_numpy(), f32.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+
+
+def test_8k_lanczos_sharpen_matte_cfg5_reduced_and_strips():
+    """cfg5 shape: 7680 wide forces two column strips in the fused kernel."""
+    fr = U.random_frames(1, 7680, 432, seed0=31, alpha=True)
+    p = run_case(7680, 432, 400, 23, frames=fr, filt=Filter.Lanczos, sharpen=15.0, alpha=True,
+                 compose=BitmapCompositing.BlendWithMatte, matte=0xFFFFFFFF)
+    assert p.kernel_kind() == 0
+
+
+def test_host_buffer_drop_in_matches_oracle():
+    from oracle import oracle as O
+    fr = U.random_frames(1, 333, 222, seed0=9)[0]
+    cst = U.stride_for(60)
+    canvas0 = np.random.default_rng(4).integers(0, 256, size=(50, cst), dtype=np.uint8)
+    for compose, alpha in ((BitmapCompositing.ReplaceSelf, False), (BitmapCompositing.BlendWithSelf, True),
+                           (BitmapCompositing.BlendWithMatte, True)):
+        exp = canvas0.copy()
+        rc, _ = O.scale_and_render(fr, 333, 222, exp, 60, 50, 7, 9, 40, 27, compositing=int(compose),
+                                   matte_bgra=0xFF00FF00, alpha_meaningful=alpha)
+        assert rc == 0
+        got = canvas0.copy()
+        scale_and_render_host(fr, 333, 222, fr.shape[1], alpha, got, 60, 50, cst,
+                              ScaleAndRenderParams(7, 9, 40, 27), compose, 0xFF00FF00)
+        assert np.array_equal(got, exp)
+
+
+def test_error_kinds_match_reference():
+    src = np.zeros((4, 64), np.uint8)
+    dst = np.zeros((4, 64), np.uint8)
+    with pytest.raises(FlowError) as e:      # scaling.rs:24-29
+        scale_and_render_host(src, 4, 4, 64, False, dst, 4, 4, 64, ScaleAndRenderParams(2, 0, 4, 4))
+    assert e.value.kind == ErrorKind.InvalidArgument
+    with pytest.raises(FlowError) as e:
+        ResamplePlan(10, 10, 0, 5)
+    assert e.value.kind == ErrorKind.InvalidArgument
+    with pytest.raises(FlowError) as e:
+        ResamplePlan(10, 10, 5, 5, filter=77)
+    assert e.value.kind == ErrorKind.InvalidArgument
+
+
+def test_linearity_property_alpha_weights_partition_of_unity():
+    """Size-independent property: resizing an opaque constant-colour frame returns that colour exactly for every
+    filter whose weights sum to one in f32 (checked against the oracle, which has the same property test on CPU)."""
+    for val in (1, 64, 200):
+        fr = np.full((1, 2160, U.stride_for(3840)), val, np.uint8)
+        inp = Bitmap.from_numpy(fr, 3840, 2160, fr.shape[2], DEV)
+        can = Bitmap.create_u8(1, 200, 200, DEV)
+        scale_and_render(inp, can, ScaleAndRenderParams(0, 0, 200, 200))
+        torch.cuda.synchronize()
+        px = can.to_numpy()[0, :, :800].reshape(200, 200, 4)
+        assert np.all(px[..., 3] == 255)
+        assert np.all(np.abs(px[..., :3].astype(int) - val) <= 1)
