@@ -33,8 +33,9 @@ struct ResampleArgs {
     // horizontal tables
     const uint32_t* h_left;
     const uint32_t* h_count;
-    const float* h_wT;               // [h_max_taps][out_w], zero padded
-    uint32_t h_max_taps;
+    const float* h_wpad;             // [out_w][h_tpad], zero padded, rows 16-byte aligned
+    uint32_t h_tpad;                 // taps per output rounded up to a multiple of 4
+    uint32_t h_w_in_lds;             // 1: the strip's weight rows are staged in LDS
     // generic-kernel tables
     const uint32_t* v_left;
     const uint32_t* v_count;
@@ -50,5 +51,25 @@ struct ResampleArgs {
     float m0, m1, m2, matte_a;       // matte colour in the working space, matte alpha / 255
     uint32_t n_images;
 };
+
+// LDS carve of the fused kernel, shared by host (size) and device (offsets); all offsets in bytes, 16-aligned.
+struct FusedLds {
+    uint32_t lut, hmeta, obuf, l2s, hw, inter, total;
+};
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline FusedLds fused_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t tpad, int channels, bool w_in_lds) {
+    FusedLds l;
+    uint32_t off = 0;
+    l.lut = off;   off += 256u * 4u;
+    l.hmeta = off; off += ((n_u * 8u) + 15u) & ~15u;
+    l.obuf = off;  off += n_u * 16u;
+    l.l2s = off;   off += w_in_lds ? 16384u : 0u;          // linear->sRGB table rides along with the weights
+    l.hw = off;    off += w_in_lds ? n_u * tpad * 4u : 0u;
+    l.inter = off; off += nquads * 4u * static_cast<uint32_t>(channels) * 4u;
+    l.total = off;
+    return l;
+}
 
 }  // namespace ifhip

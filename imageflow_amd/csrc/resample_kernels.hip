@@ -34,22 +34,34 @@ __device__ __forceinline__ uint8_t uchar_clamp_ff(float v) {        // graphics/
     return static_cast<uint8_t>(r);
 }
 
-__device__ __forceinline__ uint8_t encode_channel(const ResampleArgs& a, float v) {   // color.rs:61-71
-    if (a.linear) {                                                                   // lut.rs:4-8
+// Tables the output stage reads: `s2f` = sRGB byte -> working float (256), `l2s` = linear -> sRGB byte (16384).
+// Template parameters so that the fused kernel can hand in LDS pointers (address space known statically) and the
+// generic kernels HBM pointers.
+template <typename LutF, typename LutB>
+struct OutTables {
+    LutF s2f;
+    LutB l2s;
+};
+
+template <typename LutB>
+__device__ __forceinline__ uint8_t encode_channel(const ResampleArgs& a, LutB l2s, float v) {   // color.rs:61-71
+    if (a.linear) {                                                                            // lut.rs:4-8
         float s = v * 16383.0f;
         s = (s != s) ? 0.0f : s;
         s = s < 0.0f ? 0.0f : s;
         s = s > 16383.0f ? 16383.0f : s;
-        return a.l2s[static_cast<uint32_t>(s)];
+        return l2s[static_cast<uint32_t>(s)];
     }
     return uchar_clamp_ff(255.0f * v);
 }
 
 // px: premultiplied working-space pixel (B,G,R,A).  Returns the BGRA8 word to store at the canvas pixel
 // whose current content is `dst` (only read for BlendWithSelf).
-template <bool ALPHA>
+template <bool ALPHA, typename LutF, typename LutB>
 __device__ __forceinline__ uint32_t render_pixel(const ResampleArgs& a, float p0, float p1, float p2, float pa,
-                                                 uint32_t dst, const float* lut) {
+                                                 uint32_t dst, const OutTables<LutF, LutB>& tb) {
+    const LutF lut = tb.s2f;
+    auto encode_channel = [&](const ResampleArgs& aa, float v) -> uint32_t { return ifhip::encode_channel(aa, tb.l2s, v); };
     uint32_t b, g, r, al;
     if (!ALPHA) {
         // scaling.rs:227-232 / :267-271: alpha is not meaningful -> straight encode, alpha = 255
@@ -87,30 +99,46 @@ __device__ __forceinline__ uint32_t render_pixel(const ResampleArgs& a, float p0
     return b | (g << 8) | (r << 16) | (al << 24);
 }
 
-template <bool ALPHA>
+// Canvas stores go out through inline asm on purpose.  On gfx950 loads and stores share vmcnt, and as soon as the
+// compiler sees both kinds pending it treats the counter as out-of-order and drains it (s_waitcnt vmcnt(0)) at the
+// next use of any loaded value -- which here would flush the D source rows every lane keeps in flight.  A store the
+// compiler cannot see only makes its counted waits more conservative (vmcnt(N) with N = younger LOADS still implies
+// the awaited load has returned); nothing ever reads these stores back inside the kernel, and the wave's
+// outstanding stores are completed by the hardware before s_endpgm retires it.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_u32_untracked(uint32_t* p, uint32_t v) {
+    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_f32x4_untracked(float4* p, float x, float y, float z, float w) {
+    f32x4_t v = {x, y, z, w};
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+
+template <bool ALPHA, typename LutF, typename LutB>
 __device__ __forceinline__ void store_pixel(const ResampleArgs& a, uint32_t img, uint32_t j, uint32_t u,
-                                            float p0, float p1, float p2, float pa, const float* lut) {
+                                            float p0, float p1, float p2, float pa, const OutTables<LutF, LutB>& tb) {
     uint8_t* cp = a.canvas + static_cast<size_t>(img) * a.canvas_image_bytes
                   + static_cast<size_t>(a.y + j) * a.c_stride + static_cast<size_t>(a.x + u) * 4u;
     uint32_t* cw = reinterpret_cast<uint32_t*>(cp);           // canvas rows are 4-byte aligned (checked on host)
     uint32_t dst = 0;
     if (ALPHA && a.mode == IFHIP_BLEND_WITH_SELF) dst = *cw;
-    *cw = render_pixel<ALPHA>(a, p0, p1, p2, pa, dst, lut);
+    store_u32_untracked(cw, render_pixel<ALPHA>(a, p0, p1, p2, pa, dst, tb));
     if (a.f32_dump) {
         float4* d = reinterpret_cast<float4*>(a.f32_dump) + (static_cast<size_t>(img) * a.out_h + j) * a.out_w + u;
-        *d = make_float4(p0, p1, p2, ALPHA ? pa : 1.0f);
+        store_f32x4_untracked(d, p0, p1, p2, ALPHA ? pa : 1.0f);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // Fused kernel: one workgroup = (image, band of output rows, column strip)
 // ------------------------------------------------------------------------------------------------------
-constexpr int kPrefetch = 2;        // source rows in flight per lane beyond the one being consumed
-
-template <int K, bool ALPHA>
+template <int K, bool ALPHA, bool WLDS>
 __global__ void __launch_bounds__(1024)
-fused_resample_kernel(const ResampleArgs a) {
+fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
+    // `steps` is a separate __restrict__ argument (not a field of `a`) so that the compiler can prove the canvas
+    // stores never clobber it and keeps the per-step 64-byte records on the scalar path (s_load_dwordx16).
     constexpr int C = ALPHA ? 4 : 3;
+    constexpr int D = kPrefetchRows;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const uint32_t tid = threadIdx.x;
@@ -122,18 +150,42 @@ fused_resample_kernel(const ResampleArgs a) {
 
     const Strip strip = a.strips[strip_i];
     const uint32_t n_u = strip.u1 - strip.u0;
+    const uint32_t tpad = a.h_tpad;
 
-    float* lut = reinterpret_cast<float*>(smem);                 // 256 floats
-    float* obuf = lut + 256;                                     // n_u * 4 floats
-    float* inter = obuf + ((n_u * 4u + 3u) & ~3u);               // nquads * 4 * C floats
+    const FusedLds L = fused_lds_layout(n_u, strip.nquads, tpad, C, WLDS);
+    float* lut = reinterpret_cast<float*>(smem + L.lut);             // 256 floats
+    uint2* hmeta = reinterpret_cast<uint2*>(smem + L.hmeta);         // per output column: {left - cx0, taps}
+    float4* obuf = reinterpret_cast<float4*>(smem + L.obuf);         // horizontally filtered row, 4 floats / px
+    float4* hw_lds = reinterpret_cast<float4*>(smem + L.hw);         // [n_u][tpad] weights (when WLDS)
+    float* inter = reinterpret_cast<float*>(smem + L.inter);         // vertically filtered row [4*nquads][C]
+    uint8_t* l2s_lds = smem + L.l2s;                                 // linear -> sRGB bytes (when WLDS)
 
     for (uint32_t i = tid; i < 256u; i += T) lut[i] = a.lut_in[i];
+    for (uint32_t i = tid; i < n_u; i += T)
+        hmeta[i] = make_uint2(a.h_left[strip.u0 + i] - strip.cx0, a.h_count[strip.u0 + i]);
+    const float4* hw_src = reinterpret_cast<const float4*>(a.h_wpad + static_cast<size_t>(strip.u0) * tpad);
+    if (WLDS) {
+        const uint32_t n4 = n_u * (tpad >> 2);
+        for (uint32_t i = tid; i < n4; i += T) hw_lds[i] = hw_src[i];
+        const uint4* tsrc = reinterpret_cast<const uint4*>(a.l2s);
+        for (uint32_t i = tid; i < 1024u; i += T) reinterpret_cast<uint4*>(l2s_lds)[i] = tsrc[i];
+    }
     __syncthreads();
+    // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. throw away the
+    // D source rows every lane keeps in flight, twice per output row.
+    auto lds_barrier = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
 
     const uint32_t s0 = a.band_begin[band], s1 = a.band_begin[band + 1];
     const bool lane_on = tid < strip.nquads;
+    // lanes past the strip re-read its last quad instead of branching: every row load is unconditional, so the
+    // number of loads in flight is known statically and the compiler can wait with vmcnt(D-1) instead of vmcnt(0)
+    const uint32_t quad = lane_on ? tid : strip.nquads - 1u;
     const uint8_t* src = a.in + static_cast<size_t>(img) * a.in_image_bytes
-                         + static_cast<size_t>(strip.cx0 + 4u * tid) * 4u;
+                         + static_cast<size_t>(strip.cx0 + 4u * quad) * 4u;
 
     float acc[K][4][C];
 #pragma unroll
@@ -143,32 +195,27 @@ fused_resample_kernel(const ResampleArgs a) {
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[s][p][c] = 0.0f;
 
-    auto fetch = [&](uint32_t si) -> uint4 {
-        uint4 r = make_uint4(0, 0, 0, 0);
-        if (si < s1) {
-            const int y = a.steps[si].y;                          // wave-uniform
-            if (y >= 0 && lane_on)
-                r = *reinterpret_cast<const uint4*>(src + static_cast<size_t>(y) * a.in_stride);
-        }
-        return r;
+    auto fetch_row = [&](int y) -> uint4 {                               // y is wave-uniform; -1 = nothing needed
+        const uint32_t yy = y < 0 ? 0u : static_cast<uint32_t>(y);      // (row 0 is re-read: stays in L2)
+        return *reinterpret_cast<const uint4*>(src + static_cast<size_t>(yy) * a.in_stride);
     };
 
-    uint4 raw[kPrefetch];
+    uint4 raw[D];
 #pragma unroll
-    for (int d = 0; d < kPrefetch; ++d) raw[d] = fetch(s0 + d);
+    for (int d = 0; d < D; ++d) {
+        raw[d] = fetch_row(steps[s0 + d].y);
+        __builtin_amdgcn_sched_barrier(0);      // keep issue order raw[0..D-1]: the loop's vmcnt(D-1) relies on it
+    }
 
-    for (uint32_t sb = s0; sb < s1; sb += kPrefetch) {
+    // the host pads every band to a multiple of D steps, so the group loop has no early exit and raw[d] keeps
+    // a fixed register assignment (no rotation copies, no vmcnt(0) at the back edge)
+    for (uint32_t sb = s0; sb < s1; sb += D) {
 #pragma unroll
-        for (int d = 0; d < kPrefetch; ++d) {
-            const uint32_t si = sb + d;
-            if (si >= s1) break;
-            const VStep st = a.steps[si];                        // 64-byte scalar load
-            const uint4 cur = raw[d];
-            raw[d] = fetch(si + kPrefetch);
-
-            if (st.y >= 0) {
-                const uint32_t w4[4] = {cur.x, cur.y, cur.z, cur.w};
-                float v[4][C];
+        for (int d = 0; d < D; ++d) {
+            const VStep st = steps[sb + d];
+            float v[4][C];
+            {
+                const uint32_t w4[4] = {raw[d].x, raw[d].y, raw[d].z, raw[d].w};
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const uint32_t px = w4[p];
@@ -183,9 +230,18 @@ fused_resample_kernel(const ResampleArgs a) {
                         v[p][C - 1] = af;
                     }
                 }
+            }
+            // The bytes of raw[d] are consumed; only now re-issue the load into the same registers (row of step
+            // sb+d+D).  Issuing it earlier would overlap the two live ranges and make the compiler rotate the
+            // registers with copies (and a vmcnt(0) drain) at the loop back edge.
+            __builtin_amdgcn_sched_barrier(0);
+            raw[d] = fetch_row(st.y_ahead);
+            __builtin_amdgcn_sched_barrier(0);
+
+            if (st.y >= 0) {
 #pragma unroll
                 for (int s = 0; s < K; ++s) {
-                    if (st.active & (1u << s)) {                 // scalar branch
+                    if (st.active & (1u << s)) {                     // scalar branch
                         const float w = st.w[s];
 #pragma unroll
                         for (int p = 0; p < 4; ++p)
@@ -201,11 +257,16 @@ fused_resample_kernel(const ResampleArgs a) {
                 for (int s = 0; s < K; ++s) {
                     if (st.flush_slot == s) {
                         if (lane_on) {
-                            float* dstp = inter + static_cast<size_t>(tid) * (4 * C);
+                            float4* dstp = reinterpret_cast<float4*>(inter + static_cast<size_t>(tid) * (4 * C));
+                            if (ALPHA) {
 #pragma unroll
-                            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                                for (int c = 0; c < C; ++c) dstp[p * C + c] = acc[s][p][c];
+                                for (int p = 0; p < 4; ++p)
+                                    dstp[p] = make_float4(acc[s][p][0], acc[s][p][1], acc[s][p][2], acc[s][p][C - 1]);
+                            } else {
+                                dstp[0] = make_float4(acc[s][0][0], acc[s][0][1], acc[s][0][2], acc[s][1][0]);
+                                dstp[1] = make_float4(acc[s][1][1], acc[s][1][2], acc[s][2][0], acc[s][2][1]);
+                                dstp[2] = make_float4(acc[s][2][2], acc[s][3][0], acc[s][3][1], acc[s][3][2]);
+                            }
                         }
 #pragma unroll
                         for (int p = 0; p < 4; ++p)
@@ -213,22 +274,44 @@ fused_resample_kernel(const ResampleArgs a) {
                             for (int c = 0; c < C; ++c) acc[s][p][c] = 0.0f;
                     }
                 }
-                __syncthreads();
+                lds_barrier();
                 const uint32_t j = static_cast<uint32_t>(st.out_row);
                 const uint32_t n_chain = n_u * C;
                 for (uint32_t idx = tid; idx < n_chain; idx += T) {
-                    const uint32_t ul = idx / C, c = idx - ul * C, u = strip.u0 + ul;
-                    const uint32_t left = a.h_left[u] - strip.cx0, n = a.h_count[u];
-                    const float* wp = a.h_wT + u;
-                    const float* ip = inter + static_cast<size_t>(left) * C + c;
+                    const uint32_t ul = idx / C, c = idx - ul * C;
+                    const uint2 m = hmeta[ul];
+                    const float* ip = inter + static_cast<size_t>(m.x) * C + c;
+                    const float4* w4p = WLDS ? (hw_lds + static_cast<size_t>(ul) * (tpad >> 2))
+                                             : (hw_src + static_cast<size_t>(ul) * (tpad >> 2));
+                    const uint32_t n = m.y;
                     float h = 0.0f;
-                    for (uint32_t k = 0; k < n; ++k) h = __builtin_fmaf(wp[static_cast<size_t>(k) * a.out_w], ip[k * C], h);
-                    obuf[ul * 4u + c] = h;
+                    uint32_t k = 0;
+                    for (; k + 4u <= n; k += 4u) {
+                        const float4 w = w4p[k >> 2];
+                        const float i0 = ip[(k + 0u) * C], i1 = ip[(k + 1u) * C], i2 = ip[(k + 2u) * C], i3 = ip[(k + 3u) * C];
+                        h = __builtin_fmaf(w.x, i0, h);
+                        h = __builtin_fmaf(w.y, i1, h);
+                        h = __builtin_fmaf(w.z, i2, h);
+                        h = __builtin_fmaf(w.w, i3, h);
+                    }
+                    if (k < n) {
+                        const float4 w = w4p[k >> 2];
+                        h = __builtin_fmaf(w.x, ip[k * C], h);
+                        if (k + 1u < n) h = __builtin_fmaf(w.y, ip[(k + 1u) * C], h);
+                        if (k + 2u < n) h = __builtin_fmaf(w.z, ip[(k + 2u) * C], h);
+                    }
+                    reinterpret_cast<float*>(obuf)[ul * 4u + c] = h;
                 }
-                __syncthreads();
+                lds_barrier();
                 for (uint32_t ul = tid; ul < n_u; ul += T) {
-                    const float* o = obuf + ul * 4u;
-                    store_pixel<ALPHA>(a, img, j, strip.u0 + ul, o[0], o[1], o[2], ALPHA ? o[3] : 1.0f, lut);
+                    const float4 o = obuf[ul];
+                    if (WLDS) {
+                        const OutTables<const float*, const uint8_t*> tb{lut, l2s_lds};
+                        store_pixel<ALPHA>(a, img, j, strip.u0 + ul, o.x, o.y, o.z, ALPHA ? o.w : 1.0f, tb);
+                    } else {
+                        const OutTables<const float*, const uint8_t*> tb{lut, a.l2s};
+                        store_pixel<ALPHA>(a, img, j, strip.u0 + ul, o.x, o.y, o.z, ALPHA ? o.w : 1.0f, tb);
+                    }
                 }
             }
         }
@@ -286,7 +369,8 @@ hpass_generic_kernel(const ResampleArgs a, const float4* scratch, uint32_t img0)
         s2 = __builtin_fmaf(wk, v.z, s2);
         if (ALPHA) s3 = __builtin_fmaf(wk, v.w, s3);
     }
-    store_pixel<ALPHA>(a, img, j, u, s0, s1, s2, ALPHA ? s3 : 1.0f, a.lut_in);
+    const OutTables<const float*, const uint8_t*> tb{a.lut_in, a.l2s};
+    store_pixel<ALPHA>(a, img, j, u, s0, s1, s2, ALPHA ? s3 : 1.0f, tb);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -336,18 +420,21 @@ __global__ void __launch_bounds__(256) apply_matte_kernel(const MatteArgs a) {
 // ------------------------------------------------------------------------------------------------------
 // Launchers (called from api.cpp)
 // ------------------------------------------------------------------------------------------------------
+template <int K, bool ALPHA, bool WLDS>
+static hipError_t launch_fused_kaw(const ResampleArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_resample_kernel<K, ALPHA, WLDS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL((fused_resample_kernel<K, ALPHA, WLDS>), grid, block, lds, st, a, a.steps);
+    return hipGetLastError();
+}
+
 template <int K>
 static hipError_t launch_fused_k(const ResampleArgs& a, bool alpha, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    if (alpha) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_resample_kernel<K, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        hipLaunchKernelGGL((fused_resample_kernel<K, true>), grid, block, lds, st, a);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_resample_kernel<K, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        hipLaunchKernelGGL((fused_resample_kernel<K, false>), grid, block, lds, st, a);
-    }
-    return hipGetLastError();
+    const bool wl = a.h_w_in_lds != 0;
+    if (alpha) return wl ? launch_fused_kaw<K, true, true>(a, grid, block, lds, st)
+                         : launch_fused_kaw<K, true, false>(a, grid, block, lds, st);
+    return wl ? launch_fused_kaw<K, false, true>(a, grid, block, lds, st)
+              : launch_fused_kaw<K, false, false>(a, grid, block, lds, st);
 }
 
 hipError_t launch_fused(const ResampleArgs& a, int slots, bool alpha, uint32_t grid, uint32_t block, size_t lds,

@@ -316,6 +316,17 @@ bool build_vschedule(const AxisWeights& wv, int n_bands, VSchedule* out) {
             }
             while (jlo < j1 && wv.left[jlo] + wv.count[jlo] - 1 <= y) ++jlo;
         }
+        while ((s.steps.size() - s.band_begin.back()) % kPrefetchRows != 0) {   // kernel consumes steps in groups
+            VStep nop;
+            std::memset(&nop, 0, sizeof nop);
+            nop.y = -1; nop.flush_slot = -1; nop.out_row = -1; nop.y_ahead = -1;
+            s.steps.push_back(nop);
+        }
+        const size_t begin = s.band_begin.back(), end = s.steps.size();
+        for (size_t i = begin; i < end; ++i) {
+            const size_t a = i + kPrefetchRows;
+            s.steps[i].y_ahead = a < end ? s.steps[a].y : -1;
+        }
         s.band_begin.push_back(static_cast<uint32_t>(s.steps.size()));
     }
     *out = std::move(s);
