@@ -47,6 +47,7 @@ struct DeviceTables {
     float* s2l = nullptr;
     float* s2f = nullptr;
     uint8_t* l2s = nullptr;
+    uint16_t* l2s_thr = nullptr;
 };
 std::mutex g_dev_mu;
 std::map<int, DeviceTables> g_dev_tables;
@@ -70,6 +71,8 @@ int device_tables(DeviceTables* out) {
         HIP_TRY(hipMemcpy(d.s2l, t.s2l, sizeof t.s2l, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d.s2f, t.s2f, sizeof t.s2f, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d.l2s, t.l2s, sizeof t.l2s, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.l2s_thr), sizeof t.l2s_thr));
+        HIP_TRY(hipMemcpy(d.l2s_thr, t.l2s_thr, sizeof t.l2s_thr, hipMemcpyHostToDevice));
         it = g_dev_tables.emplace(dev, d).first;
     }
     *out = it->second;
@@ -249,6 +252,7 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
     a.linear = working_space == IFHIP_SPACE_LINEAR;
     a.lut_in = a.linear ? tb.s2l : tb.s2f;
     a.l2s = tb.l2s;
+    a.l2s_thr = tb.l2s_thr;
     a.mode = compositing;
     const float* s2 = a.linear ? host_tb.s2l : host_tb.s2f;       // matte colour in working space, scaling.rs:141-143
     a.m0 = s2[matte & 255u]; a.m1 = s2[(matte >> 8) & 255u]; a.m2 = s2[(matte >> 16) & 255u];
@@ -368,6 +372,12 @@ int ifhip_table_srgb_to_floatspace(int working_space, float* out256) {
 int ifhip_table_linear_to_srgb(uint8_t* out16384) {
     if (!out16384) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null table pointer");
     std::memcpy(out16384, color_tables().l2s, 16384);
+    return IFHIP_OK;
+}
+
+int ifhip_table_linear_to_srgb_thresholds(uint16_t* out256) {
+    if (!out256) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null table pointer");
+    std::memcpy(out256, color_tables().l2s_thr, 512);
     return IFHIP_OK;
 }
 

@@ -29,6 +29,14 @@ static void fill_tables() {
         q = q < 0.0 ? 0.0 : (q > 255.0 ? 255.0 : q);
         g_tables.l2s[i] = static_cast<uint8_t>(q);
     }
+    // The table is monotone, so it is fully described by where each output value first appears; the fused kernel
+    // searches these 256 thresholds in LDS instead of holding the 16 KiB table there.
+    for (int k = 0; k < 256; ++k) g_tables.l2s_thr[k] = 65535;
+    for (int i = 16383; i >= 0; --i) {
+        const int v = g_tables.l2s[i];
+        for (int k = 0; k < v; ++k)
+            if (g_tables.l2s_thr[k] > i) g_tables.l2s_thr[k] = static_cast<uint16_t>(i);
+    }
 }
 
 const ColorTables& color_tables() {

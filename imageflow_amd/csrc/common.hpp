@@ -50,6 +50,7 @@ struct ColorTables {
     float s2l[256];        // ColorContext(LinearRGB).byte_to_float
     float s2f[256];        // ColorContext(StandardRGB).byte_to_float
     uint8_t l2s[16384];    // LINEAR_TO_SRGB_LUT
+    uint16_t l2s_thr[256]; // thr[k] = smallest i with l2s[i] >= k+1 (65535 if none): l2s[i] == #{k : thr[k] <= i}
 };
 const ColorTables& color_tables();
 

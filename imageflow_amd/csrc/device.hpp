@@ -46,6 +46,7 @@ struct ResampleArgs {
     // colour
     const float* lut_in;             // 256 floats in HBM: s2l (linear) or s2f (srgb)
     const uint8_t* l2s;              // 16384 bytes in HBM
+    const uint16_t* l2s_thr;         // 256 u16 in HBM: thr[k] = first LUT index whose value is >= k+1 (65535 pad)
     int linear;                      // working space
     int mode;                        // ifhip_compositing
     float m0, m1, m2, matte_a;       // matte colour in the working space, matte alpha / 255
@@ -54,7 +55,7 @@ struct ResampleArgs {
 
 // LDS carve of the fused kernel, shared by host (size) and device (offsets); all offsets in bytes, 16-aligned.
 struct FusedLds {
-    uint32_t lut, hmeta, obuf, l2s, hw, inter, total;
+    uint32_t lut, thr, hmeta, obuf, hw, inter, total;
 };
 #if defined(__HIPCC__)
 __host__ __device__
@@ -62,10 +63,10 @@ __host__ __device__
 inline FusedLds fused_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t tpad, int channels, bool w_in_lds) {
     FusedLds l;
     uint32_t off = 0;
-    l.lut = off;   off += 256u * 4u;
+    l.lut = off;   off += 256u * 32u * 4u;                 // sRGB->float table, one copy per LDS bank
+    l.thr = off;   off += 256u * 2u;                       // linear->sRGB thresholds (binary search)
     l.hmeta = off; off += ((n_u * 8u) + 15u) & ~15u;
     l.obuf = off;  off += n_u * 16u;
-    l.l2s = off;   off += w_in_lds ? 16384u : 0u;          // linear->sRGB table rides along with the weights
     l.hw = off;    off += w_in_lds ? n_u * tpad * 4u : 0u;
     l.inter = off; off += nquads * 4u * static_cast<uint32_t>(channels) * 4u;
     l.total = off;

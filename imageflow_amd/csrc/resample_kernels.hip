@@ -43,6 +43,29 @@ struct OutTables {
     LutB l2s;
 };
 
+// LDS-resident tables of the fused kernel.
+//  * BankedLut: 32 copies of the 256-entry float table, copy b living entirely in LDS bank b
+//    (dword address = idx*32 + lane%32), so the 32 lanes a ds_read_b32 services per cycle never collide,
+//    whatever their indices.  A single copy costs ~3.5 LDS cycles per lane group on random pixels and made
+//    the whole kernel LDS-bound (profiles/r1_v2_pmc_summary.txt).
+//  * ThresholdL2S: linear->sRGB via upper_bound over the 256 thresholds of the (monotone) 16384-entry table:
+//    8 dependent ds_read_u16, only ~600 times per output row, and 512 B of LDS instead of 16 KiB.
+struct BankedLut {
+    const float* base;      // LDS
+    uint32_t lane_off;      // lane % 32
+    __device__ __forceinline__ float operator[](uint32_t idx) const { return base[(idx << 5) + lane_off]; }
+};
+struct ThresholdL2S {
+    const uint16_t* thr;    // LDS, 256 entries
+    __device__ __forceinline__ uint8_t operator[](uint32_t idx) const {
+        uint32_t lo = 0;                        // count of thresholds <= idx
+#pragma unroll
+        for (uint32_t step = 128; step > 0; step >>= 1)
+            if (thr[lo + step - 1] <= idx) lo += step;
+        return static_cast<uint8_t>(lo);
+    }
+};
+
 template <typename LutB>
 __device__ __forceinline__ uint8_t encode_channel(const ResampleArgs& a, LutB l2s, float v) {   // color.rs:61-71
     if (a.linear) {                                                                            // lut.rs:4-8
@@ -153,22 +176,22 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     const uint32_t tpad = a.h_tpad;
 
     const FusedLds L = fused_lds_layout(n_u, strip.nquads, tpad, C, WLDS);
-    float* lut = reinterpret_cast<float*>(smem + L.lut);             // 256 floats
+    float* lut_banked = reinterpret_cast<float*>(smem + L.lut);      // [256][32] floats, one copy per bank
+    uint16_t* thr = reinterpret_cast<uint16_t*>(smem + L.thr);       // 256 linear->sRGB thresholds
     uint2* hmeta = reinterpret_cast<uint2*>(smem + L.hmeta);         // per output column: {left - cx0, taps}
     float4* obuf = reinterpret_cast<float4*>(smem + L.obuf);         // horizontally filtered row, 4 floats / px
     float4* hw_lds = reinterpret_cast<float4*>(smem + L.hw);         // [n_u][tpad] weights (when WLDS)
     float* inter = reinterpret_cast<float*>(smem + L.inter);         // vertically filtered row [4*nquads][C]
-    uint8_t* l2s_lds = smem + L.l2s;                                 // linear -> sRGB bytes (when WLDS)
 
-    for (uint32_t i = tid; i < 256u; i += T) lut[i] = a.lut_in[i];
+    for (uint32_t i = tid; i < 256u * 32u; i += T) lut_banked[i] = a.lut_in[i >> 5];
+    for (uint32_t i = tid; i < 256u; i += T) thr[i] = a.l2s_thr[i];
+    const BankedLut lut{lut_banked, tid & 31u};
     for (uint32_t i = tid; i < n_u; i += T)
         hmeta[i] = make_uint2(a.h_left[strip.u0 + i] - strip.cx0, a.h_count[strip.u0 + i]);
     const float4* hw_src = reinterpret_cast<const float4*>(a.h_wpad + static_cast<size_t>(strip.u0) * tpad);
     if (WLDS) {
         const uint32_t n4 = n_u * (tpad >> 2);
         for (uint32_t i = tid; i < n4; i += T) hw_lds[i] = hw_src[i];
-        const uint4* tsrc = reinterpret_cast<const uint4*>(a.l2s);
-        for (uint32_t i = tid; i < 1024u; i += T) reinterpret_cast<uint4*>(l2s_lds)[i] = tsrc[i];
     }
     __syncthreads();
     // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. throw away the
@@ -305,13 +328,8 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                 lds_barrier();
                 for (uint32_t ul = tid; ul < n_u; ul += T) {
                     const float4 o = obuf[ul];
-                    if (WLDS) {
-                        const OutTables<const float*, const uint8_t*> tb{lut, l2s_lds};
-                        store_pixel<ALPHA>(a, img, j, strip.u0 + ul, o.x, o.y, o.z, ALPHA ? o.w : 1.0f, tb);
-                    } else {
-                        const OutTables<const float*, const uint8_t*> tb{lut, a.l2s};
-                        store_pixel<ALPHA>(a, img, j, strip.u0 + ul, o.x, o.y, o.z, ALPHA ? o.w : 1.0f, tb);
-                    }
+                    const OutTables<BankedLut, ThresholdL2S> tb{lut, ThresholdL2S{thr}};
+                    store_pixel<ALPHA>(a, img, j, strip.u0 + ul, o.x, o.y, o.z, ALPHA ? o.w : 1.0f, tb);
                 }
             }
         }

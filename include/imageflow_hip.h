@@ -85,6 +85,9 @@ IFHIP_API int ifhip_populate_weights(int filter, int lobe_mode, float lobe_value
 IFHIP_API int ifhip_table_srgb_to_floatspace(int working_space, float* out256);
 /* graphics/lut.rs:14-271 LINEAR_TO_SRGB_LUT, 16384 bytes. */
 IFHIP_API int ifhip_table_linear_to_srgb(uint8_t* out16384);
+/* The same table in the form the fused kernel keeps in LDS: thr[k] = first index whose value is >= k+1
+ * (65535 if none), so table[i] == number of k with thr[k] <= i. */
+IFHIP_API int ifhip_table_linear_to_srgb_thresholds(uint16_t* out256);
 
 /* ---- Inner A: resample + render ---------------------------------------------------------------------- */
 /*

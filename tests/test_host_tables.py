@@ -112,6 +112,18 @@ def test_colour_tables_match_reference_and_oracle(golden_dir):
     assert np.array_equal(pinned.view(np.uint32), s2l.view(np.uint32))
 
 
+def test_threshold_form_of_the_l2s_table_is_equivalent():
+    """The fused kernel encodes linear->sRGB by upper_bound over 256 thresholds; that must reproduce the table."""
+    import ctypes as C
+    thr = np.zeros(256, np.uint16)
+    _native.lib().ifhip_table_linear_to_srgb_thresholds.argtypes = [C.c_void_p]
+    assert _native.lib().ifhip_table_linear_to_srgb_thresholds(thr.ctypes.data) == 0
+    table = Cc.linear_to_srgb_table()
+    assert np.all(np.diff(table.astype(int)) >= 0)
+    rebuilt = np.searchsorted(thr.astype(np.int64), np.arange(16384), side="right")
+    assert np.array_equal(rebuilt.astype(np.uint8), table)
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a GPU every compute entry point must refuse loudly (never fall back to a CPU path)."""
     import torch
