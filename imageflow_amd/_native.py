@@ -5,7 +5,7 @@ import os
 from .errors import FlowError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libimageflow_hip.so")
+LIB_PATH = os.environ.get("IFHIP_LIB") or os.path.join(_HERE, "lib", "libimageflow_hip.so")
 _lib = None
 
 u8p, u32p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_float)

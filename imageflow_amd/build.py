@@ -31,6 +31,17 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name, defines):
+    """Experiment builds (tools/): same sources with extra -D flags into lib/libimageflow_hip_<name>.so."""
+    out = os.path.join(HERE, "lib", f"libimageflow_hip_{name}.so")
+    srcs = []
+    for src in sources():
+        srcs += (["-x", "hip"] if src.endswith(".cpp") else ["-x", "hip"]) + [src]
+    cmd = [HIPCC, "--offload-arch=gfx950"] + COMMON + [f"-D{d}" for d in defines] + ["-shared"] + srcs + ["-o", out]
+    subprocess.run(cmd, check=True)
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB

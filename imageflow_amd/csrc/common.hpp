@@ -58,14 +58,18 @@ const ColorTables& color_tables();
 // Vertical schedule for the fused kernel (our own construct; DESIGN.md "vertical schedule")
 // ---------------------------------------------------------------------------------------------------
 constexpr int kMaxSlots = 8;
-constexpr int kPrefetchRows = 4;     // source rows kept in flight per lane by the fused kernel
+#ifndef IFHIP_PREFETCH_ROWS
+#define IFHIP_PREFETCH_ROWS 4
+#endif
+static_assert(IFHIP_PREFETCH_ROWS % 2 == 0, "the step loop double-buffers by step parity");
+constexpr int kPrefetchRows = IFHIP_PREFETCH_ROWS;     // source rows kept in flight per lane by the fused kernel
 struct alignas(64) VStep {
     int32_t y;            // source row to load and accumulate, or -1
     uint32_t active;      // bit s set: ring slot s accumulates row y with weight w[s]
     int32_t flush_slot;   // ring slot completed by this step (-1: none)
     int32_t out_row;      // output row index held by flush_slot
     float w[kMaxSlots];
-    int32_t y_ahead;      // source row of the step kPrefetchRows later in the same band (-1: none) -- issued now
+    int32_t y_ahead;      // source row of step i+1+kPrefetchRows of the same band (-1: none): the load issued at step i
     int32_t pad[3];
 };
 static_assert(sizeof(VStep) == 64, "VStep must be one 64-byte scalar-load line");

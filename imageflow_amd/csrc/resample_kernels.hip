@@ -223,58 +223,85 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
         return *reinterpret_cast<const uint4*>(src + static_cast<size_t>(yy) * a.in_stride);
     };
 
+    // sample -> working float for the 4 pixels of one 16-byte load (arithmetic contract step 1)
+    auto convert = [&](const uint4& q, float (&v)[4][C]) {
+        const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t px = w4[p];
+            v[p][0] = lut[px & 255u];
+            v[p][1] = lut[(px >> 8) & 255u];
+            v[p][2] = lut[(px >> 16) & 255u];
+            if (ALPHA) {
+                const float af = static_cast<float>(px >> 24) * (1.0f / 255.0f);
+                v[p][0] = v[p][0] * af;
+                v[p][1] = v[p][1] * af;
+                v[p][2] = v[p][2] * af;
+                v[p][C - 1] = af;
+            }
+        }
+    };
+
+    // Software pipeline over steps (one step = one source row):
+    //   raw[D]  : D source rows in flight per lane (16 B each), refilled in place -> fixed registers, vmcnt(D-1)
+    //   vbuf[2] : converted floats of the current / the next step; the 12-16 LUT reads of step i+1 are issued before
+    //             the FMAs of step i, so their LDS latency hides under the lane's own arithmetic
+    //   rec[2]  : the 64-byte step records of the current / the next step (scalar loads, same overlap)
+    // The host pads every band to a multiple of D steps (D even), so the unrolled group has no early exit and every
+    // buffer index below is a compile-time constant.
     uint4 raw[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         raw[d] = fetch_row(steps[s0 + d].y);
         __builtin_amdgcn_sched_barrier(0);      // keep issue order raw[0..D-1]: the loop's vmcnt(D-1) relies on it
     }
+    float vbuf[2][4][C];
+    VStep rec[2];
+    rec[0] = steps[s0];
+    convert(raw[0], vbuf[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    raw[0] = fetch_row((s0 + D < s1) ? steps[s0 + D].y : -1);
+    __builtin_amdgcn_sched_barrier(0);
 
-    // the host pads every band to a multiple of D steps, so the group loop has no early exit and raw[d] keeps
-    // a fixed register assignment (no rotation copies, no vmcnt(0) at the back edge)
     for (uint32_t sb = s0; sb < s1; sb += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const VStep st = steps[sb + d];
-            float v[4][C];
-            {
-                const uint32_t w4[4] = {raw[d].x, raw[d].y, raw[d].z, raw[d].w};
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const uint32_t px = w4[p];
-                    v[p][0] = lut[px & 255u];
-                    v[p][1] = lut[(px >> 8) & 255u];
-                    v[p][2] = lut[(px >> 16) & 255u];
-                    if (ALPHA) {
-                        const float af = static_cast<float>(px >> 24) * (1.0f / 255.0f);
-                        v[p][0] = v[p][0] * af;
-                        v[p][1] = v[p][1] * af;
-                        v[p][2] = v[p][2] * af;
-                        v[p][C - 1] = af;
-                    }
-                }
-            }
-            // The bytes of raw[d] are consumed; only now re-issue the load into the same registers (row of step
-            // sb+d+D).  Issuing it earlier would overlap the two live ranges and make the compiler rotate the
-            // registers with copies (and a vmcnt(0) drain) at the loop back edge.
+            const int cur = d & 1, nxt = cur ^ 1;
+            const int slot_next = (d + 1) % D;
+            const uint32_t si = sb + d;
+            // ---- stage A: start step si+1 (record, LUT gathers), refill its row slot for step si+1+D ----
+            rec[nxt] = steps[(si + 1 < s1) ? si + 1 : si];
+            convert(raw[slot_next], vbuf[nxt]);
             __builtin_amdgcn_sched_barrier(0);
-            raw[d] = fetch_row(st.y_ahead);
+            raw[slot_next] = fetch_row(rec[cur].y_ahead);
             __builtin_amdgcn_sched_barrier(0);
-
+            // ---- stage B: finish step si ----
+            const VStep& st = rec[cur];
+            float (&v)[4][C] = vbuf[cur];
+#if defined(IFHIP_EXP_LOAD_ONLY)   // experiment: stream rows, no arithmetic (NOT a product path)
+            acc[0][0][0] += v[0][0] + v[1][1] + v[2][2] + v[3][0];
+#else
+            // Every ring slot accumulates unconditionally: a slot outside its window holds exactly +0.0f (initial
+            // value / reset at flush) and has weight +0.0f in the step record, and fmaf(+0, v, +0) == +0 for the
+            // finite non-negative v we feed it, so the result is bit-identical to skipping the slot -- without
+            // K scalar branches (and their instruction-fetch bubbles) per source row.
             if (st.y >= 0) {
 #pragma unroll
                 for (int s = 0; s < K; ++s) {
-                    if (st.active & (1u << s)) {                     // scalar branch
-                        const float w = st.w[s];
+                    const float w = st.w[s];
 #pragma unroll
-                        for (int p = 0; p < 4; ++p)
+                    for (int p = 0; p < 4; ++p)
 #pragma unroll
-                            for (int c = 0; c < C; ++c) acc[s][p][c] = __builtin_fmaf(w, v[p][c], acc[s][p][c]);
-                    }
+                        for (int c = 0; c < C; ++c) acc[s][p][c] = __builtin_fmaf(w, v[p][c], acc[s][p][c]);
                 }
             }
+#endif
 
+#if defined(IFHIP_EXP_NO_H)        // experiment: vertical pass only (NOT a product path)
+            if (st.flush_slot >= 0 && st.out_row == 0x7fffffff) {
+#else
             if (st.flush_slot >= 0) {
+#endif
                 // ---- hand the finished vertically-filtered row to the horizontal pass through LDS ----
 #pragma unroll
                 for (int s = 0; s < K; ++s) {
@@ -309,6 +336,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                     const uint32_t n = m.y;
                     float h = 0.0f;
                     uint32_t k = 0;
+#pragma unroll 4
                     for (; k + 4u <= n; k += 4u) {
                         const float4 w = w4p[k >> 2];
                         const float i0 = ip[(k + 0u) * C], i1 = ip[(k + 1u) * C], i2 = ip[(k + 2u) * C], i3 = ip[(k + 3u) * C];
@@ -458,12 +486,15 @@ static hipError_t launch_fused_k(const ResampleArgs& a, bool alpha, dim3 grid, d
 hipError_t launch_fused(const ResampleArgs& a, int slots, bool alpha, uint32_t grid, uint32_t block, size_t lds,
                         hipStream_t st) {
     const dim3 g(grid), b(block);
-    switch (slots) {
-    case 1: case 2: return launch_fused_k<2>(a, alpha, g, b, lds, st);
-    case 3: case 4: return launch_fused_k<4>(a, alpha, g, b, lds, st);
+    switch (slots) {            // K must equal the ring size exactly: every slot accumulates on every row
+    case 1: return launch_fused_k<1>(a, alpha, g, b, lds, st);
+    case 2: return launch_fused_k<2>(a, alpha, g, b, lds, st);
+    case 3: return launch_fused_k<3>(a, alpha, g, b, lds, st);
+    case 4: return launch_fused_k<4>(a, alpha, g, b, lds, st);
     case 5: return launch_fused_k<5>(a, alpha, g, b, lds, st);
     case 6: return launch_fused_k<6>(a, alpha, g, b, lds, st);
-    case 7: case 8: return launch_fused_k<8>(a, alpha, g, b, lds, st);
+    case 7: return launch_fused_k<7>(a, alpha, g, b, lds, st);
+    case 8: return launch_fused_k<8>(a, alpha, g, b, lds, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -324,7 +324,9 @@ bool build_vschedule(const AxisWeights& wv, int n_bands, VSchedule* out) {
         }
         const size_t begin = s.band_begin.back(), end = s.steps.size();
         for (size_t i = begin; i < end; ++i) {
-            const size_t a = i + kPrefetchRows;
+            // the kernel converts the row of step i+1 while it finishes step i, and refills that register slot at
+            // once with the row the slot serves next, i.e. the row of step i+1+kPrefetchRows
+            const size_t a = i + 1 + kPrefetchRows;
             s.steps[i].y_ahead = a < end ? s.steps[a].y : -1;
         }
         s.band_begin.push_back(static_cast<uint32_t>(s.steps.size()));
