@@ -104,8 +104,10 @@ struct ifhip_resample_plan {
     // device copies of the contribution tables
     uint32_t *d_v_left = nullptr, *d_v_count = nullptr, *d_v_off = nullptr;
     uint32_t *d_h_left = nullptr, *d_h_count = nullptr, *d_h_off = nullptr;
-    float *d_v_w = nullptr, *d_h_w = nullptr, *d_h_wpad = nullptr;
-    uint32_t h_tpad = 0;
+    float *d_v_w = nullptr, *d_h_w = nullptr, *d_h_wu = nullptr;
+    uint4* d_h_meta = nullptr;
+    uint32_t h_wu_floats = 0;       // de-duplicated, 4-tap padded horizontal weight rows
+    uint32_t h_avg_groups = 0;      // mean 4-tap groups per horizontal chain
     // fused-kernel geometry
     bool fused_possible = false;
     int slots = 0;
@@ -120,7 +122,7 @@ struct ifhip_resample_plan {
 
     ~ifhip_resample_plan() {
         for (void* p : {(void*)d_v_left, (void*)d_v_count, (void*)d_v_off, (void*)d_h_left, (void*)d_h_count,
-                        (void*)d_h_off, (void*)d_v_w, (void*)d_h_w, (void*)d_h_wpad, (void*)d_strips, (void*)scratch})
+                        (void*)d_h_off, (void*)d_v_w, (void*)d_h_w, (void*)d_h_wu, (void*)d_h_meta, (void*)d_strips, (void*)scratch})
             if (p) (void)hipFree(p);
         for (auto& kv : schedules) {
             if (kv.second.steps) (void)hipFree(kv.second.steps);
@@ -131,8 +133,9 @@ struct ifhip_resample_plan {
 
 namespace {
 
-size_t fused_lds_bytes(uint32_t n_u, uint32_t nquads, int channels, uint32_t tpad = 0, bool w_in_lds = false) {
-    return fused_lds_layout(n_u, nquads, tpad, channels, w_in_lds).total;
+size_t fused_lds_bytes(uint32_t n_u, uint32_t nquads, int channels, uint32_t wu_floats = 0, bool w_in_lds = false,
+                       bool l2s_in_lds = false) {
+    return fused_lds_layout(n_u, nquads, wu_floats, channels, w_in_lds, l2s_in_lds).total;
 }
 
 // Split the output columns into strips whose staged source span fits one workgroup (<= 1024 lanes x 4 px)
@@ -246,7 +249,8 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
     a.in = d_in; a.in_image_bytes = in_image_bytes; a.in_stride = in_stride; a.in_w = p->in_w; a.in_h = p->in_h;
     a.canvas = d_canvas; a.canvas_image_bytes = canvas_image_bytes; a.c_stride = c_stride; a.x = x; a.y = y;
     a.out_w = p->out_w; a.out_h = p->out_h; a.f32_dump = d_f32;
-    a.h_left = p->d_h_left; a.h_count = p->d_h_count; a.h_wpad = p->d_h_wpad; a.h_tpad = p->h_tpad;
+    a.h_meta = p->d_h_meta; a.h_wu = p->d_h_wu; a.h_wu_floats = p->h_wu_floats;
+    a.h_left = p->d_h_left; a.h_count = p->d_h_count;
     a.v_left = p->d_v_left; a.v_count = p->d_v_count; a.v_off = p->d_v_off; a.v_w = p->d_v_w;
     a.h_off = p->d_h_off; a.h_w = p->d_h_w;
     a.linear = working_space == IFHIP_SPACE_LINEAR;
@@ -273,14 +277,20 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         a.steps = sd.steps; a.band_begin = sd.band_begin; a.n_bands = sd.n_bands;
         a.strips = p->d_strips; a.n_strips = static_cast<uint32_t>(p->strips.size());
         const int channels = alpha ? 4 : 3;
-        // stage the strip's horizontal weights in LDS when everything still fits one CU's 160 KB
+        // LDS budget, in priority order: banked LUT + double-buffered rows (always), the de-duplicated horizontal
+        // weight rows, then the 16 KiB linear->sRGB table (otherwise encoded by threshold search)
         bool w_in_lds = std::getenv("IFHIP_HW_GLOBAL") == nullptr;
         for (const Strip& s : p->strips)
-            if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_tpad, true) > kLdsLimit) w_in_lds = false;
+            if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, true) > kLdsLimit) w_in_lds = false;
+        bool l2s_in_lds = std::getenv("IFHIP_L2S_SEARCH") == nullptr;
+        for (const Strip& s : p->strips)
+            if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w_in_lds, true) > kLdsLimit) l2s_in_lds = false;
         a.h_w_in_lds = w_in_lds ? 1u : 0u;
+        a.l2s_in_lds = l2s_in_lds ? 1u : 0u;
         size_t lds = 0;
         for (const Strip& s : p->strips)
-            lds = std::max(lds, fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_tpad, w_in_lds));
+            lds = std::max(lds, fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w_in_lds, l2s_in_lds));
+        if (lds > kLdsLimit) return fail(IFHIP_INVALID_STATE, "InvalidState: fused kernel LDS plan exceeds the CU (%zu bytes)", lds);
         const uint32_t block = std::max<uint32_t>(64u, (p->max_quads + 63u) & ~63u);
         const uint64_t grid = static_cast<uint64_t>(n_images) * sd.n_bands * a.n_strips;
         if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
@@ -404,16 +414,39 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
     rc = build_axis_weights(spec, w, in_w, &p->wh);
     if (rc) return rc;
 
-    // horizontal weights as zero-padded rows [out_w][tpad], 16-byte aligned so a lane reads 4 taps per load
-    p->h_tpad = (p->wh.max_taps + 3u) & ~3u;
-    std::vector<float> wpad(static_cast<size_t>(p->h_tpad) * w, 0.0f);
-    for (uint32_t u = 0; u < w; ++u)
-        for (uint32_t k = 0; k < p->wh.count[u]; ++k) wpad[static_cast<size_t>(u) * p->h_tpad + k] = p->wh.w[p->wh.offset[u] + k];
+    // Horizontal weight rows for the fused kernel.  A row starts at the output's first tap rounded DOWN to a multiple
+    // of 4 source columns (so that a lane gathers 4 taps with one aligned 16-byte LDS read), the skipped columns get
+    // weight +0.0f (exact: fmaf(+0, x, +0) == +0 for finite x, and the chain starts at +0), and the row is zero-padded
+    // to a multiple of 4 (the kernel predicates the taps of the last group).  Rows are then de-duplicated bit for
+    // bit: at rational scale factors they recur with period out_w / gcd(in_w, out_w) (3840 -> 200: 36 rows of 200),
+    // which is what lets the whole table live in LDS.
+    std::vector<float> wu;
+    std::vector<uint4> hmeta(w);
+    {
+        std::map<std::vector<uint32_t>, uint32_t> seen;        // row bits -> offset in wu
+        uint64_t groups = 0;
+        for (uint32_t u = 0; u < w; ++u) {
+            const uint32_t n = p->wh.count[u], lead = p->wh.left[u] & 3u, total = lead + n, npad = (total + 3u) & ~3u;
+            std::vector<uint32_t> bits(npad, 0u);
+            std::memcpy(bits.data() + lead, p->wh.w.data() + p->wh.offset[u], n * sizeof(float));
+            auto it = seen.find(bits);
+            if (it == seen.end()) {
+                const uint32_t off = static_cast<uint32_t>(wu.size());
+                wu.resize(wu.size() + npad, 0.0f);
+                std::memcpy(wu.data() + off, bits.data(), npad * sizeof(float));
+                it = seen.emplace(std::move(bits), off).first;
+            }
+            hmeta[u] = make_uint4(p->wh.left[u] & ~3u, npad / 4u, it->second, ((total - 1u) & 3u) + 1u);
+            groups += npad / 4u;
+        }
+        p->h_wu_floats = static_cast<uint32_t>(wu.size());
+        p->h_avg_groups = static_cast<uint32_t>((groups + w - 1u) / w);
+    }
 
     if ((rc = upload(p->wv.left, &p->d_v_left)) || (rc = upload(p->wv.count, &p->d_v_count)) ||
         (rc = upload(p->wv.offset, &p->d_v_off)) || (rc = upload(p->wv.w, &p->d_v_w)) ||
         (rc = upload(p->wh.left, &p->d_h_left)) || (rc = upload(p->wh.count, &p->d_h_count)) ||
-        (rc = upload(p->wh.offset, &p->d_h_off)) || (rc = upload(p->wh.w, &p->d_h_w)) || (rc = upload(wpad, &p->d_h_wpad)))
+        (rc = upload(p->wh.offset, &p->d_h_off)) || (rc = upload(p->wh.w, &p->d_h_w)) || (rc = upload(wu, &p->d_h_wu)) || (rc = upload(hmeta, &p->d_h_meta)))
         return rc;
 
     p->slots = max_live_rows(p->wv);

@@ -30,13 +30,15 @@ struct ResampleArgs {
     uint32_t n_bands;
     const Strip* strips;
     uint32_t n_strips;
-    // horizontal tables
+    // horizontal tables (fused kernel): per output column {left, taps, first weight (float index into h_wu)}
+    const uint4* h_meta;             // [out_w] {first tap column rounded down to 4, 4-tap groups, weight row offset, taps valid in the last group}
+    const float* h_wu;               // de-duplicated weight rows: (left & 3) leading zeros, taps, zero pad to 4; 16-B aligned
+    uint32_t h_wu_floats;            // size of h_wu
+    uint32_t h_w_in_lds;             // 1: h_wu is staged in LDS
+    uint32_t l2s_in_lds;             // 1: the 16 KiB linear->sRGB table is staged in LDS (else threshold search)
+    // generic-kernel tables
     const uint32_t* h_left;
     const uint32_t* h_count;
-    const float* h_wpad;             // [out_w][h_tpad], zero padded, rows 16-byte aligned
-    uint32_t h_tpad;                 // taps per output rounded up to a multiple of 4
-    uint32_t h_w_in_lds;             // 1: the strip's weight rows are staged in LDS
-    // generic-kernel tables
     const uint32_t* v_left;
     const uint32_t* v_count;
     const uint32_t* v_off;
@@ -55,20 +57,26 @@ struct ResampleArgs {
 
 // LDS carve of the fused kernel, shared by host (size) and device (offsets); all offsets in bytes, 16-aligned.
 struct FusedLds {
-    uint32_t lut, thr, hmeta, obuf, hw, inter, total;
+    uint32_t lut, thr, l2s, hmeta, obuf, hw, inter, plane_pitch, inter_stride, total;
 };
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline FusedLds fused_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t tpad, int channels, bool w_in_lds) {
+inline FusedLds fused_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t wu_floats, int channels, bool w_in_lds,
+                                 bool l2s_in_lds) {
     FusedLds l;
     uint32_t off = 0;
     l.lut = off;   off += 256u * 32u * 4u;                 // sRGB->float table, one copy per LDS bank
-    l.thr = off;   off += 256u * 2u;                       // linear->sRGB thresholds (binary search)
-    l.hmeta = off; off += ((n_u * 8u) + 15u) & ~15u;
-    l.obuf = off;  off += n_u * 16u;
-    l.hw = off;    off += w_in_lds ? n_u * tpad * 4u : 0u;
-    l.inter = off; off += nquads * 4u * static_cast<uint32_t>(channels) * 4u;
+    l.thr = off;   off += 256u * 2u;                       // linear->sRGB thresholds (binary search fallback)
+    l.l2s = off;   off += l2s_in_lds ? 16384u : 0u;        // linear->sRGB table
+    l.hmeta = off; off += n_u * 16u;
+    l.obuf = off;  off += 2u * n_u * 16u;                  // horizontally filtered rows j-1 / j
+    l.hw = off;    off += w_in_lds ? ((wu_floats * 4u + 15u) & ~15u) : 0u;
+    // vertically filtered row, one plane per channel; the pitch is == 4 (mod 64) dwords so that the planes of one
+    // pixel sit 4 banks apart for the 16-byte horizontal gathers
+    l.plane_pitch = ((nquads * 4u + 63u) & ~63u) + 4u;                         // floats
+    l.inter_stride = l.plane_pitch * static_cast<uint32_t>(channels) * 4u;    // bytes per buffered row
+    l.inter = off; off += 2u * l.inter_stride;             // vertically filtered rows j / j+1
     l.total = off;
     return l;
 }

@@ -57,7 +57,9 @@ struct BankedLut {
 };
 struct ThresholdL2S {
     const uint16_t* thr;    // LDS, 256 entries
+    const uint8_t* table;   // LDS, 16384 entries, or nullptr when LDS is short (wave-uniform choice)
     __device__ __forceinline__ uint8_t operator[](uint32_t idx) const {
+        if (table) return table[idx];
         uint32_t lo = 0;                        // count of thresholds <= idx
 #pragma unroll
         for (uint32_t step = 128; step > 0; step >>= 1)
@@ -154,12 +156,17 @@ __device__ __forceinline__ void store_pixel(const ResampleArgs& a, uint32_t img,
 
 // ------------------------------------------------------------------------------------------------------
 // Fused kernel: one workgroup = (image, band of output rows, column strip)
+//
+// Vertical pass in registers, one lane = 4 source columns x K live output rows; when an output row completes, its
+// vertically filtered row goes to LDS (double buffered) and the horizontal pass for it is *interleaved* into the
+// following source-row steps, a few taps per step, so that its LDS latency and its strictly sequential fmaf chains
+// hide under the vertical pass instead of stopping it.  One LDS-only workgroup barrier per output row.
 // ------------------------------------------------------------------------------------------------------
 template <int K, bool ALPHA, bool WLDS>
 __global__ void __launch_bounds__(1024)
 fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     // `steps` is a separate __restrict__ argument (not a field of `a`) so that the compiler can prove the canvas
-    // stores never clobber it and keeps the per-step 64-byte records on the scalar path (s_load_dwordx16).
+    // stores never clobber it and keeps the per-step 64-byte records on the scalar path.
     constexpr int C = ALPHA ? 4 : 3;
     constexpr int D = kPrefetchRows;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -173,29 +180,38 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
 
     const Strip strip = a.strips[strip_i];
     const uint32_t n_u = strip.u1 - strip.u0;
-    const uint32_t tpad = a.h_tpad;
 
-    const FusedLds L = fused_lds_layout(n_u, strip.nquads, tpad, C, WLDS);
+    const FusedLds L = fused_lds_layout(n_u, strip.nquads, a.h_wu_floats, C, WLDS, a.l2s_in_lds != 0);
     float* lut_banked = reinterpret_cast<float*>(smem + L.lut);      // [256][32] floats, one copy per bank
     uint16_t* thr = reinterpret_cast<uint16_t*>(smem + L.thr);       // 256 linear->sRGB thresholds
-    uint2* hmeta = reinterpret_cast<uint2*>(smem + L.hmeta);         // per output column: {left - cx0, taps}
-    float4* obuf = reinterpret_cast<float4*>(smem + L.obuf);         // horizontally filtered row, 4 floats / px
-    float4* hw_lds = reinterpret_cast<float4*>(smem + L.hw);         // [n_u][tpad] weights (when WLDS)
-    float* inter = reinterpret_cast<float*>(smem + L.inter);         // vertically filtered row [4*nquads][C]
+    uint4* hmeta = reinterpret_cast<uint4*>(smem + L.hmeta);         // per output column {left - cx0, taps, w offset}
+    float* obuf = reinterpret_cast<float*>(smem + L.obuf);           // 2 x [n_u][4] horizontally filtered rows
+    const float* hw_lds = reinterpret_cast<const float*>(smem + L.hw);
+    float* inter = reinterpret_cast<float*>(smem + L.inter);         // 2 x vertically filtered row, C planes each
+    const uint32_t inter_stride = L.inter_stride >> 2;               // floats per buffered row
+    const uint32_t plane_pitch = L.plane_pitch;                      // floats per channel plane
+    const uint32_t obuf_stride = n_u * 4u;                           // floats
 
     for (uint32_t i = tid; i < 256u * 32u; i += T) lut_banked[i] = a.lut_in[i >> 5];
     for (uint32_t i = tid; i < 256u; i += T) thr[i] = a.l2s_thr[i];
+    const uint8_t* l2s_lds = a.l2s_in_lds ? smem + L.l2s : nullptr;
+    if (a.l2s_in_lds)
+        for (uint32_t i = tid; i < 1024u; i += T)
+            reinterpret_cast<uint4*>(smem + L.l2s)[i] = reinterpret_cast<const uint4*>(a.l2s)[i];
     const BankedLut lut{lut_banked, tid & 31u};
-    for (uint32_t i = tid; i < n_u; i += T)
-        hmeta[i] = make_uint2(a.h_left[strip.u0 + i] - strip.cx0, a.h_count[strip.u0 + i]);
-    const float4* hw_src = reinterpret_cast<const float4*>(a.h_wpad + static_cast<size_t>(strip.u0) * tpad);
+    for (uint32_t i = tid; i < n_u; i += T) {
+        uint4 m = a.h_meta[strip.u0 + i];
+        m.x -= strip.cx0;
+        hmeta[i] = m;
+    }
     if (WLDS) {
-        const uint32_t n4 = n_u * (tpad >> 2);
-        for (uint32_t i = tid; i < n4; i += T) hw_lds[i] = hw_src[i];
+        const float4* src4 = reinterpret_cast<const float4*>(a.h_wu);
+        float4* dst4 = reinterpret_cast<float4*>(smem + L.hw);
+        for (uint32_t i = tid; i < (a.h_wu_floats >> 2); i += T) dst4[i] = src4[i];
     }
     __syncthreads();
     // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. throw away the
-    // D source rows every lane keeps in flight, twice per output row.
+    // D source rows every lane keeps in flight.
     auto lds_barrier = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         __builtin_amdgcn_s_barrier();
@@ -239,6 +255,50 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                 v[p][2] = v[p][2] * af;
                 v[p][C - 1] = af;
             }
+        }
+    };
+
+    // ---- horizontal pass of one output row: chain idx = (output column ul, channel c), the strictly ascending
+    // fmaf sum over its taps (arithmetic contract step 3).  Runs right after the row hand-over barrier on the
+    // lowest lanes.  Samples come from the channel's plane, weights from the output's (de-duplicated) row, both as
+    // aligned 16-byte LDS reads of 4 taps; the first group may begin with +0 weights (columns before the first tap),
+    // the last group is predicated on the number of valid taps.
+    const uint32_t n_chain = n_u * C;
+    auto h_run_row = [&](const float* vrow, float* orow) {
+        for (uint32_t idx = tid; idx < n_chain; idx += T) {
+            const uint32_t ul = idx / C, c = idx - ul * C;
+            const uint4 m = hmeta[ul];
+            const float4* sp = reinterpret_cast<const float4*>(vrow + c * plane_pitch + m.x);
+            const float4* wp = reinterpret_cast<const float4*>((WLDS ? hw_lds : a.h_wu) + m.z);
+            const uint32_t last = m.y - 1u;
+            float h = 0.0f;
+#pragma unroll 2
+            for (uint32_t q = 0; q < last; ++q) {
+                const float4 w = wp[q];
+                const float4 x = sp[q];
+                h = __builtin_fmaf(w.x, x.x, h);
+                h = __builtin_fmaf(w.y, x.y, h);
+                h = __builtin_fmaf(w.z, x.z, h);
+                h = __builtin_fmaf(w.w, x.w, h);
+            }
+            {
+                const float4 w = wp[last];
+                const float4 x = sp[last];
+                h = __builtin_fmaf(w.x, x.x, h);
+                if (m.w > 1u) h = __builtin_fmaf(w.y, x.y, h);
+                if (m.w > 2u) h = __builtin_fmaf(w.z, x.z, h);
+                if (m.w > 3u) h = __builtin_fmaf(w.w, x.w, h);
+            }
+            orow[ul * 4u + c] = h;
+        }
+    };
+    int h_out_row = -1;              // output row whose horizontal result is waiting in obuf (uniform), -1: none
+    auto h_store_row = [&](uint32_t j, const float* orow) {      // output stage of a horizontally filtered row
+        // the lanes at the top of the workgroup take it: the chains sit on the lowest lanes
+        for (uint32_t ul = T - 1u - tid; ul < n_u; ul += T) {
+            const float4 o = *reinterpret_cast<const float4*>(orow + ul * 4u);
+            const OutTables<BankedLut, ThresholdL2S> tb{lut, ThresholdL2S{thr, l2s_lds}};
+            store_pixel<ALPHA>(a, img, j, strip.u0 + ul, o.x, o.y, o.z, ALPHA ? o.w : 1.0f, tb);
         }
     };
 
@@ -296,27 +356,22 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                 }
             }
 #endif
-
 #if defined(IFHIP_EXP_NO_H)        // experiment: vertical pass only (NOT a product path)
             if (st.flush_slot >= 0 && st.out_row == 0x7fffffff) {
 #else
             if (st.flush_slot >= 0) {
 #endif
-                // ---- hand the finished vertically-filtered row to the horizontal pass through LDS ----
+                // ---- output row j's vertical pass is complete: hand its row to the horizontal pass ----
+                const uint32_t j = static_cast<uint32_t>(st.out_row);
+                float* dst_row = inter + (j & 1u) * inter_stride;
 #pragma unroll
                 for (int s = 0; s < K; ++s) {
                     if (st.flush_slot == s) {
                         if (lane_on) {
-                            float4* dstp = reinterpret_cast<float4*>(inter + static_cast<size_t>(tid) * (4 * C));
-                            if (ALPHA) {
 #pragma unroll
-                                for (int p = 0; p < 4; ++p)
-                                    dstp[p] = make_float4(acc[s][p][0], acc[s][p][1], acc[s][p][2], acc[s][p][C - 1]);
-                            } else {
-                                dstp[0] = make_float4(acc[s][0][0], acc[s][0][1], acc[s][0][2], acc[s][1][0]);
-                                dstp[1] = make_float4(acc[s][1][1], acc[s][1][2], acc[s][2][0], acc[s][2][1]);
-                                dstp[2] = make_float4(acc[s][2][2], acc[s][3][0], acc[s][3][1], acc[s][3][2]);
-                            }
+                            for (int c = 0; c < C; ++c)
+                                *reinterpret_cast<float4*>(dst_row + c * plane_pitch + 4u * tid) =
+                                    make_float4(acc[s][0][c], acc[s][1][c], acc[s][2][c], acc[s][3][c]);
                         }
 #pragma unroll
                         for (int p = 0; p < 4; ++p)
@@ -324,43 +379,25 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                             for (int c = 0; c < C; ++c) acc[s][p][c] = 0.0f;
                     }
                 }
+                // One barrier per output row.  After it: row j's vertical result (inter[j&1]) and row j-1's horizontal
+                // result (obuf[(j-1)&1]) are complete.  inter[j&1] is next written at row j+2 and obuf[(j-1)&1] by
+                // row j+1's chains, both only after every wave has passed the barrier of row j+1, i.e. after every
+                // wave has finished reading them.
                 lds_barrier();
-                const uint32_t j = static_cast<uint32_t>(st.out_row);
-                const uint32_t n_chain = n_u * C;
-                for (uint32_t idx = tid; idx < n_chain; idx += T) {
-                    const uint32_t ul = idx / C, c = idx - ul * C;
-                    const uint2 m = hmeta[ul];
-                    const float* ip = inter + static_cast<size_t>(m.x) * C + c;
-                    const float4* w4p = WLDS ? (hw_lds + static_cast<size_t>(ul) * (tpad >> 2))
-                                             : (hw_src + static_cast<size_t>(ul) * (tpad >> 2));
-                    const uint32_t n = m.y;
-                    float h = 0.0f;
-                    uint32_t k = 0;
-#pragma unroll 4
-                    for (; k + 4u <= n; k += 4u) {
-                        const float4 w = w4p[k >> 2];
-                        const float i0 = ip[(k + 0u) * C], i1 = ip[(k + 1u) * C], i2 = ip[(k + 2u) * C], i3 = ip[(k + 3u) * C];
-                        h = __builtin_fmaf(w.x, i0, h);
-                        h = __builtin_fmaf(w.y, i1, h);
-                        h = __builtin_fmaf(w.z, i2, h);
-                        h = __builtin_fmaf(w.w, i3, h);
-                    }
-                    if (k < n) {
-                        const float4 w = w4p[k >> 2];
-                        h = __builtin_fmaf(w.x, ip[k * C], h);
-                        if (k + 1u < n) h = __builtin_fmaf(w.y, ip[(k + 1u) * C], h);
-                        if (k + 2u < n) h = __builtin_fmaf(w.z, ip[(k + 2u) * C], h);
-                    }
-                    reinterpret_cast<float*>(obuf)[ul * 4u + c] = h;
-                }
-                lds_barrier();
-                for (uint32_t ul = tid; ul < n_u; ul += T) {
-                    const float4 o = obuf[ul];
-                    const OutTables<BankedLut, ThresholdL2S> tb{lut, ThresholdL2S{thr}};
-                    store_pixel<ALPHA>(a, img, j, strip.u0 + ul, o.x, o.y, o.z, ALPHA ? o.w : 1.0f, tb);
-                }
+#if !defined(IFHIP_EXP_NO_STORE)
+                if (h_out_row >= 0) h_store_row(static_cast<uint32_t>(h_out_row), obuf + (static_cast<uint32_t>(h_out_row) & 1u) * obuf_stride);
+#endif
+                h_out_row = static_cast<int>(j);
+#if !defined(IFHIP_EXP_NO_CHAIN)
+                h_run_row(dst_row, obuf + (j & 1u) * obuf_stride);
+#endif
             }
         }
+    }
+    // drain: the last output row of the band still has its horizontal pass and output stage to do
+    if (h_out_row >= 0) {
+        lds_barrier();
+        h_store_row(static_cast<uint32_t>(h_out_row), obuf + (static_cast<uint32_t>(h_out_row) & 1u) * obuf_stride);
     }
 }
 
