@@ -236,7 +236,12 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
 
     auto fetch_row = [&](int y) -> uint4 {                               // y is wave-uniform; -1 = nothing needed
         const uint32_t yy = y < 0 ? 0u : static_cast<uint32_t>(y);      // (row 0 is re-read: stays in L2)
-        return *reinterpret_cast<const uint4*>(src + static_cast<size_t>(yy) * a.in_stride);
+        const uint4* p = reinterpret_cast<const uint4*>(src + static_cast<size_t>(yy) * a.in_stride);
+        // source frames are streamed exactly once: non-temporal loads keep them from displacing the tables in L2
+        // (measured -1.7% kernel time, profiles/r1_notes.md)
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        return make_uint4(t.x, t.y, t.z, t.w);
     };
 
     // sample -> working float for the 4 pixels of one 16-byte load (arithmetic contract step 1)
