@@ -89,8 +89,8 @@ def cpu_baseline(sample_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (default 256 = BASELINE config 2)")
     ap.add_argument("--pattern", default="mixed", choices=["mixed", "gradient", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -169,6 +169,13 @@ def main():
         value = mp_per_step * args.steps / elapsed
         algo_bytes = n * ALGO_BYTES_PER_FRAME
         achieved = algo_bytes / (kernel_ms * 1e-3)
+        traffic = None          # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/), if recorded
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "traffic_cfg2.json")))
+            if n == FRAMES_PER_GPU:
+                traffic = t["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "megapixels/sec resize (4K->200px Robidoux)", "value": round(value, 1), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -179,7 +186,7 @@ def main():
                        "frames_per_gpu": n, "kernel": "fused_resample_kernel" if plan.kernel_kind() == 0 else "generic",
                        "gather": "rccl all_gather of outputs, overlapped" if gather else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
