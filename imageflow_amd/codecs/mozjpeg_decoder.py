@@ -1,0 +1,85 @@
+"""Host mirror of the pixel half of MozJpegDecoder::read_frame (imageflow_core/src/codecs/mozjpeg_decoder.rs:295-420):
+what libjpeg does after entropy decoding -- de-quantise, islow IDCT, fancy chroma up-sampling, YCbCr -> BGRA
+(out_color_space = JCS_EXT_BGRA) -- runs in libimageflow_hip.so on frames that stay in HBM.
+The Huffman pass stays on the host (mozjpeg's jpeg_read_coefficients in the reference integration)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _native
+from ..graphics.bitmaps import Bitmap, get_stride
+
+
+def _bind():
+    L = _native.lib()
+    if getattr(L, "_jpeg_bound", False):
+        return L
+    L.ifhip_jpeg_idct_color.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.ifhip_jpeg_stage_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_uint32]
+    L.ifhip_jpeg_stage_destroy.argtypes = [C.c_void_p]
+    L.ifhip_jpeg_stage_destroy.restype = None
+    L.ifhip_jpeg_stage_block_dims.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ifhip_jpeg_idct_color_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                     C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+    L._jpeg_bound = True
+    return L
+
+
+class JpegPixelStage:
+    """ifhip_jpeg_stage: geometry + the component planes between the IDCT and the colour kernel."""
+
+    def __init__(self, width, height, n_components, h_samp, v_samp, max_images, device="cuda:0"):
+        L = _bind()
+        self.width, self.height, self.n = width, height, n_components
+        self.device = torch.device(device)
+        self._h = C.c_void_p()
+        hs = np.array(list(h_samp)[:3] + [0] * (3 - len(h_samp)), np.uint8)
+        vs = np.array(list(v_samp)[:3] + [0] * (3 - len(v_samp)), np.uint8)
+        with torch.cuda.device(self.device):
+            _native.check(L.ifhip_jpeg_stage_create(C.byref(self._h), width, height, n_components, hs.ctypes.data,
+                                                    vs.ctypes.data, max_images))
+        bw, bh = np.zeros(3, np.uint32), np.zeros(3, np.uint32)
+        _native.check(L.ifhip_jpeg_stage_block_dims(self._h, bw.ctypes.data, bh.ctypes.data))
+        self.blocks_w, self.blocks_h = [int(v) for v in bw], [int(v) for v in bh]
+
+    def read_frames(self, coef, qt, out: Bitmap = None):
+        """coef: list of int16 cuda tensors [n, bh_c, bw_c, 64]; qt: uint16 cuda tensor [n, ncomp, 64] (as int16 storage).
+        Returns a Bitmap of n BGRA frames (alpha not meaningful, as MozJpegDecoder::read_frame creates it, :101-123)."""
+        L = _bind()
+        n = coef[0].shape[0]
+        if out is None:
+            out = Bitmap.create_u8(n, self.width, self.height, self.device, alpha_meaningful=False)
+        ptr = [coef[c].data_ptr() if c < self.n else None for c in range(3)]
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _native.check(L.ifhip_jpeg_idct_color_batch_device(self._h, ptr[0], ptr[1], ptr[2], qt.data_ptr(), n,
+                                                               out.data.data_ptr(), out.image_bytes, out.stride,
+                                                               C.c_void_p(stream)))
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                _bind().ifhip_jpeg_stage_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def jpeg_idct_color_host(coef, qt, n_components, h_samp, v_samp, width, height, stride=None):
+    """Host-buffer drop-in (numpy): coef = list of int16 arrays [bh][bw][64], qt = uint16 [ncomp][64] -> BGRA rows."""
+    L = _bind()
+    stride = stride or get_stride(width)
+    out = np.zeros((height, stride), np.uint8)
+    hs = np.array(list(h_samp)[:3], np.uint8)
+    vs = np.array(list(v_samp)[:3], np.uint8)
+    p = [np.ascontiguousarray(coef[c]).ctypes.data if c < n_components else None for c in range(3)]
+    keep = [np.ascontiguousarray(coef[c]) for c in range(n_components)]
+    p = [keep[c].ctypes.data if c < n_components else None for c in range(3)]
+    q = np.ascontiguousarray(qt[:n_components], np.uint16)
+    _native.check(L.ifhip_jpeg_idct_color(p[0], p[1], p[2], q.ctypes.data, n_components, hs.ctypes.data, vs.ctypes.data,
+                                          width, height, out.ctypes.data, stride))
+    return out

@@ -1,0 +1,362 @@
+// jpeg_kernels.hip -- gfx950 kernels + C ABI for the JPEG pixel stage.
+//
+// Replaces the arithmetic libjpeg runs between entropy decoding and scanline output when imageflow decodes a JPEG
+// (codecs/mozjpeg_decoder.rs:295-420 with dct_method = JDCT_ISLOW, do_fancy_upsampling = TRUE,
+// out_color_space = JCS_EXT_BGRA): de-quantisation + 8x8 "islow" IDCT, triangle chroma up-sampling, fixed-point
+// YCbCr -> BGRA.  All integer; bit-exact against oracle/jpeg_oracle.c (which is pinned to libjpeg-turbo's decode).
+//
+// Two kernels (bound: HBM; byte work, no MFMA):
+//   jpeg_idct_kernel      8 lanes per 8x8 block, 32 blocks per workgroup.  A wave reads 8 consecutive blocks = 1 KiB of
+//                         coefficients fully coalesced (16 B per lane), de-quantises into an LDS workspace (block
+//                         pitch 72 dwords -> conflict-free column reads), runs the column pass (lane = column) and the
+//                         row pass (lane = row) and stores 8 bytes per lane into the component plane.
+//   jpeg_color_kernel     one lane per output pixel: Y + the (up to 4+4) chroma samples of the fancy up-sampler from
+//                         L1/L2, 4-byte coalesced BGRA stores.
+// Algorithmic bytes per 4:2:0 pixel: 3 B coefficients + 4 B BGRA (+ 1.5 B written and re-read for the planes).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+
+#include "common.hpp"
+
+namespace ifhip {
+
+struct JpegGeom {
+    uint32_t width, height;
+    int ncomp;
+    uint32_t hs[3], vs[3];
+    uint32_t hmax, vmax;
+    uint32_t bw[3], bh[3];          // blocks per row / column (MCU padded)
+    uint32_t pw[3], ph[3];          // plane width / height in samples (= 8 * blocks)
+    uint32_t dw[3], dh[3];          // libjpeg downsampled_width / downsampled_height
+    uint32_t blocks_before[4];      // prefix sums of bw*bh over components
+};
+
+struct JpegArgs {
+    JpegGeom g;
+    const int16_t* coef[3];
+    const uint16_t* qt;             // [n_images][ncomp][64]
+    uint8_t* plane[3];              // [n_images][ph][pw]
+    uint8_t* bgra;
+    size_t image_bytes;
+    uint32_t stride;
+    uint32_t n_images;
+};
+
+// ---- IDCT ("islow": 13-bit fixed point, 12-multiply factorisation; ITU T.81 A.3.3 + the IJG constants) ----------
+__device__ __forceinline__ int32_t descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+__device__ __forceinline__ uint32_t range_limit(int32_t v) {   // libjpeg post-IDCT table, index (v & 1023)
+    const uint32_t i = static_cast<uint32_t>(v) & 1023u;
+    return i < 128u ? i + 128u : (i < 512u ? 255u : (i < 896u ? 0u : i - 896u));
+}
+
+// one 8-point pass; in[] are the 8 inputs, sh the descale amount; out via callback-free arrays
+__device__ __forceinline__ void idct8(const int32_t (&in)[8], int32_t (&out)[8], int sh) {
+    constexpr int32_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633,
+                      F1_501 = 12299, F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+    int32_t z2 = in[2], z3 = in[6];
+    int32_t z1 = (z2 + z3) * F0_541;
+    int32_t tmp2 = z1 + z3 * (-F1_847);
+    int32_t tmp3 = z1 + z2 * F0_765;
+    int32_t tmp0 = static_cast<int32_t>(static_cast<uint32_t>(in[0] + in[4]) << 13);
+    int32_t tmp1 = static_cast<int32_t>(static_cast<uint32_t>(in[0] - in[4]) << 13);
+    const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    int32_t z4 = tmp1 + tmp3;
+    const int32_t z5 = (z3 + z4) * F1_175;
+    tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
+    z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    out[0] = descale(tmp10 + tmp3, sh); out[7] = descale(tmp10 - tmp3, sh);
+    out[1] = descale(tmp11 + tmp2, sh); out[6] = descale(tmp11 - tmp2, sh);
+    out[2] = descale(tmp12 + tmp1, sh); out[5] = descale(tmp12 - tmp1, sh);
+    out[3] = descale(tmp13 + tmp0, sh); out[4] = descale(tmp13 - tmp0, sh);
+}
+
+constexpr int kBlocksPerWg = 32;
+constexpr int kBlockPitch = 72;     // dwords per 8x8 workspace in LDS (64 + 8: spreads 4 blocks over the 32 banks)
+
+__global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
+    __shared__ int32_t ws[kBlocksPerWg * kBlockPitch];
+    const uint32_t t = threadIdx.x, lane8 = t & 7u, lb = t >> 3;
+    const uint32_t per_image = a.g.blocks_before[a.g.ncomp];
+    const uint64_t gb = static_cast<uint64_t>(blockIdx.x) * kBlocksPerWg + lb;
+    const uint64_t total = static_cast<uint64_t>(per_image) * a.n_images;
+    const bool on = gb < total;
+    uint32_t img = 0, c = 0, bidx = 0;
+    if (on) {
+        img = static_cast<uint32_t>(gb / per_image);
+        const uint32_t r = static_cast<uint32_t>(gb - static_cast<uint64_t>(img) * per_image);
+        c = (a.g.ncomp > 1 && r >= a.g.blocks_before[1]) ? ((r >= a.g.blocks_before[2]) ? 2u : 1u) : 0u;
+        bidx = r - a.g.blocks_before[c];
+    }
+    int32_t* w = ws + lb * kBlockPitch;
+    if (on) {
+        const uint32_t nblk = a.g.bw[c] * a.g.bh[c];
+        const int16_t* src = a.coef[c] + (static_cast<size_t>(img) * nblk + bidx) * 64u + lane8 * 8u;
+        const uint16_t* q = a.qt + (static_cast<size_t>(img) * a.g.ncomp + c) * 64u + lane8 * 8u;
+        const uint4 cv = *reinterpret_cast<const uint4*>(src);          // row lane8 of the block: 8 x int16
+        const uint4 qv = *reinterpret_cast<const uint4*>(q);
+        const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int32_t c0 = static_cast<int16_t>(cw[k] & 0xffffu), c1 = static_cast<int16_t>(cw[k] >> 16);
+            const int32_t q0 = static_cast<int32_t>(qw[k] & 0xffffu), q1 = static_cast<int32_t>(qw[k] >> 16);
+            w[lane8 * 8u + 2 * k] = c0 * q0;
+            w[lane8 * 8u + 2 * k + 1] = c1 * q1;
+        }
+    }
+    __syncthreads();
+    if (on) {                                   // column pass: lane8 = column (CONST_BITS - PASS1_BITS = 11)
+        int32_t in[8], out[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) in[r] = w[r * 8 + lane8];
+        idct8(in, out, 11);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) w[r * 8 + lane8] = out[r];
+    }
+    __syncthreads();
+    if (on) {                                   // row pass: lane8 = row (CONST_BITS + PASS1_BITS + 3 = 18)
+        int32_t in[8], out[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) in[k] = w[lane8 * 8u + k];
+        idct8(in, out, 18);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo |= range_limit(out[k]) << (8 * k);
+            hi |= range_limit(out[4 + k]) << (8 * k);
+        }
+        const uint32_t by = bidx / a.g.bw[c], bx = bidx - by * a.g.bw[c];
+        uint8_t* dst = a.plane[c] + static_cast<size_t>(img) * a.g.pw[c] * a.g.ph[c]
+                       + static_cast<size_t>(by * 8u + lane8) * a.g.pw[c] + bx * 8u;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+    }
+}
+
+// ---- up-sample + colour ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t chroma_at(const uint8_t* p, uint32_t pw, uint32_t dw, uint32_t dh, int32_t x, int32_t y) {
+    x = x < 0 ? 0 : (x >= static_cast<int32_t>(dw) ? static_cast<int32_t>(dw) - 1 : x);   // edge duplication (jdmainct.c)
+    y = y < 0 ? 0 : (y >= static_cast<int32_t>(dh) ? static_cast<int32_t>(dh) - 1 : y);
+    return p[static_cast<size_t>(y) * pw + static_cast<size_t>(x)];
+}
+
+__device__ __forceinline__ uint32_t clamp255(int32_t v) { return static_cast<uint32_t>(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+__global__ void __launch_bounds__(256) jpeg_color_kernel(const JpegArgs a) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
+    if (x >= a.g.width) return;
+    const uint8_t* py = a.plane[0] + static_cast<size_t>(img) * a.g.pw[0] * a.g.ph[0];
+    const int32_t Y = py[static_cast<size_t>(y) * a.g.pw[0] + x];
+    uint32_t out;
+    if (a.g.ncomp == 1) {
+        out = static_cast<uint32_t>(Y) * 0x010101u | 0xff000000u;
+    } else {
+        int32_t v[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = 1 + k;
+            const uint8_t* P = a.plane[c] + static_cast<size_t>(img) * a.g.pw[c] * a.g.ph[c];
+            const uint32_t W = a.g.pw[c], DW = a.g.dw[c], DH = a.g.dh[c];
+            if (a.g.hmax == 1 && a.g.vmax == 1) {
+                v[k] = P[static_cast<size_t>(y) * W + x];
+            } else if (a.g.vmax == 1) {                                   // h2v1 fancy
+                const int32_t cx = static_cast<int32_t>(x >> 1), far = (x & 1u) ? cx + 1 : cx - 1, bias = (x & 1u) ? 2 : 1;
+                v[k] = (3 * chroma_at(P, W, DW, DH, cx, static_cast<int32_t>(y))
+                        + chroma_at(P, W, DW, DH, far, static_cast<int32_t>(y)) + bias) >> 2;
+            } else {                                                      // h2v2 fancy
+                const int32_t cx = static_cast<int32_t>(x >> 1), cy = static_cast<int32_t>(y >> 1);
+                const int32_t ny = (y & 1u) ? cy + 1 : cy - 1;
+                const int32_t thiscol = 3 * chroma_at(P, W, DW, DH, cx, cy) + chroma_at(P, W, DW, DH, cx, ny);
+                if ((x & 1u) == 0) {
+                    if (cx == 0) v[k] = (thiscol * 4 + 8) >> 4;
+                    else {
+                        const int32_t last = 3 * chroma_at(P, W, DW, DH, cx - 1, cy) + chroma_at(P, W, DW, DH, cx - 1, ny);
+                        v[k] = (thiscol * 3 + last + 8) >> 4;
+                    }
+                } else {
+                    if (cx == static_cast<int32_t>(DW) - 1) v[k] = (thiscol * 4 + 7) >> 4;
+                    else {
+                        const int32_t next = 3 * chroma_at(P, W, DW, DH, cx + 1, cy) + chroma_at(P, W, DW, DH, cx + 1, ny);
+                        v[k] = (thiscol * 3 + next + 7) >> 4;
+                    }
+                }
+            }
+        }
+        const int32_t cb = v[0] - 128, cr = v[1] - 128;                    // jdcolor.c tables, evaluated in place
+        const int32_t r = Y + ((91881 * cr + 32768) >> 16);
+        const int32_t g = Y + ((-22554 * cb + 32768 + (-46802) * cr) >> 16);
+        const int32_t b = Y + ((116130 * cb + 32768) >> 16);
+        out = clamp255(b) | (clamp255(g) << 8) | (clamp255(r) << 16) | 0xff000000u;
+    }
+    uint32_t* dst = reinterpret_cast<uint32_t*>(a.bgra + static_cast<size_t>(img) * a.image_bytes + static_cast<size_t>(y) * a.stride) + x;
+    *dst = out;
+}
+
+}  // namespace ifhip
+
+// ==================================================================================================================
+using namespace ifhip;
+
+struct ifhip_jpeg_stage {
+    int device = -1;
+    JpegGeom g;
+    uint32_t max_images = 0;
+    uint8_t* planes[3] = {nullptr, nullptr, nullptr};
+    ~ifhip_jpeg_stage() { for (auto* p : planes) if (p) (void)hipFree(p); }
+};
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(IFHIP_GPU_ERROR, "GpuError: %s failed: %s", #expr, hipGetErrorString(e__));     \
+    } while (0)
+
+static int make_geom(uint32_t width, uint32_t height, int ncomp, const uint8_t* hs, const uint8_t* vs, JpegGeom* g) {
+    if (width == 0 || height == 0) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: Bitmap dimensions cannot be zero");
+    if (ncomp != 1 && ncomp != 3) return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: %d-component JPEG", ncomp);
+    std::memset(g, 0, sizeof *g);
+    g->width = width; g->height = height; g->ncomp = ncomp; g->hmax = g->vmax = 1;
+    for (int c = 0; c < ncomp; ++c) {
+        g->hs[c] = (ncomp == 1) ? 1u : hs[c]; g->vs[c] = (ncomp == 1) ? 1u : vs[c];
+        if (g->hs[c] < 1 || g->hs[c] > 2 || g->vs[c] < 1 || g->vs[c] > 2)
+            return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: sampling factor %ux%u", g->hs[c], g->vs[c]);
+        g->hmax = g->hs[c] > g->hmax ? g->hs[c] : g->hmax;
+        g->vmax = g->vs[c] > g->vmax ? g->vs[c] : g->vmax;
+    }
+    if (ncomp == 3) {
+        const bool chroma_1x1 = g->hs[1] == 1 && g->vs[1] == 1 && g->hs[2] == 1 && g->vs[2] == 1;
+        const bool luma_max = g->hs[0] == g->hmax && g->vs[0] == g->vmax;
+        if (!chroma_1x1 || !luma_max || (g->hmax == 1 && g->vmax == 2))
+            return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: only 4:4:4, 4:2:2 (h2v1) and 4:2:0 sampling");
+    }
+    const uint32_t mw = (width + 8u * g->hmax - 1u) / (8u * g->hmax), mh = (height + 8u * g->vmax - 1u) / (8u * g->vmax);
+    g->blocks_before[0] = 0;
+    for (int c = 0; c < ncomp; ++c) {
+        g->bw[c] = mw * g->hs[c]; g->bh[c] = mh * g->vs[c];
+        g->pw[c] = g->bw[c] * 8u; g->ph[c] = g->bh[c] * 8u;
+        g->dw[c] = (width * g->hs[c] + g->hmax - 1u) / g->hmax;
+        g->dh[c] = (height * g->vs[c] + g->vmax - 1u) / g->vmax;
+        g->blocks_before[c + 1] = g->blocks_before[c] + g->bw[c] * g->bh[c];
+    }
+    return IFHIP_OK;
+}
+
+extern "C" {
+
+int ifhip_jpeg_stage_create(ifhip_jpeg_stage** stage, uint32_t width, uint32_t height, int n_components,
+                            const uint8_t* h_samp, const uint8_t* v_samp, uint32_t max_images) {
+    if (!stage) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null stage out-pointer");
+    *stage = nullptr;
+    if (max_images == 0 || (n_components == 3 && (!h_samp || !v_samp)))
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: jpeg stage needs sampling factors and max_images >= 1");
+    std::unique_ptr<ifhip_jpeg_stage> s(new ifhip_jpeg_stage);
+    int rc = make_geom(width, height, n_components, h_samp, v_samp, &s->g);
+    if (rc) return rc;
+    if (s->g.height > 65535u || max_images > 65535u) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: more than 65535 rows/images per launch");
+    if (hipGetDevice(&s->device) != hipSuccess)
+        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device; this library has no CPU path");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: device %d is %s, this library is built for gfx950 only", s->device, prop.gcnArchName);
+    s->max_images = max_images;
+    for (int c = 0; c < n_components; ++c)
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->planes[c]), static_cast<size_t>(s->g.pw[c]) * s->g.ph[c] * max_images));
+    *stage = s.release();
+    return IFHIP_OK;
+}
+
+void ifhip_jpeg_stage_destroy(ifhip_jpeg_stage* stage) { delete stage; }
+
+int ifhip_jpeg_stage_block_dims(const ifhip_jpeg_stage* stage, uint32_t* blocks_w3, uint32_t* blocks_h3) {
+    if (!stage || !blocks_w3 || !blocks_h3) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
+    for (int c = 0; c < 3; ++c) { blocks_w3[c] = c < stage->g.ncomp ? stage->g.bw[c] : 0; blocks_h3[c] = c < stage->g.ncomp ? stage->g.bh[c] : 0; }
+    return IFHIP_OK;
+}
+
+int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d_coef0, const int16_t* d_coef1,
+                                       const int16_t* d_coef2, const uint16_t* d_qt, uint32_t n_images,
+                                       uint8_t* d_bgra, size_t image_bytes, uint32_t stride, void* hip_stream) {
+    if (!stage) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null stage");
+    if (n_images == 0) return IFHIP_OK;
+    if (n_images > stage->max_images) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: %u images exceed the stage capacity %u", n_images, stage->max_images);
+    if (!d_coef0 || !d_qt || !d_bgra || (stage->g.ncomp == 3 && (!d_coef1 || !d_coef2)))
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null coefficient / table / bitmap pointer");
+    if (static_cast<uint64_t>(stage->g.width) * 4u > stride || (stride & 3u) || (image_bytes & 3u) || (reinterpret_cast<uintptr_t>(d_bgra) & 3u))
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: BGRA rows must be 4-byte aligned and stride >= 4*w");
+    if ((reinterpret_cast<uintptr_t>(d_coef0) | reinterpret_cast<uintptr_t>(d_coef1) | reinterpret_cast<uintptr_t>(d_coef2)
+         | reinterpret_cast<uintptr_t>(d_qt)) & 15u)
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: coefficient planes and quantisation tables must be 16-byte aligned");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != stage->device) return fail(IFHIP_INVALID_STATE, "InvalidState: stage belongs to device %d, current device is %d", stage->device, dev);
+    JpegArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.g = stage->g;
+    a.coef[0] = d_coef0; a.coef[1] = d_coef1; a.coef[2] = d_coef2;
+    a.qt = d_qt;
+    for (int c = 0; c < 3; ++c) a.plane[c] = stage->planes[c];
+    a.bgra = d_bgra; a.image_bytes = image_bytes; a.stride = stride; a.n_images = n_images;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const uint64_t total_blocks = static_cast<uint64_t>(a.g.blocks_before[a.g.ncomp]) * n_images;
+    const uint64_t wgs = (total_blocks + kBlocksPerWg - 1) / kBlocksPerWg;
+    if (wgs > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3(static_cast<uint32_t>(wgs)), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((a.g.width + 255u) / 256u, a.g.height, n_images), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return IFHIP_OK;
+}
+
+int ifhip_jpeg_idct_color(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2, const uint16_t* qt,
+                          int n_components, const uint8_t* h_samp, const uint8_t* v_samp, uint32_t width,
+                          uint32_t height, uint8_t* bgra, uint32_t stride) {
+    JpegGeom g;
+    int rc = make_geom(width, height, n_components, h_samp, v_samp, &g);
+    if (rc) return rc;
+    if (!coef0 || !qt || !bgra || (n_components == 3 && (!coef1 || !coef2)))
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null coefficient / table / bitmap pointer");
+    if (static_cast<uint64_t>(width) * 4u > stride || (stride & 3u))
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: stride smaller than a BGRA row or not a multiple of 4");
+    ifhip_jpeg_stage* stage = nullptr;
+    rc = ifhip_jpeg_stage_create(&stage, width, height, n_components, h_samp, v_samp, 1);
+    if (rc) return rc;
+    std::unique_ptr<ifhip_jpeg_stage> guard(stage);
+    const int16_t* hc[3] = {coef0, coef1, coef2};
+    int16_t* dc[3] = {nullptr, nullptr, nullptr};
+    uint16_t* dq = nullptr;
+    uint8_t* dout = nullptr;
+    const size_t out_bytes = static_cast<size_t>(height) * stride;
+    hipError_t e = hipSuccess;
+    for (int c = 0; c < n_components && e == hipSuccess; ++c) {
+        const size_t bytes = static_cast<size_t>(g.bw[c]) * g.bh[c] * 128u;
+        e = hipMalloc(reinterpret_cast<void**>(&dc[c]), bytes);
+        if (e == hipSuccess) e = hipMemcpy(dc[c], hc[c], bytes, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dq), 128u * n_components);
+    if (e == hipSuccess) e = hipMemcpy(dq, qt, 128u * n_components, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dout), out_bytes);
+    if (e == hipSuccess) e = hipMemcpy(dout, bgra, static_cast<size_t>(height - 1) * stride + static_cast<size_t>(width) * 4u, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = ifhip_jpeg_idct_color_batch_device(stage, dc[0], dc[1], dc[2], dq, 1, dout, out_bytes, stride, nullptr);
+        if (rc == IFHIP_OK) {
+            e = hipStreamSynchronize(nullptr);
+            if (e == hipSuccess)
+                e = hipMemcpy(bgra, dout, static_cast<size_t>(height - 1) * stride + static_cast<size_t>(width) * 4u, hipMemcpyDeviceToHost);
+        }
+    }
+    for (auto* p : dc) if (p) (void)hipFree(p);
+    if (dq) (void)hipFree(dq);
+    if (dout) (void)hipFree(dout);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(IFHIP_GPU_ERROR, "GpuError: jpeg stage staging failed: %s", hipGetErrorString(e));
+    return IFHIP_OK;
+}
+
+}  // extern "C"

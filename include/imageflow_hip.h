@@ -140,6 +140,36 @@ IFHIP_API int ifhip_apply_matte_batch_device(uint8_t* d_bgra, size_t image_bytes
                                              uint32_t w, uint32_t h, uint32_t stride, int alpha_meaningful,
                                              uint32_t matte_bgra, void* hip_stream);
 
+/* ---- Inner C: JPEG pixel stage ------------------------------------------------------------------------- */
+/*
+ * Replaces what libjpeg does between entropy decoding and the scanline hand-over inside MzDec::read_frame
+ * (codecs/mozjpeg_decoder.rs:295-420, wrap_jpeg_read_scan_lines codec_jpeg_wrapper.c:203-212): de-quantisation,
+ * the islow 8x8 IDCT, "fancy" chroma up-sampling (h2v1 / h2v2) and YCbCr -> BGRA (out_color_space = JCS_EXT_BGRA,
+ * :320; alpha bytes 255).  A GPU stage cannot be libjpeg's per-block IDCT callback, so the boundary is
+ * "coefficient planes in, BGRA8 64-byte-stride bitmap out": the host keeps mozjpeg for the (serial) Huffman pass and
+ * hands over what jpeg_read_coefficients() returns.
+ *   coef[c]   int16 [blocks_h_c][blocks_w_c][64], natural (de-zigzagged) order, quantised;
+ *             blocks_w_c = ceil(width / (8*hmax)) * h_samp[c], blocks_h_c likewise (MCU padded, as libjpeg's arrays)
+ *   qt        uint16 [n_components][64], natural order (JQUANT_TBL.quantval)
+ * Supported sampling: grayscale, 4:4:4, 4:2:2 (h2v1), 4:2:0 (h2v2).  Full-size decode (scale_num = 8) only.
+ */
+IFHIP_API int ifhip_jpeg_idct_color(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2,
+                                    const uint16_t* qt, int n_components,
+                                    const uint8_t* h_samp, const uint8_t* v_samp,
+                                    uint32_t width, uint32_t height, uint8_t* bgra, uint32_t stride);
+
+/* Device-resident batch of equally shaped frames.  The stage object owns the component planes between the two
+ * kernels.  d_coef[c]: image i at d_coef[c] + i * blocks_w_c*blocks_h_c*64; d_qt: [n_images][n_components][64]. */
+typedef struct ifhip_jpeg_stage ifhip_jpeg_stage;
+IFHIP_API int ifhip_jpeg_stage_create(ifhip_jpeg_stage** stage, uint32_t width, uint32_t height, int n_components,
+                                      const uint8_t* h_samp, const uint8_t* v_samp, uint32_t max_images);
+IFHIP_API void ifhip_jpeg_stage_destroy(ifhip_jpeg_stage* stage);
+IFHIP_API int ifhip_jpeg_stage_block_dims(const ifhip_jpeg_stage* stage, uint32_t* blocks_w3, uint32_t* blocks_h3);
+IFHIP_API int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d_coef0,
+                                                 const int16_t* d_coef1, const int16_t* d_coef2,
+                                                 const uint16_t* d_qt, uint32_t n_images,
+                                                 uint8_t* d_bgra, size_t image_bytes, uint32_t stride, void* hip_stream);
+
 /* ---- measurement helpers (bench.py) -------------------------------------------------------------------- */
 /* Runs `launches` back-to-back launches of the batch op on `hip_stream` bracketed by hipEvents on that stream
  * and returns the average milliseconds per launch. */

@@ -65,6 +65,15 @@ def lib():
         L.ifo_apply_matte.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
         L.ifo_stride_for_width.restype = C.c_uint32
         L.ifo_stride_for_width.argtypes = [C.c_uint32]
+        for fn in ("jo_jpeg_info", "jo_jpeg_block_dims", "jo_jpeg_read_coefficients", "jo_jpeg_idct_color", "jo_idct_islow_block"):
+            getattr(L, fn).restype = C.c_int
+        L.jo_jpeg_info.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.jo_jpeg_block_dims.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.jo_jpeg_read_coefficients.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.jo_jpeg_idct_color.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.jo_idct_islow_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.jo_idct_islow_block.restype = None
         L.ifo_init_tables()
         _LIB = L
     return _LIB
@@ -126,3 +135,50 @@ def scale_and_render_batch(inp, canvas, in_w, in_h, in_stride, cw, ch, c_stride,
 
 def apply_matte(bgra, w, h, stride, matte_bgra, alpha_meaningful=True):
     return lib().ifo_apply_matte(bgra.ctypes.data, w, h, stride, int(alpha_meaningful), matte_bgra)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# JPEG pixel stage (oracle/jpeg_oracle.c)
+# ---------------------------------------------------------------------------------------------------------
+def jpeg_read_coefficients(data: bytes):
+    """-> dict(width, height, ncomp, hs, vs, bw, bh, coef=[int16 [bh][bw][64]...], qt=uint16 [ncomp][64])"""
+    L = lib()
+    buf = np.frombuffer(data, np.uint8)
+    info = np.zeros(9, np.uint32)
+    rc = L.jo_jpeg_info(buf.ctypes.data, C.c_size_t(len(data)), info.ctypes.data)
+    if rc:
+        raise RuntimeError(f"jpeg oracle: header rc={rc}")
+    bw, bh = np.zeros(3, np.uint32), np.zeros(3, np.uint32)
+    L.jo_jpeg_block_dims(buf.ctypes.data, C.c_size_t(len(data)), bw.ctypes.data, bh.ctypes.data)
+    n = int(info[2])
+    coef = [np.zeros((int(bh[c]), int(bw[c]), 64), np.int16) if c < n else np.zeros((1, 1, 64), np.int16) for c in range(3)]
+    qt = np.zeros((3, 64), np.uint16)
+    rc = L.jo_jpeg_read_coefficients(buf.ctypes.data, C.c_size_t(len(data)), coef[0].ctypes.data, coef[1].ctypes.data,
+                                     coef[2].ctypes.data, qt.ctypes.data)
+    if rc:
+        raise RuntimeError(f"jpeg oracle: entropy decode rc={rc}")
+    return dict(width=int(info[0]), height=int(info[1]), ncomp=n, hs=[int(v) for v in info[3:6]],
+                vs=[int(v) for v in info[6:9]], bw=[int(v) for v in bw], bh=[int(v) for v in bh], coef=coef, qt=qt)
+
+
+def jpeg_idct_color(j, stride=None):
+    """coefficient planes -> BGRA8 [height][stride] (alpha 255), the oracle's full-size pixel stage."""
+    L = lib()
+    w, h = j["width"], j["height"]
+    stride = stride or stride_for_width(w)
+    out = np.zeros((h, stride), np.uint8)
+    hs = np.array(j["hs"], np.uint8)
+    vs = np.array(j["vs"], np.uint8)
+    rc = L.jo_jpeg_idct_color(j["coef"][0].ctypes.data, j["coef"][1].ctypes.data, j["coef"][2].ctypes.data,
+                              j["qt"].ctypes.data, j["ncomp"], hs.ctypes.data, vs.ctypes.data, w, h, out.ctypes.data, stride)
+    if rc:
+        raise RuntimeError(f"jpeg oracle: pixel stage rc={rc}")
+    return out
+
+
+def idct_islow_block(coef64, quant64):
+    out = np.zeros((8, 8), np.uint8)
+    c = np.ascontiguousarray(coef64, np.int16)
+    q = np.ascontiguousarray(quant64, np.uint16)
+    lib().jo_idct_islow_block(c.ctypes.data, q.ctypes.data, out.ctypes.data, 8)
+    return out
