@@ -122,6 +122,7 @@ def main():
     info = ScaleAndRenderParams(0, 0, OUT_W, OUT_H, 0.0, Filter.Robidoux)
     plan = plan_for(IN_W, IN_H, OUT_W, OUT_H, info.interpolation_filter, 0.0, dev)
     gather = distributed and not args.no_gather and os.environ.get("IFHIP_BENCH_GATHER", "1") != "0"
+    from imageflow_amd.sharding import gather_outputs, max_over_ranks
     gathered = [torch.empty((world,) + tuple(c.data.shape), dtype=torch.uint8, device=dev) for c in canv] if gather else None
 
     def step(i, pending):
@@ -131,7 +132,7 @@ def main():
             pending[i & 1] = None
         scale_and_render(inp, c, info, plan=plan)
         if gather:
-            pending[i & 1] = dist.all_gather_into_tensor(gathered[i & 1].view(-1), c.data.view(-1), async_op=True)
+            pending[i & 1], _ = gather_outputs(c.data, world * n, async_op=True, out=gathered[i & 1])
 
     def sync_all(pending):
         for k in range(2):
@@ -155,10 +156,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dev)
 
     # dominant-kernel duration: hipEvents on the launch stream around back-to-back launches of the same op
     kernel_ms = time_scale_and_render(inp, canv[0], info, launches=max(5, min(args.steps, 50)), plan=plan)

@@ -1,0 +1,58 @@
+"""Multi-GPU layout of a batch job: frames are independent, so a batch is cut into contiguous
+blocks of frames, one block per rank (one process per GPU); there is no collective on the data path.  The only
+exchange is the optional gather of the finished (small) output frames, one all_gather per batch over RCCL
+(`backend="nccl"` on ROCm) -- or gloo on CPU tensors in the tests."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_frames: int, rank: int, world: int):
+    """Frames [lo, hi) owned by `rank`: frame i lives on rank floor(i * world / n_frames) (contiguous blocks whose
+    sizes differ by at most one)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    lo = -(-rank * n_frames // world)          # ceil(rank * n / world)
+    hi = -(-(rank + 1) * n_frames // world)
+    return lo, hi
+
+
+def owner_of(frame: int, n_frames: int, world: int) -> int:
+    return frame * world // n_frames
+
+
+def gather_outputs(local: torch.Tensor, n_frames: int, group=None, async_op=False, out=None):
+    """All-gather equally shaped per-frame outputs.  `local` is [n_local, ...]; ranks may hold n_local differing by one,
+    so shards are padded to the largest shard for the collective and trimmed afterwards.
+    Returns the full [n_frames, ...] tensor (or (work, finish) when async_op, where finish() returns it)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    biggest = -(-n_frames // world)
+    lo, hi = shard_range(n_frames, rank, world)
+    assert local.shape[0] == hi - lo, (local.shape, lo, hi)
+    if local.shape[0] < biggest:
+        pad = torch.zeros((biggest - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], 0)
+    local = local.contiguous()
+    if out is None:
+        out = torch.empty((world, biggest) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out.view(-1), local.view(-1), group=group, async_op=async_op)
+
+    def finish():
+        parts = []
+        for r in range(world):
+            a, b = shard_range(n_frames, r, world)
+            parts.append(out[r, : b - a])
+        return torch.cat(parts, 0)
+
+    if async_op:
+        return work, finish
+    return finish()
+
+
+def max_over_ranks(seconds: float, device) -> float:
+    """bench.py's timing rule: the job takes as long as its slowest rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

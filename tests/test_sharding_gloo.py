@@ -1,0 +1,91 @@
+"""The N > 1 path on CPU: world_size-2 (and 3) gloo process groups exercise the frame sharding, the gather of outputs
+and bench.py's barrier / max-over-ranks timing rule.  The per-shard "compute" here is the CPU oracle (test
+infrastructure standing in for the GPU kernel, which needs a device); what is under test is the distributed layout."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from imageflow_amd.sharding import gather_outputs, max_over_ranks, owner_of, shard_range  # noqa: E402
+
+
+def test_shard_range_partitions_every_batch():
+    for n in (1, 2, 7, 8, 255, 256, 1024):
+        for world in (1, 2, 3, 4, 8):
+            if world > n:
+                continue
+            seen = []
+            for r in range(world):
+                lo, hi = shard_range(n, r, world)
+                assert hi - lo in (n // world, n // world + 1) or n % world == 0
+                seen += list(range(lo, hi))
+                for i in range(lo, hi):
+                    assert owner_of(i, n, world) == r
+            assert seen == list(range(n))
+    assert shard_range(1024, 3, 8) == (384, 512)        # BASELINE config 3: 128 frames per GPU
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from tests import util as U
+        in_w, in_h, ow, oh = 192, 108, 20, 11
+        lo, hi = shard_range(n_frames, rank, world)
+        frames = np.concatenate([U.gradient_frames(1, in_w, in_h, k0=i) for i in range(lo, hi)]) if hi > lo else \
+            np.zeros((0, in_h, U.stride_for(in_w)), np.uint8)
+        cst = U.stride_for(ow)
+        canv = np.zeros((hi - lo, oh, cst), np.uint8)
+        U.oracle_render(frames, in_w, in_h, canv, ow, oh, 0, 0, ow, oh)
+        local = torch.from_numpy(canv.reshape(hi - lo, -1))
+        dist.barrier()
+        full = gather_outputs(local, n_frames)
+        work, finish = gather_outputs(local, n_frames, async_op=True)
+        work.wait()
+        full2 = finish()
+        t = max_over_ranks(0.5 + rank, torch.device("cpu"))
+        q.put((rank, full.numpy().copy(), bool(torch.equal(full, full2)), t))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 6), (2, 5), (3, 7)])
+def test_two_rank_gloo_gather_equals_single_process(world, n_frames):
+    from oracle import oracle as O  # noqa: F401  (build the checker before forking)
+    from tests import util as U
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    in_w, in_h, ow, oh = 192, 108, 20, 11
+    frames = U.gradient_frames(n_frames, in_w, in_h)
+    exp = np.zeros((n_frames, oh, U.stride_for(ow)), np.uint8)
+    U.oracle_render(frames, in_w, in_h, exp, ow, oh, 0, 0, ow, oh)
+    for rank, full, same, t in results:
+        assert np.array_equal(full.reshape(exp.shape), exp), rank     # every rank holds the whole job's output
+        assert same
+        assert abs(t - (0.5 + world - 1)) < 1e-9                      # max over ranks
