@@ -23,6 +23,15 @@ FRAMES_PER_GPU = 256
 ALGO_BYTES_PER_FRAME = IN_W * IN_H * 4 + OUT_W * OUT_H * 4        # 33,337,600 B
 HBM_PEAK = 8.0e12                                                   # MI355X_MICROARCH.md: 8 TB/s spec
 
+# Other BASELINE shapes, selectable with --workload (parity cases; the headline line stays cfg2)
+WORKLOADS = {
+    # name: (in_w, in_h, out_w, out_h, filter, sharpen, alpha_meaningful, compositing, matte, default frames)
+    "cfg2": (3840, 2160, 200, 200, "Robidoux", 0.0, False, "ReplaceSelf", 0, 256),
+    "cfg2-alpha": (3840, 2160, 200, 200, "Robidoux", 0.0, True, "ReplaceSelf", 0, 256),
+    "cfg5": (7680, 4320, 400, 225, "Lanczos", 15.0, True, "BlendWithMatte", 0xFFFFFFFF, 64),
+    "cfg3-l0": (3840, 2160, 1600, 900, "Robidoux", 0.0, False, "ReplaceSelf", 0, 256),
+}
+
 
 def make_frames(torch, n, rank, device, pattern):
     """frame k pixel (x,y): B=(x+k)&255, G=(y+k)&255, R=(x+y+k)&255, A=255 (bench_graphics.rs:403-414 + offset);
@@ -95,12 +104,19 @@ def main():
     ap.add_argument("--pattern", default="mixed", choices=["mixed", "gradient", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     args = ap.parse_args()
+    global IN_W, IN_H, OUT_W, OUT_H, ALGO_BYTES_PER_FRAME
+    wl = WORKLOADS[args.workload]
+    IN_W, IN_H, OUT_W, OUT_H = wl[0], wl[1], wl[2], wl[3]
+    ALGO_BYTES_PER_FRAME = IN_W * IN_H * 4 + OUT_W * OUT_H * 4
+    if args.workload != "cfg2" and args.frames == FRAMES_PER_GPU:
+        args.frames = wl[9]
 
     import torch
     import torch.distributed as dist
 
-    from imageflow_amd.graphics.bitmaps import Bitmap
+    from imageflow_amd.graphics.bitmaps import Bitmap, BitmapCompositing
     from imageflow_amd.graphics.scaling import ScaleAndRenderParams, plan_for, scale_and_render, time_scale_and_render
     from imageflow_amd.graphics.weights import Filter
 
@@ -118,9 +134,12 @@ def main():
 
     n = args.frames
     inp = make_frames(torch, n, rank, dev, args.pattern)
-    canv = [Bitmap.create_u8(n, OUT_W, OUT_H, dev) for _ in range(2)]
-    info = ScaleAndRenderParams(0, 0, OUT_W, OUT_H, 0.0, Filter.Robidoux)
-    plan = plan_for(IN_W, IN_H, OUT_W, OUT_H, info.interpolation_filter, 0.0, dev)
+    inp.alpha_meaningful = wl[6]
+    if wl[6]:
+        inp.data.view(n, IN_H, -1)[:, :, 3::4] = torch.randint(0, 256, (n, IN_H, inp.stride // 4), dtype=torch.uint8, device=dev)
+    canv = [Bitmap.create_u8(n, OUT_W, OUT_H, dev, compose=BitmapCompositing[wl[7]], matte=wl[8]) for _ in range(2)]
+    info = ScaleAndRenderParams(0, 0, OUT_W, OUT_H, wl[5], Filter[wl[4]])
+    plan = plan_for(IN_W, IN_H, OUT_W, OUT_H, info.interpolation_filter, wl[5], dev)
     gather = distributed and not args.no_gather and os.environ.get("IFHIP_BENCH_GATHER", "1") != "0"
     from imageflow_amd.sharding import gather_outputs, max_over_ranks
     gathered = [torch.empty((world,) + tuple(c.data.shape), dtype=torch.uint8, device=dev) for c in canv] if gather else None
@@ -170,7 +189,7 @@ def main():
         traffic = None          # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/), if recorded
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", "traffic_cfg2.json")))
-            if n == FRAMES_PER_GPU:
+            if n == FRAMES_PER_GPU and args.workload == "cfg2":
                 traffic = t["traffic_bytes_per_launch"]
         except Exception:
             pass
@@ -179,15 +198,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8 (f32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 2: {n} x 3840x2160 BGRA8 frames per GPU -> 200x200 Robidoux, linear "
-                                   f"light, ReplaceSelf, device resident, pattern={args.pattern}",
-                       "frames_per_gpu": n, "kernel": "fused_resample_kernel" if plan.kernel_kind() == 0 else "generic",
+            "config": {"workload": f"BASELINE {args.workload}: {n} x {IN_W}x{IN_H} BGRA8 frames per GPU -> {OUT_W}x{OUT_H} {wl[4]}"
+                                   f"{' sharpen ' + str(wl[5]) if wl[5] else ''}, linear light, {wl[7]}, "
+                                   f"alpha {'meaningful' if wl[6] else 'not meaningful'}, device resident, pattern={args.pattern}",
+                       "frames_per_gpu": n, "kernel": "fused_resample_kernel" if plan.kernel_kind(wl[6]) == 0 else "generic",
                        "gather": "rccl all_gather of outputs, overlapped" if gather else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
             try:
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:   # the baseline is a report, never a reason to lose the GPU number

@@ -39,7 +39,6 @@ using namespace ifhip;
 namespace {
 
 constexpr size_t kLdsLimit = 160 * 1024;       // gfx950 LDS per CU == per-workgroup maximum
-constexpr uint32_t kMaxQuads = 1024;           // lanes per workgroup
 constexpr uint32_t kMaxStripOutputs = 2048;
 
 // ---- per-device colour tables -----------------------------------------------------------------------
@@ -111,9 +110,12 @@ struct ifhip_resample_plan {
     // fused-kernel geometry
     bool fused_possible = false;
     int slots = 0;
-    std::vector<Strip> strips;
-    Strip* d_strips = nullptr;
-    uint32_t max_quads = 0;
+    struct StripSet {                // column strips for one (alpha) variant of the fused kernel
+        std::vector<Strip> strips;
+        Strip* d_strips = nullptr;
+        uint32_t max_quads = 0;
+        bool ok = false;
+    } sets[2];                       // [in_alpha_meaningful]
     // lazily built, guarded by mu
     mutable std::mutex mu;
     mutable std::map<uint32_t, ScheduleOnDevice> schedules;
@@ -122,7 +124,8 @@ struct ifhip_resample_plan {
 
     ~ifhip_resample_plan() {
         for (void* p : {(void*)d_v_left, (void*)d_v_count, (void*)d_v_off, (void*)d_h_left, (void*)d_h_count,
-                        (void*)d_h_off, (void*)d_v_w, (void*)d_h_w, (void*)d_h_wu, (void*)d_h_meta, (void*)d_strips, (void*)scratch})
+                        (void*)d_h_off, (void*)d_v_w, (void*)d_h_w, (void*)d_h_wu, (void*)d_h_meta, (void*)sets[0].d_strips,
+                        (void*)sets[1].d_strips, (void*)scratch})
             if (p) (void)hipFree(p);
         for (auto& kv : schedules) {
             if (kv.second.steps) (void)hipFree(kv.second.steps);
@@ -138,9 +141,9 @@ size_t fused_lds_bytes(uint32_t n_u, uint32_t nquads, int channels, uint32_t wu_
     return fused_lds_layout(n_u, nquads, wu_floats, channels, w_in_lds, l2s_in_lds).total;
 }
 
-// Split the output columns into strips whose staged source span fits one workgroup (<= 1024 lanes x 4 px)
-// and whose LDS footprint (with 4 channels, the worst case) fits the CU.
-bool plan_strips(const AxisWeights& wh, std::vector<Strip>* out, uint32_t* max_quads) {
+// Split the output columns into strips whose staged source span fits one workgroup (max_lanes lanes x 4 px)
+// and whose minimal LDS footprint fits the CU.
+bool plan_strips(const AxisWeights& wh, uint32_t max_lanes, int channels, std::vector<Strip>* out, uint32_t* max_quads) {
     for (uint32_t n = 1; n <= wh.n_out; ++n) {
         std::vector<Strip> s;
         bool ok = true;
@@ -157,8 +160,8 @@ bool plan_strips(const AxisWeights& wh, std::vector<Strip>* out, uint32_t* max_q
             }
             t.cx0 = lo & ~3u;
             t.nquads = (hi - t.cx0 + 3u) / 4u;
-            if (t.nquads > kMaxQuads || (t.u1 - t.u0) > kMaxStripOutputs) ok = false;
-            if (fused_lds_bytes(t.u1 - t.u0, t.nquads, 4) > kLdsLimit) ok = false;
+            if (t.nquads > max_lanes || (t.u1 - t.u0) > kMaxStripOutputs) ok = false;
+            if (fused_lds_bytes(t.u1 - t.u0, t.nquads, channels) > kLdsLimit) ok = false;
             mq = std::max(mq, t.nquads);
             s.push_back(t);
         }
@@ -187,23 +190,23 @@ int get_schedule(const ifhip_resample_plan* p, uint32_t n_bands, ScheduleOnDevic
     return IFHIP_OK;
 }
 
-uint32_t choose_bands(const ifhip_resample_plan* p, uint32_t n_images) {
+uint32_t choose_bands(const ifhip_resample_plan* p, uint32_t n_images, size_t n_strips) {
     if (const char* e = std::getenv("IFHIP_BANDS")) {
         const int v = std::atoi(e);
         if (v >= 1) return std::min<uint32_t>(static_cast<uint32_t>(v), p->out_h);
     }
     // enough workgroups to cover 256 CUs twice over; a band re-reads its halo rows, so no more than needed
-    const uint64_t wgs = static_cast<uint64_t>(n_images) * p->strips.size();
+    const uint64_t wgs = static_cast<uint64_t>(n_images) * n_strips;
     uint32_t bands = 1;
     if (wgs < 512) bands = static_cast<uint32_t>((512 + wgs - 1) / wgs);
     const uint32_t max_bands = std::max<uint32_t>(1u, p->out_h / 4u);
     return std::max<uint32_t>(1u, std::min(bands, max_bands));
 }
 
-bool fused_usable(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride) {
-    if (!p->fused_possible) return false;
+bool fused_usable(const ifhip_resample_plan* p, int alpha, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride) {
+    if (!p->fused_possible || !p->sets[alpha ? 1 : 0].ok) return false;
     if ((reinterpret_cast<uintptr_t>(d_in) & 15u) || (in_image_bytes & 15u) || (in_stride & 15u)) return false;
-    for (const Strip& s : p->strips)
+    for (const Strip& s : p->sets[alpha ? 1 : 0].strips)
         if (static_cast<uint64_t>(s.cx0 + 4u * s.nquads) * 4u > in_stride) return false;   // 16-byte row reads stay inside the row
     return true;
 }
@@ -263,35 +266,36 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
     a.matte_a = static_cast<float>(matte >> 24) * (1.0f / 255.0f);
     a.n_images = n_images;
 
-    bool fused = fused_usable(p, d_in, in_image_bytes, in_stride);
+    bool fused = fused_usable(p, alpha, d_in, in_image_bytes, in_stride);
     if (force_kernel == 0 && !fused)
         return fail(IFHIP_INVALID_STATE, "InvalidState: fused kernel requested but its preconditions do not hold "
                     "(live rows %d > %d, or rows not 16-byte aligned / padded)", p->slots, kMaxSlots);
     if (force_kernel == 1) fused = false;
 
     if (fused) {
-        const uint32_t want_bands = choose_bands(p, n_images);
+        const ifhip_resample_plan::StripSet& ss = p->sets[alpha ? 1 : 0];
+        const uint32_t want_bands = choose_bands(p, n_images, ss.strips.size());
         ScheduleOnDevice sd;
         rc = get_schedule(p, want_bands, &sd);
         if (rc) return rc;
         a.steps = sd.steps; a.band_begin = sd.band_begin; a.n_bands = sd.n_bands;
-        a.strips = p->d_strips; a.n_strips = static_cast<uint32_t>(p->strips.size());
+        a.strips = ss.d_strips; a.n_strips = static_cast<uint32_t>(ss.strips.size());
         const int channels = alpha ? 4 : 3;
         // LDS budget, in priority order: banked LUT + double-buffered rows (always), the de-duplicated horizontal
         // weight rows, then the 16 KiB linear->sRGB table (otherwise encoded by threshold search)
         bool w_in_lds = std::getenv("IFHIP_HW_GLOBAL") == nullptr;
-        for (const Strip& s : p->strips)
+        for (const Strip& s : ss.strips)
             if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, true) > kLdsLimit) w_in_lds = false;
         bool l2s_in_lds = std::getenv("IFHIP_L2S_SEARCH") == nullptr;
-        for (const Strip& s : p->strips)
+        for (const Strip& s : ss.strips)
             if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w_in_lds, true) > kLdsLimit) l2s_in_lds = false;
         a.h_w_in_lds = w_in_lds ? 1u : 0u;
         a.l2s_in_lds = l2s_in_lds ? 1u : 0u;
         size_t lds = 0;
-        for (const Strip& s : p->strips)
+        for (const Strip& s : ss.strips)
             lds = std::max(lds, fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w_in_lds, l2s_in_lds));
         if (lds > kLdsLimit) return fail(IFHIP_INVALID_STATE, "InvalidState: fused kernel LDS plan exceeds the CU (%zu bytes)", lds);
-        const uint32_t block = std::max<uint32_t>(64u, (p->max_quads + 63u) & ~63u);
+        const uint32_t block = std::max<uint32_t>(64u, (ss.max_quads + 63u) & ~63u);
         const uint64_t grid = static_cast<uint64_t>(n_images) * sd.n_bands * a.n_strips;
         if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
         HIP_TRY(launch_fused(a, p->slots, alpha != 0, static_cast<uint32_t>(grid), block, lds, st));
@@ -451,16 +455,21 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
 
     p->slots = max_live_rows(p->wv);
     VSchedule probe;
-    p->fused_possible = p->slots <= kMaxSlots && build_vschedule(p->wv, 1, &probe) && plan_strips(p->wh, &p->strips, &p->max_quads);
-    if (p->fused_possible && (rc = upload(p->strips, &p->d_strips))) return rc;
+    p->fused_possible = p->slots >= 1 && p->slots <= kMaxSlots && build_vschedule(p->wv, 1, &probe);
+    for (int al = 0; al < 2 && p->fused_possible; ++al) {
+        const int channels = al ? 4 : 3;
+        ifhip_resample_plan::StripSet& ss = p->sets[al];
+        ss.ok = plan_strips(p->wh, static_cast<uint32_t>(fused_max_threads(p->slots, channels)), channels, &ss.strips, &ss.max_quads);
+        if (ss.ok && (rc = upload(ss.strips, &ss.d_strips))) return rc;
+    }
     *plan = p.release();
     return IFHIP_OK;
 }
 
 void ifhip_resample_plan_destroy(ifhip_resample_plan* plan) { delete plan; }
 
-int ifhip_resample_plan_kernel_kind(const ifhip_resample_plan* plan, int /*in_alpha_meaningful*/) {
-    return (plan && plan->fused_possible) ? 0 : 1;
+int ifhip_resample_plan_kernel_kind(const ifhip_resample_plan* plan, int in_alpha_meaningful) {
+    return (plan && plan->fused_possible && plan->sets[in_alpha_meaningful ? 1 : 0].ok) ? 0 : 1;
 }
 
 int ifhip_scale_and_render_batch_device(const ifhip_resample_plan* plan, const uint8_t* d_in, size_t in_image_bytes,

@@ -55,6 +55,11 @@ struct ResampleArgs {
     uint32_t n_images;
 };
 
+// Workgroup width of the fused kernel for a ring of K rows and C channels per pixel.  The vertical accumulators alone
+// take K*4*C registers per lane; up to 52 of them fit the 128-register budget of a 1024-lane workgroup (4 waves per
+// SIMD), beyond that the kernel is built for 512 lanes (256 registers, 2 waves per SIMD) and strips get narrower.
+constexpr int fused_max_threads(int K, int channels) { return (K * 4 * channels <= 52) ? 1024 : 512; }
+
 // LDS carve of the fused kernel, shared by host (size) and device (offsets); all offsets in bytes, 16-aligned.
 struct FusedLds {
     uint32_t lut, thr, l2s, hmeta, obuf, hw, inter, plane_pitch, inter_stride, total;

@@ -163,7 +163,7 @@ __device__ __forceinline__ void store_pixel(const ResampleArgs& a, uint32_t img,
 // hide under the vertical pass instead of stopping it.  One LDS-only workgroup barrier per output row.
 // ------------------------------------------------------------------------------------------------------
 template <int K, bool ALPHA, bool WLDS>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(fused_max_threads(K, ALPHA ? 4 : 3))
 fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     // `steps` is a separate __restrict__ argument (not a field of `a`) so that the compiler can prove the canvas
     // stores never clobber it and keeps the per-step 64-byte records on the scalar path.
