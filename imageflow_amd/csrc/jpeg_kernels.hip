@@ -16,7 +16,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 
 #include "common.hpp"
 
@@ -356,6 +358,157 @@ int ifhip_jpeg_idct_color(const int16_t* coef0, const int16_t* coef1, const int1
     if (dout) (void)hipFree(dout);
     if (rc) return rc;
     if (e != hipSuccess) return fail(IFHIP_GPU_ERROR, "GpuError: jpeg stage staging failed: %s", hipGetErrorString(e));
+    return IFHIP_OK;
+}
+
+}  // extern "C"
+
+// ==================================================================================================================
+// 8x8 -> NxN spatial block scalers (c_components/lib/codecs_jpeg_idct_fast.c flow_scale_spatial[_srgb]_NxN)
+// ==================================================================================================================
+#include "block_scalers.hpp"
+
+namespace ifhip {
+
+struct ScalerArgs {
+    const uint8_t* in;       // plane of 8x8 blocks
+    uint8_t* out;            // plane of NxN blocks
+    uint32_t in_pitch, out_pitch, blocks_w, blocks_h;
+    uint32_t n;
+    int srgb;
+    int32_t w[7][8];
+    uint32_t log2_div[7];
+    const uint16_t* s2l;     // 256 x u16 (12-bit linear)
+    const uint8_t* l2s;      // 4096 x u8
+};
+
+// one lane per (block, output row r): vertical pass for the 8 columns, then the N horizontal outputs -- the order
+// the generated C uses ("Scale vertically, then horizontally", variation.rs:240); all int32, exact.
+__global__ void __launch_bounds__(256) scale_spatial_kernel(const ScalerArgs a) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = a.blocks_w * a.blocks_h * a.n;
+    if (t >= total) return;
+    const uint32_t r = t % a.n, b = t / a.n;
+    const uint32_t by = b / a.blocks_w, bx = b - by * a.blocks_w;
+    const uint8_t* blk = a.in + static_cast<size_t>(by) * 8u * a.in_pitch + bx * 8u;
+    int32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int32_t wr = a.w[r][i];
+        const uint2 row = *reinterpret_cast<const uint2*>(blk + static_cast<size_t>(i) * a.in_pitch);
+        const uint32_t px[2] = {row.x, row.y};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t byte = (px[j >> 2] >> (8 * (j & 3))) & 255u;
+            const int32_t p = a.srgb ? static_cast<int32_t>(a.s2l[byte]) : static_cast<int32_t>(byte);
+            v[j] += wr * p;
+        }
+    }
+    uint8_t* orow = a.out + static_cast<size_t>(by * a.n + r) * a.out_pitch + bx * a.n;
+    for (uint32_t c = 0; c < a.n; ++c) {
+        const uint32_t sh = a.log2_div[r] + a.log2_div[c];
+        int32_t sum = static_cast<int32_t>(1u << (sh - 1u));             // divisor_sum / 2
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[j] * a.w[c][j];
+        uint32_t o;
+        if (sum < 0) o = 0;
+        else if (static_cast<uint32_t>(sum) >= (4096u << sh)) o = 255;     // REVERSE_LUT_SIZE_SHORT * divisor_sum
+        else o = a.srgb ? a.l2s[sum >> sh] : static_cast<uint32_t>(sum >> sh);
+        orow[c] = static_cast<uint8_t>(o);
+    }
+}
+
+}  // namespace ifhip
+
+namespace {
+struct ScalerDeviceTables { uint16_t* s2l = nullptr; uint8_t* l2s = nullptr; };
+std::mutex g_sc_mu;
+std::map<int, ScalerDeviceTables> g_sc_tables;
+
+int scaler_device_tables(ScalerDeviceTables* out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0)
+        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device; this library has no CPU path");
+    const BlockScalerTables* t = block_scaler_tables();
+    if (!t) return fail(IFHIP_INVALID_STATE, "InvalidState: block scaler tables could not be generated");
+    std::lock_guard<std::mutex> lk(g_sc_mu);
+    auto it = g_sc_tables.find(dev);
+    if (it == g_sc_tables.end()) {
+        ScalerDeviceTables d;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.s2l), sizeof t->srgb_to_linear));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.l2s), sizeof t->linear_to_srgb));
+        HIP_TRY(hipMemcpy(d.s2l, t->srgb_to_linear, sizeof t->srgb_to_linear, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d.l2s, t->linear_to_srgb, sizeof t->linear_to_srgb, hipMemcpyHostToDevice));
+        it = g_sc_tables.emplace(dev, d).first;
+    }
+    *out = it->second;
+    return IFHIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ifhip_block_scaler_tables(int n, int8_t* weights_7x8, uint8_t* log2_divisors_7, uint16_t* srgb_to_linear_256,
+                              uint8_t* linear_to_srgb_4096) {
+    const BlockScalerTables* t = block_scaler_tables();
+    if (!t) return fail(IFHIP_INVALID_STATE, "InvalidState: block scaler tables could not be generated");
+    if (n < 1 || n > 7) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: block scaler size %d", n);
+    if (weights_7x8) std::memcpy(weights_7x8, t->scaler[n].w, 56);
+    if (log2_divisors_7) std::memcpy(log2_divisors_7, t->scaler[n].log2_div, 7);
+    if (srgb_to_linear_256) std::memcpy(srgb_to_linear_256, t->srgb_to_linear, 512);
+    if (linear_to_srgb_4096) std::memcpy(linear_to_srgb_4096, t->linear_to_srgb, 4096);
+    return IFHIP_OK;
+}
+
+int ifhip_scale_spatial_plane_device(const uint8_t* d_in, uint32_t in_pitch, uint32_t blocks_w, uint32_t blocks_h,
+                                     int n, int srgb, uint8_t* d_out, uint32_t out_pitch, void* hip_stream) {
+    if (n < 1 || n > 7) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: block scaler size %d", n);
+    if (!d_in || !d_out) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null plane pointer");
+    if (blocks_w == 0 || blocks_h == 0) return IFHIP_OK;
+    if ((in_pitch & 7u) || (reinterpret_cast<uintptr_t>(d_in) & 7u) || in_pitch < blocks_w * 8u || out_pitch < blocks_w * static_cast<uint32_t>(n))
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: block planes need 8-byte aligned rows and pitch >= row bytes");
+    ScalerDeviceTables dt;
+    int rc = scaler_device_tables(&dt);
+    if (rc) return rc;
+    const BlockScalerTables* t = block_scaler_tables();
+    ScalerArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = d_in; a.out = d_out; a.in_pitch = in_pitch; a.out_pitch = out_pitch; a.blocks_w = blocks_w; a.blocks_h = blocks_h;
+    a.n = static_cast<uint32_t>(n); a.srgb = srgb ? 1 : 0; a.s2l = dt.s2l; a.l2s = dt.l2s;
+    for (int i = 0; i < 7; ++i) {
+        a.log2_div[i] = t->scaler[n].log2_div[i];
+        for (int j = 0; j < 8; ++j) a.w[i][j] = t->scaler[n].w[i][j];
+    }
+    const uint64_t total = static_cast<uint64_t>(blocks_w) * blocks_h * static_cast<uint32_t>(n);
+    if (total > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: plane too large for one launch");
+    hipLaunchKernelGGL(scale_spatial_kernel, dim3(static_cast<uint32_t>((total + 255u) / 256u)), dim3(256), 0,
+                       static_cast<hipStream_t>(hip_stream), a);
+    HIP_TRY(hipGetLastError());
+    return IFHIP_OK;
+}
+
+int ifhip_scale_spatial_blocks(const uint8_t* blocks, uint32_t n_blocks, int n, int srgb, uint8_t* out) {
+    if (n < 1 || n > 7) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: block scaler size %d", n);
+    if (n_blocks == 0) return IFHIP_OK;
+    if (!blocks || !out) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null block pointer");
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    const size_t in_bytes = static_cast<size_t>(n_blocks) * 64u, out_bytes = static_cast<size_t>(n_blocks) * n * n;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), in_bytes));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), out_bytes);
+    int rc = IFHIP_OK;
+    if (e == hipSuccess) e = hipMemcpy(d_in, blocks, in_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        // the block array is a plane one block wide: pitch 8 in, pitch n out
+        rc = ifhip_scale_spatial_plane_device(d_in, 8, 1, n_blocks, n, srgb, d_out, static_cast<uint32_t>(n), nullptr);
+        if (rc == IFHIP_OK) {
+            e = hipStreamSynchronize(nullptr);
+            if (e == hipSuccess) e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(IFHIP_GPU_ERROR, "GpuError: block scaler staging failed: %s", hipGetErrorString(e));
     return IFHIP_OK;
 }
 

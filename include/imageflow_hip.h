@@ -170,6 +170,20 @@ IFHIP_API int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const 
                                                  const uint16_t* d_qt, uint32_t n_images,
                                                  uint8_t* d_bgra, size_t image_bytes, uint32_t stride, void* hip_stream);
 
+/* imageflow's 8x8 -> NxN spatial block scalers for the luma plane of a scaled decode: replaces
+ * flow_scale_spatial[_srgb]_{1..7}x{1..7} (c_components/lib/codecs_jpeg_idct_fast.c, .h:17-43), the functions the IDCT
+ * method selector installs for component 1 (codec_jpeg_wrapper.c:274-343).  `srgb` selects the linear-light variants.
+ * Plane form: blocks_w x blocks_h blocks of 8x8 bytes in, n x n bytes out per block (device pointers).
+ * Block form: host array [n_blocks][64] -> [n_blocks][n][n]. */
+IFHIP_API int ifhip_scale_spatial_plane_device(const uint8_t* d_in, uint32_t in_pitch, uint32_t blocks_w,
+                                               uint32_t blocks_h, int n, int srgb, uint8_t* d_out, uint32_t out_pitch,
+                                               void* hip_stream);
+IFHIP_API int ifhip_scale_spatial_blocks(const uint8_t* blocks, uint32_t n_blocks, int n, int srgb, uint8_t* out);
+/* The tables behind them (rebuilt from populate_weights(Robidoux, n, 8) as tests/integration/variation.rs does):
+ * int8 weights [7][8], log2 of each output's divisor [7], lut_srgb_to_linear[256], lut_linear_to_srgb[4096]. */
+IFHIP_API int ifhip_block_scaler_tables(int n, int8_t* weights_7x8, uint8_t* log2_divisors_7,
+                                        uint16_t* srgb_to_linear_256, uint8_t* linear_to_srgb_4096);
+
 /* ---- measurement helpers (bench.py) -------------------------------------------------------------------- */
 /* Runs `launches` back-to-back launches of the batch op on `hip_stream` bracketed by hipEvents on that stream
  * and returns the average milliseconds per launch. */
