@@ -28,6 +28,31 @@ def _bind():
     return L
 
 
+def apply_downscaling(original_width, original_height, downscale_if_wider_than, or_if_taller_than,
+                      downscaled_min_width, downscaled_min_height):
+    """MzDec::apply_downscaling (mozjpeg_decoder.rs:588-618): the scale_num/8 libjpeg is asked for, given the decoder
+    hints (ffi/c_interop.rs:6-15).  Returns (scale_num, w, h); scale_num == 8 means full-size decode.
+    (The GPU stage decodes full size today; a scaled request is served as full decode + resample.)"""
+    if (downscaled_min_width > 0 and downscaled_min_height > 0
+            and (original_width > downscale_if_wider_than or original_height > or_if_taller_than)):
+        for i in range(1, 8):
+            if i == 7:
+                continue                      # "Because 7/8ths is slower than 8/8"
+            new_w = -(-original_width * i // 8)
+            new_h = -(-original_height * i // 8)
+            if new_w >= downscaled_min_width and new_h >= downscaled_min_height:
+                return i, new_w, new_h
+    return 8, original_width, original_height
+
+
+def idct_method_for_luma(scaled_size, scale_luma_spatially, gamma_correct_for_srgb):
+    """wrap_jpeg_idct_method_selector (codec_jpeg_wrapper.c:274-343): which block routine the luma component gets.
+    Returns ("islow", 8) or ("spatial" | "spatial_srgb", n)."""
+    if 0 < scaled_size < 8 and scale_luma_spatially:
+        return ("spatial_srgb" if gamma_correct_for_srgb else "spatial", scaled_size)
+    return ("islow", 8)
+
+
 class JpegPixelStage:
     """ifhip_jpeg_stage: geometry + the component planes between the IDCT and the colour kernel."""
 
