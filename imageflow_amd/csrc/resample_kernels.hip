@@ -15,9 +15,13 @@
 // separately, exactly as the arithmetic contract in oracle/if_oracle.c (tests compare bit for bit).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "device.hpp"
 
 namespace ifhip {
+
+constexpr size_t kFusedLdsCap = 160 * 1024;      // gfx950: a workgroup may use the whole CU's LDS
 
 // ------------------------------------------------------------------------------------------------------
 // Output stage (shared by the fused and the generic kernels)
@@ -510,8 +514,16 @@ __global__ void __launch_bounds__(256) apply_matte_kernel(const MatteArgs a) {
 // ------------------------------------------------------------------------------------------------------
 template <int K, bool ALPHA, bool WLDS>
 static hipError_t launch_fused_kaw(const ResampleArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_resample_kernel<K, ALPHA, WLDS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    // raise the dynamic-LDS cap once per kernel variant and device (it is sticky), not on every launch
+    static std::atomic<size_t> cap[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<size_t>& c = cap[dev & 15];
+    if (c.load(std::memory_order_relaxed) < lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_resample_kernel<K, ALPHA, WLDS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsCap));
+        c.store(kFusedLdsCap, std::memory_order_relaxed);
+    }
     hipLaunchKernelGGL((fused_resample_kernel<K, ALPHA, WLDS>), grid, block, lds, st, a, a.steps);
     return hipGetLastError();
 }

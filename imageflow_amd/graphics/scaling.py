@@ -74,10 +74,15 @@ def scale_and_render(input: Bitmap, canvas: Bitmap, info: ScaleAndRenderParams, 
     dev = input.data.device
     plan = plan or plan_for(input.w, input.h, info.w, info.h, info.interpolation_filter, info.sharpen_percent_goal, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    with torch.cuda.device(dev):
+    if torch.cuda.current_device() == dev.index:
         _native.check(_native.lib().ifhip_scale_and_render_batch_device(
             *_batch_args(plan, input, canvas, info),
             f32_out.data_ptr() if f32_out is not None else None, force_kernel, C.c_void_p(stream)))
+    else:
+        with torch.cuda.device(dev):
+            _native.check(_native.lib().ifhip_scale_and_render_batch_device(
+                *_batch_args(plan, input, canvas, info),
+                f32_out.data_ptr() if f32_out is not None else None, force_kernel, C.c_void_p(stream)))
     return plan
 
 
