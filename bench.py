@@ -5,7 +5,7 @@ Workload (config.workload): BASELINE config 2 -- a batch of 256 synthetic 3840x2
 resident, each resized to 200x200 with Robidoux in linear light (ReplaceSelf canvas, alpha not meaningful, as after
 a JPEG decode).  One "step" = one pass of the fused kernel over the rank's whole batch.  Weak scaling: every rank owns
 its own 256 frames (independent images: no data-path collective); for N > 1 the 200x200 outputs of each step are
-gathered with one RCCL all_gather on a side stream, overlapped with the next step.
+gathered to rank 0 over RCCL (one direct xGMI transfer per peer), asynchronously, overlapped with the next step.
 
 Prints ONE JSON line (rank 0).  value = source megapixels resized per second over all ranks, inputs already in HBM.
 """
@@ -141,8 +141,9 @@ def main():
     info = ScaleAndRenderParams(0, 0, OUT_W, OUT_H, wl[5], Filter[wl[4]])
     plan = plan_for(IN_W, IN_H, OUT_W, OUT_H, info.interpolation_filter, wl[5], dev)
     gather = distributed and not args.no_gather and os.environ.get("IFHIP_BENCH_GATHER", "1") != "0"
-    from imageflow_amd.sharding import gather_outputs, max_over_ranks
-    gathered = [torch.empty((world,) + tuple(c.data.shape), dtype=torch.uint8, device=dev) for c in canv] if gather else None
+    from imageflow_amd.sharding import gather_to_root, max_over_ranks
+    gathered = [torch.empty((world,) + tuple(c.data.shape), dtype=torch.uint8, device=dev) if rank == 0 else None
+                for c in canv] if gather else None
 
     def step(i, pending):
         c = canv[i & 1]
@@ -151,7 +152,7 @@ def main():
             pending[i & 1] = None
         scale_and_render(inp, c, info, plan=plan)
         if gather:
-            pending[i & 1], _ = gather_outputs(c.data, world * n, async_op=True, out=gathered[i & 1])
+            pending[i & 1], _ = gather_to_root(c.data, 0, async_op=True, out=gathered[i & 1])
 
     def sync_all(pending):
         for k in range(2):
@@ -202,7 +203,7 @@ def main():
                                    f"{' sharpen ' + str(wl[5]) if wl[5] else ''}, linear light, {wl[7]}, "
                                    f"alpha {'meaningful' if wl[6] else 'not meaningful'}, device resident, pattern={args.pattern}",
                        "frames_per_gpu": n, "kernel": "fused_resample_kernel" if plan.kernel_kind(wl[6]) == 0 else "generic",
-                       "gather": "rccl all_gather of outputs, overlapped" if gather else "none"},
+                       "gather": "rccl gather of the outputs to rank 0, asynchronous, double buffered" if gather else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},

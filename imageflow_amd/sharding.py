@@ -49,6 +49,22 @@ def gather_outputs(local: torch.Tensor, n_frames: int, group=None, async_op=Fals
     return finish()
 
 
+def gather_to_root(local: torch.Tensor, root: int = 0, group=None, async_op=False, out=None):
+    """The job's final gather (BASELINE north_star): equally shaped shards [n_local, ...] -> rank `root` receives
+    [world, n_local, ...]; every other rank only sends.  Over RCCL this is one direct xGMI transfer per peer (7 links
+    into the root in parallel), 1/8 of an all_gather's traffic.  Returns (work_or_None, out_or_None)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    local = local.contiguous()
+    gather_list = None
+    if rank == root:
+        if out is None:
+            out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        gather_list = [out[r] for r in range(world)]
+    work = dist.gather(local, gather_list, dst=root, group=group, async_op=async_op)
+    return (work if async_op else None), (out if rank == root else None)
+
+
 def max_over_ranks(seconds: float, device) -> float:
     """bench.py's timing rule: the job takes as long as its slowest rank."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

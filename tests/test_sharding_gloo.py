@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from imageflow_amd.sharding import gather_outputs, max_over_ranks, owner_of, shard_range  # noqa: E402
+from imageflow_amd.sharding import gather_outputs, gather_to_root, max_over_ranks, owner_of, shard_range  # noqa: E402
 
 
 def test_shard_range_partitions_every_batch():
@@ -62,7 +62,19 @@ def _worker(rank, world, port, n_frames, q):
         work.wait()
         full2 = finish()
         t = max_over_ranks(0.5 + rank, torch.device("cpu"))
-        q.put((rank, full.numpy().copy(), bool(torch.equal(full, full2)), t))
+        # gather-to-root with equal shards (what bench.py does): pad the local shard to the common size first
+        biggest = -(-n_frames // world)
+        padded = torch.zeros((biggest, local.shape[1]), dtype=local.dtype)
+        padded[: local.shape[0]] = local
+        work, out = gather_to_root(padded, 0, async_op=True)
+        work.wait()
+        root_ok = True
+        if rank == 0:
+            parts = [out[r, : shard_range(n_frames, r, world)[1] - shard_range(n_frames, r, world)[0]] for r in range(world)]
+            root_ok = bool(torch.equal(torch.cat(parts, 0), full))
+        else:
+            root_ok = out is None
+        q.put((rank, full.numpy().copy(), bool(torch.equal(full, full2)) and root_ok, t))
     finally:
         dist.destroy_process_group()
 
