@@ -16,9 +16,10 @@ def _bind():
     if getattr(L, "_jpeg_bound", False):
         return L
     L.ifhip_jpeg_idct_color.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                        C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+                                        C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32]
     L.ifhip_jpeg_stage_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p,
-                                          C.c_uint32]
+                                          C.c_int, C.c_int, C.c_int, C.c_uint32]
+    L.ifhip_jpeg_stage_output_size.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifhip_jpeg_stage_destroy.argtypes = [C.c_void_p]
     L.ifhip_jpeg_stage_destroy.restype = None
     L.ifhip_jpeg_stage_block_dims.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -56,7 +57,8 @@ def idct_method_for_luma(scaled_size, scale_luma_spatially, gamma_correct_for_sr
 class JpegPixelStage:
     """ifhip_jpeg_stage: geometry + the component planes between the IDCT and the colour kernel."""
 
-    def __init__(self, width, height, n_components, h_samp, v_samp, max_images, device="cuda:0"):
+    def __init__(self, width, height, n_components, h_samp, v_samp, max_images, device="cuda:0", scale_num=8,
+                 luma_spatial=False, luma_srgb=False):
         L = _bind()
         self.width, self.height, self.n = width, height, n_components
         self.device = torch.device(device)
@@ -65,7 +67,10 @@ class JpegPixelStage:
         vs = np.array(list(v_samp)[:3] + [0] * (3 - len(v_samp)), np.uint8)
         with torch.cuda.device(self.device):
             _native.check(L.ifhip_jpeg_stage_create(C.byref(self._h), width, height, n_components, hs.ctypes.data,
-                                                    vs.ctypes.data, max_images))
+                                                    vs.ctypes.data, scale_num, int(luma_spatial), int(luma_srgb), max_images))
+        ow, oh = C.c_uint32(), C.c_uint32()
+        _native.check(L.ifhip_jpeg_stage_output_size(self._h, C.byref(ow), C.byref(oh)))
+        self.out_w, self.out_h = ow.value, oh.value
         bw, bh = np.zeros(3, np.uint32), np.zeros(3, np.uint32)
         _native.check(L.ifhip_jpeg_stage_block_dims(self._h, bw.ctypes.data, bh.ctypes.data))
         self.blocks_w, self.blocks_h = [int(v) for v in bw], [int(v) for v in bh]
@@ -76,7 +81,7 @@ class JpegPixelStage:
         L = _bind()
         n = coef[0].shape[0]
         if out is None:
-            out = Bitmap.create_u8(n, self.width, self.height, self.device, alpha_meaningful=False)
+            out = Bitmap.create_u8(n, self.out_w, self.out_h, self.device, alpha_meaningful=False)
         ptr = [coef[c].data_ptr() if c < self.n else None for c in range(3)]
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
@@ -94,11 +99,13 @@ class JpegPixelStage:
             pass
 
 
-def jpeg_idct_color_host(coef, qt, n_components, h_samp, v_samp, width, height, stride=None):
+def jpeg_idct_color_host(coef, qt, n_components, h_samp, v_samp, width, height, stride=None, scale_num=8,
+                         luma_spatial=False, luma_srgb=False):
     """Host-buffer drop-in (numpy): coef = list of int16 arrays [bh][bw][64], qt = uint16 [ncomp][64] -> BGRA rows."""
     L = _bind()
-    stride = stride or get_stride(width)
-    out = np.zeros((height, stride), np.uint8)
+    ow, oh = (width * scale_num + 7) // 8, (height * scale_num + 7) // 8
+    stride = stride or get_stride(ow)
+    out = np.zeros((oh, stride), np.uint8)
     hs = np.array(list(h_samp)[:3], np.uint8)
     vs = np.array(list(v_samp)[:3], np.uint8)
     p = [np.ascontiguousarray(coef[c]).ctypes.data if c < n_components else None for c in range(3)]
@@ -106,5 +113,5 @@ def jpeg_idct_color_host(coef, qt, n_components, h_samp, v_samp, width, height, 
     p = [keep[c].ctypes.data if c < n_components else None for c in range(3)]
     q = np.ascontiguousarray(qt[:n_components], np.uint16)
     _native.check(L.ifhip_jpeg_idct_color(p[0], p[1], p[2], q.ctypes.data, n_components, hs.ctypes.data, vs.ctypes.data,
-                                          width, height, out.ctypes.data, stride))
+                                          width, height, scale_num, int(luma_spatial), int(luma_srgb), out.ctypes.data, stride))
     return out

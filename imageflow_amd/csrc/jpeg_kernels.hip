@@ -33,10 +33,23 @@ struct JpegGeom {
     uint32_t pw[3], ph[3];          // plane width / height in samples (= 8 * blocks)
     uint32_t dw[3], dh[3];          // libjpeg downsampled_width / downsampled_height
     uint32_t blocks_before[4];      // prefix sums of bw*bh over components
+    uint32_t out_w, out_h;          // ceil(width * scale_num / 8), ceil(height * scale_num / 8)
+    uint32_t scale_num;             // 8 = full size; 1, 2, 4 = reduced-size decode
+    uint32_t idct_n[3];             // samples per block edge each component's IDCT produces (1, 2, 4 or 8)
+    uint32_t luma_mode;             // 0: libjpeg's own (reduced) IDCT, 1: islow + flow_scale_spatial, 2: ... _srgb
+    uint32_t upsample;              // 0 none (planes already at output resolution), 1 h2v1 fancy, 2 h2v2 fancy
+};
+
+struct JpegScalerTab {              // flow_scale_spatial tables for the luma size in use
+    int32_t w[7][8];
+    uint32_t log2_div[7];
+    const uint16_t* s2l;
+    const uint8_t* l2s;
 };
 
 struct JpegArgs {
     JpegGeom g;
+    JpegScalerTab sc;
     const int16_t* coef[3];
     const uint16_t* qt;             // [n_images][ncomp][64]
     uint8_t* plane[3];              // [n_images][ph][pw]
@@ -79,6 +92,23 @@ __device__ __forceinline__ void idct8(const int32_t (&in)[8], int32_t (&out)[8],
     out[3] = descale(tmp13 + tmp0, sh); out[4] = descale(tmp13 - tmp0, sh);
 }
 
+// reduced-size passes of jidctred.c (jpeg_idct_4x4 / jpeg_idct_2x2): same 13-bit constants family
+__device__ __forceinline__ void idct4_pass(int32_t d0, int32_t d1, int32_t d2, int32_t d3, int32_t d5, int32_t d6, int32_t d7,
+                                           int32_t (&out)[4], int sh) {
+    const int32_t t0 = static_cast<int32_t>(static_cast<uint32_t>(d0) << 14);
+    const int32_t t2 = d2 * 15137 + d6 * (-6270);
+    const int32_t t10 = t0 + t2, t12 = t0 - t2;
+    const int32_t o0 = d7 * (-1730) + d5 * 11893 + d3 * (-17799) + d1 * 8697;
+    const int32_t o2 = d7 * (-4176) + d5 * (-4926) + d3 * 7373 + d1 * 20995;
+    out[0] = descale(t10 + o2, sh); out[3] = descale(t10 - o2, sh);
+    out[1] = descale(t12 + o0, sh); out[2] = descale(t12 - o0, sh);
+}
+__device__ __forceinline__ void idct2_pass(int32_t d0, int32_t d1, int32_t d3, int32_t d5, int32_t d7, int32_t (&out)[2], int sh) {
+    const int32_t t10 = static_cast<int32_t>(static_cast<uint32_t>(d0) << 15);
+    const int32_t t0 = d7 * (-5906) + d5 * 6967 + d3 * (-10426) + d1 * 29692;
+    out[0] = descale(t10 + t0, sh); out[1] = descale(t10 - t0, sh);
+}
+
 constexpr int kBlocksPerWg = 32;
 constexpr int kBlockPitch = 72;     // dwords per 8x8 workspace in LDS (64 + 8: spreads 4 blocks over the 32 banks)
 
@@ -96,10 +126,14 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
         c = (a.g.ncomp > 1 && r >= a.g.blocks_before[1]) ? ((r >= a.g.blocks_before[2]) ? 2u : 1u) : 0u;
         bidx = r - a.g.blocks_before[c];
     }
+    const uint32_t n = a.g.idct_n[c];                                   // output samples per block edge
+    const bool spatial = (c == 0u) && a.g.luma_mode != 0u && n < 8u;    // islow, then imageflow's block scaler
+    const uint32_t m = spatial ? 8u : n;                                // size of the IDCT actually run
     int32_t* w = ws + lb * kBlockPitch;
     if (on) {
         const uint32_t nblk = a.g.bw[c] * a.g.bh[c];
         const int16_t* src = a.coef[c] + (static_cast<size_t>(img) * nblk + bidx) * 64u + lane8 * 8u;
+        // the luma scalers' islow runs with the FIRST component's table, as jpeg_idct_islow(cinfo, compptr, ...) does
         const uint16_t* q = a.qt + (static_cast<size_t>(img) * a.g.ncomp + c) * 64u + lane8 * 8u;
         const uint4 cv = *reinterpret_cast<const uint4*>(src);          // row lane8 of the block: 8 x int16
         const uint4 qv = *reinterpret_cast<const uint4*>(q);
@@ -113,30 +147,98 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
         }
     }
     __syncthreads();
-    if (on) {                                   // column pass: lane8 = column (CONST_BITS - PASS1_BITS = 11)
-        int32_t in[8], out[8];
+    if (on) {                                   // column pass: lane8 = column
+        int32_t in[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) in[r] = w[r * 8 + lane8];
-        idct8(in, out, 11);
+        if (m == 8u) {
+            int32_t out[8];
+            idct8(in, out, 11);                 // CONST_BITS - PASS1_BITS
 #pragma unroll
-        for (int r = 0; r < 8; ++r) w[r * 8 + lane8] = out[r];
+            for (int r = 0; r < 8; ++r) w[r * 8 + lane8] = out[r];
+        } else if (m == 4u) {
+            int32_t out[4];
+            idct4_pass(in[0], in[1], in[2], in[3], in[5], in[6], in[7], out, 12);     // CONST_BITS - PASS1_BITS + 1
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r * 8 + lane8] = out[r];
+        } else if (m == 2u) {
+            int32_t out[2];
+            idct2_pass(in[0], in[1], in[3], in[5], in[7], out, 13);                   // CONST_BITS - PASS1_BITS + 2
+            w[lane8] = out[0]; w[8 + lane8] = out[1];
+        }
     }
     __syncthreads();
-    if (on) {                                   // row pass: lane8 = row (CONST_BITS + PASS1_BITS + 3 = 18)
-        int32_t in[8], out[8];
+    uint8_t* plane = a.plane[c] + static_cast<size_t>(img) * a.g.pw[c] * a.g.ph[c];
+    const uint32_t by = on ? bidx / a.g.bw[c] : 0u, bx = on ? bidx - by * a.g.bw[c] : 0u;
+    uint8_t* bytes = reinterpret_cast<uint8_t*>(w);          // the 8x8 bytes of a full IDCT, for the spatial scaler
+    if (on) {                                   // row pass: lane8 = row
+        if (m == 8u) {
+            int32_t in[8], out[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) in[k] = w[lane8 * 8u + k];
-        idct8(in, out, 18);
-        uint32_t lo = 0, hi = 0;
+            for (int k = 0; k < 8; ++k) in[k] = w[lane8 * 8u + k];
+            idct8(in, out, 18);                 // CONST_BITS + PASS1_BITS + 3
+            uint32_t lo = 0, hi = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            lo |= range_limit(out[k]) << (8 * k);
-            hi |= range_limit(out[4 + k]) << (8 * k);
+            for (int k = 0; k < 4; ++k) {
+                lo |= range_limit(out[k]) << (8 * k);
+                hi |= range_limit(out[4 + k]) << (8 * k);
+            }
+            if (!spatial) {
+                uint8_t* dst = plane + static_cast<size_t>(by * 8u + lane8) * a.g.pw[c] + bx * 8u;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+            } else {
+                // keep the row's 8 bytes in the first two dwords of the lane's own (already consumed) workspace row
+                *reinterpret_cast<uint2*>(w + lane8 * 8u) = make_uint2(lo, hi);
+            }
+        } else if (m == 4u) {
+            if (lane8 < 4u) {
+                const int32_t* r = w + lane8 * 8u;
+                int32_t out[4];
+                idct4_pass(r[0], r[1], r[2], r[3], r[5], r[6], r[7], out, 19);       // CONST_BITS + PASS1_BITS + 3 + 1
+                const uint32_t v = range_limit(out[0]) | (range_limit(out[1]) << 8) | (range_limit(out[2]) << 16) | (range_limit(out[3]) << 24);
+                *reinterpret_cast<uint32_t*>(plane + static_cast<size_t>(by * 4u + lane8) * a.g.pw[c] + bx * 4u) = v;
+            }
+        } else if (m == 2u) {
+            if (lane8 < 2u) {
+                const int32_t* r = w + lane8 * 8u;
+                int32_t out[2];
+                idct2_pass(r[0], r[1], r[3], r[5], r[7], out, 20);                    // CONST_BITS + PASS1_BITS + 3 + 2
+                const uint32_t v = range_limit(out[0]) | (range_limit(out[1]) << 8);
+                *reinterpret_cast<uint16_t*>(plane + static_cast<size_t>(by * 2u + lane8) * a.g.pw[c] + bx * 2u) = static_cast<uint16_t>(v);
+            }
+        } else {                                                                     // 1x1: DC / 8
+            if (lane8 == 0u) plane[static_cast<size_t>(by) * a.g.pw[c] + bx] = static_cast<uint8_t>(range_limit(descale(w[0], 3)));
         }
-        const uint32_t by = bidx / a.g.bw[c], bx = bidx - by * a.g.bw[c];
-        uint8_t* dst = a.plane[c] + static_cast<size_t>(img) * a.g.pw[c] * a.g.ph[c]
-                       + static_cast<size_t>(by * 8u + lane8) * a.g.pw[c] + bx * 8u;
-        *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+    }
+    if (spatial) {
+        __syncthreads();
+        // flow_scale_spatial[_srgb]_NxN on the block's 8x8 bytes: lane r < n produces output row r
+        if (on && lane8 < n) {
+            const uint8_t* blk = bytes;                      // row i of the block: bytes [32*i, 32*i + 8)
+            const bool srgb = a.g.luma_mode == 2u;
+            int32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int32_t wr = a.sc.w[lane8][i];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t byte = blk[i * 32 + j];
+                    v[j] += wr * (srgb ? static_cast<int32_t>(a.sc.s2l[byte]) : static_cast<int32_t>(byte));
+                }
+            }
+            uint8_t* orow = plane + static_cast<size_t>(by * n + lane8) * a.g.pw[c] + bx * n;
+            for (uint32_t cc = 0; cc < n; ++cc) {
+                const uint32_t sh = a.sc.log2_div[lane8] + a.sc.log2_div[cc];
+                int32_t sum = static_cast<int32_t>(1u << (sh - 1u));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += v[j] * a.sc.w[cc][j];
+                uint32_t o;
+                if (sum < 0) o = 0;
+                else if (static_cast<uint32_t>(sum) >= (4096u << sh)) o = 255;
+                else o = srgb ? a.sc.l2s[sum >> sh] : static_cast<uint32_t>(sum >> sh);
+                orow[cc] = static_cast<uint8_t>(o);
+            }
+        }
     }
 }
 
@@ -151,7 +253,7 @@ __device__ __forceinline__ uint32_t clamp255(int32_t v) { return static_cast<uin
 
 __global__ void __launch_bounds__(256) jpeg_color_kernel(const JpegArgs a) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
-    if (x >= a.g.width) return;
+    if (x >= a.g.out_w) return;
     const uint8_t* py = a.plane[0] + static_cast<size_t>(img) * a.g.pw[0] * a.g.ph[0];
     const int32_t Y = py[static_cast<size_t>(y) * a.g.pw[0] + x];
     uint32_t out;
@@ -164,9 +266,9 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const JpegArgs a) {
             const int c = 1 + k;
             const uint8_t* P = a.plane[c] + static_cast<size_t>(img) * a.g.pw[c] * a.g.ph[c];
             const uint32_t W = a.g.pw[c], DW = a.g.dw[c], DH = a.g.dh[c];
-            if (a.g.hmax == 1 && a.g.vmax == 1) {
+            if (a.g.upsample == 0u) {                                     // plane already at output resolution
                 v[k] = P[static_cast<size_t>(y) * W + x];
-            } else if (a.g.vmax == 1) {                                   // h2v1 fancy
+            } else if (a.g.upsample == 1u) {                              // h2v1 fancy
                 const int32_t cx = static_cast<int32_t>(x >> 1), far = (x & 1u) ? cx + 1 : cx - 1, bias = (x & 1u) ? 2 : 1;
                 v[k] = (3 * chroma_at(P, W, DW, DH, cx, static_cast<int32_t>(y))
                         + chroma_at(P, W, DW, DH, far, static_cast<int32_t>(y)) + bias) >> 2;
@@ -203,6 +305,41 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const JpegArgs a) {
 
 // ==================================================================================================================
 using namespace ifhip;
+#include "block_scalers.hpp"
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(IFHIP_GPU_ERROR, "GpuError: %s failed: %s", #expr, hipGetErrorString(e__));     \
+    } while (0)
+
+namespace {
+struct ScalerDeviceTables { uint16_t* s2l = nullptr; uint8_t* l2s = nullptr; };
+std::mutex g_sc_mu;
+std::map<int, ScalerDeviceTables> g_sc_tables;
+
+int scaler_device_tables(ScalerDeviceTables* out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0)
+        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device; this library has no CPU path");
+    const BlockScalerTables* t = block_scaler_tables();
+    if (!t) return fail(IFHIP_INVALID_STATE, "InvalidState: block scaler tables could not be generated");
+    std::lock_guard<std::mutex> lk(g_sc_mu);
+    auto it = g_sc_tables.find(dev);
+    if (it == g_sc_tables.end()) {
+        ScalerDeviceTables d;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.s2l), sizeof t->srgb_to_linear));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.l2s), sizeof t->linear_to_srgb));
+        HIP_TRY(hipMemcpy(d.s2l, t->srgb_to_linear, sizeof t->srgb_to_linear, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d.l2s, t->linear_to_srgb, sizeof t->linear_to_srgb, hipMemcpyHostToDevice));
+        it = g_sc_tables.emplace(dev, d).first;
+    }
+    *out = it->second;
+    return IFHIP_OK;
+}
+}  // namespace
+
 
 struct ifhip_jpeg_stage {
     int device = -1;
@@ -212,14 +349,11 @@ struct ifhip_jpeg_stage {
     ~ifhip_jpeg_stage() { for (auto* p : planes) if (p) (void)hipFree(p); }
 };
 
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e__ = (expr);                                                                        \
-        if (e__ != hipSuccess)                                                                          \
-            return fail(IFHIP_GPU_ERROR, "GpuError: %s failed: %s", #expr, hipGetErrorString(e__));     \
-    } while (0)
 
-static int make_geom(uint32_t width, uint32_t height, int ncomp, const uint8_t* hs, const uint8_t* vs, JpegGeom* g) {
+static int make_geom(uint32_t width, uint32_t height, int ncomp, const uint8_t* hs, const uint8_t* vs, int scale_num,
+                     int luma_spatial, int luma_srgb, JpegGeom* g) {
+    if (scale_num != 8 && scale_num != 4 && scale_num != 2 && scale_num != 1)
+        return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: jpeg scale_num %d/8 (supported: 1, 2, 4, 8)", scale_num);
     if (width == 0 || height == 0) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: Bitmap dimensions cannot be zero");
     if (ncomp != 1 && ncomp != 3) return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: %d-component JPEG", ncomp);
     std::memset(g, 0, sizeof *g);
@@ -237,11 +371,21 @@ static int make_geom(uint32_t width, uint32_t height, int ncomp, const uint8_t* 
         if (!chroma_1x1 || !luma_max || (g->hmax == 1 && g->vmax == 2))
             return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: only 4:4:4, 4:2:2 (h2v1) and 4:2:0 sampling");
     }
+    const bool is420 = ncomp == 3 && g->hmax == 2 && g->vmax == 2, is422 = ncomp == 3 && g->hmax == 2 && g->vmax == 1;
+    if (scale_num != 8 && is422)
+        return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: reduced-size decode of 4:2:2 (needs libjpeg's non-square IDCTs)");
+    g->scale_num = static_cast<uint32_t>(scale_num);
+    g->luma_mode = (scale_num < 8 && luma_spatial) ? (luma_srgb ? 2u : 1u) : 0u;     // codec_jpeg_wrapper.c:285-339
+    g->out_w = (width * g->scale_num + 7u) / 8u;                                      // jpeg_calc_output_dimensions
+    g->out_h = (height * g->scale_num + 7u) / 8u;
+    // jdmaster.c: at reduced size a 2x2 sub-sampled component takes an IDCT twice as large instead of being up-sampled
+    g->upsample = (scale_num == 8) ? (is420 ? 2u : (is422 ? 1u : 0u)) : 0u;
     const uint32_t mw = (width + 8u * g->hmax - 1u) / (8u * g->hmax), mh = (height + 8u * g->vmax - 1u) / (8u * g->vmax);
     g->blocks_before[0] = 0;
     for (int c = 0; c < ncomp; ++c) {
         g->bw[c] = mw * g->hs[c]; g->bh[c] = mh * g->vs[c];
-        g->pw[c] = g->bw[c] * 8u; g->ph[c] = g->bh[c] * 8u;
+        g->idct_n[c] = (scale_num == 8) ? 8u : ((c > 0 && is420) ? 2u * g->scale_num : g->scale_num);
+        g->pw[c] = g->bw[c] * g->idct_n[c]; g->ph[c] = g->bh[c] * g->idct_n[c];
         g->dw[c] = (width * g->hs[c] + g->hmax - 1u) / g->hmax;
         g->dh[c] = (height * g->vs[c] + g->vmax - 1u) / g->vmax;
         g->blocks_before[c + 1] = g->blocks_before[c] + g->bw[c] * g->bh[c];
@@ -252,13 +396,14 @@ static int make_geom(uint32_t width, uint32_t height, int ncomp, const uint8_t* 
 extern "C" {
 
 int ifhip_jpeg_stage_create(ifhip_jpeg_stage** stage, uint32_t width, uint32_t height, int n_components,
-                            const uint8_t* h_samp, const uint8_t* v_samp, uint32_t max_images) {
+                            const uint8_t* h_samp, const uint8_t* v_samp, int scale_num, int luma_spatial,
+                            int luma_srgb, uint32_t max_images) {
     if (!stage) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null stage out-pointer");
     *stage = nullptr;
     if (max_images == 0 || (n_components == 3 && (!h_samp || !v_samp)))
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: jpeg stage needs sampling factors and max_images >= 1");
     std::unique_ptr<ifhip_jpeg_stage> s(new ifhip_jpeg_stage);
-    int rc = make_geom(width, height, n_components, h_samp, v_samp, &s->g);
+    int rc = make_geom(width, height, n_components, h_samp, v_samp, scale_num, luma_spatial, luma_srgb, &s->g);
     if (rc) return rc;
     if (s->g.height > 65535u || max_images > 65535u) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: more than 65535 rows/images per launch");
     if (hipGetDevice(&s->device) != hipSuccess)
@@ -269,12 +414,18 @@ int ifhip_jpeg_stage_create(ifhip_jpeg_stage** stage, uint32_t width, uint32_t h
         return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: device %d is %s, this library is built for gfx950 only", s->device, prop.gcnArchName);
     s->max_images = max_images;
     for (int c = 0; c < n_components; ++c)
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->planes[c]), static_cast<size_t>(s->g.pw[c]) * s->g.ph[c] * max_images));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->planes[c]), static_cast<size_t>(s->g.pw[c]) * s->g.ph[c] * max_images + 16));
     *stage = s.release();
     return IFHIP_OK;
 }
 
 void ifhip_jpeg_stage_destroy(ifhip_jpeg_stage* stage) { delete stage; }
+
+int ifhip_jpeg_stage_output_size(const ifhip_jpeg_stage* stage, uint32_t* out_w, uint32_t* out_h) {
+    if (!stage || !out_w || !out_h) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
+    *out_w = stage->g.out_w; *out_h = stage->g.out_h;
+    return IFHIP_OK;
+}
 
 int ifhip_jpeg_stage_block_dims(const ifhip_jpeg_stage* stage, uint32_t* blocks_w3, uint32_t* blocks_h3) {
     if (!stage || !blocks_w3 || !blocks_h3) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
@@ -290,7 +441,7 @@ int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d
     if (n_images > stage->max_images) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: %u images exceed the stage capacity %u", n_images, stage->max_images);
     if (!d_coef0 || !d_qt || !d_bgra || (stage->g.ncomp == 3 && (!d_coef1 || !d_coef2)))
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null coefficient / table / bitmap pointer");
-    if (static_cast<uint64_t>(stage->g.width) * 4u > stride || (stride & 3u) || (image_bytes & 3u) || (reinterpret_cast<uintptr_t>(d_bgra) & 3u))
+    if (static_cast<uint64_t>(stage->g.out_w) * 4u > stride || (stride & 3u) || (image_bytes & 3u) || (reinterpret_cast<uintptr_t>(d_bgra) & 3u))
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: BGRA rows must be 4-byte aligned and stride >= 4*w");
     if ((reinterpret_cast<uintptr_t>(d_coef0) | reinterpret_cast<uintptr_t>(d_coef1) | reinterpret_cast<uintptr_t>(d_coef2)
          | reinterpret_cast<uintptr_t>(d_qt)) & 15u)
@@ -305,29 +456,42 @@ int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d
     a.qt = d_qt;
     for (int c = 0; c < 3; ++c) a.plane[c] = stage->planes[c];
     a.bgra = d_bgra; a.image_bytes = image_bytes; a.stride = stride; a.n_images = n_images;
+    if (a.g.luma_mode != 0u) {
+        ScalerDeviceTables dt;
+        int rc = scaler_device_tables(&dt);
+        if (rc) return rc;
+        const BlockScalerTables* t = block_scaler_tables();
+        const uint32_t n = a.g.idct_n[0];
+        for (int i = 0; i < 7; ++i) {
+            a.sc.log2_div[i] = t->scaler[n].log2_div[i];
+            for (int j = 0; j < 8; ++j) a.sc.w[i][j] = t->scaler[n].w[i][j];
+        }
+        a.sc.s2l = dt.s2l; a.sc.l2s = dt.l2s;
+    }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const uint64_t total_blocks = static_cast<uint64_t>(a.g.blocks_before[a.g.ncomp]) * n_images;
     const uint64_t wgs = (total_blocks + kBlocksPerWg - 1) / kBlocksPerWg;
     if (wgs > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3(static_cast<uint32_t>(wgs)), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(jpeg_color_kernel, dim3((a.g.width + 255u) / 256u, a.g.height, n_images), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((a.g.out_w + 255u) / 256u, a.g.out_h, n_images), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     return IFHIP_OK;
 }
 
 int ifhip_jpeg_idct_color(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2, const uint16_t* qt,
                           int n_components, const uint8_t* h_samp, const uint8_t* v_samp, uint32_t width,
-                          uint32_t height, uint8_t* bgra, uint32_t stride) {
+                          uint32_t height, int scale_num, int luma_spatial, int luma_srgb, uint8_t* bgra, uint32_t stride) {
     JpegGeom g;
-    int rc = make_geom(width, height, n_components, h_samp, v_samp, &g);
+    int rc = make_geom(width, height, n_components, h_samp, v_samp, scale_num, luma_spatial, luma_srgb, &g);
     if (rc) return rc;
     if (!coef0 || !qt || !bgra || (n_components == 3 && (!coef1 || !coef2)))
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null coefficient / table / bitmap pointer");
-    if (static_cast<uint64_t>(width) * 4u > stride || (stride & 3u))
+    if (static_cast<uint64_t>(g.out_w) * 4u > stride || (stride & 3u))
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: stride smaller than a BGRA row or not a multiple of 4");
     ifhip_jpeg_stage* stage = nullptr;
-    rc = ifhip_jpeg_stage_create(&stage, width, height, n_components, h_samp, v_samp, 1);
+    rc = ifhip_jpeg_stage_create(&stage, width, height, n_components, h_samp, v_samp, scale_num, luma_spatial, luma_srgb, 1);
+    width = g.out_w; height = g.out_h;          // the bitmap the caller handed in has the scaled size
     if (rc) return rc;
     std::unique_ptr<ifhip_jpeg_stage> guard(stage);
     const int16_t* hc[3] = {coef0, coef1, coef2};
@@ -420,31 +584,6 @@ __global__ void __launch_bounds__(256) scale_spatial_kernel(const ScalerArgs a) 
 
 }  // namespace ifhip
 
-namespace {
-struct ScalerDeviceTables { uint16_t* s2l = nullptr; uint8_t* l2s = nullptr; };
-std::mutex g_sc_mu;
-std::map<int, ScalerDeviceTables> g_sc_tables;
-
-int scaler_device_tables(ScalerDeviceTables* out) {
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0)
-        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device; this library has no CPU path");
-    const BlockScalerTables* t = block_scaler_tables();
-    if (!t) return fail(IFHIP_INVALID_STATE, "InvalidState: block scaler tables could not be generated");
-    std::lock_guard<std::mutex> lk(g_sc_mu);
-    auto it = g_sc_tables.find(dev);
-    if (it == g_sc_tables.end()) {
-        ScalerDeviceTables d;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.s2l), sizeof t->srgb_to_linear));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.l2s), sizeof t->linear_to_srgb));
-        HIP_TRY(hipMemcpy(d.s2l, t->srgb_to_linear, sizeof t->srgb_to_linear, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d.l2s, t->linear_to_srgb, sizeof t->linear_to_srgb, hipMemcpyHostToDevice));
-        it = g_sc_tables.emplace(dev, d).first;
-    }
-    *out = it->second;
-    return IFHIP_OK;
-}
-}  // namespace
 
 extern "C" {
 

@@ -151,18 +151,28 @@ IFHIP_API int ifhip_apply_matte_batch_device(uint8_t* d_bgra, size_t image_bytes
  *   coef[c]   int16 [blocks_h_c][blocks_w_c][64], natural (de-zigzagged) order, quantised;
  *             blocks_w_c = ceil(width / (8*hmax)) * h_samp[c], blocks_h_c likewise (MCU padded, as libjpeg's arrays)
  *   qt        uint16 [n_components][64], natural order (JQUANT_TBL.quantval)
- * Supported sampling: grayscale, 4:4:4, 4:2:2 (h2v1), 4:2:0 (h2v2).  Full-size decode (scale_num = 8) only.
+ * scale_num / luma_spatial / luma_srgb are what MzDec::apply_downscaling (:588-618) and DecoderDownscaleHints
+ * (ffi/c_interop.rs:6-15) set: libjpeg's scale_num/8 and whether the luma component goes through imageflow's
+ * flow_scale_spatial[_srgb]_NxN block scalers (codec_jpeg_wrapper.c:274-343) instead of libjpeg's reduced IDCT.
+ * Supported: scale_num 8 (grayscale, 4:4:4, 4:2:2, 4:2:0) and 1, 2, 4 (grayscale, 4:4:4, 4:2:0 -- jidctred.c's
+ * 4x4/2x2/1x1 IDCTs, sub-sampled chroma taking the twice-larger IDCT as jdmaster.c prescribes); 3, 5, 6 are not
+ * implemented (the caller decodes at 8 and resamples).  The output bitmap is ceil(width*scale_num/8) x
+ * ceil(height*scale_num/8).
  */
 IFHIP_API int ifhip_jpeg_idct_color(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2,
                                     const uint16_t* qt, int n_components,
                                     const uint8_t* h_samp, const uint8_t* v_samp,
-                                    uint32_t width, uint32_t height, uint8_t* bgra, uint32_t stride);
+                                    uint32_t width, uint32_t height,
+                                    int scale_num, int luma_spatial, int luma_srgb,
+                                    uint8_t* bgra, uint32_t stride);
 
 /* Device-resident batch of equally shaped frames.  The stage object owns the component planes between the two
  * kernels.  d_coef[c]: image i at d_coef[c] + i * blocks_w_c*blocks_h_c*64; d_qt: [n_images][n_components][64]. */
 typedef struct ifhip_jpeg_stage ifhip_jpeg_stage;
 IFHIP_API int ifhip_jpeg_stage_create(ifhip_jpeg_stage** stage, uint32_t width, uint32_t height, int n_components,
-                                      const uint8_t* h_samp, const uint8_t* v_samp, uint32_t max_images);
+                                      const uint8_t* h_samp, const uint8_t* v_samp,
+                                      int scale_num, int luma_spatial, int luma_srgb, uint32_t max_images);
+IFHIP_API int ifhip_jpeg_stage_output_size(const ifhip_jpeg_stage* stage, uint32_t* out_w, uint32_t* out_h);
 IFHIP_API void ifhip_jpeg_stage_destroy(ifhip_jpeg_stage* stage);
 IFHIP_API int ifhip_jpeg_stage_block_dims(const ifhip_jpeg_stage* stage, uint32_t* blocks_w3, uint32_t* blocks_h3);
 IFHIP_API int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d_coef0,

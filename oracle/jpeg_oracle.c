@@ -458,3 +458,187 @@ int jo_jpeg_idct_color(const int16_t* coef0, const int16_t* coef1, const int16_t
     for (int c = 0; c < ncomp; c++) free(plane[c]);
     return JO_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Reduced-size decode (scale_num/8, scale_num in {1,2,4})                                           */
+/*                                                                                                  */
+/* libjpeg's reduced-size inverse DCTs (jidctred.c: jpeg_idct_4x4 / 2x2 / 1x1) and its rule for      */
+/* picking each component's IDCT size (jdmaster.c: a sub-sampled component takes an IDCT twice as    */
+/* large instead of being up-sampled).  With imageflow's selector installed the luma component uses  */
+/* islow + flow_scale_spatial[_srgb]_NxN instead (codec_jpeg_wrapper.c:274-343).                     */
+/* Pin: luma_mode 0 against Pillow's draft-mode decode; the spatial scalers against the reference's   */
+/* own compiled functions.                                                                          */
+/* ------------------------------------------------------------------------------------------------ */
+#define FIX_0_211164243 1730
+#define FIX_0_509795579 4176
+#define FIX_0_601344887 4926
+#define FIX_0_720959822 5906
+#define FIX_0_850430095 6967
+#define FIX_1_061594337 8697
+#define FIX_1_272758580 10426
+#define FIX_1_451774981 11893
+#define FIX_2_172734803 17799
+#define FIX_3_624509785 29692
+
+void jo_idct_4x4_block(const int16_t* in, const uint16_t* q, uint8_t* out, int out_stride) {
+    int32_t ws[8 * 4];
+    for (int col = 0; col < 8; col++) {
+        if (col == 4) continue;                              /* column 4 is not used by the second pass */
+        const int16_t* c = in + col;
+        const uint16_t* qq = q + col;
+        int32_t* w = ws + col;
+        if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
+            int32_t dc = (int32_t)((uint32_t)(c[0] * qq[0]) << PASS1_BITS);
+            w[0] = w[8] = w[16] = w[24] = dc;
+            continue;
+        }
+        int32_t tmp0 = (int32_t)((uint32_t)(c[0] * qq[0]) << (CONST_BITS + 1));
+        int32_t z2 = c[16] * qq[16], z3 = c[48] * qq[48];
+        int32_t tmp2 = z2 * FIX_1_847759065 + z3 * (-FIX_0_765366865);
+        int32_t tmp10 = tmp0 + tmp2, tmp12 = tmp0 - tmp2;
+        int32_t z1 = c[56] * qq[56];
+        z2 = c[40] * qq[40]; z3 = c[24] * qq[24];
+        int32_t z4 = c[8] * qq[8];
+        tmp0 = z1 * (-FIX_0_211164243) + z2 * FIX_1_451774981 + z3 * (-FIX_2_172734803) + z4 * FIX_1_061594337;
+        tmp2 = z1 * (-FIX_0_509795579) + z2 * (-FIX_0_601344887) + z3 * FIX_0_899976223 + z4 * FIX_2_562915447;
+        w[0]  = DESCALE(tmp10 + tmp2, CONST_BITS - PASS1_BITS + 1);
+        w[24] = DESCALE(tmp10 - tmp2, CONST_BITS - PASS1_BITS + 1);
+        w[8]  = DESCALE(tmp12 + tmp0, CONST_BITS - PASS1_BITS + 1);
+        w[16] = DESCALE(tmp12 - tmp0, CONST_BITS - PASS1_BITS + 1);
+    }
+    for (int row = 0; row < 4; row++) {
+        const int32_t* w = ws + 8 * row;
+        uint8_t* o = out + (size_t)row * out_stride;
+        int32_t tmp0 = (int32_t)((uint32_t)w[0] << (CONST_BITS + 1));
+        int32_t tmp2 = w[2] * FIX_1_847759065 + w[6] * (-FIX_0_765366865);
+        int32_t tmp10 = tmp0 + tmp2, tmp12 = tmp0 - tmp2;
+        int32_t z1 = w[7], z2 = w[5], z3 = w[3], z4 = w[1];
+        tmp0 = z1 * (-FIX_0_211164243) + z2 * FIX_1_451774981 + z3 * (-FIX_2_172734803) + z4 * FIX_1_061594337;
+        tmp2 = z1 * (-FIX_0_509795579) + z2 * (-FIX_0_601344887) + z3 * FIX_0_899976223 + z4 * FIX_2_562915447;
+        const int S = CONST_BITS + PASS1_BITS + 3 + 1;
+        o[0] = range_limit(DESCALE(tmp10 + tmp2, S));
+        o[3] = range_limit(DESCALE(tmp10 - tmp2, S));
+        o[1] = range_limit(DESCALE(tmp12 + tmp0, S));
+        o[2] = range_limit(DESCALE(tmp12 - tmp0, S));
+    }
+}
+
+void jo_idct_2x2_block(const int16_t* in, const uint16_t* q, uint8_t* out, int out_stride) {
+    int32_t ws[8 * 2];
+    for (int col = 0; col < 8; col++) {
+        if (col == 2 || col == 4 || col == 6) continue;      /* even columns other than 0 are not used */
+        const int16_t* c = in + col;
+        const uint16_t* qq = q + col;
+        int32_t* w = ws + col;
+        if (c[8] == 0 && c[24] == 0 && c[40] == 0 && c[56] == 0) {
+            int32_t dc = (int32_t)((uint32_t)(c[0] * qq[0]) << PASS1_BITS);
+            w[0] = w[8] = dc;
+            continue;
+        }
+        int32_t tmp10 = (int32_t)((uint32_t)(c[0] * qq[0]) << (CONST_BITS + 2));
+        int32_t tmp0 = (c[56] * qq[56]) * (-FIX_0_720959822) + (c[40] * qq[40]) * FIX_0_850430095
+                       + (c[24] * qq[24]) * (-FIX_1_272758580) + (c[8] * qq[8]) * FIX_3_624509785;
+        w[0] = DESCALE(tmp10 + tmp0, CONST_BITS - PASS1_BITS + 2);
+        w[8] = DESCALE(tmp10 - tmp0, CONST_BITS - PASS1_BITS + 2);
+    }
+    for (int row = 0; row < 2; row++) {
+        const int32_t* w = ws + 8 * row;
+        uint8_t* o = out + (size_t)row * out_stride;
+        int32_t tmp10 = (int32_t)((uint32_t)w[0] << (CONST_BITS + 2));
+        int32_t tmp0 = w[7] * (-FIX_0_720959822) + w[5] * FIX_0_850430095 + w[3] * (-FIX_1_272758580) + w[1] * FIX_3_624509785;
+        const int S = CONST_BITS + PASS1_BITS + 3 + 2;
+        o[0] = range_limit(DESCALE(tmp10 + tmp0, S));
+        o[1] = range_limit(DESCALE(tmp10 - tmp0, S));
+    }
+}
+
+void jo_idct_1x1_block(const int16_t* in, const uint16_t* q, uint8_t* out) {
+    out[0] = range_limit(DESCALE((int32_t)in[0] * (int32_t)q[0], 3));
+}
+
+/* flow_scale_spatial[_srgb]_NxN semantics over caller-provided tables (tests load them from
+ * tests/golden/block_scaler_tables.npz, i.e. from the reference's own file). */
+void jo_scale_spatial_block(const uint8_t* in /* 8x8, stride in_stride */, int in_stride, int n, int srgb,
+                            const int8_t* w7x8, const uint8_t* log2div7, const uint16_t* s2l, const uint8_t* l2s,
+                            uint8_t* out, int out_stride) {
+    for (int r = 0; r < n; r++) {
+        int32_t v[8];
+        for (int j = 0; j < 8; j++) {
+            int32_t s = 0;
+            for (int i = 0; i < 8; i++) {
+                int32_t p = in[i * in_stride + j];
+                s += (int32_t)w7x8[r * 8 + i] * (srgb ? (int32_t)s2l[p] : p);
+            }
+            v[j] = s;
+        }
+        for (int c = 0; c < n; c++) {
+            int sh = log2div7[r] + log2div7[c];
+            int32_t sum = (int32_t)1 << (sh - 1);
+            for (int j = 0; j < 8; j++) sum += v[j] * (int32_t)w7x8[c * 8 + j];
+            uint8_t o;
+            if (sum < 0) o = 0;
+            else if ((uint32_t)sum >= ((uint32_t)4096 << sh)) o = 255;
+            else o = srgb ? l2s[sum >> sh] : (uint8_t)(sum >> sh);
+            out[r * out_stride + c] = o;
+        }
+    }
+}
+
+/*
+ * Reduced-size pixel stage.  scale_num in {1,2,4}; luma_mode: 0 libjpeg's own reduced IDCT, 1 flow_scale_spatial,
+ * 2 flow_scale_spatial_srgb (the reference's default when scaled).  Supported: grayscale, 4:4:4, 4:2:0.
+ * Output size: ceil(width*scale_num/8) x ceil(height*scale_num/8) (jdmaster.c jpeg_calc_output_dimensions).
+ */
+int jo_jpeg_idct_color_scaled(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2, const uint16_t* qt,
+                              int ncomp, const uint8_t* hs, const uint8_t* vs, uint32_t width, uint32_t height,
+                              int scale_num, int luma_mode,
+                              const int8_t* w7x8, const uint8_t* log2div7, const uint16_t* s2l12, const uint8_t* l2s12,
+                              uint8_t* bgra, uint32_t stride) {
+    build_ycc();
+    if (scale_num != 1 && scale_num != 2 && scale_num != 4) return JO_ERR_UNSUPPORTED;
+    const int16_t* coef[3] = {coef0, coef1, coef2};
+    int hmax = 1, vmax = 1;
+    for (int c = 0; c < ncomp; c++) { if (hs[c] > hmax) hmax = hs[c]; if (vs[c] > vmax) vmax = vs[c]; }
+    int is420 = ncomp == 3 && hmax == 2 && vmax == 2 && hs[0] == 2 && vs[0] == 2 && hs[1] == 1 && vs[1] == 1 && hs[2] == 1 && vs[2] == 1;
+    int is444 = ncomp == 3 && hmax == 1 && vmax == 1;
+    if (!(ncomp == 1 || is420 || is444)) return JO_ERR_UNSUPPORTED;
+    uint32_t ow = (width * (uint32_t)scale_num + 7) / 8, oh = (height * (uint32_t)scale_num + 7) / 8;
+    uint32_t mw = (width + 8u * hmax - 1) / (8u * hmax), mh = (height + 8u * vmax - 1) / (8u * vmax);
+    uint8_t* plane[3] = {0, 0, 0};
+    uint32_t pw[3];
+    for (int c = 0; c < ncomp; c++) {
+        /* jdmaster.c: a component sub-sampled 2x in both directions takes an IDCT twice as large, no up-sampling */
+        int n = (c > 0 && is420) ? scale_num * 2 : scale_num;
+        uint32_t bw = mw * hs[c], bh = mh * vs[c];
+        pw[c] = bw * (uint32_t)n;
+        plane[c] = (uint8_t*)malloc((size_t)pw[c] * bh * n);
+        if (!plane[c]) { for (int k = 0; k < c; k++) free(plane[k]); return JO_ERR_ALLOC; }
+        for (uint32_t by = 0; by < bh; by++)
+            for (uint32_t bx = 0; bx < bw; bx++) {
+                const int16_t* blk = coef[c] + 64 * ((size_t)by * bw + bx);
+                uint8_t* dst = plane[c] + (size_t)by * n * pw[c] + (size_t)bx * n;
+                if (c == 0 && luma_mode != 0) {
+                    uint8_t full[64];
+                    jo_idct_islow_block(blk, qt, full, 8);
+                    jo_scale_spatial_block(full, 8, n, luma_mode == 2, w7x8, log2div7, s2l12, l2s12, dst, (int)pw[c]);
+                } else if (n == 8) jo_idct_islow_block(blk, qt + 64 * c, dst, (int)pw[c]);
+                else if (n == 4) jo_idct_4x4_block(blk, qt + 64 * c, dst, (int)pw[c]);
+                else if (n == 2) jo_idct_2x2_block(blk, qt + 64 * c, dst, (int)pw[c]);
+                else jo_idct_1x1_block(blk, qt + 64 * c, dst);
+            }
+    }
+    for (uint32_t y = 0; y < oh; y++) {
+        uint8_t* o = bgra + (size_t)y * stride;
+        for (uint32_t x = 0; x < ow; x++) {
+            int32_t Y = plane[0][(size_t)y * pw[0] + x];
+            if (ncomp == 1) { o[4 * x] = o[4 * x + 1] = o[4 * x + 2] = (uint8_t)Y; o[4 * x + 3] = 255; continue; }
+            int32_t cbv = plane[1][(size_t)y * pw[1] + x], crv = plane[2][(size_t)y * pw[2] + x];
+            o[4 * x + 2] = clamp255(Y + cr_r[crv]);
+            o[4 * x + 1] = clamp255(Y + ((cb_g[cbv] + cr_g[crv]) >> 16));
+            o[4 * x + 0] = clamp255(Y + cb_b[cbv]);
+            o[4 * x + 3] = 255;
+        }
+    }
+    for (int c = 0; c < ncomp; c++) free(plane[c]);
+    return JO_OK;
+}

@@ -74,6 +74,11 @@ def lib():
                                          C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
         L.jo_idct_islow_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.jo_idct_islow_block.restype = None
+        L.jo_jpeg_idct_color_scaled.restype = C.c_int
+        L.jo_jpeg_idct_color_scaled.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                                  C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_uint32]
+        L.jo_scale_spatial_block.restype = None
+        L.jo_scale_spatial_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
         L.ifo_init_tables()
         _LIB = L
     return _LIB
@@ -181,4 +186,48 @@ def idct_islow_block(coef64, quant64):
     c = np.ascontiguousarray(coef64, np.int16)
     q = np.ascontiguousarray(quant64, np.uint16)
     lib().jo_idct_islow_block(c.ctypes.data, q.ctypes.data, out.ctypes.data, 8)
+    return out
+
+
+_SCALER_TABLES = None
+
+
+def block_scaler_tables():
+    """The reference file's own scaler data (tests/golden/block_scaler_tables.npz, made by make_block_scaler_tables.py)."""
+    global _SCALER_TABLES
+    if _SCALER_TABLES is None:
+        z = np.load(os.path.join(_HERE, "..", "tests", "golden", "block_scaler_tables.npz"))
+        _SCALER_TABLES = {k: np.ascontiguousarray(z[k]) for k in ("weights", "log2div", "lut_s2l", "lut_l2s")}
+    return _SCALER_TABLES
+
+
+def scale_spatial_blocks(blocks, n, srgb):
+    """flow_scale_spatial[_srgb]_NxN restated over the reference's tables: uint8 [k][64] -> [k][n][n]."""
+    T = block_scaler_tables()
+    blocks = np.ascontiguousarray(blocks, np.uint8).reshape(-1, 64)
+    out = np.zeros((blocks.shape[0], n, n), np.uint8)
+    w, d = np.ascontiguousarray(T["weights"][n]), np.ascontiguousarray(T["log2div"][n])
+    for k in range(blocks.shape[0]):
+        lib().jo_scale_spatial_block(blocks[k].ctypes.data, 8, n, int(bool(srgb)), w.ctypes.data, d.ctypes.data,
+                                     T["lut_s2l"].ctypes.data, T["lut_l2s"].ctypes.data, out[k].ctypes.data, n)
+    return out
+
+
+def jpeg_idct_color_scaled(j, scale_num, luma_mode, stride=None):
+    """Reduced-size pixel stage: luma_mode 0 = libjpeg's reduced IDCT, 1 = flow_scale_spatial, 2 = ..._srgb."""
+    if scale_num == 8:
+        return jpeg_idct_color(j, stride)
+    T = block_scaler_tables()
+    w, h = j["width"], j["height"]
+    ow, oh = (w * scale_num + 7) // 8, (h * scale_num + 7) // 8
+    stride = stride or stride_for_width(ow)
+    out = np.zeros((oh, stride), np.uint8)
+    hs, vs = np.array(j["hs"], np.uint8), np.array(j["vs"], np.uint8)
+    wn, dn = np.ascontiguousarray(T["weights"][scale_num]), np.ascontiguousarray(T["log2div"][scale_num])
+    rc = lib().jo_jpeg_idct_color_scaled(j["coef"][0].ctypes.data, j["coef"][1].ctypes.data, j["coef"][2].ctypes.data,
+                                         j["qt"].ctypes.data, j["ncomp"], hs.ctypes.data, vs.ctypes.data, w, h, scale_num,
+                                         luma_mode, wn.ctypes.data, dn.ctypes.data, T["lut_s2l"].ctypes.data,
+                                         T["lut_l2s"].ctypes.data, out.ctypes.data, stride)
+    if rc:
+        raise RuntimeError(f"jpeg oracle: scaled pixel stage rc={rc}")
     return out

@@ -35,6 +35,13 @@ def main():
             ref = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
             out[f"jpg_{i}"] = np.frombuffer(data, np.uint8)
             out[f"rgb_{i}"] = ref
+            if sub in ("4:2:0", "4:4:4"):          # libjpeg's reduced-size decode (draft mode): scale 4/8, 2/8, 1/8
+                for denom, num in ((2, 4), (4, 2), (8, 1)):
+                    im = Image.open(io.BytesIO(data))
+                    im.draft("RGB", (max(1, w // denom), max(1, h // denom)))
+                    d = np.asarray(im.convert("RGB"))
+                    if d.shape[:2] == ((h * num + 7) // 8, (w * num + 7) // 8):
+                        out[f"rgb_{i}_s{num}"] = d
             names.append(f"{w}x{h}_{kind}_{sub}_q{q}")
             i += 1
     buf = io.BytesIO()

@@ -96,3 +96,82 @@ def test_unsupported_and_invalid_arguments():
     with pytest.raises(FlowError) as e:
         JpegPixelStage(16, 16, 4, (1, 1, 1), (1, 1, 1), 1, DEV)          # CMYK stays on the CPU path
     assert e.value.kind == ErrorKind.MethodNotImplemented
+
+
+# ---- reduced-size decode (scale_num 4, 2, 1) ---------------------------------------------------------------------
+def run_stage_scaled(js, scale_num, luma_mode):
+    j0 = js[0]
+    st = JpegPixelStage(j0["width"], j0["height"], j0["ncomp"], j0["hs"], j0["vs"], len(js), DEV, scale_num=scale_num,
+                        luma_spatial=luma_mode != 0, luma_srgb=luma_mode == 2)
+    coef = [torch.from_numpy(np.stack([j["coef"][c] for j in js])).to(DEV) for c in range(j0["ncomp"])]
+    qt = torch.from_numpy(np.stack([j["qt"][:j0["ncomp"]] for j in js]).astype(np.int16)).to(DEV)
+    out = st.read_frames(coef, qt)
+    torch.cuda.synchronize()
+    assert (out.w, out.h) == ((j0["width"] * scale_num + 7) // 8, (j0["height"] * scale_num + 7) // 8)
+    return out.to_numpy()
+
+
+@pytest.mark.parametrize("scale_num", [4, 2, 1])
+@pytest.mark.parametrize("luma_mode", [0, 1, 2])
+def test_reduced_size_decode_committed_files(golden_dir, scale_num, luma_mode):
+    z = np.load(os.path.join(golden_dir, "jpeg_cases.npz"))
+    n_checked = 0
+    for i, name in enumerate(z["names"]):
+        j = O.jpeg_read_coefficients(z[f"jpg_{i}"].tobytes())
+        if "4:2:2" in str(name):
+            continue
+        exp = O.jpeg_idct_color_scaled(j, scale_num, luma_mode)
+        got = run_stage_scaled([j], scale_num, luma_mode)[0]
+        assert np.array_equal(got, exp), (str(name), scale_num, luma_mode)
+        key = f"rgb_{i}_s{scale_num}"
+        if luma_mode == 0 and key in z.files:          # libjpeg's own reduced IDCT: equals Pillow's draft-mode decode
+            oh, ow = z[key].shape[:2]
+            assert np.array_equal(got[:, : 4 * ow].reshape(oh, ow, 4)[..., [2, 1, 0]], z[key]), str(name)
+        n_checked += 1
+    assert n_checked >= 25
+
+
+@pytest.mark.parametrize("hs,vs,ncomp", [((2, 1, 1), (2, 1, 1), 3), ((1, 1, 1), (1, 1, 1), 3), ((1, 0, 0), (1, 0, 0), 1)])
+def test_reduced_size_random_coefficients_and_4k(hs, vs, ncomp):
+    rng = np.random.default_rng(17 + ncomp)
+    for (w, h) in ((129, 67), (16, 8), (1, 1), (3840, 2160) if ncomp == 3 and hs[0] == 2 else (333, 100)):
+        js = [_random_case(rng, w, h, hs, vs, ncomp, 200) for _ in range(2)]
+        for scale_num, luma_mode in ((4, 2), (2, 1), (1, 2), (4, 0), (1, 0)):
+            got = run_stage_scaled(js, scale_num, luma_mode)
+            for k, j in enumerate(js):
+                assert np.array_equal(got[k], O.jpeg_idct_color_scaled(j, scale_num, luma_mode)), (w, h, scale_num, luma_mode, k)
+
+
+def test_reference_default_preshrink_path_cfg1():
+    """BASELINE config 1 as the reference runs it: 3840x2160 `width=200` -> hints pick scale 1/8 with
+    spatial sRGB luma -> 480x270, then Resample2D to 200x113."""
+    from imageflow_amd.codecs.mozjpeg_decoder import apply_downscaling, idct_method_for_luma
+    from imageflow_amd.graphics.bitmaps import Bitmap
+    from imageflow_amd.graphics.scaling import ScaleAndRenderParams, scale_and_render
+    from tests import util as U
+    rng = np.random.default_rng(8)
+    j = _random_case(rng, 3840, 2160, (2, 1, 1), (2, 1, 1), 3, 40)
+    num, w, h = apply_downscaling(3840, 2160, 420, 236, 420, 236)
+    assert (num, w, h) == (1, 480, 270) and idct_method_for_luma(num, True, True) == ("spatial_srgb", 1)
+    st = JpegPixelStage(3840, 2160, 3, j["hs"], j["vs"], 1, DEV, scale_num=num, luma_spatial=True, luma_srgb=True)
+    coef = [torch.from_numpy(j["coef"][c][None]).to(DEV) for c in range(3)]
+    qt = torch.from_numpy(j["qt"][None].astype(np.int16)).to(DEV)
+    decoded = st.read_frames(coef, qt)
+    out = Bitmap.create_u8(1, 200, 113, DEV)
+    scale_and_render(decoded, out, ScaleAndRenderParams(0, 0, 200, 113))
+    torch.cuda.synchronize()
+    exp_dec = O.jpeg_idct_color_scaled(j, 1, 2)
+    assert np.array_equal(decoded.to_numpy()[0], exp_dec)
+    exp = np.zeros((1, 113, U.stride_for(200)), np.uint8)
+    U.oracle_render(exp_dec[None], 480, 270, exp, 200, 113, 0, 0, 200, 113)
+    assert np.array_equal(out.to_numpy(), exp)
+
+
+def test_unsupported_scales():
+    for bad in (3, 5, 6, 7, 0, 9):
+        with pytest.raises(FlowError) as e:
+            JpegPixelStage(64, 64, 3, (2, 1, 1), (2, 1, 1), 1, DEV, scale_num=bad)
+        assert e.value.kind == ErrorKind.MethodNotImplemented
+    with pytest.raises(FlowError) as e:
+        JpegPixelStage(64, 64, 3, (2, 1, 1), (1, 1, 1), 1, DEV, scale_num=4)        # 4:2:2 reduced
+    assert e.value.kind == ErrorKind.MethodNotImplemented

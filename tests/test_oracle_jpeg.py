@@ -89,3 +89,32 @@ def test_reference_block_scalers_golden_is_self_consistent(golden_dir):
                 fn(blk.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ptrs, ctypes.c_uint32(0))
                 got = np.stack([r[:n] for r in rows])
                 assert np.array_equal(got, z[name][b])
+
+
+def test_reduced_size_decode_equals_libjpeg_turbo_draft_mode(cases):
+    """scale_num 4, 2, 1 with libjpeg's own reduced IDCTs (luma_mode 0): jidctred.c's 4x4 / 2x2 / 1x1 and jdmaster.c's
+    'sub-sampled chroma takes the twice-larger IDCT' rule, pinned byte for byte by Pillow's draft-mode decode."""
+    z, names = cases
+    checked = 0
+    for i, name in enumerate(names):
+        j = None
+        for num in (4, 2, 1):
+            key = f"rgb_{i}_s{num}"
+            if key not in z.files:
+                continue
+            j = j or O.jpeg_read_coefficients(z[f"jpg_{i}"].tobytes())
+            ref = z[key]
+            oh, ow = ref.shape[:2]
+            out = O.jpeg_idct_color_scaled(j, num, 0)
+            assert np.array_equal(out[:, : 4 * ow].reshape(oh, ow, 4)[..., [2, 1, 0]], ref), (name, num)
+            checked += 1
+    assert checked >= 60
+
+
+def test_spatial_block_scaler_restatement_equals_reference_outputs(golden_dir):
+    """jo_scale_spatial_block over the reference's tables == the reference's compiled functions (committed outputs)."""
+    z = np.load(os.path.join(golden_dir, "ref_block_scalers.npz"))
+    for srgb in (0, 1):
+        for n in range(1, 8):
+            name = f"flow_scale_spatial_{'srgb_' if srgb else ''}{n}x{n}"
+            assert np.array_equal(O.scale_spatial_blocks(z["blocks"], n, srgb), z[name]), name
