@@ -118,7 +118,7 @@ struct ifhip_resample_plan {
     } sets[2];                       // [in_alpha_meaningful]
     // lazily built, guarded by mu
     mutable std::mutex mu;
-    mutable std::map<uint32_t, ScheduleOnDevice> schedules;
+    mutable std::map<uint64_t, ScheduleOnDevice> schedules;     // key: bands | group << 32 | ahead << 40
     mutable float4* scratch = nullptr;
     mutable size_t scratch_bytes = 0;
 
@@ -137,9 +137,10 @@ struct ifhip_resample_plan {
 namespace {
 
 size_t fused_lds_bytes(uint32_t n_u, uint32_t nquads, int channels, uint32_t wu_floats = 0, bool w_in_lds = false,
-                       bool l2s_in_lds = false) {
-    return fused_lds_layout(n_u, nquads, wu_floats, channels, w_in_lds, l2s_in_lds).total;
+                       bool l2s_in_lds = false, uint32_t lut_copies_log2 = 5) {
+    return fused_lds_layout(n_u, nquads, wu_floats, channels, w_in_lds, l2s_in_lds, lut_copies_log2).total;
 }
+constexpr uint32_t kMinLutCopiesLog2 = 4;      // never fewer than 16 copies of the sRGB->float table (2-way conflicts)
 
 // Split the output columns into strips whose staged source span fits one workgroup (max_lanes lanes x 4 px)
 // and whose minimal LDS footprint fits the CU.
@@ -161,7 +162,7 @@ bool plan_strips(const AxisWeights& wh, uint32_t max_lanes, int channels, std::v
             t.cx0 = lo & ~3u;
             t.nquads = (hi - t.cx0 + 3u) / 4u;
             if (t.nquads > max_lanes || (t.u1 - t.u0) > kMaxStripOutputs) ok = false;
-            if (fused_lds_bytes(t.u1 - t.u0, t.nquads, channels) > kLdsLimit) ok = false;
+            if (fused_lds_bytes(t.u1 - t.u0, t.nquads, channels, 0, false, false, kMinLutCopiesLog2) > kLdsLimit) ok = false;
             mq = std::max(mq, t.nquads);
             s.push_back(t);
         }
@@ -171,12 +172,13 @@ bool plan_strips(const AxisWeights& wh, uint32_t max_lanes, int channels, std::v
     return false;
 }
 
-int get_schedule(const ifhip_resample_plan* p, uint32_t n_bands, ScheduleOnDevice* out) {
+int get_schedule(const ifhip_resample_plan* p, uint32_t n_bands, int group, int ahead, ScheduleOnDevice* out) {
     std::lock_guard<std::mutex> lk(p->mu);
-    auto it = p->schedules.find(n_bands);
+    const uint64_t key = static_cast<uint64_t>(n_bands) | (static_cast<uint64_t>(group) << 32) | (static_cast<uint64_t>(ahead) << 40);
+    auto it = p->schedules.find(key);
     if (it == p->schedules.end()) {
         VSchedule s;
-        if (!build_vschedule(p->wv, static_cast<int>(n_bands), &s))
+        if (!build_vschedule(p->wv, static_cast<int>(n_bands), group, ahead, &s))
             return fail(IFHIP_INVALID_STATE, "InvalidState: vertical schedule could not be built");
         ScheduleOnDevice d;
         d.n_bands = static_cast<uint32_t>(s.band_begin.size() - 1);
@@ -184,7 +186,7 @@ int get_schedule(const ifhip_resample_plan* p, uint32_t n_bands, ScheduleOnDevic
         if (rc) return rc;
         rc = upload(s.band_begin, &d.band_begin);
         if (rc) return rc;
-        it = p->schedules.emplace(n_bands, d).first;
+        it = p->schedules.emplace(key, d).first;
     }
     *out = it->second;
     return IFHIP_OK;
@@ -195,12 +197,20 @@ uint32_t choose_bands(const ifhip_resample_plan* p, uint32_t n_images, size_t n_
         const int v = std::atoi(e);
         if (v >= 1) return std::min<uint32_t>(static_cast<uint32_t>(v), p->out_h);
     }
-    // enough workgroups to cover 256 CUs twice over; a band re-reads its halo rows, so no more than needed
-    const uint64_t wgs = static_cast<uint64_t>(n_images) * n_strips;
-    uint32_t bands = 1;
-    if (wgs < 512) bands = static_cast<uint32_t>((512 + wgs - 1) / wgs);
-    const uint32_t max_bands = std::max<uint32_t>(1u, p->out_h / 4u);
-    return std::max<uint32_t>(1u, std::min(bands, max_bands));
+    // One workgroup occupies a CU (LDS), so a launch runs in ceil(workgroups / 256) rounds.  Cutting frames into bands
+    // of output rows makes the rounds finer but every extra band re-reads its halo of source rows; pick the band count
+    // with the smallest estimated time.
+    const double wgs = static_cast<double>(n_images) * static_cast<double>(n_strips);
+    const double halo = p->out_h ? static_cast<double>(p->wv.max_taps) / std::max<double>(1.0, p->in_h) : 0.0;
+    const uint32_t max_bands = std::max<uint32_t>(1u, std::min<uint32_t>(16u, p->out_h / 4u));
+    uint32_t best = 1;
+    double best_cost = 1e300;
+    for (uint32_t b = 1; b <= max_bands; ++b) {
+        const double rounds = std::ceil(wgs * b / 256.0);
+        const double cost = rounds / b * (1.0 + halo * (b - 1));
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = b; }
+    }
+    return best;
 }
 
 bool fused_usable(const ifhip_resample_plan* p, int alpha, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride) {
@@ -276,24 +286,29 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         const ifhip_resample_plan::StripSet& ss = p->sets[alpha ? 1 : 0];
         const uint32_t want_bands = choose_bands(p, n_images, ss.strips.size());
         ScheduleOnDevice sd;
-        rc = get_schedule(p, want_bands, &sd);
+        const int channels_k = alpha ? 4 : 3;
+        rc = get_schedule(p, want_bands, fused_shape(p->slots, channels_k).rows_in_flight, fused_lookahead(p->slots, channels_k), &sd);
         if (rc) return rc;
         a.steps = sd.steps; a.band_begin = sd.band_begin; a.n_bands = sd.n_bands;
         a.strips = ss.d_strips; a.n_strips = static_cast<uint32_t>(ss.strips.size());
         const int channels = alpha ? 4 : 3;
-        // LDS budget, in priority order: banked LUT + double-buffered rows (always), the de-duplicated horizontal
-        // weight rows, then the 16 KiB linear->sRGB table (otherwise encoded by threshold search)
-        bool w_in_lds = std::getenv("IFHIP_HW_GLOBAL") == nullptr;
-        for (const Strip& s : ss.strips)
-            if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, true) > kLdsLimit) w_in_lds = false;
-        bool l2s_in_lds = std::getenv("IFHIP_L2S_SEARCH") == nullptr;
-        for (const Strip& s : ss.strips)
-            if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w_in_lds, true) > kLdsLimit) l2s_in_lds = false;
+        // LDS budget, in priority order: double-buffered rows + >= 16 copies of the sRGB->float table (always; the strips
+        // were planned for that), the de-duplicated horizontal weight rows, one table copy per bank (32), then the
+        // 16 KiB linear->sRGB table (otherwise encoded by threshold search)
+        auto fits = [&](bool w, bool l2s, uint32_t copies_log2) {
+            for (const Strip& s : ss.strips)
+                if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w, l2s, copies_log2) > kLdsLimit) return false;
+            return true;
+        };
+        const bool w_in_lds = std::getenv("IFHIP_HW_GLOBAL") == nullptr && fits(true, false, kMinLutCopiesLog2);
+        const uint32_t copies_log2 = fits(w_in_lds, false, 5) ? 5u : kMinLutCopiesLog2;
+        const bool l2s_in_lds = std::getenv("IFHIP_L2S_SEARCH") == nullptr && fits(w_in_lds, true, copies_log2);
+        a.lut_copies_log2 = copies_log2;
         a.h_w_in_lds = w_in_lds ? 1u : 0u;
         a.l2s_in_lds = l2s_in_lds ? 1u : 0u;
         size_t lds = 0;
         for (const Strip& s : ss.strips)
-            lds = std::max(lds, fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w_in_lds, l2s_in_lds));
+            lds = std::max(lds, fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w_in_lds, l2s_in_lds, copies_log2));
         if (lds > kLdsLimit) return fail(IFHIP_INVALID_STATE, "InvalidState: fused kernel LDS plan exceeds the CU (%zu bytes)", lds);
         const uint32_t block = std::max<uint32_t>(64u, (ss.max_quads + 63u) & ~63u);
         const uint64_t grid = static_cast<uint64_t>(n_images) * sd.n_bands * a.n_strips;
@@ -455,7 +470,7 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
 
     p->slots = max_live_rows(p->wv);
     VSchedule probe;
-    p->fused_possible = p->slots >= 1 && p->slots <= kMaxSlots && build_vschedule(p->wv, 1, &probe);
+    p->fused_possible = p->slots >= 1 && p->slots <= kMaxSlots && build_vschedule(p->wv, 1, 4, 5, &probe);
     for (int al = 0; al < 2 && p->fused_possible; ++al) {
         const int channels = al ? 4 : 3;
         ifhip_resample_plan::StripSet& ss = p->sets[al];

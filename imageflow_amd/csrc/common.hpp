@@ -69,7 +69,7 @@ struct alignas(64) VStep {
     int32_t flush_slot;   // ring slot completed by this step (-1: none)
     int32_t out_row;      // output row index held by flush_slot
     float w[kMaxSlots];
-    int32_t y_ahead;      // source row of step i+1+kPrefetchRows of the same band (-1: none): the load issued at step i
+    int32_t y_ahead;      // source row of step i+ahead of the same band (-1: none): the load issued at step i
     int32_t pad[3];
 };
 static_assert(sizeof(VStep) == 64, "VStep must be one 64-byte scalar-load line");
@@ -81,7 +81,9 @@ struct VSchedule {
 };
 // Split out rows [0, n_out) into n_bands contiguous bands and emit the step list of each.
 // Returns false if more than kMaxSlots rows are live at once (caller uses the generic kernels).
-bool build_vschedule(const AxisWeights& wv, int n_bands, VSchedule* out);
+// `group`: bands are padded to a multiple of `group` steps (the kernel's unroll); `ahead`: steps[i].y_ahead = row of step
+// i + ahead (the load the kernel issues while working on step i).
+bool build_vschedule(const AxisWeights& wv, int n_bands, int group, int ahead, VSchedule* out);
 int max_live_rows(const AxisWeights& wv);
 
 }  // namespace ifhip

@@ -36,6 +36,7 @@ struct ResampleArgs {
     uint32_t h_wu_floats;            // size of h_wu
     uint32_t h_w_in_lds;             // 1: h_wu is staged in LDS
     uint32_t l2s_in_lds;             // 1: the 16 KiB linear->sRGB table is staged in LDS (else threshold search)
+    uint32_t lut_copies_log2;        // the sRGB->float table is replicated 2^n times in LDS (5: one copy per bank)
     // generic-kernel tables
     const uint32_t* h_left;
     const uint32_t* h_count;
@@ -55,10 +56,22 @@ struct ResampleArgs {
     uint32_t n_images;
 };
 
-// Workgroup width of the fused kernel for a ring of K rows and C channels per pixel.  The vertical accumulators alone
-// take K*4*C registers per lane; up to 52 of them fit the 128-register budget of a 1024-lane workgroup (4 waves per
-// SIMD), beyond that the kernel is built for 512 lanes (256 registers, 2 waves per SIMD) and strips get narrower.
-constexpr int fused_max_threads(int K, int channels) { return (K * 4 * channels <= 52) ? 1024 : 512; }
+// Shape of the fused kernel for a ring of K rows and C channels per pixel.  The vertical accumulators alone take
+// K*4*C registers per lane.  Three shapes, picked by a register estimate (checked against the compiler's report):
+//   wide + pipelined : 1024 lanes (128 registers), D = 4 rows in flight, converted samples double buffered
+//   wide + plain     : 1024 lanes, D = 2, no double buffering (register-heavier rings, e.g. K = 4 with alpha)
+//   narrow           : 512 lanes (256 registers), D = 4, pipelined; strips get narrower
+struct FusedShape { int threads, rows_in_flight, pipelined; };
+constexpr FusedShape fused_shape(int K, int channels) {
+    return (K * 4 * channels + 2 * 4 * channels + 4 * 4 + 30 <= 120) ? FusedShape{1024, 4, 1}
+         : (K * 4 * channels + 4 * channels + 4 * 2 + 30 <= 124)      ? FusedShape{1024, 2, 0}
+                                                                      : FusedShape{512, 4, 1};
+}
+constexpr int fused_max_threads(int K, int channels) { return fused_shape(K, channels).threads; }
+// the step whose row the kernel requests while working on step i (see build_vschedule)
+constexpr int fused_lookahead(int K, int channels) {
+    return fused_shape(K, channels).pipelined ? fused_shape(K, channels).rows_in_flight + 1 : fused_shape(K, channels).rows_in_flight;
+}
 
 // LDS carve of the fused kernel, shared by host (size) and device (offsets); all offsets in bytes, 16-aligned.
 struct FusedLds {
@@ -68,10 +81,10 @@ struct FusedLds {
 __host__ __device__
 #endif
 inline FusedLds fused_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t wu_floats, int channels, bool w_in_lds,
-                                 bool l2s_in_lds) {
+                                 bool l2s_in_lds, uint32_t lut_copies_log2 = 5) {
     FusedLds l;
     uint32_t off = 0;
-    l.lut = off;   off += 256u * 32u * 4u;                 // sRGB->float table, one copy per LDS bank
+    l.lut = off;   off += (256u << lut_copies_log2) * 4u;  // sRGB->float table, bank-interleaved copies
     l.thr = off;   off += 256u * 2u;                       // linear->sRGB thresholds (binary search fallback)
     l.l2s = off;   off += l2s_in_lds ? 16384u : 0u;        // linear->sRGB table
     l.hmeta = off; off += n_u * 16u;

@@ -56,8 +56,9 @@ struct OutTables {
 //    8 dependent ds_read_u16, only ~600 times per output row, and 512 B of LDS instead of 16 KiB.
 struct BankedLut {
     const float* base;      // LDS
-    uint32_t lane_off;      // lane % 32
-    __device__ __forceinline__ float operator[](uint32_t idx) const { return base[(idx << 5) + lane_off]; }
+    uint32_t lane_off;      // lane % copies
+    uint32_t shift;         // log2(copies): 5 = one copy per bank; fewer copies when LDS is short (2^(5-shift)-way worst case)
+    __device__ __forceinline__ float operator[](uint32_t idx) const { return base[(idx << shift) + lane_off]; }
 };
 struct ThresholdL2S {
     const uint16_t* thr;    // LDS, 256 entries
@@ -172,7 +173,8 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     // `steps` is a separate __restrict__ argument (not a field of `a`) so that the compiler can prove the canvas
     // stores never clobber it and keeps the per-step 64-byte records on the scalar path.
     constexpr int C = ALPHA ? 4 : 3;
-    constexpr int D = kPrefetchRows;
+    constexpr int D = fused_shape(K, C).rows_in_flight;
+    constexpr bool PIPE = fused_shape(K, C).pipelined != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const uint32_t tid = threadIdx.x;
@@ -185,7 +187,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     const Strip strip = a.strips[strip_i];
     const uint32_t n_u = strip.u1 - strip.u0;
 
-    const FusedLds L = fused_lds_layout(n_u, strip.nquads, a.h_wu_floats, C, WLDS, a.l2s_in_lds != 0);
+    const FusedLds L = fused_lds_layout(n_u, strip.nquads, a.h_wu_floats, C, WLDS, a.l2s_in_lds != 0, a.lut_copies_log2);
     float* lut_banked = reinterpret_cast<float*>(smem + L.lut);      // [256][32] floats, one copy per bank
     uint16_t* thr = reinterpret_cast<uint16_t*>(smem + L.thr);       // 256 linear->sRGB thresholds
     uint4* hmeta = reinterpret_cast<uint4*>(smem + L.hmeta);         // per output column {left - cx0, taps, w offset}
@@ -196,13 +198,13 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     const uint32_t plane_pitch = L.plane_pitch;                      // floats per channel plane
     const uint32_t obuf_stride = n_u * 4u;                           // floats
 
-    for (uint32_t i = tid; i < 256u * 32u; i += T) lut_banked[i] = a.lut_in[i >> 5];
+    for (uint32_t i = tid; i < (256u << a.lut_copies_log2); i += T) lut_banked[i] = a.lut_in[i >> a.lut_copies_log2];
     for (uint32_t i = tid; i < 256u; i += T) thr[i] = a.l2s_thr[i];
     const uint8_t* l2s_lds = a.l2s_in_lds ? smem + L.l2s : nullptr;
     if (a.l2s_in_lds)
         for (uint32_t i = tid; i < 1024u; i += T)
             reinterpret_cast<uint4*>(smem + L.l2s)[i] = reinterpret_cast<const uint4*>(a.l2s)[i];
-    const BankedLut lut{lut_banked, tid & 31u};
+    const BankedLut lut{lut_banked, tid & ((1u << a.lut_copies_log2) - 1u), a.lut_copies_log2};
     for (uint32_t i = tid; i < n_u; i += T) {
         uint4 m = a.h_meta[strip.u0 + i];
         m.x -= strip.cx0;
@@ -313,37 +315,51 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
 
     // Software pipeline over steps (one step = one source row):
     //   raw[D]  : D source rows in flight per lane (16 B each), refilled in place -> fixed registers, vmcnt(D-1)
-    //   vbuf[2] : converted floats of the current / the next step; the 12-16 LUT reads of step i+1 are issued before
-    //             the FMAs of step i, so their LDS latency hides under the lane's own arithmetic
-    //   rec[2]  : the 64-byte step records of the current / the next step (scalar loads, same overlap)
-    // The host pads every band to a multiple of D steps (D even), so the unrolled group has no early exit and every
-    // buffer index below is a compile-time constant.
+    //   vbuf[2] : (PIPE) converted floats of the current / the next step; the 12-16 LUT reads of step i+1 are issued
+    //             before the FMAs of step i, so their LDS latency hides under the lane's own arithmetic
+    //   rec[2]  : (PIPE) the 64-byte step records of the current / the next step (scalar loads, same overlap)
+    // Register-heavier rings use the plain form (!PIPE): convert, refill, accumulate, one step at a time.
+    // The host pads every band to a multiple of D steps, so the unrolled group has no early exit and every buffer
+    // index below is a compile-time constant.
     uint4 raw[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         raw[d] = fetch_row(steps[s0 + d].y);
         __builtin_amdgcn_sched_barrier(0);      // keep issue order raw[0..D-1]: the loop's vmcnt(D-1) relies on it
     }
-    float vbuf[2][4][C];
-    VStep rec[2];
-    rec[0] = steps[s0];
-    convert(raw[0], vbuf[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    raw[0] = fetch_row((s0 + D < s1) ? steps[s0 + D].y : -1);
-    __builtin_amdgcn_sched_barrier(0);
+    float vbuf[PIPE ? 2 : 1][4][C];
+    VStep rec[PIPE ? 2 : 1];
+    if (PIPE) {
+        rec[0] = steps[s0];
+        convert(raw[0], vbuf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        raw[0] = fetch_row((s0 + D < s1) ? steps[s0 + D].y : -1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     for (uint32_t sb = s0; sb < s1; sb += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const int cur = d & 1, nxt = cur ^ 1;
-            const int slot_next = (d + 1) % D;
+            const int cur = PIPE ? (d & 1) : 0, nxt = PIPE ? (cur ^ 1) : 0;
             const uint32_t si = sb + d;
-            // ---- stage A: start step si+1 (record, LUT gathers), refill its row slot for step si+1+D ----
-            rec[nxt] = steps[(si + 1 < s1) ? si + 1 : si];
-            convert(raw[slot_next], vbuf[nxt]);
-            __builtin_amdgcn_sched_barrier(0);
-            raw[slot_next] = fetch_row(rec[cur].y_ahead);
-            __builtin_amdgcn_sched_barrier(0);
+            if (PIPE) {
+                // ---- stage A: start step si+1 (record, LUT gathers), refill its row slot for step si+1+D ----
+                const int slot_next = (d + 1) % D;
+                rec[nxt] = steps[(si + 1 < s1) ? si + 1 : si];
+                convert(raw[slot_next], vbuf[nxt]);
+                __builtin_amdgcn_sched_barrier(0);
+                raw[slot_next] = fetch_row(rec[cur].y_ahead);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                rec[0] = steps[si];
+                convert(raw[d], vbuf[0]);
+                // The bytes of raw[d] are consumed; only now re-issue the load into the same registers (row of step
+                // si+D).  Issuing it earlier would overlap the two live ranges and make the compiler rotate the
+                // registers with copies (and a vmcnt(0) drain) at the loop back edge.
+                __builtin_amdgcn_sched_barrier(0);
+                raw[d] = fetch_row(rec[0].y_ahead);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // ---- stage B: finish step si ----
             const VStep& st = rec[cur];
             float (&v)[4][C] = vbuf[cur];

@@ -270,7 +270,8 @@ int max_live_rows(const AxisWeights& wv) {
     return best;
 }
 
-bool build_vschedule(const AxisWeights& wv, int n_bands, VSchedule* out) {
+bool build_vschedule(const AxisWeights& wv, int n_bands, int group, int ahead, VSchedule* out) {
+    if (group < 1 || ahead < 1) return false;
     const int K = max_live_rows(wv);
     if (K > kMaxSlots) return false;
     // monotonicity is what makes `j % K` a valid ring assignment; verify instead of assuming
@@ -316,7 +317,7 @@ bool build_vschedule(const AxisWeights& wv, int n_bands, VSchedule* out) {
             }
             while (jlo < j1 && wv.left[jlo] + wv.count[jlo] - 1 <= y) ++jlo;
         }
-        while ((s.steps.size() - s.band_begin.back()) % kPrefetchRows != 0) {   // kernel consumes steps in groups
+        while ((s.steps.size() - s.band_begin.back()) % static_cast<size_t>(group) != 0) {   // kernel consumes steps in groups
             VStep nop;
             std::memset(&nop, 0, sizeof nop);
             nop.y = -1; nop.flush_slot = -1; nop.out_row = -1; nop.y_ahead = -1;
@@ -324,9 +325,7 @@ bool build_vschedule(const AxisWeights& wv, int n_bands, VSchedule* out) {
         }
         const size_t begin = s.band_begin.back(), end = s.steps.size();
         for (size_t i = begin; i < end; ++i) {
-            // the kernel converts the row of step i+1 while it finishes step i, and refills that register slot at
-            // once with the row the slot serves next, i.e. the row of step i+1+kPrefetchRows
-            const size_t a = i + 1 + kPrefetchRows;
+            const size_t a = i + static_cast<size_t>(ahead);
             s.steps[i].y_ahead = a < end ? s.steps[a].y : -1;
         }
         s.band_begin.push_back(static_cast<uint32_t>(s.steps.size()));
