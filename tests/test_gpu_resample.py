@@ -205,3 +205,32 @@ def test_linearity_property_alpha_weights_partition_of_unity():
         px = can.to_numpy()[0, :, :800].reshape(200, 200, 4)
         assert np.all(px[..., 3] == 255)
         assert np.all(np.abs(px[..., :3].astype(int) - val) <= 1)
+
+
+def test_very_wide_and_very_tall_frames():
+    """Maximum-size edge cases: many column strips (fused) and a tall thin frame."""
+    fr = U.random_frames(1, 20000, 40, seed0=41, alpha=True)
+    p = run_case(20000, 40, 1000, 8, frames=fr, alpha=False)
+    assert p.kernel_kind(False) == 0
+    run_case(20000, 40, 1000, 8, frames=fr, alpha=True, compose=BitmapCompositing.BlendWithSelf)
+    fr = U.random_frames(1, 12, 30000, seed0=42, alpha=True)
+    run_case(12, 30000, 3, 2000, frames=fr, alpha=True)
+
+
+def test_empty_batch_is_a_no_op():
+    inp = Bitmap.create_u8(0, 64, 64, DEV)
+    can = Bitmap.create_u8(0, 8, 8, DEV)
+    scale_and_render(inp, can, ScaleAndRenderParams(0, 0, 8, 8))
+    torch.cuda.synchronize()
+
+
+def test_every_ring_size_and_shape_variant():
+    """Vertical ratios chosen so that the ring holds 1..8 live rows (all fused kernel instantiations, both alpha forms)."""
+    seen = set()
+    for (ih, oh, filt) in ((64, 64, Filter.Box), (200, 100, Filter.Box), (120, 64, Filter.Triangle), (300, 100, Filter.Hermite),
+                           (400, 37, Filter.Robidoux), (400, 90, Filter.Robidoux), (500, 45, Filter.Lanczos),
+                           (330, 200, Filter.Lanczos), (640, 48, Filter.Ginseng), (512, 100, Filter.NCubic), (600, 520, Filter.Jinc)):
+        for alpha in (False, True):
+            p = run_case(96, ih, 17, oh, filt=filt, alpha=alpha, n=1, seed=ih + oh)
+            seen.add((p.kernel_kind(alpha)))
+    assert 0 in seen
