@@ -125,12 +125,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: imageflow_amd has no CPU path")
+    # IFHIP_BENCH_DRYRUN_ONE_GPU=1: development aid -- run N ranks on ONE GPU over gloo to exercise the multi-rank control
+    # flow where only a single GPU is available (never used by the driver; numbers from such a run mean nothing)
+    dryrun = os.environ.get("IFHIP_BENCH_DRYRUN_ONE_GPU") == "1"
+    if dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if dryrun:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n = args.frames
     inp = make_frames(torch, n, rank, dev, args.pattern)
@@ -141,6 +149,8 @@ def main():
     info = ScaleAndRenderParams(0, 0, OUT_W, OUT_H, wl[5], Filter[wl[4]])
     plan = plan_for(IN_W, IN_H, OUT_W, OUT_H, info.interpolation_filter, wl[5], dev)
     gather = distributed and not args.no_gather and os.environ.get("IFHIP_BENCH_GATHER", "1") != "0"
+    if dryrun and gather:          # gloo cannot gather device tensors: stage the shard through the host in the dry run
+        raise SystemExit("dry run: pass --no-gather")
     from imageflow_amd.sharding import gather_to_root, max_over_ranks
     gathered = [torch.empty((world,) + tuple(c.data.shape), dtype=torch.uint8, device=dev) if rank == 0 else None
                 for c in canv] if gather else None
@@ -198,7 +208,7 @@ def main():
             "metric": "megapixels/sec resize (4K->200px Robidoux)", "value": round(value, 1), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8 (f32 accumulate)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE {args.workload}: {n} x {IN_W}x{IN_H} BGRA8 frames per GPU -> {OUT_W}x{OUT_H} {wl[4]}"
                                    f"{' sharpen ' + str(wl[5]) if wl[5] else ''}, linear light, {wl[7]}, "
                                    f"alpha {'meaningful' if wl[6] else 'not meaningful'}, device resident, pattern={args.pattern}",
