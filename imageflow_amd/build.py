@@ -19,8 +19,43 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "
           "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 
+FUSED = "resample_fused.hip"          # compiled once per ring size K (-DIFHIP_FUSED_K=K), in parallel
+FUSED_KS = range(1, 9)
+
+
 def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hip")))
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hip")) and f != FUSED)
+
+
+def compile_jobs(extra_defines=()):
+    """(command, object) pairs for every translation unit."""
+    jobs = []
+    defs = [f"-D{d}" for d in extra_defines]
+    for src in sources():
+        obj = os.path.join(HERE, "lib", os.path.basename(src) + ".o")
+        jobs.append(([HIPCC, "-x", "hip", "--offload-arch=gfx950"] + COMMON + defs + ["-c", src, "-o", obj], obj))
+    for k in FUSED_KS:
+        obj = os.path.join(HERE, "lib", f"resample_fused_k{k}.o")
+        jobs.append(([HIPCC, "-x", "hip", "--offload-arch=gfx950"] + COMMON + defs + [f"-DIFHIP_FUSED_K={k}", "-c",
+                     os.path.join(CSRC, FUSED), "-o", obj], obj))
+    return jobs
+
+
+def run_jobs(jobs, verbose=False):
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(job):
+        cmd, obj = job
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        return list(ex.map(one, jobs))
 
 
 def stale():
@@ -34,11 +69,12 @@ def stale():
 def build_variant(name, defines):
     """Experiment builds (tools/): same sources with extra -D flags into lib/libimageflow_hip_<name>.so."""
     out = os.path.join(HERE, "lib", f"libimageflow_hip_{name}.so")
-    srcs = []
-    for src in sources():
-        srcs += (["-x", "hip"] if src.endswith(".cpp") else ["-x", "hip"]) + [src]
-    cmd = [HIPCC, "--offload-arch=gfx950"] + COMMON + [f"-D{d}" for d in defines] + ["-shared"] + srcs + ["-o", out]
-    subprocess.run(cmd, check=True)
+    tmp = os.path.join(HERE, "lib", f"variant_{name}")
+    os.makedirs(tmp, exist_ok=True)
+    jobs = [(cmd[:-1] + [os.path.join(tmp, os.path.basename(obj))], os.path.join(tmp, os.path.basename(obj)))
+            for cmd, obj in compile_jobs(defines)]
+    objs = run_jobs(jobs)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, check=True)
     return out
 
 
@@ -46,17 +82,7 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    objs = []
-    for src in sources():
-        obj = os.path.join(HERE, "lib", os.path.basename(src) + ".o")
-        cmd = [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-c", src, "-o", obj]
-        if src.endswith(".cpp"):
-            cmd.insert(1, "-x")
-            cmd.insert(2, "hip")          # host-only translation units still include hip_runtime.h
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
-        objs.append(obj)
+    objs = run_jobs(compile_jobs(), verbose)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))

@@ -18,8 +18,8 @@
 #include "device.hpp"
 
 namespace ifhip {
-hipError_t launch_fused(const ResampleArgs& a, int slots, bool alpha, uint32_t grid, uint32_t block, size_t lds,
-                        hipStream_t st);
+hipError_t launch_fused(const ResampleArgs& a, int slots, bool alpha, bool per_pixel, uint32_t grid, uint32_t block,
+                        size_t lds, hipStream_t st);
 hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, uint32_t img0, uint32_t n_img,
                           hipStream_t st);
 hipError_t launch_apply_matte(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w, uint32_t h,
@@ -313,7 +313,11 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         const uint32_t block = std::max<uint32_t>(64u, (ss.max_quads + 63u) & ~63u);
         const uint64_t grid = static_cast<uint64_t>(n_images) * sd.n_bands * a.n_strips;
         if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
-        HIP_TRY(launch_fused(a, p->slots, alpha != 0, static_cast<uint32_t>(grid), block, lds, st));
+        // more horizontal chains than lanes (moderate scale factors): one lane per output pixel instead of per (pixel, channel)
+        uint32_t max_nu = 0;
+        for (const Strip& s : ss.strips) max_nu = std::max(max_nu, s.u1 - s.u0);
+        const bool per_pixel = static_cast<uint64_t>(max_nu) * static_cast<uint32_t>(channels) > block;
+        HIP_TRY(launch_fused(a, p->slots, alpha != 0, per_pixel, static_cast<uint32_t>(grid), block, lds, st));
         return IFHIP_OK;
     }
 

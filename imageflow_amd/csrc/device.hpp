@@ -63,9 +63,10 @@ struct ResampleArgs {
 //   narrow           : 512 lanes (256 registers), D = 4, pipelined; strips get narrower
 struct FusedShape { int threads, rows_in_flight, pipelined; };
 constexpr FusedShape fused_shape(int K, int channels) {
-    return (K * 4 * channels + 2 * 4 * channels + 4 * 4 + 30 <= 120) ? FusedShape{1024, 4, 1}
-         : (K * 4 * channels + 4 * channels + 4 * 2 + 30 <= 124)      ? FusedShape{1024, 2, 0}
-                                                                      : FusedShape{512, 4, 1};
+    // thresholds read off the compiler's register report (python -m imageflow_amd.kernel_report): no variant spills
+    return (channels == 3 ? K <= 4 : K <= 2) ? FusedShape{1024, 4, 1}
+         : (channels == 3 ? K <= 5 : K <= 4) ? FusedShape{1024, 2, 0}
+                                             : FusedShape{512, 4, 1};
 }
 constexpr int fused_max_threads(int K, int channels) { return fused_shape(K, channels).threads; }
 // the step whose row the kernel requests while working on step i (see build_vschedule)

@@ -1,0 +1,381 @@
+// resample_fused.hip -- the fused resample + render kernel of imageflow's hot path for ONE ring size K
+// (compiled once per K = 1..8 with -DIFHIP_FUSED_K=K, in parallel; see imageflow_amd/build.py).
+//
+// Replaces the arithmetic behind imageflow_core::graphics::scaling::scale_and_render
+// (graphics/scaling.rs:19-90): sample -> working float (graphics/color.rs:22-45), vertical then horizontal
+// weighted convolution driven by PixelRowWeights tables (graphics/weights.rs:521-571,681-788), and the three
+// output stages (scaling.rs:211-251 ReplaceSelf, :119-148 BlendWithMatte, :254-287 BlendWithSelf).
+//
+// Bound: HBM.  This is a 1-D stencil per axis, so there is no MFMA here; the design points are
+//   * every source byte is read from HBM exactly once, 16 B per lane, rows fully coalesced;
+//   * the vertical pass never leaves registers: each lane owns 4 source columns and a ring of K live
+//     output rows; the per-row weights are wave-uniform and arrive through the scalar cache (VStep);
+//   * only the 10-20x smaller vertically-reduced row goes through LDS for the horizontal pass;
+//   * the sRGB->linear table lives in LDS, one copy per bank (one conflict-free ds_read per channel sample).
+// Build with -ffp-contract=off: every fused multiply-add below is an explicit fmaf, everything else rounds
+// separately, exactly as the arithmetic contract in oracle/if_oracle.c (tests compare bit for bit).
+#include <atomic>
+
+#include "resample_device.hpp"
+
+#ifndef IFHIP_FUSED_K
+#error "compile with -DIFHIP_FUSED_K=<ring size 1..8>"
+#endif
+#ifndef IFHIP_H_UNROLL
+#define IFHIP_H_UNROLL 1     // measured: 1 beats 2 and 3 (-1.7%); the chain is not latency-bound per group, code size matters
+#endif
+
+namespace ifhip {
+
+// ------------------------------------------------------------------------------------------------------
+// Fused kernel: one workgroup = (image, band of output rows, column strip)
+//
+// Vertical pass in registers, one lane = 4 source columns x K live output rows; when an output row completes, its
+// vertically filtered row goes to LDS (double buffered) and the horizontal pass for it is *interleaved* into the
+// following source-row steps, a few taps per step, so that its LDS latency and its strictly sequential fmaf chains
+// hide under the vertical pass instead of stopping it.  One LDS-only workgroup barrier per output row.
+// ------------------------------------------------------------------------------------------------------
+template <int K, bool ALPHA, bool WLDS, bool PERPIXEL>
+__global__ void __launch_bounds__(fused_max_threads(K, ALPHA ? 4 : 3))
+fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
+    // `steps` is a separate __restrict__ argument (not a field of `a`) so that the compiler can prove the canvas
+    // stores never clobber it and keeps the per-step 64-byte records on the scalar path.
+    constexpr int C = ALPHA ? 4 : 3;
+    constexpr int D = fused_shape(K, C).rows_in_flight;
+    constexpr bool PIPE = fused_shape(K, C).pipelined != 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t T = blockDim.x;
+    uint32_t b = blockIdx.x;
+    const uint32_t strip_i = b % a.n_strips; b /= a.n_strips;
+    const uint32_t band = b % a.n_bands;
+    const uint32_t img = b / a.n_bands;
+
+    const Strip strip = a.strips[strip_i];
+    const uint32_t n_u = strip.u1 - strip.u0;
+
+    const FusedLds L = fused_lds_layout(n_u, strip.nquads, a.h_wu_floats, C, WLDS, a.l2s_in_lds != 0, a.lut_copies_log2);
+    float* lut_banked = reinterpret_cast<float*>(smem + L.lut);      // [256][32] floats, one copy per bank
+    uint16_t* thr = reinterpret_cast<uint16_t*>(smem + L.thr);       // 256 linear->sRGB thresholds
+    uint4* hmeta = reinterpret_cast<uint4*>(smem + L.hmeta);         // per output column {left - cx0, taps, w offset}
+    float* obuf = reinterpret_cast<float*>(smem + L.obuf);           // 2 x [n_u][4] horizontally filtered rows
+    const float* hw_lds = reinterpret_cast<const float*>(smem + L.hw);
+    float* inter = reinterpret_cast<float*>(smem + L.inter);         // 2 x vertically filtered row, C planes each
+    const uint32_t inter_stride = L.inter_stride >> 2;               // floats per buffered row
+    const uint32_t plane_pitch = L.plane_pitch;                      // floats per channel plane
+    const uint32_t obuf_stride = n_u * 4u;                           // floats
+
+    for (uint32_t i = tid; i < (256u << a.lut_copies_log2); i += T) lut_banked[i] = a.lut_in[i >> a.lut_copies_log2];
+    for (uint32_t i = tid; i < 256u; i += T) thr[i] = a.l2s_thr[i];
+    const uint8_t* l2s_lds = a.l2s_in_lds ? smem + L.l2s : nullptr;
+    if (a.l2s_in_lds)
+        for (uint32_t i = tid; i < 1024u; i += T)
+            reinterpret_cast<uint4*>(smem + L.l2s)[i] = reinterpret_cast<const uint4*>(a.l2s)[i];
+    const BankedLut lut{lut_banked, tid & ((1u << a.lut_copies_log2) - 1u), a.lut_copies_log2};
+    for (uint32_t i = tid; i < n_u; i += T) {
+        uint4 m = a.h_meta[strip.u0 + i];
+        m.x -= strip.cx0;
+        hmeta[i] = m;
+    }
+    if (WLDS) {
+        const float4* src4 = reinterpret_cast<const float4*>(a.h_wu);
+        float4* dst4 = reinterpret_cast<float4*>(smem + L.hw);
+        for (uint32_t i = tid; i < (a.h_wu_floats >> 2); i += T) dst4[i] = src4[i];
+    }
+    __syncthreads();
+    // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. throw away the
+    // D source rows every lane keeps in flight.
+    auto lds_barrier = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+
+    const uint32_t s0 = a.band_begin[band], s1 = a.band_begin[band + 1];
+    const bool lane_on = tid < strip.nquads;
+    // lanes past the strip re-read its last quad instead of branching: every row load is unconditional, so the
+    // number of loads in flight is known statically and the compiler can wait with vmcnt(D-1) instead of vmcnt(0)
+    const uint32_t quad = lane_on ? tid : strip.nquads - 1u;
+    const uint8_t* src = a.in + static_cast<size_t>(img) * a.in_image_bytes
+                         + static_cast<size_t>(strip.cx0 + 4u * quad) * 4u;
+
+    float acc[K][4][C];
+#pragma unroll
+    for (int s = 0; s < K; ++s)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[s][p][c] = 0.0f;
+
+    auto fetch_row = [&](int y) -> uint4 {                               // y is wave-uniform; -1 = nothing needed
+        const uint32_t yy = y < 0 ? 0u : static_cast<uint32_t>(y);      // (row 0 is re-read: stays in L2)
+        const uint4* p = reinterpret_cast<const uint4*>(src + static_cast<size_t>(yy) * a.in_stride);
+        // source frames are streamed exactly once: non-temporal loads keep them from displacing the tables in L2
+        // (measured -1.7% kernel time, profiles/r1_notes.md)
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        return make_uint4(t.x, t.y, t.z, t.w);
+    };
+
+    // sample -> working float for the 4 pixels of one 16-byte load (arithmetic contract step 1)
+    auto convert = [&](const uint4& q, float (&v)[4][C]) {
+        const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t px = w4[p];
+            v[p][0] = lut[px & 255u];
+            v[p][1] = lut[(px >> 8) & 255u];
+            v[p][2] = lut[(px >> 16) & 255u];
+            if (ALPHA) {
+                const float af = static_cast<float>(px >> 24) * (1.0f / 255.0f);
+                v[p][0] = v[p][0] * af;
+                v[p][1] = v[p][1] * af;
+                v[p][2] = v[p][2] * af;
+                v[p][C - 1] = af;
+            }
+        }
+    };
+
+    // ---- horizontal pass of one output row: chain idx = (output column ul, channel c), the strictly ascending
+    // fmaf sum over its taps (arithmetic contract step 3).  Runs right after the row hand-over barrier on the
+    // lowest lanes.  Samples come from the channel's plane, weights from the output's (de-duplicated) row, both as
+    // aligned 16-byte LDS reads of 4 taps; the first group may begin with +0 weights (columns before the first tap),
+    // the last group is predicated on the number of valid taps.
+    const uint32_t n_chain = n_u * C;
+    auto h_run_row = [&](const float* vrow, float* orow) {
+        for (uint32_t idx = tid; idx < n_chain; idx += T) {
+            const uint32_t ul = idx / C, c = idx - ul * C;
+            const uint4 m = hmeta[ul];
+            const float4* sp = reinterpret_cast<const float4*>(vrow + c * plane_pitch + m.x);
+            const float4* wp = reinterpret_cast<const float4*>((WLDS ? hw_lds : a.h_wu) + m.z);
+            const uint32_t last = m.y - 1u;
+            float h = 0.0f;
+#pragma unroll IFHIP_H_UNROLL
+            for (uint32_t q = 0; q < last; ++q) {
+                const float4 w = wp[q];
+                const float4 x = sp[q];
+                h = __builtin_fmaf(w.x, x.x, h);
+                h = __builtin_fmaf(w.y, x.y, h);
+                h = __builtin_fmaf(w.z, x.z, h);
+                h = __builtin_fmaf(w.w, x.w, h);
+            }
+            {
+                const float4 w = wp[last];
+                const float4 x = sp[last];
+                h = __builtin_fmaf(w.x, x.x, h);
+                if (m.w > 1u) h = __builtin_fmaf(w.y, x.y, h);
+                if (m.w > 2u) h = __builtin_fmaf(w.z, x.z, h);
+                if (m.w > 3u) h = __builtin_fmaf(w.w, x.w, h);
+            }
+            orow[ul * 4u + c] = h;
+        }
+    };
+    // Same pass, one lane per output PIXEL (all its channels, then encode + store at once): used when there are more
+    // chains than lanes (moderate scale factors: many short chains), where the per-chain set-up and the separate
+    // store phase would dominate.  No obuf round trip in this form.
+    constexpr bool h_per_pixel = PERPIXEL;           // host: n_u * C > workgroup size
+    auto h_run_row_pixels = [&](uint32_t j, const float* vrow) {
+        for (uint32_t ul = tid; ul < n_u; ul += T) {
+            const uint4 m = hmeta[ul];
+            const float* sp = vrow + m.x;
+            const float4* wp = reinterpret_cast<const float4*>((WLDS ? hw_lds : a.h_wu) + m.z);
+            const uint32_t last = m.y - 1u;
+            float h[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) h[c] = 0.0f;
+            for (uint32_t q = 0; q < last; ++q) {
+                const float4 w = wp[q];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float4 x = *reinterpret_cast<const float4*>(sp + c * plane_pitch + 4u * q);
+                    h[c] = __builtin_fmaf(w.x, x.x, h[c]);
+                    h[c] = __builtin_fmaf(w.y, x.y, h[c]);
+                    h[c] = __builtin_fmaf(w.z, x.z, h[c]);
+                    h[c] = __builtin_fmaf(w.w, x.w, h[c]);
+                }
+            }
+            {
+                const float4 w = wp[last];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float4 x = *reinterpret_cast<const float4*>(sp + c * plane_pitch + 4u * last);
+                    h[c] = __builtin_fmaf(w.x, x.x, h[c]);
+                    if (m.w > 1u) h[c] = __builtin_fmaf(w.y, x.y, h[c]);
+                    if (m.w > 2u) h[c] = __builtin_fmaf(w.z, x.z, h[c]);
+                    if (m.w > 3u) h[c] = __builtin_fmaf(w.w, x.w, h[c]);
+                }
+            }
+            const OutTables<BankedLut, ThresholdL2S> tb{lut, ThresholdL2S{thr, l2s_lds}};
+            store_pixel<ALPHA>(a, img, j, strip.u0 + ul, h[0], h[1], h[2], ALPHA ? h[C - 1] : 1.0f, tb);
+        }
+    };
+    int h_out_row = -1;              // output row whose horizontal result is waiting in obuf (uniform), -1: none
+    auto h_store_row = [&](uint32_t j, const float* orow) {      // output stage of a horizontally filtered row
+        // the lanes at the top of the workgroup take it: the chains sit on the lowest lanes
+        for (uint32_t ul = T - 1u - tid; ul < n_u; ul += T) {
+            const float4 o = *reinterpret_cast<const float4*>(orow + ul * 4u);
+            const OutTables<BankedLut, ThresholdL2S> tb{lut, ThresholdL2S{thr, l2s_lds}};
+            store_pixel<ALPHA>(a, img, j, strip.u0 + ul, o.x, o.y, o.z, ALPHA ? o.w : 1.0f, tb);
+        }
+    };
+
+    // Software pipeline over steps (one step = one source row):
+    //   raw[D]  : D source rows in flight per lane (16 B each), refilled in place -> fixed registers, vmcnt(D-1)
+    //   vbuf[2] : (PIPE) converted floats of the current / the next step; the 12-16 LUT reads of step i+1 are issued
+    //             before the FMAs of step i, so their LDS latency hides under the lane's own arithmetic
+    //   rec[2]  : (PIPE) the 64-byte step records of the current / the next step (scalar loads, same overlap)
+    // Register-heavier rings use the plain form (!PIPE): convert, refill, accumulate, one step at a time.
+    // The host pads every band to a multiple of D steps, so the unrolled group has no early exit and every buffer
+    // index below is a compile-time constant.
+    uint4 raw[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        raw[d] = fetch_row(steps[s0 + d].y);
+        __builtin_amdgcn_sched_barrier(0);      // keep issue order raw[0..D-1]: the loop's vmcnt(D-1) relies on it
+    }
+    float vbuf[PIPE ? 2 : 1][4][C];
+    VStep rec[PIPE ? 2 : 1];
+    if (PIPE) {
+        rec[0] = steps[s0];
+        convert(raw[0], vbuf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        raw[0] = fetch_row((s0 + D < s1) ? steps[s0 + D].y : -1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    for (uint32_t sb = s0; sb < s1; sb += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int cur = PIPE ? (d & 1) : 0, nxt = PIPE ? (cur ^ 1) : 0;
+            const uint32_t si = sb + d;
+            if (PIPE) {
+                // ---- stage A: start step si+1 (record, LUT gathers), refill its row slot for step si+1+D ----
+                const int slot_next = (d + 1) % D;
+                rec[nxt] = steps[(si + 1 < s1) ? si + 1 : si];
+                convert(raw[slot_next], vbuf[nxt]);
+                __builtin_amdgcn_sched_barrier(0);
+                raw[slot_next] = fetch_row(rec[cur].y_ahead);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                rec[0] = steps[si];
+                convert(raw[d], vbuf[0]);
+                // The bytes of raw[d] are consumed; only now re-issue the load into the same registers (row of step
+                // si+D).  Issuing it earlier would overlap the two live ranges and make the compiler rotate the
+                // registers with copies (and a vmcnt(0) drain) at the loop back edge.
+                __builtin_amdgcn_sched_barrier(0);
+                raw[d] = fetch_row(rec[0].y_ahead);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- stage B: finish step si ----
+            const VStep& st = rec[cur];
+            float (&v)[4][C] = vbuf[cur];
+#if defined(IFHIP_EXP_LOAD_ONLY)   // experiment: stream rows, no arithmetic (NOT a product path)
+            acc[0][0][0] += v[0][0] + v[1][1] + v[2][2] + v[3][0];
+#else
+            // Every ring slot accumulates unconditionally: a slot outside its window holds exactly +0.0f (initial
+            // value / reset at flush) and has weight +0.0f in the step record, and fmaf(+0, v, +0) == +0 for the
+            // finite non-negative v we feed it, so the result is bit-identical to skipping the slot -- without
+            // K scalar branches (and their instruction-fetch bubbles) per source row.
+            if (st.y >= 0) {
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    const float w = st.w[s];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[s][p][c] = __builtin_fmaf(w, v[p][c], acc[s][p][c]);
+                }
+            }
+#endif
+#if defined(IFHIP_EXP_NO_H)        // experiment: vertical pass only (NOT a product path)
+            if (st.flush_slot >= 0 && st.out_row == 0x7fffffff) {
+#else
+            if (st.flush_slot >= 0) {
+#endif
+                // ---- output row j's vertical pass is complete: hand its row to the horizontal pass ----
+                const uint32_t j = static_cast<uint32_t>(st.out_row);
+                float* dst_row = inter + (j & 1u) * inter_stride;
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    if (st.flush_slot == s) {
+                        if (lane_on) {
+#pragma unroll
+                            for (int c = 0; c < C; ++c)
+                                *reinterpret_cast<float4*>(dst_row + c * plane_pitch + 4u * tid) =
+                                    make_float4(acc[s][0][c], acc[s][1][c], acc[s][2][c], acc[s][3][c]);
+                        }
+#pragma unroll
+                        for (int p = 0; p < 4; ++p)
+#pragma unroll
+                            for (int c = 0; c < C; ++c) acc[s][p][c] = 0.0f;
+                    }
+                }
+                // One barrier per output row.  After it: row j's vertical result (inter[j&1]) and row j-1's horizontal
+                // result (obuf[(j-1)&1]) are complete.  inter[j&1] is next written at row j+2 and obuf[(j-1)&1] by
+                // row j+1's chains, both only after every wave has passed the barrier of row j+1, i.e. after every
+                // wave has finished reading them.
+                lds_barrier();
+                if constexpr (h_per_pixel) {
+#if !defined(IFHIP_EXP_NO_CHAIN)
+                    h_run_row_pixels(j, dst_row);
+#endif
+                } else {
+#if !defined(IFHIP_EXP_NO_STORE)
+                    if (h_out_row >= 0) h_store_row(static_cast<uint32_t>(h_out_row), obuf + (static_cast<uint32_t>(h_out_row) & 1u) * obuf_stride);
+#endif
+                    h_out_row = static_cast<int>(j);
+#if !defined(IFHIP_EXP_NO_CHAIN)
+                    h_run_row(dst_row, obuf + (j & 1u) * obuf_stride);
+#endif
+                }
+            }
+        }
+    }
+    // drain: the last output row of the band still has its horizontal pass and output stage to do
+    if (h_out_row >= 0) {
+        lds_barrier();
+        h_store_row(static_cast<uint32_t>(h_out_row), obuf + (static_cast<uint32_t>(h_out_row) & 1u) * obuf_stride);
+    }
+}
+
+
+template <int K, bool ALPHA, bool WLDS, bool PERPIXEL>
+static hipError_t launch_variant(const ResampleArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    // raise the dynamic-LDS cap once per kernel variant and device (it is sticky), not on every launch
+    static std::atomic<size_t> cap[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<size_t>& c = cap[dev & 15];
+    if (c.load(std::memory_order_relaxed) < lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_resample_kernel<K, ALPHA, WLDS, PERPIXEL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsCap));
+        c.store(kFusedLdsCap, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL((fused_resample_kernel<K, ALPHA, WLDS, PERPIXEL>), grid, block, lds, st, a, a.steps);
+    return hipGetLastError();
+}
+
+#define IFHIP_CAT2(a, b) a##b
+#define IFHIP_CAT(a, b) IFHIP_CAT2(a, b)
+
+// launch_fused_k<K>: picks the (alpha, weights-in-LDS, per-pixel) instantiation.  K must equal the ring size exactly:
+// every slot accumulates on every row.
+hipError_t IFHIP_CAT(launch_fused_k, IFHIP_FUSED_K)(const ResampleArgs& a, bool alpha, bool per_pixel, dim3 grid, dim3 block,
+                                                    size_t lds, hipStream_t st) {
+    constexpr int K = IFHIP_FUSED_K;
+    const bool wl = a.h_w_in_lds != 0;
+    const int sel = (alpha ? 4 : 0) | (wl ? 2 : 0) | (per_pixel ? 1 : 0);
+    switch (sel) {
+    case 0: return launch_variant<K, false, false, false>(a, grid, block, lds, st);
+    case 1: return launch_variant<K, false, false, true>(a, grid, block, lds, st);
+    case 2: return launch_variant<K, false, true, false>(a, grid, block, lds, st);
+    case 3: return launch_variant<K, false, true, true>(a, grid, block, lds, st);
+    case 4: return launch_variant<K, true, false, false>(a, grid, block, lds, st);
+    case 5: return launch_variant<K, true, false, true>(a, grid, block, lds, st);
+    case 6: return launch_variant<K, true, true, false>(a, grid, block, lds, st);
+    default: return launch_variant<K, true, true, true>(a, grid, block, lds, st);
+    }
+}
+
+}  // namespace ifhip

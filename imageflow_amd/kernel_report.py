@@ -6,11 +6,11 @@ import sys
 from . import build as B
 
 
-def report(src=None):
+def report(src=None, k=4):
     import os
-    src = src or os.path.join(B.CSRC, "resample_kernels.hip")
-    cmd = [B.HIPCC, "--offload-arch=gfx950"] + B.COMMON + ["-c", src, "-o", "/dev/null",
-                                                           "-Rpass-analysis=kernel-resource-usage"]
+    src = src or os.path.join(B.CSRC, B.FUSED)
+    cmd = [B.HIPCC, "-x", "hip", "--offload-arch=gfx950"] + B.COMMON + [f"-DIFHIP_FUSED_K={k}", "-c", src, "-o", "/dev/null",
+                                                                      "-Rpass-analysis=kernel-resource-usage"]
     out = subprocess.run(cmd, capture_output=True, text=True).stderr
     rows, cur = [], None
     for line in out.splitlines():
@@ -32,4 +32,10 @@ def report(src=None):
 
 
 if __name__ == "__main__":
-    report(sys.argv[1] if len(sys.argv) > 1 else None)
+    if len(sys.argv) > 1 and sys.argv[1].isdigit():
+        report(k=int(sys.argv[1]))
+    elif len(sys.argv) > 1:
+        report(sys.argv[1])
+    else:
+        for kk in range(1, 9):
+            report(k=kk)
