@@ -57,6 +57,7 @@ struct JpegArgs {
     size_t image_bytes;
     uint32_t stride;
     uint32_t n_images;
+    uint32_t comp;                  // component the IDCT launch works on (one launch per component)
 };
 
 // ---- IDCT ("islow": 13-bit fixed point, 12-multiply factorisation; ITU T.81 A.3.3 + the IJG constants) ----------
@@ -114,18 +115,11 @@ constexpr int kBlockPitch = 72;     // dwords per 8x8 workspace in LDS (64 + 8: 
 
 __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
     __shared__ int32_t ws[kBlocksPerWg * kBlockPitch];
+    // grid: x = groups of 32 blocks of component a.comp, y = image
     const uint32_t t = threadIdx.x, lane8 = t & 7u, lb = t >> 3;
-    const uint32_t per_image = a.g.blocks_before[a.g.ncomp];
-    const uint64_t gb = static_cast<uint64_t>(blockIdx.x) * kBlocksPerWg + lb;
-    const uint64_t total = static_cast<uint64_t>(per_image) * a.n_images;
-    const bool on = gb < total;
-    uint32_t img = 0, c = 0, bidx = 0;
-    if (on) {
-        img = static_cast<uint32_t>(gb / per_image);
-        const uint32_t r = static_cast<uint32_t>(gb - static_cast<uint64_t>(img) * per_image);
-        c = (a.g.ncomp > 1 && r >= a.g.blocks_before[1]) ? ((r >= a.g.blocks_before[2]) ? 2u : 1u) : 0u;
-        bidx = r - a.g.blocks_before[c];
-    }
+    const uint32_t c = a.comp, img = blockIdx.y;
+    const uint32_t bidx = blockIdx.x * kBlocksPerWg + lb;
+    const bool on = bidx < a.g.bw[c] * a.g.bh[c];
     const uint32_t n = a.g.idct_n[c];                                   // output samples per block edge
     const bool spatial = (c == 0u) && a.g.luma_mode != 0u && n < 8u;    // islow, then imageflow's block scaler
     const uint32_t m = spatial ? 8u : n;                                // size of the IDCT actually run
@@ -251,54 +245,89 @@ __device__ __forceinline__ int32_t chroma_at(const uint8_t* p, uint32_t pw, uint
 
 __device__ __forceinline__ uint32_t clamp255(int32_t v) { return static_cast<uint32_t>(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
-__global__ void __launch_bounds__(256) jpeg_color_kernel(const JpegArgs a) {
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
-    if (x >= a.g.out_w) return;
-    const uint8_t* py = a.plane[0] + static_cast<size_t>(img) * a.g.pw[0] * a.g.ph[0];
-    const int32_t Y = py[static_cast<size_t>(y) * a.g.pw[0] + x];
-    uint32_t out;
-    if (a.g.ncomp == 1) {
-        out = static_cast<uint32_t>(Y) * 0x010101u | 0xff000000u;
+__device__ __forceinline__ uint32_t ycc_to_bgra(int32_t Y, int32_t cbv, int32_t crv) {   // jdcolor.c tables, in place
+    const int32_t cb = cbv - 128, cr = crv - 128;
+    const int32_t r = Y + ((91881 * cr + 32768) >> 16);
+    const int32_t g = Y + ((-22554 * cb + 32768 + (-46802) * cr) >> 16);
+    const int32_t b = Y + ((116130 * cb + 32768) >> 16);
+    return clamp255(b) | (clamp255(g) << 8) | (clamp255(r) << 16) | 0xff000000u;
+}
+
+// 4 neighbouring chroma samples of one row starting at column c0 (may be -1), edge-duplicated like libjpeg:
+// interior lanes use one unaligned 4-byte load, lanes at the left/right edge fall back to clamped byte loads.
+__device__ __forceinline__ void chroma4(const uint8_t* P, uint32_t W, uint32_t DW, uint32_t DH, int32_t c0, int32_t y,
+                                        int32_t (&o)[4]) {
+    y = y < 0 ? 0 : (y >= static_cast<int32_t>(DH) ? static_cast<int32_t>(DH) - 1 : y);
+    const uint8_t* row = P + static_cast<size_t>(y) * W;
+    if (c0 >= 0 && c0 + 3 < static_cast<int32_t>(DW)) {
+        uint32_t v;
+        __builtin_memcpy(&v, row + c0, 4);
+        o[0] = v & 255u; o[1] = (v >> 8) & 255u; o[2] = (v >> 16) & 255u; o[3] = v >> 24;
     } else {
-        int32_t v[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int32_t x = c0 + k;
+            x = x < 0 ? 0 : (x >= static_cast<int32_t>(DW) ? static_cast<int32_t>(DW) - 1 : x);
+            o[k] = row[x];
+        }
+    }
+}
+
+// one lane = 4 horizontally adjacent output pixels: one 4-byte Y load, 4-byte chroma loads, one 16-byte BGRA store
+__global__ void __launch_bounds__(256) jpeg_color_kernel(const JpegArgs a) {
+    const uint32_t x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u, y = blockIdx.y, img = blockIdx.z;
+    if (x0 >= a.g.out_w) return;
+    const uint8_t* py = a.plane[0] + static_cast<size_t>(img) * a.g.pw[0] * a.g.ph[0] + static_cast<size_t>(y) * a.g.pw[0] + x0;
+    uint32_t yv;
+    __builtin_memcpy(&yv, py, 4);                       // planes carry 16 bytes of slack behind the last row
+    const int32_t Y[4] = {static_cast<int32_t>(yv & 255u), static_cast<int32_t>((yv >> 8) & 255u),
+                          static_cast<int32_t>((yv >> 16) & 255u), static_cast<int32_t>(yv >> 24)};
+    uint32_t out[4];
+    if (a.g.ncomp == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = static_cast<uint32_t>(Y[k]) * 0x010101u | 0xff000000u;
+    } else {
+        int32_t v[2][4];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int c = 1 + k;
             const uint8_t* P = a.plane[c] + static_cast<size_t>(img) * a.g.pw[c] * a.g.ph[c];
             const uint32_t W = a.g.pw[c], DW = a.g.dw[c], DH = a.g.dh[c];
             if (a.g.upsample == 0u) {                                     // plane already at output resolution
-                v[k] = P[static_cast<size_t>(y) * W + x];
-            } else if (a.g.upsample == 1u) {                              // h2v1 fancy
-                const int32_t cx = static_cast<int32_t>(x >> 1), far = (x & 1u) ? cx + 1 : cx - 1, bias = (x & 1u) ? 2 : 1;
-                v[k] = (3 * chroma_at(P, W, DW, DH, cx, static_cast<int32_t>(y))
-                        + chroma_at(P, W, DW, DH, far, static_cast<int32_t>(y)) + bias) >> 2;
-            } else {                                                      // h2v2 fancy
-                const int32_t cx = static_cast<int32_t>(x >> 1), cy = static_cast<int32_t>(y >> 1);
-                const int32_t ny = (y & 1u) ? cy + 1 : cy - 1;
-                const int32_t thiscol = 3 * chroma_at(P, W, DW, DH, cx, cy) + chroma_at(P, W, DW, DH, cx, ny);
-                if ((x & 1u) == 0) {
-                    if (cx == 0) v[k] = (thiscol * 4 + 8) >> 4;
-                    else {
-                        const int32_t last = 3 * chroma_at(P, W, DW, DH, cx - 1, cy) + chroma_at(P, W, DW, DH, cx - 1, ny);
-                        v[k] = (thiscol * 3 + last + 8) >> 4;
-                    }
-                } else {
-                    if (cx == static_cast<int32_t>(DW) - 1) v[k] = (thiscol * 4 + 7) >> 4;
-                    else {
-                        const int32_t next = 3 * chroma_at(P, W, DW, DH, cx + 1, cy) + chroma_at(P, W, DW, DH, cx + 1, ny);
-                        v[k] = (thiscol * 3 + next + 7) >> 4;
-                    }
+                uint32_t cv;
+                __builtin_memcpy(&cv, P + static_cast<size_t>(y) * W + x0, 4);
+                v[k][0] = cv & 255u; v[k][1] = (cv >> 8) & 255u; v[k][2] = (cv >> 16) & 255u; v[k][3] = cv >> 24;
+            } else {
+                // columns cx-1 .. cx+2 around the two chroma samples (cx = x0/2, cx+1) under this lane's 4 pixels
+                const int32_t c0 = static_cast<int32_t>(x0 >> 1) - 1;
+                int32_t s[4];
+                if (a.g.upsample == 1u) {                                 // h2v1 fancy: (3*near + far + {1,2}) >> 2
+                    chroma4(P, W, DW, DH, c0, static_cast<int32_t>(y), s);
+                    v[k][0] = (3 * s[1] + s[0] + 1) >> 2; v[k][1] = (3 * s[1] + s[2] + 2) >> 2;
+                    v[k][2] = (3 * s[2] + s[1] + 1) >> 2; v[k][3] = (3 * s[2] + s[3] + 2) >> 2;
+                } else {                                                  // h2v2 fancy: triangle in both directions
+                    const int32_t cy = static_cast<int32_t>(y >> 1), ny = (y & 1u) ? cy + 1 : cy - 1;
+                    int32_t n0[4], n1[4];
+                    chroma4(P, W, DW, DH, c0, cy, n0);
+                    chroma4(P, W, DW, DH, c0, ny, n1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[i] = 3 * n0[i] + n1[i];
+                    v[k][0] = (3 * s[1] + s[0] + 8) >> 4; v[k][1] = (3 * s[1] + s[2] + 7) >> 4;
+                    v[k][2] = (3 * s[2] + s[1] + 8) >> 4; v[k][3] = (3 * s[2] + s[3] + 7) >> 4;
                 }
             }
         }
-        const int32_t cb = v[0] - 128, cr = v[1] - 128;                    // jdcolor.c tables, evaluated in place
-        const int32_t r = Y + ((91881 * cr + 32768) >> 16);
-        const int32_t g = Y + ((-22554 * cb + 32768 + (-46802) * cr) >> 16);
-        const int32_t b = Y + ((116130 * cb + 32768) >> 16);
-        out = clamp255(b) | (clamp255(g) << 8) | (clamp255(r) << 16) | 0xff000000u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = ycc_to_bgra(Y[i], v[0][i], v[1][i]);
     }
-    uint32_t* dst = reinterpret_cast<uint32_t*>(a.bgra + static_cast<size_t>(img) * a.image_bytes + static_cast<size_t>(y) * a.stride) + x;
-    *dst = out;
+    uint8_t* dst = a.bgra + static_cast<size_t>(img) * a.image_bytes + static_cast<size_t>(y) * a.stride + static_cast<size_t>(x0) * 4u;
+    if (x0 + 4u <= a.g.out_w && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0u)) {
+        *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i)
+            if (x0 + i < a.g.out_w) reinterpret_cast<uint32_t*>(dst)[i] = out[i];
+    }
 }
 
 }  // namespace ifhip
@@ -472,9 +501,14 @@ int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d
     const uint64_t total_blocks = static_cast<uint64_t>(a.g.blocks_before[a.g.ncomp]) * n_images;
     const uint64_t wgs = (total_blocks + kBlocksPerWg - 1) / kBlocksPerWg;
     if (wgs > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
-    hipLaunchKernelGGL(jpeg_idct_kernel, dim3(static_cast<uint32_t>(wgs)), dim3(256), 0, st, a);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(jpeg_color_kernel, dim3((a.g.out_w + 255u) / 256u, a.g.out_h, n_images), dim3(256), 0, st, a);
+    (void)wgs;
+    for (int c = 0; c < a.g.ncomp; ++c) {
+        a.comp = static_cast<uint32_t>(c);
+        const uint32_t nblk = a.g.bw[c] * a.g.bh[c];
+        hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nblk + kBlocksPerWg - 1) / kBlocksPerWg, n_images), dim3(256), 0, st, a);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((a.g.out_w + 1023u) / 1024u, a.g.out_h, n_images), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     return IFHIP_OK;
 }
