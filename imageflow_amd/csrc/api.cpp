@@ -13,6 +13,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <tuple>
 
 #include "common.hpp"
 #include "device.hpp"
@@ -558,6 +559,45 @@ int ifhip_measure_copy_bandwidth(size_t bytes, int iters, double* bytes_per_seco
 }
 
 // ---- host-buffer drop-ins ---------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+struct PlanKey {
+    int device; uint32_t in_w, in_h, w, h; int filter; uint32_t sharpen_bits;
+    bool operator<(const PlanKey& o) const {
+        return std::tie(device, in_w, in_h, w, h, filter, sharpen_bits) < std::tie(o.device, o.in_w, o.in_h, o.w, o.h, o.filter, o.sharpen_bits);
+    }
+};
+std::mutex g_plan_mu;
+std::map<PlanKey, std::shared_ptr<ifhip_resample_plan>> g_plan_cache;
+constexpr size_t kPlanCacheMax = 64;
+
+int cached_plan(uint32_t in_w, uint32_t in_h, uint32_t w, uint32_t h, int filter, float sharpen,
+                std::shared_ptr<ifhip_resample_plan>* out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0)
+        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device (hipGetDevice failed); this library has no CPU path");
+    uint32_t bits;
+    std::memcpy(&bits, &sharpen, 4);
+    const PlanKey key{dev, in_w, in_h, w, h, filter, bits};
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        auto it = g_plan_cache.find(key);
+        if (it != g_plan_cache.end()) { *out = it->second; return IFHIP_OK; }
+    }
+    ifhip_resample_plan* raw = nullptr;
+    const int rc = ifhip_resample_plan_create(&raw, in_w, in_h, w, h, filter, sharpen);
+    if (rc) return rc;
+    std::shared_ptr<ifhip_resample_plan> sp(raw);
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (g_plan_cache.size() >= kPlanCacheMax) g_plan_cache.erase(g_plan_cache.begin());   // bounded; eviction order is arbitrary
+    g_plan_cache[key] = sp;
+    *out = sp;
+    return IFHIP_OK;
+}
+}  // namespace
+
+extern "C" {
 int ifhip_scale_and_render(const uint8_t* in, uint32_t in_w, uint32_t in_h, uint32_t in_stride, int in_alpha_meaningful,
                            uint8_t* canvas, uint32_t canvas_w, uint32_t canvas_h, uint32_t canvas_stride,
                            int /*canvas_alpha_meaningful*/, uint32_t x, uint32_t y, uint32_t w, uint32_t h, int filter,
@@ -565,10 +605,12 @@ int ifhip_scale_and_render(const uint8_t* in, uint32_t in_w, uint32_t in_h, uint
     int rc = validate_render(in_w, in_h, in_stride, canvas_w, canvas_h, canvas_stride, x, y, w, h, working_space, compositing);
     if (rc) return rc;
     if (!in || !canvas) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null bitmap pointer");
-    ifhip_resample_plan* plan = nullptr;
-    rc = ifhip_resample_plan_create(&plan, in_w, in_h, w, h, filter, sharpen_percent_goal);
+    // plans are cached per (device, shape, filter, sharpen): a server resizing many frames of the same size pays for the
+    // weight tables and the vertical schedule once
+    std::shared_ptr<ifhip_resample_plan> plan_ref;
+    rc = cached_plan(in_w, in_h, w, h, filter, sharpen_percent_goal, &plan_ref);
     if (rc) return rc;
-    std::unique_ptr<ifhip_resample_plan> guard(plan);
+    ifhip_resample_plan* plan = plan_ref.get();
     // stage: source rows as given; only the canvas rows the rect touches
     const size_t in_bytes = (static_cast<size_t>(in_h) * in_stride + 15u) & ~static_cast<size_t>(15);
     const size_t in_valid = static_cast<size_t>(in_h - 1) * in_stride + static_cast<size_t>(in_w) * 4u;
