@@ -314,10 +314,14 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         const uint32_t block = std::max<uint32_t>(64u, (ss.max_quads + 63u) & ~63u);
         const uint64_t grid = static_cast<uint64_t>(n_images) * sd.n_bands * a.n_strips;
         if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
-        // more horizontal chains than lanes (moderate scale factors): one lane per output pixel instead of per (pixel, channel)
+        // Horizontal pass mapping: one lane per output pixel (its C chains interleave, encode + store follow at once, no
+        // obuf round trip) measured faster than one lane per (pixel, channel) on every BASELINE shape (cfg2 -2.6 %,
+        // cfg2 with alpha -10 %, cfg3 -27 %); the per-channel form is kept for strips with less than one wave of outputs,
+        // where it is the only way to spread the (long) chains over more lanes.
         uint32_t max_nu = 0;
         for (const Strip& s : ss.strips) max_nu = std::max(max_nu, s.u1 - s.u0);
-        const bool per_pixel = static_cast<uint64_t>(max_nu) * static_cast<uint32_t>(channels) > block;
+        bool per_pixel = max_nu >= 64u || static_cast<uint64_t>(max_nu) * static_cast<uint32_t>(channels) > block;
+        if (const char* e = std::getenv("IFHIP_PERPIXEL")) per_pixel = std::atoi(e) != 0;      // experiment switch
         HIP_TRY(launch_fused(a, p->slots, alpha != 0, per_pixel, static_cast<uint32_t>(grid), block, lds, st));
         return IFHIP_OK;
     }
