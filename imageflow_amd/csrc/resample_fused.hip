@@ -21,6 +21,9 @@
 #ifndef IFHIP_FUSED_K
 #error "compile with -DIFHIP_FUSED_K=<ring size 1..8>"
 #endif
+#ifndef IFHIP_HP_UNROLL
+#define IFHIP_HP_UNROLL 1    // per-pixel horizontal loop
+#endif
 #ifndef IFHIP_H_UNROLL
 #define IFHIP_H_UNROLL 1     // measured: 1 beats 2 and 3 (-1.7%); the chain is not latency-bound per group, code size matters
 #endif
@@ -184,6 +187,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             float h[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) h[c] = 0.0f;
+#pragma unroll IFHIP_HP_UNROLL
             for (uint32_t q = 0; q < last; ++q) {
                 const float4 w = wp[q];
 #pragma unroll
