@@ -1,0 +1,110 @@
+"""Host mirror of the pixel half of MozjpegEncoder::write_frame (imageflow_core/src/codecs/mozjpeg.rs:78-160, the
+classic preset: Defaults::LibJPEGv6 -> set_fastest_defaults, so no trellis quantisation and no overshoot deringing):
+what libjpeg runs between write_scanlines and the entropy coder -- BGRA -> YCbCr, chroma down-sampling with edge
+expansion, islow forward DCT, quantisation, dummy blocks -- runs in libimageflow_hip.so on frames that stay in HBM.
+The entropy coder (and evalchroma's sampling decision) stay on the host."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _native
+from ..graphics.bitmaps import Bitmap
+
+DEFAULT_QUALITY = 90          # mozjpeg.rs:21
+
+# ITU T.81 Annex K.1 / K.2 in natural order: the base tables jpeg_set_quality scales (jcparam.c std_*_quant_tbl)
+STD_LUMINANCE_QUANT_TBL = (
+    16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+    18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101,
+    72, 92, 95, 98, 112, 100, 103, 99)
+STD_CHROMINANCE_QUANT_TBL = (
+    17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+    99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99)
+
+
+def quant_tables_for_quality(quality):
+    """jpeg_set_quality(cinfo, q, force_baseline = TRUE) (mozjpeg.rs:113-115 -> jcparam.c jpeg_quality_scaling +
+    jpeg_add_quant_table): uint16 [3][64] natural order, rows = the table each of Y, Cb, Cr uses."""
+    q = min(100, max(1, int(quality)))
+    scale = 5000 // q if q < 50 else 200 - 2 * q
+    out = np.zeros((3, 64), np.uint16)
+    for row, base in ((0, STD_LUMINANCE_QUANT_TBL), (1, STD_CHROMINANCE_QUANT_TBL)):
+        t = (np.array(base, np.int64) * scale + 50) // 100
+        out[row] = np.clip(t, 1, 255)
+    out[2] = out[1]
+    return out
+
+
+def sampling_factors(cb, cr):
+    """mozjpeg.rs:141-149: evalchroma's chroma pixel sizes -> per-component (h_samp, v_samp)."""
+    mh, mv = max(cb[0], cr[0]), max(cb[1], cr[1])
+    sizes = ((1, 1), cb, cr)
+    return [mh // s[0] for s in sizes], [mv // s[1] for s in sizes]
+
+
+def _bind():
+    L = _native.lib()
+    if getattr(L, "_jpeg_fwd_bound", False):
+        return L
+    L.ifhip_jpeg_fwd_stage_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.ifhip_jpeg_fwd_stage_destroy.argtypes = [C.c_void_p]
+    L.ifhip_jpeg_fwd_stage_destroy.restype = None
+    L.ifhip_jpeg_fwd_stage_block_dims.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ifhip_jpeg_forward_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_uint32,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ifhip_jpeg_forward.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6
+    L._jpeg_fwd_bound = True
+    return L
+
+
+class JpegForwardStage:
+    """ifhip_jpeg_fwd_stage: geometry + the down-sampled component planes between the colour and the DCT kernels."""
+
+    def __init__(self, width, height, h_samp, v_samp, max_images, device="cuda:0"):
+        L = _bind()
+        self.width, self.height = width, height
+        self.device = torch.device(device)
+        self._h = C.c_void_p()
+        hs, vs = np.array(list(h_samp), np.uint8), np.array(list(v_samp), np.uint8)
+        with torch.cuda.device(self.device):
+            _native.check(L.ifhip_jpeg_fwd_stage_create(C.byref(self._h), width, height, hs.ctypes.data, vs.ctypes.data, max_images))
+        bw, bh = np.zeros(3, np.uint32), np.zeros(3, np.uint32)
+        _native.check(L.ifhip_jpeg_fwd_stage_block_dims(self._h, bw.ctypes.data, bh.ctypes.data))
+        self.blocks_w, self.blocks_h = [int(v) for v in bw], [int(v) for v in bh]
+
+    def write_frames(self, frames: Bitmap, qt, coef=None):
+        """frames: n BGRA frames (already matted, mozjpeg.rs:88-94); qt: cuda tensor [n, 3, 64] of uint16 bit patterns.
+        Returns int16 cuda tensors [n, bh_c, bw_c, 64]: what the entropy coder consumes."""
+        L = _bind()
+        n = frames.n
+        if coef is None:
+            coef = [torch.empty((n, self.blocks_h[c], self.blocks_w[c], 64), dtype=torch.int16, device=self.device) for c in range(3)]
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _native.check(L.ifhip_jpeg_forward_batch_device(self._h, frames.data.data_ptr(), frames.image_bytes, frames.stride,
+                                                            qt.data_ptr(), n, coef[0].data_ptr(), coef[1].data_ptr(),
+                                                            coef[2].data_ptr(), C.c_void_p(stream)))
+        return coef
+
+    def __del__(self):
+        try:
+            if self._h:
+                _bind().ifhip_jpeg_fwd_stage_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def jpeg_forward_host(bgra, width, height, stride, h_samp, v_samp, qt):
+    """Host-buffer drop-in (numpy): BGRA rows -> list of int16 arrays [bh_c][bw_c][64]."""
+    L = _bind()
+    hs, vs = np.array(list(h_samp), np.uint8), np.array(list(v_samp), np.uint8)
+    hmax, vmax = int(hs.max()), int(vs.max())
+    mw, mh = -(-width // (8 * hmax)), -(-height // (8 * vmax))
+    coef = [np.zeros((mh * int(vs[c]), mw * int(hs[c]), 64), np.int16) for c in range(3)]
+    src = np.ascontiguousarray(bgra, np.uint8)
+    q = np.ascontiguousarray(qt, np.uint16)
+    _native.check(L.ifhip_jpeg_forward(src.ctypes.data, width, height, stride, hs.ctypes.data, vs.ctypes.data, q.ctypes.data,
+                                       coef[0].ctypes.data, coef[1].ctypes.data, coef[2].ctypes.data))
+    return coef

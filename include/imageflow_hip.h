@@ -182,6 +182,25 @@ IFHIP_API int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const 
                                                  const uint16_t* d_qt, uint32_t n_images,
                                                  uint8_t* d_bgra, size_t image_bytes, uint32_t stride, void* hip_stream);
 
+/* Encode-side pixel stage ("next" row 1): what libjpeg runs before entropy coding when
+ * MozjpegEncoder::write_frame (codecs/mozjpeg.rs:78-160, classic preset = set_fastest_defaults, input JCS_EXT_BGRA /
+ * JCS_EXT_BGRX) compresses a flattened frame: rgb_ycc_convert, chroma down-sampling with libjpeg's edge expansion,
+ * the islow forward DCT, quantisation (round-half-up division by 8*Q) and the dummy blocks of the last MCU
+ * column/row.  Output = the quantised coefficient planes jpeg_write_coefficients / the entropy coder consume
+ * (same layout as the decode stage's input); sampling factors and quantisation tables come from the host
+ * (evalchroma / set_quality stay host logic).  Call ifhip_apply_matte first when alpha is meaningful (:88-94). */
+typedef struct ifhip_jpeg_fwd_stage ifhip_jpeg_fwd_stage;
+IFHIP_API int ifhip_jpeg_fwd_stage_create(ifhip_jpeg_fwd_stage** stage, uint32_t width, uint32_t height,
+                                          const uint8_t* h_samp, const uint8_t* v_samp, uint32_t max_images);
+IFHIP_API void ifhip_jpeg_fwd_stage_destroy(ifhip_jpeg_fwd_stage* stage);
+IFHIP_API int ifhip_jpeg_fwd_stage_block_dims(const ifhip_jpeg_fwd_stage* stage, uint32_t* blocks_w3, uint32_t* blocks_h3);
+IFHIP_API int ifhip_jpeg_forward_batch_device(ifhip_jpeg_fwd_stage* stage, const uint8_t* d_bgra, size_t image_bytes,
+                                              uint32_t stride, const uint16_t* d_qt, uint32_t n_images,
+                                              int16_t* d_coef0, int16_t* d_coef1, int16_t* d_coef2, void* hip_stream);
+IFHIP_API int ifhip_jpeg_forward(const uint8_t* bgra, uint32_t width, uint32_t height, uint32_t stride,
+                                 const uint8_t* h_samp, const uint8_t* v_samp, const uint16_t* qt,
+                                 int16_t* coef0, int16_t* coef1, int16_t* coef2);
+
 /* imageflow's 8x8 -> NxN spatial block scalers for the luma plane of a scaled decode: replaces
  * flow_scale_spatial[_srgb]_{1..7}x{1..7} (c_components/lib/codecs_jpeg_idct_fast.c, .h:17-43), the functions the IDCT
  * method selector installs for component 1 (codec_jpeg_wrapper.c:274-343).  `srgb` selects the linear-light variants.

@@ -642,3 +642,142 @@ int jo_jpeg_idct_color_scaled(const int16_t* coef0, const int16_t* coef1, const 
     for (int c = 0; c < ncomp; c++) free(plane[c]);
     return JO_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Encode-side pixel stage: BGRA -> YCbCr -> chroma down-sampling -> forward   */
+/* DCT (islow) -> quantisation -> coefficient planes.  What libjpeg runs before entropy coding when  */
+/* imageflow encodes with its classic preset (codecs/mozjpeg.rs:78-160: set_fastest_defaults, i.e.   */
+/* no trellis; input colour space JCS_EXT_BGRA/BGRX).  Restated from the published IJG algorithms:    */
+/*   jccolor.c rgb_ycc_convert, jcsample.c fullsize/h2v1/h2v2_downsample (+ edge expansion),          */
+/*   jfdctint.c jpeg_fdct_islow, jcdctmgr.c quantize (round-half-up division by 8*Q),                 */
+/*   jccoefct.c compress_data dummy blocks at the right/bottom MCU edges (AC = 0, DC = previous).     */
+/* PIN: tests encode with Pillow/libjpeg-turbo (optimize=False), entropy-decode the file with the     */
+/* decoder above and require these coefficient planes to be identical.                                */
+/* ------------------------------------------------------------------------------------------------ */
+static void fdct_islow_block(const uint8_t* s, int stride, int32_t* out) {
+    int32_t ws[64];
+    for (int r = 0; r < 8; r++) {
+        const uint8_t* d = s + (size_t)r * stride;
+        int32_t e[8];
+        for (int k = 0; k < 8; k++) e[k] = (int32_t)d[k] - 128;
+        int32_t tmp0 = e[0] + e[7], tmp7 = e[0] - e[7], tmp1 = e[1] + e[6], tmp6 = e[1] - e[6];
+        int32_t tmp2 = e[2] + e[5], tmp5 = e[2] - e[5], tmp3 = e[3] + e[4], tmp4 = e[3] - e[4];
+        int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        int32_t* w = ws + 8 * r;
+        w[0] = (int32_t)((uint32_t)(tmp10 + tmp11) << PASS1_BITS);
+        w[4] = (int32_t)((uint32_t)(tmp10 - tmp11) << PASS1_BITS);
+        int32_t z1 = (tmp12 + tmp13) * FIX_0_541196100;
+        w[2] = DESCALE(z1 + tmp13 * FIX_0_765366865, CONST_BITS - PASS1_BITS);
+        w[6] = DESCALE(z1 + tmp12 * (-FIX_1_847759065), CONST_BITS - PASS1_BITS);
+        z1 = tmp4 + tmp7;
+        int32_t z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
+        int32_t z5 = (z3 + z4) * FIX_1_175875602;
+        tmp4 *= FIX_0_298631336; tmp5 *= FIX_2_053119869; tmp6 *= FIX_3_072711026; tmp7 *= FIX_1_501321110;
+        z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
+        z3 += z5; z4 += z5;
+        w[7] = DESCALE(tmp4 + z1 + z3, CONST_BITS - PASS1_BITS);
+        w[5] = DESCALE(tmp5 + z2 + z4, CONST_BITS - PASS1_BITS);
+        w[3] = DESCALE(tmp6 + z2 + z3, CONST_BITS - PASS1_BITS);
+        w[1] = DESCALE(tmp7 + z1 + z4, CONST_BITS - PASS1_BITS);
+    }
+    for (int c = 0; c < 8; c++) {
+        const int32_t* w = ws + c;
+        int32_t tmp0 = w[0] + w[56], tmp7 = w[0] - w[56], tmp1 = w[8] + w[48], tmp6 = w[8] - w[48];
+        int32_t tmp2 = w[16] + w[40], tmp5 = w[16] - w[40], tmp3 = w[24] + w[32], tmp4 = w[24] - w[32];
+        int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        int32_t* o = out + c;
+        o[0] = DESCALE(tmp10 + tmp11, PASS1_BITS);
+        o[32] = DESCALE(tmp10 - tmp11, PASS1_BITS);
+        int32_t z1 = (tmp12 + tmp13) * FIX_0_541196100;
+        o[16] = DESCALE(z1 + tmp13 * FIX_0_765366865, CONST_BITS + PASS1_BITS);
+        o[48] = DESCALE(z1 + tmp12 * (-FIX_1_847759065), CONST_BITS + PASS1_BITS);
+        z1 = tmp4 + tmp7;
+        int32_t z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
+        int32_t z5 = (z3 + z4) * FIX_1_175875602;
+        tmp4 *= FIX_0_298631336; tmp5 *= FIX_2_053119869; tmp6 *= FIX_3_072711026; tmp7 *= FIX_1_501321110;
+        z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
+        z3 += z5; z4 += z5;
+        o[56] = DESCALE(tmp4 + z1 + z3, CONST_BITS + PASS1_BITS);
+        o[40] = DESCALE(tmp5 + z2 + z4, CONST_BITS + PASS1_BITS);
+        o[24] = DESCALE(tmp6 + z2 + z3, CONST_BITS + PASS1_BITS);
+        o[8]  = DESCALE(tmp7 + z1 + z4, CONST_BITS + PASS1_BITS);
+    }
+}
+
+/*
+ * bgra: height rows of `stride` bytes (alpha ignored, as JCS_EXT_BGRX).  hs/vs: sampling (4:4:4, 4:2:2 h2v1, 4:2:0).
+ * qt: [3][64] natural order.  coef[c]: int16 [bh_c][bw_c][64] natural order, MCU padded (as jo_jpeg_read_coefficients).
+ */
+int jo_jpeg_forward(const uint8_t* bgra, uint32_t width, uint32_t height, uint32_t stride, int ncomp,
+                    const uint8_t* hs, const uint8_t* vs, const uint16_t* qt,
+                    int16_t* coef0, int16_t* coef1, int16_t* coef2) {
+    if (ncomp != 3) return JO_ERR_UNSUPPORTED;
+    int hmax = hs[0], vmax = vs[0];
+    if (!(hs[1] == 1 && vs[1] == 1 && hs[2] == 1 && vs[2] == 1 && (hmax == 1 || hmax == 2) && (vmax == 1 || vmax == 2)) ||
+        (hmax == 1 && vmax == 2))
+        return JO_ERR_UNSUPPORTED;
+    int16_t* coef[3] = {coef0, coef1, coef2};
+    uint32_t mw = (width + 8u * hmax - 1) / (8u * hmax), mh = (height + 8u * vmax - 1) / (8u * vmax);
+    for (int c = 0; c < 3; c++) {
+        uint32_t bw = mw * hs[c], bh = mh * vs[c];
+        uint32_t dw = (width * hs[c] + hmax - 1) / hmax, dh = (height * vs[c] + vmax - 1) / vmax;   /* downsampled size */
+        uint32_t rbw = (dw + 7) / 8, rbh = (dh + 7) / 8;                                             /* real blocks */
+        uint32_t pw = rbw * 8, ph = rbh * 8;
+        uint8_t* plane = (uint8_t*)malloc((size_t)pw * ph);
+        if (!plane) return JO_ERR_ALLOC;
+        int fx = hmax / hs[c], fy = vmax / vs[c];                     /* source pixels per sample: 1 or 2 */
+        for (uint32_t y = 0; y < ph; y++) {
+            if (y >= dh) {          /* jcprepct.c: rows below the last down-sampled row repeat that row */
+                memcpy(plane + (size_t)y * pw, plane + (size_t)(dh - 1) * pw, pw);
+                continue;
+            }
+            for (uint32_t x = 0; x < pw; x++) {
+                int32_t sum = 0;
+                for (int dy = 0; dy < fy; dy++)
+                    for (int dx = 0; dx < fx; dx++) {
+                        uint32_t sx = x * (uint32_t)fx + (uint32_t)dx, sy = y * (uint32_t)fy + (uint32_t)dy;
+                        if (sx >= width) sx = width - 1;               /* expand_right_edge / expand_bottom_edge */
+                        if (sy >= height) sy = height - 1;
+                        const uint8_t* p = bgra + (size_t)sy * stride + (size_t)sx * 4;
+                        int32_t b = p[0], g = p[1], r = p[2], v;
+                        if (c == 0) v = (19595 * r + 38470 * g + 7471 * b + 32768) >> 16;
+                        else if (c == 1) v = (-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16;
+                        else v = (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16;
+                        sum += v;
+                    }
+                int32_t v;
+                if (fx == 1 && fy == 1) v = sum;
+                else if (fy == 1) v = (sum + (int32_t)(x & 1)) >> 1;          /* h2v1: bias 0,1,0,1 */
+                else v = (sum + 1 + (int32_t)(x & 1)) >> 2;                    /* h2v2: bias 1,2,1,2 */
+                plane[(size_t)y * pw + x] = (uint8_t)v;
+            }
+        }
+        const uint16_t* q = qt + 64 * c;
+        memset(coef[c], 0, sizeof(int16_t) * 64 * (size_t)bw * bh);
+        for (uint32_t by = 0; by < rbh; by++)
+            for (uint32_t bx = 0; bx < rbw; bx++) {
+                int32_t d[64];
+                fdct_islow_block(plane + (size_t)by * 8 * pw + bx * 8, (int)pw, d);
+                int16_t* o = coef[c] + 64 * ((size_t)by * bw + bx);
+                for (int i = 0; i < 64; i++) {
+                    int32_t qv = (int32_t)q[i] << 3, t = d[i];
+                    if (t < 0) { t = -t; t += qv >> 1; t = (t >= qv) ? t / qv : 0; t = -t; }
+                    else { t += qv >> 1; t = (t >= qv) ? t / qv : 0; }
+                    o[i] = (int16_t)t;
+                }
+            }
+        free(plane);
+        /* dummy blocks (jccoefct.c compress_data): right edge: DC of the block to the left; bottom edge rows of an MCU:
+           DC of the previous block in MCU order = the last block of the MCU's previous block row */
+        for (uint32_t by = 0; by < rbh; by++)
+            for (uint32_t bx = rbw; bx < bw; bx++)
+                coef[c][64 * ((size_t)by * bw + bx)] = coef[c][64 * ((size_t)by * bw + bx - 1)];
+        for (uint32_t by = rbh; by < bh; by++)
+            for (uint32_t bx = 0; bx < bw; bx++) {
+                uint32_t mcu_x = bx / hs[c];
+                uint32_t prev_bx = mcu_x * hs[c] + hs[c] - 1;          /* last block of the MCU's previous block row */
+                coef[c][64 * ((size_t)by * bw + bx)] = coef[c][64 * ((size_t)(by - 1) * bw + prev_bx)];
+            }
+    }
+    return JO_OK;
+}

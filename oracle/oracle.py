@@ -77,6 +77,7 @@ def lib():
         L.jo_jpeg_idct_color_scaled.restype = C.c_int
         L.jo_jpeg_idct_color_scaled.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                                                   C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_uint32]
+        L.jo_jpeg_forward.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int] + [C.c_void_p] * 6
         L.jo_scale_spatial_block.restype = None
         L.jo_scale_spatial_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
         L.ifo_init_tables()
@@ -231,3 +232,24 @@ def jpeg_idct_color_scaled(j, scale_num, luma_mode, stride=None):
     if rc:
         raise RuntimeError(f"jpeg oracle: scaled pixel stage rc={rc}")
     return out
+
+
+def jpeg_block_geometry(width, height, hs, vs):
+    """MCU-padded blocks per row/column of each component, as jo_jpeg_block_dims reports for a file."""
+    hmax, vmax = max(hs), max(vs)
+    mw, mh = -(-width // (8 * hmax)), -(-height // (8 * vmax))
+    return [mw * h for h in hs], [mh * v for v in vs]
+
+
+def jpeg_forward(bgra, width, height, stride, hs, vs, qt):
+    """Encode-side pixel stage: BGRA rows -> quantised coefficient planes [bh_c][bw_c][64] (natural order), int16."""
+    bw, bh = jpeg_block_geometry(width, height, hs, vs)
+    coef = [np.zeros((bh[c], bw[c], 64), np.int16) for c in range(3)]
+    h8, v8 = np.array(hs, np.uint8), np.array(vs, np.uint8)
+    q = np.ascontiguousarray(qt, np.uint16)
+    src = np.ascontiguousarray(bgra, np.uint8)
+    rc = lib().jo_jpeg_forward(src.ctypes.data, width, height, stride, 3, h8.ctypes.data, v8.ctypes.data, q.ctypes.data,
+                               coef[0].ctypes.data, coef[1].ctypes.data, coef[2].ctypes.data)
+    if rc:
+        raise RuntimeError(f"jpeg oracle: forward stage rc={rc}")
+    return coef

@@ -1,0 +1,103 @@
+"""GPU parity: the encode-side pixel stage in libimageflow_hip.so (ifhip_jpeg_forward*) vs the oracle and vs the
+coefficients libjpeg-turbo wrote into the committed files.  Coefficient-exact (int16 equality)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from imageflow_amd.codecs import mozjpeg as M
+from imageflow_amd.codecs.mozjpeg_decoder import JpegPixelStage
+from imageflow_amd.graphics.bitmaps import Bitmap
+from imageflow_amd.errors import FlowError
+
+pytestmark = pytest.mark.gpu
+
+SAMPLINGS = {"444": ([1, 1, 1], [1, 1, 1]), "422": ([2, 1, 1], [1, 1, 1]), "420": ([2, 1, 1], [2, 1, 1])}
+
+
+def to_bgra(rgb, stride=None):
+    h, w = rgb.shape[:2]
+    stride = stride or O.stride_for_width(w)
+    out = np.zeros((h, stride), np.uint8)
+    px = out[:, :4 * w].reshape(h, w, 4)
+    px[..., 0], px[..., 1], px[..., 2], px[..., 3] = rgb[..., 2], rgb[..., 1], rgb[..., 0], 255
+    return out, stride
+
+
+def test_host_dropin_equals_libjpeg_turbo_on_all_committed_cases(golden_dir):
+    z = np.load(os.path.join(golden_dir, "jpeg_encode_cases.npz"))
+    for i, name in enumerate(str(n) for n in z["names"]):
+        j = O.jpeg_read_coefficients(z[f"jpg_{i}"].tobytes())
+        src = z[f"src_{i}"]
+        h, w = src.shape[:2]
+        bgra, stride = to_bgra(src)
+        coef = M.jpeg_forward_host(bgra, w, h, stride, j["hs"], j["vs"], j["qt"])
+        for c in range(3):
+            assert np.array_equal(coef[c], j["coef"][c]), (name, c)
+
+
+@pytest.mark.parametrize("sub", ["444", "422", "420"])
+@pytest.mark.parametrize("size", [(1, 1), (8, 8), (17, 9), (250, 131), (641, 479), (1920, 1080)])
+def test_batch_equals_oracle(sub, size):
+    w, h = size
+    hs, vs = SAMPLINGS[sub]
+    rng = np.random.default_rng(w * 31 + h)
+    n = 3
+    stride = O.stride_for_width(w) + 32
+    frames = rng.integers(0, 256, size=(n, h, stride), dtype=np.uint8)
+    if w >= 64:                                   # smooth content in one frame: non-trivial low frequencies
+        y, x = np.mgrid[0:h, 0:w]
+        frames[1, :, 0:4 * w:4] = (x * 255 // w).astype(np.uint8)
+        frames[1, :, 1:4 * w:4] = (y * 255 // h).astype(np.uint8)
+        frames[1, :, 2:4 * w:4] = ((x + y) // 3 % 256).astype(np.uint8)
+    qts = np.stack([M.quant_tables_for_quality(q) for q in (35, 90, 100)])
+    stage = M.JpegForwardStage(w, h, hs, vs, n)
+    bm = Bitmap.from_numpy(frames, w, h, stride, "cuda:0")
+    coef = stage.write_frames(bm, torch.from_numpy(qts.view(np.int16)).cuda())
+    torch.cuda.synchronize()
+    for k in range(n):
+        ref = O.jpeg_forward(frames[k], w, h, stride, hs, vs, qts[k])
+        for c in range(3):
+            assert np.array_equal(coef[c][k].cpu().numpy(), ref[c]), (k, c)
+
+
+def test_encode_then_decode_on_device_round_trip():
+    """Full-size property through both GPU stages: quality-100 4:4:4 forward + inverse stays within 3 levels (4K frame)."""
+    w, h, n = 3840, 2160, 2
+    hs, vs = SAMPLINGS["444"]
+    y, x = np.mgrid[0:h, 0:w]
+    rgb = np.stack([(x // 2) % 256, (y // 3) % 256, ((x + y) // 5) % 256], -1).astype(np.uint8)
+    bgra, stride = to_bgra(rgb)
+    frames = np.stack([bgra, bgra[::-1].copy()])
+    qt = np.stack([M.quant_tables_for_quality(100)] * n)
+    fwd = M.JpegForwardStage(w, h, hs, vs, n)
+    d_qt = torch.from_numpy(qt.view(np.int16)).cuda()
+    coef = fwd.write_frames(Bitmap.from_numpy(frames, w, h, stride, "cuda:0"), d_qt)
+    inv = JpegPixelStage(w, h, 3, hs, vs, n)
+    back = inv.read_frames(coef, d_qt).to_numpy()
+    d = np.abs(back[:, :, :4 * w].reshape(n, h, w, 4)[..., :3].astype(int) - frames[:, :, :4 * w].reshape(n, h, w, 4)[..., :3].astype(int))
+    assert d.max() <= 3
+    # 4:2:0 of the same frames: checksum against the oracle on one frame (full size, a few seconds of CPU)
+    hs2, vs2 = SAMPLINGS["420"]
+    q85 = np.stack([M.quant_tables_for_quality(85)] * n)
+    coef2 = M.JpegForwardStage(w, h, hs2, vs2, n).write_frames(Bitmap.from_numpy(frames, w, h, stride, "cuda:0"),
+                                                             torch.from_numpy(q85.view(np.int16)).cuda())
+    ref = O.jpeg_forward(frames[1], w, h, stride, hs2, vs2, q85[1])
+    for c in range(3):
+        assert np.array_equal(coef2[c][1].cpu().numpy(), ref[c])
+
+
+def test_error_behaviour():
+    with pytest.raises(FlowError):
+        M.JpegForwardStage(0, 10, [1, 1, 1], [1, 1, 1], 1)
+    with pytest.raises(FlowError):
+        M.JpegForwardStage(16, 16, [1, 1, 1], [2, 1, 1], 1)          # h1v2 luma: not produced by the reference mapping
+    with pytest.raises(FlowError):
+        M.JpegForwardStage(16, 16, [4, 1, 1], [1, 1, 1], 1)
+    st = M.JpegForwardStage(16, 16, [2, 1, 1], [2, 1, 1], 1)
+    bm = Bitmap.create_u8(2, 16, 16, "cuda:0")
+    qt = torch.zeros((2, 3, 64), dtype=torch.int16, device="cuda:0")
+    with pytest.raises(FlowError):
+        st.write_frames(bm, qt)                                       # more frames than the stage was created for

@@ -60,6 +60,23 @@ def main():
             "decode_ms": round(t_dec * 1e3, 3), "decode_source_MPps": round(n * w * h / 1e6 / t_dec, 1),
             "decode_algorithmic_GBps": round((coef_bytes + n * st.out_w * st.out_h * 4) / t_dec / 1e9, 1),
             "decode_plus_resize_800_ms": round(t_all * 1e3, 3), "chain_source_MPps": round(n * w * h / 1e6 / t_all, 1)}
+    # encode side: n x 4K BGRA frames in HBM -> quantised coefficient planes (4:2:0 and 4:4:4)
+    from imageflow_amd.codecs.mozjpeg import JpegForwardStage, quant_tables_for_quality
+    frames = Bitmap.create_u8(n, w, h, dev)
+    frames.data.copy_(torch.randint(0, 256, frames.data.shape, dtype=torch.uint8, device=dev))
+    qt = torch.from_numpy(np.stack([quant_tables_for_quality(90)] * n).view(np.int16)).to(dev)
+    for name, hs, vs in (("420", (2, 1, 1), (2, 1, 1)), ("444", (1, 1, 1), (1, 1, 1))):
+        st = JpegForwardStage(w, h, hs, vs, n, dev)
+        coef = st.write_frames(frames, qt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            st.write_frames(frames, qt, coef)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / 20
+        coef_bytes = sum(int(np.prod(c.shape)) * 2 for c in coef)
+        res[f"forward_{name}"] = {"frames": n, "ms": round(t * 1e3, 3), "MPps": round(n * w * h / 1e6 / t, 1),
+                                  "algorithmic_GBps": round((n * w * h * 4 + coef_bytes) / t / 1e9, 1)}
     print(json.dumps(res, indent=1))
 
 
