@@ -686,317 +686,3 @@ int ifhip_scale_spatial_blocks(const uint8_t* blocks, uint32_t n_blocks, int n, 
 }
 
 }  // extern "C"
-
-// ==================================================================================================================
-// Encode-side pixel stage: BGRA -> YCbCr -> chroma down-sampling -> forward DCT (islow) -> quantisation
-// (what libjpeg runs before entropy coding in MozjpegEncoder::write_frame, codecs/mozjpeg.rs:78-160, classic preset)
-// ==================================================================================================================
-namespace ifhip {
-
-struct FwdGeom {
-    uint32_t width, height;
-    uint32_t hs[3], vs[3], hmax, vmax;
-    uint32_t bw[3], bh[3];          // coefficient blocks per row / column, MCU padded
-    uint32_t rbw[3], rbh[3];        // real blocks (ceil(downsampled size / 8)); the rest are dummy blocks
-    uint32_t dw[3], dh[3];          // downsampled component size
-    uint32_t pw[3], ph[3];          // sample plane = real blocks * 8
-};
-
-struct FwdArgs {
-    FwdGeom g;
-    const uint8_t* bgra;
-    size_t image_bytes;
-    uint32_t stride, n_images, comp;
-    uint8_t* plane[3];              // [n_images][ph][pw]
-    const uint16_t* qt;             // [n_images][3][64]
-    int16_t* coef[3];               // [n_images][bh][bw][64]
-};
-
-// jccolor.c rgb_ycc_convert, 16-bit fixed point, evaluated in place
-__device__ __forceinline__ int32_t rgb_to_component(uint32_t px, uint32_t c) {
-    const int32_t b = px & 255u, g = (px >> 8) & 255u, r = (px >> 16) & 255u;
-    if (c == 0u) return (19595 * r + 38470 * g + 7471 * b + 32768) >> 16;
-    if (c == 1u) return (-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16;
-    return (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16;
-}
-
-// one lane = 4 adjacent samples of one component row; source pixels edge-replicated (jcsample.c expand_right_edge,
-// jcprepct.c expand_bottom_edge); rows below the last down-sampled row repeat that row
-__global__ void __launch_bounds__(256) jpeg_fwd_sample_kernel(const FwdArgs a) {
-    const uint32_t c = a.comp, img = blockIdx.z;
-    const uint32_t x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
-    uint32_t y = blockIdx.y;
-    if (x0 >= a.g.pw[c]) return;
-    const uint32_t yo = y;
-    if (y >= a.g.dh[c]) y = a.g.dh[c] - 1u;
-    const uint32_t fx = a.g.hmax / a.g.hs[c], fy = a.g.vmax / a.g.vs[c];
-    const uint8_t* src = a.bgra + static_cast<size_t>(img) * a.image_bytes;
-    uint32_t packed = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 4u; ++i) {
-        const uint32_t x = x0 + i;
-        int32_t sum = 0;
-        for (uint32_t dy = 0; dy < fy; ++dy)
-            for (uint32_t dx = 0; dx < fx; ++dx) {
-                uint32_t sx = x * fx + dx, sy = y * fy + dy;
-                sx = sx >= a.g.width ? a.g.width - 1u : sx;
-                sy = sy >= a.g.height ? a.g.height - 1u : sy;
-                const uint32_t px = *reinterpret_cast<const uint32_t*>(src + static_cast<size_t>(sy) * a.stride + static_cast<size_t>(sx) * 4u);
-                sum += rgb_to_component(px, c);
-            }
-        int32_t v;
-        if (fx == 1u && fy == 1u) v = sum;
-        else if (fy == 1u) v = (sum + static_cast<int32_t>(x & 1u)) >> 1;            // h2v1: bias 0,1,0,1
-        else v = (sum + 1 + static_cast<int32_t>(x & 1u)) >> 2;                       // h2v2: bias 1,2,1,2
-        packed |= static_cast<uint32_t>(v & 255) << (8u * i);
-    }
-    uint8_t* dst = a.plane[c] + static_cast<size_t>(img) * a.g.pw[c] * a.g.ph[c] + static_cast<size_t>(yo) * a.g.pw[c] + x0;
-    *reinterpret_cast<uint32_t*>(dst) = packed;                    // pw is a multiple of 8
-}
-
-// jfdctint.c jpeg_fdct_islow, one 8-point pass; first = row pass (outputs scaled up by PASS1_BITS)
-__device__ __forceinline__ void fdct8(const int32_t (&e)[8], int32_t (&o)[8], bool first) {
-    constexpr int32_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633,
-                      F1_501 = 12299, F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
-    int32_t tmp0 = e[0] + e[7], tmp7 = e[0] - e[7], tmp1 = e[1] + e[6], tmp6 = e[1] - e[6];
-    int32_t tmp2 = e[2] + e[5], tmp5 = e[2] - e[5], tmp3 = e[3] + e[4], tmp4 = e[3] - e[4];
-    const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-    const int sh = first ? 11 : 15;                      // CONST_BITS -/+ PASS1_BITS
-    if (first) {
-        o[0] = static_cast<int32_t>(static_cast<uint32_t>(tmp10 + tmp11) << 2);
-        o[4] = static_cast<int32_t>(static_cast<uint32_t>(tmp10 - tmp11) << 2);
-    } else {
-        o[0] = descale(tmp10 + tmp11, 2);
-        o[4] = descale(tmp10 - tmp11, 2);
-    }
-    int32_t z1 = (tmp12 + tmp13) * F0_541;
-    o[2] = descale(z1 + tmp13 * F0_765, sh);
-    o[6] = descale(z1 + tmp12 * (-F1_847), sh);
-    z1 = tmp4 + tmp7;
-    int32_t z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
-    const int32_t z5 = (z3 + z4) * F1_175;
-    tmp4 *= F0_298; tmp5 *= F2_053; tmp6 *= F3_072; tmp7 *= F1_501;
-    z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
-    z3 += z5; z4 += z5;
-    o[7] = descale(tmp4 + z1 + z3, sh);
-    o[5] = descale(tmp5 + z2 + z4, sh);
-    o[3] = descale(tmp6 + z2 + z3, sh);
-    o[1] = descale(tmp7 + z1 + z4, sh);
-}
-
-// 8 lanes per block: row pass (lane = row), column pass + quantisation (lane = column), 16-byte coefficient rows out.
-// Dummy blocks (outside the real-block area) are written as zeros here; their DC is patched by the next kernel.
-__global__ void __launch_bounds__(256) jpeg_fdct_quant_kernel(const FwdArgs a) {
-    __shared__ int32_t ws[kBlocksPerWg * kBlockPitch];
-    const uint32_t t = threadIdx.x, lane8 = t & 7u, lb = t >> 3;
-    const uint32_t c = a.comp, img = blockIdx.y;
-    const uint32_t bidx = blockIdx.x * kBlocksPerWg + lb;
-    const bool on = bidx < a.g.bw[c] * a.g.bh[c];
-    const uint32_t by = on ? bidx / a.g.bw[c] : 0u, bx = on ? bidx - by * a.g.bw[c] : 0u;
-    const bool real = on && bx < a.g.rbw[c] && by < a.g.rbh[c];
-    int32_t* w = ws + lb * kBlockPitch;
-    if (real) {
-        const uint8_t* p = a.plane[c] + static_cast<size_t>(img) * a.g.pw[c] * a.g.ph[c]
-                           + static_cast<size_t>(by * 8u + lane8) * a.g.pw[c] + bx * 8u;
-        const uint2 v = *reinterpret_cast<const uint2*>(p);
-        int32_t e[8], o[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            e[k] = static_cast<int32_t>((v.x >> (8 * k)) & 255u) - 128;
-            e[4 + k] = static_cast<int32_t>((v.y >> (8 * k)) & 255u) - 128;
-        }
-        fdct8(e, o, true);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) w[lane8 * 8u + k] = o[k];
-    }
-    __syncthreads();
-    if (real) {
-        int32_t e[8], o[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) e[r] = w[r * 8 + lane8];
-        fdct8(e, o, false);
-        const uint16_t* q = a.qt + (static_cast<size_t>(img) * 3u + c) * 64u;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {                      // jcdctmgr.c: round-half-up division by 8*Q
-            const int32_t qv = static_cast<int32_t>(q[r * 8 + lane8]) << 3;
-            int32_t v = o[r];
-            const bool neg = v < 0;
-            v = neg ? -v : v;
-            v += qv >> 1;
-            v = (v >= qv) ? static_cast<int32_t>(static_cast<uint32_t>(v) / static_cast<uint32_t>(qv)) : 0;
-            w[r * 8 + lane8] = neg ? -v : v;
-        }
-    }
-    __syncthreads();
-    if (on) {
-        uint4 outv = make_uint4(0, 0, 0, 0);
-        if (real) {
-            const int32_t* r = w + lane8 * 8u;
-            outv.x = (static_cast<uint32_t>(r[0]) & 0xffffu) | (static_cast<uint32_t>(r[1]) << 16);
-            outv.y = (static_cast<uint32_t>(r[2]) & 0xffffu) | (static_cast<uint32_t>(r[3]) << 16);
-            outv.z = (static_cast<uint32_t>(r[4]) & 0xffffu) | (static_cast<uint32_t>(r[5]) << 16);
-            outv.w = (static_cast<uint32_t>(r[6]) & 0xffffu) | (static_cast<uint32_t>(r[7]) << 16);
-        }
-        int16_t* dst = a.coef[c] + (static_cast<size_t>(img) * a.g.bw[c] * a.g.bh[c] + bidx) * 64u + lane8 * 8u;
-        *reinterpret_cast<uint4*>(dst) = outv;
-    }
-}
-
-// jccoefct.c compress_data: dummy blocks at the right / bottom MCU edges carry AC = 0 and the DC of the previous block
-__global__ void __launch_bounds__(256) jpeg_dummy_dc_kernel(const FwdArgs a) {
-    const uint32_t c = a.comp, img = blockIdx.y;
-    const uint32_t bidx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bidx >= a.g.bw[c] * a.g.bh[c]) return;
-    const uint32_t by = bidx / a.g.bw[c], bx = bidx - by * a.g.bw[c];
-    if (bx < a.g.rbw[c] && by < a.g.rbh[c]) return;
-    int16_t* base = a.coef[c] + static_cast<size_t>(img) * a.g.bw[c] * a.g.bh[c] * 64u;
-    uint32_t sy, sx;
-    if (by < a.g.rbh[c]) { sy = by; sx = a.g.rbw[c] - 1u; }                       // right edge: the row's last real block
-    else {                                                                        // bottom edge: previous block of the MCU
-        sy = a.g.rbh[c] - 1u;
-        const uint32_t prev = (bx / a.g.hs[c]) * a.g.hs[c] + a.g.hs[c] - 1u;
-        sx = prev < a.g.rbw[c] ? prev : a.g.rbw[c] - 1u;
-    }
-    base[(static_cast<size_t>(by) * a.g.bw[c] + bx) * 64u] = base[(static_cast<size_t>(sy) * a.g.bw[c] + sx) * 64u];
-}
-
-}  // namespace ifhip
-
-struct ifhip_jpeg_fwd_stage {
-    int device = -1;
-    FwdGeom g;
-    uint32_t max_images = 0;
-    uint8_t* planes[3] = {nullptr, nullptr, nullptr};
-    ~ifhip_jpeg_fwd_stage() { for (auto* p : planes) if (p) (void)hipFree(p); }
-};
-
-static int make_fwd_geom(uint32_t width, uint32_t height, const uint8_t* hs, const uint8_t* vs, FwdGeom* g) {
-    if (width == 0 || height == 0) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: Bitmap dimensions cannot be zero");
-    if (!hs || !vs) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null sampling factors");
-    std::memset(g, 0, sizeof *g);
-    g->width = width; g->height = height;
-    for (int c = 0; c < 3; ++c) { g->hs[c] = hs[c]; g->vs[c] = vs[c]; }
-    g->hmax = hs[0]; g->vmax = vs[0];
-    const bool ok = hs[1] == 1 && vs[1] == 1 && hs[2] == 1 && vs[2] == 1 && (g->hmax == 1 || g->hmax == 2) &&
-                    (g->vmax == 1 || g->vmax == 2) && !(g->hmax == 1 && g->vmax == 2);
-    if (!ok) return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: only 4:4:4, 4:2:2 (h2v1) and 4:2:0 sampling");
-    const uint32_t mw = (width + 8u * g->hmax - 1u) / (8u * g->hmax), mh = (height + 8u * g->vmax - 1u) / (8u * g->vmax);
-    for (int c = 0; c < 3; ++c) {
-        g->bw[c] = mw * g->hs[c]; g->bh[c] = mh * g->vs[c];
-        g->dw[c] = (width * g->hs[c] + g->hmax - 1u) / g->hmax;
-        g->dh[c] = (height * g->vs[c] + g->vmax - 1u) / g->vmax;
-        g->rbw[c] = (g->dw[c] + 7u) / 8u; g->rbh[c] = (g->dh[c] + 7u) / 8u;
-        g->pw[c] = g->rbw[c] * 8u; g->ph[c] = g->rbh[c] * 8u;
-    }
-    return IFHIP_OK;
-}
-
-extern "C" {
-
-int ifhip_jpeg_fwd_stage_create(ifhip_jpeg_fwd_stage** stage, uint32_t width, uint32_t height, const uint8_t* h_samp,
-                                const uint8_t* v_samp, uint32_t max_images) {
-    if (!stage) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null stage out-pointer");
-    *stage = nullptr;
-    if (max_images == 0 || max_images > 65535u) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: 1..65535 images per stage");
-    std::unique_ptr<ifhip_jpeg_fwd_stage> s(new ifhip_jpeg_fwd_stage);
-    int rc = make_fwd_geom(width, height, h_samp, v_samp, &s->g);
-    if (rc) return rc;
-    if (s->g.ph[0] > 65535u) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: more than 65535 rows per launch");
-    if (hipGetDevice(&s->device) != hipSuccess)
-        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device; this library has no CPU path");
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: device %d is %s, this library is built for gfx950 only", s->device, prop.gcnArchName);
-    s->max_images = max_images;
-    for (int c = 0; c < 3; ++c)
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->planes[c]), static_cast<size_t>(s->g.pw[c]) * s->g.ph[c] * max_images));
-    *stage = s.release();
-    return IFHIP_OK;
-}
-
-void ifhip_jpeg_fwd_stage_destroy(ifhip_jpeg_fwd_stage* stage) { delete stage; }
-
-int ifhip_jpeg_fwd_stage_block_dims(const ifhip_jpeg_fwd_stage* stage, uint32_t* blocks_w3, uint32_t* blocks_h3) {
-    if (!stage || !blocks_w3 || !blocks_h3) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
-    for (int c = 0; c < 3; ++c) { blocks_w3[c] = stage->g.bw[c]; blocks_h3[c] = stage->g.bh[c]; }
-    return IFHIP_OK;
-}
-
-int ifhip_jpeg_forward_batch_device(ifhip_jpeg_fwd_stage* stage, const uint8_t* d_bgra, size_t image_bytes, uint32_t stride,
-                                    const uint16_t* d_qt, uint32_t n_images, int16_t* d_coef0, int16_t* d_coef1,
-                                    int16_t* d_coef2, void* hip_stream) {
-    if (!stage) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null stage");
-    if (n_images == 0) return IFHIP_OK;
-    if (n_images > stage->max_images) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: %u images exceed the stage capacity %u", n_images, stage->max_images);
-    if (!d_bgra || !d_qt || !d_coef0 || !d_coef1 || !d_coef2) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
-    if (static_cast<uint64_t>(stage->g.width) * 4u > stride || (stride & 3u) || (image_bytes & 3u) || (reinterpret_cast<uintptr_t>(d_bgra) & 3u))
-        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: BGRA rows must be 4-byte aligned and stride >= 4*w");
-    if ((reinterpret_cast<uintptr_t>(d_coef0) | reinterpret_cast<uintptr_t>(d_coef1) | reinterpret_cast<uintptr_t>(d_coef2)) & 15u)
-        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: coefficient planes must be 16-byte aligned");
-    int dev = -1;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev != stage->device) return fail(IFHIP_INVALID_STATE, "InvalidState: stage belongs to device %d, current device is %d", stage->device, dev);
-    FwdArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.g = stage->g; a.bgra = d_bgra; a.image_bytes = image_bytes; a.stride = stride; a.n_images = n_images; a.qt = d_qt;
-    a.coef[0] = d_coef0; a.coef[1] = d_coef1; a.coef[2] = d_coef2;
-    for (int c = 0; c < 3; ++c) a.plane[c] = stage->planes[c];
-    hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    for (uint32_t c = 0; c < 3u; ++c) {
-        a.comp = c;
-        hipLaunchKernelGGL(jpeg_fwd_sample_kernel, dim3((a.g.pw[c] / 4u + 255u) / 256u, a.g.ph[c], n_images), dim3(256), 0, st, a);
-        HIP_TRY(hipGetLastError());
-    }
-    for (uint32_t c = 0; c < 3u; ++c) {
-        a.comp = c;
-        const uint32_t nblk = a.g.bw[c] * a.g.bh[c];
-        hipLaunchKernelGGL(jpeg_fdct_quant_kernel, dim3((nblk + kBlocksPerWg - 1) / kBlocksPerWg, n_images), dim3(256), 0, st, a);
-        HIP_TRY(hipGetLastError());
-        if (a.g.rbw[c] != a.g.bw[c] || a.g.rbh[c] != a.g.bh[c]) {
-            hipLaunchKernelGGL(jpeg_dummy_dc_kernel, dim3((nblk + 255u) / 256u, n_images), dim3(256), 0, st, a);
-            HIP_TRY(hipGetLastError());
-        }
-    }
-    return IFHIP_OK;
-}
-
-int ifhip_jpeg_forward(const uint8_t* bgra, uint32_t width, uint32_t height, uint32_t stride, const uint8_t* h_samp,
-                       const uint8_t* v_samp, const uint16_t* qt, int16_t* coef0, int16_t* coef1, int16_t* coef2) {
-    if (!bgra || !qt || !coef0 || !coef1 || !coef2) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
-    ifhip_jpeg_fwd_stage* stage = nullptr;
-    int rc = ifhip_jpeg_fwd_stage_create(&stage, width, height, h_samp, v_samp, 1);
-    if (rc) return rc;
-    std::unique_ptr<ifhip_jpeg_fwd_stage> guard(stage);
-    if (static_cast<uint64_t>(width) * 4u > stride || (stride & 3u))
-        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: stride smaller than a BGRA row or not a multiple of 4");
-    const size_t in_bytes = static_cast<size_t>(height) * stride, in_valid = static_cast<size_t>(height - 1) * stride + static_cast<size_t>(width) * 4u;
-    uint8_t* d_in = nullptr;
-    uint16_t* d_qt = nullptr;
-    int16_t* d_c[3] = {nullptr, nullptr, nullptr};
-    int16_t* h_c[3] = {coef0, coef1, coef2};
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_in), in_bytes);
-    if (e == hipSuccess) e = hipMemcpy(d_in, bgra, in_valid, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_qt), 384);
-    if (e == hipSuccess) e = hipMemcpy(d_qt, qt, 384, hipMemcpyHostToDevice);
-    size_t cb[3];
-    for (int c = 0; c < 3 && e == hipSuccess; ++c) {
-        cb[c] = static_cast<size_t>(stage->g.bw[c]) * stage->g.bh[c] * 128u;
-        e = hipMalloc(reinterpret_cast<void**>(&d_c[c]), cb[c]);
-    }
-    if (e == hipSuccess) {
-        rc = ifhip_jpeg_forward_batch_device(stage, d_in, in_bytes, stride, d_qt, 1, d_c[0], d_c[1], d_c[2], nullptr);
-        if (rc == IFHIP_OK) {
-            e = hipStreamSynchronize(nullptr);
-            for (int c = 0; c < 3 && e == hipSuccess; ++c) e = hipMemcpy(h_c[c], d_c[c], cb[c], hipMemcpyDeviceToHost);
-        }
-    }
-    if (d_in) (void)hipFree(d_in);
-    if (d_qt) (void)hipFree(d_qt);
-    for (auto* p : d_c) if (p) (void)hipFree(p);
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(IFHIP_GPU_ERROR, "GpuError: jpeg forward staging failed: %s", hipGetErrorString(e));
-    return IFHIP_OK;
-}
-
-}  // extern "C"
