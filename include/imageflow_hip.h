@@ -215,6 +215,63 @@ IFHIP_API int ifhip_scale_spatial_blocks(const uint8_t* blocks, uint32_t n_block
 IFHIP_API int ifhip_block_scaler_tables(int n, int8_t* weights_7x8, uint8_t* log2_divisors_7,
                                         uint16_t* srgb_to_linear_256, uint8_t* linear_to_srgb_4096);
 
+/* ---- Inner D: whole-bitmap operations around the resampler ------------- */
+/* Byte-exact replacements for the bitmap primitives imageflow's graphs run between decode, resample and encode, so a
+ * frame batch stays in HBM for the whole chain.  In-place unless a canvas is named; BGRA8, any 4-byte aligned stride.
+ * Every *_batch_device call works on n_images equally shaped frames at a fixed byte pitch. */
+
+/* graphics::color_matrix::window_bgra32_apply_color_matrix (graphics/color_matrix.rs:5-29): matrix25 = row-major
+ * [[f32; 5]; 5] (host memory) as built by flow/nodes/color.rs:86-230 (ColorFilterSrgb; watermark opacity = Alpha(a),
+ * flow/nodes/watermark.rs:165-172). */
+IFHIP_API int ifhip_apply_color_matrix(uint8_t* bgra, uint32_t w, uint32_t h, uint32_t stride, const float* matrix25);
+IFHIP_API int ifhip_apply_color_matrix_batch_device(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w,
+                                                    uint32_t h, uint32_t stride, const float* matrix25, void* hip_stream);
+
+/* graphics::copy_rect::copy_rectangle (graphics/copy_rect.rs:12-119; crop / clone / expand_canvas /
+ * copy_rect_to_canvas, flow/nodes/clone_crop_fill_expand.rs).  Alpha bookkeeping as the reference: a Bgr32 canvas
+ * receiving a Bgra32 input gets its alpha set to 255 and *canvas_alpha_meaningful = 1 (:47-54); a Bgr32 input copied
+ * into a Bgra32 canvas has its own alpha set to 255 first (:64-66, the input bitmap is modified). */
+IFHIP_API int ifhip_copy_rect(uint8_t* input, uint32_t in_w, uint32_t in_h, uint32_t in_stride, int in_alpha_meaningful,
+                              uint8_t* canvas, uint32_t canvas_w, uint32_t canvas_h, uint32_t canvas_stride,
+                              int* canvas_alpha_meaningful, uint32_t from_x, uint32_t from_y, uint32_t to_x,
+                              uint32_t to_y, uint32_t w, uint32_t h);
+IFHIP_API int ifhip_copy_rect_batch_device(uint8_t* d_in, size_t in_image_bytes, uint32_t in_w, uint32_t in_h,
+                                           uint32_t in_stride, int in_alpha_meaningful, uint8_t* d_canvas,
+                                           size_t canvas_image_bytes, uint32_t canvas_w, uint32_t canvas_h,
+                                           uint32_t canvas_stride, int* canvas_alpha_meaningful, uint32_t from_x,
+                                           uint32_t from_y, uint32_t to_x, uint32_t to_y, uint32_t w, uint32_t h,
+                                           uint32_t n_images, void* hip_stream);
+
+/* BitmapWindowMut::fill_rectangle (graphics/bitmaps.rs:1504-1548): [x1, x2) x [y1, y2) := color (Color32 0xAARRGGBB);
+ * empty rectangles succeed, BlendWithMatte canvases only accept the full rectangle. */
+IFHIP_API int ifhip_fill_rect(uint8_t* bgra, uint32_t w, uint32_t h, uint32_t stride, int compositing, uint32_t x1,
+                              uint32_t y1, uint32_t x2, uint32_t y2, uint32_t color_bgra);
+IFHIP_API int ifhip_fill_rect_batch_device(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w, uint32_t h,
+                                           uint32_t stride, int compositing, uint32_t x1, uint32_t y1, uint32_t x2,
+                                           uint32_t y2, uint32_t color_bgra, void* hip_stream);
+
+/* BitmapWindowMut::normalize_unused_alpha (graphics/bitmaps.rs:1570-1576): alpha := 255 unless it is meaningful
+ * (EnableTransparency, flow/nodes/enable_transparency.rs:70-84). */
+IFHIP_API int ifhip_normalize_unused_alpha_batch_device(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w,
+                                                        uint32_t h, uint32_t stride, int alpha_meaningful, void* hip_stream);
+
+/* graphics::flip::flow_bitmap_bgra_flip_{vertical,horizontal}_safe (graphics/flip.rs:10-38); row padding stays. */
+IFHIP_API int ifhip_flip_vertical(uint8_t* bgra, uint32_t w, uint32_t h, uint32_t stride);
+IFHIP_API int ifhip_flip_horizontal(uint8_t* bgra, uint32_t w, uint32_t h, uint32_t stride);
+IFHIP_API int ifhip_flip_vertical_batch_device(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w,
+                                               uint32_t h, uint32_t stride, void* hip_stream);
+IFHIP_API int ifhip_flip_horizontal_batch_device(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w,
+                                                 uint32_t h, uint32_t stride, void* hip_stream);
+
+/* graphics::transpose::bitmap_window_transpose (graphics/transpose.rs:95-121): to(y, x) = from(x, y); needs
+ * from_w == to_h and from_h == to_w, distinct bitmaps (flow/nodes/rotate_flip_transpose.rs:150-153). */
+IFHIP_API int ifhip_transpose(const uint8_t* from, uint32_t from_w, uint32_t from_h, uint32_t from_stride, uint8_t* to,
+                              uint32_t to_w, uint32_t to_h, uint32_t to_stride);
+IFHIP_API int ifhip_transpose_batch_device(const uint8_t* d_from, size_t from_image_bytes, uint32_t from_w,
+                                           uint32_t from_h, uint32_t from_stride, uint8_t* d_to, size_t to_image_bytes,
+                                           uint32_t to_w, uint32_t to_h, uint32_t to_stride, uint32_t n_images,
+                                           void* hip_stream);
+
 /* ---- measurement helpers (bench.py) -------------------------------------------------------------------- */
 /* Runs `launches` back-to-back launches of the batch op on `hip_stream` bracketed by hipEvents on that stream
  * and returns the average milliseconds per launch. */

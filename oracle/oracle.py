@@ -79,6 +79,13 @@ def lib():
                                                                   C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_uint32]
         L.jo_jpeg_forward.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int] + [C.c_void_p] * 6
         L.jo_scale_spatial_block.restype = None
+        u32 = C.c_uint32
+        L.bo_apply_color_matrix.argtypes = [C.c_void_p, u32, u32, u32, C.c_void_p]
+        L.bo_copy_rect.argtypes = [C.c_void_p, u32, u32, u32, C.c_int, C.c_void_p, u32, u32, u32, C.POINTER(C.c_int)] + [u32] * 6
+        L.bo_fill_rect.argtypes = [C.c_void_p, u32, u32, u32, C.c_int] + [u32] * 5
+        L.bo_flip_vertical.argtypes = [C.c_void_p, u32, u32, u32]
+        L.bo_flip_horizontal.argtypes = [C.c_void_p, u32, u32, u32]
+        L.bo_transpose.argtypes = [C.c_void_p, u32, u32, u32, C.c_void_p, u32, u32, u32]
         L.jo_scale_spatial_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
         L.ifo_init_tables()
         _LIB = L
@@ -253,3 +260,35 @@ def jpeg_forward(bgra, width, height, stride, hs, vs, qt):
     if rc:
         raise RuntimeError(f"jpeg oracle: forward stage rc={rc}")
     return coef
+
+
+# ---------------------------------------------------------------------------------------------------------
+# whole-bitmap operations (oracle/bitmap_oracle.c); arrays are uint8 [h][stride], modified in place
+# ---------------------------------------------------------------------------------------------------------
+def apply_color_matrix(bgra, w, h, stride, matrix):
+    m = np.ascontiguousarray(matrix, np.float32).reshape(25)
+    return lib().bo_apply_color_matrix(bgra.ctypes.data, w, h, stride, m.ctypes.data)
+
+
+def copy_rect(inp, in_w, in_h, in_stride, in_alpha, canvas, cw, ch, c_stride, canvas_alpha, from_x, from_y, to_x, to_y, w, h):
+    """-> (rc, canvas_alpha_meaningful after the call)"""
+    flag = C.c_int(int(canvas_alpha))
+    rc = lib().bo_copy_rect(inp.ctypes.data, in_w, in_h, in_stride, int(in_alpha), canvas.ctypes.data, cw, ch, c_stride,
+                            C.byref(flag), from_x, from_y, to_x, to_y, w, h)
+    return rc, bool(flag.value)
+
+
+def fill_rect(bgra, w, h, stride, blend_with_matte, x1, y1, x2, y2, color32):
+    return lib().bo_fill_rect(bgra.ctypes.data, w, h, stride, int(blend_with_matte), x1, y1, x2, y2, color32)
+
+
+def flip_vertical(bgra, w, h, stride):
+    return lib().bo_flip_vertical(bgra.ctypes.data, w, h, stride)
+
+
+def flip_horizontal(bgra, w, h, stride):
+    return lib().bo_flip_horizontal(bgra.ctypes.data, w, h, stride)
+
+
+def transpose(frm, fw, fh, fstride, to, tw, th, tstride):
+    return lib().bo_transpose(frm.ctypes.data, fw, fh, fstride, to.ctypes.data, tw, th, tstride)
