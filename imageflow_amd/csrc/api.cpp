@@ -137,9 +137,23 @@ struct ifhip_resample_plan {
 
 namespace {
 
-size_t fused_lds_bytes(uint32_t n_u, uint32_t nquads, int channels, uint32_t wu_floats = 0, bool w_in_lds = false,
-                       bool l2s_in_lds = false, uint32_t lut_copies_log2 = 5) {
-    return fused_lds_layout(n_u, nquads, wu_floats, channels, w_in_lds, l2s_in_lds, lut_copies_log2).total;
+size_t fused_lds_bytes(uint32_t n_u, uint32_t nquads, int channels, uint32_t wu_floats, bool w_in_lds, bool l2s_in_lds,
+                       uint32_t lut_copies_log2, bool per_pixel) {
+    return fused_lds_layout(n_u, nquads, wu_floats, channels, w_in_lds, l2s_in_lds, lut_copies_log2, per_pixel).total;
+}
+// Horizontal pass mapping: one lane per output pixel (its C chains interleave, encode + store follow at once, no obuf
+// round trip) measured faster than one lane per (pixel, channel) on every BASELINE shape (cfg2 -2.6 %, cfg2 with alpha
+// -10 %, cfg3 -27 %); the per-channel form is kept for strips with less than one wave of outputs, where it is the only
+// way to spread the (long) chains over more lanes.
+bool use_per_pixel(uint32_t max_nu, int channels, uint32_t block) {
+    bool per_pixel = max_nu >= 64u || static_cast<uint64_t>(max_nu) * static_cast<uint32_t>(channels) > block;
+    if (const char* e = std::getenv("IFHIP_PERPIXEL")) per_pixel = std::atoi(e) != 0;      // experiment switch
+    return per_pixel;
+}
+uint32_t block_for(uint32_t max_quads) { return std::max<uint32_t>(64u, (max_quads + 63u) & ~63u); }
+size_t lds_limit() {                                   // experiment switch: cap the per-workgroup LDS (co-residency)
+    if (const char* e = std::getenv("IFHIP_LDS_LIMIT")) { const long v = std::atol(e); if (v >= 16384 && v <= 160 * 1024) return static_cast<size_t>(v); }
+    return kLdsLimit;
 }
 constexpr uint32_t kMinLutCopiesLog2 = 4;      // never fewer than 16 copies of the sRGB->float table (2-way conflicts)
 
@@ -149,7 +163,7 @@ bool plan_strips(const AxisWeights& wh, uint32_t max_lanes, int channels, std::v
     for (uint32_t n = 1; n <= wh.n_out; ++n) {
         std::vector<Strip> s;
         bool ok = true;
-        uint32_t mq = 0;
+        uint32_t mq = 0, mu = 0;
         for (uint32_t i = 0; i < n && ok; ++i) {
             Strip t;
             t.u0 = static_cast<uint32_t>(static_cast<uint64_t>(wh.n_out) * i / n);
@@ -163,9 +177,14 @@ bool plan_strips(const AxisWeights& wh, uint32_t max_lanes, int channels, std::v
             t.cx0 = lo & ~3u;
             t.nquads = (hi - t.cx0 + 3u) / 4u;
             if (t.nquads > max_lanes || (t.u1 - t.u0) > kMaxStripOutputs) ok = false;
-            if (fused_lds_bytes(t.u1 - t.u0, t.nquads, channels, 0, false, false, kMinLutCopiesLog2) > kLdsLimit) ok = false;
             mq = std::max(mq, t.nquads);
+            mu = std::max(mu, t.u1 - t.u0);
             s.push_back(t);
+        }
+        if (ok) {
+            const bool pp = use_per_pixel(mu, channels, block_for(mq));
+            for (const Strip& t : s)
+                if (fused_lds_bytes(t.u1 - t.u0, t.nquads, channels, 0, false, false, kMinLutCopiesLog2, pp) > lds_limit()) ok = false;
         }
         if (ok) { *out = std::move(s); *max_quads = mq; return true; }
         if (n > 4096) break;
@@ -296,32 +315,42 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         // LDS budget, in priority order: double-buffered rows + >= 16 copies of the sRGB->float table (always; the strips
         // were planned for that), the de-duplicated horizontal weight rows, one table copy per bank (32), then the
         // 16 KiB linear->sRGB table (otherwise encoded by threshold search)
+        const uint32_t block = block_for(ss.max_quads);
+        uint32_t max_nu = 0;
+        for (const Strip& s : ss.strips) max_nu = std::max(max_nu, s.u1 - s.u0);
+        const bool per_pixel = use_per_pixel(max_nu, channels, block);
+        const size_t limit = lds_limit();
         auto fits = [&](bool w, bool l2s, uint32_t copies_log2) {
             for (const Strip& s : ss.strips)
-                if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w, l2s, copies_log2) > kLdsLimit) return false;
+                if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w, l2s, copies_log2, per_pixel) > limit) return false;
             return true;
         };
         const bool w_in_lds = std::getenv("IFHIP_HW_GLOBAL") == nullptr && fits(true, false, kMinLutCopiesLog2);
-        const uint32_t copies_log2 = fits(w_in_lds, false, 5) ? 5u : kMinLutCopiesLog2;
-        const bool l2s_in_lds = std::getenv("IFHIP_L2S_SEARCH") == nullptr && fits(w_in_lds, true, copies_log2);
+        // What goes next depends on where the lookups are: the 16 KiB linear->sRGB table saves an 8-step threshold
+        // search (~40 instructions) per encoded channel, the second set of 16 table copies saves one LDS conflict cycle
+        // per converted sample.  Per output row a strip encodes 3*n_u channels and converts 12*nquads*(in_h/out_h)
+        // samples; thumbnail-sized outputs (cfg2) want the copies first, moderate ratios (cfg3) the encode table.
+        const double enc_cost = 3.0 * max_nu * 40.0;
+        const double conv_cost = 12.0 * ss.max_quads * (static_cast<double>(p->in_h) / std::max<uint32_t>(1u, p->out_h)) * 2.0;
+        const bool l2s_allowed = a.linear && std::getenv("IFHIP_L2S_SEARCH") == nullptr;
+        uint32_t copies_log2 = kMinLutCopiesLog2;
+        bool l2s_in_lds = false;
+        if (enc_cost > conv_cost) {
+            l2s_in_lds = l2s_allowed && fits(w_in_lds, true, kMinLutCopiesLog2);
+            if (fits(w_in_lds, l2s_in_lds, 5)) copies_log2 = 5u;
+        } else {
+            if (fits(w_in_lds, false, 5)) copies_log2 = 5u;
+            l2s_in_lds = l2s_allowed && fits(w_in_lds, true, copies_log2);
+        }
         a.lut_copies_log2 = copies_log2;
         a.h_w_in_lds = w_in_lds ? 1u : 0u;
         a.l2s_in_lds = l2s_in_lds ? 1u : 0u;
         size_t lds = 0;
         for (const Strip& s : ss.strips)
-            lds = std::max(lds, fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w_in_lds, l2s_in_lds, copies_log2));
+            lds = std::max(lds, fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w_in_lds, l2s_in_lds, copies_log2, per_pixel));
         if (lds > kLdsLimit) return fail(IFHIP_INVALID_STATE, "InvalidState: fused kernel LDS plan exceeds the CU (%zu bytes)", lds);
-        const uint32_t block = std::max<uint32_t>(64u, (ss.max_quads + 63u) & ~63u);
         const uint64_t grid = static_cast<uint64_t>(n_images) * sd.n_bands * a.n_strips;
         if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
-        // Horizontal pass mapping: one lane per output pixel (its C chains interleave, encode + store follow at once, no
-        // obuf round trip) measured faster than one lane per (pixel, channel) on every BASELINE shape (cfg2 -2.6 %,
-        // cfg2 with alpha -10 %, cfg3 -27 %); the per-channel form is kept for strips with less than one wave of outputs,
-        // where it is the only way to spread the (long) chains over more lanes.
-        uint32_t max_nu = 0;
-        for (const Strip& s : ss.strips) max_nu = std::max(max_nu, s.u1 - s.u0);
-        bool per_pixel = max_nu >= 64u || static_cast<uint64_t>(max_nu) * static_cast<uint32_t>(channels) > block;
-        if (const char* e = std::getenv("IFHIP_PERPIXEL")) per_pixel = std::atoi(e) != 0;      // experiment switch
         HIP_TRY(launch_fused(a, p->slots, alpha != 0, per_pixel, static_cast<uint32_t>(grid), block, lds, st));
         return IFHIP_OK;
     }
@@ -483,7 +512,12 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
     for (int al = 0; al < 2 && p->fused_possible; ++al) {
         const int channels = al ? 4 : 3;
         ifhip_resample_plan::StripSet& ss = p->sets[al];
-        ss.ok = plan_strips(p->wh, static_cast<uint32_t>(fused_max_threads(p->slots, channels)), channels, &ss.strips, &ss.max_quads);
+        uint32_t max_lanes = static_cast<uint32_t>(fused_max_threads(p->slots, channels));
+        if (const char* e = std::getenv("IFHIP_MAX_LANES")) {               // experiment switch: narrower strips
+            const int v = std::atoi(e);
+            if (v >= 64) max_lanes = std::min<uint32_t>(max_lanes, static_cast<uint32_t>(v) & ~63u);
+        }
+        ss.ok = plan_strips(p->wh, max_lanes, channels, &ss.strips, &ss.max_quads);
         if (ss.ok && (rc = upload(ss.strips, &ss.d_strips))) return rc;
     }
     *plan = p.release();

@@ -59,14 +59,23 @@ struct ResampleArgs {
 // Shape of the fused kernel for a ring of K rows and C channels per pixel.  The vertical accumulators alone take
 // K*4*C registers per lane.  Three shapes, picked by a register estimate (checked against the compiler's report):
 //   wide + pipelined : 1024 lanes (128 registers), D = 4 rows in flight, converted samples double buffered
-//   wide + plain     : 1024 lanes, D = 2, no double buffering (register-heavier rings, e.g. K = 4 with alpha)
-//   narrow           : 512 lanes (256 registers), D = 4, pipelined; strips get narrower
+//   wide + plain     : 1024 lanes, D = 4, no double buffering (register-heavier rings, e.g. K = 4 with alpha)
+//   narrow           : 512 lanes (256 registers), D = 8, pipelined; strips get narrower
+// D is sized by bytes in flight: a CU needs ~46 KB outstanding to cover HBM latency at its share of the bandwidth
+// (1024 lanes x 4 rows x 16 B = 64 KB; 512 lanes need 8 rows for the same).  Measured: cfg5 2.78 -> 2.46 ms with
+// D = 8 on the narrow shape, cfg2 with alpha 2.05 -> 2.03 ms with D = 4 on the plain shape.
+#ifndef IFHIP_PLAIN_D
+#define IFHIP_PLAIN_D 4
+#endif
+#ifndef IFHIP_NARROW_D
+#define IFHIP_NARROW_D 8
+#endif
 struct FusedShape { int threads, rows_in_flight, pipelined; };
 constexpr FusedShape fused_shape(int K, int channels) {
     // thresholds read off the compiler's register report (python -m imageflow_amd.kernel_report): no variant spills
     return (channels == 3 ? K <= 4 : K <= 2) ? FusedShape{1024, 4, 1}
-         : (channels == 3 ? K <= 5 : K <= 4) ? FusedShape{1024, 2, 0}
-                                             : FusedShape{512, 4, 1};
+         : (channels == 3 ? K <= 5 : K <= 4) ? FusedShape{1024, IFHIP_PLAIN_D, 0}
+                                             : FusedShape{512, IFHIP_NARROW_D, 1};
 }
 constexpr int fused_max_threads(int K, int channels) { return fused_shape(K, channels).threads; }
 // the step whose row the kernel requests while working on step i (see build_vschedule)
@@ -82,17 +91,20 @@ struct FusedLds {
 __host__ __device__
 #endif
 inline FusedLds fused_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t wu_floats, int channels, bool w_in_lds,
-                                 bool l2s_in_lds, uint32_t lut_copies_log2 = 5) {
+                                 bool l2s_in_lds, uint32_t lut_copies_log2, bool per_pixel) {
     FusedLds l;
     uint32_t off = 0;
     l.lut = off;   off += (256u << lut_copies_log2) * 4u;  // sRGB->float table, bank-interleaved copies
     l.thr = off;   off += 256u * 2u;                       // linear->sRGB thresholds (binary search fallback)
     l.l2s = off;   off += l2s_in_lds ? 16384u : 0u;        // linear->sRGB table
     l.hmeta = off; off += n_u * 16u;
-    l.obuf = off;  off += 2u * n_u * 16u;                  // horizontally filtered rows j-1 / j
+    l.obuf = off;  off += per_pixel ? 0u : 2u * n_u * 16u; // horizontally filtered rows j-1 / j (per-channel mapping only)
     l.hw = off;    off += w_in_lds ? ((wu_floats * 4u + 15u) & ~15u) : 0u;
-    // vertically filtered row, one plane per channel; the pitch is == 4 (mod 64) dwords so that the planes of one
-    // pixel sit 4 banks apart for the 16-byte horizontal gathers
+    // vertically filtered row, C sub-planes of 16 B per 4-pixel group: sub-planes 0 / 1 hold the (c0, c1) pairs of
+    // pixels 0,1 / 2,3 of the group (v_pk_fma_f32 operand order: one 16-byte read = two taps of two channels), the
+    // rest hold c2 of the four pixels (no alpha) or the (c2, c3) pairs likewise.  One chunk per group and sub-plane
+    // keeps the lane-to-lane stride of the horizontal gathers at (groups stepped) chunks, odd as often as even; the
+    // pitch is == 4 (mod 64) dwords so that the sub-planes of one group sit 4 banks apart.
     l.plane_pitch = ((nquads * 4u + 63u) & ~63u) + 4u;                         // floats
     l.inter_stride = l.plane_pitch * static_cast<uint32_t>(channels) * 4u;    // bytes per buffered row
     l.inter = off; off += 2u * l.inter_stride;             // vertically filtered rows j / j+1

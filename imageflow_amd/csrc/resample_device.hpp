@@ -62,10 +62,9 @@ struct ThresholdL2S {
 template <typename LutB>
 __device__ __forceinline__ uint8_t encode_channel(const ResampleArgs& a, LutB l2s, float v) {   // color.rs:61-71
     if (a.linear) {                                                                            // lut.rs:4-8
-        float s = v * 16383.0f;
-        s = (s != s) ? 0.0f : s;
-        s = s < 0.0f ? 0.0f : s;
-        s = s > 16383.0f ? 16383.0f : s;
+        // (v * 16383).clamp(0, 16383) as usize, NaN -> 0: max(NaN, 0) = 0 (maxNum), two instructions instead of three
+        // compare/select pairs
+        const float s = __builtin_fminf(__builtin_fmaxf(v * 16383.0f, 0.0f), 16383.0f);
         return l2s[static_cast<uint32_t>(s)];
     }
     return uchar_clamp_ff(255.0f * v);
@@ -145,7 +144,11 @@ __device__ __forceinline__ void store_pixel(const ResampleArgs& a, uint32_t img,
                   + static_cast<size_t>(a.y + j) * a.c_stride + static_cast<size_t>(a.x + u) * 4u;
     uint32_t* cw = reinterpret_cast<uint32_t*>(cp);           // canvas rows are 4-byte aligned (checked on host)
     uint32_t dst = 0;
-    if (ALPHA && a.mode == IFHIP_BLEND_WITH_SELF) dst = *cw;
+    // BlendWithSelf reads the canvas pixel.  The load and its wait are one asm statement: a load the compiler tracks
+    // would make it guard every later reuse of the destination register with s_waitcnt vmcnt(0) -- also on the paths
+    // (other compositing modes) where no load was issued -- and each such wait drains the source rows in flight.
+    if (ALPHA && a.mode == IFHIP_BLEND_WITH_SELF)
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(dst) : "v"(cw) : "memory");
     store_u32_untracked(cw, render_pixel<ALPHA>(a, p0, p1, p2, pa, dst, tb));
     if (a.f32_dump) {
         float4* d = reinterpret_cast<float4*>(a.f32_dump) + (static_cast<size_t>(img) * a.out_h + j) * a.out_w + u;

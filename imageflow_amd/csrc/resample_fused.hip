@@ -21,6 +21,9 @@
 #ifndef IFHIP_FUSED_K
 #error "compile with -DIFHIP_FUSED_K=<ring size 1..8>"
 #endif
+#ifndef IFHIP_PK_FMA
+#define IFHIP_PK_FMA 1       // vertical pass on v_pk_fma_f32 (0: scalar v_fma_f32, kept for A/B measurements)
+#endif
 #ifndef IFHIP_HP_UNROLL
 #define IFHIP_HP_UNROLL 1    // per-pixel horizontal loop
 #endif
@@ -58,7 +61,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     const Strip strip = a.strips[strip_i];
     const uint32_t n_u = strip.u1 - strip.u0;
 
-    const FusedLds L = fused_lds_layout(n_u, strip.nquads, a.h_wu_floats, C, WLDS, a.l2s_in_lds != 0, a.lut_copies_log2);
+    const FusedLds L = fused_lds_layout(n_u, strip.nquads, a.h_wu_floats, C, WLDS, a.l2s_in_lds != 0, a.lut_copies_log2, PERPIXEL);
     float* lut_banked = reinterpret_cast<float*>(smem + L.lut);      // [256][32] floats, one copy per bank
     uint16_t* thr = reinterpret_cast<uint16_t*>(smem + L.thr);       // 256 linear->sRGB thresholds
     uint4* hmeta = reinterpret_cast<uint4*>(smem + L.hmeta);         // per output column {left - cx0, taps, w offset}
@@ -66,7 +69,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     const float* hw_lds = reinterpret_cast<const float*>(smem + L.hw);
     float* inter = reinterpret_cast<float*>(smem + L.inter);         // 2 x vertically filtered row, C planes each
     const uint32_t inter_stride = L.inter_stride >> 2;               // floats per buffered row
-    const uint32_t plane_pitch = L.plane_pitch;                      // floats per channel plane
+    const uint32_t plane_pitch = L.plane_pitch;                      // floats per sub-plane
     const uint32_t obuf_stride = n_u * 4u;                           // floats
 
     for (uint32_t i = tid; i < (256u << a.lut_copies_log2); i += T) lut_banked[i] = a.lut_in[i >> a.lut_copies_log2];
@@ -103,13 +106,17 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     const uint8_t* src = a.in + static_cast<size_t>(img) * a.in_image_bytes
                          + static_cast<size_t>(strip.cx0 + 4u * quad) * 4u;
 
-    float acc[K][4][C];
+    // Ring accumulators and converted samples live as float2 pairs over the flattened (pixel, channel) index
+    // f = p*C + c, so that the vertical pass issues v_pk_fma_f32 (two IEEE fmaf per instruction, the weight broadcast
+    // from its SGPR): half the VALU issue slots of scalar v_fma_f32 for bit-identical results.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int NP = 2 * C;                       // pairs per lane and ring slot (4 pixels x C channels)
+    f32x2 acc[K][NP];
 #pragma unroll
     for (int s = 0; s < K; ++s)
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[s][p][c] = 0.0f;
+        for (int i = 0; i < NP; ++i) acc[s][i] = f32x2{0.0f, 0.0f};
+    auto acc_at = [&](int s, int p, int c) -> float { const int f = p * C + c; return (f & 1) ? acc[s][f >> 1].y : acc[s][f >> 1].x; };
 
     auto fetch_row = [&](int y) -> uint4 {                               // y is wave-uniform; -1 = nothing needed
         const uint32_t yy = y < 0 ? 0u : static_cast<uint32_t>(y);      // (row 0 is re-read: stays in L2)
@@ -122,8 +129,9 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     };
 
     // sample -> working float for the 4 pixels of one 16-byte load (arithmetic contract step 1)
-    auto convert = [&](const uint4& q, float (&v)[4][C]) {
+    auto convert = [&](const uint4& q, f32x2 (&vv)[NP]) {
         const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+        float v[4][C];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const uint32_t px = w4[p];
@@ -138,80 +146,70 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                 v[p][C - 1] = af;
             }
         }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) vv[i] = f32x2{v[(2 * i) / C][(2 * i) % C], v[(2 * i + 1) / C][(2 * i + 1) % C]};
     };
 
-    // ---- horizontal pass of one output row: chain idx = (output column ul, channel c), the strictly ascending
-    // fmaf sum over its taps (arithmetic contract step 3).  Runs right after the row hand-over barrier on the
-    // lowest lanes.  Samples come from the channel's plane, weights from the output's (de-duplicated) row, both as
-    // aligned 16-byte LDS reads of 4 taps; the first group may begin with +0 weights (columns before the first tap),
-    // the last group is predicated on the number of valid taps.
-    const uint32_t n_chain = n_u * C;
+    // ---- horizontal pass of one output row (arithmetic contract step 3: per channel, the strictly ascending fmaf sum
+    // over the taps).  Samples come from the row's two planes, weights from the output's de-duplicated row, all as
+    // aligned 16-byte LDS reads of one 4-tap group.  A group may begin or end with +0 weights (columns before the first /
+    // after the last tap): fmaf(+0, x, h) == h exactly for the finite x staged in LDS and h is never -0, so the padded
+    // groups run unpredicated.  The (c0, c1) chains advance together in one v_pk_fma_f32 per tap, likewise (c2, c3).
+    auto h_pair_group = [&](f32x2& h, const float4& w, const float4& t01, const float4& t23) {
+        h = __builtin_elementwise_fma(f32x2{w.x, w.x}, f32x2{t01.x, t01.y}, h);
+        h = __builtin_elementwise_fma(f32x2{w.y, w.y}, f32x2{t01.z, t01.w}, h);
+        h = __builtin_elementwise_fma(f32x2{w.z, w.z}, f32x2{t23.x, t23.y}, h);
+        h = __builtin_elementwise_fma(f32x2{w.w, w.w}, f32x2{t23.z, t23.w}, h);
+    };
+    auto h_single_group = [&](float& h, const float4& w, const float4& t) {
+        h = __builtin_fmaf(w.x, t.x, h);
+        h = __builtin_fmaf(w.y, t.y, h);
+        h = __builtin_fmaf(w.z, t.z, h);
+        h = __builtin_fmaf(w.w, t.w, h);
+    };
+    // Mapping 1: one lane per chain group g of an output column (g = 0: the (c0, c1) pair, g = 1: c2 / the (c2, c3)
+    // pair); results go through obuf and are encoded by the next row's hand-over.  Used for strips with less than one
+    // wave of outputs, where it spreads the (long) chains over twice the lanes.
+    const uint32_t n_chain = n_u * 2u;
     auto h_run_row = [&](const float* vrow, float* orow) {
         for (uint32_t idx = tid; idx < n_chain; idx += T) {
-            const uint32_t ul = idx / C, c = idx - ul * C;
+            const uint32_t ul = idx >> 1, g = idx & 1u;
             const uint4 m = hmeta[ul];
-            const float4* sp = reinterpret_cast<const float4*>(vrow + c * plane_pitch + m.x);
             const float4* wp = reinterpret_cast<const float4*>((WLDS ? hw_lds : a.h_wu) + m.z);
-            const uint32_t last = m.y - 1u;
-            float h = 0.0f;
-#pragma unroll IFHIP_H_UNROLL
-            for (uint32_t q = 0; q < last; ++q) {
-                const float4 w = wp[q];
-                const float4 x = sp[q];
-                h = __builtin_fmaf(w.x, x.x, h);
-                h = __builtin_fmaf(w.y, x.y, h);
-                h = __builtin_fmaf(w.z, x.z, h);
-                h = __builtin_fmaf(w.w, x.w, h);
+            if (g == 0u || ALPHA) {
+                const float4* s0 = reinterpret_cast<const float4*>(vrow + (2u * g) * plane_pitch + m.x);
+                const float4* s1 = reinterpret_cast<const float4*>(vrow + (2u * g + 1u) * plane_pitch + m.x);
+                f32x2 h = {0.0f, 0.0f};
+                for (uint32_t q = 0; q < m.y; ++q) h_pair_group(h, wp[q], s0[q], s1[q]);
+                *reinterpret_cast<float2*>(orow + ul * 4u + 2u * g) = make_float2(h.x, h.y);
+            } else {
+                const float4* sp = reinterpret_cast<const float4*>(vrow + 2u * plane_pitch + m.x);
+                float h = 0.0f;
+                for (uint32_t q = 0; q < m.y; ++q) h_single_group(h, wp[q], sp[q]);
+                orow[ul * 4u + 2u] = h;
             }
-            {
-                const float4 w = wp[last];
-                const float4 x = sp[last];
-                h = __builtin_fmaf(w.x, x.x, h);
-                if (m.w > 1u) h = __builtin_fmaf(w.y, x.y, h);
-                if (m.w > 2u) h = __builtin_fmaf(w.z, x.z, h);
-                if (m.w > 3u) h = __builtin_fmaf(w.w, x.w, h);
-            }
-            orow[ul * 4u + c] = h;
         }
     };
-    // Same pass, one lane per output PIXEL (all its channels, then encode + store at once): used when there are more
-    // chains than lanes (moderate scale factors: many short chains), where the per-chain set-up and the separate
-    // store phase would dominate.  No obuf round trip in this form.
-    constexpr bool h_per_pixel = PERPIXEL;           // host: n_u * C > workgroup size
+    // Mapping 2: one lane per output PIXEL (all its channels, then encode + store at once, no obuf round trip): used
+    // whenever a strip has at least a wave of outputs.
+    constexpr bool h_per_pixel = PERPIXEL;
     auto h_run_row_pixels = [&](uint32_t j, const float* vrow) {
         for (uint32_t ul = tid; ul < n_u; ul += T) {
             const uint4 m = hmeta[ul];
-            const float* sp = vrow + m.x;
             const float4* wp = reinterpret_cast<const float4*>((WLDS ? hw_lds : a.h_wu) + m.z);
-            const uint32_t last = m.y - 1u;
-            float h[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) h[c] = 0.0f;
+            const float4* sp = reinterpret_cast<const float4*>(vrow + m.x);       // sub-plane k at sp + k * (plane_pitch / 4)
+            const uint32_t pp4 = plane_pitch >> 2;
+            f32x2 h01 = {0.0f, 0.0f}, h23 = {0.0f, 0.0f};
+            float h2 = 0.0f;
 #pragma unroll IFHIP_HP_UNROLL
-            for (uint32_t q = 0; q < last; ++q) {
+            for (uint32_t q = 0; q < m.y; ++q) {
                 const float4 w = wp[q];
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float4 x = *reinterpret_cast<const float4*>(sp + c * plane_pitch + 4u * q);
-                    h[c] = __builtin_fmaf(w.x, x.x, h[c]);
-                    h[c] = __builtin_fmaf(w.y, x.y, h[c]);
-                    h[c] = __builtin_fmaf(w.z, x.z, h[c]);
-                    h[c] = __builtin_fmaf(w.w, x.w, h[c]);
-                }
-            }
-            {
-                const float4 w = wp[last];
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float4 x = *reinterpret_cast<const float4*>(sp + c * plane_pitch + 4u * last);
-                    h[c] = __builtin_fmaf(w.x, x.x, h[c]);
-                    if (m.w > 1u) h[c] = __builtin_fmaf(w.y, x.y, h[c]);
-                    if (m.w > 2u) h[c] = __builtin_fmaf(w.z, x.z, h[c]);
-                    if (m.w > 3u) h[c] = __builtin_fmaf(w.w, x.w, h[c]);
-                }
+                h_pair_group(h01, w, sp[q], sp[pp4 + q]);
+                if (ALPHA) h_pair_group(h23, w, sp[2u * pp4 + q], sp[3u * pp4 + q]);
+                else h_single_group(h2, w, sp[2u * pp4 + q]);
             }
             const OutTables<BankedLut, ThresholdL2S> tb{lut, ThresholdL2S{thr, l2s_lds}};
-            store_pixel<ALPHA>(a, img, j, strip.u0 + ul, h[0], h[1], h[2], ALPHA ? h[C - 1] : 1.0f, tb);
+            store_pixel<ALPHA>(a, img, j, strip.u0 + ul, h01.x, h01.y, ALPHA ? h23.x : h2, ALPHA ? h23.y : 1.0f, tb);
         }
     };
     int h_out_row = -1;              // output row whose horizontal result is waiting in obuf (uniform), -1: none
@@ -238,7 +236,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
         raw[d] = fetch_row(steps[s0 + d].y);
         __builtin_amdgcn_sched_barrier(0);      // keep issue order raw[0..D-1]: the loop's vmcnt(D-1) relies on it
     }
-    float vbuf[PIPE ? 2 : 1][4][C];
+    f32x2 vbuf[PIPE ? 2 : 1][NP];
     VStep rec[PIPE ? 2 : 1];
     if (PIPE) {
         rec[0] = steps[s0];
@@ -273,9 +271,9 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             }
             // ---- stage B: finish step si ----
             const VStep& st = rec[cur];
-            float (&v)[4][C] = vbuf[cur];
+            f32x2 (&v)[NP] = vbuf[cur];
 #if defined(IFHIP_EXP_LOAD_ONLY)   // experiment: stream rows, no arithmetic (NOT a product path)
-            acc[0][0][0] += v[0][0] + v[1][1] + v[2][2] + v[3][0];
+            acc[0][0] += v[0] + v[1] + v[2] + v[NP - 1];
 #else
             // Every ring slot accumulates unconditionally: a slot outside its window holds exactly +0.0f (initial
             // value / reset at flush) and has weight +0.0f in the step record, and fmaf(+0, v, +0) == +0 for the
@@ -286,9 +284,14 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                 for (int s = 0; s < K; ++s) {
                     const float w = st.w[s];
 #pragma unroll
-                    for (int p = 0; p < 4; ++p)
-#pragma unroll
-                        for (int c = 0; c < C; ++c) acc[s][p][c] = __builtin_fmaf(w, v[p][c], acc[s][p][c]);
+                    for (int i = 0; i < NP; ++i) {
+#if IFHIP_PK_FMA
+                        acc[s][i] = __builtin_elementwise_fma(f32x2{w, w}, v[i], acc[s][i]);
+#else
+                        acc[s][i].x = __builtin_fmaf(w, v[i].x, acc[s][i].x);
+                        acc[s][i].y = __builtin_fmaf(w, v[i].y, acc[s][i].y);
+#endif
+                    }
                 }
             }
 #endif
@@ -304,15 +307,19 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                 for (int s = 0; s < K; ++s) {
                     if (st.flush_slot == s) {
                         if (lane_on) {
-#pragma unroll
-                            for (int c = 0; c < C; ++c)
-                                *reinterpret_cast<float4*>(dst_row + c * plane_pitch + 4u * tid) =
-                                    make_float4(acc[s][0][c], acc[s][1][c], acc[s][2][c], acc[s][3][c]);
+                            float4* g4 = reinterpret_cast<float4*>(dst_row + 4u * tid);
+                            const uint32_t pp4 = plane_pitch >> 2;
+                            g4[0] = make_float4(acc_at(s, 0, 0), acc_at(s, 0, 1), acc_at(s, 1, 0), acc_at(s, 1, 1));
+                            g4[pp4] = make_float4(acc_at(s, 2, 0), acc_at(s, 2, 1), acc_at(s, 3, 0), acc_at(s, 3, 1));
+                            if (ALPHA) {
+                                g4[2u * pp4] = make_float4(acc_at(s, 0, 2), acc_at(s, 0, C - 1), acc_at(s, 1, 2), acc_at(s, 1, C - 1));
+                                g4[3u * pp4] = make_float4(acc_at(s, 2, 2), acc_at(s, 2, C - 1), acc_at(s, 3, 2), acc_at(s, 3, C - 1));
+                            } else {
+                                g4[2u * pp4] = make_float4(acc_at(s, 0, 2), acc_at(s, 1, 2), acc_at(s, 2, 2), acc_at(s, 3, 2));
+                            }
                         }
 #pragma unroll
-                        for (int p = 0; p < 4; ++p)
-#pragma unroll
-                            for (int c = 0; c < C; ++c) acc[s][p][c] = 0.0f;
+                        for (int i = 0; i < NP; ++i) acc[s][i] = f32x2{0.0f, 0.0f};
                     }
                 }
                 // One barrier per output row.  After it: row j's vertical result (inter[j&1]) and row j-1's horizontal
