@@ -30,6 +30,12 @@ WORKLOADS = {
     "cfg2-alpha": (3840, 2160, 200, 200, "Robidoux", 0.0, True, "ReplaceSelf", 0, 256),
     "cfg5": (7680, 4320, 400, 225, "Lanczos", 15.0, True, "BlendWithMatte", 0xFFFFFFFF, 64),
     "cfg3-l0": (3840, 2160, 1600, 900, "Robidoux", 0.0, False, "ReplaceSelf", 0, 256),
+    # the remaining levels of the export_4_sizes pyramid (self_test.rs:185-198) and the cfg4 / cfg1 resizes
+    "cfg3-l1": (1600, 900, 1200, 675, "Robidoux", 0.0, False, "ReplaceSelf", 0, 1024),
+    "cfg3-l2": (1600, 900, 800, 450, "Robidoux", 0.0, False, "ReplaceSelf", 0, 1024),
+    "cfg3-l3": (1200, 675, 400, 225, "Robidoux", 0.0, False, "ReplaceSelf", 0, 1024),
+    "cfg4-resize": (1920, 1080, 800, 450, "Robidoux", 0.0, False, "ReplaceSelf", 0, 1024),
+    "cfg1-resize": (480, 270, 200, 113, "Robidoux", 0.0, False, "ReplaceSelf", 0, 4096),
 }
 
 

@@ -138,8 +138,8 @@ struct ifhip_resample_plan {
 namespace {
 
 size_t fused_lds_bytes(uint32_t n_u, uint32_t nquads, int channels, uint32_t wu_floats, bool w_in_lds, bool l2s_in_lds,
-                       uint32_t lut_copies_log2, bool per_pixel) {
-    return fused_lds_layout(n_u, nquads, wu_floats, channels, w_in_lds, l2s_in_lds, lut_copies_log2, per_pixel).total;
+                       uint32_t lut_copies_log2, bool per_pixel, uint32_t frames = 1) {
+    return fused_lds_layout(n_u, nquads, wu_floats, channels, w_in_lds, l2s_in_lds, lut_copies_log2, per_pixel, frames).total;
 }
 // Horizontal pass mapping: one lane per output pixel (its C chains interleave, encode + store follow at once, no obuf
 // round trip) measured faster than one lane per (pixel, channel) on every BASELINE shape (cfg2 -2.6 %, cfg2 with alpha
@@ -320,9 +320,21 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         for (const Strip& s : ss.strips) max_nu = std::max(max_nu, s.u1 - s.u0);
         const bool per_pixel = use_per_pixel(max_nu, channels, block);
         const size_t limit = lds_limit();
+        // Frames per workgroup: a source narrower than half the workgroup would leave the CU with a handful of waves
+        // (one workgroup per CU: the tables fill most of the LDS), so F frames share a workgroup and its tables.
+        uint32_t frames = 1;
+        if (ss.strips.size() == 1 && std::getenv("IFHIP_ONE_FRAME_PER_WG") == nullptr) {
+            const uint32_t max_f = std::min<uint32_t>(static_cast<uint32_t>(fused_max_threads(p->slots, channels)) / block, n_images);
+            const Strip& s0 = ss.strips[0];
+            for (uint32_t f = max_f; f > 1; --f)
+                if (fused_lds_bytes(s0.u1 - s0.u0, s0.nquads, channels, p->h_wu_floats, true, a.linear != 0, kMinLutCopiesLog2, per_pixel, f) <= limit) {
+                    frames = f;
+                    break;
+                }
+        }
         auto fits = [&](bool w, bool l2s, uint32_t copies_log2) {
             for (const Strip& s : ss.strips)
-                if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w, l2s, copies_log2, per_pixel) > limit) return false;
+                if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w, l2s, copies_log2, per_pixel, frames) > limit) return false;
             return true;
         };
         const bool w_in_lds = std::getenv("IFHIP_HW_GLOBAL") == nullptr && fits(true, false, kMinLutCopiesLog2);
@@ -347,11 +359,13 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         a.l2s_in_lds = l2s_in_lds ? 1u : 0u;
         size_t lds = 0;
         for (const Strip& s : ss.strips)
-            lds = std::max(lds, fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w_in_lds, l2s_in_lds, copies_log2, per_pixel));
+            lds = std::max(lds, fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w_in_lds, l2s_in_lds, copies_log2, per_pixel, frames));
         if (lds > kLdsLimit) return fail(IFHIP_INVALID_STATE, "InvalidState: fused kernel LDS plan exceeds the CU (%zu bytes)", lds);
-        const uint64_t grid = static_cast<uint64_t>(n_images) * sd.n_bands * a.n_strips;
+        a.frames_per_wg = frames;
+        a.lanes_per_frame = block;
+        const uint64_t grid = static_cast<uint64_t>((n_images + frames - 1u) / frames) * sd.n_bands * a.n_strips;
         if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
-        HIP_TRY(launch_fused(a, p->slots, alpha != 0, per_pixel, static_cast<uint32_t>(grid), block, lds, st));
+        HIP_TRY(launch_fused(a, p->slots, alpha != 0, per_pixel, static_cast<uint32_t>(grid), block * frames, lds, st));
         return IFHIP_OK;
     }
 

@@ -37,6 +37,8 @@ struct ResampleArgs {
     uint32_t h_w_in_lds;             // 1: h_wu is staged in LDS
     uint32_t l2s_in_lds;             // 1: the 16 KiB linear->sRGB table is staged in LDS (else threshold search)
     uint32_t lut_copies_log2;        // the sRGB->float table is replicated 2^n times in LDS (5: one copy per bank)
+    uint32_t frames_per_wg;          // F: frames one workgroup works on side by side (narrow sources; tables shared)
+    uint32_t lanes_per_frame;        // multiple of 64; the workgroup has F * lanes_per_frame lanes
     // generic-kernel tables
     const uint32_t* h_left;
     const uint32_t* h_count;
@@ -85,20 +87,21 @@ constexpr int fused_lookahead(int K, int channels) {
 
 // LDS carve of the fused kernel, shared by host (size) and device (offsets); all offsets in bytes, 16-aligned.
 struct FusedLds {
-    uint32_t lut, thr, l2s, hmeta, obuf, hw, inter, plane_pitch, inter_stride, total;
+    uint32_t lut, thr, l2s, hmeta, obuf, hw, obuf_stride, inter, plane_pitch, inter_stride, total;
 };
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline FusedLds fused_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t wu_floats, int channels, bool w_in_lds,
-                                 bool l2s_in_lds, uint32_t lut_copies_log2, bool per_pixel) {
+                                 bool l2s_in_lds, uint32_t lut_copies_log2, bool per_pixel, uint32_t frames) {
     FusedLds l;
     uint32_t off = 0;
     l.lut = off;   off += (256u << lut_copies_log2) * 4u;  // sRGB->float table, bank-interleaved copies
     l.thr = off;   off += 256u * 2u;                       // linear->sRGB thresholds (binary search fallback)
     l.l2s = off;   off += l2s_in_lds ? 16384u : 0u;        // linear->sRGB table
     l.hmeta = off; off += n_u * 16u;
-    l.obuf = off;  off += per_pixel ? 0u : 2u * n_u * 16u; // horizontally filtered rows j-1 / j (per-channel mapping only)
+    l.obuf_stride = per_pixel ? 0u : 2u * n_u * 16u;       // horizontally filtered rows j-1 / j (per-chain mapping only)
+    l.obuf = off;  off += frames * l.obuf_stride;          // one pair per frame slot
     l.hw = off;    off += w_in_lds ? ((wu_floats * 4u + 15u) & ~15u) : 0u;
     // vertically filtered row, C sub-planes of 16 B per 4-pixel group: sub-planes 0 / 1 hold the (c0, c1) pairs of
     // pixels 0,1 / 2,3 of the group (v_pk_fma_f32 operand order: one 16-byte read = two taps of two channels), the
@@ -107,7 +110,7 @@ inline FusedLds fused_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t wu_floa
     // pitch is == 4 (mod 64) dwords so that the sub-planes of one group sit 4 banks apart.
     l.plane_pitch = ((nquads * 4u + 63u) & ~63u) + 4u;                         // floats
     l.inter_stride = l.plane_pitch * static_cast<uint32_t>(channels) * 4u;    // bytes per buffered row
-    l.inter = off; off += 2u * l.inter_stride;             // vertically filtered rows j / j+1
+    l.inter = off; off += frames * 2u * l.inter_stride;    // vertically filtered rows j / j+1, one pair per frame slot
     l.total = off;
     return l;
 }

@@ -51,35 +51,44 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     constexpr bool PIPE = fused_shape(K, C).pipelined != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const uint32_t tid = threadIdx.x;
-    const uint32_t T = blockDim.x;
+    // A workgroup works on F = a.frames_per_wg frames side by side (F > 1 only for sources narrower than half the
+    // workgroup: the tables in LDS are shared, the CU keeps a full complement of waves).  `wtid` indexes the whole
+    // workgroup (table fills), `tid` the lane within its frame slot, T the lanes per slot; slots are whole waves.
+    const uint32_t wtid = threadIdx.x;
+    const uint32_t WT = blockDim.x;
+    const uint32_t T = a.lanes_per_frame;
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(wtid / T);    // slots are whole waves: wave-uniform, lives in an SGPR
+    const uint32_t tid = wtid - slot * T;
     uint32_t b = blockIdx.x;
     const uint32_t strip_i = b % a.n_strips; b /= a.n_strips;
     const uint32_t band = b % a.n_bands;
-    const uint32_t img = b / a.n_bands;
+    const uint32_t img_raw = (b / a.n_bands) * a.frames_per_wg + slot;
+    const bool img_on = img_raw < a.n_images;              // the last workgroup may have idle slots: they run the same
+    const uint32_t img = img_on ? img_raw : a.n_images - 1u;   // schedule (barriers!) on the last frame and store nothing
 
     const Strip strip = a.strips[strip_i];
     const uint32_t n_u = strip.u1 - strip.u0;
 
-    const FusedLds L = fused_lds_layout(n_u, strip.nquads, a.h_wu_floats, C, WLDS, a.l2s_in_lds != 0, a.lut_copies_log2, PERPIXEL);
+    const FusedLds L = fused_lds_layout(n_u, strip.nquads, a.h_wu_floats, C, WLDS, a.l2s_in_lds != 0, a.lut_copies_log2, PERPIXEL,
+                                        a.frames_per_wg);
     float* lut_banked = reinterpret_cast<float*>(smem + L.lut);      // [256][32] floats, one copy per bank
     uint16_t* thr = reinterpret_cast<uint16_t*>(smem + L.thr);       // 256 linear->sRGB thresholds
     uint4* hmeta = reinterpret_cast<uint4*>(smem + L.hmeta);         // per output column {left - cx0, taps, w offset}
-    float* obuf = reinterpret_cast<float*>(smem + L.obuf);           // 2 x [n_u][4] horizontally filtered rows
+    float* obuf = reinterpret_cast<float*>(smem + L.obuf + slot * L.obuf_stride);   // 2 x [n_u][4] horizontally filtered rows
     const float* hw_lds = reinterpret_cast<const float*>(smem + L.hw);
-    float* inter = reinterpret_cast<float*>(smem + L.inter);         // 2 x vertically filtered row, C planes each
+    float* inter = reinterpret_cast<float*>(smem + L.inter + slot * 2u * L.inter_stride);   // 2 x vertically filtered row
     const uint32_t inter_stride = L.inter_stride >> 2;               // floats per buffered row
     const uint32_t plane_pitch = L.plane_pitch;                      // floats per sub-plane
     const uint32_t obuf_stride = n_u * 4u;                           // floats
 
-    for (uint32_t i = tid; i < (256u << a.lut_copies_log2); i += T) lut_banked[i] = a.lut_in[i >> a.lut_copies_log2];
-    for (uint32_t i = tid; i < 256u; i += T) thr[i] = a.l2s_thr[i];
+    for (uint32_t i = wtid; i < (256u << a.lut_copies_log2); i += WT) lut_banked[i] = a.lut_in[i >> a.lut_copies_log2];
+    for (uint32_t i = wtid; i < 256u; i += WT) thr[i] = a.l2s_thr[i];
     const uint8_t* l2s_lds = a.l2s_in_lds ? smem + L.l2s : nullptr;
     if (a.l2s_in_lds)
-        for (uint32_t i = tid; i < 1024u; i += T)
+        for (uint32_t i = wtid; i < 1024u; i += WT)
             reinterpret_cast<uint4*>(smem + L.l2s)[i] = reinterpret_cast<const uint4*>(a.l2s)[i];
-    const BankedLut lut{lut_banked, tid & ((1u << a.lut_copies_log2) - 1u), a.lut_copies_log2};
-    for (uint32_t i = tid; i < n_u; i += T) {
+    const BankedLut lut{lut_banked, wtid & ((1u << a.lut_copies_log2) - 1u), a.lut_copies_log2};
+    for (uint32_t i = wtid; i < n_u; i += WT) {
         uint4 m = a.h_meta[strip.u0 + i];
         m.x -= strip.cx0;
         hmeta[i] = m;
@@ -87,7 +96,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     if (WLDS) {
         const float4* src4 = reinterpret_cast<const float4*>(a.h_wu);
         float4* dst4 = reinterpret_cast<float4*>(smem + L.hw);
-        for (uint32_t i = tid; i < (a.h_wu_floats >> 2); i += T) dst4[i] = src4[i];
+        for (uint32_t i = wtid; i < (a.h_wu_floats >> 2); i += WT) dst4[i] = src4[i];
     }
     __syncthreads();
     // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. throw away the
@@ -171,6 +180,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     // pair); results go through obuf and are encoded by the next row's hand-over.  Used for strips with less than one
     // wave of outputs, where it spreads the (long) chains over twice the lanes.
     const uint32_t n_chain = n_u * 2u;
+    const uint32_t n_store = img_on ? n_u : 0u;      // idle frame slots compute nothing they would have to store
     auto h_run_row = [&](const float* vrow, float* orow) {
         for (uint32_t idx = tid; idx < n_chain; idx += T) {
             const uint32_t ul = idx >> 1, g = idx & 1u;
@@ -194,7 +204,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     // whenever a strip has at least a wave of outputs.
     constexpr bool h_per_pixel = PERPIXEL;
     auto h_run_row_pixels = [&](uint32_t j, const float* vrow) {
-        for (uint32_t ul = tid; ul < n_u; ul += T) {
+        for (uint32_t ul = tid; ul < n_store; ul += T) {
             const uint4 m = hmeta[ul];
             const float4* wp = reinterpret_cast<const float4*>((WLDS ? hw_lds : a.h_wu) + m.z);
             const float4* sp = reinterpret_cast<const float4*>(vrow + m.x);       // sub-plane k at sp + k * (plane_pitch / 4)
@@ -215,7 +225,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     int h_out_row = -1;              // output row whose horizontal result is waiting in obuf (uniform), -1: none
     auto h_store_row = [&](uint32_t j, const float* orow) {      // output stage of a horizontally filtered row
         // the lanes at the top of the workgroup take it: the chains sit on the lowest lanes
-        for (uint32_t ul = T - 1u - tid; ul < n_u; ul += T) {
+        for (uint32_t ul = T - 1u - tid; ul < n_store; ul += T) {
             const float4 o = *reinterpret_cast<const float4*>(orow + ul * 4u);
             const OutTables<BankedLut, ThresholdL2S> tb{lut, ThresholdL2S{thr, l2s_lds}};
             store_pixel<ALPHA>(a, img, j, strip.u0 + ul, o.x, o.y, o.z, ALPHA ? o.w : 1.0f, tb);

@@ -234,3 +234,14 @@ def test_every_ring_size_and_shape_variant():
             p = run_case(96, ih, 17, oh, filt=filt, alpha=alpha, n=1, seed=ih + oh)
             seen.add((p.kernel_kind(alpha)))
     assert 0 in seen
+
+
+@pytest.mark.parametrize("case", [(1600, 90, 600, 34, 3), (1600, 90, 1200, 68, 5), (480, 135, 200, 57, 11), (480, 135, 20, 6, 11),
+                                  (800, 60, 333, 25, 7), (1920, 108, 800, 45, 3)])
+@pytest.mark.parametrize("alpha", [False, True])
+def test_several_frames_per_workgroup(case, alpha):
+    """Sources narrower than half a workgroup share one workgroup (F frames side by side, csrc/api.cpp); batch sizes that
+    are not a multiple of F leave idle frame slots in the last workgroup."""
+    iw, ih, ow, oh, n = case
+    run_case(iw, ih, ow, oh, n=n, alpha=alpha, compose=BitmapCompositing.BlendWithSelf if alpha else BitmapCompositing.ReplaceSelf)
+    run_case(iw, ih, ow, oh, n=1, alpha=alpha, x=3, y=2, cw=ow + 5, ch=oh + 4)
