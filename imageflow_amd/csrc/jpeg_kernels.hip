@@ -10,8 +10,9 @@
 //                         coefficients fully coalesced (16 B per lane), de-quantises into an LDS workspace (block
 //                         pitch 72 dwords -> conflict-free column reads), runs the column pass (lane = column) and the
 //                         row pass (lane = row) and stores 8 bytes per lane into the component plane.
-//   jpeg_color_kernel     one lane per output pixel: Y + the (up to 4+4) chroma samples of the fancy up-sampler from
-//                         L1/L2, 4-byte coalesced BGRA stores.
+//   jpeg_color_kernel     one lane = 4 adjacent output pixels x 16 rows; walking down, the lane keeps the last two chroma
+//                         rows of the fancy up-sampler in registers (one new 4-byte chroma load per component and row
+//                         pair), 16-byte BGRA stores.
 // Algorithmic bytes per 4:2:0 pixel: 3 B coefficients + 4 B BGRA (+ 1.5 B written and re-read for the planes).
 #include <hip/hip_runtime.h>
 
@@ -273,60 +274,103 @@ __device__ __forceinline__ void chroma4(const uint8_t* P, uint32_t W, uint32_t D
     }
 }
 
-// one lane = 4 horizontally adjacent output pixels: one 4-byte Y load, 4-byte chroma loads, one 16-byte BGRA store
+// One lane = 4 horizontally adjacent output pixels x kColorRows output rows (one 4-byte Y load and one 16-byte BGRA store
+// per row).  With h2v2 fancy up-sampling a row pair (2cy, 2cy+1) needs chroma rows cy-1, cy, cy+1; walking down the rows
+// the lane keeps the last two chroma rows in registers and loads one new row per pair, so a pixel costs 0.25 Y loads
+// + 0.25 chroma loads instead of 1.25, and a wave lives 16 rows instead of one.
+constexpr uint32_t kColorRows = 16;
+
 __global__ void __launch_bounds__(256) jpeg_color_kernel(const JpegArgs a) {
-    const uint32_t x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u, y = blockIdx.y, img = blockIdx.z;
+    const uint32_t x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u, img = blockIdx.z;
     if (x0 >= a.g.out_w) return;
-    const uint8_t* py = a.plane[0] + static_cast<size_t>(img) * a.g.pw[0] * a.g.ph[0] + static_cast<size_t>(y) * a.g.pw[0] + x0;
-    uint32_t yv;
-    __builtin_memcpy(&yv, py, 4);                       // planes carry 16 bytes of slack behind the last row
-    const int32_t Y[4] = {static_cast<int32_t>(yv & 255u), static_cast<int32_t>((yv >> 8) & 255u),
-                          static_cast<int32_t>((yv >> 16) & 255u), static_cast<int32_t>(yv >> 24)};
-    uint32_t out[4];
+    const uint32_t y_begin = blockIdx.y * kColorRows;
+    const uint32_t y_end = min(y_begin + kColorRows, a.g.out_h);
+    const uint8_t* py = a.plane[0] + static_cast<size_t>(img) * a.g.pw[0] * a.g.ph[0] + x0;
+    uint8_t* dst0 = a.bgra + static_cast<size_t>(img) * a.image_bytes + static_cast<size_t>(x0) * 4u;
+    const bool vec_store = x0 + 4u <= a.g.out_w && ((reinterpret_cast<uintptr_t>(dst0) | a.stride) & 15u) == 0u;
+
+    auto emit = [&](uint32_t y, const int32_t (&v)[2][4], bool gray) {
+        uint32_t yv;
+        __builtin_memcpy(&yv, py + static_cast<size_t>(y) * a.g.pw[0], 4);     // planes carry 16 bytes of slack behind the last row
+        const int32_t Y[4] = {static_cast<int32_t>(yv & 255u), static_cast<int32_t>((yv >> 8) & 255u),
+                              static_cast<int32_t>((yv >> 16) & 255u), static_cast<int32_t>(yv >> 24)};
+        uint32_t out[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            out[i] = gray ? (static_cast<uint32_t>(Y[i]) * 0x010101u | 0xff000000u) : ycc_to_bgra(Y[i], v[0][i], v[1][i]);
+        uint8_t* dst = dst0 + static_cast<size_t>(y) * a.stride;
+        if (vec_store) {
+            *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i)
+                if (x0 + i < a.g.out_w) reinterpret_cast<uint32_t*>(dst)[i] = out[i];
+        }
+    };
+
+    int32_t v[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     if (a.g.ncomp == 1) {
+        for (uint32_t y = y_begin; y < y_end; ++y) emit(y, v, true);
+        return;
+    }
+    const uint8_t* P[2] = {a.plane[1] + static_cast<size_t>(img) * a.g.pw[1] * a.g.ph[1],
+                           a.plane[2] + static_cast<size_t>(img) * a.g.pw[2] * a.g.ph[2]};
+    if (a.g.upsample == 0u) {                                         // planes already at output resolution
+        for (uint32_t y = y_begin; y < y_end; ++y) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) out[k] = static_cast<uint32_t>(Y[k]) * 0x010101u | 0xff000000u;
-    } else {
-        int32_t v[2][4];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int c = 1 + k;
-            const uint8_t* P = a.plane[c] + static_cast<size_t>(img) * a.g.pw[c] * a.g.ph[c];
-            const uint32_t W = a.g.pw[c], DW = a.g.dw[c], DH = a.g.dh[c];
-            if (a.g.upsample == 0u) {                                     // plane already at output resolution
+            for (int k = 0; k < 2; ++k) {
                 uint32_t cv;
-                __builtin_memcpy(&cv, P + static_cast<size_t>(y) * W + x0, 4);
+                __builtin_memcpy(&cv, P[k] + static_cast<size_t>(y) * a.g.pw[1 + k] + x0, 4);
                 v[k][0] = cv & 255u; v[k][1] = (cv >> 8) & 255u; v[k][2] = (cv >> 16) & 255u; v[k][3] = cv >> 24;
-            } else {
-                // columns cx-1 .. cx+2 around the two chroma samples (cx = x0/2, cx+1) under this lane's 4 pixels
-                const int32_t c0 = static_cast<int32_t>(x0 >> 1) - 1;
-                int32_t s[4];
-                if (a.g.upsample == 1u) {                                 // h2v1 fancy: (3*near + far + {1,2}) >> 2
-                    chroma4(P, W, DW, DH, c0, static_cast<int32_t>(y), s);
-                    v[k][0] = (3 * s[1] + s[0] + 1) >> 2; v[k][1] = (3 * s[1] + s[2] + 2) >> 2;
-                    v[k][2] = (3 * s[2] + s[1] + 1) >> 2; v[k][3] = (3 * s[2] + s[3] + 2) >> 2;
-                } else {                                                  // h2v2 fancy: triangle in both directions
-                    const int32_t cy = static_cast<int32_t>(y >> 1), ny = (y & 1u) ? cy + 1 : cy - 1;
-                    int32_t n0[4], n1[4];
-                    chroma4(P, W, DW, DH, c0, cy, n0);
-                    chroma4(P, W, DW, DH, c0, ny, n1);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) s[i] = 3 * n0[i] + n1[i];
-                    v[k][0] = (3 * s[1] + s[0] + 8) >> 4; v[k][1] = (3 * s[1] + s[2] + 7) >> 4;
-                    v[k][2] = (3 * s[2] + s[1] + 8) >> 4; v[k][3] = (3 * s[2] + s[3] + 7) >> 4;
-                }
             }
+            emit(y, v, false);
+        }
+        return;
+    }
+    // columns cx-1 .. cx+2 around the two chroma samples (cx = x0/2, cx+1) under this lane's 4 pixels
+    const int32_t c0 = static_cast<int32_t>(x0 >> 1) - 1;
+    if (a.g.upsample == 1u) {                                         // h2v1 fancy: (3*near + far + {1,2}) >> 2
+        for (uint32_t y = y_begin; y < y_end; ++y) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                int32_t s[4];
+                chroma4(P[k], a.g.pw[1 + k], a.g.dw[1 + k], a.g.dh[1 + k], c0, static_cast<int32_t>(y), s);
+                v[k][0] = (3 * s[1] + s[0] + 1) >> 2; v[k][1] = (3 * s[1] + s[2] + 2) >> 2;
+                v[k][2] = (3 * s[2] + s[1] + 1) >> 2; v[k][3] = (3 * s[2] + s[3] + 2) >> 2;
+            }
+            emit(y, v, false);
+        }
+        return;
+    }
+    // h2v2 fancy: triangle in both directions; y_begin is even (kColorRows is), rows come in pairs (2cy, 2cy+1)
+    int32_t prev[2][4], cur[2][4], next[2][4];
+    const int32_t cy0 = static_cast<int32_t>(y_begin >> 1);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        chroma4(P[k], a.g.pw[1 + k], a.g.dw[1 + k], a.g.dh[1 + k], c0, cy0 - 1, prev[k]);
+        chroma4(P[k], a.g.pw[1 + k], a.g.dw[1 + k], a.g.dh[1 + k], c0, cy0, cur[k]);
+    }
+    for (uint32_t y = y_begin; y < y_end; y += 2u) {
+        const int32_t cy = static_cast<int32_t>(y >> 1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) chroma4(P[k], a.g.pw[1 + k], a.g.dw[1 + k], a.g.dh[1 + k], c0, cy + 1, next[k]);
+#pragma unroll
+        for (uint32_t r = 0; r < 2u; ++r) {
+            if (y + r >= y_end) break;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                int32_t s[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] = 3 * cur[k][i] + (r ? next[k][i] : prev[k][i]);
+                v[k][0] = (3 * s[1] + s[0] + 8) >> 4; v[k][1] = (3 * s[1] + s[2] + 7) >> 4;
+                v[k][2] = (3 * s[2] + s[1] + 8) >> 4; v[k][3] = (3 * s[2] + s[3] + 7) >> 4;
+            }
+            emit(y + r, v, false);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) out[i] = ycc_to_bgra(Y[i], v[0][i], v[1][i]);
-    }
-    uint8_t* dst = a.bgra + static_cast<size_t>(img) * a.image_bytes + static_cast<size_t>(y) * a.stride + static_cast<size_t>(x0) * 4u;
-    if (x0 + 4u <= a.g.out_w && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0u)) {
-        *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
-    } else {
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (uint32_t i = 0; i < 4u; ++i)
-            if (x0 + i < a.g.out_w) reinterpret_cast<uint32_t*>(dst)[i] = out[i];
+            for (int i = 0; i < 4; ++i) { prev[k][i] = cur[k][i]; cur[k][i] = next[k][i]; }
     }
 }
 
@@ -508,7 +552,7 @@ int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d
         hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nblk + kBlocksPerWg - 1) / kBlocksPerWg, n_images), dim3(256), 0, st, a);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(jpeg_color_kernel, dim3((a.g.out_w + 1023u) / 1024u, a.g.out_h, n_images), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((a.g.out_w + 1023u) / 1024u, (a.g.out_h + kColorRows - 1u) / kColorRows, n_images), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     return IFHIP_OK;
 }
