@@ -109,7 +109,11 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (default 256 = BASELINE config 2)")
     ap.add_argument("--pattern", default="mixed", choices=["mixed", "gradient", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather", default="final", choices=["final", "every", "none"],
+                    help="N > 1 only.  final: one RCCL gather of the outputs to rank 0 at the end of the timed region "
+                         "(the job's final gather, BASELINE north_star); every: one per step, asynchronous and double "
+                         "buffered against the next step; none: results stay sharded")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     args = ap.parse_args()
     global IN_W, IN_H, OUT_W, OUT_H, ALGO_BYTES_PER_FRAME
@@ -154,12 +158,16 @@ def main():
     canv = [Bitmap.create_u8(n, OUT_W, OUT_H, dev, compose=BitmapCompositing[wl[7]], matte=wl[8]) for _ in range(2)]
     info = ScaleAndRenderParams(0, 0, OUT_W, OUT_H, wl[5], Filter[wl[4]])
     plan = plan_for(IN_W, IN_H, OUT_W, OUT_H, info.interpolation_filter, wl[5], dev)
-    gather = distributed and not args.no_gather and os.environ.get("IFHIP_BENCH_GATHER", "1") != "0"
-    if dryrun and gather:          # gloo cannot gather device tensors: stage the shard through the host in the dry run
-        raise SystemExit("dry run: pass --no-gather")
+    mode = "none" if (not distributed or args.no_gather or os.environ.get("IFHIP_BENCH_GATHER", "1") == "0") else args.gather
+    gather = mode == "every"
+    if dryrun and mode != "none":  # gloo cannot gather device tensors: stage the shard through the host in the dry run
+        raise SystemExit("dry run: pass --gather none")
     from imageflow_amd.sharding import gather_to_root, max_over_ranks
     gathered = [torch.empty((world,) + tuple(c.data.shape), dtype=torch.uint8, device=dev) if rank == 0 else None
-                for c in canv] if gather else None
+                for c in canv] if mode != "none" else None
+    gather_note = {"none": "none",
+                   "every": "rccl gather of the outputs to rank 0 every step, asynchronous, double buffered",
+                   "final": "rccl gather of the outputs to rank 0 once, at the end of the timed region"}[mode]
 
     def step(i, pending):
         c = canv[i & 1]
@@ -188,6 +196,14 @@ def main():
     for i in range(args.steps):
         step(i, pending)
     sync_all(pending)
+    if mode == "final":
+        # The frames never meet before this point (no data-path collective).  A gather kernel running beside the
+        # resample kernel would take CUs from a grid that is exactly one workgroup per CU, so the job's one exchange
+        # happens after the last batch; a failure here is reported, it does not cost the measurement.
+        try:
+            gather_to_root(canv[(args.steps - 1) & 1].data, 0, async_op=False, out=gathered[0])
+        except Exception as e:  # noqa: BLE001
+            gather_note = f"final rccl gather failed: {type(e).__name__}: {e}"
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -219,7 +235,7 @@ def main():
                                    f"{' sharpen ' + str(wl[5]) if wl[5] else ''}, linear light, {wl[7]}, "
                                    f"alpha {'meaningful' if wl[6] else 'not meaningful'}, device resident, pattern={args.pattern}",
                        "frames_per_gpu": n, "kernel": "fused_resample_kernel" if plan.kernel_kind(wl[6]) == 0 else "generic",
-                       "gather": "rccl gather of the outputs to rank 0, asynchronous, double buffered" if gather else "none"},
+                       "gather": gather_note},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
