@@ -120,13 +120,11 @@ struct ifhip_resample_plan {
     // lazily built, guarded by mu
     mutable std::mutex mu;
     mutable std::map<uint64_t, ScheduleOnDevice> schedules;     // key: bands | group << 32 | ahead << 40
-    mutable float4* scratch = nullptr;
-    mutable size_t scratch_bytes = 0;
 
     ~ifhip_resample_plan() {
         for (void* p : {(void*)d_v_left, (void*)d_v_count, (void*)d_v_off, (void*)d_h_left, (void*)d_h_count,
                         (void*)d_h_off, (void*)d_v_w, (void*)d_h_w, (void*)d_h_wu, (void*)d_h_meta, (void*)sets[0].d_strips,
-                        (void*)sets[1].d_strips, (void*)scratch})
+                        (void*)sets[1].d_strips})
             if (p) (void)hipFree(p);
         for (auto& kv : schedules) {
             if (kv.second.steps) (void)hipFree(kv.second.steps);
@@ -304,17 +302,8 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
 
     if (fused) {
         const ifhip_resample_plan::StripSet& ss = p->sets[alpha ? 1 : 0];
-        const uint32_t want_bands = choose_bands(p, n_images, ss.strips.size());
-        ScheduleOnDevice sd;
-        const int channels_k = alpha ? 4 : 3;
-        rc = get_schedule(p, want_bands, fused_shape(p->slots, channels_k).rows_in_flight, fused_lookahead(p->slots, channels_k), &sd);
-        if (rc) return rc;
-        a.steps = sd.steps; a.band_begin = sd.band_begin; a.n_bands = sd.n_bands;
         a.strips = ss.d_strips; a.n_strips = static_cast<uint32_t>(ss.strips.size());
         const int channels = alpha ? 4 : 3;
-        // LDS budget, in priority order: double-buffered rows + >= 16 copies of the sRGB->float table (always; the strips
-        // were planned for that), the de-duplicated horizontal weight rows, one table copy per bank (32), then the
-        // 16 KiB linear->sRGB table (otherwise encoded by threshold search)
         const uint32_t block = block_for(ss.max_quads);
         uint32_t max_nu = 0;
         for (const Strip& s : ss.strips) max_nu = std::max(max_nu, s.u1 - s.u0);
@@ -332,6 +321,15 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
                     break;
                 }
         }
+        // bands: by the number of workgroups the launch really has (frames / F per strip)
+        const uint32_t want_bands = choose_bands(p, (n_images + frames - 1u) / frames, ss.strips.size());
+        ScheduleOnDevice sd;
+        rc = get_schedule(p, want_bands, fused_shape(p->slots, channels).rows_in_flight, fused_lookahead(p->slots, channels), &sd);
+        if (rc) return rc;
+        a.steps = sd.steps; a.band_begin = sd.band_begin; a.n_bands = sd.n_bands;
+        // LDS budget beyond the minimum the strips were planned for (double-buffered rows + 16 copies of the sRGB->float
+        // table): the de-duplicated horizontal weight rows, then -- by lookup cost -- the second 16 table copies and the
+        // 16 KiB linear->sRGB table (otherwise encoded by threshold search)
         auto fits = [&](bool w, bool l2s, uint32_t copies_log2) {
             for (const Strip& s : ss.strips)
                 if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w, l2s, copies_log2, per_pixel, frames) > limit) return false;
@@ -375,18 +373,18 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
     const size_t budget = static_cast<size_t>(1) << 30;
     uint32_t chunk = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(n_images, budget / std::max<size_t>(per_image, 1))));
     chunk = std::min<uint32_t>(chunk, 65535u);
-    {
-        std::lock_guard<std::mutex> lk(p->mu);
-        if (p->scratch_bytes < per_image * chunk) {
-            if (p->scratch) { HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(p->scratch); p->scratch = nullptr; p->scratch_bytes = 0; }
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->scratch), per_image * chunk));
-            p->scratch_bytes = per_image * chunk;
-        }
-    }
-    for (uint32_t i0 = 0; i0 < n_images; i0 += chunk) {
+    // stream-ordered scratch: nothing is shared between concurrent calls on the same plan, and the memory returns to
+    // the pool as soon as the last kernel of this call has run
+    float4* scratch = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), per_image * chunk, st));
+    hipError_t le = hipSuccess;
+    for (uint32_t i0 = 0; i0 < n_images && le == hipSuccess; i0 += chunk) {
         const uint32_t n = std::min(chunk, n_images - i0);
-        HIP_TRY(launch_generic(a, alpha != 0, p->scratch, i0, n, st));
+        le = launch_generic(a, alpha != 0, scratch, i0, n, st);
     }
+    const hipError_t fe = hipFreeAsync(scratch, st);
+    HIP_TRY(le);
+    HIP_TRY(fe);
     return IFHIP_OK;
 }
 
