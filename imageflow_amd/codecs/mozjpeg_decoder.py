@@ -115,3 +115,100 @@ def jpeg_idct_color_host(coef, qt, n_components, h_samp, v_samp, width, height, 
     _native.check(L.ifhip_jpeg_idct_color(p[0], p[1], p[2], q.ctypes.data, n_components, hs.ctypes.data, vs.ctypes.data,
                                           width, height, scale_num, int(luma_spatial), int(luma_srgb), out.ctypes.data, stride))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# entropy stage on the GPU (csrc/jpeg_entropy.hip): whole baseline files in, coefficient planes out
+# ---------------------------------------------------------------------------------------------------------
+def _bind_entropy():
+    L = _native.lib()
+    if getattr(L, "_jpeg_entropy_bound", False):
+        return L
+    L.ifhip_jpeg_parse_headers.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 9
+    L.ifhip_jpeg_entropy_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_uint32]
+    L.ifhip_jpeg_entropy_destroy.argtypes = [C.c_void_p]
+    L.ifhip_jpeg_entropy_destroy.restype = None
+    L.ifhip_jpeg_entropy_info.argtypes = [C.c_void_p] + [C.c_void_p] * 9
+    L.ifhip_jpeg_entropy_quant_tables.argtypes = [C.c_void_p, C.c_void_p]
+    L.ifhip_jpeg_entropy_decode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L._jpeg_entropy_bound = True
+    return L
+
+
+def get_image_info(data: bytes):
+    """The header facts MozJpegDecoder::get_unscaled_image_info needs (mozjpeg_decoder.rs:245-293), parsed on the host
+    (no GPU): dict(width, height, ncomp, hs, vs, bw, bh, qt [3][64] natural order, restart_interval)."""
+    L = _bind_entropy()
+    buf = np.frombuffer(data, np.uint8)
+    w, h, n, ri = C.c_uint32(), C.c_uint32(), C.c_int(), C.c_uint32()
+    hs, vs = np.zeros(3, np.uint8), np.zeros(3, np.uint8)
+    bw, bh = np.zeros(3, np.uint32), np.zeros(3, np.uint32)
+    qt = np.zeros((3, 64), np.uint16)
+    _native.check(L.ifhip_jpeg_parse_headers(buf.ctypes.data, len(data), C.addressof(w), C.addressof(h), C.addressof(n),
+                                             hs.ctypes.data, vs.ctypes.data, bw.ctypes.data, bh.ctypes.data, qt.ctypes.data,
+                                             C.addressof(ri)))
+    k = n.value
+    return dict(width=w.value, height=h.value, ncomp=k, hs=[int(v) for v in hs[:k]], vs=[int(v) for v in vs[:k]],
+                bw=[int(v) for v in bw[:k]], bh=[int(v) for v in bh[:k]], qt=qt, restart_interval=ri.value)
+
+
+class JpegEntropyBatch:
+    """ifhip_jpeg_entropy: n baseline files of one geometry, parsed and un-stuffed on the host, Huffman-decoded on the
+    GPU by the self-synchronising parallel decoder."""
+
+    def __init__(self, files, device="cuda:0"):
+        L = _bind_entropy()
+        self.device = torch.device(device)
+        self.n = len(files)
+        self._keep = [np.frombuffer(f, np.uint8) for f in files]
+        ptrs = (C.c_void_p * self.n)(*[k.ctypes.data for k in self._keep])
+        lens = (C.c_size_t * self.n)(*[len(f) for f in files])
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _native.check(L.ifhip_jpeg_entropy_create(C.byref(self._h), ptrs, lens, self.n))
+        w, h, n, ns, ng = C.c_uint32(), C.c_uint32(), C.c_int(), C.c_uint32(), C.c_uint32()
+        hs, vs = np.zeros(3, np.uint8), np.zeros(3, np.uint8)
+        bw, bh = np.zeros(3, np.uint32), np.zeros(3, np.uint32)
+        _native.check(L.ifhip_jpeg_entropy_info(self._h, C.addressof(w), C.addressof(h), C.addressof(n), hs.ctypes.data,
+                                                vs.ctypes.data, bw.ctypes.data, bh.ctypes.data, C.addressof(ns), C.addressof(ng)))
+        self.width, self.height, self.ncomp = w.value, h.value, n.value
+        self.h_samp, self.v_samp = [int(v) for v in hs[:self.ncomp]], [int(v) for v in vs[:self.ncomp]]
+        self.blocks_w, self.blocks_h = [int(v) for v in bw], [int(v) for v in bh]
+        self.n_subsequences, self.n_segments = ns.value, ng.value
+        qt = np.zeros((self.n, 3, 64), np.uint16)
+        _native.check(L.ifhip_jpeg_entropy_quant_tables(self._h, qt.ctypes.data))
+        self.qt = qt
+        self.rounds = 0
+
+    def read_coefficients(self, coef=None):
+        """-> list of int16 cuda tensors [n, bh_c, bw_c, 64] (jpeg_read_coefficients' virtual block arrays)."""
+        L = _bind_entropy()
+        if coef is None:
+            coef = [torch.empty((self.n, max(self.blocks_h[c], 1), max(self.blocks_w[c], 1), 64), dtype=torch.int16, device=self.device)
+                    for c in range(3)]
+        r = C.c_uint32()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _native.check(L.ifhip_jpeg_entropy_decode_device(self._h, coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
+                                                             C.addressof(r), C.c_void_p(stream)))
+        self.rounds = r.value
+        return coef
+
+    def __del__(self):
+        try:
+            if self._h:
+                _bind_entropy().ifhip_jpeg_entropy_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def decode_frames(files, device="cuda:0", scale_num=8, luma_spatial=False, luma_srgb=False) -> Bitmap:
+    """MozJpegDecoder::read_frame for a batch of equally shaped baseline files, entirely on the device:
+    entropy decode -> de-quantise + IDCT -> up-sample + colour -> BGRA frames."""
+    ent = JpegEntropyBatch(files, device)
+    coef = ent.read_coefficients()
+    stage = JpegPixelStage(ent.width, ent.height, ent.ncomp, ent.h_samp, ent.v_samp, ent.n, device, scale_num=scale_num,
+                           luma_spatial=luma_spatial, luma_srgb=luma_srgb)
+    qt = torch.from_numpy(ent.qt[:, :ent.ncomp].copy().view(np.int16)).to(device)
+    return stage.read_frames(coef, qt)

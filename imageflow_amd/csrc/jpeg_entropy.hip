@@ -1,0 +1,617 @@
+// jpeg_entropy.hip -- baseline (sequential Huffman) JPEG entropy decoding on gfx950.
+//
+// Replaces the serial jpeg_read_coefficients / decode_mcu loop that MzDec::read_frame drives on the host
+// (codecs/mozjpeg_decoder.rs:346-362 -> mozjpeg jdhuff.c) and that caps the JPEG path at ~50 MP/s per core: the scan's
+// bit stream is decoded by thousands of lanes at once and lands as the quantised coefficient planes the pixel stage
+// (jpeg_kernels.hip) consumes, so a compressed file is the only thing that crosses PCIe.
+//
+// Host (this file, plain C++): marker parsing (SOF0/SOF1, DHT, DQT, DRI, SOS), byte un-stuffing, splitting the scan at
+// restart markers into *segments* (independent bit streams with a known start state), canonical Huffman tables.
+// Device: the self-synchronising parallel decode (Klein & Wiseman; Weissenberger & Schmidt, ICPP 2018):
+//   * the stream is cut into sub-sequences of 1024 bits, one lane each;
+//   * round 0 decodes every sub-sequence speculatively from state (block 0 of the MCU, coefficient 0); because Huffman
+//     codes re-synchronise, most lanes end in the true state;
+//   * round r > 0 restarts each lane from its predecessor's exit state; lanes whose start did not change skip; the
+//     rounds stop when no exit state changes (first lanes of a segment are exact, so the fixpoint is the true decode);
+//   * a per-segment scan of (blocks started, DC sums per component) gives every lane its output block and DC predictors;
+//   * the write pass decodes once more and stores coefficients (natural order) straight into the planes.
+// Integer / table work, bound by dependent bit-serial decoding per lane and L1/L2 latency, not by HBM (no MFMA).
+// Coefficient-exact against oracle/jpeg_oracle.c jo_jpeg_read_coefficients (itself pinned to libjpeg-turbo).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "common.hpp"
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(IFHIP_GPU_ERROR, "GpuError: %s failed: %s", #expr, hipGetErrorString(e__));     \
+    } while (0)
+
+namespace ifhip {
+
+constexpr uint32_t kSubBits = 1024;                 // bits per sub-sequence (one lane)
+constexpr uint32_t kSubWords = kSubBits / 32;
+constexpr uint32_t kLutBits = 9;
+
+struct DerivedTab {                                  // one Huffman table, decode form (jdhuff.c jpeg_make_d_derived_tbl)
+    uint16_t lut[1u << kLutBits];                    // (length << 8) | symbol for codes of length <= 9, else 0
+    int32_t maxcode[18];                             // largest code of each length, -1 if none; [17] = sentinel
+    int32_t valoff[18];                              // huffval index of the first code of each length minus that code
+    uint8_t val[256];
+};
+
+struct EntropyGeom {
+    uint32_t ncomp, blocks_per_mcu, mcus_w, mcus_h;
+    uint32_t bw[3], bh[3];
+    uint8_t kcomp[10], kdx[10], kdy[10];             // block k of an MCU: component and offset inside the MCU
+    uint32_t hs[3], vs[3];
+};
+
+struct Segment {                                     // an independently decodable run: (image, restart interval)
+    uint32_t first_sub, n_sub;
+    uint32_t bit_end;                                // absolute bit index one past the segment's data
+    uint32_t n_blocks;                               // blocks it must produce
+    uint32_t image, first_mcu;
+};
+
+struct EntropyArgs {
+    EntropyGeom g;
+    const uint32_t* words;                           // un-stuffed scan data, big-endian words, segments 1024-bit aligned
+    const Segment* segs;
+    const uint32_t* sub_seg;                         // segment of every sub-sequence
+    const DerivedTab* tabs;                          // [image][comp][dc, ac]
+    uint32_t n_sub, n_seg;
+    uint32_t* exit_p[2];                             // exit bit position, double buffered by round parity
+    uint32_t* exit_cz[2];                            // exit (block-in-MCU << 8) | zigzag index
+    uint32_t* start_p;                               // start state the lane last decoded from
+    uint32_t* start_cz;
+    int4* cnt;                                       // per sub-sequence {blocks started, DC sum comp 0, 1, 2}
+    int4* prefix;                                    // exclusive per-segment scan of cnt
+    uint32_t* changed;                               // lanes whose exit state moved this round
+    uint32_t* errors;                                // bit 0 invalid code, 1 bad DC category, 2 run past 63, 3 short segment
+    int16_t* coef[3];                                // [image][bh][bw][64]
+    uint32_t round;
+};
+
+__constant__ uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
+                                    41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
+                                    15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// 32 bits of the stream starting at bit position p (two aligned word loads; the buffer is padded)
+__device__ __forceinline__ uint32_t peek32(const uint32_t* words, uint32_t p) {
+    const uint32_t w = p >> 5, s = p & 31u;
+    const uint64_t v = (static_cast<uint64_t>(words[w]) << 32) | words[w + 1u];
+    return static_cast<uint32_t>((v << s) >> 32);
+}
+
+// one Huffman symbol at the top of `bits` (32 bits of lookahead): returns the symbol, advances *len by the code length
+__device__ __forceinline__ uint32_t huff_symbol(const DerivedTab& t, uint32_t bits, uint32_t* len, uint32_t* err) {
+    const uint32_t e = t.lut[bits >> (32u - kLutBits)];
+    if (e) { *len = e >> 8; return e & 255u; }
+    uint32_t l = kLutBits + 1u;
+    int32_t code = static_cast<int32_t>(bits >> (32u - l));
+    while (l <= 16u && code > t.maxcode[l]) { ++l; code = static_cast<int32_t>(bits >> (32u - l)); }
+    if (l > 16u) { *err |= 1u; *len = 16u; return 0u; }          // garbage (speculative start or corrupt data): keep moving
+    *len = l;
+    return t.val[(code + t.valoff[l]) & 255];
+}
+
+__device__ __forceinline__ int32_t extend(uint32_t v, uint32_t s) {   // jdhuff.c HUFF_EXTEND
+    return s == 0u ? 0 : (v < (1u << (s - 1u)) ? static_cast<int32_t>(v) - static_cast<int32_t>((1u << s) - 1u) : static_cast<int32_t>(v));
+}
+
+// Decode from (p, c, z) until the bit position reaches `end`.  WRITE: store coefficients; else only track the state.
+template <bool WRITE>
+__device__ __forceinline__ void decode_run(const EntropyArgs& a, const DerivedTab* tabs, const Segment& sg, uint32_t& p, uint32_t& c,
+                                           uint32_t& z, uint32_t end, int32_t& n_started, int32_t (&dc)[3], int32_t block, uint32_t& err) {
+    const uint32_t B = a.g.blocks_per_mcu;
+    int16_t* blk = nullptr;
+    uint32_t comp = a.g.kcomp[c];
+    auto locate = [&](int32_t b) -> int16_t* {                       // block b of the segment -> its 64 coefficients
+        if (b < 0 || static_cast<uint32_t>(b) >= sg.n_blocks) return nullptr;
+        const uint32_t m = sg.first_mcu + static_cast<uint32_t>(b) / B, k = static_cast<uint32_t>(b) % B;
+        const uint32_t cm = a.g.kcomp[k];
+        const uint32_t my = m / a.g.mcus_w, mx = m - my * a.g.mcus_w;
+        const uint32_t bx = mx * a.g.hs[cm] + a.g.kdx[k], by = my * a.g.vs[cm] + a.g.kdy[k];
+        return a.coef[cm] + ((static_cast<size_t>(sg.image) * a.g.bh[cm] + by) * a.g.bw[cm] + bx) * 64u;
+    };
+    if (WRITE && z > 0u) blk = locate(block);
+    while (p < end) {
+        const uint32_t bits = peek32(a.words, p);
+        uint32_t len = 0;
+        if (z == 0u) {                                               // DC difference
+            const uint32_t t = huff_symbol(tabs[comp * 2u], bits, &len, &err);
+            if (t > 11u) err |= 2u;
+            const uint32_t s = t & 15u;
+            const uint32_t v = s ? ((bits << len) >> (32u - s)) : 0u;
+            const int32_t diff = extend(v, s);
+            p += len + s;
+            ++n_started;
+            dc[comp] += diff;
+            if (WRITE) {
+                ++block;
+                blk = locate(block);
+                if (blk) blk[0] = static_cast<int16_t>(dc[comp]);
+            }
+            z = 1u;
+        } else {
+            const uint32_t rs = huff_symbol(tabs[comp * 2u + 1u], bits, &len, &err);
+            const uint32_t r = rs >> 4, s = rs & 15u;
+            if (s == 0u) {
+                p += len;
+                if (r == 15u) z += 16u;                              // ZRL
+                else z = 64u;                                        // EOB
+            } else {
+                z += r;
+                const uint32_t v = (bits << len) >> (32u - s);
+                p += len + s;
+                if (z > 63u) err |= 4u;
+                else if (WRITE && blk) blk[kZigzag[z]] = static_cast<int16_t>(extend(v, s));
+                ++z;
+            }
+        }
+        if (z >= 64u) {                                              // block complete: next block of the MCU
+            z = 0u;
+            c = c + 1u == B ? 0u : c + 1u;
+            comp = a.g.kcomp[c];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) entropy_round_kernel(const EntropyArgs a) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.n_sub) return;
+    const uint32_t seg_i = a.sub_seg[s];
+    const Segment sg = a.segs[seg_i];
+    const uint32_t cur = a.round & 1u, prv = cur ^ 1u;
+    const bool first = s == sg.first_sub;
+    uint32_t p = s * kSubBits, cz = 0;
+    if (!first && a.round > 0u) { p = a.exit_p[prv][s - 1u]; cz = a.exit_cz[prv][s - 1u]; }
+    if (a.round > 0u && p == a.start_p[s] && cz == a.start_cz[s]) {          // same start as last time: same result
+        a.exit_p[cur][s] = a.exit_p[prv][s];
+        a.exit_cz[cur][s] = a.exit_cz[prv][s];
+        return;
+    }
+    a.start_p[s] = p;
+    a.start_cz[s] = cz;
+    const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end);
+    uint32_t c = cz >> 8, z = cz & 255u, err = 0;
+    int32_t n = 0, dc[3] = {0, 0, 0};
+    const DerivedTab* tabs = a.tabs + static_cast<size_t>(sg.image) * 6u;
+    decode_run<false>(a, tabs, sg, p, c, z, end, n, dc, 0, err);
+    const uint32_t ncz = (c << 8) | z;
+    if (a.round > 0u && (p != a.exit_p[prv][s] || ncz != a.exit_cz[prv][s])) atomicAdd(a.changed, 1u);
+    a.exit_p[cur][s] = p;
+    a.exit_cz[cur][s] = ncz;
+    a.cnt[s] = make_int4(n, dc[0], dc[1], dc[2]);
+}
+
+// exclusive scan of cnt over the sub-sequences of one segment (one workgroup per segment)
+__global__ void __launch_bounds__(256) entropy_scan_kernel(const EntropyArgs a) {
+    __shared__ int4 sh[256];
+    const Segment sg = a.segs[blockIdx.x];
+    int4 carry = make_int4(0, 0, 0, 0);
+    for (uint32_t base = 0; base < sg.n_sub; base += 256u) {
+        const uint32_t i = base + threadIdx.x;
+        int4 v = i < sg.n_sub ? a.cnt[sg.first_sub + i] : make_int4(0, 0, 0, 0);
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 256u; d <<= 1) {
+            int4 o = make_int4(0, 0, 0, 0);
+            if (threadIdx.x >= d) o = sh[threadIdx.x - d];
+            __syncthreads();
+            int4 m = sh[threadIdx.x];
+            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+            sh[threadIdx.x] = m;
+            __syncthreads();
+        }
+        const int4 inc = sh[threadIdx.x];
+        if (i < sg.n_sub) a.prefix[sg.first_sub + i] = make_int4(carry.x + inc.x - v.x, carry.y + inc.y - v.y, carry.z + inc.z - v.z, carry.w + inc.w - v.w);
+        const int4 tot = sh[255];
+        __syncthreads();
+        carry.x += tot.x; carry.y += tot.y; carry.z += tot.z; carry.w += tot.w;
+    }
+}
+
+__global__ void __launch_bounds__(256) entropy_write_kernel(const EntropyArgs a) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.n_sub) return;
+    const uint32_t seg_i = a.sub_seg[s];
+    const Segment sg = a.segs[seg_i];
+    const uint32_t fin = a.round & 1u;                       // parity of the last round run
+    const bool first = s == sg.first_sub;
+    uint32_t p = s * kSubBits, cz = 0;
+    if (!first) { p = a.exit_p[fin][s - 1u]; cz = a.exit_cz[fin][s - 1u]; }
+    const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end);
+    uint32_t c = cz >> 8, z = cz & 255u, err = 0;
+    const int4 pre = a.prefix[s];
+    int32_t n = 0, dc[3] = {pre.y, pre.z, pre.w};
+    const DerivedTab* tabs = a.tabs + static_cast<size_t>(sg.image) * 6u;
+    decode_run<true>(a, tabs, sg, p, c, z, end, n, dc, pre.x - 1, err);
+    // errors only count inside the segment's real blocks; the pad bits behind the last block decode to garbage by design
+    const bool last = s + 1u == sg.first_sub + sg.n_sub;
+    if (last && static_cast<uint32_t>(pre.x + n) < sg.n_blocks) err |= 8u;
+    if (!last && err) atomicOr(a.errors, err);
+    if (last && (err & 8u)) atomicOr(a.errors, 8u);
+}
+
+}  // namespace ifhip
+
+using namespace ifhip;
+
+// ==================================================================================================================
+// host: parser, un-stuffing, tables
+// ==================================================================================================================
+namespace {
+
+struct HuffSpec { uint8_t bits[17]; uint8_t vals[256]; bool present = false; };
+
+struct ParsedJpeg {
+    uint32_t width = 0, height = 0;
+    int ncomp = 0;
+    uint8_t comp_id[3] = {0, 0, 0}, hs[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+    uint16_t qt[4][64];
+    bool qt_present[4] = {false, false, false, false};
+    HuffSpec dc[4], ac[4];
+    uint32_t restart_interval = 0;
+    size_t scan_begin = 0;
+    uint32_t mcus_w = 0, mcus_h = 0, bw[3] = {0, 0, 0}, bh[3] = {0, 0, 0}, blocks_per_mcu = 0;
+};
+
+const uint8_t kZigzagHost[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
+                                 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
+                                 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+int parse_jpeg(const uint8_t* d, size_t len, ParsedJpeg* out) {
+    ParsedJpeg& P = *out;
+    if (!d || len < 4 || d[0] != 0xFF || d[1] != 0xD8) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: not a JPEG (no SOI)");
+    size_t i = 2;
+    bool have_sof = false;
+    while (i + 4 <= len) {
+        if (d[i] != 0xFF) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: marker expected at byte %zu", i);
+        while (i < len && d[i] == 0xFF) ++i;                                   // fill bytes
+        if (i >= len) break;
+        const uint8_t m = d[i++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;      // no payload
+        if (m == 0xD9) break;
+        if (i + 2 > len) break;
+        const size_t seg = (static_cast<size_t>(d[i]) << 8) | d[i + 1];
+        if (seg < 2 || i + seg > len) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: truncated marker segment FF%02X", m);
+        const uint8_t* q = d + i + 2;
+        const size_t n = seg - 2;
+        if (m == 0xDB) {                                                       // DQT
+            size_t k = 0;
+            while (k < n) {
+                const int pq = q[k] >> 4, t = q[k] & 15;
+                ++k;
+                if (t > 3 || k + (pq ? 128u : 64u) > n) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: bad DQT");
+                for (int z = 0; z < 64; ++z) {
+                    const uint16_t v = pq ? static_cast<uint16_t>((q[k] << 8) | q[k + 1]) : q[k];
+                    k += pq ? 2 : 1;
+                    P.qt[t][kZigzagHost[z]] = v;
+                }
+                P.qt_present[t] = true;
+            }
+        } else if (m == 0xC4) {                                                // DHT
+            size_t k = 0;
+            while (k + 17 <= n) {
+                const int tc = q[k] >> 4, th = q[k] & 15;
+                if (tc > 1 || th > 3) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: bad DHT");
+                HuffSpec& h = tc ? P.ac[th] : P.dc[th];
+                h.bits[0] = 0;
+                size_t total = 0;
+                for (int l = 1; l <= 16; ++l) { h.bits[l] = q[k + l]; total += q[k + l]; }
+                k += 17;
+                if (total > 256 || k + total > n) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: bad DHT");
+                std::memset(h.vals, 0, sizeof h.vals);
+                std::memcpy(h.vals, q + k, total);
+                k += total;
+                h.present = true;
+            }
+        } else if (m == 0xC0 || m == 0xC1) {                                   // baseline / extended sequential, Huffman
+            if (n < 6 || q[0] != 8) return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: %d-bit JPEG", n ? q[0] : 0);
+            P.height = (q[1] << 8) | q[2];
+            P.width = (q[3] << 8) | q[4];
+            P.ncomp = q[5];
+            if (P.ncomp != 1 && P.ncomp != 3) return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: %d-component JPEG", P.ncomp);
+            if (n < 6u + 3u * P.ncomp) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: bad SOF");
+            for (int c = 0; c < P.ncomp; ++c) {
+                P.comp_id[c] = q[6 + 3 * c];
+                P.hs[c] = q[7 + 3 * c] >> 4; P.vs[c] = q[7 + 3 * c] & 15; P.tq[c] = q[8 + 3 * c] & 3;
+            }
+            have_sof = true;
+        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: JPEG process SOF%d (only baseline Huffman)", m - 0xC0);
+        } else if (m == 0xDD) {
+            if (n >= 2) P.restart_interval = (q[0] << 8) | q[1];
+        } else if (m == 0xDA) {                                                // SOS
+            if (!have_sof) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: SOS before SOF");
+            if (n < 1 || q[0] != P.ncomp || n < 4u + 2u * P.ncomp)
+                return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: non-interleaved / multi-scan JPEG");
+            for (int s = 0; s < P.ncomp; ++s) {
+                int c = -1;
+                for (int k = 0; k < P.ncomp; ++k) if (P.comp_id[k] == q[1 + 2 * s]) c = k;
+                if (c != s) return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: scan component order");
+                P.td[c] = q[2 + 2 * s] >> 4; P.ta[c] = q[2 + 2 * s] & 15;
+                if (P.td[c] > 3 || P.ta[c] > 3) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: bad SOS");
+            }
+            P.scan_begin = i + seg;
+            break;
+        }
+        i += seg;
+    }
+    if (!have_sof || !P.scan_begin || P.width == 0 || P.height == 0) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: no frame / scan found");
+    uint32_t hmax = 1, vmax = 1;
+    for (int c = 0; c < P.ncomp; ++c) {
+        if (P.hs[c] < 1 || P.hs[c] > 2 || P.vs[c] < 1 || P.vs[c] > 2)
+            return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: sampling factor %dx%d", P.hs[c], P.vs[c]);
+        if (!P.qt_present[P.tq[c]] || !P.dc[P.td[c]].present || !P.ac[P.ta[c]].present)
+            return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: missing quantisation or Huffman table");
+        hmax = std::max<uint32_t>(hmax, P.hs[c]); vmax = std::max<uint32_t>(vmax, P.vs[c]);
+    }
+    if (P.ncomp == 1) { P.hs[0] = P.vs[0] = 1; hmax = vmax = 1; }             // a single-component scan is never interleaved
+    P.mcus_w = (P.width + 8 * hmax - 1) / (8 * hmax);
+    P.mcus_h = (P.height + 8 * vmax - 1) / (8 * vmax);
+    P.blocks_per_mcu = 0;
+    for (int c = 0; c < P.ncomp; ++c) { P.bw[c] = P.mcus_w * P.hs[c]; P.bh[c] = P.mcus_h * P.vs[c]; P.blocks_per_mcu += P.hs[c] * P.vs[c]; }
+    return IFHIP_OK;
+}
+
+void derive_table(const HuffSpec& h, DerivedTab* t) {
+    std::memset(t, 0, sizeof *t);
+    std::memcpy(t->val, h.vals, 256);
+    int32_t code = 0;
+    int k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        t->valoff[l] = k - code;
+        for (int i = 0; i < h.bits[l]; ++i, ++k, ++code) {
+            if (l <= static_cast<int>(kLutBits)) {
+                const uint32_t first = static_cast<uint32_t>(code) << (kLutBits - l);
+                for (uint32_t f = 0; f < (1u << (kLutBits - l)); ++f)
+                    if (first + f < (1u << kLutBits)) t->lut[first + f] = static_cast<uint16_t>((l << 8) | h.vals[k]);
+            }
+        }
+        t->maxcode[l] = h.bits[l] ? code - 1 : -1;
+        code <<= 1;
+    }
+    t->maxcode[17] = 0x7fffffff;
+}
+
+}  // namespace
+
+struct ifhip_jpeg_entropy {
+    int device = -1;
+    uint32_t n_images = 0;
+    ParsedJpeg first;                                // geometry shared by the batch
+    std::vector<uint16_t> qt;                        // [n][3][64]
+    EntropyArgs a;
+    std::vector<void*> owned;
+    uint32_t* h_flags = nullptr;                     // pinned: [0] changed, [1] errors
+    ~ifhip_jpeg_entropy() {
+        for (void* p : owned) if (p) (void)hipFree(p);
+        if (h_flags) (void)hipHostFree(h_flags);
+    }
+};
+
+template <typename T>
+static int dev_alloc(ifhip_jpeg_entropy* e, T** out, size_t count, const T* init = nullptr) {
+    *out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(out), std::max<size_t>(count, 1) * sizeof(T)));
+    e->owned.push_back(*out);
+    if (init && count) HIP_TRY(hipMemcpy(*out, init, count * sizeof(T), hipMemcpyHostToDevice));
+    return IFHIP_OK;
+}
+
+extern "C" {
+
+int ifhip_jpeg_parse_headers(const uint8_t* jpeg, size_t len, uint32_t* width, uint32_t* height, int* n_components,
+                             uint8_t* h_samp3, uint8_t* v_samp3, uint32_t* blocks_w3, uint32_t* blocks_h3,
+                             uint16_t* qt3x64, uint32_t* restart_interval) {
+    ParsedJpeg P;
+    int rc = parse_jpeg(jpeg, len, &P);
+    if (rc) return rc;
+    if (width) *width = P.width;
+    if (height) *height = P.height;
+    if (n_components) *n_components = P.ncomp;
+    for (int c = 0; c < 3; ++c) {
+        if (h_samp3) h_samp3[c] = c < P.ncomp ? P.hs[c] : 0;
+        if (v_samp3) v_samp3[c] = c < P.ncomp ? P.vs[c] : 0;
+        if (blocks_w3) blocks_w3[c] = c < P.ncomp ? P.bw[c] : 0;
+        if (blocks_h3) blocks_h3[c] = c < P.ncomp ? P.bh[c] : 0;
+        if (qt3x64) {
+            if (c < P.ncomp) std::memcpy(qt3x64 + 64 * c, P.qt[P.tq[c]], 128);
+            else std::memset(qt3x64 + 64 * c, 0, 128);
+        }
+    }
+    if (restart_interval) *restart_interval = P.restart_interval;
+    return IFHIP_OK;
+}
+
+int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* files, const size_t* lengths, uint32_t n_images) {
+    if (!out) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null out-pointer");
+    *out = nullptr;
+    if (!files || !lengths || n_images == 0) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: empty batch");
+    std::unique_ptr<ifhip_jpeg_entropy> e(new ifhip_jpeg_entropy);
+    if (hipGetDevice(&e->device) != hipSuccess)
+        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device; this library has no CPU path");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: device %d is %s, this library is built for gfx950 only", e->device, prop.gcnArchName);
+    e->n_images = n_images;
+    std::vector<uint32_t> words;
+    std::vector<Segment> segs;
+    std::vector<uint32_t> sub_seg;
+    std::vector<DerivedTab> tabs(static_cast<size_t>(n_images) * 6u);
+    e->qt.assign(static_cast<size_t>(n_images) * 192u, 0);
+    std::vector<uint8_t> bytes;
+    for (uint32_t img = 0; img < n_images; ++img) {
+        ParsedJpeg P;
+        int rc = parse_jpeg(files[img], lengths[img], &P);
+        if (rc) return rc;
+        if (img == 0) e->first = P;
+        else {
+            const ParsedJpeg& F = e->first;
+            bool same = P.width == F.width && P.height == F.height && P.ncomp == F.ncomp;
+            for (int c = 0; c < P.ncomp && same; ++c) same = P.hs[c] == F.hs[c] && P.vs[c] == F.vs[c];
+            if (!same) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: image %u differs in size or sampling from image 0 (one batch = one geometry)", img);
+        }
+        for (int c = 0; c < P.ncomp; ++c) {
+            std::memcpy(&e->qt[(static_cast<size_t>(img) * 3u + c) * 64u], P.qt[P.tq[c]], 128);
+            derive_table(P.dc[P.td[c]], &tabs[static_cast<size_t>(img) * 6u + 2u * c]);
+            derive_table(P.ac[P.ta[c]], &tabs[static_cast<size_t>(img) * 6u + 2u * c + 1u]);
+        }
+        // un-stuff the scan and cut it at restart markers
+        const uint8_t* d = files[img];
+        const size_t len = lengths[img];
+        const uint32_t total_mcus = P.mcus_w * P.mcus_h;
+        const uint32_t per_seg = P.restart_interval ? P.restart_interval : total_mcus;
+        uint32_t mcu0 = 0;
+        size_t i = P.scan_begin;
+        bool more = true;
+        while (more && mcu0 < total_mcus) {
+            bytes.clear();
+            more = false;
+            while (i < len) {
+                const uint8_t b = d[i++];
+                if (b != 0xFF) { bytes.push_back(b); continue; }
+                while (i < len && d[i] == 0xFF) ++i;                           // fill bytes before a marker
+                if (i >= len) break;
+                const uint8_t m = d[i++];
+                if (m == 0x00) { bytes.push_back(0xFF); continue; }
+                if (m >= 0xD0 && m <= 0xD7) { more = true; break; }            // restart: next segment
+                break;                                                         // EOI or any other marker: scan ends
+            }
+            Segment sg;
+            sg.image = img;
+            sg.first_mcu = mcu0;
+            const uint32_t mcus = std::min(per_seg, total_mcus - mcu0);
+            sg.n_blocks = mcus * P.blocks_per_mcu;
+            sg.first_sub = static_cast<uint32_t>(words.size() / kSubWords);
+            const size_t bits = bytes.size() * 8u;
+            sg.n_sub = static_cast<uint32_t>(std::max<size_t>(1, (bits + kSubBits - 1) / kSubBits));
+            const uint64_t bit_end = static_cast<uint64_t>(sg.first_sub) * kSubBits + bits;
+            if (bit_end + 4096 >= (1ull << 32)) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch holds more than 512 MB of scan data");
+            sg.bit_end = static_cast<uint32_t>(bit_end);
+            const size_t w0 = words.size();
+            words.resize(w0 + static_cast<size_t>(sg.n_sub) * kSubWords, 0u);
+            for (size_t k = 0; k < bytes.size(); ++k) words[w0 + (k >> 2)] |= static_cast<uint32_t>(bytes[k]) << (24u - 8u * (k & 3u));
+            for (uint32_t k = 0; k < sg.n_sub; ++k) sub_seg.push_back(static_cast<uint32_t>(segs.size()));
+            segs.push_back(sg);
+            mcu0 += mcus;
+        }
+        if (mcu0 < total_mcus) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: scan of image %u ends after %u of %u MCUs", img, mcu0, total_mcus);
+    }
+    words.resize(words.size() + 64, 0u);                                        // lookahead slack behind the last segment
+    const ParsedJpeg& F = e->first;
+    EntropyArgs& a = e->a;
+    std::memset(&a, 0, sizeof a);
+    a.g.ncomp = static_cast<uint32_t>(F.ncomp); a.g.blocks_per_mcu = F.blocks_per_mcu; a.g.mcus_w = F.mcus_w; a.g.mcus_h = F.mcus_h;
+    uint32_t k = 0;
+    for (int c = 0; c < F.ncomp; ++c) {
+        a.g.bw[c] = F.bw[c]; a.g.bh[c] = F.bh[c]; a.g.hs[c] = F.hs[c]; a.g.vs[c] = F.vs[c];
+        for (uint32_t dy = 0; dy < F.vs[c]; ++dy)
+            for (uint32_t dx = 0; dx < F.hs[c]; ++dx, ++k) { a.g.kcomp[k] = static_cast<uint8_t>(c); a.g.kdx[k] = static_cast<uint8_t>(dx); a.g.kdy[k] = static_cast<uint8_t>(dy); }
+    }
+    a.n_sub = static_cast<uint32_t>(sub_seg.size());
+    a.n_seg = static_cast<uint32_t>(segs.size());
+    int rc;
+    uint32_t *d_words = nullptr, *d_sub = nullptr;
+    Segment* d_segs = nullptr;
+    DerivedTab* d_tabs = nullptr;
+    if ((rc = dev_alloc(e.get(), &d_words, words.size(), words.data()))) return rc;
+    if ((rc = dev_alloc(e.get(), &d_segs, segs.size(), segs.data()))) return rc;
+    if ((rc = dev_alloc(e.get(), &d_sub, sub_seg.size(), sub_seg.data()))) return rc;
+    if ((rc = dev_alloc(e.get(), &d_tabs, tabs.size(), tabs.data()))) return rc;
+    a.words = d_words; a.segs = d_segs; a.sub_seg = d_sub; a.tabs = d_tabs;
+    for (int b = 0; b < 2; ++b) {
+        if ((rc = dev_alloc<uint32_t>(e.get(), &a.exit_p[b], a.n_sub))) return rc;
+        if ((rc = dev_alloc<uint32_t>(e.get(), &a.exit_cz[b], a.n_sub))) return rc;
+    }
+    if ((rc = dev_alloc<uint32_t>(e.get(), &a.start_p, a.n_sub))) return rc;
+    if ((rc = dev_alloc<uint32_t>(e.get(), &a.start_cz, a.n_sub))) return rc;
+    if ((rc = dev_alloc<int4>(e.get(), &a.cnt, a.n_sub))) return rc;
+    if ((rc = dev_alloc<int4>(e.get(), &a.prefix, a.n_sub))) return rc;
+    if ((rc = dev_alloc<uint32_t>(e.get(), &a.changed, 2))) return rc;
+    a.errors = a.changed + 1;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_flags), 2 * sizeof(uint32_t), hipHostMallocDefault));
+    *out = e.release();
+    return IFHIP_OK;
+}
+
+void ifhip_jpeg_entropy_destroy(ifhip_jpeg_entropy* e) { delete e; }
+
+int ifhip_jpeg_entropy_info(const ifhip_jpeg_entropy* e, uint32_t* width, uint32_t* height, int* n_components, uint8_t* h_samp3,
+                            uint8_t* v_samp3, uint32_t* blocks_w3, uint32_t* blocks_h3, uint32_t* n_subsequences, uint32_t* n_segments) {
+    if (!e) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null handle");
+    const ParsedJpeg& F = e->first;
+    if (width) *width = F.width;
+    if (height) *height = F.height;
+    if (n_components) *n_components = F.ncomp;
+    for (int c = 0; c < 3; ++c) {
+        if (h_samp3) h_samp3[c] = c < F.ncomp ? F.hs[c] : 0;
+        if (v_samp3) v_samp3[c] = c < F.ncomp ? F.vs[c] : 0;
+        if (blocks_w3) blocks_w3[c] = c < F.ncomp ? F.bw[c] : 0;
+        if (blocks_h3) blocks_h3[c] = c < F.ncomp ? F.bh[c] : 0;
+    }
+    if (n_subsequences) *n_subsequences = e->a.n_sub;
+    if (n_segments) *n_segments = e->a.n_seg;
+    return IFHIP_OK;
+}
+
+int ifhip_jpeg_entropy_quant_tables(const ifhip_jpeg_entropy* e, uint16_t* qt_n3x64) {
+    if (!e || !qt_n3x64) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
+    std::memcpy(qt_n3x64, e->qt.data(), e->qt.size() * sizeof(uint16_t));
+    return IFHIP_OK;
+}
+
+// Decodes the whole batch into d_coef* (each [n_images][bh_c][bw_c][64] int16, natural order).  The rounds need their
+// "anything changed?" answer on the host, so the call synchronises the stream; *rounds (optional) reports how many
+// synchronisation rounds ran.
+int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, int16_t* d_coef1, int16_t* d_coef2,
+                                     uint32_t* rounds, void* hip_stream) {
+    if (!e) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null handle");
+    const ParsedJpeg& F = e->first;
+    if (!d_coef0 || (F.ncomp == 3 && (!d_coef1 || !d_coef2))) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null coefficient plane");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != e->device) return fail(IFHIP_INVALID_STATE, "InvalidState: handle belongs to device %d, current device is %d", e->device, dev);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    EntropyArgs a = e->a;
+    a.coef[0] = d_coef0; a.coef[1] = d_coef1; a.coef[2] = d_coef2;
+    int16_t* planes[3] = {d_coef0, d_coef1, d_coef2};
+    for (int c = 0; c < F.ncomp; ++c)
+        HIP_TRY(hipMemsetAsync(planes[c], 0, static_cast<size_t>(e->n_images) * F.bw[c] * F.bh[c] * 128u, st));
+    HIP_TRY(hipMemsetAsync(a.changed, 0, 2 * sizeof(uint32_t), st));
+    const dim3 grid((a.n_sub + 255u) / 256u), block(256);
+    uint32_t r = 0;
+    const uint32_t max_rounds = a.n_sub + 2u;
+    for (;; ++r) {
+        a.round = r;
+        hipLaunchKernelGGL(entropy_round_kernel, grid, block, 0, st, a);
+        HIP_TRY(hipGetLastError());
+        if (r == 0) continue;
+        HIP_TRY(hipMemcpyAsync(e->h_flags, a.changed, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (e->h_flags[0] == 0u) break;
+        if (r >= max_rounds) return fail(IFHIP_INVALID_STATE, "InvalidState: entropy decode did not converge");
+        HIP_TRY(hipMemsetAsync(a.changed, 0, sizeof(uint32_t), st));
+    }
+    a.round = r;
+    hipLaunchKernelGGL(entropy_scan_kernel, dim3(a.n_seg), block, 0, st, a);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(entropy_write_kernel, grid, block, 0, st, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->h_flags + 1, a.errors, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (rounds) *rounds = r + 1u;
+    if (e->h_flags[1]) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: corrupt entropy-coded data (flags 0x%x)", e->h_flags[1]);
+    return IFHIP_OK;
+}
+
+}  // extern "C"

@@ -182,6 +182,27 @@ IFHIP_API int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const 
                                                  const uint16_t* d_qt, uint32_t n_images,
                                                  uint8_t* d_bgra, size_t image_bytes, uint32_t stride, void* hip_stream);
 
+/* Entropy stage: baseline sequential-Huffman decode of whole files on the GPU, in place of
+ * the serial jpeg_read_coefficients / decode_mcu loop MzDec::read_frame drives on the host
+ * (codecs/mozjpeg_decoder.rs:346-362).  ifhip_jpeg_parse_headers is host-only (no GPU): the SOF / DQT / DRI facts the
+ * decoder's get_image_info needs (mozjpeg_decoder.rs:245-293).  A batch = n files of one geometry (size + sampling);
+ * create() parses, un-stuffs and uploads the scans, decode_device() fills the coefficient planes the pixel stage reads
+ * ([n][blocks_h][blocks_w][64] int16, natural order) and synchronises the stream.  Progressive, arithmetic-coded,
+ * 12-bit, multi-scan and CMYK files return IFHIP_METHOD_NOT_IMPLEMENTED: keep those on libjpeg. */
+typedef struct ifhip_jpeg_entropy ifhip_jpeg_entropy;
+IFHIP_API int ifhip_jpeg_parse_headers(const uint8_t* jpeg, size_t len, uint32_t* width, uint32_t* height,
+                                       int* n_components, uint8_t* h_samp3, uint8_t* v_samp3, uint32_t* blocks_w3,
+                                       uint32_t* blocks_h3, uint16_t* qt3x64, uint32_t* restart_interval);
+IFHIP_API int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* files, const size_t* lengths,
+                                        uint32_t n_images);
+IFHIP_API void ifhip_jpeg_entropy_destroy(ifhip_jpeg_entropy* e);
+IFHIP_API int ifhip_jpeg_entropy_info(const ifhip_jpeg_entropy* e, uint32_t* width, uint32_t* height, int* n_components,
+                                      uint8_t* h_samp3, uint8_t* v_samp3, uint32_t* blocks_w3, uint32_t* blocks_h3,
+                                      uint32_t* n_subsequences, uint32_t* n_segments);
+IFHIP_API int ifhip_jpeg_entropy_quant_tables(const ifhip_jpeg_entropy* e, uint16_t* qt_n3x64);
+IFHIP_API int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, int16_t* d_coef1,
+                                               int16_t* d_coef2, uint32_t* rounds, void* hip_stream);
+
 /* Encode-side pixel stage ("next" row 1): what libjpeg runs before entropy coding when
  * MozjpegEncoder::write_frame (codecs/mozjpeg.rs:78-160, classic preset = set_fastest_defaults, input JCS_EXT_BGRA /
  * JCS_EXT_BGRX) compresses a flattened frame: rgb_ycc_convert, chroma down-sampling with libjpeg's edge expansion,

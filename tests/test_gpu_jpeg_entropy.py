@@ -1,0 +1,93 @@
+"""GPU parity of the entropy stage (csrc/jpeg_entropy.hip): the self-synchronising parallel Huffman decoder against the
+oracle's serial decoder (pinned to libjpeg-turbo), coefficient for coefficient, on every committed JPEG -- plain,
+restart intervals, optimised tables, grayscale -- decoded in batches of equal geometry; plus whole files -> BGRA."""
+import io
+import os
+from collections import defaultdict
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from imageflow_amd.codecs import mozjpeg_decoder as D  # noqa: E402
+from imageflow_amd.errors import FlowError  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def groups(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    g = defaultdict(list)
+    for i, n in enumerate(z["names"]):
+        data = z[f"jpg_{i}"].tobytes()
+        info = D.get_image_info(data)
+        g[(info["width"], info["height"], info["ncomp"], tuple(info["hs"]), tuple(info["vs"]))].append((str(n), data))
+    return g
+
+
+@pytest.mark.parametrize("fixture", ["jpeg_cases.npz", "jpeg_encode_cases.npz", "jpeg_entropy_cases.npz"])
+def test_batches_equal_the_serial_decoder(golden_dir, fixture):
+    total = 0
+    for key, items in groups(golden_dir, fixture).items():
+        files = [d for _, d in items]
+        ent = D.JpegEntropyBatch(files, DEV)
+        coef = ent.read_coefficients()
+        assert ent.rounds <= ent.n_subsequences + 2, (key, ent.rounds)      # worst case: one sub-sequence per round (q100 noise)
+        for k, (name, data) in enumerate(items):
+            j = O.jpeg_read_coefficients(data)
+            assert np.array_equal(ent.qt[k][:j["ncomp"]], j["qt"][:j["ncomp"]]), name
+            for c in range(j["ncomp"]):
+                got = coef[c][k].cpu().numpy()
+                assert got.shape == j["coef"][c].shape, name
+                if not np.array_equal(got, j["coef"][c]):
+                    bad = np.argwhere(got != j["coef"][c])
+                    raise AssertionError(f"{name} comp {c}: {len(bad)} coefficients differ, first at {bad[0]}")
+            total += 1
+    assert total in (36, 108, 62)
+
+
+def test_files_to_bgra_on_device(golden_dir):
+    for key, items in list(groups(golden_dir, "jpeg_entropy_cases.npz").items())[:6]:
+        files = [d for _, d in items]
+        frames = D.decode_frames(files, DEV).to_numpy()
+        for k, (name, data) in enumerate(items):
+            assert np.array_equal(frames[k], O.jpeg_idct_color(O.jpeg_read_coefficients(data))), name
+
+
+def test_large_files_and_convergence():
+    """4K-class inputs (BASELINE cfg4 shape): 2 files of 3840x2160 4:2:0 q85, gradient + noise, no restart markers --
+    ~20 000 sub-sequences each; the decoder must converge in a handful of rounds and match the serial decode."""
+    PIL = pytest.importorskip("PIL.Image")
+    w, h = 3840, 2160
+    y, x = np.mgrid[0:h, 0:w]
+    rng = np.random.default_rng(3)
+    pics = [np.stack([x * 255 // (w - 1), y * 255 // (h - 1), (x + y) * 255 // (w + h - 2)], -1).astype(np.uint8),
+            np.clip(np.stack([128 + 90 * np.sin(x / 9.0), 128 + 90 * np.cos(y / 7.0), 128 + 60 * np.sin((x + y) / 5.0)], -1)
+                    + rng.integers(-30, 31, size=(h, w, 3)), 0, 255).astype(np.uint8)]
+    files = []
+    for p in pics:
+        buf = io.BytesIO()
+        PIL.fromarray(p).save(buf, "JPEG", quality=85, subsampling="4:2:0", optimize=False)
+        files.append(buf.getvalue())
+    ent = D.JpegEntropyBatch(files, DEV)
+    coef = ent.read_coefficients()
+    assert ent.rounds <= 16, ent.rounds                 # typical content re-synchronises within a few symbols
+    for k, data in enumerate(files):
+        j = O.jpeg_read_coefficients(data)
+        for c in range(3):
+            assert np.array_equal(coef[c][k].cpu().numpy(), j["coef"][c]), (k, c)
+
+
+def test_rejections_and_corruption(golden_dir):
+    z = np.load(os.path.join(golden_dir, "jpeg_entropy_cases.npz"))
+    with pytest.raises(FlowError):
+        D.JpegEntropyBatch([z["progressive"].tobytes()], DEV)
+    a, b = z["jpg_0"].tobytes(), z["jpg_20"].tobytes()           # different geometry in one batch
+    with pytest.raises(FlowError):
+        D.JpegEntropyBatch([a, b], DEV)
+    cut = a[: len(a) * 2 // 3] + b"\xff\xd9"                     # scan ends early
+    with pytest.raises(FlowError):
+        D.JpegEntropyBatch([cut], DEV).read_coefficients()

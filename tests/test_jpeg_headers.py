@@ -1,0 +1,57 @@
+"""Host-only part of the entropy stage: ifhip_jpeg_parse_headers (csrc/jpeg_entropy.hip) against the oracle's parser on
+every committed file, and the oracle's serial Huffman decoder against libjpeg-turbo (Pillow) on the restart-interval /
+optimised-table fixtures that the GPU decoder is checked with."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from imageflow_amd.codecs import mozjpeg_decoder as D
+from imageflow_amd.errors import FlowError
+
+
+def all_files(golden_dir):
+    for name in ("jpeg_cases.npz", "jpeg_encode_cases.npz", "jpeg_entropy_cases.npz"):
+        z = np.load(os.path.join(golden_dir, name))
+        for i, n in enumerate(z["names"]):
+            yield f"{name}:{n}", z[f"jpg_{i}"].tobytes()
+
+
+def test_headers_match_the_oracle_parser(golden_dir):
+    count = 0
+    for name, data in all_files(golden_dir):
+        info = D.get_image_info(data)
+        j = O.jpeg_read_coefficients(data)
+        n = j["ncomp"]
+        assert (info["width"], info["height"], info["ncomp"]) == (j["width"], j["height"], n), name
+        assert info["hs"] == j["hs"][:n] and info["vs"] == j["vs"][:n], name
+        assert info["bw"] == j["bw"][:n] and info["bh"] == j["bh"][:n], name
+        assert np.array_equal(info["qt"][:n], j["qt"][:n]), name
+        count += 1
+    assert count == 36 + 108 + 62
+
+
+def test_rejections(golden_dir):
+    z = np.load(os.path.join(golden_dir, "jpeg_entropy_cases.npz"))
+    with pytest.raises(FlowError) as e:
+        D.get_image_info(z["progressive"].tobytes())
+    assert "MethodNotImplemented" in str(e.value)
+    with pytest.raises(FlowError):
+        D.get_image_info(b"\\x89PNG\\r\\n\\x1a\\n" + bytes(64))
+    data = z["jpg_0"].tobytes()
+    with pytest.raises(FlowError):
+        D.get_image_info(data[:200])                      # truncated inside the tables
+
+
+def test_oracle_decoder_equals_libjpeg_turbo_on_the_entropy_fixtures(golden_dir):
+    PIL = pytest.importorskip("PIL.Image")
+    z = np.load(os.path.join(golden_dir, "jpeg_entropy_cases.npz"))
+    for i, name in enumerate(z["names"]):
+        data = z[f"jpg_{i}"].tobytes()
+        ref = np.asarray(PIL.open(io.BytesIO(data)).convert("RGB"))
+        j = O.jpeg_read_coefficients(data)
+        h, w = ref.shape[:2]
+        px = O.jpeg_idct_color(j)[:, :4 * w].reshape(h, w, 4)
+        assert np.array_equal(px[..., [2, 1, 0]], ref), name
