@@ -34,7 +34,10 @@
 
 namespace ifhip {
 
-constexpr uint32_t kSubBits = 1024;                 // bits per sub-sequence (one lane)
+#ifndef IFHIP_ENT_SUBBITS
+#define IFHIP_ENT_SUBBITS 1024
+#endif
+constexpr uint32_t kSubBits = IFHIP_ENT_SUBBITS;     // bits per sub-sequence (one lane)
 constexpr uint32_t kSubWords = kSubBits / 32;
 constexpr uint32_t kLutBits = 9;
 
@@ -82,113 +85,198 @@ __constant__ uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18
                                     41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
                                     15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-// 32 bits of the stream starting at bit position p (two aligned word loads; the buffer is padded)
-__device__ __forceinline__ uint32_t peek32(const uint32_t* words, uint32_t p) {
-    const uint32_t w = p >> 5, s = p & 31u;
-    const uint64_t v = (static_cast<uint64_t>(words[w]) << 32) | words[w + 1u];
-    return static_cast<uint32_t>((v << s) >> 32);
+// ---- per-workgroup staging -------------------------------------------------------------------------------------
+// A workgroup of 256 lanes owns 256 consecutive sub-sequences = 32 KiB of contiguous stream.  Every lane walks its own
+// 128 bytes, so direct global reads are 64 different cache lines per wave instruction; instead the workgroup copies its
+// span (plus kMarginSubs sub-sequences of overshoot room) into LDS with coalesced loads.  One pad dword per 32-word
+// chunk makes the lane-to-lane stride 33 dwords: conflict-free when the lanes read at the same offset of their chunks.
+// The Huffman tables of the workgroup's first image go to LDS too; lanes of any other image (only in workgroups that
+// straddle two files) read theirs from global memory.
+constexpr uint32_t kLanes = 256;
+constexpr uint32_t kMarginSubs = 2;
+constexpr uint32_t kStageWords = (kLanes + kMarginSubs) * kSubWords;
+
+struct BitSrc {
+    const uint32_t* lds;         // staged words, skewed
+    uint32_t word0;              // absolute word index of lds[0]
+    const uint32_t* glob;
+    __device__ __forceinline__ uint32_t word(uint32_t w) const {
+        const uint32_t r = w - word0;
+        return r < kStageWords ? lds[r + (r >> 5)] : glob[w];
+    }
+    // 32 bits of the stream starting at bit position p (the buffer is padded behind the last segment)
+    __device__ __forceinline__ uint32_t peek32(uint32_t p) const {
+        const uint32_t w = p >> 5, s = p & 31u;
+        const uint64_t v = (static_cast<uint64_t>(word(w)) << 32) | word(w + 1u);
+        return static_cast<uint32_t>((v << s) >> 32);
+    }
+};
+
+__device__ __forceinline__ void stage_stream(const EntropyArgs& a, uint32_t* lds_words, uint32_t first_sub) {
+    const uint32_t word0 = first_sub * kSubWords;
+    const uint32_t total = (a.n_sub + 2u) * kSubWords;                 // the buffer carries 64 slack words
+    for (uint32_t r = threadIdx.x; r < kStageWords; r += kLanes) {
+        const uint32_t w = word0 + r;
+        lds_words[r + (r >> 5)] = w < total ? a.words[w] : 0u;
+    }
 }
 
-// one Huffman symbol at the top of `bits` (32 bits of lookahead): returns the symbol, advances *len by the code length
-__device__ __forceinline__ uint32_t huff_symbol(const DerivedTab& t, uint32_t bits, uint32_t* len, uint32_t* err) {
-    const uint32_t e = t.lut[bits >> (32u - kLutBits)];
+// one Huffman symbol at the top of `bits` (32 bits of lookahead): returns the symbol, sets *len to the code length
+template <typename Tab>
+__device__ __forceinline__ uint32_t huff_symbol(const Tab* t, uint32_t bits, uint32_t* len, uint32_t* err) {
+    const uint32_t e = t->lut[bits >> (32u - kLutBits)];
     if (e) { *len = e >> 8; return e & 255u; }
     uint32_t l = kLutBits + 1u;
     int32_t code = static_cast<int32_t>(bits >> (32u - l));
-    while (l <= 16u && code > t.maxcode[l]) { ++l; code = static_cast<int32_t>(bits >> (32u - l)); }
+    while (l <= 16u && code > t->maxcode[l]) { ++l; code = static_cast<int32_t>(bits >> (32u - l)); }
     if (l > 16u) { *err |= 1u; *len = 16u; return 0u; }          // garbage (speculative start or corrupt data): keep moving
     *len = l;
-    return t.val[(code + t.valoff[l]) & 255];
+    return t->val[(code + t->valoff[l]) & 255];
 }
 
 __device__ __forceinline__ int32_t extend(uint32_t v, uint32_t s) {   // jdhuff.c HUFF_EXTEND
     return s == 0u ? 0 : (v < (1u << (s - 1u)) ? static_cast<int32_t>(v) - static_cast<int32_t>((1u << s) - 1u) : static_cast<int32_t>(v));
 }
 
-// Decode from (p, c, z) until the bit position reaches `end`.  WRITE: store coefficients; else only track the state.
-template <bool WRITE>
-__device__ __forceinline__ void decode_run(const EntropyArgs& a, const DerivedTab* tabs, const Segment& sg, uint32_t& p, uint32_t& c,
-                                           uint32_t& z, uint32_t end, int32_t& n_started, int32_t (&dc)[3], int32_t block, uint32_t& err) {
-    const uint32_t B = a.g.blocks_per_mcu;
-    int16_t* blk = nullptr;
-    uint32_t comp = a.g.kcomp[c];
-    auto locate = [&](int32_t b) -> int16_t* {                       // block b of the segment -> its 64 coefficients
-        if (b < 0 || static_cast<uint32_t>(b) >= sg.n_blocks) return nullptr;
-        const uint32_t m = sg.first_mcu + static_cast<uint32_t>(b) / B, k = static_cast<uint32_t>(b) % B;
-        const uint32_t cm = a.g.kcomp[k];
-        const uint32_t my = m / a.g.mcus_w, mx = m - my * a.g.mcus_w;
-        const uint32_t bx = mx * a.g.hs[cm] + a.g.kdx[k], by = my * a.g.vs[cm] + a.g.kdy[k];
-        return a.coef[cm] + ((static_cast<size_t>(sg.image) * a.g.bh[cm] + by) * a.g.bw[cm] + bx) * 64u;
-    };
-    if (WRITE && z > 0u) blk = locate(block);
-    while (p < end) {
-        const uint32_t bits = peek32(a.words, p);
-        uint32_t len = 0;
-        if (z == 0u) {                                               // DC difference
-            const uint32_t t = huff_symbol(tabs[comp * 2u], bits, &len, &err);
-            if (t > 11u) err |= 2u;
-            const uint32_t s = t & 15u;
-            const uint32_t v = s ? ((bits << len) >> (32u - s)) : 0u;
-            const int32_t diff = extend(v, s);
-            p += len + s;
-            ++n_started;
-            dc[comp] += diff;
-            if (WRITE) {
-                ++block;
-                blk = locate(block);
-                if (blk) blk[0] = static_cast<int16_t>(dc[comp]);
-            }
-            z = 1u;
-        } else {
-            const uint32_t rs = huff_symbol(tabs[comp * 2u + 1u], bits, &len, &err);
-            const uint32_t r = rs >> 4, s = rs & 15u;
-            if (s == 0u) {
-                p += len;
-                if (r == 15u) z += 16u;                              // ZRL
-                else z = 64u;                                        // EOB
-            } else {
-                z += r;
-                const uint32_t v = (bits << len) >> (32u - s);
-                p += len + s;
-                if (z > 63u) err |= 4u;
-                else if (WRITE && blk) blk[kZigzag[z]] = static_cast<int16_t>(extend(v, s));
-                ++z;
-            }
-        }
-        if (z >= 64u) {                                              // block complete: next block of the MCU
-            z = 0u;
-            c = c + 1u == B ? 0u : c + 1u;
-            comp = a.g.kcomp[c];
-        }
+// Bit reader over the staged stream: 64 bits of lookahead in registers, topped up one word at a time, so a symbol costs
+// one table read and (every third symbol or so) one stream read instead of two stream reads of its own.
+struct BitReader {
+    const BitSrc& src;
+    uint64_t bb;            // stream bits from position p on, left-aligned
+    uint32_t avail;         // valid bits in bb (> 32 between symbols)
+    uint32_t next_w;        // next word to append
+    uint32_t p;             // absolute bit position of bb's top bit
+    __device__ __forceinline__ BitReader(const BitSrc& s, uint32_t pos) : src(s), p(pos) {
+        const uint32_t w = pos >> 5, sh = pos & 31u;
+        bb = ((static_cast<uint64_t>(src.word(w)) << 32) | src.word(w + 1u)) << sh;
+        avail = 64u - sh;
+        next_w = w + 2u;
+    }
+    __device__ __forceinline__ uint32_t peek() const { return static_cast<uint32_t>(bb >> 32); }
+    __device__ __forceinline__ void skip(uint32_t n) {
+        bb <<= n; avail -= n; p += n;
+        if (avail <= 32u) { bb |= static_cast<uint64_t>(src.word(next_w)) << (32u - avail); avail += 32u; ++next_w; }
+    }
+};
+
+// One symbol of the scan: updates (c, z) and the reader; reports what it was.  kind: 0 = DC (value = difference,
+// at = component), 1 = AC coefficient at zigzag index `at`, 2 = run / end of block (nothing to store).  DC and AC share
+// one path (a DC symbol is a category with run 0), so lanes at different places of their blocks do not diverge.
+template <typename Tab>
+__device__ __forceinline__ void decode_symbol(const EntropyGeom& g, BitReader& br, const Tab* tabs, uint32_t& c, uint32_t& z,
+                                              uint32_t& kind, uint32_t& at, int32_t& value, uint32_t& err) {
+    const uint32_t comp = g.kcomp[c];
+    const bool ac = z != 0u;
+    const uint32_t bits = br.peek();
+    uint32_t len = 0;
+    const uint32_t sym = huff_symbol(tabs + comp * 2u + (ac ? 1u : 0u), bits, &len, &err);
+    const uint32_t r = ac ? sym >> 4 : 0u, sz = sym & 15u;
+    if (!ac && sym > 11u) err |= 2u;
+    if (ac && sz == 0u) {
+        br.skip(len);
+        z = r == 15u ? z + 16u : 64u;                                // ZRL / EOB
+        kind = 2u;
+    } else {
+        z += r;
+        value = extend(sz ? ((bits << len) >> (32u - sz)) : 0u, sz);
+        br.skip(len + sz);
+        kind = ac ? 1u : 0u;
+        at = ac ? z : comp;
+        if (z > 63u) { err |= 4u; kind = 2u; }
+        ++z;
+    }
+    if (z >= 64u) {                                                  // block complete: next block of the MCU
+        z = 0u;
+        c = c + 1u == g.blocks_per_mcu ? 0u : c + 1u;
     }
 }
 
-__global__ void __launch_bounds__(256) entropy_round_kernel(const EntropyArgs a) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= a.n_sub) return;
-    const uint32_t seg_i = a.sub_seg[s];
-    const Segment sg = a.segs[seg_i];
+template <typename F>
+__device__ __forceinline__ void with_tables(const EntropyArgs& a, const DerivedTab* lds_tabs, uint32_t lds_image, uint32_t image, F&& f) {
+    if (image == lds_image) f(reinterpret_cast<const __attribute__((address_space(3))) DerivedTab*>(
+                                  static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_tabs))));
+    else f(a.tabs + static_cast<size_t>(image) * 6u);
+}
+
+// One synchronisation launch.  Inside the workgroup the fixpoint iteration runs in LDS (a lane whose predecessor's exit
+// state moved decodes again, up to kInnerRounds times), so a launch propagates a correction through all 256
+// sub-sequences of a workgroup; the host only iterates for corrections that cross workgroup boundaries.
+#ifndef IFHIP_ENT_INNER
+#define IFHIP_ENT_INNER 10
+#endif
+constexpr uint32_t kInnerRounds = IFHIP_ENT_INNER;
+
+__global__ void __launch_bounds__(kLanes) entropy_round_kernel(const EntropyArgs a) {
+    __shared__ uint32_t lds_words[kStageWords + kStageWords / 32u + 1u];
+    __shared__ DerivedTab lds_tabs[6];
+    __shared__ uint32_t ex_p[kLanes], ex_cz[kLanes];
+    const uint32_t first_sub = blockIdx.x * kLanes;
+    const uint32_t t = threadIdx.x, s = first_sub + t;
+    const bool on = s < a.n_sub;
     const uint32_t cur = a.round & 1u, prv = cur ^ 1u;
-    const bool first = s == sg.first_sub;
-    uint32_t p = s * kSubBits, cz = 0;
-    if (!first && a.round > 0u) { p = a.exit_p[prv][s - 1u]; cz = a.exit_cz[prv][s - 1u]; }
-    if (a.round > 0u && p == a.start_p[s] && cz == a.start_cz[s]) {          // same start as last time: same result
-        a.exit_p[cur][s] = a.exit_p[prv][s];
-        a.exit_cz[cur][s] = a.exit_cz[prv][s];
+    Segment sg = a.segs[a.sub_seg[on ? s : first_sub]];
+    const bool first = on && s == sg.first_sub;
+    // start state for this launch: exact for the first lane of a segment, speculative in round 0, else the
+    // predecessor's exit state of the previous launch
+    uint32_t p0 = s * kSubBits, cz0 = 0;
+    if (on && !first && a.round > 0u) { p0 = a.exit_p[prv][s - 1u]; cz0 = a.exit_cz[prv][s - 1u]; }
+    uint32_t used_p = on && a.round > 0u ? a.start_p[s] : 0xffffffffu, used_cz = on && a.round > 0u ? a.start_cz[s] : 0xffffffffu;
+    uint32_t my_p = on && a.round > 0u ? a.exit_p[prv][s] : 0u, my_cz = on && a.round > 0u ? a.exit_cz[prv][s] : 0u;
+    const uint32_t old_p = my_p, old_cz = my_cz;
+    int4 my_cnt = make_int4(0, 0, 0, 0);
+    bool have_cnt = false;
+    bool need = on && (p0 != used_p || cz0 != used_cz);
+    if (!__syncthreads_or(need ? 1 : 0)) {                           // nothing moved in front of this workgroup
+        if (on) { a.exit_p[cur][s] = my_p; a.exit_cz[cur][s] = my_cz; }
         return;
     }
-    a.start_p[s] = p;
-    a.start_cz[s] = cz;
+    const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
+    stage_stream(a, lds_words, first_sub);
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.tabs + static_cast<size_t>(wg_image) * 6u);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lds_tabs);
+        for (uint32_t i = t; i < sizeof(DerivedTab) * 6u / 4u; i += kLanes) dst[i] = src[i];
+    }
+    ex_p[t] = my_p; ex_cz[t] = my_cz;
+    __syncthreads();
+    const BitSrc src{lds_words, first_sub * kSubWords, a.words};
     const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end);
-    uint32_t c = cz >> 8, z = cz & 255u, err = 0;
-    int32_t n = 0, dc[3] = {0, 0, 0};
-    const DerivedTab* tabs = a.tabs + static_cast<size_t>(sg.image) * 6u;
-    decode_run<false>(a, tabs, sg, p, c, z, end, n, dc, 0, err);
-    const uint32_t ncz = (c << 8) | z;
-    if (a.round > 0u && (p != a.exit_p[prv][s] || ncz != a.exit_cz[prv][s])) atomicAdd(a.changed, 1u);
-    a.exit_p[cur][s] = p;
-    a.exit_cz[cur][s] = ncz;
-    a.cnt[s] = make_int4(n, dc[0], dc[1], dc[2]);
+    bool pending = false;
+    for (uint32_t it = 0; it < kInnerRounds; ++it) {
+        if (need) {
+            used_p = p0; used_cz = cz0;
+            uint32_t c = cz0 >> 8, z = cz0 & 255u, err = 0;
+            int32_t n = 0, dc[3] = {0, 0, 0};
+            BitReader br(src, p0);
+            with_tables(a, lds_tabs, wg_image, sg.image, [&](auto tabs) {
+                while (br.p < end) {
+                    uint32_t kind, at = 0;
+                    int32_t value = 0;
+                    decode_symbol(a.g, br, tabs, c, z, kind, at, value, err);
+                    if (kind == 0u) { ++n; dc[at] += value; }
+                }
+            });
+            my_p = br.p; my_cz = (c << 8) | z;
+            my_cnt = make_int4(n, dc[0], dc[1], dc[2]);
+            have_cnt = true;
+        }
+        __syncthreads();                                             // everyone has read ex[t-1] of the previous iteration
+        ex_p[t] = my_p; ex_cz[t] = my_cz;
+        __syncthreads();
+        if (on && !first && t > 0u) { p0 = ex_p[t - 1u]; cz0 = ex_cz[t - 1u]; }
+        need = on && (p0 != used_p || cz0 != used_cz);
+        pending = __syncthreads_or(need ? 1 : 0) != 0;
+        if (!pending) break;
+    }
+    if (!on) return;
+    a.exit_p[cur][s] = my_p;
+    a.exit_cz[cur][s] = my_cz;
+    a.start_p[s] = used_p;
+    a.start_cz[s] = used_cz;
+    if (have_cnt) a.cnt[s] = my_cnt;
+    // another launch is needed if this lane's exit moved (its successor may sit in the next workgroup) or the inner
+    // iteration was cut short
+    if (a.round > 0u && (my_p != old_p || my_cz != old_cz || need)) atomicAdd(a.changed, 1u);
 }
 
 // exclusive scan of cnt over the sub-sequences of one segment (one workgroup per segment)
@@ -218,11 +306,29 @@ __global__ void __launch_bounds__(256) entropy_scan_kernel(const EntropyArgs a) 
     }
 }
 
-__global__ void __launch_bounds__(256) entropy_write_kernel(const EntropyArgs a) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+// Write pass.  A block belongs to the lane in whose sub-sequence it STARTS: that lane decodes it to the end (running
+// past its sub-sequence if need be), assembles the 64 coefficients in a private LDS row (pitch 34 dwords: conflict-free
+// across lanes) and stores the whole block with eight 16-byte stores -- every block is written exactly once, zeros
+// included, so the planes need no clearing and no two lanes ever touch the same block.  A lane that starts inside a
+// block skips to its end without storing.
+constexpr uint32_t kBlkPitch = 34;                   // dwords per lane row (32 + 2)
+
+__global__ void __launch_bounds__(kLanes) entropy_write_kernel(const EntropyArgs a) {
+    __shared__ uint32_t lds_words[kStageWords + kStageWords / 32u + 1u];
+    __shared__ DerivedTab lds_tabs[6];
+    __shared__ __attribute__((aligned(8))) uint32_t lds_blk[kLanes * kBlkPitch];
+    const uint32_t first_sub = blockIdx.x * kLanes;
+    const uint32_t s = first_sub + threadIdx.x;
+    const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
+    stage_stream(a, lds_words, first_sub);
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.tabs + static_cast<size_t>(wg_image) * 6u);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lds_tabs);
+        for (uint32_t i = threadIdx.x; i < sizeof(DerivedTab) * 6u / 4u; i += kLanes) dst[i] = src[i];
+    }
+    __syncthreads();
     if (s >= a.n_sub) return;
-    const uint32_t seg_i = a.sub_seg[s];
-    const Segment sg = a.segs[seg_i];
+    const Segment sg = a.segs[a.sub_seg[s]];
     const uint32_t fin = a.round & 1u;                       // parity of the last round run
     const bool first = s == sg.first_sub;
     uint32_t p = s * kSubBits, cz = 0;
@@ -230,14 +336,42 @@ __global__ void __launch_bounds__(256) entropy_write_kernel(const EntropyArgs a)
     const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end);
     uint32_t c = cz >> 8, z = cz & 255u, err = 0;
     const int4 pre = a.prefix[s];
-    int32_t n = 0, dc[3] = {pre.y, pre.z, pre.w};
-    const DerivedTab* tabs = a.tabs + static_cast<size_t>(sg.image) * 6u;
-    decode_run<true>(a, tabs, sg, p, c, z, end, n, dc, pre.x - 1, err);
-    // errors only count inside the segment's real blocks; the pad bits behind the last block decode to garbage by design
+    int32_t dc[3] = {pre.y, pre.z, pre.w};
+    int32_t block = pre.x - 1;                               // last block started before this lane
+    const BitSrc src{lds_words, first_sub * kSubWords, a.words};
+    int16_t* row = reinterpret_cast<int16_t*>(lds_blk + threadIdx.x * kBlkPitch);
+    uint2* row2 = reinterpret_cast<uint2*>(lds_blk + threadIdx.x * kBlkPitch);
+    const uint32_t B = a.g.blocks_per_mcu;
+    BitReader br(src, p);
+    with_tables(a, lds_tabs, wg_image, sg.image, [&](auto tabs) {
+        uint32_t kind, at = 0;
+        int32_t value = 0;
+        while (z != 0u) decode_symbol(a.g, br, tabs, c, z, kind, at, value, err);           // tail of the predecessor's block
+        while (br.p < end) {
+            ++block;
+            if (static_cast<uint32_t>(block) >= sg.n_blocks) break;                        // pad bits behind the last block
+#pragma unroll
+            for (uint32_t i = 0; i < 16u; ++i) row2[i] = make_uint2(0u, 0u);
+            do {
+                decode_symbol(a.g, br, tabs, c, z, kind, at, value, err);
+                if (kind == 0u) { dc[at] += value; row[0] = static_cast<int16_t>(dc[at]); }
+                else if (kind == 1u) row[kZigzag[at]] = static_cast<int16_t>(value);
+            } while (z != 0u);
+            const uint32_t m = sg.first_mcu + static_cast<uint32_t>(block) / B, k = static_cast<uint32_t>(block) % B;
+            const uint32_t cm = a.g.kcomp[k];
+            const uint32_t my = m / a.g.mcus_w, mx = m - my * a.g.mcus_w;
+            const uint32_t bx = mx * a.g.hs[cm] + a.g.kdx[k], by = my * a.g.vs[cm] + a.g.kdy[k];
+            uint4* dst = reinterpret_cast<uint4*>(a.coef[cm] + ((static_cast<size_t>(sg.image) * a.g.bh[cm] + by) * a.g.bw[cm] + bx) * 64u);
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) {
+                const uint2 lo = row2[2u * i], hi = row2[2u * i + 1u];
+                dst[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+        }
+    });
     const bool last = s + 1u == sg.first_sub + sg.n_sub;
-    if (last && static_cast<uint32_t>(pre.x + n) < sg.n_blocks) err |= 8u;
-    if (!last && err) atomicOr(a.errors, err);
-    if (last && (err & 8u)) atomicOr(a.errors, 8u);
+    if (last && static_cast<uint32_t>(block + 1) < sg.n_blocks) err |= 8u;     // the segment ran out of data
+    if (err) atomicOr(a.errors, err);
 }
 
 }  // namespace ifhip
@@ -477,9 +611,13 @@ int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* fi
         while (more && mcu0 < total_mcus) {
             bytes.clear();
             more = false;
-            while (i < len) {
-                const uint8_t b = d[i++];
-                if (b != 0xFF) { bytes.push_back(b); continue; }
+            while (i < len) {                                                   // runs between 0xFF bytes are copied whole
+                const uint8_t* ff = static_cast<const uint8_t*>(std::memchr(d + i, 0xFF, len - i));
+                const size_t run_end = ff ? static_cast<size_t>(ff - d) : len;
+                bytes.insert(bytes.end(), d + i, d + run_end);
+                i = run_end;
+                if (i >= len) break;
+                ++i;                                                           // the 0xFF
                 while (i < len && d[i] == 0xFF) ++i;                           // fill bytes before a marker
                 if (i >= len) break;
                 const uint8_t m = d[i++];
@@ -500,7 +638,8 @@ int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* fi
             sg.bit_end = static_cast<uint32_t>(bit_end);
             const size_t w0 = words.size();
             words.resize(w0 + static_cast<size_t>(sg.n_sub) * kSubWords, 0u);
-            for (size_t k = 0; k < bytes.size(); ++k) words[w0 + (k >> 2)] |= static_cast<uint32_t>(bytes[k]) << (24u - 8u * (k & 3u));
+            std::memcpy(&words[w0], bytes.data(), bytes.size());               // bytes in stream order, then big-endian words
+            for (size_t k = w0; k < words.size(); ++k) words[k] = __builtin_bswap32(words[k]);
             for (uint32_t k = 0; k < sg.n_sub; ++k) sub_seg.push_back(static_cast<uint32_t>(segs.size()));
             segs.push_back(sg);
             mcu0 += mcus;
@@ -584,9 +723,8 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     EntropyArgs a = e->a;
     a.coef[0] = d_coef0; a.coef[1] = d_coef1; a.coef[2] = d_coef2;
-    int16_t* planes[3] = {d_coef0, d_coef1, d_coef2};
-    for (int c = 0; c < F.ncomp; ++c)
-        HIP_TRY(hipMemsetAsync(planes[c], 0, static_cast<size_t>(e->n_images) * F.bw[c] * F.bh[c] * 128u, st));
+    if ((reinterpret_cast<uintptr_t>(d_coef0) | reinterpret_cast<uintptr_t>(d_coef1) | reinterpret_cast<uintptr_t>(d_coef2)) & 15u)
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: coefficient planes must be 16-byte aligned");
     HIP_TRY(hipMemsetAsync(a.changed, 0, 2 * sizeof(uint32_t), st));
     const dim3 grid((a.n_sub + 255u) / 256u), block(256);
     uint32_t r = 0;

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Measurement of the GPU entropy stage (BASELINE config 4 inputs): n baseline 4:2:0 q85 3840x2160 files (gradient +
+noise mix, written by Pillow on the spot) -> coefficient planes -> BGRA.  Reports host preparation (parse, un-stuff,
+upload), device decode (rounds), and the whole file -> BGRA chain; a serial CPU decode of one file for scale."""
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from imageflow_amd.codecs import mozjpeg_decoder as D  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    w, h = 3840, 2160
+    y, x = np.mgrid[0:h, 0:w]
+    rng = np.random.default_rng(1)
+    files = []
+    for k in range(n):
+        base = np.stack([(x + 3 * k) * 255 // (w + 60), (y + 5 * k) * 255 // (h + 90), (x + y) * 255 // (w + h)], -1).astype(np.int16)
+        tex = (40 * np.sin(x / (3.0 + k % 5)) * np.cos(y / (4.0 + k % 3)))[..., None] + rng.integers(-12, 13, size=(h, w, 3))
+        buf = io.BytesIO()
+        Image.fromarray(np.clip(base + tex, 0, 255).astype(np.uint8)).save(buf, "JPEG", quality=85, subsampling="4:2:0", optimize=False)
+        files.append(buf.getvalue())
+    size = sum(len(f) for f in files)
+    torch.zeros(1, device="cuda").item()                    # HIP context up before anything is timed
+    D.JpegEntropyBatch(files[:1]).read_coefficients()       # code objects loaded
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ent = D.JpegEntropyBatch(files)
+    torch.cuda.synchronize()
+    t_prep = time.perf_counter() - t0
+    coef = ent.read_coefficients()
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ent.read_coefficients(coef)
+    torch.cuda.synchronize()
+    t_dec = (time.perf_counter() - t0) / reps
+    stage = D.JpegPixelStage(w, h, 3, ent.h_samp, ent.v_samp, n)
+    qt = torch.from_numpy(ent.qt.view(np.int16)).cuda()
+    out = stage.read_frames(coef, qt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ent.read_coefficients(coef)
+        stage.read_frames(coef, qt, out)
+    torch.cuda.synchronize()
+    t_all = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    Image.open(io.BytesIO(files[0])).convert("RGB").load()
+    t_cpu = time.perf_counter() - t0
+    mp = n * w * h / 1e6
+    print(json.dumps({
+        "files": n, "compressed_MB": round(size / 1e6, 2), "sub_sequences": ent.n_subsequences, "rounds": ent.rounds,
+        "host_prepare_ms": round(t_prep * 1e3, 2), "host_prepare_MBps": round(size / 1e6 / t_prep, 1),
+        "entropy_decode_ms": round(t_dec * 1e3, 3), "entropy_MPps": round(mp / t_dec, 1),
+        "entropy_compressed_GBps": round(size / 1e9 / t_dec, 2),
+        "file_to_bgra_ms": round(t_all * 1e3, 3), "file_to_bgra_MPps": round(mp / t_all, 1),
+        "libjpeg_turbo_one_core_MPps": round(w * h / 1e6 / t_cpu, 1)}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
