@@ -52,6 +52,7 @@ struct EntropyGeom {
     uint32_t ncomp, blocks_per_mcu, mcus_w, mcus_h;
     uint32_t bw[3], bh[3];
     uint8_t kcomp[10], kdx[10], kdy[10];             // block k of an MCU: component and offset inside the MCU
+    uint32_t kcomp_packed;                           // kcomp as 2-bit fields: the per-symbol lookup is a shift, not a load
     uint32_t hs[3], vs[3];
 };
 
@@ -165,7 +166,7 @@ struct BitReader {
 template <typename Tab>
 __device__ __forceinline__ void decode_symbol(const EntropyGeom& g, BitReader& br, const Tab* tabs, uint32_t& c, uint32_t& z,
                                               uint32_t& kind, uint32_t& at, int32_t& value, uint32_t& err) {
-    const uint32_t comp = g.kcomp[c];
+    const uint32_t comp = (g.kcomp_packed >> (2u * c)) & 3u;
     const bool ac = z != 0u;
     const uint32_t bits = br.peek();
     uint32_t len = 0;
@@ -655,7 +656,10 @@ int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* fi
     for (int c = 0; c < F.ncomp; ++c) {
         a.g.bw[c] = F.bw[c]; a.g.bh[c] = F.bh[c]; a.g.hs[c] = F.hs[c]; a.g.vs[c] = F.vs[c];
         for (uint32_t dy = 0; dy < F.vs[c]; ++dy)
-            for (uint32_t dx = 0; dx < F.hs[c]; ++dx, ++k) { a.g.kcomp[k] = static_cast<uint8_t>(c); a.g.kdx[k] = static_cast<uint8_t>(dx); a.g.kdy[k] = static_cast<uint8_t>(dy); }
+            for (uint32_t dx = 0; dx < F.hs[c]; ++dx, ++k) {
+                a.g.kcomp[k] = static_cast<uint8_t>(c); a.g.kdx[k] = static_cast<uint8_t>(dx); a.g.kdy[k] = static_cast<uint8_t>(dy);
+                a.g.kcomp_packed |= static_cast<uint32_t>(c) << (2u * k);
+            }
     }
     a.n_sub = static_cast<uint32_t>(sub_seg.size());
     a.n_seg = static_cast<uint32_t>(segs.size());
