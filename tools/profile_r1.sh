@@ -8,9 +8,10 @@ OUT=gpurun_out/prof
 SUM=gpurun_out/prof_summary
 mkdir -p $OUT $SUM
 CMD="python bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+TRACE_CMD="python bench.py --steps 50 --warmup 5 --no-cpu-baseline"   # long enough that the cold first launches do not move the average
 
 # 1. kernel trace + stats (per-kernel average duration; must agree with bench.py's hipEvent number)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $SUM/bench_under_trace.json 2> $OUT/trace.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $TRACE_CMD > $SUM/bench_under_trace.json 2> $OUT/trace.err
 find $OUT/trace -name '*kernel_stats.csv' -exec cp {} $SUM/kernel_stats.csv \;
 find $OUT/trace -name '*kernel_trace.csv' | head -1 | xargs -I{} sh -c "head -1 {} > $SUM/kernel_trace_head.csv; grep fused_resample {} | head -20 >> $SUM/kernel_trace_head.csv"
 
