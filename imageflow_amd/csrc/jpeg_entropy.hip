@@ -94,16 +94,17 @@ __constant__ uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18
 // The Huffman tables of the workgroup's first image go to LDS too; lanes of any other image (only in workgroups that
 // straddle two files) read theirs from global memory.
 constexpr uint32_t kLanes = 256;
-constexpr uint32_t kMarginSubs = 2;
+constexpr uint32_t kMarginSubs = 3;                  // > the longest possible block (64 symbols x 31 bits) + lookahead
 constexpr uint32_t kStageWords = (kLanes + kMarginSubs) * kSubWords;
 
 struct BitSrc {
     const uint32_t* lds;         // staged words, skewed
     uint32_t word0;              // absolute word index of lds[0]
-    const uint32_t* glob;
+    // Every read of a lane stays inside the staged span: a lane starts inside its workgroup's 256 sub-sequences and
+    // runs at most one block (< 2 048 bits) plus 64 bits of lookahead past them; the clamp only matters for garbage.
     __device__ __forceinline__ uint32_t word(uint32_t w) const {
-        const uint32_t r = w - word0;
-        return r < kStageWords ? lds[r + (r >> 5)] : glob[w];
+        const uint32_t r = min(w - word0, kStageWords - 1u);
+        return lds[r + (r >> 5)];
     }
     // 32 bits of the stream starting at bit position p (the buffer is padded behind the last segment)
     __device__ __forceinline__ uint32_t peek32(uint32_t p) const {
@@ -240,7 +241,7 @@ __global__ void __launch_bounds__(kLanes) entropy_round_kernel(const EntropyArgs
     }
     ex_p[t] = my_p; ex_cz[t] = my_cz;
     __syncthreads();
-    const BitSrc src{lds_words, first_sub * kSubWords, a.words};
+    const BitSrc src{lds_words, first_sub * kSubWords};
     const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end);
     bool pending = false;
     for (uint32_t it = 0; it < kInnerRounds; ++it) {
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(kLanes) entropy_write_kernel(const EntropyArgs
     const int4 pre = a.prefix[s];
     int32_t dc[3] = {pre.y, pre.z, pre.w};
     int32_t block = pre.x - 1;                               // last block started before this lane
-    const BitSrc src{lds_words, first_sub * kSubWords, a.words};
+    const BitSrc src{lds_words, first_sub * kSubWords};
     int16_t* row = reinterpret_cast<int16_t*>(lds_blk + threadIdx.x * kBlkPitch);
     uint2* row2 = reinterpret_cast<uint2*>(lds_blk + threadIdx.x * kBlkPitch);
     const uint32_t B = a.g.blocks_per_mcu;
