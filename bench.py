@@ -226,6 +226,15 @@ def main():
                 traffic = t["traffic_bytes_per_launch"]
         except Exception:
             pass
+        measured_copy = None    # same-process calibration: device-to-device memcpy of 2 GiB, read + write bytes per second
+        try:
+            import ctypes
+            from imageflow_amd import _native
+            bps = ctypes.c_double(0.0)
+            _native.check(_native.lib().ifhip_measure_copy_bandwidth(2 << 30, 5, ctypes.byref(bps)))
+            measured_copy = bps.value
+        except Exception:  # noqa: BLE001
+            pass
         out = {
             "metric": "megapixels/sec resize (4K->200px Robidoux)", "value": round(value, 1), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -238,7 +247,9 @@ def main():
                        "gather": gather_note},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
-                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
+                         "measured_copy_GBps": round(measured_copy / 1e9, 1) if measured_copy else None,
+                         "frac_of_measured_copy": round(achieved / measured_copy, 4) if measured_copy else None},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
             try:
