@@ -2,7 +2,8 @@
 
 The product is libimageflow_hip.so (C ABI in include/imageflow_hip.h, sources in imageflow_amd/csrc).
 This package is the host-side mirror of the reference's Rust interface for the same path
-(imageflow_core::graphics::{scaling, weights, color, blend, bitmaps}) used by tests and bench.py;
+(imageflow_core::graphics::{scaling, weights, color, blend, bitmaps, color_matrix, copy_rect, flip, transpose},
+codecs::{mozjpeg_decoder, mozjpeg} and the flow nodes in front of them) used by tests and bench.py;
 PyTorch supplies device memory, streams and torch.distributed only.
 """
 from .errors import ErrorKind, FlowError  # noqa: F401

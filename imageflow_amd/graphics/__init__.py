@@ -1,1 +1,1 @@
-"""Mirror of imageflow_core::graphics for the resample / flatten path."""
+"""Mirror of imageflow_core::graphics: scaling, weights, color, blend, bitmaps and the whole-bitmap primitives (bitmap_ops)."""
