@@ -13,15 +13,14 @@ constexpr size_t kFusedLdsCap = 160 * 1024;      // gfx950: a workgroup may use 
 // Output stage (shared by the fused and the generic kernels)
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint8_t uchar_clamp_ff(float v) {        // graphics/color.rs:101-108
-    const double t = static_cast<double>(v) + 0.5;
-    int i;
-    if (t != t) i = 0;
-    else if (t >= 32767.0) i = 32767;
-    else if (t <= -32768.0) i = -32768;
-    else i = static_cast<int>(t);
-    unsigned r = static_cast<unsigned>(i) & 0xFFFFu;
-    if (r > 255u) r = (v < 0.0f) ? 0u : 255u;
-    return static_cast<uint8_t>(r);
+    // `(v as f64 + 0.5) as i16 as u16`, > 255 -> (v < 0 ? 0 : 255), restated without f64: negative inputs and NaN give
+    // 0, everything else min(255, floor(v) + (frac(v) >= 0.5)) -- floor and the fraction are exact in f32.  Equal to the
+    // f64 form for all 2^32 float bit patterns (exhaustive host check, tests/test_oracle_color.py samples it).
+    const float c = __builtin_fminf(v, 300.0f);
+    const float f = __builtin_floorf(c);
+    int i = static_cast<int>(f) + ((c - f) >= 0.5f ? 1 : 0);
+    i = i > 255 ? 255 : i;
+    return (v >= 0.0f) ? static_cast<uint8_t>(i) : static_cast<uint8_t>(0);
 }
 
 // Tables the output stage reads: `s2f` = sRGB byte -> working float (256), `l2s` = linear -> sRGB byte (16384).

