@@ -60,7 +60,10 @@ hpass_generic_kernel(const ResampleArgs a, const float4* scratch, uint32_t img0)
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Flatten: graphics/blend.rs:6-59, one lane per pixel, 4 B in / 4 B out, in place.
+// Flatten: graphics/blend.rs:6-59, in place.  One lane = 4 adjacent pixels x kMatteRows rows (16-byte accesses when the
+// rows are 16-byte aligned).  Both tables live in LDS: the sRGB->linear table with one copy per bank (conflict-free for
+// any pixel values, as in the resample kernel), the 16 KiB linear->sRGB table as is; 512 lanes x 32 rows per workgroup
+// amortise the 48 KiB table fill (from L2) over 256 KiB of pixels.
 // ------------------------------------------------------------------------------------------------------
 struct MatteArgs {
     uint8_t* bgra;
@@ -70,37 +73,59 @@ struct MatteArgs {
     float mb, mg, mr, ma;       // linear matte colour, matte alpha / 255
     const float* s2l;
     const uint8_t* l2s;
+    uint32_t vec16;             // rows are 16-byte aligned
 };
+constexpr uint32_t kMatteRows = 32;
+constexpr uint32_t kMatteLanes = 512;
 
-__global__ void __launch_bounds__(256) apply_matte_kernel(const MatteArgs a) {
-    __shared__ float lut[256];
-    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) lut[i] = a.s2l[i];
-    __syncthreads();
-    const uint32_t xx = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t yy = blockIdx.y;
-    const uint32_t img = blockIdx.z;
-    if (xx >= a.w) return;
-    uint32_t* p = reinterpret_cast<uint32_t*>(a.bgra + static_cast<size_t>(img) * a.image_bytes
-                                              + static_cast<size_t>(yy) * a.stride) + xx;
-    const uint32_t px = *p;
+__device__ __forceinline__ uint32_t matte_pixel(const MatteArgs& a, const BankedLut& lut, const uint8_t* l2s, uint32_t px) {
     const uint32_t pa = px >> 24;
-    if (pa == 255u) return;
-    if (pa == 0u) { *p = a.matte; return; }
+    if (pa == 255u) return px;
+    if (pa == 0u) return a.matte;
     const float paf = static_cast<float>(static_cast<int>(pa)) * (1.0f / 255.0f);
     const float ma = (1.0f - paf) * a.ma;
     const float fa = ma + paf;
     auto enc = [&](float v) -> uint32_t {
-        float s = v * 16383.0f;
-        s = (s != s) ? 0.0f : s;
-        s = s < 0.0f ? 0.0f : s;
-        s = s > 16383.0f ? 16383.0f : s;
-        return a.l2s[static_cast<uint32_t>(s)];
+        const float s = __builtin_fminf(__builtin_fmaxf(v * 16383.0f, 0.0f), 16383.0f);     // NaN -> 0, as lut.rs:4-8
+        return l2s[static_cast<uint32_t>(s)];
     };
     const uint32_t nb = enc((lut[px & 255u] * paf + a.mb * ma) / fa);
     const uint32_t ng = enc((lut[(px >> 8) & 255u] * paf + a.mg * ma) / fa);
     const uint32_t nr = enc((lut[(px >> 16) & 255u] * paf + a.mr * ma) / fa);
     const uint32_t na = uchar_clamp_ff(255.0f * fa);
-    *p = nb | (ng << 8) | (nr << 16) | (na << 24);
+    return nb | (ng << 8) | (nr << 16) | (na << 24);
+}
+
+__global__ void __launch_bounds__(kMatteLanes) apply_matte_kernel(const MatteArgs a) {
+    __shared__ float lut_banked[256 * 32];
+    __shared__ __attribute__((aligned(16))) uint8_t l2s[16384];
+    for (uint32_t i = threadIdx.x; i < 256u * 32u; i += blockDim.x) lut_banked[i] = a.s2l[i >> 5];
+    for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x)
+        reinterpret_cast<uint4*>(l2s)[i] = reinterpret_cast<const uint4*>(a.l2s)[i];
+    __syncthreads();
+    const BankedLut lut{lut_banked, threadIdx.x & 31u, 5u};
+    const uint32_t x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+    if (x0 >= a.w) return;
+    const uint32_t img = blockIdx.z;
+    const uint32_t y_end = min((blockIdx.y + 1u) * kMatteRows, a.h);
+    const bool full = a.vec16 && x0 + 3u < a.w;
+    for (uint32_t yy = blockIdx.y * kMatteRows; yy < y_end; ++yy) {
+        uint32_t* p = reinterpret_cast<uint32_t*>(a.bgra + static_cast<size_t>(img) * a.image_bytes
+                                                  + static_cast<size_t>(yy) * a.stride) + x0;
+        if (full) {
+            uint4 v = *reinterpret_cast<uint4*>(p);
+            if ((v.x & v.y & v.z & v.w) >> 24 == 255u) continue;            // four opaque pixels: nothing to do
+            v.x = matte_pixel(a, lut, l2s, v.x); v.y = matte_pixel(a, lut, l2s, v.y);
+            v.z = matte_pixel(a, lut, l2s, v.z); v.w = matte_pixel(a, lut, l2s, v.w);
+            *reinterpret_cast<uint4*>(p) = v;
+        } else {
+            const uint32_t n = min(4u, a.w - x0);
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t px = p[i];
+                if ((px >> 24) != 255u) p[i] = matte_pixel(a, lut, l2s, px);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -142,8 +167,9 @@ hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, ui
 hipError_t launch_apply_matte(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w, uint32_t h,
                               uint32_t stride, uint32_t matte, float mb, float mg, float mr, float ma,
                               const float* s2l, const uint8_t* l2s, hipStream_t st) {
-    MatteArgs m{d_bgra, image_bytes, w, h, stride, n_images, matte, mb, mg, mr, ma, s2l, l2s};
-    const dim3 block(256), grid((w + 255u) / 256u, h, n_images);
+    MatteArgs m{d_bgra, image_bytes, w, h, stride, n_images, matte, mb, mg, mr, ma, s2l, l2s, 0u};
+    m.vec16 = ((reinterpret_cast<uintptr_t>(d_bgra) | image_bytes | stride) & 15u) == 0 ? 1u : 0u;
+    const dim3 block(kMatteLanes), grid(((w + 3u) / 4u + kMatteLanes - 1u) / kMatteLanes, (h + kMatteRows - 1u) / kMatteRows, n_images);
     hipLaunchKernelGGL(apply_matte_kernel, grid, block, 0, st, m);
     return hipGetLastError();
 }
