@@ -47,22 +47,40 @@ __device__ __forceinline__ uint8_t uchar_clamp_ff(float v) {        // graphics/
 
 struct Matrix5 { float m[25]; };
 
-// color_matrix.rs:5-29: one lane per pixel; the sums are evaluated left to right with one rounding per operation
-// (this translation unit is compiled with -ffp-contract=off, like the oracle).
-__global__ void __launch_bounds__(256) color_matrix_kernel(const Frames f, const Matrix5 k) {
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= f.w) return;
-    uint32_t* p = px_ptr(f, blockIdx.z, x, blockIdx.y);
-    const uint32_t px = *p;
+// color_matrix.rs:5-29: one lane = 4 adjacent pixels x kCmRows rows (16-byte accesses when the rows allow); the sums are
+// evaluated left to right with one rounding per operation (this translation unit is compiled with -ffp-contract=off,
+// like the oracle).
+constexpr uint32_t kCmRows = 8;
+
+__device__ __forceinline__ uint32_t color_matrix_pixel(const float* m, float m40, float m41, float m42, float m43, uint32_t px) {
     const float b = static_cast<float>(px & 255u), g = static_cast<float>((px >> 8) & 255u);
     const float r = static_cast<float>((px >> 16) & 255u), a = static_cast<float>(px >> 24);
-    const float* m = k.m;
-    const float m40 = m[20] * 255.0f, m41 = m[21] * 255.0f, m42 = m[22] * 255.0f, m43 = m[23] * 255.0f;
     const uint32_t nr = uchar_clamp_ff(m[0] * r + m[5] * g + m[10] * b + m[15] * a + m40);
     const uint32_t ng = uchar_clamp_ff(m[1] * r + m[6] * g + m[11] * b + m[16] * a + m41);
     const uint32_t nb = uchar_clamp_ff(m[2] * r + m[7] * g + m[12] * b + m[17] * a + m42);
     const uint32_t na = uchar_clamp_ff(m[3] * r + m[8] * g + m[13] * b + m[18] * a + m43);
-    *p = nb | (ng << 8) | (nr << 16) | (na << 24);
+    return nb | (ng << 8) | (nr << 16) | (na << 24);
+}
+
+__global__ void __launch_bounds__(256) color_matrix_kernel(const Frames f, const Matrix5 k, const uint32_t vec16) {
+    const uint32_t x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+    if (x0 >= f.w) return;
+    const float* m = k.m;
+    const float m40 = m[20] * 255.0f, m41 = m[21] * 255.0f, m42 = m[22] * 255.0f, m43 = m[23] * 255.0f;
+    const uint32_t y_end = min((blockIdx.y + 1u) * kCmRows, f.h);
+    const bool full = vec16 && x0 + 3u < f.w;
+    for (uint32_t y = blockIdx.y * kCmRows; y < y_end; ++y) {
+        uint32_t* p = px_ptr(f, blockIdx.z, x0, y);
+        if (full) {
+            uint4 v = *reinterpret_cast<uint4*>(p);
+            v.x = color_matrix_pixel(m, m40, m41, m42, m43, v.x); v.y = color_matrix_pixel(m, m40, m41, m42, m43, v.y);
+            v.z = color_matrix_pixel(m, m40, m41, m42, m43, v.z); v.w = color_matrix_pixel(m, m40, m41, m42, m43, v.w);
+            *reinterpret_cast<uint4*>(p) = v;
+        } else {
+            const uint32_t n = min(4u, f.w - x0);
+            for (uint32_t i = 0; i < n; ++i) p[i] = color_matrix_pixel(m, m40, m41, m42, m43, p[i]);
+        }
+    }
 }
 
 // Rectangle kernels: one lane per 4 adjacent pixels of the rectangle (16-byte accesses when `vec` says every group
@@ -214,7 +232,8 @@ int ifhip_apply_color_matrix_batch_device(uint8_t* d_bgra, size_t image_bytes, u
     Matrix5 k;
     std::memcpy(k.m, matrix25, sizeof k.m);
     const Frames f{d_bgra, image_bytes, w, h, stride};
-    hipLaunchKernelGGL(color_matrix_kernel, dim3((w + 255u) / 256u, h, n_images), dim3(256), 0, static_cast<hipStream_t>(hip_stream), f, k);
+    hipLaunchKernelGGL(color_matrix_kernel, dim3(((w + 3u) / 4u + 255u) / 256u, (h + kCmRows - 1u) / kCmRows, n_images), dim3(256), 0,
+                       static_cast<hipStream_t>(hip_stream), f, k, aligned16(f, 0) ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return IFHIP_OK;
 }
