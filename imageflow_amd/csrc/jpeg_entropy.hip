@@ -123,25 +123,9 @@ __device__ __forceinline__ void stage_stream(const EntropyArgs& a, uint32_t* lds
     }
 }
 
-// one Huffman symbol at the top of `bits` (32 bits of lookahead): returns the symbol, sets *len to the code length
-template <typename Tab>
-__device__ __forceinline__ uint32_t huff_symbol(const Tab* t, uint32_t bits, uint32_t* len, uint32_t* err) {
-    const uint32_t e = t->lut[bits >> (32u - kLutBits)];
-    if (e) { *len = e >> 8; return e & 255u; }
-    uint32_t l = kLutBits + 1u;
-    int32_t code = static_cast<int32_t>(bits >> (32u - l));
-    while (l <= 16u && code > t->maxcode[l]) { ++l; code = static_cast<int32_t>(bits >> (32u - l)); }
-    if (l > 16u) { *err |= 1u; *len = 16u; return 0u; }          // garbage (speculative start or corrupt data): keep moving
-    *len = l;
-    return t->val[(code + t->valoff[l]) & 255];
-}
-
-__device__ __forceinline__ int32_t extend(uint32_t v, uint32_t s) {   // jdhuff.c HUFF_EXTEND
-    return s == 0u ? 0 : (v < (1u << (s - 1u)) ? static_cast<int32_t>(v) - static_cast<int32_t>((1u << s) - 1u) : static_cast<int32_t>(v));
-}
-
-// Bit reader over the staged stream: 64 bits of lookahead in registers, topped up one word at a time, so a symbol costs
-// one table read and (every third symbol or so) one stream read instead of two stream reads of its own.
+// Bit reader over the staged stream: 64 bits of lookahead in registers, topped up one word at a time.  The top-up is
+// branchless (the next word is always fetched from LDS, merged only when needed): a lone wave walking a correction
+// through the workgroup is bound by instruction issue, and exec-mask juggling costs more than the spare read.
 struct BitReader {
     const BitSrc& src;
     uint64_t bb;            // stream bits from position p on, left-aligned
@@ -155,38 +139,50 @@ struct BitReader {
         next_w = w + 2u;
     }
     __device__ __forceinline__ uint32_t peek() const { return static_cast<uint32_t>(bb >> 32); }
-    __device__ __forceinline__ void skip(uint32_t n) {
+    __device__ __forceinline__ void skip(uint32_t n) {               // n <= 31
+        const uint32_t nw = src.word(next_w);
         bb <<= n; avail -= n; p += n;
-        if (avail <= 32u) { bb |= static_cast<uint64_t>(src.word(next_w)) << (32u - avail); avail += 32u; ++next_w; }
+        const bool need = avail <= 32u;
+        const uint64_t add = static_cast<uint64_t>(nw) << ((32u - avail) & 31u);
+        bb |= need ? add : 0ull;
+        avail += need ? 32u : 0u;
+        next_w += need ? 1u : 0u;
     }
 };
 
 // One symbol of the scan: updates (c, z) and the reader; reports what it was.  kind: 0 = DC (value = difference,
-// at = component), 1 = AC coefficient at zigzag index `at`, 2 = run / end of block (nothing to store).  DC and AC share
-// one path (a DC symbol is a category with run 0), so lanes at different places of their blocks do not diverge.
+// at = component), 1 = AC coefficient at zigzag index `at`, 2 = run / end of block (nothing to store).  DC and AC, run
+// and coefficient share one select-based path (a DC symbol is a category with run 0), so lanes at different places of
+// their blocks do not diverge; only codes longer than the 9-bit lookup and block ends branch.
 template <typename Tab>
 __device__ __forceinline__ void decode_symbol(const EntropyGeom& g, BitReader& br, const Tab* tabs, uint32_t& c, uint32_t& z,
                                               uint32_t& kind, uint32_t& at, int32_t& value, uint32_t& err) {
     const uint32_t comp = (g.kcomp_packed >> (2u * c)) & 3u;
     const bool ac = z != 0u;
+    const Tab* t = tabs + comp * 2u + (ac ? 1u : 0u);
     const uint32_t bits = br.peek();
-    uint32_t len = 0;
-    const uint32_t sym = huff_symbol(tabs + comp * 2u + (ac ? 1u : 0u), bits, &len, &err);
-    const uint32_t r = ac ? sym >> 4 : 0u, sz = sym & 15u;
-    if (!ac && sym > 11u) err |= 2u;
-    if (ac && sz == 0u) {
-        br.skip(len);
-        z = r == 15u ? z + 16u : 64u;                                // ZRL / EOB
-        kind = 2u;
-    } else {
-        z += r;
-        value = extend(sz ? ((bits << len) >> (32u - sz)) : 0u, sz);
-        br.skip(len + sz);
-        kind = ac ? 1u : 0u;
-        at = ac ? z : comp;
-        if (z > 63u) { err |= 4u; kind = 2u; }
-        ++z;
+    uint32_t e = t->lut[bits >> (32u - kLutBits)];
+    if (e == 0u) {                                                   // code longer than 9 bits (rare), or garbage
+        uint32_t l = kLutBits + 1u;
+        int32_t code = static_cast<int32_t>(bits >> (32u - l));
+        while (l <= 16u && code > t->maxcode[l]) { ++l; code = static_cast<int32_t>(bits >> (32u - l)); }
+        if (l > 16u) { err |= 1u; e = 16u << 8; }
+        else e = (l << 8) | t->val[(code + t->valoff[l]) & 255];
     }
+    const uint32_t len = e >> 8, sym = e & 255u;
+    const uint32_t r = ac ? sym >> 4 : 0u, sz = sym & 15u;
+    const bool run = ac && sz == 0u;                                 // ZRL / EOB
+    const uint32_t v = ((bits << len) >> 1) >> (31u - sz);           // sz bits behind the code (sz = 0 -> top bit, unused)
+    const int32_t half = static_cast<int32_t>((1u << sz) >> 1);
+    const int32_t ext = static_cast<int32_t>(v) < half ? static_cast<int32_t>(v) - static_cast<int32_t>((1u << sz) - 1u) : static_cast<int32_t>(v);
+    value = sz ? ext : 0;                                            // jdhuff.c HUFF_EXTEND
+    br.skip(len + (run ? 0u : sz));
+    const uint32_t pos = z + r;
+    const bool bad = !run && pos > 63u;
+    err |= (bad ? 4u : 0u) | ((!ac && sym > 11u) ? 2u : 0u);
+    kind = (run || bad) ? 2u : (ac ? 1u : 0u);
+    at = ac ? pos : comp;
+    z = run ? (r == 15u ? z + 16u : 64u) : pos + 1u;
     if (z >= 64u) {                                                  // block complete: next block of the MCU
         z = 0u;
         c = c + 1u == g.blocks_per_mcu ? 0u : c + 1u;
