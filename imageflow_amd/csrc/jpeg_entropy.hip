@@ -391,6 +391,7 @@ struct ParsedJpeg {
     bool qt_present[4] = {false, false, false, false};
     HuffSpec dc[4], ac[4];
     uint32_t restart_interval = 0;
+    int adobe_transform = -1;                        // APP14 "Adobe" colour transform flag, -1: no such marker
     size_t scan_begin = 0;
     uint32_t mcus_w = 0, mcus_h = 0, bw[3] = {0, 0, 0}, bh[3] = {0, 0, 0}, blocks_per_mcu = 0;
 };
@@ -461,6 +462,8 @@ int parse_jpeg(const uint8_t* d, size_t len, ParsedJpeg* out) {
             return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: JPEG process SOF%d (only baseline Huffman)", m - 0xC0);
         } else if (m == 0xDD) {
             if (n >= 2) P.restart_interval = (q[0] << 8) | q[1];
+        } else if (m == 0xEE && n >= 12 && std::memcmp(q, "Adobe", 5) == 0) {
+            P.adobe_transform = q[11];                                         // 0: RGB / CMYK stored as is, 1: YCbCr, 2: YCCK
         } else if (m == 0xDA) {                                                // SOS
             if (!have_sof) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: SOS before SOF");
             if (n < 1 || q[0] != P.ncomp || n < 4u + 2u * P.ncomp)
@@ -478,6 +481,10 @@ int parse_jpeg(const uint8_t* d, size_t len, ParsedJpeg* out) {
         i += seg;
     }
     if (!have_sof || !P.scan_begin || P.width == 0 || P.height == 0) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: no frame / scan found");
+    // libjpeg's colour-space guess (jdapimin.c default_decompress_parms): the pixel stage converts YCbCr only
+    if (P.ncomp == 3 && (P.adobe_transform == 0 ||
+                         (P.adobe_transform < 0 && P.comp_id[0] == 'R' && P.comp_id[1] == 'G' && P.comp_id[2] == 'B')))
+        return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: RGB-coded JPEG (no YCbCr transform)");
     uint32_t hmax = 1, vmax = 1;
     for (int c = 0; c < P.ncomp; ++c) {
         if (P.hs[c] < 1 || P.hs[c] > 2 || P.vs[c] < 1 || P.vs[c] > 2)

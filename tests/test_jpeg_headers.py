@@ -55,3 +55,16 @@ def test_oracle_decoder_equals_libjpeg_turbo_on_the_entropy_fixtures(golden_dir)
         h, w = ref.shape[:2]
         px = O.jpeg_idct_color(j)[:, :4 * w].reshape(h, w, 4)
         assert np.array_equal(px[..., [2, 1, 0]], ref), name
+
+
+def test_rgb_coded_files_are_left_to_libjpeg():
+    PIL = pytest.importorskip("PIL.Image")
+    a = np.random.default_rng(0).integers(0, 256, size=(24, 32, 3), dtype=np.uint8)
+    buf = io.BytesIO()
+    try:
+        PIL.fromarray(a).save(buf, "JPEG", quality=90, keep_rgb=True)           # Adobe marker, transform 0
+    except TypeError:
+        pytest.skip("this Pillow cannot write RGB-coded JPEG")
+    with pytest.raises(FlowError) as e:
+        D.get_image_info(buf.getvalue())
+    assert "RGB-coded" in str(e.value)
