@@ -59,7 +59,11 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     const uint32_t T = a.lanes_per_frame;
     const uint32_t slot = __builtin_amdgcn_readfirstlane(wtid / T);    // slots are whole waves: wave-uniform, lives in an SGPR
     const uint32_t tid = wtid - slot * T;
+    // Workgroups go to the 8 XCDs round-robin (id % 8), each XCD with its own L2.  With several column strips per frame,
+    // neighbouring strips read the same halo columns at about the same time: renumber so that consecutive logical
+    // workgroups (the strips of one frame) share an XCD and the halo is fetched from HBM once.
     uint32_t b = blockIdx.x;
+    if (a.n_strips > 1u && (gridDim.x & 7u) == 0u) b = (b & 7u) * (gridDim.x >> 3) + (b >> 3);
     const uint32_t strip_i = b % a.n_strips; b /= a.n_strips;
     const uint32_t band = b % a.n_bands;
     const uint32_t img_raw = (b / a.n_bands) * a.frames_per_wg + slot;
