@@ -148,7 +148,9 @@ bool use_per_pixel(uint32_t max_nu, int channels, uint32_t block) {
     if (const char* e = std::getenv("IFHIP_PERPIXEL")) per_pixel = std::atoi(e) != 0;      // experiment switch
     return per_pixel;
 }
-uint32_t block_for(uint32_t max_quads) { return std::max<uint32_t>(64u, (max_quads + 63u) & ~63u); }
+uint32_t block_for(uint32_t max_quads, int px) {          // lanes of a frame slot: one per px source pixels, whole waves
+    return std::max<uint32_t>(64u, (max_quads * static_cast<uint32_t>(4 / px) + 63u) & ~63u);
+}
 size_t lds_limit() {                                   // experiment switch: cap the per-workgroup LDS (co-residency)
     if (const char* e = std::getenv("IFHIP_LDS_LIMIT")) { const long v = std::atol(e); if (v >= 16384 && v <= 160 * 1024) return static_cast<size_t>(v); }
     return kLdsLimit;
@@ -157,7 +159,7 @@ constexpr uint32_t kMinLutCopiesLog2 = 4;      // never fewer than 16 copies of 
 
 // Split the output columns into strips whose staged source span fits one workgroup (max_lanes lanes x 4 px)
 // and whose minimal LDS footprint fits the CU.
-bool plan_strips(const AxisWeights& wh, uint32_t max_lanes, int channels, std::vector<Strip>* out, uint32_t* max_quads) {
+bool plan_strips(const AxisWeights& wh, uint32_t max_lanes, int px, int channels, std::vector<Strip>* out, uint32_t* max_quads) {
     for (uint32_t n = 1; n <= wh.n_out; ++n) {
         std::vector<Strip> s;
         bool ok = true;
@@ -180,7 +182,7 @@ bool plan_strips(const AxisWeights& wh, uint32_t max_lanes, int channels, std::v
             s.push_back(t);
         }
         if (ok) {
-            const bool pp = use_per_pixel(mu, channels, block_for(mq));
+            const bool pp = use_per_pixel(mu, channels, block_for(mq, px));
             for (const Strip& t : s)
                 if (fused_lds_bytes(t.u1 - t.u0, t.nquads, channels, 0, false, false, kMinLutCopiesLog2, pp) > lds_limit()) ok = false;
         }
@@ -304,7 +306,7 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         const ifhip_resample_plan::StripSet& ss = p->sets[alpha ? 1 : 0];
         a.strips = ss.d_strips; a.n_strips = static_cast<uint32_t>(ss.strips.size());
         const int channels = alpha ? 4 : 3;
-        const uint32_t block = block_for(ss.max_quads);
+        const uint32_t block = block_for(ss.max_quads, fused_shape(p->slots, channels).px);
         uint32_t max_nu = 0;
         for (const Strip& s : ss.strips) max_nu = std::max(max_nu, s.u1 - s.u0);
         const bool per_pixel = use_per_pixel(max_nu, channels, block);
@@ -524,12 +526,12 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
     for (int al = 0; al < 2 && p->fused_possible; ++al) {
         const int channels = al ? 4 : 3;
         ifhip_resample_plan::StripSet& ss = p->sets[al];
-        uint32_t max_lanes = static_cast<uint32_t>(fused_max_threads(p->slots, channels));
+        uint32_t max_lanes = static_cast<uint32_t>(fused_max_quads(p->slots, channels));      // in 4-pixel groups
         if (const char* e = std::getenv("IFHIP_MAX_LANES")) {               // experiment switch: narrower strips
             const int v = std::atoi(e);
             if (v >= 64) max_lanes = std::min<uint32_t>(max_lanes, static_cast<uint32_t>(v) & ~63u);
         }
-        ss.ok = plan_strips(p->wh, max_lanes, channels, &ss.strips, &ss.max_quads);
+        ss.ok = plan_strips(p->wh, max_lanes, fused_shape(p->slots, channels).px, channels, &ss.strips, &ss.max_quads);
         if (ss.ok && (rc = upload(ss.strips, &ss.d_strips))) return rc;
     }
     *plan = p.release();

@@ -62,7 +62,10 @@ struct ResampleArgs {
 // K*4*C registers per lane.  Three shapes, picked by a register estimate (checked against the compiler's report):
 //   wide + pipelined : 1024 lanes (128 registers), D = 4 rows in flight, converted samples double buffered
 //   wide + plain     : 1024 lanes, D = 4, no double buffering (register-heavier rings, e.g. K = 4 with alpha)
-//   narrow           : 512 lanes (256 registers), D = 8, pipelined; strips get narrower
+//   narrow           : big rings (K >= 6, or K >= 5 with alpha): 512 lanes (256 registers), D = 8, pipelined; strips get
+//                      narrower.  (IFHIP_NARROW_PX=2 builds the same strips as 1024 lanes x 2 pixels with 8-byte loads --
+//                      twice the waves, half the accumulators per lane; these shapes are instruction-bound, so the extra
+//                      per-lane overhead costs more than the occupancy buys.)
 // D is sized by bytes in flight: a CU needs ~46 KB outstanding to cover HBM latency at its share of the bandwidth
 // (1024 lanes x 4 rows x 16 B = 64 KB; 512 lanes need 8 rows for the same).  Measured: cfg5 2.78 -> 2.46 ms with
 // D = 8 on the narrow shape, cfg2 with alpha 2.05 -> 2.03 ms with D = 4 on the plain shape.
@@ -72,14 +75,18 @@ struct ResampleArgs {
 #ifndef IFHIP_NARROW_D
 #define IFHIP_NARROW_D 8
 #endif
-struct FusedShape { int threads, rows_in_flight, pipelined; };
+#ifndef IFHIP_NARROW_PX
+#define IFHIP_NARROW_PX 4    // 2 = 1024 lanes x 2 pixels (8-byte loads): parity-tested, measured 1.3 % slower on cfg5 (instruction-bound)
+#endif
+struct FusedShape { int threads, rows_in_flight, pipelined, px; };   // px: source pixels per lane (16- or 8-byte loads)
 constexpr FusedShape fused_shape(int K, int channels) {
     // thresholds read off the compiler's register report (python -m imageflow_amd.kernel_report): no variant spills
-    return (channels == 3 ? K <= 4 : K <= 2) ? FusedShape{1024, 4, 1}
-         : (channels == 3 ? K <= 5 : K <= 4) ? FusedShape{1024, IFHIP_PLAIN_D, 0}
-                                             : FusedShape{512, IFHIP_NARROW_D, 1};
+    return (channels == 3 ? K <= 4 : K <= 2) ? FusedShape{1024, 4, 1, 4}
+         : (channels == 3 ? K <= 5 : K <= 4) ? FusedShape{1024, IFHIP_PLAIN_D, 0, 4}
+                                             : FusedShape{IFHIP_NARROW_PX == 2 ? 1024 : 512, (IFHIP_NARROW_PX == 2 && K == 8) ? 6 : IFHIP_NARROW_D, 1, IFHIP_NARROW_PX};   // (K = 8: 6 rows, else the alpha variants spill)
 }
 constexpr int fused_max_threads(int K, int channels) { return fused_shape(K, channels).threads; }
+constexpr int fused_max_quads(int K, int channels) { return fused_shape(K, channels).threads * fused_shape(K, channels).px / 4; }
 // the step whose row the kernel requests while working on step i (see build_vschedule)
 constexpr int fused_lookahead(int K, int channels) {
     return fused_shape(K, channels).pipelined ? fused_shape(K, channels).rows_in_flight + 1 : fused_shape(K, channels).rows_in_flight;

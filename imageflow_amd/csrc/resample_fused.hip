@@ -112,18 +112,20 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     };
 
     const uint32_t s0 = a.band_begin[band], s1 = a.band_begin[band + 1];
-    const bool lane_on = tid < strip.nquads;
+    constexpr int PX = fused_shape(K, C).px;                // source pixels per lane: 4 (16-byte loads) or 2 (8-byte loads)
+    const uint32_t n_groups = strip.nquads * (4u / PX);     // lanes that own source columns
+    const bool lane_on = tid < n_groups;
     // lanes past the strip re-read its last quad instead of branching: every row load is unconditional, so the
     // number of loads in flight is known statically and the compiler can wait with vmcnt(D-1) instead of vmcnt(0)
-    const uint32_t quad = lane_on ? tid : strip.nquads - 1u;
+    const uint32_t quad = lane_on ? tid : n_groups - 1u;
     const uint8_t* src = a.in + static_cast<size_t>(img) * a.in_image_bytes
-                         + static_cast<size_t>(strip.cx0 + 4u * quad) * 4u;
+                         + static_cast<size_t>(strip.cx0 + static_cast<uint32_t>(PX) * quad) * 4u;
 
     // Ring accumulators and converted samples live as float2 pairs over the flattened (pixel, channel) index
     // f = p*C + c, so that the vertical pass issues v_pk_fma_f32 (two IEEE fmaf per instruction, the weight broadcast
     // from its SGPR): half the VALU issue slots of scalar v_fma_f32 for bit-identical results.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    constexpr int NP = 2 * C;                       // pairs per lane and ring slot (4 pixels x C channels)
+    constexpr int NP = PX * C / 2;                  // pairs per lane and ring slot (PX pixels x C channels)
     f32x2 acc[K][NP];
 #pragma unroll
     for (int s = 0; s < K; ++s)
@@ -131,23 +133,20 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
         for (int i = 0; i < NP; ++i) acc[s][i] = f32x2{0.0f, 0.0f};
     auto acc_at = [&](int s, int p, int c) -> float { const int f = p * C + c; return (f & 1) ? acc[s][f >> 1].y : acc[s][f >> 1].x; };
 
-    auto fetch_row = [&](int y) -> uint4 {                               // y is wave-uniform; -1 = nothing needed
+    typedef uint32_t raw_t __attribute__((ext_vector_type(PX)));        // one lane's PX source pixels
+    auto fetch_row = [&](int y) -> raw_t {                               // y is wave-uniform; -1 = nothing needed
         const uint32_t yy = y < 0 ? 0u : static_cast<uint32_t>(y);      // (row 0 is re-read: stays in L2)
-        const uint4* p = reinterpret_cast<const uint4*>(src + static_cast<size_t>(yy) * a.in_stride);
         // source frames are streamed exactly once: non-temporal loads keep them from displacing the tables in L2
         // (measured -1.7% kernel time, profiles/r1_notes.md)
-        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-        const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
-        return make_uint4(t.x, t.y, t.z, t.w);
+        return __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(src + static_cast<size_t>(yy) * a.in_stride));
     };
 
     // sample -> working float for the 4 pixels of one 16-byte load (arithmetic contract step 1)
-    auto convert = [&](const uint4& q, f32x2 (&vv)[NP]) {
-        const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
-        float v[4][C];
+    auto convert = [&](const raw_t& q, f32x2 (&vv)[NP]) {
+        float v[PX][C];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const uint32_t px = w4[p];
+        for (int p = 0; p < PX; ++p) {
+            const uint32_t px = q[p];
             v[p][0] = lut[px & 255u];
             v[p][1] = lut[(px >> 8) & 255u];
             v[p][2] = lut[(px >> 16) & 255u];
@@ -244,7 +243,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     // Register-heavier rings use the plain form (!PIPE): convert, refill, accumulate, one step at a time.
     // The host pads every band to a multiple of D steps, so the unrolled group has no early exit and every buffer
     // index below is a compile-time constant.
-    uint4 raw[D];
+    raw_t raw[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         raw[d] = fetch_row(steps[s0 + d].y);
@@ -321,15 +320,24 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                 for (int s = 0; s < K; ++s) {
                     if (st.flush_slot == s) {
                         if (lane_on) {
-                            float4* g4 = reinterpret_cast<float4*>(dst_row + 4u * tid);
                             const uint32_t pp4 = plane_pitch >> 2;
-                            g4[0] = make_float4(acc_at(s, 0, 0), acc_at(s, 0, 1), acc_at(s, 1, 0), acc_at(s, 1, 1));
-                            g4[pp4] = make_float4(acc_at(s, 2, 0), acc_at(s, 2, 1), acc_at(s, 3, 0), acc_at(s, 3, 1));
-                            if (ALPHA) {
-                                g4[2u * pp4] = make_float4(acc_at(s, 0, 2), acc_at(s, 0, C - 1), acc_at(s, 1, 2), acc_at(s, 1, C - 1));
-                                g4[3u * pp4] = make_float4(acc_at(s, 2, 2), acc_at(s, 2, C - 1), acc_at(s, 3, 2), acc_at(s, 3, C - 1));
+                            if constexpr (PX == 4) {
+                                float4* g4 = reinterpret_cast<float4*>(dst_row + 4u * tid);
+                                g4[0] = make_float4(acc_at(s, 0, 0), acc_at(s, 0, 1), acc_at(s, 1, 0), acc_at(s, 1, 1));
+                                g4[pp4] = make_float4(acc_at(s, 2, 0), acc_at(s, 2, 1), acc_at(s, 3, 0), acc_at(s, 3, 1));
+                                if (ALPHA) {
+                                    g4[2u * pp4] = make_float4(acc_at(s, 0, 2), acc_at(s, 0, C - 1), acc_at(s, 1, 2), acc_at(s, 1, C - 1));
+                                    g4[3u * pp4] = make_float4(acc_at(s, 2, 2), acc_at(s, 2, C - 1), acc_at(s, 3, 2), acc_at(s, 3, C - 1));
+                                } else {
+                                    g4[2u * pp4] = make_float4(acc_at(s, 0, 2), acc_at(s, 1, 2), acc_at(s, 2, 2), acc_at(s, 3, 2));
+                                }
                             } else {
-                                g4[2u * pp4] = make_float4(acc_at(s, 0, 2), acc_at(s, 1, 2), acc_at(s, 2, 2), acc_at(s, 3, 2));
+                                // 2 pixels per lane: lane g holds pixels 2g, 2g+1 = half (g & 1) of 4-pixel group g >> 1
+                                const uint32_t half = tid & 1u;
+                                float4* g4 = reinterpret_cast<float4*>(dst_row + 4u * (tid >> 1));
+                                g4[half * pp4] = make_float4(acc_at(s, 0, 0), acc_at(s, 0, 1), acc_at(s, 1, 0), acc_at(s, 1, 1));
+                                if (ALPHA) g4[(2u + half) * pp4] = make_float4(acc_at(s, 0, 2), acc_at(s, 0, C - 1), acc_at(s, 1, 2), acc_at(s, 1, C - 1));
+                                else *reinterpret_cast<float2*>(dst_row + 2u * plane_pitch + 2u * tid) = make_float2(acc_at(s, 0, 2), acc_at(s, 1, 2));
                             }
                         }
 #pragma unroll
