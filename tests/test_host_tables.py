@@ -139,3 +139,14 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(FlowError) as e:
         scale_and_render_host(src, 4, 4, 64, False, dst, 2, 2, 64, ScaleAndRenderParams(1, 0, 2, 2))
     assert e.value.kind == ErrorKind.InvalidArgument
+
+
+def test_generated_rust_bindings_cover_the_header():
+    """bindings/hip_interop.rs (tools/gen_rust_bindings.py) names exactly the functions include/imageflow_hip.h declares."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "imageflow_hip.h")).read()
+    rs = open(os.path.join(root, "bindings", "hip_interop.rs")).read()
+    declared = set(re.findall(r"IFHIP_API\s+[^;{(]*?\b(ifhip_\w+)\s*\(", header))
+    bound = set(re.findall(r"pub fn (ifhip_\w+)\(", rs))
+    assert declared == bound and len(bound) > 40
