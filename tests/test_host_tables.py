@@ -150,3 +150,20 @@ def test_generated_rust_bindings_cover_the_header():
     declared = set(re.findall(r"IFHIP_API\s+[^;{(]*?\b(ifhip_\w+)\s*\(", header))
     bound = set(re.findall(r"pub fn (ifhip_\w+)\(", rs))
     assert declared == bound and len(bound) > 40
+
+
+def test_header_is_plain_c_and_links_with_c_linkage(tmp_path):
+    """tests/c_abi_smoke.c: a C99 program (-pedantic) including include/imageflow_hip.h and linking libimageflow_hip.so,
+    calling host-only entry points."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "imageflow_amd", "lib")
+    exe = str(tmp_path / "c_abi_smoke")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_abi_smoke.c"), "-o", exe, "-L", libdir, "-limageflow_hip",
+                    f"-Wl,-rpath,{libdir}"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "c abi ok" in out.stdout, out.stdout + out.stderr
