@@ -160,10 +160,10 @@ def main():
     plan = plan_for(IN_W, IN_H, OUT_W, OUT_H, info.interpolation_filter, wl[5], dev)
     mode = "none" if (not distributed or args.no_gather or os.environ.get("IFHIP_BENCH_GATHER", "1") == "0") else args.gather
     gather = mode == "every"
-    if dryrun and mode != "none":  # gloo cannot gather device tensors: stage the shard through the host in the dry run
-        raise SystemExit("dry run: pass --gather none")
+    if dryrun and mode == "every":  # gloo cannot gather device tensors; the dry run only walks the final gather (via the host)
+        raise SystemExit("dry run: pass --gather final or none")
     from imageflow_amd.sharding import gather_to_root, max_over_ranks
-    gathered = [torch.empty((world,) + tuple(c.data.shape), dtype=torch.uint8, device=dev) if rank == 0 else None
+    gathered = [torch.empty((world,) + tuple(c.data.shape), dtype=torch.uint8, device="cpu" if dryrun else dev) if rank == 0 else None
                 for c in canv] if mode != "none" else None
     gather_note = {"none": "none",
                    "every": "rccl gather of the outputs to rank 0 every step, asynchronous, double buffered",
@@ -201,7 +201,8 @@ def main():
         # resample kernel would take CUs from a grid that is exactly one workgroup per CU, so the job's one exchange
         # happens after the last batch; a failure here is reported, it does not cost the measurement.
         try:
-            gather_to_root(canv[(args.steps - 1) & 1].data, 0, async_op=False, out=gathered[0])
+            last = canv[(args.steps - 1) & 1].data
+            gather_to_root(last.cpu() if dryrun else last, 0, async_op=False, out=gathered[0])
         except Exception as e:  # noqa: BLE001
             gather_note = f"final rccl gather failed: {type(e).__name__}: {e}"
     if distributed:
