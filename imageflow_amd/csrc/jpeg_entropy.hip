@@ -39,7 +39,10 @@ namespace ifhip {
 #endif
 constexpr uint32_t kSubBits = IFHIP_ENT_SUBBITS;     // bits per sub-sequence (one lane)
 constexpr uint32_t kSubWords = kSubBits / 32;
-constexpr uint32_t kLutBits = 9;
+#ifndef IFHIP_ENT_LUTBITS
+#define IFHIP_ENT_LUTBITS 9
+#endif
+constexpr uint32_t kLutBits = IFHIP_ENT_LUTBITS;
 
 struct DerivedTab {                                  // one Huffman table, decode form (jdhuff.c jpeg_make_d_derived_tbl)
     uint16_t lut[1u << kLutBits];                    // (length << 8) | symbol for codes of length <= 9, else 0
