@@ -16,6 +16,7 @@
 // Algorithmic bytes per 4:2:0 pixel: 3 B coefficients + 4 B BGRA (+ 1.5 B written and re-read for the planes).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -280,8 +281,74 @@ __device__ __forceinline__ void chroma4(const uint8_t* P, uint32_t W, uint32_t D
 // + 0.25 chroma loads instead of 1.25, and a wave lives 16 rows instead of one.
 constexpr uint32_t kColorRows = 16;
 
+constexpr uint32_t kTilePx = 1024, kYsPitch = kTilePx + 16;      // luma tile of the fused form: 16 rows x 1024 pixels
+
+__device__ __forceinline__ void wave_sync_lds() {       // the 8 lanes of a block share a wave: order LDS traffic, no s_barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// FUSED_LUMA (full-size decode of 3-component files): the workgroup first runs the islow IDCT of the 2 x 128 luma
+// blocks under its 1024 x 16 pixel tile into LDS -- 8 passes of 32 blocks, 8 lanes per block as in jpeg_idct_kernel, ordered
+// by wave-scope fences -- and the colour pass reads Y from there: the luma plane never exists in HBM (1 B/px written
+// + 1 B/px read less, one launch less).
+template <bool FUSED_LUMA>
 __global__ void __launch_bounds__(256) jpeg_color_kernel(const JpegArgs a) {
-    const uint32_t x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u, img = blockIdx.z;
+    __shared__ int32_t ws[FUSED_LUMA ? kBlocksPerWg * kBlockPitch : 1];
+    __shared__ __attribute__((aligned(16))) uint8_t ys[FUSED_LUMA ? kColorRows * kYsPitch : 16];
+    const uint32_t img = blockIdx.z;
+    if (FUSED_LUMA) {
+        const uint32_t t = threadIdx.x, lane8 = t & 7u, lb = t >> 3;
+        int32_t* w = ws + lb * kBlockPitch;
+        const uint32_t nblk = a.g.bw[0] * a.g.bh[0];
+        const uint16_t* q = a.qt + static_cast<size_t>(img) * a.g.ncomp * 64u + lane8 * 8u;
+        const uint4 qv = *reinterpret_cast<const uint4*>(q);
+        const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+        for (uint32_t pass = 0; pass < 8u; ++pass) {
+            const uint32_t bl = pass * kBlocksPerWg + lb;                 // 0..255: block row bl >> 7, block column bl & 127
+            const uint32_t by = blockIdx.y * 2u + (bl >> 7), bx = blockIdx.x * 128u + (bl & 127u);
+            const bool on = bx < a.g.bw[0] && by < a.g.bh[0];
+            if (on) {
+                const int16_t* src = a.coef[0] + (static_cast<size_t>(img) * nblk + static_cast<size_t>(by) * a.g.bw[0] + bx) * 64u + lane8 * 8u;
+                const uint4 cv = *reinterpret_cast<const uint4*>(src);
+                const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int32_t c0 = static_cast<int16_t>(cw[k] & 0xffffu), c1 = static_cast<int16_t>(cw[k] >> 16);
+                    w[lane8 * 8u + 2 * k] = c0 * static_cast<int32_t>(qw[k] & 0xffffu);
+                    w[lane8 * 8u + 2 * k + 1] = c1 * static_cast<int32_t>(qw[k] >> 16);
+                }
+            }
+            wave_sync_lds();
+            if (on) {                                                   // column pass: lane8 = column
+                int32_t in[8], out[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) in[r] = w[r * 8 + lane8];
+                idct8(in, out, 11);
+                wave_sync_lds();
+#pragma unroll
+                for (int r = 0; r < 8; ++r) w[r * 8 + lane8] = out[r];
+            }
+            wave_sync_lds();
+            if (on) {                                                   // row pass: lane8 = row
+                int32_t in[8], out[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) in[k] = w[lane8 * 8u + k];
+                idct8(in, out, 18);
+                uint32_t lo = 0, hi = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    lo |= range_limit(out[k]) << (8 * k);
+                    hi |= range_limit(out[4 + k]) << (8 * k);
+                }
+                *reinterpret_cast<uint2*>(&ys[((bl >> 7) * 8u + lane8) * kYsPitch + (bl & 127u) * 8u]) = make_uint2(lo, hi);
+            }
+            wave_sync_lds();
+        }
+        __syncthreads();
+    }
+    const uint32_t x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
     if (x0 >= a.g.out_w) return;
     const uint32_t y_begin = blockIdx.y * kColorRows;
     const uint32_t y_end = min(y_begin + kColorRows, a.g.out_h);
@@ -291,7 +358,8 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const JpegArgs a) {
 
     auto emit = [&](uint32_t y, const int32_t (&v)[2][4], bool gray) {
         uint32_t yv;
-        __builtin_memcpy(&yv, py + static_cast<size_t>(y) * a.g.pw[0], 4);     // planes carry 16 bytes of slack behind the last row
+        if (FUSED_LUMA) yv = *reinterpret_cast<const uint32_t*>(&ys[(y - y_begin) * kYsPitch + threadIdx.x * 4u]);
+        else __builtin_memcpy(&yv, py + static_cast<size_t>(y) * a.g.pw[0], 4);     // planes carry 16 bytes of slack behind the last row
         const int32_t Y[4] = {static_cast<int32_t>(yv & 255u), static_cast<int32_t>((yv >> 8) & 255u),
                               static_cast<int32_t>((yv >> 16) & 255u), static_cast<int32_t>(yv >> 24)};
         uint32_t out[4];
@@ -546,13 +614,17 @@ int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d
     const uint64_t wgs = (total_blocks + kBlocksPerWg - 1) / kBlocksPerWg;
     if (wgs > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
     (void)wgs;
-    for (int c = 0; c < a.g.ncomp; ++c) {
+    // full-size colour decode: the luma IDCT runs inside the colour kernel (no luma plane in HBM)
+    const bool fused_luma = a.g.ncomp == 3 && a.g.scale_num == 8u && a.g.luma_mode == 0u && std::getenv("IFHIP_JPEG_UNFUSED") == nullptr;
+    for (int c = fused_luma ? 1 : 0; c < a.g.ncomp; ++c) {
         a.comp = static_cast<uint32_t>(c);
         const uint32_t nblk = a.g.bw[c] * a.g.bh[c];
         hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nblk + kBlocksPerWg - 1) / kBlocksPerWg, n_images), dim3(256), 0, st, a);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(jpeg_color_kernel, dim3((a.g.out_w + 1023u) / 1024u, (a.g.out_h + kColorRows - 1u) / kColorRows, n_images), dim3(256), 0, st, a);
+    const dim3 cgrid((a.g.out_w + 1023u) / 1024u, (a.g.out_h + kColorRows - 1u) / kColorRows, n_images);
+    if (fused_luma) hipLaunchKernelGGL((jpeg_color_kernel<true>), cgrid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((jpeg_color_kernel<false>), cgrid, dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     return IFHIP_OK;
 }
