@@ -73,6 +73,7 @@ struct EntropyArgs {
     const uint32_t* sub_seg;                         // segment of every sub-sequence
     const DerivedTab* tabs;                          // [image][comp][dc, ac]
     uint32_t n_sub, n_seg;
+    uint32_t uniform_tables;                         // every image carries the same Huffman tables (e.g. the standard ones)
     uint32_t* exit_p[2];                             // exit bit position, double buffered by round parity
     uint32_t* exit_cz[2];                            // exit (block-in-MCU << 8) | zigzag index
     uint32_t* start_p;                               // start state the lane last decoded from
@@ -194,7 +195,7 @@ __device__ __forceinline__ void decode_symbol(const EntropyGeom& g, BitReader& b
 
 template <typename F>
 __device__ __forceinline__ void with_tables(const EntropyArgs& a, const DerivedTab* lds_tabs, uint32_t lds_image, uint32_t image, F&& f) {
-    if (image == lds_image) f(reinterpret_cast<const __attribute__((address_space(3))) DerivedTab*>(
+    if (image == lds_image || a.uniform_tables) f(reinterpret_cast<const __attribute__((address_space(3))) DerivedTab*>(
                                   static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_tabs))));
     else f(a.tabs + static_cast<size_t>(image) * 6u);
 }
@@ -670,6 +671,9 @@ int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* fi
     }
     a.n_sub = static_cast<uint32_t>(sub_seg.size());
     a.n_seg = static_cast<uint32_t>(segs.size());
+    a.uniform_tables = 1u;                           // batches of small files put many images into one workgroup: with
+    for (uint32_t img = 1; img < n_images && a.uniform_tables; ++img)     // identical tables they all use the LDS copy
+        if (std::memcmp(&tabs[static_cast<size_t>(img) * 6u], &tabs[0], 6u * sizeof(DerivedTab)) != 0) a.uniform_tables = 0u;
     int rc;
     uint32_t *d_words = nullptr, *d_sub = nullptr;
     Segment* d_segs = nullptr;

@@ -91,3 +91,24 @@ def test_rejections_and_corruption(golden_dir):
     cut = a[: len(a) * 2 // 3] + b"\xff\xd9"                     # scan ends early
     with pytest.raises(FlowError):
         D.JpegEntropyBatch([cut], DEV).read_coefficients()
+
+
+def test_many_small_files_in_one_batch(golden_dir):
+    """Hundreds of tiny files: a workgroup of 256 sub-sequences spans dozens of images (uniform standard tables -> the LDS
+    copy serves all of them; an optimised-table file in the batch switches the foreign lanes to the global tables)."""
+    z = np.load(os.path.join(golden_dir, "jpeg_cases.npz"))
+    names = [str(n) for n in z["names"]]
+    small = [z[f"jpg_{i}"].tobytes() for i, n in enumerate(names) if n.startswith("16x16_") and "4:2:0" in n]
+    assert len(small) >= 2
+    files = [small[k % len(small)] for k in range(300)]
+    zz = np.load(os.path.join(golden_dir, "jpeg_entropy_cases.npz"))
+    opt = [zz[f"jpg_{i}"].tobytes() for i, n in enumerate(zz["names"]) if str(n).startswith("16x16_") and "4:2:0" in str(n) and "optimize=True" in str(n)]
+    for batch in (files, files[:150] + opt[:1] + files[150:]):
+        ent = D.JpegEntropyBatch(batch, DEV)
+        coef = ent.read_coefficients()
+        ref = {}
+        for k in (0, 1, 149, 150, 151, len(batch) - 1):
+            data = batch[k]
+            j = ref.setdefault(data, O.jpeg_read_coefficients(data))
+            for c in range(3):
+                assert np.array_equal(coef[c][k].cpu().numpy(), j["coef"][c]), (k, c)
