@@ -33,7 +33,7 @@ def apply_downscaling(original_width, original_height, downscale_if_wider_than, 
                       downscaled_min_width, downscaled_min_height):
     """MzDec::apply_downscaling (mozjpeg_decoder.rs:588-618): the scale_num/8 libjpeg is asked for, given the decoder
     hints (ffi/c_interop.rs:6-15).  Returns (scale_num, w, h); scale_num == 8 means full-size decode.
-    (The GPU stage decodes full size today; a scaled request is served as full decode + resample.)"""
+    (The GPU pixel stage implements scale_num 8, 4, 2, 1; for 3, 5, 6 decode at 8/8 and let the resampler reduce.)"""
     if (downscaled_min_width > 0 and downscaled_min_height > 0
             and (original_width > downscale_if_wider_than or original_height > or_if_taller_than)):
         for i in range(1, 8):
@@ -108,7 +108,6 @@ def jpeg_idct_color_host(coef, qt, n_components, h_samp, v_samp, width, height, 
     out = np.zeros((oh, stride), np.uint8)
     hs = np.array(list(h_samp)[:3], np.uint8)
     vs = np.array(list(v_samp)[:3], np.uint8)
-    p = [np.ascontiguousarray(coef[c]).ctypes.data if c < n_components else None for c in range(3)]
     keep = [np.ascontiguousarray(coef[c]) for c in range(n_components)]
     p = [keep[c].ctypes.data if c < n_components else None for c in range(3)]
     q = np.ascontiguousarray(qt[:n_components], np.uint16)
