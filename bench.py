@@ -104,8 +104,9 @@ def cpu_baseline(sample_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)     # 0.3 s of GPU time: long enough that the clock ramp after the
+    # idle barrier (the first ~20 launches run 3-5 % slower) does not colour the average
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (default 256 = BASELINE config 2)")
     ap.add_argument("--pattern", default="mixed", choices=["mixed", "gradient", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
