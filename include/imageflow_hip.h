@@ -4,7 +4,7 @@
  *
  * Every entry point names the reference interface it replaces (paths relative to the imageflow tree).
  * The Rust side binds these with an `extern "C"` block exactly like imageflow_core/src/ffi/c_interop.rs:115-213
- * binds c_components today (binding source: INTEGRATION.md).
+ * binds c_components today (binding source: bindings/hip_interop.rs, generated from this file; call sites: INTEGRATION.md).
  *
  * Conventions (mirroring wrap_jpeg_* in c_components/lib/codec_jpeg_wrapper.c:187-233 and FlowError):
  *   - functions return an ifhip_status (0 = ok); the message of the last failure on the calling thread is
