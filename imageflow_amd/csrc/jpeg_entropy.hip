@@ -19,8 +19,14 @@
 // Coefficient-exact against oracle/jpeg_oracle.c jo_jpeg_read_coefficients (itself pinned to libjpeg-turbo).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <cstdio>
 #include <vector>
 
 #include "common.hpp"
@@ -527,6 +533,42 @@ void derive_table(const HuffSpec& h, DerivedTab* t) {
 
 }  // namespace
 
+// Pinned staging for the packed scans, kept between calls (a service decodes batch after batch): pageable memory costs a
+// page fault per 4 KiB on first touch and a bounce copy on upload -- together more than the GPU needs for the decode.
+namespace {
+struct PinnedPool {
+    std::mutex mu;
+    void* ptr = nullptr;
+    size_t cap = 0;
+    bool busy = false;
+} g_staging;
+
+struct StagingLease {                    // the pool's buffer if it is free, a private pinned allocation otherwise
+    void* ptr = nullptr;
+    bool pooled = false;
+    int acquire(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> lk(g_staging.mu);
+            if (!g_staging.busy) {
+                if (g_staging.cap < bytes) {
+                    if (g_staging.ptr) (void)hipHostFree(g_staging.ptr);
+                    g_staging.ptr = nullptr; g_staging.cap = 0;
+                    const size_t want = bytes + bytes / 4;
+                    if (hipHostMalloc(&g_staging.ptr, want, hipHostMallocPortable) == hipSuccess) g_staging.cap = want;
+                }
+                if (g_staging.cap >= bytes) { g_staging.busy = true; ptr = g_staging.ptr; pooled = true; return IFHIP_OK; }
+            }
+        }
+        HIP_TRY(hipHostMalloc(&ptr, bytes, hipHostMallocPortable));
+        return IFHIP_OK;
+    }
+    ~StagingLease() {
+        if (pooled) { std::lock_guard<std::mutex> lk(g_staging.mu); g_staging.busy = false; }
+        else if (ptr) (void)hipHostFree(ptr);
+    }
+};
+}  // namespace
+
 struct ifhip_jpeg_entropy {
     int device = -1;
     uint32_t n_images = 0;
@@ -587,23 +629,39 @@ int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* fi
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: device %d is %s, this library is built for gfx950 only", e->device, prop.gcnArchName);
     e->n_images = n_images;
-    std::vector<uint32_t> words;
     std::vector<Segment> segs;
     std::vector<uint32_t> sub_seg;
     std::vector<DerivedTab> tabs(static_cast<size_t>(n_images) * 6u);
     e->qt.assign(static_cast<size_t>(n_images) * 192u, 0);
-    std::vector<uint8_t> bytes;
-    for (uint32_t img = 0; img < n_images; ++img) {
+
+    // Host preparation runs on a few threads, one file at a time each: parsing and un-stuffing are independent per file
+    // and would otherwise take several times longer than the GPU needs to decode the batch.
+    struct Prep {
         ParsedJpeg P;
-        int rc = parse_jpeg(files[img], lengths[img], &P);
-        if (rc) return rc;
-        if (img == 0) e->first = P;
-        else {
-            const ParsedJpeg& F = e->first;
-            bool same = P.width == F.width && P.height == F.height && P.ncomp == F.ncomp;
-            for (int c = 0; c < P.ncomp && same; ++c) same = P.hs[c] == F.hs[c] && P.vs[c] == F.vs[c];
-            if (!same) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: image %u differs in size or sampling from image 0 (one batch = one geometry)", img);
-        }
+        int rc = IFHIP_OK;
+        std::string message;
+        std::vector<std::vector<uint8_t>> seg_bytes;      // un-stuffed data of every restart segment
+        std::vector<uint32_t> seg_mcu0, seg_mcus;
+        uint32_t first_seg = 0;
+    };
+    const bool timing = std::getenv("IFHIP_ENT_TIMING") != nullptr;        // development aid: phase times on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    const auto t_start = now();
+    std::vector<Prep> prep(n_images);
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(n_images, hw), 16u);
+    auto run_parallel = [&](auto&& body) {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back([&, t] { for (uint32_t i = t; i < n_images; i += n_threads) body(i); });
+        for (uint32_t i = 0; i < n_images; i += n_threads) body(i);
+        for (auto& th : pool) th.join();
+    };
+    run_parallel([&](uint32_t img) {
+        Prep& R = prep[img];
+        ParsedJpeg& P = R.P;
+        R.rc = parse_jpeg(files[img], lengths[img], &P);
+        if (R.rc) { R.message = last_error(); return; }
         for (int c = 0; c < P.ncomp; ++c) {
             std::memcpy(&e->qt[(static_cast<size_t>(img) * 3u + c) * 64u], P.qt[P.tq[c]], 128);
             derive_table(P.dc[P.td[c]], &tabs[static_cast<size_t>(img) * 6u + 2u * c]);
@@ -618,7 +676,8 @@ int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* fi
         size_t i = P.scan_begin;
         bool more = true;
         while (more && mcu0 < total_mcus) {
-            bytes.clear();
+            R.seg_bytes.emplace_back();
+            std::vector<uint8_t>& bytes = R.seg_bytes.back();
             more = false;
             while (i < len) {                                                   // runs between 0xFF bytes are copied whole
                 const uint8_t* ff = static_cast<const uint8_t*>(std::memchr(d + i, 0xFF, len - i));
@@ -634,28 +693,70 @@ int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* fi
                 if (m >= 0xD0 && m <= 0xD7) { more = true; break; }            // restart: next segment
                 break;                                                         // EOI or any other marker: scan ends
             }
-            Segment sg;
-            sg.image = img;
-            sg.first_mcu = mcu0;
             const uint32_t mcus = std::min(per_seg, total_mcus - mcu0);
-            sg.n_blocks = mcus * P.blocks_per_mcu;
-            sg.first_sub = static_cast<uint32_t>(words.size() / kSubWords);
-            const size_t bits = bytes.size() * 8u;
-            sg.n_sub = static_cast<uint32_t>(std::max<size_t>(1, (bits + kSubBits - 1) / kSubBits));
-            const uint64_t bit_end = static_cast<uint64_t>(sg.first_sub) * kSubBits + bits;
-            if (bit_end + 4096 >= (1ull << 32)) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch holds more than 512 MB of scan data");
-            sg.bit_end = static_cast<uint32_t>(bit_end);
-            const size_t w0 = words.size();
-            words.resize(w0 + static_cast<size_t>(sg.n_sub) * kSubWords, 0u);
-            std::memcpy(&words[w0], bytes.data(), bytes.size());               // bytes in stream order, then big-endian words
-            for (size_t k = w0; k < words.size(); ++k) words[k] = __builtin_bswap32(words[k]);
-            for (uint32_t k = 0; k < sg.n_sub; ++k) sub_seg.push_back(static_cast<uint32_t>(segs.size()));
-            segs.push_back(sg);
+            R.seg_mcu0.push_back(mcu0);
+            R.seg_mcus.push_back(mcus);
             mcu0 += mcus;
         }
-        if (mcu0 < total_mcus) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: scan of image %u ends after %u of %u MCUs", img, mcu0, total_mcus);
+        if (mcu0 < total_mcus) {
+            R.rc = IFHIP_INVALID_ARGUMENT;
+            char buf[160];
+            std::snprintf(buf, sizeof buf, "ImageMalformed: scan of image %u ends after %u of %u MCUs", img, mcu0, total_mcus);
+            R.message = buf;
+        }
+    });
+    const double t_parse = ms_since(t_start);
+    // serial: errors in file order, geometry check, segment table and word offsets
+    uint64_t total_subs = 0;
+    for (uint32_t img = 0; img < n_images; ++img) {
+        Prep& R = prep[img];
+        if (R.rc) return fail(R.rc, "%s", R.message.c_str());
+        const ParsedJpeg& P = R.P;
+        if (img == 0) e->first = P;
+        else {
+            const ParsedJpeg& F = e->first;
+            bool same = P.width == F.width && P.height == F.height && P.ncomp == F.ncomp;
+            for (int c = 0; c < P.ncomp && same; ++c) same = P.hs[c] == F.hs[c] && P.vs[c] == F.vs[c];
+            if (!same) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: image %u differs in size or sampling from image 0 (one batch = one geometry)", img);
+        }
+        R.first_seg = static_cast<uint32_t>(segs.size());
+        for (size_t k = 0; k < R.seg_bytes.size(); ++k) {
+            Segment sg;
+            sg.image = img;
+            sg.first_mcu = R.seg_mcu0[k];
+            sg.n_blocks = R.seg_mcus[k] * P.blocks_per_mcu;
+            sg.first_sub = static_cast<uint32_t>(total_subs);
+            const size_t bits = R.seg_bytes[k].size() * 8u;
+            sg.n_sub = static_cast<uint32_t>(std::max<size_t>(1, (bits + kSubBits - 1) / kSubBits));
+            const uint64_t bit_end = total_subs * kSubBits + bits;
+            if (bit_end + 4096 >= (1ull << 32)) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch holds more than 512 MB of scan data");
+            sg.bit_end = static_cast<uint32_t>(bit_end);
+            total_subs += sg.n_sub;
+            segs.push_back(sg);
+        }
     }
-    words.resize(words.size() + 64, 0u);                                        // lookahead slack behind the last segment
+    const size_t n_words = static_cast<size_t>(total_subs) * kSubWords + 64u;  // + lookahead slack behind the last segment
+    StagingLease staging;
+    {
+        const int src = staging.acquire(n_words * sizeof(uint32_t));
+        if (src) return src;
+    }
+    uint32_t* words = static_cast<uint32_t*>(staging.ptr);
+    std::memset(words + (n_words - 64u), 0, 64u * sizeof(uint32_t));
+    sub_seg.resize(static_cast<size_t>(total_subs));
+    run_parallel([&](uint32_t img) {                                            // pack: stream order bytes -> big-endian words
+        const Prep& R = prep[img];
+        for (size_t k = 0; k < R.seg_bytes.size(); ++k) {
+            const Segment& sg = segs[R.first_seg + k];
+            uint32_t* w = words + static_cast<size_t>(sg.first_sub) * kSubWords;
+            const size_t nw = static_cast<size_t>(sg.n_sub) * kSubWords, nb = R.seg_bytes[k].size();
+            std::memcpy(w, R.seg_bytes[k].data(), nb);
+            std::memset(reinterpret_cast<uint8_t*>(w) + nb, 0, nw * sizeof(uint32_t) - nb);      // pad to the 1 024-bit boundary
+            for (size_t q = 0; q < nw; ++q) w[q] = __builtin_bswap32(w[q]);
+            for (uint32_t q = 0; q < sg.n_sub; ++q) sub_seg[sg.first_sub + q] = R.first_seg + static_cast<uint32_t>(k);
+        }
+    });
+    const double t_pack = ms_since(t_start);
     const ParsedJpeg& F = e->first;
     EntropyArgs& a = e->a;
     std::memset(&a, 0, sizeof a);
@@ -678,7 +779,7 @@ int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* fi
     uint32_t *d_words = nullptr, *d_sub = nullptr;
     Segment* d_segs = nullptr;
     DerivedTab* d_tabs = nullptr;
-    if ((rc = dev_alloc(e.get(), &d_words, words.size(), words.data()))) return rc;
+    if ((rc = dev_alloc(e.get(), &d_words, n_words, words))) return rc;
     if ((rc = dev_alloc(e.get(), &d_segs, segs.size(), segs.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_sub, sub_seg.size(), sub_seg.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_tabs, tabs.size(), tabs.data()))) return rc;
@@ -694,6 +795,9 @@ int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* fi
     if ((rc = dev_alloc<uint32_t>(e.get(), &a.changed, 2))) return rc;
     a.errors = a.changed + 1;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_flags), 2 * sizeof(uint32_t), hipHostMallocDefault));
+    if (timing)
+        std::fprintf(stderr, "[ifhip entropy create] threads %u (hw %u): parse+unstuff %.2f ms, +pack %.2f ms, +upload/alloc %.2f ms\n",
+                     n_threads, hw, t_parse, t_pack, ms_since(t_start));
     *out = e.release();
     return IFHIP_OK;
 }
