@@ -613,6 +613,124 @@ int ifo_scale_and_render(const uint8_t* in, uint32_t in_w, uint32_t in_h, uint32
     return rc;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Contract variants.  Used ONLY by tests/test_oracle_reference_checksums.py to measure how far
+ * the choices of the arithmetic contract (header, steps 1-4) can move the BGRA8 result, and
+ * which of them still reproduce the reference's stored checksums
+ * (tests/integration/visuals/canvas.checksums, trim.checksums).  flags == 0 is the contract.
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    IFO_VAR_HFIRST       = 1u << 0,   /* horizontal pass first                                   */
+    IFO_VAR_ACC_MASK     = 3u << 1,   /* 0 ascending fmaf | 1 ascending mul,add | 2 f64 sum, one rounding | 3 descending fmaf */
+    IFO_VAR_UNPREMUL_RCP = 1u << 3,   /* c * (1/a) instead of c / a                              */
+    IFO_VAR_ENCODE_EXACT = 1u << 4,   /* linear->sRGB by the f64 formula, round half up, no LUT  */
+    IFO_VAR_S2L_F64      = 1u << 5,   /* sRGB->linear table from f64 pow, rounded to f32         */
+    IFO_VAR_ALPHA_RNE    = 1u << 6,   /* alpha byte by round-half-even instead of uchar_clamp_ff */
+    IFO_VAR_NO_PREMUL    = 1u << 7,   /* negative control: straight alpha, four plain channels   */
+    IFO_VAR_SRGB_SPACE   = 1u << 8    /* negative control: filter in sRGB space                  */
+};
+
+static inline float var_acc(uint32_t mode, const float* w, const float* v, size_t vstep, uint32_t n) {
+    if (mode == 0) { float a = 0.f; for (uint32_t k = 0; k < n; k++) a = fmaf(w[k], v[k * vstep], a); return a; }
+    if (mode == 1) { float a = 0.f; for (uint32_t k = 0; k < n; k++) { float p = w[k] * v[k * vstep]; a = a + p; } return a; }
+    if (mode == 2) { double a = 0.0; for (uint32_t k = 0; k < n; k++) a += (double)w[k] * (double)v[k * vstep]; return (float)a; }
+    float a = 0.f; for (uint32_t k = n; k-- > 0;) a = fmaf(w[k], v[k * vstep], a); return a;
+}
+
+static uint8_t var_encode(uint32_t flags, int linear, float v) {
+    if (!linear || !(flags & IFO_VAR_ENCODE_EXACT)) return float_to_srgb(linear, v);
+    double l = (double)v;
+    if (!(l == l) || l <= 0.0) return 0;
+    if (l >= 1.0) return 255;
+    double s = l <= 0.0031308 ? 12.92 * l : 1.055 * pow(l, 1.0 / 2.4) - 0.055;
+    double e = s * 255.0 + 0.5;
+    return (uint8_t)(e < 0.0 ? 0.0 : (e > 255.0 ? 255.0 : e));
+}
+
+int ifo_scale_and_render_variant(const uint8_t* in, uint32_t in_w, uint32_t in_h, uint32_t in_stride,
+                                 int alpha_meaningful, uint8_t* canvas, uint32_t c_stride, uint32_t w, uint32_t h,
+                                 int filter, float sharpen, int working_space, uint32_t flags) {
+    ifo_init_tables();
+    int linear = working_space == 1 && !(flags & IFO_VAR_SRGB_SPACE);
+    uint32_t mode = (flags & IFO_VAR_ACC_MASK) >> 1;
+    ifo_plan P;
+    int rc = make_plan(&P, in_w, in_h, w, h, filter, sharpen);
+    if (rc) return rc;
+    float lut[256];
+    for (int i = 0; i < 256; i++) {
+        lut[i] = linear ? g_s2l[i] : g_s2f[i];
+        if (linear && (flags & IFO_VAR_S2L_F64)) {
+            double s = (double)i / 255.0;
+            lut[i] = (float)(s <= 0.04045 ? s / 12.92 : pow((s + 0.055) / 1.055, 2.4));
+        }
+    }
+    size_t npx = (size_t)in_w * in_h;
+    float* src = (float*)malloc(sizeof(float) * 4 * npx);
+    size_t mid_w = (flags & IFO_VAR_HFIRST) ? w : in_w, mid_h = (flags & IFO_VAR_HFIRST) ? in_h : h;
+    float* mid = (float*)malloc(sizeof(float) * 4 * mid_w * mid_h);
+    float* out = (float*)malloc(sizeof(float) * 4 * (size_t)w * h);
+    if (!src || !mid || !out) { free(src); free(mid); free(out); ifo_weights_free(&P.wv); ifo_weights_free(&P.wh); return IFO_ERR_ALLOC; }
+    for (uint32_t y = 0; y < in_h; y++) {
+        const uint8_t* row = in + (size_t)y * in_stride;
+        float* d = src + (size_t)y * in_w * 4;
+        if (alpha_meaningful && (flags & IFO_VAR_NO_PREMUL)) {
+            for (uint32_t x = 0; x < in_w; x++) {
+                d[4 * x] = lut[row[4 * x]]; d[4 * x + 1] = lut[row[4 * x + 1]]; d[4 * x + 2] = lut[row[4 * x + 2]];
+                d[4 * x + 3] = (float)row[4 * x + 3] * (1.0f / 255.0f);
+            }
+        } else row_to_float(row, in_w, alpha_meaningful, lut, d);
+    }
+    if (flags & IFO_VAR_HFIRST) {
+        for (uint32_t y = 0; y < in_h; y++)
+            for (uint32_t u = 0; u < w; u++)
+                for (int c = 0; c < 4; c++)
+                    mid[((size_t)y * w + u) * 4 + c] = var_acc(mode, P.wh.w + P.wh.offset[u],
+                        src + ((size_t)y * in_w + P.wh.left[u]) * 4 + c, 4, P.wh.count[u]);
+        for (uint32_t j = 0; j < h; j++)
+            for (uint32_t u = 0; u < w; u++)
+                for (int c = 0; c < 4; c++)
+                    out[((size_t)j * w + u) * 4 + c] = var_acc(mode, P.wv.w + P.wv.offset[j],
+                        mid + ((size_t)P.wv.left[j] * w + u) * 4 + c, (size_t)w * 4, P.wv.count[j]);
+    } else {
+        for (uint32_t j = 0; j < h; j++)
+            for (uint32_t x = 0; x < in_w; x++)
+                for (int c = 0; c < 4; c++)
+                    mid[((size_t)j * in_w + x) * 4 + c] = var_acc(mode, P.wv.w + P.wv.offset[j],
+                        src + ((size_t)P.wv.left[j] * in_w + x) * 4 + c, (size_t)in_w * 4, P.wv.count[j]);
+        for (uint32_t j = 0; j < h; j++)
+            for (uint32_t u = 0; u < w; u++)
+                for (int c = 0; c < 4; c++)
+                    out[((size_t)j * w + u) * 4 + c] = var_acc(mode, P.wh.w + P.wh.offset[u],
+                        mid + ((size_t)j * in_w + P.wh.left[u]) * 4 + c, 4, P.wh.count[u]);
+    }
+    for (uint32_t j = 0; j < h; j++) {
+        uint8_t* cp = canvas + (size_t)j * c_stride;
+        const float* sp = out + (size_t)j * w * 4;
+        for (uint32_t u = 0; u < w; u++, cp += 4, sp += 4) {
+            if (!alpha_meaningful) {
+                cp[0] = var_encode(flags, linear, sp[0]); cp[1] = var_encode(flags, linear, sp[1]);
+                cp[2] = var_encode(flags, linear, sp[2]); cp[3] = 255;
+                continue;
+            }
+            float a = sp[3], c0 = 0.f, c1 = 0.f, c2 = 0.f;
+            if (flags & IFO_VAR_NO_PREMUL) { c0 = sp[0]; c1 = sp[1]; c2 = sp[2]; }
+            else if (a > 0.0f) {
+                if (flags & IFO_VAR_UNPREMUL_RCP) { float r = 1.0f / a; c0 = sp[0] * r; c1 = sp[1] * r; c2 = sp[2] * r; }
+                else { c0 = sp[0] / a; c1 = sp[1] / a; c2 = sp[2] / a; }
+            }
+            cp[0] = var_encode(flags, linear, c0); cp[1] = var_encode(flags, linear, c1); cp[2] = var_encode(flags, linear, c2);
+            if (flags & IFO_VAR_ALPHA_RNE) {
+                float t = a * 255.0f;
+                t = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);
+                cp[3] = (uint8_t)lrintf(t);
+            } else cp[3] = ifo_uchar_clamp_ff(a * 255.0f);
+        }
+    }
+    free(src); free(mid); free(out);
+    ifo_weights_free(&P.wv); ifo_weights_free(&P.wh);
+    return IFO_OK;
+}
+
 /* Batch over independent images, one image per OpenMP thread (the CPU baseline leg). */
 int ifo_scale_and_render_batch(const uint8_t* in, size_t in_image_bytes, uint32_t n_images,
                                uint32_t in_w, uint32_t in_h, uint32_t in_stride, int in_alpha_meaningful,
