@@ -1,90 +1,107 @@
 #!/usr/bin/env python3
 """bench.py -- megapixels/s of the resample hot path (BASELINE.json metric) on N MI355X of one node.
 
-Workload (config.workload): BASELINE config 2 -- a batch of 256 synthetic 3840x2160 BGRA8 frames per GPU, device
-resident, each resized to 200x200 with Robidoux in linear light (ReplaceSelf canvas, alpha not meaningful, as after
-a JPEG decode).  One "step" = one pass of the fused kernel over the rank's whole batch.  Weak scaling: every rank owns
-its own 256 frames (independent images: no data-path collective); for N > 1 the 200x200 outputs of each step are
-gathered to rank 0 over RCCL (one direct xGMI transfer per peer), asynchronously, overlapped with the next step.
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--workload ...]
+
+Default workload (config.workload): BASELINE config 2 -- a batch of 256 synthetic 3840x2160 BGRA8 frames per GPU, device
+resident, each resized to 200x200 with Robidoux in linear light (ReplaceSelf canvas, alpha not meaningful, as after a
+JPEG decode).  One "step" = one pass of the hot path over the rank's whole batch.
+
+Multi-GPU: images are independent, so frame i of a job belongs to rank floor(i * N / total)
+(imageflow_amd/sharding.py) and nothing is exchanged on the data path; the job's only collective is the RCCL gather of
+the finished outputs to rank 0, issued once inside the timed region.
+  --scaling weak   (default) every rank owns --frames frames (256): per-GPU work fixed.
+  --scaling strong the job is --total-frames frames (1024, the north_star batch) cut into N contiguous blocks.
+`--gpus N` with no torch.distributed environment re-executes this file under `python -m torch.distributed.run` with N
+ranks; under a launcher, WORLD_SIZE must equal --gpus (anything else is an error, never a silent 1-GPU run).
+
+--workload cfg3 is BASELINE config 3 as a job: the export_4_sizes pyramid 3840x2160 -> 1600x900 -> {1200x675 -> 400x225,
+800x450} (imageflow_tool/src/self_test.rs:185-198), four chained launches per batch, 58 737 600 algorithmic bytes per
+image, 128 frames per GPU by default (1024 images over 8 GPUs).
 
 Prints ONE JSON line (rank 0).  value = source megapixels resized per second over all ranks, inputs already in HBM.
 """
 import argparse
 import json
 import os
+import shutil
+import socket
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-IN_W, IN_H, OUT_W, OUT_H = 3840, 2160, 200, 200
 FRAMES_PER_GPU = 256
-ALGO_BYTES_PER_FRAME = IN_W * IN_H * 4 + OUT_W * OUT_H * 4        # 33,337,600 B
 HBM_PEAK = 8.0e12                                                   # MI355X_MICROARCH.md: 8 TB/s spec
 
-# Other BASELINE shapes, selectable with --workload (parity cases; the headline line stays cfg2)
+# name: (in_w, in_h, out_w, out_h, filter, sharpen, alpha_meaningful, compositing, matte, default frames per GPU)
 WORKLOADS = {
-    # name: (in_w, in_h, out_w, out_h, filter, sharpen, alpha_meaningful, compositing, matte, default frames)
     "cfg2": (3840, 2160, 200, 200, "Robidoux", 0.0, False, "ReplaceSelf", 0, 256),
     "cfg2-alpha": (3840, 2160, 200, 200, "Robidoux", 0.0, True, "ReplaceSelf", 0, 256),
     "cfg5": (7680, 4320, 400, 225, "Lanczos", 15.0, True, "BlendWithMatte", 0xFFFFFFFF, 64),
     "cfg3-l0": (3840, 2160, 1600, 900, "Robidoux", 0.0, False, "ReplaceSelf", 0, 256),
-    # the remaining levels of the export_4_sizes pyramid (self_test.rs:185-198) and the cfg4 / cfg1 resizes
     "cfg3-l1": (1600, 900, 1200, 675, "Robidoux", 0.0, False, "ReplaceSelf", 0, 1024),
     "cfg3-l2": (1600, 900, 800, 450, "Robidoux", 0.0, False, "ReplaceSelf", 0, 1024),
     "cfg3-l3": (1200, 675, 400, 225, "Robidoux", 0.0, False, "ReplaceSelf", 0, 1024),
     "cfg4-resize": (1920, 1080, 800, 450, "Robidoux", 0.0, False, "ReplaceSelf", 0, 1024),
     "cfg1-resize": (480, 270, 200, 113, "Robidoux", 0.0, False, "ReplaceSelf", 0, 4096),
+    # the whole export_4_sizes job: the tuple describes level 0, PYRAMID the chain
+    "cfg3": (3840, 2160, 1600, 900, "Robidoux", 0.0, False, "ReplaceSelf", 0, 128),
 }
+PYRAMID = [("src", "1600", 1600, 900), ("1600", "1200", 1200, 675), ("1600", "800", 800, 450), ("1200", "400", 400, 225)]
+PYRAMID_BYTES_PER_IMAGE = 58_737_600
 
 
-def make_frames(torch, n, rank, device, pattern):
+def make_frames(torch, n, first_index, seed, device, pattern, in_w, in_h):
     """frame k pixel (x,y): B=(x+k)&255, G=(y+k)&255, R=(x+y+k)&255, A=255 (bench_graphics.rs:403-414 + offset);
     the random half is uniform bytes (worst case for LUT bank conflicts and rounding)."""
     from imageflow_amd.graphics.bitmaps import Bitmap, get_stride
-    stride = get_stride(IN_W)
-    data = torch.empty((n, IN_H, stride), dtype=torch.uint8, device=device)
-    x = torch.arange(IN_W, device=device, dtype=torch.int32)[None, :]
-    y = torch.arange(IN_H, device=device, dtype=torch.int32)[:, None]
+    stride = get_stride(in_w)
+    data = torch.empty((n, in_h, stride), dtype=torch.uint8, device=device)
+    x = torch.arange(in_w, device=device, dtype=torch.int32)[None, :]
+    y = torch.arange(in_h, device=device, dtype=torch.int32)[:, None]
     gen = torch.Generator(device=device)
-    gen.manual_seed(1000 + rank)
+    gen.manual_seed(1000 + seed)
     for i in range(n):
-        k = rank * n + i
+        k = first_index + i
         use_random = pattern == "random" or (pattern == "mixed" and i >= n // 2)
         if use_random:
-            data[i] = torch.randint(0, 256, (IN_H, stride), dtype=torch.uint8, device=device, generator=gen)
+            data[i] = torch.randint(0, 256, (in_h, stride), dtype=torch.uint8, device=device, generator=gen)
             data[i, :, 3::4] = 255
         else:
-            px = data[i, :, : IN_W * 4].view(IN_H, IN_W, 4)
+            px = data[i, :, : in_w * 4].view(in_h, in_w, 4)
             px[..., 0] = ((x + k) & 255).to(torch.uint8)
-            px[..., 1] = ((y + k) & 255).to(torch.uint8).expand(IN_H, IN_W)
+            px[..., 1] = ((y + k) & 255).to(torch.uint8).expand(in_h, in_w)
             px[..., 2] = ((x + y + k) & 255).to(torch.uint8)
             px[..., 3] = 255
-    return Bitmap(data.view(n, IN_H * stride), IN_W, IN_H, stride, alpha_meaningful=False)
+    return Bitmap(data.view(n, in_h * stride), in_w, in_h, stride, alpha_meaningful=False)
 
 
 def cpu_baseline(sample_seconds=15.0):
-    """The oracle (our C port of the reference's CPU path; the Rust reference cannot be built here) timed on the
-    host cores on a bounded sample of the same workload."""
+    """The oracle (our C port of the reference's CPU path) timed on the host cores on a bounded sample of cfg2.  The
+    Rust reference itself (cargo bench -p imageflow_core --bench bench_graphics -- full_scale_pipeline,
+    benches/bench_graphics.rs:382-456) needs a Rust toolchain AND the reference tree; both are probed and reported."""
     import numpy as np
     from oracle import oracle as O
     from tests import util as U
+    in_w, in_h, out_w, out_h = 3840, 2160, 200, 200
     cores = os.cpu_count() or 1
-    fr = U.gradient_frames(1, IN_W, IN_H)
-    cst = U.stride_for(OUT_W)
-    can = np.zeros((1, OUT_H, cst), np.uint8)
+    fr = U.gradient_frames(1, in_w, in_h)
+    cst = U.stride_for(out_w)
+    can = np.zeros((1, out_h, cst), np.uint8)
     t0 = time.perf_counter()
-    O.scale_and_render_batch(fr.reshape(1, -1), can.reshape(1, -1), IN_W, IN_H, fr.shape[2], OUT_W, OUT_H, cst,
-                             0, 0, OUT_W, OUT_H, n_threads=1)
+    O.scale_and_render_batch(fr.reshape(1, -1), can.reshape(1, -1), in_w, in_h, fr.shape[2], out_w, out_h, cst,
+                             0, 0, out_w, out_h, n_threads=1)
     t1 = time.perf_counter() - t0
     n = min(4 * cores, 96)
-    frames = np.concatenate([U.gradient_frames(n // 2, IN_W, IN_H), U.random_frames(n - n // 2, IN_W, IN_H, alpha=False)])
-    cans = np.zeros((n, OUT_H * cst), np.uint8)
+    frames = np.concatenate([U.gradient_frames(n // 2, in_w, in_h), U.random_frames(n - n // 2, in_w, in_h, alpha=False)])
+    cans = np.zeros((n, out_h * cst), np.uint8)
     flat = frames.reshape(n, -1)
+
     def one_pass():
         t0 = time.perf_counter()
-        rc = O.scale_and_render_batch(flat, cans, IN_W, IN_H, frames.shape[2], OUT_W, OUT_H, cst, 0, 0, OUT_W, OUT_H,
+        rc = O.scale_and_render_batch(flat, cans, in_w, in_h, frames.shape[2], out_w, out_h, cst, 0, 0, out_w, out_h,
                                       n_threads=cores)
         assert rc == 0
         return time.perf_counter() - t0
@@ -94,20 +111,58 @@ def cpu_baseline(sample_seconds=15.0):
     for _ in range(reps):
         one_pass()
     total = time.perf_counter() - t0
-    mp = reps * n * IN_W * IN_H / 1e6
+    mp = reps * n * in_w * in_h / 1e6
+    cargo = shutil.which("cargo")
+    ref_tree = os.path.isdir("/root/reference/imageflow_core")
     return {"value": round(mp / total, 2), "unit": "MP/s", "cores": cores, "kind": "port",
-            "single_thread_MPps": round(IN_W * IN_H / 1e6 / t1, 2),
+            "single_thread_MPps": round(in_w * in_h / 1e6 / t1, 2),
             "sample": f"{reps} passes over {n} frames 3840x2160->200x200 Robidoux linear (half gradient, half random), "
-                      f"{total:.1f} s wall, oracle/if_oracle.c -O3 x86-64-v3, {cores} OpenMP threads (one frame per thread)"}
+                      f"{total:.1f} s wall, oracle/if_oracle.c -O3 x86-64-v3, {cores} OpenMP threads (one frame per thread)",
+            "reference_leg": ("cargo present but the reference tree is not on this box" if cargo and not ref_tree else
+                              "not run: no Rust toolchain on this box (cargo not found)" if not cargo else
+                              "cargo and tree present: run `cargo bench -p imageflow_core --bench bench_graphics -- full_scale_pipeline` by hand")}
 
 
-def main():
+def host_dropin_rate(torch, seconds=3.0):
+    """ifhip_scale_and_render -- the symbol graphics/scaling.rs would bind: host buffers in,
+    host buffers out, PCIe both ways.  One 4K frame -> 200x200 per call, calls back to back from one thread."""
+    import numpy as np
+    from imageflow_amd.graphics.bitmaps import get_stride
+    from imageflow_amd.graphics.scaling import ScaleAndRenderParams, scale_and_render_host
+    in_w, in_h, out_w, out_h = 3840, 2160, 200, 200
+    st, cst = get_stride(in_w), get_stride(out_w)
+    frame = np.random.default_rng(5).integers(0, 256, (in_h, st), dtype=np.uint8)
+    can = np.zeros((out_h, cst), np.uint8)
+    info = ScaleAndRenderParams(0, 0, out_w, out_h)
+    for _ in range(3):
+        scale_and_render_host(frame, in_w, in_h, st, False, can, out_w, out_h, cst, info)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        scale_and_render_host(frame, in_w, in_h, st, False, can, out_w, out_h, cst, info)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"images_per_s": round(n / dt, 1), "MPps": round(n * in_w * in_h / 1e6 / dt, 1), "ms_per_call": round(dt / n * 1e3, 3),
+            "what": "ifhip_scale_and_render, one 3840x2160 frame -> 200x200 per call, pageable host buffers, one thread, "
+                    "PCIe inclusive (persistent pinned staging + per-thread stream); never `value`"}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)     # 0.3 s of GPU time: long enough that the clock ramp after the
     # idle barrier (the first ~20 launches run 3-5 % slower) does not colour the average
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU (default 256 = BASELINE config 2)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--frames", type=int, default=None, help="weak scaling: frames per GPU (default: the workload's, 256 for cfg2)")
+    ap.add_argument("--total-frames", type=int, default=1024, help="strong scaling: frames of the whole job")
     ap.add_argument("--pattern", default="mixed", choices=["mixed", "gradient", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", default="final", choices=["final", "every", "none"],
@@ -116,13 +171,28 @@ def main():
                          "buffered against the next step; none: results stay sharded")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    args = ap.parse_args()
-    global IN_W, IN_H, OUT_W, OUT_H, ALGO_BYTES_PER_FRAME
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: become one.  One process per GPU under torch.distributed.run, rendezvous on 127.0.0.1.
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to "
+                         f"measure a different job than the one asked for")
+
     wl = WORKLOADS[args.workload]
-    IN_W, IN_H, OUT_W, OUT_H = wl[0], wl[1], wl[2], wl[3]
-    ALGO_BYTES_PER_FRAME = IN_W * IN_H * 4 + OUT_W * OUT_H * 4
-    if args.workload != "cfg2" and args.frames == FRAMES_PER_GPU:
-        args.frames = wl[9]
+    in_w, in_h, out_w, out_h = wl[0], wl[1], wl[2], wl[3]
+    pyramid = args.workload == "cfg3"
 
     import torch
     import torch.distributed as dist
@@ -130,10 +200,8 @@ def main():
     from imageflow_amd.graphics.bitmaps import Bitmap, BitmapCompositing
     from imageflow_amd.graphics.scaling import ScaleAndRenderParams, plan_for, scale_and_render, time_scale_and_render
     from imageflow_amd.graphics.weights import Filter
+    from imageflow_amd.sharding import gather_to_root, max_over_ranks, shard_range
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: imageflow_amd has no CPU path")
     # IFHIP_BENCH_DRYRUN_ONE_GPU=1: development aid -- run N ranks on ONE GPU over gloo to exercise the multi-rank control
@@ -141,6 +209,8 @@ def main():
     dryrun = os.environ.get("IFHIP_BENCH_DRYRUN_ONE_GPU") == "1"
     if dryrun:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
@@ -151,33 +221,65 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    n = args.frames
-    inp = make_frames(torch, n, rank, dev, args.pattern)
+    # this rank's block of the job
+    if args.scaling == "strong":
+        total = args.total_frames
+        lo, hi = shard_range(total, rank, world)
+    else:
+        per = args.frames or wl[9]
+        total = per * world
+        lo, hi = rank * per, (rank + 1) * per
+    n = hi - lo
+    if n < 1:
+        raise SystemExit(f"rank {rank} owns no frames ({total} frames over {world} ranks)")
+    n_max = -(-total // world)                           # gather slots are sized by the largest block
+
+    inp = make_frames(torch, n, lo, rank, dev, args.pattern, in_w, in_h)
     inp.alpha_meaningful = wl[6]
     if wl[6]:
-        inp.data.view(n, IN_H, -1)[:, :, 3::4] = torch.randint(0, 256, (n, IN_H, inp.stride // 4), dtype=torch.uint8, device=dev)
-    canv = [Bitmap.create_u8(n, OUT_W, OUT_H, dev, compose=BitmapCompositing[wl[7]], matte=wl[8]) for _ in range(2)]
-    info = ScaleAndRenderParams(0, 0, OUT_W, OUT_H, wl[5], Filter[wl[4]])
-    plan = plan_for(IN_W, IN_H, OUT_W, OUT_H, info.interpolation_filter, wl[5], dev)
+        inp.data.view(n, in_h, -1)[:, :, 3::4] = torch.randint(0, 256, (n, in_h, inp.stride // 4), dtype=torch.uint8, device=dev)
+    if pyramid:
+        sizes = {name: (w, h) for _, name, w, h in PYRAMID}
+        levels = {name: Bitmap.create_u8(n_max, w, h, dev) for name, (w, h) in sizes.items()}
+        for b in levels.values():
+            b.data = b.data[:n]
+        chain = []
+        for a, b, w, h in PYRAMID:
+            s = inp if a == "src" else levels[a]
+            chain.append((s, levels[b], ScaleAndRenderParams(0, 0, w, h), plan_for(s.w, s.h, w, h, Filter.Robidoux, 0.0, dev)))
+        out_bytes_per_frame = sum(b.image_bytes for b in levels.values())
+        packed = torch.empty((n_max, out_bytes_per_frame), dtype=torch.uint8, device=dev)     # the four outputs of a frame, side by side
+        canv = None
+    else:
+        canv = [Bitmap.create_u8(n_max, out_w, out_h, dev, compose=BitmapCompositing[wl[7]], matte=wl[8]) for _ in range(2)]
+        views = [Bitmap(c.data[:n], c.w, c.h, c.stride, c.alpha_meaningful, c.compose, c.matte) for c in canv]
+        info = ScaleAndRenderParams(0, 0, out_w, out_h, wl[5], Filter[wl[4]])
+        plan = plan_for(in_w, in_h, out_w, out_h, info.interpolation_filter, wl[5], dev)
+        out_bytes_per_frame = canv[0].image_bytes
     mode = "none" if (not distributed or args.no_gather or os.environ.get("IFHIP_BENCH_GATHER", "1") == "0") else args.gather
-    gather = mode == "every"
+    if pyramid and mode == "every":
+        raise SystemExit("--workload cfg3 gathers once per job: use --gather final or none")
     if dryrun and mode == "every":  # gloo cannot gather device tensors; the dry run only walks the final gather (via the host)
         raise SystemExit("dry run: pass --gather final or none")
-    from imageflow_amd.sharding import gather_to_root, max_over_ranks
-    gathered = [torch.empty((world,) + tuple(c.data.shape), dtype=torch.uint8, device="cpu" if dryrun else dev) if rank == 0 else None
-                for c in canv] if mode != "none" else None
+    gathered = None
+    if mode != "none" and rank == 0:
+        gathered = [torch.empty((world, n_max, out_bytes_per_frame), dtype=torch.uint8, device="cpu" if dryrun else dev)
+                    for _ in range(2 if mode == "every" else 1)]
     gather_note = {"none": "none",
                    "every": "rccl gather of the outputs to rank 0 every step, asynchronous, double buffered",
                    "final": "rccl gather of the outputs to rank 0 once, at the end of the timed region"}[mode]
 
     def step(i, pending):
-        c = canv[i & 1]
-        if gather and pending[i & 1] is not None:
+        if pyramid:
+            for s, d, inf, pl in chain:
+                scale_and_render(s, d, inf, plan=pl)
+            return
+        if mode == "every" and pending[i & 1] is not None:
             pending[i & 1].wait()                  # the buffer we are about to overwrite has been gathered
             pending[i & 1] = None
-        scale_and_render(inp, c, info, plan=plan)
-        if gather:
-            pending[i & 1], _ = gather_to_root(c.data, 0, async_op=True, out=gathered[i & 1])
+        scale_and_render(inp, views[i & 1], info, plan=plan)
+        if mode == "every":
+            pending[i & 1], _ = gather_to_root(canv[i & 1].data, 0, async_op=True, out=gathered[i & 1] if rank == 0 else None)
 
     def sync_all(pending):
         for k in range(2):
@@ -185,6 +287,15 @@ def main():
                 pending[k].wait()
                 pending[k] = None
         torch.cuda.synchronize()
+
+    def final_payload():
+        if not pyramid:
+            return canv[(args.steps - 1) & 1].data
+        off = 0
+        for b in levels.values():                                  # device-side packing: one message per rank
+            packed[:n, off:off + b.image_bytes] = b.data
+            off += b.image_bytes
+        return packed
 
     pending = [None, None]
     for i in range(args.warmup):
@@ -202,8 +313,8 @@ def main():
         # resample kernel would take CUs from a grid that is exactly one workgroup per CU, so the job's one exchange
         # happens after the last batch; a failure here is reported, it does not cost the measurement.
         try:
-            last = canv[(args.steps - 1) & 1].data
-            gather_to_root(last.cpu() if dryrun else last, 0, async_op=False, out=gathered[0])
+            last = final_payload()
+            gather_to_root(last.cpu() if dryrun else last, 0, async_op=False, out=gathered[0] if rank == 0 else None)
         except Exception as e:  # noqa: BLE001
             gather_note = f"final rccl gather failed: {type(e).__name__}: {e}"
     if distributed:
@@ -213,45 +324,57 @@ def main():
     elapsed = max_over_ranks(elapsed, dev)
 
     # dominant-kernel duration: hipEvents on the launch stream around back-to-back launches of the same op
-    kernel_ms = time_scale_and_render(inp, canv[0], info, launches=max(5, min(args.steps, 50)), plan=plan)
+    launches = max(5, min(args.steps, 50))
+    if pyramid:
+        level_ms = [time_scale_and_render(s, d, inf, launches=launches, plan=pl) for s, d, inf, pl in chain]
+        kernel_ms = sum(level_ms)
+        algo_bytes = n * PYRAMID_BYTES_PER_IMAGE
+        kernel_name = "fused_resample_kernel x4 (levels %s ms)" % "/".join(f"{m:.3f}" for m in level_ms)
+    else:
+        kernel_ms = time_scale_and_render(inp, views[0], info, launches=launches, plan=plan)
+        algo_bytes = n * (in_w * in_h * 4 + out_w * out_h * 4)
+        kernel_name = "fused_resample_kernel" if plan.kernel_kind(wl[6]) == 0 else "generic"
     torch.cuda.synchronize()
 
     if rank == 0:
-        mp_per_step = world * n * IN_W * IN_H / 1e6
+        mp_per_step = total * in_w * in_h / 1e6
         value = mp_per_step * args.steps / elapsed
-        algo_bytes = n * ALGO_BYTES_PER_FRAME
         achieved = algo_bytes / (kernel_ms * 1e-3)
-        traffic = None          # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/), if recorded
+        # HBM bytes per launch: NOT measured in this run -- the figure of the separate rocprofv3 --pmc passes kept under
+        # profiles/ (FETCH_SIZE / WRITE_SIZE with the guide's gfx950 corrections), quoted for the default job only
+        traffic, traffic_source = None, None
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", "traffic_cfg2.json")))
             if n == FRAMES_PER_GPU and args.workload == "cfg2":
                 traffic = t["traffic_bytes_per_launch"]
-        except Exception:
+                traffic_source = "static: profiles/traffic_cfg2.json (" + t.get("source", "rocprofv3 --pmc passes") + ")"
+        except Exception:  # noqa: BLE001
             pass
-        measured_copy = None    # same-process calibration: device-to-device memcpy of 2 GiB, read + write bytes per second
+        measured_read = None    # same-process yardstick: a read-only streaming kernel over 4 GiB (16-byte nt loads)
         try:
             import ctypes
             from imageflow_amd import _native
             bps = ctypes.c_double(0.0)
-            _native.check(_native.lib().ifhip_measure_copy_bandwidth(2 << 30, 5, ctypes.byref(bps)))
-            measured_copy = bps.value
+            _native.check(_native.lib().ifhip_measure_read_bandwidth(4 << 30, 5, ctypes.byref(bps)))
+            measured_read = bps.value
         except Exception:  # noqa: BLE001
             pass
+        shape = (f"{in_w}x{in_h} -> 1600x900 -> {{1200x675 -> 400x225, 800x450}} (export_4_sizes), four chained launches"
+                 if pyramid else f"{in_w}x{in_h} BGRA8 -> {out_w}x{out_h}")
         out = {
             "metric": "megapixels/sec resize (4K->200px Robidoux)", "value": round(value, 1), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE {args.workload}: {n} x {IN_W}x{IN_H} BGRA8 frames per GPU -> {OUT_W}x{OUT_H} {wl[4]}"
+            "config": {"workload": f"BASELINE {args.workload}: {total} frames ({n} on rank 0) {shape} {wl[4]}"
                                    f"{' sharpen ' + str(wl[5]) if wl[5] else ''}, linear light, {wl[7]}, "
                                    f"alpha {'meaningful' if wl[6] else 'not meaningful'}, device resident, pattern={args.pattern}",
-                       "frames_per_gpu": n, "kernel": "fused_resample_kernel" if plan.kernel_kind(wl[6]) == 0 else "generic",
-                       "gather": gather_note},
+                       "frames_per_gpu": n, "total_frames": total, "kernel": kernel_name, "gather": gather_note},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
-                         "measured_copy_GBps": round(measured_copy / 1e9, 1) if measured_copy else None,
-                         "frac_of_measured_copy": round(achieved / measured_copy, 4) if measured_copy else None},
+                         "measured_read_GBps": round(measured_read / 1e9, 1) if measured_read else None,
+                         "frac_of_measured_read": round(achieved / measured_read, 4) if measured_read else None},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
             try:
@@ -259,6 +382,10 @@ def main():
             except Exception as e:   # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "MP/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e}"}
+            try:
+                out["host_dropin"] = host_dropin_rate(torch)
+            except Exception as e:  # noqa: BLE001
+                out["host_dropin"] = {"images_per_s": None, "what": f"failed: {e}"}
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()

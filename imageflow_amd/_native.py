@@ -46,6 +46,7 @@ def lib():
     L.ifhip_scale_and_render_batch_device.argtypes = _batch + [C.c_void_p, C.c_int, C.c_void_p]
     L.ifhip_time_scale_and_render_batch_device.argtypes = _batch + [C.c_int, C.c_void_p, C.c_int, f32p]
     L.ifhip_measure_copy_bandwidth.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    L.ifhip_measure_read_bandwidth.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.ifhip_apply_matte.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
     L.ifhip_apply_matte_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  C.c_uint32, C.c_int, C.c_uint32, C.c_void_p]

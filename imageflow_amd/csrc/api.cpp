@@ -14,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 #include "common.hpp"
 #include "device.hpp"
@@ -23,12 +24,33 @@ hipError_t launch_fused(const ResampleArgs& a, int slots, bool alpha, bool per_p
                         size_t lds, hipStream_t st);
 hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, uint32_t img0, uint32_t n_img,
                           hipStream_t st);
+hipError_t launch_read_probe(const uint8_t* d, size_t bytes, uint32_t* sink, hipStream_t st);
 hipError_t launch_apply_matte(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w, uint32_t h,
                               uint32_t stride, uint32_t matte, float mb, float mg, float mr, float ma,
                               const float* s2l, const uint8_t* l2s, hipStream_t st);
 }  // namespace ifhip
 
 using namespace ifhip;
+
+namespace {
+// Scope guards: every early return of an entry point releases what it created.
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t create() {
+        hipError_t e = hipEventCreate(&e0);
+        return e != hipSuccess ? e : hipEventCreate(&e1);
+    }
+    ~EventPair() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+struct DeviceBuffer {
+    void* p = nullptr;
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    ~DeviceBuffer() { if (p) (void)hipFree(p); }
+};
+}  // namespace
 
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
@@ -205,7 +227,7 @@ int get_schedule(const ifhip_resample_plan* p, uint32_t n_bands, int group, int 
         int rc = upload(s.steps, &d.steps);
         if (rc) return rc;
         rc = upload(s.band_begin, &d.band_begin);
-        if (rc) return rc;
+        if (rc) { (void)hipFree(d.steps); return rc; }
         it = p->schedules.emplace(key, d).first;
     }
     *out = it->second;
@@ -564,21 +586,18 @@ int ifhip_time_scale_and_render_batch_device(const ifhip_resample_plan* plan, co
                                              float* avg_ms_per_launch) {
     if (launches < 1 || !avg_ms_per_launch) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: launches/avg pointer");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, st));
+    EventPair ev;
+    HIP_TRY(ev.create());
+    HIP_TRY(hipEventRecord(ev.e0, st));
     int rc = IFHIP_OK;
     for (int i = 0; i < launches && rc == IFHIP_OK; ++i)
         rc = enqueue_batch(plan, d_in, in_image_bytes, in_stride, in_alpha_meaningful, n_images, d_canvas,
                            canvas_image_bytes, canvas_w, canvas_h, canvas_stride, x, y, working_space, compositing,
                            matte_bgra, nullptr, force_kernel, st);
-    hipError_t er = hipEventRecord(e1, st);
-    if (er == hipSuccess) er = hipEventSynchronize(e1);
+    hipError_t er = hipEventRecord(ev.e1, st);
+    if (er == hipSuccess) er = hipEventSynchronize(ev.e1);
     float ms = 0.f;
-    if (er == hipSuccess) er = hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (er == hipSuccess) er = hipEventElapsedTime(&ms, ev.e0, ev.e1);
     if (rc) return rc;
     if (er != hipSuccess) return fail(IFHIP_GPU_ERROR, "GpuError: event timing failed: %s", hipGetErrorString(er));
     *avg_ms_per_launch = ms / static_cast<float>(launches);
@@ -590,23 +609,44 @@ int ifhip_measure_copy_bandwidth(size_t bytes, int iters, double* bytes_per_seco
     DeviceTables tb;
     int rc = device_tables(&tb);
     if (rc) return rc;
-    void *a = nullptr, *b = nullptr;
-    HIP_TRY(hipMalloc(&a, bytes));
-    HIP_TRY(hipMalloc(&b, bytes));
-    HIP_TRY(hipMemset(a, 1, bytes));
-    HIP_TRY(hipMemcpy(b, a, bytes, hipMemcpyDeviceToDevice));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < iters; ++i) HIP_TRY(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, nullptr));
-    HIP_TRY(hipEventRecord(e1, nullptr));
-    HIP_TRY(hipEventSynchronize(e1));
+    DeviceBuffer a, b;
+    HIP_TRY(a.alloc(bytes));
+    HIP_TRY(b.alloc(bytes));
+    HIP_TRY(hipMemset(a.p, 1, bytes));
+    HIP_TRY(hipMemcpy(b.p, a.p, bytes, hipMemcpyDeviceToDevice));
+    EventPair ev;
+    HIP_TRY(ev.create());
+    HIP_TRY(hipEventRecord(ev.e0, nullptr));
+    for (int i = 0; i < iters; ++i) HIP_TRY(hipMemcpyAsync(b.p, a.p, bytes, hipMemcpyDeviceToDevice, nullptr));
+    HIP_TRY(hipEventRecord(ev.e1, nullptr));
+    HIP_TRY(hipEventSynchronize(ev.e1));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(a); (void)hipFree(b);
+    HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
     *bytes_per_second = 2.0 * static_cast<double>(bytes) * iters / (static_cast<double>(ms) * 1e-3);
+    return IFHIP_OK;
+}
+
+int ifhip_measure_read_bandwidth(size_t bytes, int iters, double* bytes_per_second) {
+    if (!bytes_per_second || iters < 1 || bytes < (1u << 20)) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: read bandwidth probe");
+    DeviceTables tb;
+    int rc = device_tables(&tb);
+    if (rc) return rc;
+    bytes &= ~static_cast<size_t>(4095);
+    DeviceBuffer a, sink;
+    HIP_TRY(a.alloc(bytes));
+    HIP_TRY(sink.alloc(4096));
+    HIP_TRY(hipMemset(a.p, 1, bytes));
+    HIP_TRY(hipMemset(sink.p, 0, 4096));
+    HIP_TRY(launch_read_probe(static_cast<const uint8_t*>(a.p), bytes, static_cast<uint32_t*>(sink.p), nullptr));   // warm-up
+    EventPair ev;
+    HIP_TRY(ev.create());
+    HIP_TRY(hipEventRecord(ev.e0, nullptr));
+    for (int i = 0; i < iters; ++i) HIP_TRY(launch_read_probe(static_cast<const uint8_t*>(a.p), bytes, static_cast<uint32_t*>(sink.p), nullptr));
+    HIP_TRY(hipEventRecord(ev.e1, nullptr));
+    HIP_TRY(hipEventSynchronize(ev.e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+    *bytes_per_second = static_cast<double>(bytes) * iters / (static_cast<double>(ms) * 1e-3);
     return IFHIP_OK;
 }
 
@@ -620,8 +660,13 @@ struct PlanKey {
         return std::tie(device, in_w, in_h, w, h, filter, sharpen_bits) < std::tie(o.device, o.in_w, o.in_h, o.w, o.h, o.filter, o.sharpen_bits);
     }
 };
+struct PlanEntry {
+    std::shared_ptr<ifhip_resample_plan> plan;
+    uint64_t last_use = 0;
+};
 std::mutex g_plan_mu;
-std::map<PlanKey, std::shared_ptr<ifhip_resample_plan>> g_plan_cache;
+std::map<PlanKey, PlanEntry> g_plan_cache;
+uint64_t g_plan_clock = 0;
 constexpr size_t kPlanCacheMax = 64;
 
 int cached_plan(uint32_t in_w, uint32_t in_h, uint32_t w, uint32_t h, int filter, float sharpen,
@@ -635,17 +680,103 @@ int cached_plan(uint32_t in_w, uint32_t in_h, uint32_t w, uint32_t h, int filter
     {
         std::lock_guard<std::mutex> lk(g_plan_mu);
         auto it = g_plan_cache.find(key);
-        if (it != g_plan_cache.end()) { *out = it->second; return IFHIP_OK; }
+        if (it != g_plan_cache.end()) { it->second.last_use = ++g_plan_clock; *out = it->second.plan; return IFHIP_OK; }
     }
     ifhip_resample_plan* raw = nullptr;
     const int rc = ifhip_resample_plan_create(&raw, in_w, in_h, w, h, filter, sharpen);
     if (rc) return rc;
     std::shared_ptr<ifhip_resample_plan> sp(raw);
     std::lock_guard<std::mutex> lk(g_plan_mu);
-    if (g_plan_cache.size() >= kPlanCacheMax) g_plan_cache.erase(g_plan_cache.begin());   // bounded; eviction order is arbitrary
-    g_plan_cache[key] = sp;
+    if (g_plan_cache.size() >= kPlanCacheMax) {             // least recently used shape goes (callers still holding it keep it alive)
+        auto victim = g_plan_cache.begin();
+        for (auto it = g_plan_cache.begin(); it != g_plan_cache.end(); ++it)
+            if (it->second.last_use < victim->second.last_use) victim = it;
+        g_plan_cache.erase(victim);
+    }
+    g_plan_cache[key] = PlanEntry{sp, ++g_plan_clock};
     *out = sp;
     return IFHIP_OK;
+}
+
+// ---- staging of the host-buffer drop-ins -------------------------------------------------------------
+// imageflow runs "one Context per thread" (imageflow_abi/src/lib.rs:20-27), so every calling thread gets its own
+// HIP stream, pinned host staging and HBM staging, all grow-only and kept between calls: no hipMalloc / hipFree /
+// hipMemset on the call path, no null-stream serialisation between threads.  A thread's staging returns to a pool
+// when the thread ends (no HIP call at thread exit) and is adopted by the next new thread.
+struct HostStage {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint8_t *pin_in = nullptr, *pin_c = nullptr, *d_in = nullptr, *d_c = nullptr;
+    size_t pin_in_cap = 0, pin_c_cap = 0, d_in_cap = 0, d_c_cap = 0;
+};
+std::mutex g_stage_mu;
+std::vector<HostStage*> g_stage_pool;
+struct StageLease {
+    HostStage* s = nullptr;
+    ~StageLease() {
+        if (!s) return;
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        g_stage_pool.push_back(s);
+    }
+};
+thread_local StageLease t_stage;
+
+int grow_pinned(uint8_t** p, size_t* cap, size_t want) {
+    if (*cap >= want) return IFHIP_OK;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr; *cap = 0;
+    const size_t sz = (want + (want >> 2) + 4095u) & ~static_cast<size_t>(4095);
+    if (hipHostMalloc(reinterpret_cast<void**>(p), sz, hipHostMallocDefault) != hipSuccess)
+        return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: %zu bytes of pinned host staging", sz);
+    *cap = sz;
+    return IFHIP_OK;
+}
+int grow_device(uint8_t** p, size_t* cap, size_t want) {
+    if (*cap >= want) return IFHIP_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    const size_t sz = (want + (want >> 2) + 4095u) & ~static_cast<size_t>(4095);
+    if (hipMalloc(reinterpret_cast<void**>(p), sz) != hipSuccess)
+        return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: %zu bytes of HBM staging", sz);
+    *cap = sz;
+    return IFHIP_OK;
+}
+
+int host_stage(HostStage** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0)
+        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device (hipGetDevice failed); this library has no CPU path");
+    HostStage*& s = t_stage.s;
+    if (s && s->device != dev) {                       // the thread switched devices: hand the old staging back
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        g_stage_pool.push_back(s);
+        s = nullptr;
+    }
+    if (!s) {
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        for (size_t i = 0; i < g_stage_pool.size(); ++i)
+            if (g_stage_pool[i]->device == dev) { s = g_stage_pool[i]; g_stage_pool.erase(g_stage_pool.begin() + static_cast<long>(i)); break; }
+    }
+    if (!s) {
+        std::unique_ptr<HostStage> n(new HostStage);
+        n->device = dev;
+        HIP_TRY(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+        s = n.release();
+    }
+    *out = s;
+    return IFHIP_OK;
+}
+
+// Host -> HBM through the pinned buffer in chunks: the DMA of chunk k runs while the CPU copies chunk k+1.
+hipError_t upload_chunked(HostStage* s, uint8_t* d_dst, uint8_t* pinned, const uint8_t* src, size_t bytes) {
+    constexpr size_t kChunk = 4u << 20;
+    for (size_t off = 0; off < bytes; off += kChunk) {
+        const size_t n = std::min(kChunk, bytes - off);
+        std::memcpy(pinned + off, src + off, n);
+        const hipError_t e = hipMemcpyAsync(d_dst + off, pinned + off, n, hipMemcpyHostToDevice, s->stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 }  // namespace
 
@@ -663,30 +794,38 @@ int ifhip_scale_and_render(const uint8_t* in, uint32_t in_w, uint32_t in_h, uint
     rc = cached_plan(in_w, in_h, w, h, filter, sharpen_percent_goal, &plan_ref);
     if (rc) return rc;
     ifhip_resample_plan* plan = plan_ref.get();
+    HostStage* s = nullptr;
+    if ((rc = host_stage(&s))) return rc;
     // stage: source rows as given; only the canvas rows the rect touches
     const size_t in_bytes = (static_cast<size_t>(in_h) * in_stride + 15u) & ~static_cast<size_t>(15);
     const size_t in_valid = static_cast<size_t>(in_h - 1) * in_stride + static_cast<size_t>(in_w) * 4u;
-    const size_t c_rows_bytes = static_cast<size_t>(h) * canvas_stride;
+    const size_t c_rows_bytes = (static_cast<size_t>(h) * canvas_stride + 3u) & ~static_cast<size_t>(3);
     const size_t c_valid = static_cast<size_t>(h - 1) * canvas_stride + static_cast<size_t>(canvas_w) * 4u;
-    uint8_t *d_in = nullptr, *d_c = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_in), in_bytes + 64));
-    if (hipMalloc(reinterpret_cast<void**>(&d_c), c_rows_bytes + 64) != hipSuccess) {
-        (void)hipFree(d_in);
-        return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: %zu bytes of HBM for the canvas", c_rows_bytes);
-    }
-    hipError_t e = hipMemset(d_in, 0, in_bytes + 64);
-    if (e == hipSuccess) e = hipMemcpy(d_in, in, in_valid, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_c, canvas + static_cast<size_t>(y) * canvas_stride, c_valid, hipMemcpyHostToDevice);
+    if ((rc = grow_pinned(&s->pin_in, &s->pin_in_cap, in_valid)) || (rc = grow_pinned(&s->pin_c, &s->pin_c_cap, c_valid)) ||
+        (rc = grow_device(&s->d_in, &s->d_in_cap, in_bytes + 64)) || (rc = grow_device(&s->d_c, &s->d_c_cap, c_rows_bytes + 64)))
+        return rc;
+    uint8_t* crow0 = canvas + static_cast<size_t>(y) * canvas_stride;
+    hipError_t e = upload_chunked(s, s->d_in, s->pin_in, in, in_valid);
+    // the kernels read whole 16-byte groups up to the row stride: the tail of the last row gets defined bytes
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_in + in_valid, 0, in_bytes + 64 - in_valid, s->stream);
+    // the canvas rows travel to the device only when the call can leave some of their bytes untouched or reads them
+    const bool canvas_needed = compositing == IFHIP_BLEND_WITH_SELF || x != 0 || w != canvas_w;
+    if (e == hipSuccess && canvas_needed) e = upload_chunked(s, s->d_c, s->pin_c, crow0, c_valid);
     if (e == hipSuccess) {
-        rc = enqueue_batch(plan, d_in, in_bytes, in_stride, in_alpha_meaningful, 1, d_c, (c_rows_bytes + 3u) & ~static_cast<size_t>(3),
-                           canvas_w, h, canvas_stride, x, 0, working_space, compositing, matte_bgra, nullptr, -1, nullptr);
+        rc = enqueue_batch(plan, s->d_in, in_bytes, in_stride, in_alpha_meaningful, 1, s->d_c, c_rows_bytes,
+                           canvas_w, h, canvas_stride, x, 0, working_space, compositing, matte_bgra, nullptr, -1, s->stream);
         if (rc == IFHIP_OK) {
-            e = hipStreamSynchronize(nullptr);
-            if (e == hipSuccess) e = hipMemcpy(canvas + static_cast<size_t>(y) * canvas_stride, d_c, c_valid, hipMemcpyDeviceToHost);
-        }
-    }
-    (void)hipFree(d_in);
-    (void)hipFree(d_c);
+            e = hipMemcpyAsync(s->pin_c, s->d_c, c_valid, hipMemcpyDeviceToHost, s->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+            if (e == hipSuccess) {
+                if (canvas_needed) std::memcpy(crow0, s->pin_c, c_valid);
+                else                                      // whole rows were produced: leave the caller's row padding alone
+                    for (uint32_t j = 0; j < h; ++j)
+                        std::memcpy(crow0 + static_cast<size_t>(j) * canvas_stride, s->pin_c + static_cast<size_t>(j) * canvas_stride,
+                                    static_cast<size_t>(canvas_w) * 4u);
+            }
+        } else (void)hipStreamSynchronize(s->stream);
+    } else (void)hipStreamSynchronize(s->stream);
     if (rc) return rc;
     if (e != hipSuccess) return fail(IFHIP_GPU_ERROR, "GpuError: staging failed: %s", hipGetErrorString(e));
     return IFHIP_OK;
@@ -699,7 +838,6 @@ int ifhip_apply_matte_batch_device(uint8_t* d_bgra, size_t image_bytes, uint32_t
     if (!d_bgra) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null bitmap pointer");
     if (static_cast<uint64_t>(w) * 4u > stride || (stride & 3u) || (image_bytes & 3u) || (reinterpret_cast<uintptr_t>(d_bgra) & 3u))
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: BGRA rows must be 4-byte aligned and stride >= 4*w");
-    if (h > 65535u || n_images > 65535u) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: more than 65535 rows/images per launch");
     DeviceTables tb;
     int rc = device_tables(&tb);
     if (rc) return rc;
@@ -715,20 +853,23 @@ int ifhip_apply_matte(uint8_t* bgra, uint32_t w, uint32_t h, uint32_t stride, in
     if (!alpha_meaningful) return IFHIP_OK;
     if (w == 0 || h == 0) return IFHIP_OK;
     if (!bgra) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null bitmap pointer");
+    if (static_cast<uint64_t>(w) * 4u > stride || (stride & 3u))
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: BGRA rows must be 4-byte aligned and stride >= 4*w");
     const size_t valid = static_cast<size_t>(h - 1) * stride + static_cast<size_t>(w) * 4u;
-    const size_t bytes = (static_cast<size_t>(h) * stride + 3u) & ~static_cast<size_t>(3);
-    uint8_t* d = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), bytes));
-    hipError_t e = hipMemcpy(d, bgra, valid, hipMemcpyHostToDevice);
-    int rc = IFHIP_OK;
+    const size_t bytes = (static_cast<size_t>(h) * stride + 15u) & ~static_cast<size_t>(15);
+    HostStage* s = nullptr;
+    int rc = host_stage(&s);
+    if (rc) return rc;
+    if ((rc = grow_pinned(&s->pin_c, &s->pin_c_cap, valid)) || (rc = grow_device(&s->d_c, &s->d_c_cap, bytes + 64))) return rc;
+    hipError_t e = upload_chunked(s, s->d_c, s->pin_c, bgra, valid);
     if (e == hipSuccess) {
-        rc = ifhip_apply_matte_batch_device(d, bytes, 1, w, h, stride, 1, matte_bgra, nullptr);
+        rc = ifhip_apply_matte_batch_device(s->d_c, bytes, 1, w, h, stride, 1, matte_bgra, s->stream);
         if (rc == IFHIP_OK) {
-            e = hipStreamSynchronize(nullptr);
-            if (e == hipSuccess) e = hipMemcpy(bgra, d, valid, hipMemcpyDeviceToHost);
-        }
-    }
-    (void)hipFree(d);
+            e = hipMemcpyAsync(s->pin_c, s->d_c, valid, hipMemcpyDeviceToHost, s->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+            if (e == hipSuccess) std::memcpy(bgra, s->pin_c, valid);
+        } else (void)hipStreamSynchronize(s->stream);
+    } else (void)hipStreamSynchronize(s->stream);
     if (rc) return rc;
     if (e != hipSuccess) return fail(IFHIP_GPU_ERROR, "GpuError: staging failed: %s", hipGetErrorString(e));
     return IFHIP_OK;

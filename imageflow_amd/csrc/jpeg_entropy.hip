@@ -57,10 +57,11 @@ struct DerivedTab {                                  // one Huffman table, decod
     uint8_t val[256];
 };
 
+constexpr uint32_t kMaxBlocksInMcu = 10;        // libjpeg's D_MAX_BLOCKS_IN_MCU: files with more are rejected by the parser
 struct EntropyGeom {
     uint32_t ncomp, blocks_per_mcu, mcus_w, mcus_h;
     uint32_t bw[3], bh[3];
-    uint8_t kcomp[10], kdx[10], kdy[10];             // block k of an MCU: component and offset inside the MCU
+    uint8_t kcomp[kMaxBlocksInMcu], kdx[kMaxBlocksInMcu], kdy[kMaxBlocksInMcu];   // block k of an MCU: component and offset inside the MCU
     uint32_t kcomp_packed;                           // kcomp as 2-bit fields: the per-symbol lookup is a shift, not a load
     uint32_t hs[3], vs[3];
 };
@@ -508,6 +509,14 @@ int parse_jpeg(const uint8_t* d, size_t len, ParsedJpeg* out) {
     P.mcus_h = (P.height + 8 * vmax - 1) / (8 * vmax);
     P.blocks_per_mcu = 0;
     for (int c = 0; c < P.ncomp; ++c) { P.bw[c] = P.mcus_w * P.hs[c]; P.bh[c] = P.mcus_h * P.vs[c]; P.blocks_per_mcu += P.hs[c] * P.vs[c]; }
+    // The same whitelist as the pixel stage (make_geom): luma carries the maximum factors, chroma is 1x1 -- 4:4:4, 4:2:2,
+    // 4:4:0, 4:2:0.  That bounds an MCU at 6 blocks; libjpeg itself refuses more than D_MAX_BLOCKS_IN_MCU = 10
+    // (e.g. 2x2 / 2x2 / 2x2), and the per-MCU block tables of the decoder are sized by that constant.
+    if (P.ncomp == 3 && (P.hs[0] != hmax || P.vs[0] != vmax || P.hs[1] != 1 || P.vs[1] != 1 || P.hs[2] != 1 || P.vs[2] != 1))
+        return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: sampling %dx%d,%dx%d,%dx%d (chroma must be 1x1)",
+                    P.hs[0], P.vs[0], P.hs[1], P.vs[1], P.hs[2], P.vs[2]);
+    if (P.blocks_per_mcu > kMaxBlocksInMcu)
+        return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: %u blocks per MCU (limit %u)", P.blocks_per_mcu, kMaxBlocksInMcu);
     return IFHIP_OK;
 }
 
@@ -617,7 +626,7 @@ int ifhip_jpeg_parse_headers(const uint8_t* jpeg, size_t len, uint32_t* width, u
     return IFHIP_OK;
 }
 
-int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* files, const size_t* lengths, uint32_t n_images) {
+static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* files, const size_t* lengths, uint32_t n_images) {
     if (!out) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null out-pointer");
     *out = nullptr;
     if (!files || !lengths || n_images == 0) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: empty batch");
@@ -651,10 +660,22 @@ int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* fi
     std::vector<Prep> prep(n_images);
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(n_images, hw), 16u);
+    // Workers never let an exception escape (a bad_alloc on a huge scan becomes that file's error), and a thread that
+    // cannot be created (container thread limits) leaves its share of the files to the calling thread.
     auto run_parallel = [&](auto&& body) {
+        auto guarded = [&](uint32_t i) {
+            try { body(i); }
+            catch (const std::bad_alloc&) { prep[i].rc = IFHIP_ALLOCATION_FAILED; prep[i].message = "AllocationFailed: host memory while preparing the scan"; }
+            catch (const std::exception& ex) { prep[i].rc = IFHIP_INVALID_STATE; prep[i].message = std::string("InvalidState: ") + ex.what(); }
+        };
         std::vector<std::thread> pool;
-        for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back([&, t] { for (uint32_t i = t; i < n_images; i += n_threads) body(i); });
-        for (uint32_t i = 0; i < n_images; i += n_threads) body(i);
+        std::vector<uint32_t> inline_lanes{0u};
+        for (uint32_t t = 1; t < n_threads; ++t) {
+            try { pool.emplace_back([&, t] { for (uint32_t i = t; i < n_images; i += n_threads) guarded(i); }); }
+            catch (const std::exception&) { inline_lanes.push_back(t); }
+        }
+        for (uint32_t t : inline_lanes)
+            for (uint32_t i = t; i < n_images; i += n_threads) guarded(i);
         for (auto& th : pool) th.join();
     };
     run_parallel([&](uint32_t img) {
@@ -803,6 +824,18 @@ int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* fi
 }
 
 void ifhip_jpeg_entropy_destroy(ifhip_jpeg_entropy* e) { delete e; }
+
+int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* files, const size_t* lengths, uint32_t n_images) {
+    try {                                                   // nothing C++ crosses the C ABI
+        return entropy_create_impl(out, files, lengths, n_images);
+    } catch (const std::bad_alloc&) {
+        if (out) *out = nullptr;
+        return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: host memory while preparing the batch");
+    } catch (const std::exception& ex) {
+        if (out) *out = nullptr;
+        return fail(IFHIP_INVALID_STATE, "InvalidState: %s", ex.what());
+    }
+}
 
 int ifhip_jpeg_entropy_info(const ifhip_jpeg_entropy* e, uint32_t* width, uint32_t* height, int* n_components, uint8_t* h_samp3,
                             uint8_t* v_samp3, uint32_t* blocks_w3, uint32_t* blocks_h3, uint32_t* n_subsequences, uint32_t* n_segments) {

@@ -167,10 +167,51 @@ hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, ui
 hipError_t launch_apply_matte(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w, uint32_t h,
                               uint32_t stride, uint32_t matte, float mb, float mg, float mr, float ma,
                               const float* s2l, const uint8_t* l2s, hipStream_t st) {
-    MatteArgs m{d_bgra, image_bytes, w, h, stride, n_images, matte, mb, mg, mr, ma, s2l, l2s, 0u};
-    m.vec16 = ((reinterpret_cast<uintptr_t>(d_bgra) | image_bytes | stride) & 15u) == 0 ? 1u : 0u;
-    const dim3 block(kMatteLanes), grid(((w + 3u) / 4u + kMatteLanes - 1u) / kMatteLanes, (h + kMatteRows - 1u) / kMatteRows, n_images);
-    hipLaunchKernelGGL(apply_matte_kernel, grid, block, 0, st, m);
+    // grid.y / grid.z are 16-bit: tall bitmaps and big batches go out as several launches
+    const uint32_t rows_per_launch = 65535u * kMatteRows;
+    for (uint32_t i0 = 0; i0 < n_images; i0 += 65535u) {
+        const uint32_t n = min(65535u, n_images - i0);
+        for (uint32_t y0 = 0; y0 < h; y0 += rows_per_launch) {
+            const uint32_t hh = min(rows_per_launch, h - y0);
+            uint8_t* base = d_bgra + static_cast<size_t>(i0) * image_bytes + static_cast<size_t>(y0) * stride;
+            MatteArgs m{base, image_bytes, w, hh, stride, n, matte, mb, mg, mr, ma, s2l, l2s, 0u};
+            m.vec16 = ((reinterpret_cast<uintptr_t>(base) | image_bytes | stride) & 15u) == 0 ? 1u : 0u;
+            const dim3 block(kMatteLanes), grid(((w + 3u) / 4u + kMatteLanes - 1u) / kMatteLanes, (hh + kMatteRows - 1u) / kMatteRows, n);
+            hipLaunchKernelGGL(apply_matte_kernel, grid, block, 0, st, m);
+        }
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Read-only streaming probe: the yardstick for a kernel whose traffic is (almost) all reads.  Same access shape as
+// the resample kernel's source rows -- 16-byte non-temporal loads, consecutive lanes on consecutive 16-byte groups,
+// each workgroup walking its own contiguous span -- with one XOR per load as the only arithmetic.
+// ------------------------------------------------------------------------------------------------------
+typedef uint32_t probe_vec_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024) void read_probe_kernel(const probe_vec_t* __restrict__ src, size_t n_vec, uint32_t* sink) {
+    const size_t per_wg = (n_vec + gridDim.x - 1) / gridDim.x;
+    const size_t lo = per_wg * blockIdx.x;
+    size_t hi = lo + per_wg;
+    if (hi > n_vec) hi = n_vec;
+    uint32_t acc = 0;
+    size_t i = lo + threadIdx.x;
+    for (; i + 3u * 1024u < hi; i += 4u * 1024u) {
+        const probe_vec_t a = __builtin_nontemporal_load(src + i);
+        const probe_vec_t b = __builtin_nontemporal_load(src + i + 1024u);
+        const probe_vec_t c = __builtin_nontemporal_load(src + i + 2048u);
+        const probe_vec_t d = __builtin_nontemporal_load(src + i + 3072u);
+        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+    }
+    for (; i < hi; i += 1024u) {
+        const probe_vec_t a = __builtin_nontemporal_load(src + i);
+        acc ^= a.x ^ a.y ^ a.z ^ a.w;
+    }
+    if (acc == 0x9e3779b9u) sink[threadIdx.x] = acc;          // practically never true: keeps the loads alive
+}
+
+hipError_t launch_read_probe(const uint8_t* d, size_t bytes, uint32_t* sink, hipStream_t st) {
+    hipLaunchKernelGGL(read_probe_kernel, dim3(256u * 8u), dim3(1024), 0, st, reinterpret_cast<const probe_vec_t*>(d), bytes / 16u, sink);
     return hipGetLastError();
 }
 

@@ -74,4 +74,16 @@ class Bitmap:
         return Bitmap(t, w, h, stride, **kw)
 
     def to_numpy(self):
-        return self.data.cpu().numpy().reshape(self.n, self.h, self.stride)
+        """uint8 [n][h][stride].  A cropped window (flow/nodes crop) holds (h-1)*stride + 4*w bytes per frame: its last
+        row is returned zero-padded to the stride."""
+        flat = self.data.cpu().numpy()
+        want = self.h * self.stride
+        if flat.shape[1] == want:
+            return flat.reshape(self.n, self.h, self.stride)
+        import numpy as np
+        if flat.shape[1] > want or flat.shape[1] < (self.h - 1) * self.stride + 4 * self.w:
+            raise FlowError(ErrorKind.InvalidState, f"bitmap window holds {flat.shape[1]} bytes per frame, {self.w}x{self.h} "
+                                                    f"at stride {self.stride} needs {want}")
+        out = np.zeros((self.n, want), np.uint8)
+        out[:, :flat.shape[1]] = flat
+        return out.reshape(self.n, self.h, self.stride)

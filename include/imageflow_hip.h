@@ -307,6 +307,9 @@ IFHIP_API int ifhip_time_scale_and_render_batch_device(const ifhip_resample_plan
                                                        float* avg_ms_per_launch);
 /* device-to-device copy bandwidth probe (bytes read + bytes written per second), for the "measured roofline" note */
 IFHIP_API int ifhip_measure_copy_bandwidth(size_t bytes, int iters, double* bytes_per_second);
+/* read-only streaming probe (bytes read per second; 16-byte non-temporal loads, one XOR per load): the yardstick for
+ * the resample kernel, whose traffic is 99.5 % reads */
+IFHIP_API int ifhip_measure_read_bandwidth(size_t bytes, int iters, double* bytes_per_second);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,83 @@
+"""The N > 1 path with the HIP kernel under a process group: 2 and 3 ranks on the test box's one GPU, each
+rendering its shard_range block with the fused kernel, outputs gathered to rank 0, compared with the single-process HIP
+result and with the oracle.  Plus bench.py's own launcher: `--gpus 2` with no torch.distributed environment must start
+2 ranks by itself and say so in its JSON line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from imageflow_amd.graphics.bitmaps import Bitmap  # noqa: E402
+from imageflow_amd.graphics.scaling import ScaleAndRenderParams, scale_and_render  # noqa: E402
+from tests import util as U  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK"):
+        env.pop(k, None)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    return env
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_hip_render_equals_single_process(tmp_path, world):
+    n_frames, in_w, in_h, ow, oh = 7, 960, 540, 50, 50
+    out = str(tmp_path / "gathered.npy")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "pg_worker.py"), out] + [str(v) for v in (n_frames, in_w, in_h, ow, oh)]
+    r = subprocess.run(cmd, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    frames = np.concatenate([U.random_frames(1, in_w, in_h, seed0=4000 + i, alpha=False) for i in range(n_frames)])
+    inp = Bitmap.from_numpy(frames, in_w, in_h, frames.shape[2], "cuda:0")
+    can = Bitmap.create_u8(n_frames, ow, oh, "cuda:0")
+    scale_and_render(inp, can, ScaleAndRenderParams(0, 0, ow, oh))
+    torch.cuda.synchronize()
+    single = can.data.cpu().numpy()
+    assert np.array_equal(got, single)
+    exp = np.zeros((n_frames, oh, U.stride_for(ow)), np.uint8)
+    U.oracle_render(frames, in_w, in_h, exp, ow, oh, 0, 0, ow, oh)
+    assert np.array_equal(got.reshape(exp.shape), exp)
+
+
+@pytest.mark.parametrize("extra,scaling,total", [([], "weak", 16), (["--scaling", "strong", "--total-frames", "9"], "strong", 9),
+                                                 (["--workload", "cfg3", "--frames", "3"], "weak", 6)])
+def test_bench_launches_its_own_ranks(extra, scaling, total):
+    env = _clean_env()
+    env["IFHIP_BENCH_DRYRUN_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    if "--frames" not in extra and scaling == "weak":
+        cmd += ["--frames", "8"]
+    r = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == scaling and j["config"]["total_frames"] == total, j
+    assert "failed" not in j["config"]["gather"], j["config"]["gather"]
+    assert j["value"] > 0 and j["roofline"]["frac"] > 0
+
+
+def test_bench_refuses_a_mismatched_launcher():
+    env = _clean_env()
+    env.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_PORT": str(_free_port())})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -68,3 +68,33 @@ def test_rgb_coded_files_are_left_to_libjpeg():
     with pytest.raises(FlowError) as e:
         D.get_image_info(buf.getvalue())
     assert "RGB-coded" in str(e.value)
+
+
+def _patch_sampling(data, factors):
+    """Rewrite the sampling bytes of the SOF0 segment: factors = [(h, v)] * 3."""
+    b = bytearray(data)
+    i = 2
+    while i + 4 <= len(b):
+        assert b[i] == 0xFF
+        m, seg = b[i + 1], (b[i + 2] << 8) | b[i + 3]
+        if m == 0xC0:
+            for c, (h, v) in enumerate(factors):
+                b[i + 4 + 6 + 3 * c + 1] = (h << 4) | v
+            return bytes(b)
+        i += 2 + seg
+    raise AssertionError("no SOF0")
+
+
+def test_oversized_mcu_is_rejected_by_the_parser(golden_dir):
+    """A crafted 2x2 / 2x2 / 2x2 header is 12 blocks per MCU: libjpeg refuses it (D_MAX_BLOCKS_IN_MCU = 10) and so must
+    the parser, BEFORE the entropy stage sizes its per-MCU block tables from it (round-1 advisor finding: device
+    out-of-bounds write driven by file bytes)."""
+    z = np.load(os.path.join(golden_dir, "jpeg_cases.npz"))
+    data = next(z[f"jpg_{i}"].tobytes() for i, n in enumerate(z["names"]) if "420" in str(n) or True)
+    info = D.get_image_info(data)
+    if info["ncomp"] != 3:
+        pytest.skip("first fixture is grayscale")
+    for factors in ([(2, 2)] * 3, [(2, 2), (2, 1), (1, 1)], [(1, 1), (2, 2), (2, 2)], [(2, 1), (1, 2), (1, 1)]):
+        with pytest.raises(FlowError) as e:
+            D.get_image_info(_patch_sampling(data, factors))
+        assert "MethodNotImplemented" in str(e.value) or "ImageMalformed" in str(e.value), str(e.value)

@@ -54,6 +54,12 @@ def test_crop_is_a_window_onto_the_same_bytes():
     for bad in ((3, 1, 3, 5), (0, 0, 11, 6), (0, 4, 5, 4), (0, 0, 10, 7)):
         with pytest.raises(FlowError):
             CC.crop(b, *bad)
+    # to_numpy of a window: rows at the parent's stride, the (short) last row zero-padded
+    got = c.to_numpy()
+    full = data.numpy().reshape(n, h, stride)
+    assert got.shape == (n, 4, stride)
+    assert np.array_equal(got[:, :, :20], full[:, 1:5, 8:28])
+    assert np.array_equal(got[:, :3], full.reshape(n, -1)[:, stride + 8: stride + 8 + 3 * stride].reshape(n, 3, stride))
 
 
 def test_orientation_sizes_and_quality_tables():
