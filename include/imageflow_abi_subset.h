@@ -1,0 +1,84 @@
+/*
+ * imageflow_abi_subset.h -- the part of libimageflow's C ABI v3.2 that libimageflow_hip.so re-exports, so that a C
+ * caller (or any language binding generated from bindings/headers/imageflow_default.h) can run resize jobs on the
+ * MI355X path without the Rust host.  Same names, argument order and ownership rules as the reference:
+ *   imageflow_abi/src/lib.rs (line numbers per function below), ABI version imageflow_abi/src/abi_version.rs:4,7.
+ *
+ * What a job may contain (anything else answers ActionNotSupported, HTTP 400): decode (baseline JPEG, or the raw
+ * BGRA container EXTENSION), create_canvas, fill_rect, expand_canvas, crop, flip_h/flip_v, transpose, rotate_90/180/270,
+ * resample_2d, constrain (within | fit | distort), command_string (ir4: width/height, mode=max), encode.
+ * `encode` writes the raw BGRA container EXTENSION whatever the preset says (this library has no entropy/deflate
+ * encoder): 8 bytes "IFBGRA1\0", u32le w, h, stride, alpha_meaningful, then h rows of `stride` bytes.
+ * Implementation: imageflow_amd/csrc/abi_shim.cpp.
+ */
+#ifndef IMAGEFLOW_ABI_SUBSET_H
+#define IMAGEFLOW_ABI_SUBSET_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define IMAGEFLOW_ABI_VER_MAJOR 3
+#define IMAGEFLOW_ABI_VER_MINOR 2
+#define IMAGEFLOW_SHIM_API __attribute__((visibility("default")))
+
+struct imageflow_context;
+struct imageflow_json_response;
+
+/* imageflow_abi/src/lib.rs:281-288 */
+typedef enum imageflow_lifetime {
+  imageflow_lifetime_lifetime_outlives_function_call = 0,
+  imageflow_lifetime_lifetime_outlives_context = 1,
+} imageflow_lifetime;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+IMAGEFLOW_SHIM_API bool imageflow_abi_compatible(uint32_t imageflow_abi_ver_major, uint32_t imageflow_abi_ver_minor);  /* :389 */
+IMAGEFLOW_SHIM_API uint32_t imageflow_abi_version_major(void);                                                         /* :398 */
+IMAGEFLOW_SHIM_API uint32_t imageflow_abi_version_minor(void);                                                         /* :403 */
+
+IMAGEFLOW_SHIM_API struct imageflow_context *imageflow_context_create(uint32_t imageflow_abi_ver_major,
+                                                                      uint32_t imageflow_abi_ver_minor);                /* :430 */
+IMAGEFLOW_SHIM_API bool imageflow_context_begin_terminate(struct imageflow_context *context);                          /* :459 */
+IMAGEFLOW_SHIM_API void imageflow_context_destroy(struct imageflow_context *context);                                  /* :492 */
+
+IMAGEFLOW_SHIM_API bool imageflow_context_has_error(struct imageflow_context *context);                                /* :530 */
+IMAGEFLOW_SHIM_API bool imageflow_context_error_recoverable(struct imageflow_context *context);                        /* :549 */
+IMAGEFLOW_SHIM_API bool imageflow_context_error_try_clear(struct imageflow_context *context);                          /* :572 */
+IMAGEFLOW_SHIM_API int32_t imageflow_context_error_code(struct imageflow_context *context);                            /* :600 */
+IMAGEFLOW_SHIM_API int32_t imageflow_context_error_as_exit_code(struct imageflow_context *context);                    /* :620 */
+IMAGEFLOW_SHIM_API int32_t imageflow_context_error_as_http_code(struct imageflow_context *context);                    /* :645 */
+IMAGEFLOW_SHIM_API bool imageflow_context_error_write_to_buffer(struct imageflow_context *context, char *buffer,
+                                                                size_t buffer_length, size_t *bytes_written);          /* :684 */
+
+IMAGEFLOW_SHIM_API const struct imageflow_json_response *imageflow_context_send_json(struct imageflow_context *context,
+                                                                                     const char *method,
+                                                                                     const uint8_t *json_buffer,
+                                                                                     size_t json_buffer_size);         /* :944 */
+IMAGEFLOW_SHIM_API bool imageflow_json_response_read(struct imageflow_context *context,
+                                                     const struct imageflow_json_response *response_in,
+                                                     int64_t *status_as_http_code_out,
+                                                     const uint8_t **buffer_utf8_no_nulls_out,
+                                                     size_t *buffer_size_out);                                         /* :783 */
+IMAGEFLOW_SHIM_API bool imageflow_json_response_destroy(struct imageflow_context *context,
+                                                        struct imageflow_json_response *response);                     /* :842 */
+
+IMAGEFLOW_SHIM_API bool imageflow_context_add_input_buffer(struct imageflow_context *context, int32_t io_id,
+                                                           const uint8_t *buffer, size_t buffer_byte_count,
+                                                           imageflow_lifetime lifetime);                               /* :1137 */
+IMAGEFLOW_SHIM_API bool imageflow_context_add_output_buffer(struct imageflow_context *context, int32_t io_id);         /* :1224 */
+IMAGEFLOW_SHIM_API bool imageflow_context_get_output_buffer_by_id(struct imageflow_context *context, int32_t io_id,
+                                                                  const uint8_t **result_buffer,
+                                                                  size_t *result_buffer_length);                       /* :1272 */
+
+IMAGEFLOW_SHIM_API void *imageflow_context_memory_allocate(struct imageflow_context *context, size_t bytes,
+                                                           const char *filename, int32_t line);                        /* :1424 */
+IMAGEFLOW_SHIM_API bool imageflow_context_memory_free(struct imageflow_context *context, void *pointer,
+                                                      const char *filename, int32_t line);                             /* :1484 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMAGEFLOW_ABI_SUBSET_H */
