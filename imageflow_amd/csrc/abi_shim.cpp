@@ -589,6 +589,7 @@ struct Job {
         if (name == "constrain") return constrain(in, p);
         if (name == "encode") { encode(in, static_cast<int32_t>(want_int(p, "io_id", "encode"))); return in; }
         if (name == "fill_rect") {                                                    // clone_crop_fill_expand.rs:107-137
+            in->compose = IFHIP_BLEND_WITH_SELF;                                      // :112: set before the fill, so matte canvases accept sub-rects
             check(ifhip_fill_rect_batch_device(in->d, in->bytes(), 1, in->w, in->h, in->stride, in->compose, want_u32(p, "x1", name.c_str()),
                                                want_u32(p, "y1", name.c_str()), want_u32(p, "x2", name.c_str()), want_u32(p, "y2", name.c_str()),
                                                parse_color(p.get("color"), "fill_rect.color"), nullptr));

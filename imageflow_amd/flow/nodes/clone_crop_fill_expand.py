@@ -47,6 +47,8 @@ def expand_canvas(b: Bitmap, left, top, right, bottom, color32) -> Bitmap:
 
 
 def fill_rect(b: Bitmap, x1, y1, x2, y2, color32) -> Bitmap:
-    """FillRectNodeDef::mutate (:107-137)."""
+    """FillRectNodeDef::mutate (:107-137): the bitmap becomes BlendWithSelf first (:112), so a matte canvas accepts a
+    sub-rectangle."""
+    b.compose = BitmapCompositing.BlendWithSelf
     G.fill_rectangle(b, color32, x1, y1, x2, y2)
     return b
