@@ -32,8 +32,8 @@ def _bind():
 def apply_downscaling(original_width, original_height, downscale_if_wider_than, or_if_taller_than,
                       downscaled_min_width, downscaled_min_height):
     """MzDec::apply_downscaling (mozjpeg_decoder.rs:588-618): the scale_num/8 libjpeg is asked for, given the decoder
-    hints (ffi/c_interop.rs:6-15).  Returns (scale_num, w, h); scale_num == 8 means full-size decode.
-    (The GPU pixel stage implements scale_num 8, 4, 2, 1; for 3, 5, 6 decode at 8/8 and let the resampler reduce.)"""
+    hints (ffi/c_interop.rs:6-15).  Returns (scale_num, w, h); scale_num == 8 means full-size decode.  Every value this
+    can return (1..6, 8) is implemented by the GPU pixel stage."""
     if (downscaled_min_width > 0 and downscaled_min_height > 0
             and (original_width > downscale_if_wider_than or original_height > or_if_taller_than)):
         for i in range(1, 8):

@@ -363,14 +363,13 @@ struct Job {
         int ncomp = 0;
         uint8_t hs[3] = {1, 1, 1}, vs[3] = {1, 1, 1};
         check(ifhip_jpeg_entropy_info(ent, &w, &h, &ncomp, hs, vs, bw, bh, &nsub, &nseg));
-        // MzDec::apply_downscaling (mozjpeg_decoder.rs:588-618); the pixel stage has scale_num 8, 4, 2, 1 today
+        // MzDec::apply_downscaling (mozjpeg_decoder.rs:588-618): smallest i/8 (7 skipped) that still covers the hint
         int scale = 8;
         if (hint_w > 0 && hint_h > 0)
             for (int i = 1; i < 8; ++i) {
                 if (i == 7) continue;
                 if ((static_cast<uint64_t>(w) * i + 7) / 8 >= hint_w && (static_cast<uint64_t>(h) * i + 7) / 8 >= hint_h) { scale = i; break; }
             }
-        if (scale == 3) scale = 4; else if (scale == 5 || scale == 6) scale = 8;     // not implemented: next supported size up
         int16_t* coef[3] = {nullptr, nullptr, nullptr};
         struct CoefGuard { int16_t** p; ~CoefGuard() { for (int i = 0; i < 3; ++i) if (p[i]) (void)hipFree(p[i]); } } cg{coef};
         for (int k = 0; k < 3; ++k)

@@ -37,9 +37,10 @@ struct JpegGeom {
     uint32_t blocks_before[4];      // prefix sums of bw*bh over components
     uint32_t out_w, out_h;          // ceil(width * scale_num / 8), ceil(height * scale_num / 8)
     uint32_t scale_num;             // 8 = full size; 1, 2, 4 = reduced-size decode
-    uint32_t idct_n[3];             // samples per block edge each component's IDCT produces (1, 2, 4 or 8)
+    uint32_t idct_n[3];             // samples per block edge each component's IDCT produces (1..6, 8, 10, 12)
     uint32_t luma_mode;             // 0: libjpeg's own (reduced) IDCT, 1: islow + flow_scale_spatial, 2: ... _srgb
-    uint32_t upsample;              // 0 none (planes already at output resolution), 1 h2v1 fancy, 2 h2v2 fancy
+    uint32_t upsample;              // 0 none (planes at output resolution), 1 h2v1 fancy, 2 h2v2 fancy, 3 h2v1 replicated,
+                                    // 4 h2v2 replicated, 5 h1v2 fancy, 6 h1v2 replicated (jdsample.c jinit_upsampler)
 };
 
 struct JpegScalerTab {              // flow_scale_spatial tables for the luma size in use
@@ -112,11 +113,138 @@ __device__ __forceinline__ void idct2_pass(int32_t d0, int32_t d1, int32_t d3, i
     out[0] = descale(t10 + t0, sh); out[1] = descale(t10 - t0, sh);
 }
 
+
+// libjpeg's other scaled IDCTs (jidctint.c jpeg_idct_3x3 / 5x5 / 6x6 / 10x10 / 12x12): the block routines behind
+// scale_num 3, 5, 6 (luma NxN; 2x2 sub-sampled chroma 2N x 2N).  One N-point pass each; `dc` arrives shifted left by
+// CONST_BITS with the pass's rounding constant added, PASS1 selects the first-pass forms (a few outputs combine
+// separately shifted halves there).  Plain arithmetic shifts, as the library.
+#define IFHIP_FIXC(x) static_cast<int32_t>((x) * 8192.0 + 0.5)
+template <bool PASS1>
+__device__ __forceinline__ void idct3_pass(int32_t dc, int32_t d1, int32_t d2, int32_t (&o)[3]) {
+    constexpr int sh = PASS1 ? 11 : 18;
+    const int32_t t12 = d2 * IFHIP_FIXC(0.707106781);
+    const int32_t t10 = dc + t12, t2 = dc - t12 - t12;
+    const int32_t t0 = d1 * IFHIP_FIXC(1.224744871);
+    o[0] = (t10 + t0) >> sh; o[2] = (t10 - t0) >> sh; o[1] = t2 >> sh;
+}
+template <bool PASS1>
+__device__ __forceinline__ void idct5_pass(int32_t dc, int32_t d1, int32_t d2, int32_t d3, int32_t d4, int32_t (&o)[5]) {
+    constexpr int sh = PASS1 ? 11 : 18;
+    int32_t z1 = (d2 + d4) * IFHIP_FIXC(0.790569415);
+    const int32_t z2 = (d2 - d4) * IFHIP_FIXC(0.353553391);
+    const int32_t z3 = dc + z2;
+    const int32_t t10 = z3 + z1, t11 = z3 - z1;
+    const int32_t t12 = dc - static_cast<int32_t>(static_cast<uint32_t>(z2) << 2);
+    z1 = (d1 + d3) * IFHIP_FIXC(0.831253876);
+    const int32_t t0 = z1 + d1 * IFHIP_FIXC(0.513743148);
+    const int32_t t1 = z1 - d3 * IFHIP_FIXC(2.176250899);
+    o[0] = (t10 + t0) >> sh; o[4] = (t10 - t0) >> sh; o[1] = (t11 + t1) >> sh; o[3] = (t11 - t1) >> sh; o[2] = t12 >> sh;
+}
+template <bool PASS1>
+__device__ __forceinline__ void idct6_pass(int32_t dc, int32_t d1, int32_t d2, int32_t d3, int32_t d4, int32_t d5, int32_t (&o)[6]) {
+    constexpr int sh = PASS1 ? 11 : 18;
+    int32_t t10 = d4 * IFHIP_FIXC(0.707106781);
+    const int32_t t1a = dc + t10;
+    const int32_t t11 = dc - t10 - t10;
+    const int32_t t0a = d2 * IFHIP_FIXC(1.224744871);
+    t10 = t1a + t0a;
+    const int32_t t12 = t1a - t0a;
+    const int32_t t1 = (d1 + d5) * IFHIP_FIXC(0.366025404);
+    const int32_t t0 = t1 + static_cast<int32_t>(static_cast<uint32_t>(d1 + d3) << 13);
+    const int32_t t2 = t1 + static_cast<int32_t>(static_cast<uint32_t>(d5 - d3) << 13);
+    o[0] = (t10 + t0) >> sh; o[5] = (t10 - t0) >> sh;
+    o[2] = (t12 + t2) >> sh; o[3] = (t12 - t2) >> sh;
+    if (PASS1) {
+        const int32_t m = static_cast<int32_t>(static_cast<uint32_t>(d1 - d3 - d5) << 2), h = t11 >> sh;
+        o[1] = h + m; o[4] = h - m;
+    } else {
+        const int32_t m = static_cast<int32_t>(static_cast<uint32_t>(d1 - d3 - d5) << 13);
+        o[1] = (t11 + m) >> sh; o[4] = (t11 - m) >> sh;
+    }
+}
+template <bool PASS1>
+__device__ __forceinline__ void idct10_pass(int32_t dc, const int32_t (&d)[8], int32_t (&o)[10]) {
+    constexpr int sh = PASS1 ? 11 : 18;
+    int32_t z1 = d[4] * IFHIP_FIXC(1.144122806), z2 = d[4] * IFHIP_FIXC(0.437016024);
+    int32_t t10 = dc + z1, t11 = dc - z2;
+    const int32_t t22 = dc - static_cast<int32_t>(static_cast<uint32_t>(z1 - z2) << 1);
+    z1 = (d[2] + d[6]) * IFHIP_FIXC(0.831253876);
+    int32_t t12 = z1 + d[2] * IFHIP_FIXC(0.513743148);
+    int32_t t13 = z1 - d[6] * IFHIP_FIXC(2.176250899);
+    const int32_t t20 = t10 + t12, t24 = t10 - t12, t21 = t11 + t13, t23 = t11 - t13;
+    const int32_t o5s = static_cast<int32_t>(static_cast<uint32_t>(d[5]) << 13);
+    t11 = d[3] + d[7];
+    t13 = d[3] - d[7];
+    t12 = t13 * IFHIP_FIXC(0.309016994);
+    z2 = t11 * IFHIP_FIXC(0.951056516);
+    int32_t z4 = o5s + t12;
+    t10 = d[1] * IFHIP_FIXC(1.396802247) + z2 + z4;
+    const int32_t t14 = d[1] * IFHIP_FIXC(0.221231742) - z2 + z4;
+    z2 = t11 * IFHIP_FIXC(0.587785252);
+    z4 = o5s - t12 - static_cast<int32_t>(static_cast<uint32_t>(t13) << 12);
+    const int32_t mid = d[1] - t13;
+    t11 = d[1] * IFHIP_FIXC(1.260073511) - z2 - z4;
+    t13 = d[1] * IFHIP_FIXC(0.642039522) - z2 + z4;
+    o[0] = (t20 + t10) >> sh; o[9] = (t20 - t10) >> sh;
+    o[1] = (t21 + t11) >> sh; o[8] = (t21 - t11) >> sh;
+    o[3] = (t23 + t13) >> sh; o[6] = (t23 - t13) >> sh;
+    o[4] = (t24 + t14) >> sh; o[5] = (t24 - t14) >> sh;
+    if (PASS1) {
+        const int32_t a = t22 >> sh, b = static_cast<int32_t>(static_cast<uint32_t>(mid - d[5]) << 2);
+        o[2] = a + b; o[7] = a - b;
+    } else {
+        const int32_t b = static_cast<int32_t>(static_cast<uint32_t>(mid) << 13) - o5s;
+        o[2] = (t22 + b) >> sh; o[7] = (t22 - b) >> sh;
+    }
+}
+template <bool PASS1>
+__device__ __forceinline__ void idct12_pass(int32_t dc, const int32_t (&d)[8], int32_t (&o)[12]) {
+    constexpr int sh = PASS1 ? 11 : 18;
+    int32_t z4 = d[4] * IFHIP_FIXC(1.224744871);
+    int32_t t10 = dc + z4, t11 = dc - z4;
+    z4 = d[2] * IFHIP_FIXC(1.366025404);
+    int32_t z1 = static_cast<int32_t>(static_cast<uint32_t>(d[2]) << 13);
+    int32_t z2 = static_cast<int32_t>(static_cast<uint32_t>(d[6]) << 13);
+    int32_t t12 = z1 - z2;
+    const int32_t t21 = dc + t12, t24 = dc - t12;
+    t12 = z4 + z2;
+    const int32_t t20 = t10 + t12, t25 = t10 - t12;
+    t12 = z4 - z1 - z2;
+    const int32_t t22 = t11 + t12, t23 = t11 - t12;
+    z1 = d[1]; z2 = d[3];
+    int32_t z3 = d[5];
+    z4 = d[7];
+    t11 = z2 * IFHIP_FIXC(1.306562965);
+    int32_t t14 = z2 * (-4433);
+    t10 = z1 + z3;
+    int32_t t15 = (t10 + z4) * IFHIP_FIXC(0.860918669);
+    t12 = t15 + t10 * IFHIP_FIXC(0.261052384);
+    t10 = t12 + t11 + z1 * IFHIP_FIXC(0.280143716);
+    int32_t t13 = (z3 + z4) * (-IFHIP_FIXC(1.045510580));
+    t12 += t13 + t14 - z3 * IFHIP_FIXC(1.478575242);
+    t13 += t15 - t11 + z4 * IFHIP_FIXC(1.586706681);
+    t15 += t14 - z1 * IFHIP_FIXC(0.676326758) - z4 * IFHIP_FIXC(1.982889723);
+    z1 -= z4;
+    z2 -= z3;
+    z3 = (z1 + z2) * 4433;
+    t11 = z3 + z1 * 6270;
+    t14 = z3 - z2 * 15137;
+    o[0] = (t20 + t10) >> sh; o[11] = (t20 - t10) >> sh;
+    o[1] = (t21 + t11) >> sh; o[10] = (t21 - t11) >> sh;
+    o[2] = (t22 + t12) >> sh; o[9] = (t22 - t12) >> sh;
+    o[3] = (t23 + t13) >> sh; o[8] = (t23 - t13) >> sh;
+    o[4] = (t24 + t14) >> sh; o[7] = (t24 - t14) >> sh;
+    o[5] = (t25 + t15) >> sh; o[6] = (t25 - t15) >> sh;
+}
+__device__ __forceinline__ int32_t dc_pass1(int32_t d0) { return static_cast<int32_t>(static_cast<uint32_t>(d0) << 13) + (1 << 10); }
+__device__ __forceinline__ int32_t dc_pass2(int32_t w0) { return static_cast<int32_t>(static_cast<uint32_t>(w0 + 16) << 13); }
+
 constexpr int kBlocksPerWg = 32;
 constexpr int kBlockPitch = 72;     // dwords per 8x8 workspace in LDS (64 + 8: spreads 4 blocks over the 32 banks)
+constexpr int kBigPitch = 104;      // jpeg_idct_kernel: up to 12 workspace rows of 8 (the 10x10 / 12x12 IDCTs) + 8
 
 __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
-    __shared__ int32_t ws[kBlocksPerWg * kBlockPitch];
+    __shared__ int32_t ws[kBlocksPerWg * kBigPitch];
     // grid: x = groups of 32 blocks of component a.comp, y = image
     const uint32_t t = threadIdx.x, lane8 = t & 7u, lb = t >> 3;
     const uint32_t c = a.comp, img = blockIdx.y;
@@ -125,7 +253,7 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
     const uint32_t n = a.g.idct_n[c];                                   // output samples per block edge
     const bool spatial = (c == 0u) && a.g.luma_mode != 0u && n < 8u;    // islow, then imageflow's block scaler
     const uint32_t m = spatial ? 8u : n;                                // size of the IDCT actually run
-    int32_t* w = ws + lb * kBlockPitch;
+    int32_t* w = ws + lb * kBigPitch;
     if (on) {
         const uint32_t nblk = a.g.bw[c] * a.g.bh[c];
         const int16_t* src = a.coef[c] + (static_cast<size_t>(img) * nblk + bidx) * 64u + lane8 * 8u;
@@ -161,6 +289,20 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
             int32_t out[2];
             idct2_pass(in[0], in[1], in[3], in[5], in[7], out, 13);                   // CONST_BITS - PASS1_BITS + 2
             w[lane8] = out[0]; w[8 + lane8] = out[1];
+        } else if (m == 3u) {
+            if (lane8 < 3u) { int32_t out[3]; idct3_pass<true>(dc_pass1(in[0]), in[1], in[2], out); for (int r = 0; r < 3; ++r) w[r * 8 + lane8] = out[r]; }
+        } else if (m == 5u) {
+            if (lane8 < 5u) { int32_t out[5]; idct5_pass<true>(dc_pass1(in[0]), in[1], in[2], in[3], in[4], out); for (int r = 0; r < 5; ++r) w[r * 8 + lane8] = out[r]; }
+        } else if (m == 6u) {
+            if (lane8 < 6u) { int32_t out[6]; idct6_pass<true>(dc_pass1(in[0]), in[1], in[2], in[3], in[4], in[5], out); for (int r = 0; r < 6; ++r) w[r * 8 + lane8] = out[r]; }
+        } else if (m == 10u) {
+            int32_t out[10]; idct10_pass<true>(dc_pass1(in[0]), in, out);
+#pragma unroll
+            for (int r = 0; r < 10; ++r) w[r * 8 + lane8] = out[r];
+        } else if (m == 12u) {
+            int32_t out[12]; idct12_pass<true>(dc_pass1(in[0]), in, out);
+#pragma unroll
+            for (int r = 0; r < 12; ++r) w[r * 8 + lane8] = out[r];
         }
     }
     __syncthreads();
@@ -202,8 +344,25 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
                 const uint32_t v = range_limit(out[0]) | (range_limit(out[1]) << 8);
                 *reinterpret_cast<uint16_t*>(plane + static_cast<size_t>(by * 2u + lane8) * a.g.pw[c] + bx * 2u) = static_cast<uint16_t>(v);
             }
-        } else {                                                                     // 1x1: DC / 8
+        } else if (m == 1u) {                                                        // 1x1: DC / 8
             if (lane8 == 0u) plane[static_cast<size_t>(by) * a.g.pw[c] + bx] = static_cast<uint8_t>(range_limit(descale(w[0], 3)));
+        } else {                                                                     // 3, 5, 6, 10, 12: byte stores (parity path)
+            for (uint32_t row = lane8; row < m; row += 8u) {
+                const int32_t* r = w + row * 8u;
+                int32_t out[12];
+                if (m == 3u) { int32_t o[3]; idct3_pass<false>(dc_pass2(r[0]), r[1], r[2], o); for (int k = 0; k < 3; ++k) out[k] = o[k]; }
+                else if (m == 5u) { int32_t o[5]; idct5_pass<false>(dc_pass2(r[0]), r[1], r[2], r[3], r[4], o); for (int k = 0; k < 5; ++k) out[k] = o[k]; }
+                else if (m == 6u) { int32_t o[6]; idct6_pass<false>(dc_pass2(r[0]), r[1], r[2], r[3], r[4], r[5], o); for (int k = 0; k < 6; ++k) out[k] = o[k]; }
+                else {
+                    int32_t d[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) d[k] = r[k];
+                    if (m == 10u) { int32_t o[10]; idct10_pass<false>(dc_pass2(r[0]), d, o); for (int k = 0; k < 10; ++k) out[k] = o[k]; }
+                    else { idct12_pass<false>(dc_pass2(r[0]), d, out); }
+                }
+                uint8_t* dst = plane + static_cast<size_t>(by * m + row) * a.g.pw[c] + bx * m;
+                for (uint32_t k = 0; k < m; ++k) dst[k] = static_cast<uint8_t>(range_limit(out[k]));
+            }
         }
     }
     if (spatial) {
@@ -410,6 +569,35 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const JpegArgs a) {
         }
         return;
     }
+    if (a.g.upsample >= 3u) {              // rare forms (parity paths): replication, and the vertical-only triangle of 4:4:0
+        for (uint32_t y = y_begin; y < y_end; ++y) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t W = a.g.pw[1 + k], DW = a.g.dw[1 + k], DH = a.g.dh[1 + k];
+                if (a.g.upsample == 3u) {                              // h2v1, samples replicated
+                    int32_t s[4];
+                    chroma4(P[k], W, DW, DH, c0, static_cast<int32_t>(y), s);
+                    v[k][0] = s[1]; v[k][1] = s[1]; v[k][2] = s[2]; v[k][3] = s[2];
+                } else if (a.g.upsample == 4u) {                       // h2v2, samples replicated
+                    int32_t s[4];
+                    chroma4(P[k], W, DW, DH, c0, static_cast<int32_t>(y >> 1), s);
+                    v[k][0] = s[1]; v[k][1] = s[1]; v[k][2] = s[2]; v[k][3] = s[2];
+                } else {                                               // h1v2: 5 fancy (3*near + far + {1,2}) >> 2, 6 replicated
+                    const int32_t cy = static_cast<int32_t>(y >> 1);
+                    int32_t near[4], far[4];
+                    chroma4(P[k], W, DW, DH, static_cast<int32_t>(x0), cy, near);
+                    if (a.g.upsample == 6u) { for (int i = 0; i < 4; ++i) v[k][i] = near[i]; }
+                    else {
+                        chroma4(P[k], W, DW, DH, static_cast<int32_t>(x0), (y & 1u) ? cy + 1 : cy - 1, far);
+                        const int32_t bias = (y & 1u) ? 2 : 1;
+                        for (int i = 0; i < 4; ++i) v[k][i] = (3 * near[i] + far[i] + bias) >> 2;
+                    }
+                }
+            }
+            emit(y, v, false);
+        }
+        return;
+    }
     // h2v2 fancy: triangle in both directions; y_begin is even (kColorRows is), rows come in pairs (2cy, 2cy+1)
     int32_t prev[2][4], cur[2][4], next[2][4];
     const int32_t cy0 = static_cast<int32_t>(y_begin >> 1);
@@ -491,10 +679,18 @@ struct ifhip_jpeg_stage {
 };
 
 
+// jdmaster.c: a component's IDCT size starts at scale_num and doubles while it stays below 8 before doubling and both
+// sampling ratios allow it (4:2:0 chroma decodes at 2 * scale_num, 4:2:2 / 4:4:0 chroma stays at scale_num)
+static uint32_t component_idct_size(uint32_t scale_num, uint32_t hs_c, uint32_t vs_c, uint32_t hmax, uint32_t vmax) {
+    uint32_t ssize = scale_num;
+    while (ssize < 8u && (hmax * scale_num) % (hs_c * ssize * 2u) == 0u && (vmax * scale_num) % (vs_c * ssize * 2u) == 0u) ssize *= 2u;
+    return ssize;
+}
+
 static int make_geom(uint32_t width, uint32_t height, int ncomp, const uint8_t* hs, const uint8_t* vs, int scale_num,
                      int luma_spatial, int luma_srgb, JpegGeom* g) {
-    if (scale_num != 8 && scale_num != 4 && scale_num != 2 && scale_num != 1)
-        return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: jpeg scale_num %d/8 (supported: 1, 2, 4, 8)", scale_num);
+    if (scale_num < 1 || scale_num > 8 || scale_num == 7)            // 7/8 is never asked for (mozjpeg_decoder.rs:603-606)
+        return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: jpeg scale_num %d/8 (supported: 1..6, 8)", scale_num);
     if (width == 0 || height == 0) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: Bitmap dimensions cannot be zero");
     if (ncomp != 1 && ncomp != 3) return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: %d-component JPEG", ncomp);
     std::memset(g, 0, sizeof *g);
@@ -509,27 +705,35 @@ static int make_geom(uint32_t width, uint32_t height, int ncomp, const uint8_t* 
     if (ncomp == 3) {
         const bool chroma_1x1 = g->hs[1] == 1 && g->vs[1] == 1 && g->hs[2] == 1 && g->vs[2] == 1;
         const bool luma_max = g->hs[0] == g->hmax && g->vs[0] == g->vmax;
-        if (!chroma_1x1 || !luma_max || (g->hmax == 1 && g->vmax == 2))
-            return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: only 4:4:4, 4:2:2 (h2v1) and 4:2:0 sampling");
+        if (!chroma_1x1 || !luma_max)
+            return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: only 4:4:4, 4:2:2 (h2v1), 4:4:0 (h1v2) and 4:2:0 sampling");
     }
-    const bool is420 = ncomp == 3 && g->hmax == 2 && g->vmax == 2, is422 = ncomp == 3 && g->hmax == 2 && g->vmax == 1;
-    if (scale_num != 8 && is422)
-        return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: reduced-size decode of 4:2:2 (needs libjpeg's non-square IDCTs)");
     g->scale_num = static_cast<uint32_t>(scale_num);
     g->luma_mode = (scale_num < 8 && luma_spatial) ? (luma_srgb ? 2u : 1u) : 0u;     // codec_jpeg_wrapper.c:285-339
     g->out_w = (width * g->scale_num + 7u) / 8u;                                      // jpeg_calc_output_dimensions
     g->out_h = (height * g->scale_num + 7u) / 8u;
-    // jdmaster.c: at reduced size a 2x2 sub-sampled component takes an IDCT twice as large instead of being up-sampled
-    g->upsample = (scale_num == 8) ? (is420 ? 2u : (is422 ? 1u : 0u)) : 0u;
     const uint32_t mw = (width + 8u * g->hmax - 1u) / (8u * g->hmax), mh = (height + 8u * g->vmax - 1u) / (8u * g->vmax);
     g->blocks_before[0] = 0;
     for (int c = 0; c < ncomp; ++c) {
         g->bw[c] = mw * g->hs[c]; g->bh[c] = mh * g->vs[c];
-        g->idct_n[c] = (scale_num == 8) ? 8u : ((c > 0 && is420) ? 2u * g->scale_num : g->scale_num);
-        g->pw[c] = g->bw[c] * g->idct_n[c]; g->ph[c] = g->bh[c] * g->idct_n[c];
-        g->dw[c] = (width * g->hs[c] + g->hmax - 1u) / g->hmax;
-        g->dh[c] = (height * g->vs[c] + g->vmax - 1u) / g->vmax;
+        const uint32_t n = component_idct_size(g->scale_num, g->hs[c], g->vs[c], g->hmax, g->vmax);
+        g->idct_n[c] = n;
+        g->pw[c] = g->bw[c] * n; g->ph[c] = g->bh[c] * n;
+        g->dw[c] = (width * g->hs[c] * n + g->hmax * 8u - 1u) / (g->hmax * 8u);         // downsampled_width at this IDCT size
+        g->dh[c] = (height * g->vs[c] * n + g->vmax * 8u - 1u) / (g->vmax * 8u);
         g->blocks_before[c + 1] = g->blocks_before[c] + g->bw[c] * g->bh[c];
+    }
+    // jdsample.c jinit_upsampler: what is left to up-sample, and whether the triangle ("fancy") forms apply:
+    // do_fancy_upsampling (libjpeg's default; the reference never touches it) needs min_DCT_scaled_size > 1, and the
+    // h2v1 / h2v2 forms need downsampled_width > 2 -- otherwise samples are replicated.
+    g->upsample = 0u;
+    if (ncomp == 3) {
+        const uint32_t ux = (g->hmax * g->scale_num) / (g->hs[1] * g->idct_n[1]), uy = (g->vmax * g->scale_num) / (g->vs[1] * g->idct_n[1]);
+        const bool fancy = g->scale_num > 1u;
+        if (ux == 2u && uy == 1u) g->upsample = (fancy && g->dw[1] > 2u) ? 1u : 3u;
+        else if (ux == 2u && uy == 2u) g->upsample = (fancy && g->dw[1] > 2u) ? 2u : 4u;
+        else if (ux == 1u && uy == 2u) g->upsample = fancy ? 5u : 6u;
+        else if (ux != 1u || uy != 1u) return fail(IFHIP_INVALID_STATE, "InvalidState: up-sampling %ux%u", ux, uy);
     }
     return IFHIP_OK;
 }

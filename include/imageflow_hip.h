@@ -156,10 +156,11 @@ IFHIP_API int ifhip_apply_matte_batch_device(uint8_t* d_bgra, size_t image_bytes
  * scale_num / luma_spatial / luma_srgb are what MzDec::apply_downscaling (:588-618) and DecoderDownscaleHints
  * (ffi/c_interop.rs:6-15) set: libjpeg's scale_num/8 and whether the luma component goes through imageflow's
  * flow_scale_spatial[_srgb]_NxN block scalers (codec_jpeg_wrapper.c:274-343) instead of libjpeg's reduced IDCT.
- * Supported: scale_num 8 (grayscale, 4:4:4, 4:2:2, 4:2:0) and 1, 2, 4 (grayscale, 4:4:4, 4:2:0 -- jidctred.c's
- * 4x4/2x2/1x1 IDCTs, sub-sampled chroma taking the twice-larger IDCT as jdmaster.c prescribes); 3, 5, 6 are not
- * implemented (the caller decodes at 8 and resamples).  The output bitmap is ceil(width*scale_num/8) x
- * ceil(height*scale_num/8).
+ * Supported: scale_num 1..6 and 8 (7/8 is never requested, mozjpeg_decoder.rs:603-606) for grayscale, 4:4:4, 4:2:2 (h2v1),
+ * 4:4:0 (h1v2) and 4:2:0 -- libjpeg's scaled IDCTs (jidctred.c 1x1/2x2/4x4, jidctint.c 3x3/5x5/6x6/10x10/12x12), its
+ * per-component IDCT size rule (jdmaster.c: 4:2:0 chroma decodes at 2*scale_num, no up-sampling) and its up-sampler
+ * choice (jdsample.c: triangle forms need scale_num > 1 and downsampled_width > 2, else replication).  The output
+ * bitmap is ceil(width*scale_num/8) x ceil(height*scale_num/8).
  */
 IFHIP_API int ifhip_jpeg_idct_color(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2,
                                     const uint16_t* qt, int n_components,

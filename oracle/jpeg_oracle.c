@@ -381,82 +381,16 @@ static inline int32_t cs(const uint8_t* plane, uint32_t pw, uint32_t dw, uint32_
  * coef[c]: [bh_c][bw_c][64] natural order; qt: [ncomp][64]; hs/vs: sampling factors.
  * Output BGRA8 with alpha = 255 (what JCS_EXT_BGRA writes), rows `stride` bytes.
  */
+int jo_jpeg_idct_color_scaled(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2, const uint16_t* qt,
+                              int ncomp, const uint8_t* hs, const uint8_t* vs, uint32_t width, uint32_t height,
+                              int scale_num, int luma_mode,
+                              const int8_t* w7x8, const uint8_t* log2div7, const uint16_t* s2l12, const uint8_t* l2s12,
+                              uint8_t* bgra, uint32_t stride);
 int jo_jpeg_idct_color(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2, const uint16_t* qt,
                        int ncomp, const uint8_t* hs, const uint8_t* vs, uint32_t width, uint32_t height,
                        uint8_t* bgra, uint32_t stride) {
-    build_ycc();
-    const int16_t* coef[3] = {coef0, coef1, coef2};
-    int hmax = 1, vmax = 1;
-    for (int c = 0; c < ncomp; c++) { if (hs[c] > hmax) hmax = hs[c]; if (vs[c] > vmax) vmax = vs[c]; }
-    if (ncomp == 3 && !(hs[1] == 1 && vs[1] == 1 && hs[2] == 1 && vs[2] == 1 && hs[0] == hmax && vs[0] == vmax))
-        return JO_ERR_UNSUPPORTED;
-    uint32_t mw = (width + 8u * hmax - 1) / (8u * hmax), mh = (height + 8u * vmax - 1) / (8u * vmax);
-    uint8_t* plane[3] = {0, 0, 0};
-    uint32_t pw[3], ph[3], dw[3], dh[3];
-    for (int c = 0; c < ncomp; c++) {
-        pw[c] = mw * hs[c] * 8; ph[c] = mh * vs[c] * 8;
-        dw[c] = (width * hs[c] + hmax - 1) / hmax;              /* downsampled_width  */
-        dh[c] = (height * vs[c] + vmax - 1) / vmax;             /* downsampled_height */
-        plane[c] = (uint8_t*)malloc((size_t)pw[c] * ph[c]);
-        if (!plane[c]) { for (int k = 0; k < c; k++) free(plane[k]); return JO_ERR_ALLOC; }
-        uint32_t bw = mw * hs[c], bh = mh * vs[c];
-        for (uint32_t by = 0; by < bh; by++)
-            for (uint32_t bx = 0; bx < bw; bx++)
-                jo_idct_islow_block(coef[c] + 64 * ((size_t)by * bw + bx), qt + 64 * c,
-                                    plane[c] + (size_t)by * 8 * pw[c] + bx * 8, (int)pw[c]);
-    }
-    for (uint32_t y = 0; y < height; y++) {
-        uint8_t* o = bgra + (size_t)y * stride;
-        for (uint32_t x = 0; x < width; x++) {
-            int32_t Y = plane[0][(size_t)y * pw[0] + x];
-            if (ncomp == 1) { o[4 * x] = o[4 * x + 1] = o[4 * x + 2] = (uint8_t)Y; o[4 * x + 3] = 255; continue; }
-            int32_t cbv, crv;
-            if (hmax == 1 && vmax == 1) {
-                cbv = plane[1][(size_t)y * pw[1] + x]; crv = plane[2][(size_t)y * pw[2] + x];
-            } else if (hmax == 2 && vmax == 1) {                  /* h2v1 fancy: 3/4 near + 1/4 far */
-                int32_t cx = (int32_t)(x >> 1), far = (x & 1) ? cx + 1 : cx - 1, bias = (x & 1) ? 2 : 1;
-                int32_t v[2];
-                for (int k = 0; k < 2; k++) {
-                    const uint8_t* P = plane[1 + k];
-                    if ((x == 0) || (x == 2 * dw[1 + k] - 1 && (x & 1)))
-                        v[k] = cs(P, pw[1 + k], dw[1 + k], dh[1 + k], cx, (int32_t)y);
-                    else
-                        v[k] = (3 * cs(P, pw[1 + k], dw[1 + k], dh[1 + k], cx, (int32_t)y)
-                                + cs(P, pw[1 + k], dw[1 + k], dh[1 + k], far, (int32_t)y) + bias) >> 2;
-                }
-                cbv = v[0]; crv = v[1];
-            } else if (hmax == 2 && vmax == 2) {                  /* h2v2 fancy: triangle in both directions */
-                int32_t cx = (int32_t)(x >> 1), cy = (int32_t)(y >> 1);
-                int32_t ny = (y & 1) ? cy + 1 : cy - 1;           /* the "other" chroma row */
-                int32_t v[2];
-                for (int k = 0; k < 2; k++) {
-                    const uint8_t* P = plane[1 + k];
-                    uint32_t W = pw[1 + k], DW = dw[1 + k], DH = dh[1 + k];
-                    int32_t thiscol = 3 * cs(P, W, DW, DH, cx, cy) + cs(P, W, DW, DH, cx, ny);
-                    if ((x & 1) == 0) {
-                        if (cx == 0) v[k] = (thiscol * 4 + 8) >> 4;
-                        else {
-                            int32_t last = 3 * cs(P, W, DW, DH, cx - 1, cy) + cs(P, W, DW, DH, cx - 1, ny);
-                            v[k] = (thiscol * 3 + last + 8) >> 4;
-                        }
-                    } else {
-                        if (cx == (int32_t)DW - 1) v[k] = (thiscol * 4 + 7) >> 4;
-                        else {
-                            int32_t next = 3 * cs(P, W, DW, DH, cx + 1, cy) + cs(P, W, DW, DH, cx + 1, ny);
-                            v[k] = (thiscol * 3 + next + 7) >> 4;
-                        }
-                    }
-                }
-                cbv = v[0]; crv = v[1];
-            } else { for (int k = 0; k < ncomp; k++) free(plane[k]); return JO_ERR_UNSUPPORTED; }
-            o[4 * x + 2] = clamp255(Y + cr_r[crv]);
-            o[4 * x + 1] = clamp255(Y + ((cb_g[cbv] + cr_g[crv]) >> 16));
-            o[4 * x + 0] = clamp255(Y + cb_b[cbv]);
-            o[4 * x + 3] = 255;
-        }
-    }
-    for (int c = 0; c < ncomp; c++) free(plane[c]);
-    return JO_OK;
+    /* full size = the scaled stage at 8/8 (no block scaler tables are touched there) */
+    return jo_jpeg_idct_color_scaled(coef0, coef1, coef2, qt, ncomp, hs, vs, width, height, 8, 0, 0, 0, 0, 0, bgra, stride);
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -556,6 +490,261 @@ void jo_idct_1x1_block(const int16_t* in, const uint16_t* q, uint8_t* out) {
     out[0] = range_limit(DESCALE((int32_t)in[0] * (int32_t)q[0], 3));
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* libjpeg's other scaled inverse DCTs (jidctint.c: jpeg_idct_3x3 / 5x5 / 6x6 / 10x10 / 12x12), the  */
+/* block routines jddctmgr.c installs for DCT_scaled_size 3, 5, 6, 10, 12: what scale_num 3, 5, 6    */
+/* need (luma NxN; a 2x2 sub-sampled chroma component takes 2N x 2N, jdmaster.c).  No zero-column     */
+/* shortcut in these; plain arithmetic shifts, the rounding constant is added to the DC term.         */
+/* Pin: tests/golden/jpeg_scaled_cases.npz, recorded from the system libjpeg-turbo 2.1.2 by           */
+/* tests/golden/make_jpeg_scaled_golden.py (mozjpeg-sys derives from the same jidctint.c).            */
+/* ------------------------------------------------------------------------------------------------ */
+#define FIXC(x) ((int32_t)((x) * 8192.0 + 0.5))
+#define DQ(k) ((int32_t)c[8 * (k)] * (int32_t)qq[8 * (k)])
+#define RS(x, n) ((x) >> (n))
+#define P1 (CONST_BITS - PASS1_BITS)
+#define P2 (CONST_BITS + PASS1_BITS + 3)
+
+void jo_idct_3x3_block(const int16_t* in, const uint16_t* q, uint8_t* out, int out_stride) {
+    int32_t ws[3 * 3];
+    for (int col = 0; col < 3; col++) {
+        const int16_t* c = in + col; const uint16_t* qq = q + col;
+        int32_t tmp0 = (int32_t)((uint32_t)DQ(0) << CONST_BITS) + (1 << (P1 - 1));
+        int32_t tmp2 = DQ(2);
+        int32_t tmp12 = tmp2 * FIXC(0.707106781);
+        int32_t tmp10 = tmp0 + tmp12;
+        tmp2 = tmp0 - tmp12 - tmp12;
+        tmp12 = DQ(1);
+        tmp0 = tmp12 * FIXC(1.224744871);
+        ws[3 * 0 + col] = RS(tmp10 + tmp0, P1);
+        ws[3 * 2 + col] = RS(tmp10 - tmp0, P1);
+        ws[3 * 1 + col] = RS(tmp2, P1);
+    }
+    for (int row = 0; row < 3; row++) {
+        const int32_t* w = ws + 3 * row;
+        uint8_t* o = out + (size_t)row * out_stride;
+        int32_t tmp0 = (int32_t)((uint32_t)(w[0] + (1 << (PASS1_BITS + 2))) << CONST_BITS);
+        int32_t tmp2 = w[2];
+        int32_t tmp12 = tmp2 * FIXC(0.707106781);
+        int32_t tmp10 = tmp0 + tmp12;
+        tmp2 = tmp0 - tmp12 - tmp12;
+        tmp12 = w[1];
+        tmp0 = tmp12 * FIXC(1.224744871);
+        o[0] = range_limit(RS(tmp10 + tmp0, P2));
+        o[2] = range_limit(RS(tmp10 - tmp0, P2));
+        o[1] = range_limit(RS(tmp2, P2));
+    }
+}
+
+static inline void idct5_core(int32_t tmp12, int32_t e2, int32_t e4, int32_t o1, int32_t o3, int32_t r[5]) {
+    int32_t z1 = (e2 + e4) * FIXC(0.790569415);
+    int32_t z2 = (e2 - e4) * FIXC(0.353553391);
+    int32_t z3 = tmp12 + z2;
+    int32_t tmp10 = z3 + z1, tmp11 = z3 - z1;
+    tmp12 -= (int32_t)((uint32_t)z2 << 2);
+    z1 = (o1 + o3) * FIXC(0.831253876);
+    int32_t tmp0 = z1 + o1 * FIXC(0.513743148);
+    int32_t tmp1 = z1 - o3 * FIXC(2.176250899);
+    r[0] = tmp10 + tmp0; r[4] = tmp10 - tmp0; r[1] = tmp11 + tmp1; r[3] = tmp11 - tmp1; r[2] = tmp12;
+}
+void jo_idct_5x5_block(const int16_t* in, const uint16_t* q, uint8_t* out, int out_stride) {
+    int32_t ws[5 * 5], r[5];
+    for (int col = 0; col < 5; col++) {
+        const int16_t* c = in + col; const uint16_t* qq = q + col;
+        idct5_core((int32_t)((uint32_t)DQ(0) << CONST_BITS) + (1 << (P1 - 1)), DQ(2), DQ(4), DQ(1), DQ(3), r);
+        for (int k = 0; k < 5; k++) ws[5 * k + col] = RS(r[k], P1);
+    }
+    for (int row = 0; row < 5; row++) {
+        const int32_t* w = ws + 5 * row;
+        uint8_t* o = out + (size_t)row * out_stride;
+        idct5_core((int32_t)((uint32_t)(w[0] + (1 << (PASS1_BITS + 2))) << CONST_BITS), w[2], w[4], w[1], w[3], r);
+        for (int k = 0; k < 5; k++) o[k] = range_limit(RS(r[k], P2));
+    }
+}
+
+void jo_idct_6x6_block(const int16_t* in, const uint16_t* q, uint8_t* out, int out_stride) {
+    int32_t ws[6 * 6];
+    for (int col = 0; col < 6; col++) {
+        const int16_t* c = in + col; const uint16_t* qq = q + col;
+        int32_t tmp0 = (int32_t)((uint32_t)DQ(0) << CONST_BITS) + (1 << (P1 - 1));
+        int32_t tmp2 = DQ(4);
+        int32_t tmp10 = tmp2 * FIXC(0.707106781);
+        int32_t tmp1 = tmp0 + tmp10;
+        int32_t tmp11 = RS(tmp0 - tmp10 - tmp10, P1);
+        tmp10 = DQ(2);
+        tmp0 = tmp10 * FIXC(1.224744871);
+        tmp10 = tmp1 + tmp0;
+        int32_t tmp12 = tmp1 - tmp0;
+        int32_t z1 = DQ(1), z2 = DQ(3), z3 = DQ(5);
+        tmp1 = (z1 + z3) * FIXC(0.366025404);
+        tmp0 = tmp1 + (int32_t)((uint32_t)(z1 + z2) << CONST_BITS);
+        tmp2 = tmp1 + (int32_t)((uint32_t)(z3 - z2) << CONST_BITS);
+        tmp1 = (int32_t)((uint32_t)(z1 - z2 - z3) << PASS1_BITS);
+        ws[6 * 0 + col] = RS(tmp10 + tmp0, P1);
+        ws[6 * 5 + col] = RS(tmp10 - tmp0, P1);
+        ws[6 * 1 + col] = tmp11 + tmp1;
+        ws[6 * 4 + col] = tmp11 - tmp1;
+        ws[6 * 2 + col] = RS(tmp12 + tmp2, P1);
+        ws[6 * 3 + col] = RS(tmp12 - tmp2, P1);
+    }
+    for (int row = 0; row < 6; row++) {
+        const int32_t* w = ws + 6 * row;
+        uint8_t* o = out + (size_t)row * out_stride;
+        int32_t tmp0 = (int32_t)((uint32_t)(w[0] + (1 << (PASS1_BITS + 2))) << CONST_BITS);
+        int32_t tmp2 = w[4];
+        int32_t tmp10 = tmp2 * FIXC(0.707106781);
+        int32_t tmp1 = tmp0 + tmp10;
+        int32_t tmp11 = tmp0 - tmp10 - tmp10;
+        tmp10 = w[2];
+        tmp0 = tmp10 * FIXC(1.224744871);
+        tmp10 = tmp1 + tmp0;
+        int32_t tmp12 = tmp1 - tmp0;
+        int32_t z1 = w[1], z2 = w[3], z3 = w[5];
+        tmp1 = (z1 + z3) * FIXC(0.366025404);
+        tmp0 = tmp1 + (int32_t)((uint32_t)(z1 + z2) << CONST_BITS);
+        tmp2 = tmp1 + (int32_t)((uint32_t)(z3 - z2) << CONST_BITS);
+        tmp1 = (int32_t)((uint32_t)(z1 - z2 - z3) << CONST_BITS);
+        o[0] = range_limit(RS(tmp10 + tmp0, P2));
+        o[5] = range_limit(RS(tmp10 - tmp0, P2));
+        o[1] = range_limit(RS(tmp11 + tmp1, P2));
+        o[4] = range_limit(RS(tmp11 - tmp1, P2));
+        o[2] = range_limit(RS(tmp12 + tmp2, P2));
+        o[3] = range_limit(RS(tmp12 - tmp2, P2));
+    }
+}
+
+/* 10-point kernel: z3 = DC term (already shifted, rounding added), e2/e4/e6 even inputs, o1/o3/o7 odd inputs,
+ * o5s = input 5 shifted left by CONST_BITS; mid = the exact middle pair's odd term; r[] = the 10 unshifted sums
+ * except r[2]/r[7], which pass 1 forms from pre-shifted halves (returned through t22/t12). */
+typedef struct { int32_t s[10]; int32_t t22, t12; } idct10_out;
+static inline void idct10_core(int32_t z3, int32_t e2, int32_t e4, int32_t e6, int32_t o1, int32_t o3, int32_t o5s,
+                               int32_t o7, idct10_out* R) {
+    int32_t z4 = e4;
+    int32_t z1 = z4 * FIXC(1.144122806);
+    int32_t z2 = z4 * FIXC(0.437016024);
+    int32_t tmp10 = z3 + z1, tmp11 = z3 - z2;
+    R->t22 = z3 - (int32_t)((uint32_t)(z1 - z2) << 1);
+    z2 = e2; int32_t z3b = e6;
+    z1 = (z2 + z3b) * FIXC(0.831253876);
+    int32_t tmp12 = z1 + z2 * FIXC(0.513743148);
+    int32_t tmp13 = z1 - z3b * FIXC(2.176250899);
+    int32_t tmp20 = tmp10 + tmp12, tmp24 = tmp10 - tmp12, tmp21 = tmp11 + tmp13, tmp23 = tmp11 - tmp13;
+    z1 = o1; z2 = o3; z4 = o7;
+    tmp11 = z2 + z4;
+    tmp13 = z2 - z4;
+    tmp12 = tmp13 * FIXC(0.309016994);
+    z2 = tmp11 * FIXC(0.951056516);
+    z4 = o5s + tmp12;
+    tmp10 = z1 * FIXC(1.396802247) + z2 + z4;
+    int32_t tmp14 = z1 * FIXC(0.221231742) - z2 + z4;
+    z2 = tmp11 * FIXC(0.587785252);
+    z4 = o5s - tmp12 - (int32_t)((uint32_t)tmp13 << (CONST_BITS - 1));
+    R->t12 = z1 - tmp13;                                      /* caller finishes: pass 1 (.. - z3) << PASS1_BITS, pass 2 (<< CONST_BITS) - z3s */
+    tmp11 = z1 * FIXC(1.260073511) - z2 - z4;
+    tmp13 = z1 * FIXC(0.642039522) - z2 + z4;
+    R->s[0] = tmp20 + tmp10; R->s[9] = tmp20 - tmp10;
+    R->s[1] = tmp21 + tmp11; R->s[8] = tmp21 - tmp11;
+    R->s[3] = tmp23 + tmp13; R->s[6] = tmp23 - tmp13;
+    R->s[4] = tmp24 + tmp14; R->s[5] = tmp24 - tmp14;
+}
+void jo_idct_10x10_block(const int16_t* in, const uint16_t* q, uint8_t* out, int out_stride) {
+    int32_t ws[8 * 10];
+    idct10_out R;
+    for (int col = 0; col < 8; col++) {
+        const int16_t* c = in + col; const uint16_t* qq = q + col;
+        int32_t z5 = DQ(5);
+        idct10_core((int32_t)((uint32_t)DQ(0) << CONST_BITS) + (1 << (P1 - 1)), DQ(2), DQ(4), DQ(6), DQ(1), DQ(3),
+                    (int32_t)((uint32_t)z5 << CONST_BITS), DQ(7), &R);
+        int32_t tmp22 = RS(R.t22, P1);
+        int32_t tmp12 = (int32_t)((uint32_t)(R.t12 - z5) << PASS1_BITS);
+        ws[8 * 0 + col] = RS(R.s[0], P1); ws[8 * 9 + col] = RS(R.s[9], P1);
+        ws[8 * 1 + col] = RS(R.s[1], P1); ws[8 * 8 + col] = RS(R.s[8], P1);
+        ws[8 * 2 + col] = tmp22 + tmp12;  ws[8 * 7 + col] = tmp22 - tmp12;
+        ws[8 * 3 + col] = RS(R.s[3], P1); ws[8 * 6 + col] = RS(R.s[6], P1);
+        ws[8 * 4 + col] = RS(R.s[4], P1); ws[8 * 5 + col] = RS(R.s[5], P1);
+    }
+    for (int row = 0; row < 10; row++) {
+        const int32_t* w = ws + 8 * row;
+        uint8_t* o = out + (size_t)row * out_stride;
+        int32_t z5s = (int32_t)((uint32_t)w[5] << CONST_BITS);
+        idct10_core((int32_t)((uint32_t)(w[0] + (1 << (PASS1_BITS + 2))) << CONST_BITS), w[2], w[4], w[6], w[1], w[3], z5s, w[7], &R);
+        int32_t tmp12 = (int32_t)((uint32_t)R.t12 << CONST_BITS) - z5s;
+        o[0] = range_limit(RS(R.s[0], P2)); o[9] = range_limit(RS(R.s[9], P2));
+        o[1] = range_limit(RS(R.s[1], P2)); o[8] = range_limit(RS(R.s[8], P2));
+        o[2] = range_limit(RS(R.t22 + tmp12, P2)); o[7] = range_limit(RS(R.t22 - tmp12, P2));
+        o[3] = range_limit(RS(R.s[3], P2)); o[6] = range_limit(RS(R.s[6], P2));
+        o[4] = range_limit(RS(R.s[4], P2)); o[5] = range_limit(RS(R.s[5], P2));
+    }
+}
+
+/* 12-point kernel; e2s/e6s are inputs 2 and 6 shifted left by CONST_BITS, e2 the unshifted input 2. */
+static inline void idct12_core(int32_t z3, int32_t e2, int32_t e4, int32_t e6, int32_t o1, int32_t o3, int32_t o5,
+                               int32_t o7, int32_t r[12]) {
+    int32_t z4 = e4 * FIXC(1.224744871);
+    int32_t tmp10 = z3 + z4, tmp11 = z3 - z4;
+    int32_t z1 = e2;
+    z4 = z1 * FIXC(1.366025404);
+    z1 = (int32_t)((uint32_t)z1 << CONST_BITS);
+    int32_t z2 = (int32_t)((uint32_t)e6 << CONST_BITS);
+    int32_t tmp12 = z1 - z2;
+    int32_t tmp21 = z3 + tmp12, tmp24 = z3 - tmp12;
+    tmp12 = z4 + z2;
+    int32_t tmp20 = tmp10 + tmp12, tmp25 = tmp10 - tmp12;
+    tmp12 = z4 - z1 - z2;
+    int32_t tmp22 = tmp11 + tmp12, tmp23 = tmp11 - tmp12;
+    z1 = o1; z2 = o3; int32_t z3o = o5; z4 = o7;
+    tmp11 = z2 * FIXC(1.306562965);
+    int32_t tmp14 = z2 * (-FIX_0_541196100);
+    tmp10 = z1 + z3o;
+    int32_t tmp15 = (tmp10 + z4) * FIXC(0.860918669);
+    tmp12 = tmp15 + tmp10 * FIXC(0.261052384);
+    tmp10 = tmp12 + tmp11 + z1 * FIXC(0.280143716);
+    int32_t tmp13 = (z3o + z4) * (-FIXC(1.045510580));
+    tmp12 += tmp13 + tmp14 - z3o * FIXC(1.478575242);
+    tmp13 += tmp15 - tmp11 + z4 * FIXC(1.586706681);
+    tmp15 += tmp14 - z1 * FIXC(0.676326758) - z4 * FIXC(1.982889723);
+    z1 -= z4;
+    z2 -= z3o;
+    z3o = (z1 + z2) * FIX_0_541196100;
+    tmp11 = z3o + z1 * FIX_0_765366865;
+    tmp14 = z3o - z2 * FIX_1_847759065;
+    r[0] = tmp20 + tmp10; r[11] = tmp20 - tmp10;
+    r[1] = tmp21 + tmp11; r[10] = tmp21 - tmp11;
+    r[2] = tmp22 + tmp12; r[9] = tmp22 - tmp12;
+    r[3] = tmp23 + tmp13; r[8] = tmp23 - tmp13;
+    r[4] = tmp24 + tmp14; r[7] = tmp24 - tmp14;
+    r[5] = tmp25 + tmp15; r[6] = tmp25 - tmp15;
+}
+void jo_idct_12x12_block(const int16_t* in, const uint16_t* q, uint8_t* out, int out_stride) {
+    int32_t ws[8 * 12], r[12];
+    for (int col = 0; col < 8; col++) {
+        const int16_t* c = in + col; const uint16_t* qq = q + col;
+        idct12_core((int32_t)((uint32_t)DQ(0) << CONST_BITS) + (1 << (P1 - 1)), DQ(2), DQ(4), DQ(6), DQ(1), DQ(3), DQ(5), DQ(7), r);
+        for (int k = 0; k < 12; k++) ws[8 * k + col] = RS(r[k], P1);
+    }
+    for (int row = 0; row < 12; row++) {
+        const int32_t* w = ws + 8 * row;
+        uint8_t* o = out + (size_t)row * out_stride;
+        idct12_core((int32_t)((uint32_t)(w[0] + (1 << (PASS1_BITS + 2))) << CONST_BITS), w[2], w[4], w[6], w[1], w[3], w[5], w[7], r);
+        for (int k = 0; k < 12; k++) o[k] = range_limit(RS(r[k], P2));
+    }
+}
+
+/* jddctmgr.c: the block routine for a DCT_scaled_size (the sizes this path can ask for) */
+int jo_idct_scaled_block(int n, const int16_t* in, const uint16_t* q, uint8_t* out, int out_stride) {
+    switch (n) {
+    case 1: jo_idct_1x1_block(in, q, out); return 0;
+    case 2: jo_idct_2x2_block(in, q, out, out_stride); return 0;
+    case 3: jo_idct_3x3_block(in, q, out, out_stride); return 0;
+    case 4: jo_idct_4x4_block(in, q, out, out_stride); return 0;
+    case 5: jo_idct_5x5_block(in, q, out, out_stride); return 0;
+    case 6: jo_idct_6x6_block(in, q, out, out_stride); return 0;
+    case 8: jo_idct_islow_block(in, q, out, out_stride); return 0;
+    case 10: jo_idct_10x10_block(in, q, out, out_stride); return 0;
+    case 12: jo_idct_12x12_block(in, q, out, out_stride); return 0;
+    default: return -1;
+    }
+}
+
 /* flow_scale_spatial[_srgb]_NxN semantics over caller-provided tables (tests load them from
  * tests/golden/block_scaler_tables.npz, i.e. from the reference's own file). */
 void jo_scale_spatial_block(const uint8_t* in /* 8x8, stride in_stride */, int in_stride, int n, int srgb,
@@ -585,32 +774,51 @@ void jo_scale_spatial_block(const uint8_t* in /* 8x8, stride in_stride */, int i
 }
 
 /*
- * Reduced-size pixel stage.  scale_num in {1,2,4}; luma_mode: 0 libjpeg's own reduced IDCT, 1 flow_scale_spatial,
- * 2 flow_scale_spatial_srgb (the reference's default when scaled).  Supported: grayscale, 4:4:4, 4:2:0.
- * Output size: ceil(width*scale_num/8) x ceil(height*scale_num/8) (jdmaster.c jpeg_calc_output_dimensions).
+ * Scaled pixel stage: scale_num in {1..6, 8}; luma_mode: 0 libjpeg's own scaled IDCT, 1 flow_scale_spatial,
+ * 2 flow_scale_spatial_srgb (the reference's default when scaled; luma only, codec_jpeg_wrapper.c:277-278).
+ * Supported: grayscale, 4:4:4, 4:2:2 (h2v1), 4:4:0 (h1v2), 4:2:0.
+ *   jdmaster.c (jpeg_calc_output_dimensions): output = ceil(dim * scale_num / 8); a component's IDCT size starts at
+ *   scale_num and doubles while it stays < 8 before doubling and both sampling ratios allow it -- so 4:2:0 chroma
+ *   decodes at 2*scale_num with no up-sampling, 4:2:2 / 4:4:0 chroma stays at scale_num and is up-sampled.
+ *   jdsample.c (jinit_upsampler): fancy (triangle) up-sampling needs do_fancy_upsampling (libjpeg's default, the
+ *   reference never changes it) AND min_DCT_scaled_size > 1; the h2v1 / h2v2 fancy forms also need
+ *   downsampled_width > 2, otherwise samples are replicated.
  */
+static int comp_idct_size(int scale_num, int hs_c, int vs_c, int hmax, int vmax) {
+    int ssize = scale_num;
+    while (ssize < 8 && (hmax * scale_num) % (hs_c * ssize * 2) == 0 && (vmax * scale_num) % (vs_c * ssize * 2) == 0) ssize *= 2;
+    return ssize;
+}
+
 int jo_jpeg_idct_color_scaled(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2, const uint16_t* qt,
                               int ncomp, const uint8_t* hs, const uint8_t* vs, uint32_t width, uint32_t height,
                               int scale_num, int luma_mode,
                               const int8_t* w7x8, const uint8_t* log2div7, const uint16_t* s2l12, const uint8_t* l2s12,
                               uint8_t* bgra, uint32_t stride) {
     build_ycc();
-    if (scale_num != 1 && scale_num != 2 && scale_num != 4) return JO_ERR_UNSUPPORTED;
+    if (scale_num < 1 || scale_num > 8 || scale_num == 7) return JO_ERR_UNSUPPORTED;
     const int16_t* coef[3] = {coef0, coef1, coef2};
     int hmax = 1, vmax = 1;
     for (int c = 0; c < ncomp; c++) { if (hs[c] > hmax) hmax = hs[c]; if (vs[c] > vmax) vmax = vs[c]; }
-    int is420 = ncomp == 3 && hmax == 2 && vmax == 2 && hs[0] == 2 && vs[0] == 2 && hs[1] == 1 && vs[1] == 1 && hs[2] == 1 && vs[2] == 1;
-    int is444 = ncomp == 3 && hmax == 1 && vmax == 1;
-    if (!(ncomp == 1 || is420 || is444)) return JO_ERR_UNSUPPORTED;
-    uint32_t ow = (width * (uint32_t)scale_num + 7) / 8, oh = (height * (uint32_t)scale_num + 7) / 8;
+    if (ncomp == 3 && !(hs[1] == 1 && vs[1] == 1 && hs[2] == 1 && vs[2] == 1 && hs[0] == hmax && vs[0] == vmax && hmax <= 2 && vmax <= 2))
+        return JO_ERR_UNSUPPORTED;
+    if (ncomp != 1 && ncomp != 3) return JO_ERR_UNSUPPORTED;
+    if (luma_mode != 0 && scale_num == 8) luma_mode = 0;                     /* the selector only acts when scaled < 8 */
+    const uint32_t N = (uint32_t)scale_num;
+    uint32_t ow = (width * N + 7) / 8, oh = (height * N + 7) / 8;
     uint32_t mw = (width + 8u * hmax - 1) / (8u * hmax), mh = (height + 8u * vmax - 1) / (8u * vmax);
+    const int fancy = scale_num > 1;
     uint8_t* plane[3] = {0, 0, 0};
-    uint32_t pw[3];
+    uint32_t pw[3], dw[3], dh[3];
+    int ux[3], uy[3];                                                        /* up-sampling factors left to do (1 or 2) */
     for (int c = 0; c < ncomp; c++) {
-        /* jdmaster.c: a component sub-sampled 2x in both directions takes an IDCT twice as large, no up-sampling */
-        int n = (c > 0 && is420) ? scale_num * 2 : scale_num;
+        int n = comp_idct_size(scale_num, hs[c], vs[c], hmax, vmax);
         uint32_t bw = mw * hs[c], bh = mh * vs[c];
         pw[c] = bw * (uint32_t)n;
+        ux[c] = (hmax * scale_num) / (hs[c] * n);
+        uy[c] = (vmax * scale_num) / (vs[c] * n);
+        dw[c] = (width * hs[c] * (uint32_t)n + (uint32_t)hmax * 8 - 1) / ((uint32_t)hmax * 8);      /* downsampled_width  */
+        dh[c] = (height * vs[c] * (uint32_t)n + (uint32_t)vmax * 8 - 1) / ((uint32_t)vmax * 8);     /* downsampled_height */
         plane[c] = (uint8_t*)malloc((size_t)pw[c] * bh * n);
         if (!plane[c]) { for (int k = 0; k < c; k++) free(plane[k]); return JO_ERR_ALLOC; }
         for (uint32_t by = 0; by < bh; by++)
@@ -621,10 +829,10 @@ int jo_jpeg_idct_color_scaled(const int16_t* coef0, const int16_t* coef1, const 
                     uint8_t full[64];
                     jo_idct_islow_block(blk, qt, full, 8);
                     jo_scale_spatial_block(full, 8, n, luma_mode == 2, w7x8, log2div7, s2l12, l2s12, dst, (int)pw[c]);
-                } else if (n == 8) jo_idct_islow_block(blk, qt + 64 * c, dst, (int)pw[c]);
-                else if (n == 4) jo_idct_4x4_block(blk, qt + 64 * c, dst, (int)pw[c]);
-                else if (n == 2) jo_idct_2x2_block(blk, qt + 64 * c, dst, (int)pw[c]);
-                else jo_idct_1x1_block(blk, qt + 64 * c, dst);
+                } else if (jo_idct_scaled_block(n, blk, qt + 64 * c, dst, (int)pw[c])) {
+                    for (int k = 0; k <= c; k++) free(plane[k]);
+                    return JO_ERR_UNSUPPORTED;
+                }
             }
     }
     for (uint32_t y = 0; y < oh; y++) {
@@ -632,10 +840,40 @@ int jo_jpeg_idct_color_scaled(const int16_t* coef0, const int16_t* coef1, const 
         for (uint32_t x = 0; x < ow; x++) {
             int32_t Y = plane[0][(size_t)y * pw[0] + x];
             if (ncomp == 1) { o[4 * x] = o[4 * x + 1] = o[4 * x + 2] = (uint8_t)Y; o[4 * x + 3] = 255; continue; }
-            int32_t cbv = plane[1][(size_t)y * pw[1] + x], crv = plane[2][(size_t)y * pw[2] + x];
-            o[4 * x + 2] = clamp255(Y + cr_r[crv]);
-            o[4 * x + 1] = clamp255(Y + ((cb_g[cbv] + cr_g[crv]) >> 16));
-            o[4 * x + 0] = clamp255(Y + cb_b[cbv]);
+            int32_t v[2];
+            for (int k = 0; k < 2; k++) {
+                const int c = 1 + k;
+                const uint8_t* P = plane[c];
+                const uint32_t W = pw[c], DW = dw[c], DH = dh[c];
+                if (ux[c] == 1 && uy[c] == 1) v[k] = P[(size_t)y * W + x];
+                else if (ux[c] == 2 && uy[c] == 1) {                          /* h2v1 */
+                    int32_t cx = (int32_t)(x >> 1);
+                    if (!(fancy && DW > 2)) v[k] = cs(P, W, DW, DH, cx, (int32_t)y);
+                    else if (x == 0 || (x == 2 * DW - 1)) v[k] = cs(P, W, DW, DH, cx, (int32_t)y);
+                    else if (x & 1) v[k] = (3 * cs(P, W, DW, DH, cx, (int32_t)y) + cs(P, W, DW, DH, cx + 1, (int32_t)y) + 2) >> 2;
+                    else v[k] = (3 * cs(P, W, DW, DH, cx, (int32_t)y) + cs(P, W, DW, DH, cx - 1, (int32_t)y) + 1) >> 2;
+                } else if (ux[c] == 1 && uy[c] == 2) {                        /* h1v2 */
+                    int32_t cy = (int32_t)(y >> 1);
+                    if (!fancy) v[k] = cs(P, W, DW, DH, (int32_t)x, cy);
+                    else if (y & 1) v[k] = (3 * cs(P, W, DW, DH, (int32_t)x, cy) + cs(P, W, DW, DH, (int32_t)x, cy + 1) + 2) >> 2;
+                    else v[k] = (3 * cs(P, W, DW, DH, (int32_t)x, cy) + cs(P, W, DW, DH, (int32_t)x, cy - 1) + 1) >> 2;
+                } else {                                                       /* h2v2 */
+                    int32_t cx = (int32_t)(x >> 1), cy = (int32_t)(y >> 1);
+                    if (!(fancy && DW > 2)) { v[k] = cs(P, W, DW, DH, cx, cy); continue; }
+                    int32_t ny = (y & 1) ? cy + 1 : cy - 1;
+                    int32_t thiscol = 3 * cs(P, W, DW, DH, cx, cy) + cs(P, W, DW, DH, cx, ny);
+                    if ((x & 1) == 0) {
+                        if (cx == 0) v[k] = (thiscol * 4 + 8) >> 4;
+                        else v[k] = (thiscol * 3 + 3 * cs(P, W, DW, DH, cx - 1, cy) + cs(P, W, DW, DH, cx - 1, ny) + 8) >> 4;
+                    } else {
+                        if (cx == (int32_t)DW - 1) v[k] = (thiscol * 4 + 7) >> 4;
+                        else v[k] = (thiscol * 3 + 3 * cs(P, W, DW, DH, cx + 1, cy) + cs(P, W, DW, DH, cx + 1, ny) + 7) >> 4;
+                    }
+                }
+            }
+            o[4 * x + 2] = clamp255(Y + cr_r[v[1]]);
+            o[4 * x + 1] = clamp255(Y + ((cb_g[v[0]] + cr_g[v[1]]) >> 16));
+            o[4 * x + 0] = clamp255(Y + cb_b[v[0]]);
             o[4 * x + 3] = 255;
         }
     }

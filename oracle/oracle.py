@@ -221,9 +221,10 @@ def scale_spatial_blocks(blocks, n, srgb):
     return out
 
 
-def jpeg_idct_color_scaled(j, scale_num, luma_mode, stride=None):
-    """Reduced-size pixel stage: luma_mode 0 = libjpeg's reduced IDCT, 1 = flow_scale_spatial, 2 = ..._srgb."""
-    if scale_num == 8:
+def jpeg_idct_color_scaled(j, scale_num, luma_mode, stride=None, general=False):
+    """Scaled pixel stage (scale_num 1..6, 8): luma_mode 0 = libjpeg's scaled IDCT, 1 = flow_scale_spatial, 2 = ..._srgb.
+    general=True sends scale_num 8 through the same (sampling-generic) function instead of jo_jpeg_idct_color."""
+    if scale_num == 8 and not general:
         return jpeg_idct_color(j, stride)
     T = block_scaler_tables()
     w, h = j["width"], j["height"]
@@ -231,7 +232,8 @@ def jpeg_idct_color_scaled(j, scale_num, luma_mode, stride=None):
     stride = stride or stride_for_width(ow)
     out = np.zeros((oh, stride), np.uint8)
     hs, vs = np.array(j["hs"], np.uint8), np.array(j["vs"], np.uint8)
-    wn, dn = np.ascontiguousarray(T["weights"][scale_num]), np.ascontiguousarray(T["log2div"][scale_num])
+    k = min(scale_num, 7)                                   # the block scalers exist for 1..7; unused at scale 8
+    wn, dn = np.ascontiguousarray(T["weights"][k]), np.ascontiguousarray(T["log2div"][k])
     rc = lib().jo_jpeg_idct_color_scaled(j["coef"][0].ctypes.data, j["coef"][1].ctypes.data, j["coef"][2].ctypes.data,
                                          j["qt"].ctypes.data, j["ncomp"], hs.ctypes.data, vs.ctypes.data, w, h, scale_num,
                                          luma_mode, wn.ctypes.data, dn.ctypes.data, T["lut_s2l"].ctypes.data,
