@@ -88,7 +88,10 @@ def test_host_buffer_drop_in(golden_dir):
 
 def test_unsupported_and_invalid_arguments():
     with pytest.raises(FlowError) as e:
-        JpegPixelStage(16, 16, 3, (1, 1, 1), (2, 1, 1), 1, DEV)          # h1v2 not implemented
+        JpegPixelStage(16, 16, 3, (2, 2, 1), (1, 1, 1), 1, DEV)          # chroma components must be 1x1
+    assert e.value.kind == ErrorKind.MethodNotImplemented
+    with pytest.raises(FlowError) as e:
+        JpegPixelStage(16, 16, 3, (2, 1, 1), (2, 1, 1), 1, DEV, scale_num=7)   # 7/8 is never requested by the decoder
     assert e.value.kind == ErrorKind.MethodNotImplemented
     with pytest.raises(FlowError) as e:
         JpegPixelStage(0, 16, 3, (2, 1, 1), (2, 1, 1), 1, DEV)
@@ -168,10 +171,9 @@ def test_reference_default_preshrink_path_cfg1():
 
 
 def test_unsupported_scales():
-    for bad in (3, 5, 6, 7, 0, 9):
+    for bad in (7, 0, 9):
         with pytest.raises(FlowError) as e:
             JpegPixelStage(64, 64, 3, (2, 1, 1), (2, 1, 1), 1, DEV, scale_num=bad)
         assert e.value.kind == ErrorKind.MethodNotImplemented
-    with pytest.raises(FlowError) as e:
-        JpegPixelStage(64, 64, 3, (2, 1, 1), (1, 1, 1), 1, DEV, scale_num=4)        # 4:2:2 reduced
-    assert e.value.kind == ErrorKind.MethodNotImplemented
+    st = JpegPixelStage(64, 64, 3, (2, 1, 1), (1, 1, 1), 1, DEV, scale_num=4)      # 4:2:2 reduced: chroma stays 4x4, h2v1 up-sampled
+    assert (st.out_w, st.out_h) == (32, 32)
