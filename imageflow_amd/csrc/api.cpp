@@ -128,6 +128,11 @@ struct ifhip_resample_plan {
     uint32_t *d_h_left = nullptr, *d_h_count = nullptr, *d_h_off = nullptr;
     float *d_v_w = nullptr, *d_h_w = nullptr, *d_h_wu = nullptr;
     uint4* d_h_meta = nullptr;
+    // fast horizontal pass: every output runs the same number G <= 4 of 4-tap groups (moderate ratios)
+    uint32_t h_fast_groups = 0;     // 0: not available (some output needs more than 4 groups)
+    float* d_h_wg = nullptr;        // distinct weight rows, each zero-padded to G groups
+    uint32_t h_wg_floats = 0;
+    uint32_t* d_h_meta2 = nullptr;  // [out_w] first group | row id << 16
     uint32_t h_wu_floats = 0;       // de-duplicated, 4-tap padded horizontal weight rows
     uint32_t h_avg_groups = 0;      // mean 4-tap groups per horizontal chain
     // fused-kernel geometry
@@ -145,7 +150,7 @@ struct ifhip_resample_plan {
 
     ~ifhip_resample_plan() {
         for (void* p : {(void*)d_v_left, (void*)d_v_count, (void*)d_v_off, (void*)d_h_left, (void*)d_h_count,
-                        (void*)d_h_off, (void*)d_v_w, (void*)d_h_w, (void*)d_h_wu, (void*)d_h_meta, (void*)sets[0].d_strips,
+                        (void*)d_h_off, (void*)d_v_w, (void*)d_h_w, (void*)d_h_wu, (void*)d_h_meta, (void*)d_h_wg, (void*)d_h_meta2, (void*)sets[0].d_strips,
                         (void*)sets[1].d_strips})
             if (p) (void)hipFree(p);
         for (auto& kv : schedules) {
@@ -158,8 +163,8 @@ struct ifhip_resample_plan {
 namespace {
 
 size_t fused_lds_bytes(uint32_t n_u, uint32_t nquads, int channels, uint32_t wu_floats, bool w_in_lds, bool l2s_in_lds,
-                       uint32_t lut_copies_log2, bool per_pixel, uint32_t frames = 1) {
-    return fused_lds_layout(n_u, nquads, wu_floats, channels, w_in_lds, l2s_in_lds, lut_copies_log2, per_pixel, frames).total;
+                       uint32_t lut_copies_log2, bool per_pixel, uint32_t frames = 1, uint32_t fast_groups = 0) {
+    return fused_lds_layout(n_u, nquads, wu_floats, channels, w_in_lds, l2s_in_lds, lut_copies_log2, per_pixel, frames, fast_groups).total;
 }
 // Horizontal pass mapping: one lane per output pixel (its C chains interleave, encode + store follow at once, no obuf
 // round trip) measured faster than one lane per (pixel, channel) on every BASELINE shape (cfg2 -2.6 %, cfg2 with alpha
@@ -333,55 +338,66 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         for (const Strip& s : ss.strips) max_nu = std::max(max_nu, s.u1 - s.u0);
         const bool per_pixel = use_per_pixel(max_nu, channels, block);
         const size_t limit = lds_limit();
-        // Frames per workgroup: a source narrower than half the workgroup would leave the CU with a handful of waves
-        // (one workgroup per CU: the tables fill most of the LDS), so F frames share a workgroup and its tables.
-        uint32_t frames = 1;
-        if (ss.strips.size() == 1 && std::getenv("IFHIP_ONE_FRAME_PER_WG") == nullptr) {
-            const uint32_t max_f = std::min<uint32_t>(static_cast<uint32_t>(fused_max_threads(p->slots, channels)) / block, n_images);
-            const Strip& s0 = ss.strips[0];
-            for (uint32_t f = max_f; f > 1; --f)
-                if (fused_lds_bytes(s0.u1 - s0.u0, s0.nquads, channels, p->h_wu_floats, true, a.linear != 0, kMinLutCopiesLog2, per_pixel, f) <= limit) {
-                    frames = f;
-                    break;
-                }
-        }
-        // bands: by the number of workgroups the launch really has (frames / F per strip)
-        const uint32_t want_bands = choose_bands(p, (n_images + frames - 1u) / frames, ss.strips.size());
+        // The fast horizontal pass (same group count G for every output, rows padded with +0 weights) needs the padded
+        // weight rows in LDS and the per-pixel mapping; when that does not fit, plan again for the general pass.
+        uint32_t frames = 1, copies_log2 = kMinLutCopiesLog2, fast_g = 0, wu_floats = p->h_wu_floats;
+        bool w_in_lds = false, l2s_in_lds = false;
         ScheduleOnDevice sd;
-        rc = get_schedule(p, want_bands, fused_shape(p->slots, channels).rows_in_flight, fused_lookahead(p->slots, channels), &sd);
-        if (rc) return rc;
-        a.steps = sd.steps; a.band_begin = sd.band_begin; a.n_bands = sd.n_bands;
-        // LDS budget beyond the minimum the strips were planned for (double-buffered rows + 16 copies of the sRGB->float
-        // table): the de-duplicated horizontal weight rows, then -- by lookup cost -- the second 16 table copies and the
-        // 16 KiB linear->sRGB table (otherwise encoded by threshold search)
-        auto fits = [&](bool w, bool l2s, uint32_t copies_log2) {
-            for (const Strip& s : ss.strips)
-                if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w, l2s, copies_log2, per_pixel, frames) > limit) return false;
-            return true;
-        };
-        const bool w_in_lds = std::getenv("IFHIP_HW_GLOBAL") == nullptr && fits(true, false, kMinLutCopiesLog2);
-        // What goes next depends on where the lookups are: the 16 KiB linear->sRGB table saves an 8-step threshold
-        // search (~40 instructions) per encoded channel, the second set of 16 table copies saves one LDS conflict cycle
-        // per converted sample.  Per output row a strip encodes 3*n_u channels and converts 12*nquads*(in_h/out_h)
-        // samples; thumbnail-sized outputs (cfg2) want the copies first, moderate ratios (cfg3) the encode table.
-        const double enc_cost = 3.0 * max_nu * 40.0;
-        const double conv_cost = 12.0 * ss.max_quads * (static_cast<double>(p->in_h) / std::max<uint32_t>(1u, p->out_h)) * 2.0;
-        const bool l2s_allowed = a.linear && std::getenv("IFHIP_L2S_SEARCH") == nullptr;
-        uint32_t copies_log2 = kMinLutCopiesLog2;
-        bool l2s_in_lds = false;
-        if (enc_cost > conv_cost) {
-            l2s_in_lds = l2s_allowed && fits(w_in_lds, true, kMinLutCopiesLog2);
-            if (fits(w_in_lds, l2s_in_lds, 5)) copies_log2 = 5u;
-        } else {
-            if (fits(w_in_lds, false, 5)) copies_log2 = 5u;
-            l2s_in_lds = l2s_allowed && fits(w_in_lds, true, copies_log2);
+        for (int attempt = (per_pixel && p->h_fast_groups && fused_shape(p->slots, channels).px == 4) ? 0 : 1; attempt < 2; ++attempt) {
+            fast_g = attempt == 0 ? p->h_fast_groups : 0u;
+            wu_floats = fast_g ? p->h_wg_floats : p->h_wu_floats;
+            // Frames per workgroup: a source narrower than half the workgroup would leave the CU with a handful of waves
+            // (one workgroup per CU: the tables fill most of the LDS), so F frames share a workgroup and its tables.
+            frames = 1;
+            if (ss.strips.size() == 1 && std::getenv("IFHIP_ONE_FRAME_PER_WG") == nullptr) {
+                const uint32_t max_f = std::min<uint32_t>(static_cast<uint32_t>(fused_max_threads(p->slots, channels)) / block, n_images);
+                const Strip& s0 = ss.strips[0];
+                for (uint32_t f = max_f; f > 1; --f)
+                    if (fused_lds_bytes(s0.u1 - s0.u0, s0.nquads, channels, wu_floats, true, a.linear != 0, kMinLutCopiesLog2, per_pixel, f, fast_g) <= limit) {
+                        frames = f;
+                        break;
+                    }
+            }
+            // bands: by the number of workgroups the launch really has (frames / F per strip)
+            const uint32_t want_bands = choose_bands(p, (n_images + frames - 1u) / frames, ss.strips.size());
+            rc = get_schedule(p, want_bands, fused_shape(p->slots, channels).rows_in_flight, fused_lookahead(p->slots, channels), &sd);
+            if (rc) return rc;
+            a.steps = sd.steps; a.band_begin = sd.band_begin; a.n_bands = sd.n_bands;
+            // LDS budget beyond the minimum the strips were planned for (double-buffered rows + 16 copies of the sRGB->float
+            // table): the de-duplicated horizontal weight rows, then -- by lookup cost -- the second 16 table copies and the
+            // 16 KiB linear->sRGB table (otherwise encoded by threshold search)
+            auto fits = [&](bool w, bool l2s, uint32_t copies_log2) {
+                for (const Strip& s : ss.strips)
+                    if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, wu_floats, w, l2s, copies_log2, per_pixel, frames, fast_g) > limit) return false;
+                return true;
+            };
+            w_in_lds = std::getenv("IFHIP_HW_GLOBAL") == nullptr && fits(true, false, kMinLutCopiesLog2);
+            // What goes next depends on where the lookups are: the 16 KiB linear->sRGB table saves an 8-step threshold
+            // search (~40 instructions) per encoded channel, the second set of 16 table copies saves one LDS conflict cycle
+            // per converted sample.  Per output row a strip encodes 3*n_u channels and converts 12*nquads*(in_h/out_h)
+            // samples; thumbnail-sized outputs (cfg2) want the copies first, moderate ratios (cfg3) the encode table.
+            const double enc_cost = 3.0 * max_nu * 40.0;
+            const double conv_cost = 12.0 * ss.max_quads * (static_cast<double>(p->in_h) / std::max<uint32_t>(1u, p->out_h)) * 2.0;
+            const bool l2s_allowed = a.linear && std::getenv("IFHIP_L2S_SEARCH") == nullptr;
+            copies_log2 = kMinLutCopiesLog2;
+            l2s_in_lds = false;
+            if (enc_cost > conv_cost) {
+                l2s_in_lds = l2s_allowed && fits(w_in_lds, true, kMinLutCopiesLog2);
+                if (fits(w_in_lds, l2s_in_lds, 5)) copies_log2 = 5u;
+            } else {
+                if (fits(w_in_lds, false, 5)) copies_log2 = 5u;
+                l2s_in_lds = l2s_allowed && fits(w_in_lds, true, copies_log2);
+            }
+            if (!fast_g || w_in_lds) break;
         }
+        a.h_groups = fast_g;
+        if (fast_g) { a.h_wu = p->d_h_wg; a.h_wu_floats = p->h_wg_floats; a.h_meta2 = p->d_h_meta2; }
         a.lut_copies_log2 = copies_log2;
         a.h_w_in_lds = w_in_lds ? 1u : 0u;
         a.l2s_in_lds = l2s_in_lds ? 1u : 0u;
         size_t lds = 0;
         for (const Strip& s : ss.strips)
-            lds = std::max(lds, fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, p->h_wu_floats, w_in_lds, l2s_in_lds, copies_log2, per_pixel, frames));
+            lds = std::max(lds, fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, wu_floats, w_in_lds, l2s_in_lds, copies_log2, per_pixel, frames, fast_g));
         if (lds > kLdsLimit) return fail(IFHIP_INVALID_STATE, "InvalidState: fused kernel LDS plan exceeds the CU (%zu bytes)", lds);
         a.frames_per_wg = frames;
         a.lanes_per_frame = block;
@@ -535,12 +551,42 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
         p->h_wu_floats = static_cast<uint32_t>(wu.size());
         p->h_avg_groups = static_cast<uint32_t>((groups + w - 1u) / w);
     }
+    // Fast horizontal pass: when no output needs more than 4 groups, pad every row to the common count G -- the extra
+    // groups carry weight +0 (exact, as the leading zeros above) -- so that the kernel runs G unrolled groups per
+    // output with immediate LDS offsets, no per-lane trip count and a 4-byte record per output.
+    std::vector<float> wg;
+    std::vector<uint32_t> hmeta2(w);
+    {
+        uint32_t g_max = 0;
+        for (uint32_t u = 0; u < w; ++u) g_max = std::max(g_max, hmeta[u].y);
+        if (g_max >= 2u && g_max <= 4u && std::getenv("IFHIP_NO_FAST_H") == nullptr) {
+            std::map<std::vector<uint32_t>, uint32_t> seen;        // padded row bits -> row id
+            const uint32_t row_floats = g_max * 4u;
+            bool ok = true;
+            for (uint32_t u = 0; u < w && ok; ++u) {
+                std::vector<uint32_t> bits(row_floats, 0u);
+                std::memcpy(bits.data(), wu.data() + hmeta[u].z, hmeta[u].y * 16u);
+                auto it = seen.find(bits);
+                if (it == seen.end()) {
+                    const uint32_t id = static_cast<uint32_t>(seen.size());
+                    if (id >= 65536u) { ok = false; break; }
+                    wg.resize(wg.size() + row_floats);
+                    std::memcpy(wg.data() + static_cast<size_t>(id) * row_floats, bits.data(), row_floats * 4u);
+                    it = seen.emplace(std::move(bits), id).first;
+                }
+                if ((hmeta[u].x >> 2) >= 65536u) { ok = false; break; }
+                hmeta2[u] = (hmeta[u].x >> 2) | (it->second << 16);
+            }
+            if (ok) { p->h_fast_groups = g_max; p->h_wg_floats = static_cast<uint32_t>(wg.size()); }
+        }
+    }
 
     if ((rc = upload(p->wv.left, &p->d_v_left)) || (rc = upload(p->wv.count, &p->d_v_count)) ||
         (rc = upload(p->wv.offset, &p->d_v_off)) || (rc = upload(p->wv.w, &p->d_v_w)) ||
         (rc = upload(p->wh.left, &p->d_h_left)) || (rc = upload(p->wh.count, &p->d_h_count)) ||
         (rc = upload(p->wh.offset, &p->d_h_off)) || (rc = upload(p->wh.w, &p->d_h_w)) || (rc = upload(wu, &p->d_h_wu)) || (rc = upload(hmeta, &p->d_h_meta)))
         return rc;
+    if (p->h_fast_groups && ((rc = upload(wg, &p->d_h_wg)) || (rc = upload(hmeta2, &p->d_h_meta2)))) return rc;
 
     p->slots = max_live_rows(p->wv);
     VSchedule probe;

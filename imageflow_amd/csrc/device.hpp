@@ -31,6 +31,9 @@ struct ResampleArgs {
     const Strip* strips;
     uint32_t n_strips;
     // horizontal tables (fused kernel): per output column {left, taps, first weight (float index into h_wu)}
+    const uint32_t* h_meta2;         // fast horizontal pass (h_groups > 0): [out_w] first 4-column group | weight row id << 16
+    uint32_t h_groups;               // G in 1..4: every output runs exactly G 4-tap groups (rows zero-padded to G groups,
+                                     // h_wu holds them at a fixed pitch of G*4 floats); 0: per-output group counts (h_meta)
     const uint4* h_meta;             // [out_w] {first tap column rounded down to 4, 4-tap groups, weight row offset, taps valid in the last group}
     const float* h_wu;               // de-duplicated weight rows: (left & 3) leading zeros, taps, zero pad to 4; 16-B aligned
     uint32_t h_wu_floats;            // size of h_wu
@@ -92,6 +95,8 @@ constexpr int fused_lookahead(int K, int channels) {
     return fused_shape(K, channels).pipelined ? fused_shape(K, channels).rows_in_flight + 1 : fused_shape(K, channels).rows_in_flight;
 }
 
+constexpr uint32_t fused_group_pitch(int channels) { return channels == 3 ? 48u : 80u; }   // bytes per 4-pixel group, fast pass
+
 // LDS carve of the fused kernel, shared by host (size) and device (offsets); all offsets in bytes, 16-aligned.
 struct FusedLds {
     uint32_t lut, thr, l2s, hmeta, obuf, hw, obuf_stride, inter, plane_pitch, inter_stride, total;
@@ -100,13 +105,14 @@ struct FusedLds {
 __host__ __device__
 #endif
 inline FusedLds fused_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t wu_floats, int channels, bool w_in_lds,
-                                 bool l2s_in_lds, uint32_t lut_copies_log2, bool per_pixel, uint32_t frames) {
+                                 bool l2s_in_lds, uint32_t lut_copies_log2, bool per_pixel, uint32_t frames,
+                                 uint32_t fast_groups = 0) {
     FusedLds l;
     uint32_t off = 0;
     l.lut = off;   off += (256u << lut_copies_log2) * 4u;  // sRGB->float table, bank-interleaved copies
     l.thr = off;   off += 256u * 2u;                       // linear->sRGB thresholds (binary search fallback)
     l.l2s = off;   off += l2s_in_lds ? 16384u : 0u;        // linear->sRGB table
-    l.hmeta = off; off += n_u * 16u;
+    l.hmeta = off; off += fast_groups ? ((n_u * 4u + 15u) & ~15u) : n_u * 16u;     // packed 4-byte records on the fast path
     l.obuf_stride = per_pixel ? 0u : 2u * n_u * 16u;       // horizontally filtered rows j-1 / j (per-chain mapping only)
     l.obuf = off;  off += frames * l.obuf_stride;          // one pair per frame slot
     l.hw = off;    off += w_in_lds ? ((wu_floats * 4u + 15u) & ~15u) : 0u;
@@ -117,6 +123,13 @@ inline FusedLds fused_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t wu_floa
     // pitch is == 4 (mod 64) dwords so that the sub-planes of one group sit 4 banks apart.
     l.plane_pitch = ((nquads * 4u + 63u) & ~63u) + 4u;                         // floats
     l.inter_stride = l.plane_pitch * static_cast<uint32_t>(channels) * 4u;    // bytes per buffered row
+    if (fast_groups) {
+        // Fast horizontal pass: the C 16-byte chunks of a 4-pixel group sit next to each other (group pitch 48 B, or
+        // 80 B with alpha: 12 / 20 banks, so 8 consecutive groups cover all 32 banks), every read of an output is
+        // base + immediate.  G - 1 groups past the staged columns are read with weight +0 and stay zero.
+        l.plane_pitch = 0;
+        l.inter_stride = ((nquads + fast_groups - 1u) * fused_group_pitch(channels) + 15u) & ~15u;
+    }
     l.inter = off; off += frames * 2u * l.inter_stride;    // vertically filtered rows j / j+1, one pair per frame slot
     l.total = off;
     return l;

@@ -15,6 +15,7 @@
 // Build with -ffp-contract=off: every fused multiply-add below is an explicit fmaf, everything else rounds
 // separately, exactly as the arithmetic contract in oracle/if_oracle.c (tests compare bit for bit).
 #include <atomic>
+#include <type_traits>
 
 #include "resample_device.hpp"
 
@@ -41,9 +42,13 @@ namespace ifhip {
 // following source-row steps, a few taps per step, so that its LDS latency and its strictly sequential fmaf chains
 // hide under the vertical pass instead of stopping it.  One LDS-only workgroup barrier per output row.
 // ------------------------------------------------------------------------------------------------------
-template <int K, bool ALPHA, bool WLDS, bool PERPIXEL>
+// FG > 0: the fast horizontal pass (moderate ratios: no output needs more than 4 groups).  Every output runs exactly FG
+// 4-tap groups -- its weight row is zero-padded to FG groups, +0 weights are exact -- fully unrolled with immediate
+// LDS offsets from two base addresses, a 4-byte record per output, groups of the vertically filtered row interleaved.
+template <int K, bool ALPHA, bool WLDS, bool PERPIXEL, int FG = 0>
 __global__ void __launch_bounds__(fused_max_threads(K, ALPHA ? 4 : 3))
 fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
+    static_assert(FG == 0 || (WLDS && PERPIXEL), "the fast horizontal pass keeps its weights in LDS and maps one lane per pixel");
     // `steps` is a separate __restrict__ argument (not a field of `a`) so that the compiler can prove the canvas
     // stores never clobber it and keeps the per-step 64-byte records on the scalar path.
     constexpr int C = ALPHA ? 4 : 3;
@@ -73,8 +78,10 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     const Strip strip = a.strips[strip_i];
     const uint32_t n_u = strip.u1 - strip.u0;
 
+    constexpr uint32_t fast_g = FG;
+    constexpr uint32_t GP = fused_group_pitch(C);                      // bytes per interleaved 4-pixel group (fast pass)
     const FusedLds L = fused_lds_layout(n_u, strip.nquads, a.h_wu_floats, C, WLDS, a.l2s_in_lds != 0, a.lut_copies_log2, PERPIXEL,
-                                        a.frames_per_wg);
+                                        a.frames_per_wg, fast_g);
     float* lut_banked = reinterpret_cast<float*>(smem + L.lut);      // [256][32] floats, one copy per bank
     uint16_t* thr = reinterpret_cast<uint16_t*>(smem + L.thr);       // 256 linear->sRGB thresholds
     uint4* hmeta = reinterpret_cast<uint4*>(smem + L.hmeta);         // per output column {left - cx0, taps, w offset}
@@ -92,10 +99,18 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
         for (uint32_t i = wtid; i < 1024u; i += WT)
             reinterpret_cast<uint4*>(smem + L.l2s)[i] = reinterpret_cast<const uint4*>(a.l2s)[i];
     const BankedLut lut{lut_banked, wtid & ((1u << a.lut_copies_log2) - 1u), a.lut_copies_log2};
-    for (uint32_t i = wtid; i < n_u; i += WT) {
-        uint4 m = a.h_meta[strip.u0 + i];
-        m.x -= strip.cx0;
-        hmeta[i] = m;
+    uint32_t* hmeta2 = reinterpret_cast<uint32_t*>(smem + L.hmeta);  // fast pass: first group (relative to the strip) | row id << 16
+    if constexpr (FG > 0) {
+        for (uint32_t i = wtid; i < n_u; i += WT) hmeta2[i] = a.h_meta2[strip.u0 + i] - (strip.cx0 >> 2);
+        // the groups past the staged columns are read (with weight +0) and never written: they must hold finite values
+        float4* z = reinterpret_cast<float4*>(smem + L.inter);
+        for (uint32_t i = wtid; i < (a.frames_per_wg * 2u * L.inter_stride) >> 4; i += WT) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        for (uint32_t i = wtid; i < n_u; i += WT) {
+            uint4 m = a.h_meta[strip.u0 + i];
+            m.x -= strip.cx0;
+            hmeta[i] = m;
+        }
     }
     if (WLDS) {
         const float4* src4 = reinterpret_cast<const float4*>(a.h_wu);
@@ -225,6 +240,35 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             store_pixel<ALPHA>(a, img, j, strip.u0 + ul, h01.x, h01.y, ALPHA ? h23.x : h2, ALPHA ? h23.y : 1.0f, tb);
         }
     };
+    // Mapping 2, fast form: two base addresses per output, everything else immediates.
+    auto h_run_row_pixels_fast = [&](uint32_t j, const float* vrow) {
+        constexpr uint32_t G = FG > 0 ? FG : 1;
+        for (uint32_t ul = tid; ul < n_store; ul += T) {
+            const uint32_t m = hmeta2[ul];
+            const unsigned char* sp = reinterpret_cast<const unsigned char*>(vrow) + (m & 0xffffu) * GP;
+            const float4* wp = reinterpret_cast<const float4*>(hw_lds) + (m >> 16) * G;
+            f32x2 h01 = {0.0f, 0.0f}, h23 = {0.0f, 0.0f};
+            float h2 = 0.0f;
+#pragma unroll
+            for (uint32_t q = 0; q < G; ++q) {
+                const float4* g = reinterpret_cast<const float4*>(sp + q * GP);
+                const float4 w = wp[q];
+                h_pair_group(h01, w, g[0], g[1]);
+                if (ALPHA) h_pair_group(h23, w, g[2], g[3]);
+                else h_single_group(h2, w, g[2]);
+                // One group's operands live at a time.  The empty asm statements pin every chain's state here: without them
+                // the optimiser sinks the c2 chain down to its first use (the encode), keeps all G groups' weights and
+                // samples alive until then, and the ring accumulators of the vertical pass go to scratch -- whose
+                // loads share vmcnt with the source rows in flight.
+                asm volatile("" : "+v"(h01));
+                if (ALPHA) asm volatile("" : "+v"(h23));
+                else asm volatile("" : "+v"(h2));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const OutTables<BankedLut, ThresholdL2S> tb{lut, ThresholdL2S{thr, l2s_lds}};
+            store_pixel<ALPHA>(a, img, j, strip.u0 + ul, h01.x, h01.y, ALPHA ? h23.x : h2, ALPHA ? h23.y : 1.0f, tb);
+        }
+    };
     int h_out_row = -1;              // output row whose horizontal result is waiting in obuf (uniform), -1: none
     auto h_store_row = [&](uint32_t j, const float* orow) {      // output stage of a horizontally filtered row
         // the lanes at the top of the workgroup take it: the chains sit on the lowest lanes
@@ -321,7 +365,18 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                     if (st.flush_slot == s) {
                         if (lane_on) {
                             const uint32_t pp4 = plane_pitch >> 2;
-                            if constexpr (PX == 4) {
+                            if constexpr (FG > 0) {
+                                static_assert(FG == 0 || PX == 4, "fast pass: 4 source pixels per lane");
+                                float4* g4 = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(dst_row) + tid * GP);
+                                g4[0] = make_float4(acc_at(s, 0, 0), acc_at(s, 0, 1), acc_at(s, 1, 0), acc_at(s, 1, 1));
+                                g4[1] = make_float4(acc_at(s, 2, 0), acc_at(s, 2, 1), acc_at(s, 3, 0), acc_at(s, 3, 1));
+                                if (ALPHA) {
+                                    g4[2] = make_float4(acc_at(s, 0, 2), acc_at(s, 0, C - 1), acc_at(s, 1, 2), acc_at(s, 1, C - 1));
+                                    g4[3] = make_float4(acc_at(s, 2, 2), acc_at(s, 2, C - 1), acc_at(s, 3, 2), acc_at(s, 3, C - 1));
+                                } else {
+                                    g4[2] = make_float4(acc_at(s, 0, 2), acc_at(s, 1, 2), acc_at(s, 2, 2), acc_at(s, 3, 2));
+                                }
+                            } else if constexpr (PX == 4) {
                                 float4* g4 = reinterpret_cast<float4*>(dst_row + 4u * tid);
                                 g4[0] = make_float4(acc_at(s, 0, 0), acc_at(s, 0, 1), acc_at(s, 1, 0), acc_at(s, 1, 1));
                                 g4[pp4] = make_float4(acc_at(s, 2, 0), acc_at(s, 2, 1), acc_at(s, 3, 0), acc_at(s, 3, 1));
@@ -351,7 +406,8 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                 lds_barrier();
                 if constexpr (h_per_pixel) {
 #if !defined(IFHIP_EXP_NO_CHAIN)
-                    h_run_row_pixels(j, dst_row);
+                    if constexpr (FG > 0) h_run_row_pixels_fast(j, dst_row);
+                    else h_run_row_pixels(j, dst_row);
 #endif
                 } else {
 #if !defined(IFHIP_EXP_NO_STORE)
@@ -373,19 +429,19 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
 }
 
 
-template <int K, bool ALPHA, bool WLDS, bool PERPIXEL>
+template <int K, bool ALPHA, bool WLDS, bool PERPIXEL, int FG = 0>
 static hipError_t launch_variant(const ResampleArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
     // raise the dynamic-LDS cap once per kernel variant and device (it is sticky), not on every launch
-    static std::atomic<size_t> cap[16];
+    static std::atomic<size_t> cap[16];      // (one per instantiation of this function template)
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::atomic<size_t>& c = cap[dev & 15];
     if (c.load(std::memory_order_relaxed) < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_resample_kernel<K, ALPHA, WLDS, PERPIXEL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_resample_kernel<K, ALPHA, WLDS, PERPIXEL, FG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsCap));
         c.store(kFusedLdsCap, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((fused_resample_kernel<K, ALPHA, WLDS, PERPIXEL>), grid, block, lds, st, a, a.steps);
+    hipLaunchKernelGGL((fused_resample_kernel<K, ALPHA, WLDS, PERPIXEL, FG>), grid, block, lds, st, a, a.steps);
     return hipGetLastError();
 }
 
@@ -397,6 +453,20 @@ static hipError_t launch_variant(const ResampleArgs& a, dim3 grid, dim3 block, s
 hipError_t IFHIP_CAT(launch_fused_k, IFHIP_FUSED_K)(const ResampleArgs& a, bool alpha, bool per_pixel, dim3 grid, dim3 block,
                                                     size_t lds, hipStream_t st) {
     constexpr int K = IFHIP_FUSED_K;
+    if (a.h_groups) {                          // fast horizontal pass: weights in LDS, one lane per pixel (host guarantees both)
+        if constexpr (fused_shape(K, 3).px == 4 && fused_shape(K, 4).px == 4) {
+            switch ((alpha ? 8 : 0) | a.h_groups) {
+            case 2: return launch_variant<K, false, true, true, 2>(a, grid, block, lds, st);
+            case 3: return launch_variant<K, false, true, true, 3>(a, grid, block, lds, st);
+            case 4: return launch_variant<K, false, true, true, 4>(a, grid, block, lds, st);
+            case 10: return launch_variant<K, true, true, true, 2>(a, grid, block, lds, st);
+            case 11: return launch_variant<K, true, true, true, 3>(a, grid, block, lds, st);
+            case 12: return launch_variant<K, true, true, true, 4>(a, grid, block, lds, st);
+            default: break;
+            }
+        }
+        return hipErrorInvalidValue;
+    }
     const bool wl = a.h_w_in_lds != 0;
     const int sel = (alpha ? 4 : 0) | (wl ? 2 : 0) | (per_pixel ? 1 : 0);
     switch (sel) {
