@@ -87,7 +87,7 @@ struct EntropyArgs {
     uint32_t* start_cz;
     int4* cnt;                                       // per sub-sequence {blocks started, DC sum comp 0, 1, 2}
     int4* prefix;                                    // exclusive per-segment scan of cnt
-    uint32_t* changed;                               // lanes whose exit state moved this round
+    uint32_t* changed;                               // [16] lanes whose exit state moved in round r, at [r & 15]
     uint32_t* errors;                                // bit 0 invalid code, 1 bad DC category, 2 run past 63, 3 short segment
     int16_t* coef[3];                                // [image][bh][bw][64]
     uint32_t round;
@@ -106,7 +106,12 @@ __constant__ uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18
 // straddle two files) read theirs from global memory.
 constexpr uint32_t kLanes = 256;
 constexpr uint32_t kMarginSubs = 3;                  // > the longest possible block (64 symbols x 31 bits) + lookahead
-constexpr uint32_t kStageWords = (kLanes + kMarginSubs) * kSubWords;
+#ifndef IFHIP_ENT_WARM
+#define IFHIP_ENT_WARM 0
+#endif
+constexpr uint32_t kWarmBits = IFHIP_ENT_WARM;       // speculative lanes start this many bits early (multiple of 32)
+constexpr uint32_t kWarmWords = kWarmBits / 32u;
+constexpr uint32_t kStageWords = (kLanes + kMarginSubs) * kSubWords + kWarmWords;
 
 struct BitSrc {
     const uint32_t* lds;         // staged words, skewed
@@ -125,8 +130,12 @@ struct BitSrc {
     }
 };
 
+__device__ __forceinline__ uint32_t stage_word0(uint32_t first_sub) {       // first staged word: the warm-up bits sit in front
+    const uint32_t w = first_sub * kSubWords;
+    return w >= kWarmWords ? w - kWarmWords : 0u;
+}
 __device__ __forceinline__ void stage_stream(const EntropyArgs& a, uint32_t* lds_words, uint32_t first_sub) {
-    const uint32_t word0 = first_sub * kSubWords;
+    const uint32_t word0 = stage_word0(first_sub);
     const uint32_t total = (a.n_sub + 2u) * kSubWords;                 // the buffer carries 64 slack words
     for (uint32_t r = threadIdx.x; r < kStageWords; r += kLanes) {
         const uint32_t w = word0 + r;
@@ -173,12 +182,19 @@ __device__ __forceinline__ void decode_symbol(const EntropyGeom& g, BitReader& b
     const Tab* t = tabs + comp * 2u + (ac ? 1u : 0u);
     const uint32_t bits = br.peek();
     uint32_t e = t->lut[bits >> (32u - kLutBits)];
-    if (e == 0u) {                                                   // code longer than 9 bits (rare), or garbage
+    if (e == 0u) {                                                   // code longer than the lookup (2 % of the symbols), or garbage
+        // jdhuff.c's "l = min{l : code_l <= maxcode[l]}" without the dependent chain: all candidate lengths are compared
+        // at once (maxcode[] arrives in wide reads), so the slow path costs three LDS round trips instead of up to nine
+        // -- with 64 lanes per wave, three iterations in ten have at least one lane here.
         uint32_t l = kLutBits + 1u;
-        int32_t code = static_cast<int32_t>(bits >> (32u - l));
-        while (l <= 16u && code > t->maxcode[l]) { ++l; code = static_cast<int32_t>(bits >> (32u - l)); }
+#pragma unroll
+        for (uint32_t k = kLutBits + 1u; k <= 16u; ++k)
+            l += static_cast<int32_t>(bits >> (32u - k)) > t->maxcode[k] ? 1u : 0u;      // monotone in k, see derive_table
         if (l > 16u) { err |= 1u; e = 16u << 8; }
-        else e = (l << 8) | t->val[(code + t->valoff[l]) & 255];
+        else {
+            const int32_t code = static_cast<int32_t>(bits >> (32u - l));
+            e = (l << 8) | t->val[(code + t->valoff[l]) & 255];
+        }
     }
     const uint32_t len = e >> 8, sym = e & 255u;
     const uint32_t r = ac ? sym >> 4 : 0u, sz = sym & 15u;
@@ -248,7 +264,7 @@ __global__ void __launch_bounds__(kLanes) entropy_round_kernel(const EntropyArgs
     }
     ex_p[t] = my_p; ex_cz[t] = my_cz;
     __syncthreads();
-    const BitSrc src{lds_words, first_sub * kSubWords};
+    const BitSrc src{lds_words, stage_word0(first_sub)};
     const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end);
     bool pending = false;
     for (uint32_t it = 0; it < kInnerRounds; ++it) {
@@ -256,8 +272,21 @@ __global__ void __launch_bounds__(kLanes) entropy_round_kernel(const EntropyArgs
             used_p = p0; used_cz = cz0;
             uint32_t c = cz0 >> 8, z = cz0 & 255u, err = 0;
             int32_t n = 0, dc[3] = {0, 0, 0};
-            BitReader br(src, p0);
+            // Warm-up (speculative start only): begin kWarmBits in front of the sub-sequence, so that the decode has that
+            // many more bits to fall into step with the true one before the part that counts begins; the state at the
+            // first symbol boundary inside the sub-sequence is then the start state the lane "used".
+            const bool warm = kWarmBits != 0u && a.round == 0u && it == 0u && !first;
+            const uint32_t seg_bit0 = sg.first_sub * kSubBits;
+            BitReader br(src, warm ? max(seg_bit0, p0 - min(p0, kWarmBits)) : p0);
             with_tables(a, lds_tabs, wg_image, sg.image, [&](auto tabs) {
+                if (warm) {
+                    while (br.p < p0) {
+                        uint32_t kind, at = 0;
+                        int32_t value = 0;
+                        decode_symbol(a.g, br, tabs, c, z, kind, at, value, err);
+                    }
+                    used_p = br.p; used_cz = (c << 8) | z;
+                }
                 while (br.p < end) {
                     uint32_t kind, at = 0;
                     int32_t value = 0;
@@ -285,33 +314,37 @@ __global__ void __launch_bounds__(kLanes) entropy_round_kernel(const EntropyArgs
     if (have_cnt) a.cnt[s] = my_cnt;
     // another launch is needed if this lane's exit moved (its successor may sit in the next workgroup) or the inner
     // iteration was cut short
-    if (a.round > 0u && (my_p != old_p || my_cz != old_cz || need)) atomicAdd(a.changed, 1u);
+    if (a.round > 0u && (my_p != old_p || my_cz != old_cz || need)) atomicAdd(a.changed + (a.round & 15u), 1u);
 }
 
-// exclusive scan of cnt over the sub-sequences of one segment (one workgroup per segment)
-__global__ void __launch_bounds__(256) entropy_scan_kernel(const EntropyArgs a) {
-    __shared__ int4 sh[256];
+// exclusive scan of cnt over the sub-sequences of one segment: one workgroup of 1024 lanes per segment, every lane sums
+// a contiguous run, the 1024 partial sums are scanned with wave shuffles + one LDS step, then every lane walks its run
+// again writing the prefixes (a 4K file is one segment of ~13 000 sub-sequences: 13 per lane)
+__device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ int4 shfl_up4(int4 v, uint32_t d) {
+    return make_int4(__shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64), __shfl_up(v.z, d, 64), __shfl_up(v.w, d, 64));
+}
+__global__ void __launch_bounds__(1024) entropy_scan_kernel(const EntropyArgs a) {
+    __shared__ int4 wave_tot[16];
     const Segment sg = a.segs[blockIdx.x];
-    int4 carry = make_int4(0, 0, 0, 0);
-    for (uint32_t base = 0; base < sg.n_sub; base += 256u) {
-        const uint32_t i = base + threadIdx.x;
-        int4 v = i < sg.n_sub ? a.cnt[sg.first_sub + i] : make_int4(0, 0, 0, 0);
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (uint32_t d = 1; d < 256u; d <<= 1) {
-            int4 o = make_int4(0, 0, 0, 0);
-            if (threadIdx.x >= d) o = sh[threadIdx.x - d];
-            __syncthreads();
-            int4 m = sh[threadIdx.x];
-            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
-            sh[threadIdx.x] = m;
-            __syncthreads();
-        }
-        const int4 inc = sh[threadIdx.x];
-        if (i < sg.n_sub) a.prefix[sg.first_sub + i] = make_int4(carry.x + inc.x - v.x, carry.y + inc.y - v.y, carry.z + inc.z - v.z, carry.w + inc.w - v.w);
-        const int4 tot = sh[255];
-        __syncthreads();
-        carry.x += tot.x; carry.y += tot.y; carry.z += tot.z; carry.w += tot.w;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t per = (sg.n_sub + 1023u) / 1024u;
+    const uint32_t lo = min(t * per, sg.n_sub), hi = min(lo + per, sg.n_sub);
+    int4 sum = make_int4(0, 0, 0, 0);
+    for (uint32_t i = lo; i < hi; ++i) sum = add4(sum, a.cnt[sg.first_sub + i]);
+    int4 inc = sum;                                                  // inclusive scan inside the wave
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const int4 o = shfl_up4(inc, d);
+        if (lane >= d) inc = add4(inc, o);
+    }
+    if (lane == 63u) wave_tot[wave] = inc;
+    __syncthreads();
+    int4 run = make_int4(inc.x - sum.x, inc.y - sum.y, inc.z - sum.z, inc.w - sum.w);
+    for (uint32_t w = 0; w < wave; ++w) run = add4(run, wave_tot[w]);
+    for (uint32_t i = lo; i < hi; ++i) {
+        a.prefix[sg.first_sub + i] = run;
+        run = add4(run, a.cnt[sg.first_sub + i]);
     }
 }
 
@@ -347,7 +380,7 @@ __global__ void __launch_bounds__(kLanes) entropy_write_kernel(const EntropyArgs
     const int4 pre = a.prefix[s];
     int32_t dc[3] = {pre.y, pre.z, pre.w};
     int32_t block = pre.x - 1;                               // last block started before this lane
-    const BitSrc src{lds_words, first_sub * kSubWords};
+    const BitSrc src{lds_words, stage_word0(first_sub)};
     int16_t* row = reinterpret_cast<int16_t*>(lds_blk + threadIdx.x * kBlkPitch);
     uint2* row2 = reinterpret_cast<uint2*>(lds_blk + threadIdx.x * kBlkPitch);
     const uint32_t B = a.g.blocks_per_mcu;
@@ -534,7 +567,11 @@ void derive_table(const HuffSpec& h, DerivedTab* t) {
                     if (first + f < (1u << kLutBits)) t->lut[first + f] = static_cast<uint16_t>((l << 8) | h.vals[k]);
             }
         }
-        t->maxcode[l] = h.bits[l] ? code - 1 : -1;
+        // Largest code of this length.  A length without codes gets the previous bound extended by a 1 bit instead of
+        // jdhuff's -1: the serial search "first l with code_l <= maxcode[l]" is unchanged (it only ever reaches l when
+        // code_(l-1) > maxcode[l-1], and then code_l > (maxcode[l-1] << 1 | 1) as well), and "code_l > maxcode[l]" becomes
+        // monotone in l, which lets the kernel count the lengths in parallel.
+        t->maxcode[l] = h.bits[l] ? code - 1 : (l > 1 ? (t->maxcode[l - 1] < 0 ? -1 : ((t->maxcode[l - 1] << 1) | 1)) : -1);
         code <<= 1;
     }
     t->maxcode[17] = 0x7fffffff;
@@ -585,7 +622,7 @@ struct ifhip_jpeg_entropy {
     std::vector<uint16_t> qt;                        // [n][3][64]
     EntropyArgs a;
     std::vector<void*> owned;
-    uint32_t* h_flags = nullptr;                     // pinned: [0] changed, [1] errors
+    uint32_t* h_flags = nullptr;                     // pinned copy of changed[16] + errors
     ~ifhip_jpeg_entropy() {
         for (void* p : owned) if (p) (void)hipFree(p);
         if (h_flags) (void)hipHostFree(h_flags);
@@ -813,9 +850,9 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     if ((rc = dev_alloc<uint32_t>(e.get(), &a.start_cz, a.n_sub))) return rc;
     if ((rc = dev_alloc<int4>(e.get(), &a.cnt, a.n_sub))) return rc;
     if ((rc = dev_alloc<int4>(e.get(), &a.prefix, a.n_sub))) return rc;
-    if ((rc = dev_alloc<uint32_t>(e.get(), &a.changed, 2))) return rc;
-    a.errors = a.changed + 1;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_flags), 2 * sizeof(uint32_t), hipHostMallocDefault));
+    if ((rc = dev_alloc<uint32_t>(e.get(), &a.changed, 17))) return rc;
+    a.errors = a.changed + 16;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_flags), 17 * sizeof(uint32_t), hipHostMallocDefault));
     if (timing)
         std::fprintf(stderr, "[ifhip entropy create] threads %u (hw %u): parse+unstuff %.2f ms, +pack %.2f ms, +upload/alloc %.2f ms\n",
                      n_threads, hw, t_parse, t_pack, ms_since(t_start));
@@ -877,30 +914,45 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
     a.coef[0] = d_coef0; a.coef[1] = d_coef1; a.coef[2] = d_coef2;
     if ((reinterpret_cast<uintptr_t>(d_coef0) | reinterpret_cast<uintptr_t>(d_coef1) | reinterpret_cast<uintptr_t>(d_coef2)) & 15u)
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: coefficient planes must be 16-byte aligned");
-    HIP_TRY(hipMemsetAsync(a.changed, 0, 2 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(a.changed, 0, 17 * sizeof(uint32_t), st));
     const dim3 grid((a.n_sub + 255u) / 256u), block(256);
-    uint32_t r = 0;
     const uint32_t max_rounds = a.n_sub + 2u;
-    for (;; ++r) {
+    // Rounds 0..2 (speculative decode with the fixpoint iteration inside every workgroup; corrections that cross a
+    // workgroup boundary; the confirmation that nothing moved any more), the scan and the write pass are enqueued
+    // back to back, and the host looks at the flags once: the typical batch needs exactly these launches.  If round 2
+    // still moved something, more rounds run (one look per round) and scan + write are repeated -- the write pass
+    // stores every block in full, so the repeat simply overwrites.
+    uint32_t r = 0;
+    for (; r < 3u; ++r) {
         a.round = r;
         hipLaunchKernelGGL(entropy_round_kernel, grid, block, 0, st, a);
         HIP_TRY(hipGetLastError());
-        if (r == 0) continue;
-        HIP_TRY(hipMemcpyAsync(e->h_flags, a.changed, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (e->h_flags[0] == 0u) break;
-        if (r >= max_rounds) return fail(IFHIP_INVALID_STATE, "InvalidState: entropy decode did not converge");
-        HIP_TRY(hipMemsetAsync(a.changed, 0, sizeof(uint32_t), st));
     }
-    a.round = r;
-    hipLaunchKernelGGL(entropy_scan_kernel, dim3(a.n_seg), block, 0, st, a);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(entropy_write_kernel, grid, block, 0, st, a);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(e->h_flags + 1, a.errors, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    r = 2u;
+    for (;;) {
+        a.round = r;
+        hipLaunchKernelGGL(entropy_scan_kernel, dim3(a.n_seg), dim3(1024), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(entropy_write_kernel, grid, block, 0, st, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(e->h_flags, a.changed, 17 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (e->h_flags[r & 15u] == 0u) break;                        // the last round confirmed the fixpoint
+        for (;;) {                                                   // rare: long-range corrections
+            ++r;
+            if (r >= max_rounds) return fail(IFHIP_INVALID_STATE, "InvalidState: entropy decode did not converge");
+            HIP_TRY(hipMemsetAsync(a.changed + (r & 15u), 0, sizeof(uint32_t), st));
+            a.round = r;
+            hipLaunchKernelGGL(entropy_round_kernel, grid, block, 0, st, a);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(e->h_flags, a.changed, 17 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (e->h_flags[r & 15u] == 0u) break;
+        }
+        HIP_TRY(hipMemsetAsync(a.errors, 0, sizeof(uint32_t), st));      // flags of the discarded write pass
+    }
     if (rounds) *rounds = r + 1u;
-    if (e->h_flags[1]) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: corrupt entropy-coded data (flags 0x%x)", e->h_flags[1]);
+    if (e->h_flags[16]) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: corrupt entropy-coded data (flags 0x%x)", e->h_flags[16]);
     return IFHIP_OK;
 }
 

@@ -162,6 +162,36 @@ def test_8k_lanczos_sharpen_matte_cfg5_reduced_and_strips():
     assert p.kernel_kind() == 0
 
 
+def test_full_size_8k_cfg5_frame_with_f32_dump():
+    """BASELINE config 5 at FULL size: 7680x4320 -> 400x225 Lanczos (window 3), sharpen_percent 15, alpha meaningful,
+    flattened over a white matte in linear light; BGRA8 bit-exact and the whole f32 working buffer 0 ULP."""
+    fr = U.random_frames(2, 7680, 4320, seed0=77, alpha=True)
+    p = run_case(7680, 4320, 400, 225, frames=fr, filt=Filter.Lanczos, sharpen=15.0, alpha=True,
+                 compose=BitmapCompositing.BlendWithMatte, matte=0xFFFFFFFF)
+    assert p.kernel_kind(True) == 0
+
+
+def test_full_size_cfg3_pyramid_four_frames():
+    """BASELINE config 3 at full size with n = 4 frames: 3840x2160 -> 1600x900 -> {1200x675 -> 400x225, 800x450}, every
+    level of every frame byte-equal to the oracle chain (levels feed each other on the device)."""
+    n = 4
+    fr = np.concatenate([U.gradient_frames(2, 3840, 2160, k0=11), U.random_frames(2, 3840, 2160, seed0=3100, alpha=False)])
+    src = Bitmap.from_numpy(fr, 3840, 2160, fr.shape[2], DEV)
+    sizes = {"1600": (1600, 900), "1200": (1200, 675), "800": (800, 450), "400": (400, 225)}
+    dev = {k: Bitmap.create_u8(n, w, h, DEV) for k, (w, h) in sizes.items()}
+    for a, b in (("src", "1600"), ("1600", "1200"), ("1600", "800"), ("1200", "400")):
+        scale_and_render(src if a == "src" else dev[a], dev[b], ScaleAndRenderParams(0, 0, *sizes[b]))
+    torch.cuda.synchronize()
+    host = {"src": fr}
+    for a, b in (("src", "1600"), ("1600", "1200"), ("1600", "800"), ("1200", "400")):
+        w, h = sizes[b]
+        iw, ih = (3840, 2160) if a == "src" else sizes[a]
+        exp = np.zeros((n, h, U.stride_for(w)), np.uint8)
+        U.oracle_render(host[a], iw, ih, exp, w, h, 0, 0, w, h)
+        host[b] = exp
+        assert np.array_equal(dev[b].to_numpy(), exp), b
+
+
 def test_host_buffer_drop_in_matches_oracle():
     from oracle import oracle as O
     fr = U.random_frames(1, 333, 222, seed0=9)[0]
