@@ -26,6 +26,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <cstdio>
 #include <vector>
 
@@ -98,88 +99,84 @@ __constant__ uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18
                                     15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 // ---- per-workgroup staging -------------------------------------------------------------------------------------
-// A workgroup of 256 lanes owns 256 consecutive sub-sequences = 32 KiB of contiguous stream.  Every lane walks its own
-// 128 bytes, so direct global reads are 64 different cache lines per wave instruction; instead the workgroup copies its
-// span (plus kMarginSubs sub-sequences of overshoot room) into LDS with coalesced loads.  One pad dword per 32-word
-// chunk makes the lane-to-lane stride 33 dwords: conflict-free when the lanes read at the same offset of their chunks.
-// The Huffman tables of the workgroup's first image go to LDS too; lanes of any other image (only in workgroups that
-// straddle two files) read theirs from global memory.
+// A workgroup of 256 lanes owns 256 consecutive sub-sequences = 32 KiB of contiguous stream (plus kMarginSubs
+// sub-sequences of overshoot room), copied into LDS with coalesced loads.  The LDS copy is WORD-MAJOR: word j of
+// sub-sequence t sits at row j, column t (row pitch kRowPitch dwords), so that
+//   * the lanes of a wave, each walking its own sub-sequence, touch consecutive banks whatever their progress;
+//   * the two words a peek needs are one row apart, because row 32 repeats row 0 shifted by one column (word 0 of the
+//     NEXT sub-sequence), and a lane that runs past its own sub-sequence simply moves on to the next column.
+// The reader keeps nothing but the bit position: every symbol costs one two-word LDS read and one 64-bit shift instead
+// of a register bit buffer with its top-up arithmetic (the symbol loop is bound by instruction issue when the wave is
+// full and by its dependent chain when a lone lane carries a correction; both shrink with the instruction count).
 constexpr uint32_t kLanes = 256;
 constexpr uint32_t kMarginSubs = 3;                  // > the longest possible block (64 symbols x 31 bits) + lookahead
-#ifndef IFHIP_ENT_WARM
-#define IFHIP_ENT_WARM 0
-#endif
-constexpr uint32_t kWarmBits = IFHIP_ENT_WARM;       // speculative lanes start this many bits early (multiple of 32)
-constexpr uint32_t kWarmWords = kWarmBits / 32u;
-constexpr uint32_t kStageWords = (kLanes + kMarginSubs) * kSubWords + kWarmWords;
+constexpr uint32_t kCols = kLanes + kMarginSubs;     // staged sub-sequences
+constexpr uint32_t kRowPitch = kCols + 2u;           // dwords per row (odd: rows start in different banks)
+constexpr uint32_t kStageDwords = (kSubWords + 1u) * kRowPitch;
+static_assert(kCols + 1u <= kRowPitch, "row pitch");
 
 struct BitSrc {
-    const uint32_t* lds;         // staged words, skewed
-    uint32_t word0;              // absolute word index of lds[0]
-    // Every read of a lane stays inside the staged span: a lane starts inside its workgroup's 256 sub-sequences and
-    // runs at most one block (< 2 048 bits) plus 64 bits of lookahead past them; the clamp only matters for garbage.
-    __device__ __forceinline__ uint32_t word(uint32_t w) const {
-        const uint32_t r = min(w - word0, kStageWords - 1u);
-        return lds[r + (r >> 5)];
-    }
-    // 32 bits of the stream starting at bit position p (the buffer is padded behind the last segment)
+    const uint32_t* lds;         // staged words, word-major
+    uint32_t bit0;               // absolute bit position of column 0, row 0
+    // 32 bits of the stream starting at bit position p.  Every read of a lane stays inside the staged span: a lane
+    // starts inside its workgroup's 256 sub-sequences and runs at most one block (< 2 048 bits) plus 32 bits of
+    // lookahead past them; the clamp only matters for garbage.
     __device__ __forceinline__ uint32_t peek32(uint32_t p) const {
-        const uint32_t w = p >> 5, s = p & 31u;
-        const uint64_t v = (static_cast<uint64_t>(word(w)) << 32) | word(w + 1u);
-        return static_cast<uint32_t>((v << s) >> 32);
+        const uint32_t rel = p - bit0;
+        const uint32_t col = min(rel / kSubBits, kCols - 1u), row = (rel >> 5) & (kSubWords - 1u);
+        const uint32_t* q = lds + row * kRowPitch + col;
+        const uint64_t v = (static_cast<uint64_t>(q[0]) << 32) | q[kRowPitch];
+        return static_cast<uint32_t>((v << (rel & 31u)) >> 32);
     }
 };
 
-__device__ __forceinline__ uint32_t stage_word0(uint32_t first_sub) {       // first staged word: the warm-up bits sit in front
-    const uint32_t w = first_sub * kSubWords;
-    return w >= kWarmWords ? w - kWarmWords : 0u;
-}
 __device__ __forceinline__ void stage_stream(const EntropyArgs& a, uint32_t* lds_words, uint32_t first_sub) {
-    const uint32_t word0 = stage_word0(first_sub);
+    const uint32_t word0 = first_sub * kSubWords;
     const uint32_t total = (a.n_sub + 2u) * kSubWords;                 // the buffer carries 64 slack words
-    for (uint32_t r = threadIdx.x; r < kStageWords; r += kLanes) {
+    for (uint32_t r = threadIdx.x; r < kCols * kSubWords; r += kLanes) {      // coalesced global reads, transposed LDS writes
         const uint32_t w = word0 + r;
-        lds_words[r + (r >> 5)] = w < total ? a.words[w] : 0u;
+        const uint32_t v = w < total ? a.words[w] : 0u;
+        const uint32_t col = r / kSubWords, row = r % kSubWords;
+        lds_words[row * kRowPitch + col] = v;
+        if (row == 0u && col > 0u) lds_words[kSubWords * kRowPitch + col - 1u] = v;      // row 32 = row 0 of the next column
+    }
+    if (threadIdx.x == 0u) {                                                             // word 0 behind the last staged column
+        const uint32_t w = word0 + kCols * kSubWords;
+        lds_words[kSubWords * kRowPitch + kCols - 1u] = w < total ? a.words[w] : 0u;
     }
 }
 
-// Bit reader over the staged stream: 64 bits of lookahead in registers, topped up one word at a time.  The top-up is
-// branchless (the next word is always fetched from LDS, merged only when needed): a lone wave walking a correction
-// through the workgroup is bound by instruction issue, and exec-mask juggling costs more than the spare read.
+// Bit reader over the staged stream: just the position.
 struct BitReader {
     const BitSrc& src;
-    uint64_t bb;            // stream bits from position p on, left-aligned
-    uint32_t avail;         // valid bits in bb (> 32 between symbols)
-    uint32_t next_w;        // next word to append
-    uint32_t p;             // absolute bit position of bb's top bit
-    __device__ __forceinline__ BitReader(const BitSrc& s, uint32_t pos) : src(s), p(pos) {
-        const uint32_t w = pos >> 5, sh = pos & 31u;
-        bb = ((static_cast<uint64_t>(src.word(w)) << 32) | src.word(w + 1u)) << sh;
-        avail = 64u - sh;
-        next_w = w + 2u;
-    }
-    __device__ __forceinline__ uint32_t peek() const { return static_cast<uint32_t>(bb >> 32); }
-    __device__ __forceinline__ void skip(uint32_t n) {               // n <= 31
-        const uint32_t nw = src.word(next_w);
-        bb <<= n; avail -= n; p += n;
-        const bool need = avail <= 32u;
-        const uint64_t add = static_cast<uint64_t>(nw) << ((32u - avail) & 31u);
-        bb |= need ? add : 0ull;
-        avail += need ? 32u : 0u;
-        next_w += need ? 1u : 0u;
-    }
+    uint32_t p;             // absolute bit position of the next unread bit
+    __device__ __forceinline__ BitReader(const BitSrc& s, uint32_t pos) : src(s), p(pos) {}
+    __device__ __forceinline__ uint32_t peek() const { return src.peek32(p); }
+    __device__ __forceinline__ void skip(uint32_t n) { p += n; }
 };
 
 // One symbol of the scan: updates (c, z) and the reader; reports what it was.  kind: 0 = DC (value = difference,
 // at = component), 1 = AC coefficient at zigzag index `at`, 2 = run / end of block (nothing to store).  DC and AC, run
 // and coefficient share one select-based path (a DC symbol is a category with run 0), so lanes at different places of
 // their blocks do not diverge; only codes longer than the 9-bit lookup and block ends branch.
+// Decoder state of a lane besides the bit position: block-in-MCU c, zigzag index z, and -- updated only when a block
+// ends, not per symbol -- the component of block c and its DC table (the AC table follows it).
 template <typename Tab>
-__device__ __forceinline__ void decode_symbol(const EntropyGeom& g, BitReader& br, const Tab* tabs, uint32_t& c, uint32_t& z,
+struct SymState {
+    uint32_t c, z, comp;
+    const Tab* tdc;
+    __device__ __forceinline__ void set_block(const EntropyGeom& g, const Tab* tabs, uint32_t cc) {
+        c = cc;
+        comp = (g.kcomp_packed >> (2u * cc)) & 3u;
+        tdc = tabs + comp * 2u;
+    }
+};
+
+template <typename Tab>
+__device__ __forceinline__ void decode_symbol(const EntropyGeom& g, BitReader& br, const Tab* tabs, SymState<Tab>& S,
                                               uint32_t& kind, uint32_t& at, int32_t& value, uint32_t& err) {
-    const uint32_t comp = (g.kcomp_packed >> (2u * c)) & 3u;
-    const bool ac = z != 0u;
-    const Tab* t = tabs + comp * 2u + (ac ? 1u : 0u);
+    const bool ac = S.z != 0u;
+    const Tab* t = S.tdc + (ac ? 1u : 0u);
     const uint32_t bits = br.peek();
     uint32_t e = t->lut[bits >> (32u - kLutBits)];
     if (e == 0u) {                                                   // code longer than the lookup (2 % of the symbols), or garbage
@@ -203,16 +200,16 @@ __device__ __forceinline__ void decode_symbol(const EntropyGeom& g, BitReader& b
     const int32_t half = static_cast<int32_t>((1u << sz) >> 1);
     const int32_t ext = static_cast<int32_t>(v) < half ? static_cast<int32_t>(v) - static_cast<int32_t>((1u << sz) - 1u) : static_cast<int32_t>(v);
     value = sz ? ext : 0;                                            // jdhuff.c HUFF_EXTEND
-    br.skip(len + (run ? 0u : sz));
-    const uint32_t pos = z + r;
+    br.skip(len + sz);                                               // (a run symbol has sz == 0)
+    const uint32_t pos = S.z + r;
     const bool bad = !run && pos > 63u;
     err |= (bad ? 4u : 0u) | ((!ac && sym > 11u) ? 2u : 0u);
     kind = (run || bad) ? 2u : (ac ? 1u : 0u);
-    at = ac ? pos : comp;
-    z = run ? (r == 15u ? z + 16u : 64u) : pos + 1u;
-    if (z >= 64u) {                                                  // block complete: next block of the MCU
-        z = 0u;
-        c = c + 1u == g.blocks_per_mcu ? 0u : c + 1u;
+    at = ac ? pos : S.comp;
+    S.z = run ? (r == 15u ? S.z + 16u : 64u) : pos + 1u;
+    if (S.z >= 64u) {                                                // block complete: next block of the MCU
+        S.z = 0u;
+        S.set_block(g, tabs, S.c + 1u == g.blocks_per_mcu ? 0u : S.c + 1u);
     }
 }
 
@@ -232,7 +229,7 @@ __device__ __forceinline__ void with_tables(const EntropyArgs& a, const DerivedT
 constexpr uint32_t kInnerRounds = IFHIP_ENT_INNER;
 
 __global__ void __launch_bounds__(kLanes) entropy_round_kernel(const EntropyArgs a) {
-    __shared__ uint32_t lds_words[kStageWords + kStageWords / 32u + 1u];
+    __shared__ uint32_t lds_words[kStageDwords];
     __shared__ DerivedTab lds_tabs[6];
     __shared__ uint32_t ex_p[kLanes], ex_cz[kLanes];
     const uint32_t first_sub = blockIdx.x * kLanes;
@@ -264,37 +261,28 @@ __global__ void __launch_bounds__(kLanes) entropy_round_kernel(const EntropyArgs
     }
     ex_p[t] = my_p; ex_cz[t] = my_cz;
     __syncthreads();
-    const BitSrc src{lds_words, stage_word0(first_sub)};
+    const BitSrc src{lds_words, first_sub * kSubBits};
     const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end);
     bool pending = false;
     for (uint32_t it = 0; it < kInnerRounds; ++it) {
         if (need) {
             used_p = p0; used_cz = cz0;
-            uint32_t c = cz0 >> 8, z = cz0 & 255u, err = 0;
+            uint32_t err = 0, c_out = 0, z_out = 0;
             int32_t n = 0, dc[3] = {0, 0, 0};
-            // Warm-up (speculative start only): begin kWarmBits in front of the sub-sequence, so that the decode has that
-            // many more bits to fall into step with the true one before the part that counts begins; the state at the
-            // first symbol boundary inside the sub-sequence is then the start state the lane "used".
-            const bool warm = kWarmBits != 0u && a.round == 0u && it == 0u && !first;
-            const uint32_t seg_bit0 = sg.first_sub * kSubBits;
-            BitReader br(src, warm ? max(seg_bit0, p0 - min(p0, kWarmBits)) : p0);
+            BitReader br(src, p0);
             with_tables(a, lds_tabs, wg_image, sg.image, [&](auto tabs) {
-                if (warm) {
-                    while (br.p < p0) {
-                        uint32_t kind, at = 0;
-                        int32_t value = 0;
-                        decode_symbol(a.g, br, tabs, c, z, kind, at, value, err);
-                    }
-                    used_p = br.p; used_cz = (c << 8) | z;
-                }
+                SymState<std::remove_cv_t<std::remove_pointer_t<decltype(tabs)>>> S;
+                S.z = cz0 & 255u;
+                S.set_block(a.g, tabs, cz0 >> 8);
                 while (br.p < end) {
                     uint32_t kind, at = 0;
                     int32_t value = 0;
-                    decode_symbol(a.g, br, tabs, c, z, kind, at, value, err);
+                    decode_symbol(a.g, br, tabs, S, kind, at, value, err);
                     if (kind == 0u) { ++n; dc[at] += value; }
                 }
+                c_out = S.c; z_out = S.z;
             });
-            my_p = br.p; my_cz = (c << 8) | z;
+            my_p = br.p; my_cz = (c_out << 8) | z_out;
             my_cnt = make_int4(n, dc[0], dc[1], dc[2]);
             have_cnt = true;
         }
@@ -356,9 +344,11 @@ __global__ void __launch_bounds__(1024) entropy_scan_kernel(const EntropyArgs a)
 constexpr uint32_t kBlkPitch = 34;                   // dwords per lane row (32 + 2)
 
 __global__ void __launch_bounds__(kLanes) entropy_write_kernel(const EntropyArgs a) {
-    __shared__ uint32_t lds_words[kStageWords + kStageWords / 32u + 1u];
+    __shared__ uint32_t lds_words[kStageDwords];
     __shared__ DerivedTab lds_tabs[6];
     __shared__ __attribute__((aligned(8))) uint32_t lds_blk[kLanes * kBlkPitch];
+    __shared__ uint8_t lds_zz[64];                   // zigzag -> natural order (a divergent index into __constant__ memory is a
+    if (threadIdx.x < 64u) lds_zz[threadIdx.x] = kZigzag[threadIdx.x];      // vector-memory load per coefficient)
     const uint32_t first_sub = blockIdx.x * kLanes;
     const uint32_t s = first_sub + threadIdx.x;
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
@@ -376,11 +366,11 @@ __global__ void __launch_bounds__(kLanes) entropy_write_kernel(const EntropyArgs
     uint32_t p = s * kSubBits, cz = 0;
     if (!first) { p = a.exit_p[fin][s - 1u]; cz = a.exit_cz[fin][s - 1u]; }
     const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end);
-    uint32_t c = cz >> 8, z = cz & 255u, err = 0;
+    uint32_t err = 0;
     const int4 pre = a.prefix[s];
     int32_t dc[3] = {pre.y, pre.z, pre.w};
     int32_t block = pre.x - 1;                               // last block started before this lane
-    const BitSrc src{lds_words, stage_word0(first_sub)};
+    const BitSrc src{lds_words, first_sub * kSubBits};
     int16_t* row = reinterpret_cast<int16_t*>(lds_blk + threadIdx.x * kBlkPitch);
     uint2* row2 = reinterpret_cast<uint2*>(lds_blk + threadIdx.x * kBlkPitch);
     const uint32_t B = a.g.blocks_per_mcu;
@@ -388,17 +378,20 @@ __global__ void __launch_bounds__(kLanes) entropy_write_kernel(const EntropyArgs
     with_tables(a, lds_tabs, wg_image, sg.image, [&](auto tabs) {
         uint32_t kind, at = 0;
         int32_t value = 0;
-        while (z != 0u) decode_symbol(a.g, br, tabs, c, z, kind, at, value, err);           // tail of the predecessor's block
+        SymState<std::remove_cv_t<std::remove_pointer_t<decltype(tabs)>>> S;
+        S.z = cz & 255u;
+        S.set_block(a.g, tabs, cz >> 8);
+        while (S.z != 0u) decode_symbol(a.g, br, tabs, S, kind, at, value, err);           // tail of the predecessor's block
         while (br.p < end) {
             ++block;
             if (static_cast<uint32_t>(block) >= sg.n_blocks) break;                        // pad bits behind the last block
 #pragma unroll
             for (uint32_t i = 0; i < 16u; ++i) row2[i] = make_uint2(0u, 0u);
             do {
-                decode_symbol(a.g, br, tabs, c, z, kind, at, value, err);
+                decode_symbol(a.g, br, tabs, S, kind, at, value, err);
                 if (kind == 0u) { dc[at] += value; row[0] = static_cast<int16_t>(dc[at]); }
-                else if (kind == 1u) row[kZigzag[at]] = static_cast<int16_t>(value);
-            } while (z != 0u);
+                else if (kind == 1u) row[lds_zz[at]] = static_cast<int16_t>(value);
+            } while (S.z != 0u);
             const uint32_t m = sg.first_mcu + static_cast<uint32_t>(block) / B, k = static_cast<uint32_t>(block) % B;
             const uint32_t cm = a.g.kcomp[k];
             const uint32_t my = m / a.g.mcus_w, mx = m - my * a.g.mcus_w;
