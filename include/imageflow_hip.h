@@ -108,8 +108,8 @@ IFHIP_API int ifhip_scale_and_render(const uint8_t* in, uint32_t in_w, uint32_t 
  * Device-resident batch form: what a job that keeps frames in HBM calls.  A plan owns the per-shape tables
  * (PixelRowWeights for both axes, the vertical schedule) for (in_w, in_h) -> (w, h); its tables are immutable and it
  * may be shared by any number of launches on the device it was created on (internal lazily built caches are locked).
- * One restriction: the generic two-pass kernels stage through a scratch buffer owned by the plan, so launches of
- * one plan that take that path (up-scaling, > 8 live rows, unaligned rows) must be ordered on one stream.
+ * The generic two-pass kernels (up-scaling, > 8 live rows, unaligned rows) stage through stream-ordered scratch
+ * (hipMallocAsync on the launch stream), so launches of one plan may run on any number of streams.
  */
 typedef struct ifhip_resample_plan ifhip_resample_plan;
 IFHIP_API int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32_t in_h,
