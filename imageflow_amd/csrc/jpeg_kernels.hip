@@ -26,6 +26,8 @@
 
 namespace ifhip {
 
+typedef uint32_t uint4_nt __attribute__((ext_vector_type(4)));      // 16 bytes, usable with __builtin_nontemporal_load
+
 struct JpegGeom {
     uint32_t width, height;
     int ncomp;
@@ -71,23 +73,33 @@ __device__ __forceinline__ uint32_t range_limit(int32_t v) {   // libjpeg post-I
     return i < 128u ? i + 128u : (i < 512u ? 255u : (i < 896u ? 0u : i - 896u));
 }
 
+// 32-bit integer multiplies run at a quarter of the rate of 24-bit ones on CDNA (v_mul_lo_u32 vs v_mul_i32_i24).  A 24-bit
+// multiply returns the low 32 bits of the exact product, i.e. the same bits as the wrapping int32 multiply the oracle
+// performs, whenever BOTH operands fit in 24 signed bits.  That always holds in the second (row) pass -- its inputs are
+// first-pass results shifted right by 11, |w| <= 2^20, and the multiplicands are sums of at most four of them -- and in
+// the first pass whenever every de-quantised coefficient of the block is below 2^21 (every 8-bit-precision file:
+// |coefficient| <= 2^11 ... 2^15, quantiser <= 255); the kernels test that per wave and keep the 32-bit form for the rest.
+template <bool M24>
+__device__ __forceinline__ int32_t mulc(int32_t x, int32_t c) { return M24 ? __mul24(x, c) : x * c; }
+
 // one 8-point pass; in[] are the 8 inputs, sh the descale amount; out via callback-free arrays
+template <bool M24>
 __device__ __forceinline__ void idct8(const int32_t (&in)[8], int32_t (&out)[8], int sh) {
     constexpr int32_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633,
                       F1_501 = 12299, F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
     int32_t z2 = in[2], z3 = in[6];
-    int32_t z1 = (z2 + z3) * F0_541;
-    int32_t tmp2 = z1 + z3 * (-F1_847);
-    int32_t tmp3 = z1 + z2 * F0_765;
+    int32_t z1 = mulc<M24>(z2 + z3, F0_541);
+    int32_t tmp2 = z1 + mulc<M24>(z3, -F1_847);
+    int32_t tmp3 = z1 + mulc<M24>(z2, F0_765);
     int32_t tmp0 = static_cast<int32_t>(static_cast<uint32_t>(in[0] + in[4]) << 13);
     int32_t tmp1 = static_cast<int32_t>(static_cast<uint32_t>(in[0] - in[4]) << 13);
     const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
     z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
     int32_t z4 = tmp1 + tmp3;
-    const int32_t z5 = (z3 + z4) * F1_175;
-    tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
-    z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
+    const int32_t z5 = mulc<M24>(z3 + z4, F1_175);
+    tmp0 = mulc<M24>(tmp0, F0_298); tmp1 = mulc<M24>(tmp1, F2_053); tmp2 = mulc<M24>(tmp2, F3_072); tmp3 = mulc<M24>(tmp3, F1_501);
+    z1 = mulc<M24>(z1, -F0_899); z2 = mulc<M24>(z2, -F2_562); z3 = mulc<M24>(z3, -F1_961); z4 = mulc<M24>(z4, -F0_390);
     z3 += z5; z4 += z5;
     tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
     out[0] = descale(tmp10 + tmp3, sh); out[7] = descale(tmp10 - tmp3, sh);
@@ -95,24 +107,36 @@ __device__ __forceinline__ void idct8(const int32_t (&in)[8], int32_t (&out)[8],
     out[2] = descale(tmp12 + tmp1, sh); out[5] = descale(tmp12 - tmp1, sh);
     out[3] = descale(tmp13 + tmp0, sh); out[4] = descale(tmp13 - tmp0, sh);
 }
+// first (column) pass: 24-bit multiplies when the whole wave's blocks are in range (wave-uniform choice)
+__device__ __forceinline__ void idct8_pass1(const int32_t (&in)[8], int32_t (&out)[8], bool small) {
+    if (small) idct8<true>(in, out, 11);
+    else idct8<false>(in, out, 11);
+}
+__device__ __forceinline__ bool wave_all_small(const int32_t (&d)[8], bool lane_on) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m |= static_cast<uint32_t>(d[k] < 0 ? -d[k] : d[k]);
+    return __all(!lane_on || m < (1u << 21)) != 0;
+}
 
 // reduced-size passes of jidctred.c (jpeg_idct_4x4 / jpeg_idct_2x2): same 13-bit constants family
+template <bool M24>
 __device__ __forceinline__ void idct4_pass(int32_t d0, int32_t d1, int32_t d2, int32_t d3, int32_t d5, int32_t d6, int32_t d7,
                                            int32_t (&out)[4], int sh) {
     const int32_t t0 = static_cast<int32_t>(static_cast<uint32_t>(d0) << 14);
-    const int32_t t2 = d2 * 15137 + d6 * (-6270);
+    const int32_t t2 = mulc<M24>(d2, 15137) + mulc<M24>(d6, -6270);
     const int32_t t10 = t0 + t2, t12 = t0 - t2;
-    const int32_t o0 = d7 * (-1730) + d5 * 11893 + d3 * (-17799) + d1 * 8697;
-    const int32_t o2 = d7 * (-4176) + d5 * (-4926) + d3 * 7373 + d1 * 20995;
+    const int32_t o0 = mulc<M24>(d7, -1730) + mulc<M24>(d5, 11893) + mulc<M24>(d3, -17799) + mulc<M24>(d1, 8697);
+    const int32_t o2 = mulc<M24>(d7, -4176) + mulc<M24>(d5, -4926) + mulc<M24>(d3, 7373) + mulc<M24>(d1, 20995);
     out[0] = descale(t10 + o2, sh); out[3] = descale(t10 - o2, sh);
     out[1] = descale(t12 + o0, sh); out[2] = descale(t12 - o0, sh);
 }
+template <bool M24>
 __device__ __forceinline__ void idct2_pass(int32_t d0, int32_t d1, int32_t d3, int32_t d5, int32_t d7, int32_t (&out)[2], int sh) {
     const int32_t t10 = static_cast<int32_t>(static_cast<uint32_t>(d0) << 15);
-    const int32_t t0 = d7 * (-5906) + d5 * 6967 + d3 * (-10426) + d1 * 29692;
+    const int32_t t0 = mulc<M24>(d7, -5906) + mulc<M24>(d5, 6967) + mulc<M24>(d3, -10426) + mulc<M24>(d1, 29692);
     out[0] = descale(t10 + t0, sh); out[1] = descale(t10 - t0, sh);
 }
-
 
 // libjpeg's other scaled IDCTs (jidctint.c jpeg_idct_3x3 / 5x5 / 6x6 / 10x10 / 12x12): the block routines behind
 // scale_num 3, 5, 6 (luma NxN; 2x2 sub-sampled chroma 2N x 2N).  One N-point pass each; `dc` arrives shifted left by
@@ -247,7 +271,7 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
     __shared__ int32_t ws[kBlocksPerWg * kBigPitch];
     // grid: x = groups of 32 blocks of component a.comp, y = image
     const uint32_t t = threadIdx.x, lane8 = t & 7u, lb = t >> 3;
-    const uint32_t c = a.comp, img = blockIdx.y;
+    const uint32_t c = a.comp + blockIdx.z, img = blockIdx.y;          // blockIdx.z: the two chroma components in one launch
     const uint32_t bidx = blockIdx.x * kBlocksPerWg + lb;
     const bool on = bidx < a.g.bw[c] * a.g.bh[c];
     const uint32_t n = a.g.idct_n[c];                                   // output samples per block edge
@@ -266,28 +290,34 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
         for (int k = 0; k < 4; ++k) {
             const int32_t c0 = static_cast<int16_t>(cw[k] & 0xffffu), c1 = static_cast<int16_t>(cw[k] >> 16);
             const int32_t q0 = static_cast<int32_t>(qw[k] & 0xffffu), q1 = static_cast<int32_t>(qw[k] >> 16);
-            w[lane8 * 8u + 2 * k] = c0 * q0;
-            w[lane8 * 8u + 2 * k + 1] = c1 * q1;
+            w[lane8 * 8u + 2 * k] = __mul24(c0, q0);            // 16-bit operands: exact
+            w[lane8 * 8u + 2 * k + 1] = __mul24(c1, q1);
         }
     }
     __syncthreads();
-    if (on) {                                   // column pass: lane8 = column
-        int32_t in[8];
+    int32_t col_in[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (on) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) in[r] = w[r * 8 + lane8];
+        for (int r = 0; r < 8; ++r) col_in[r] = w[r * 8 + lane8];
+    }
+    const bool small = wave_all_small(col_in, on);
+    if (on) {                                   // column pass: lane8 = column
+        int32_t (&in)[8] = col_in;
         if (m == 8u) {
             int32_t out[8];
-            idct8(in, out, 11);                 // CONST_BITS - PASS1_BITS
+            idct8_pass1(in, out, small);        // CONST_BITS - PASS1_BITS
 #pragma unroll
             for (int r = 0; r < 8; ++r) w[r * 8 + lane8] = out[r];
         } else if (m == 4u) {
             int32_t out[4];
-            idct4_pass(in[0], in[1], in[2], in[3], in[5], in[6], in[7], out, 12);     // CONST_BITS - PASS1_BITS + 1
+            if (small) idct4_pass<true>(in[0], in[1], in[2], in[3], in[5], in[6], in[7], out, 12);     // CONST_BITS - PASS1_BITS + 1
+            else idct4_pass<false>(in[0], in[1], in[2], in[3], in[5], in[6], in[7], out, 12);
 #pragma unroll
             for (int r = 0; r < 4; ++r) w[r * 8 + lane8] = out[r];
         } else if (m == 2u) {
             int32_t out[2];
-            idct2_pass(in[0], in[1], in[3], in[5], in[7], out, 13);                   // CONST_BITS - PASS1_BITS + 2
+            if (small) idct2_pass<true>(in[0], in[1], in[3], in[5], in[7], out, 13);                   // CONST_BITS - PASS1_BITS + 2
+            else idct2_pass<false>(in[0], in[1], in[3], in[5], in[7], out, 13);
             w[lane8] = out[0]; w[8 + lane8] = out[1];
         } else if (m == 3u) {
             if (lane8 < 3u) { int32_t out[3]; idct3_pass<true>(dc_pass1(in[0]), in[1], in[2], out); for (int r = 0; r < 3; ++r) w[r * 8 + lane8] = out[r]; }
@@ -314,7 +344,7 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
             int32_t in[8], out[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) in[k] = w[lane8 * 8u + k];
-            idct8(in, out, 18);                 // CONST_BITS + PASS1_BITS + 3
+            idct8<true>(in, out, 18);           // CONST_BITS + PASS1_BITS + 3 (second pass: always in 24-bit range)
             uint32_t lo = 0, hi = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -332,7 +362,7 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
             if (lane8 < 4u) {
                 const int32_t* r = w + lane8 * 8u;
                 int32_t out[4];
-                idct4_pass(r[0], r[1], r[2], r[3], r[5], r[6], r[7], out, 19);       // CONST_BITS + PASS1_BITS + 3 + 1
+                idct4_pass<true>(r[0], r[1], r[2], r[3], r[5], r[6], r[7], out, 19);       // CONST_BITS + PASS1_BITS + 3 + 1 (|r| <= 2^20: 24-bit exact)
                 const uint32_t v = range_limit(out[0]) | (range_limit(out[1]) << 8) | (range_limit(out[2]) << 16) | (range_limit(out[3]) << 24);
                 *reinterpret_cast<uint32_t*>(plane + static_cast<size_t>(by * 4u + lane8) * a.g.pw[c] + bx * 4u) = v;
             }
@@ -340,7 +370,7 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
             if (lane8 < 2u) {
                 const int32_t* r = w + lane8 * 8u;
                 int32_t out[2];
-                idct2_pass(r[0], r[1], r[3], r[5], r[7], out, 20);                    // CONST_BITS + PASS1_BITS + 3 + 2
+                idct2_pass<true>(r[0], r[1], r[3], r[5], r[7], out, 20);                    // CONST_BITS + PASS1_BITS + 3 + 2
                 const uint32_t v = range_limit(out[0]) | (range_limit(out[1]) << 8);
                 *reinterpret_cast<uint16_t*>(plane + static_cast<size_t>(by * 2u + lane8) * a.g.pw[c] + bx * 2u) = static_cast<uint16_t>(v);
             }
@@ -366,6 +396,13 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
         }
     }
     if (spatial) {
+        // the scalers' two tables (12-bit sRGB <-> linear) go to LDS: 64 + n*n lookups per block
+        __shared__ uint16_t s2l_lds[256];
+        __shared__ uint8_t l2s_lds[4096];
+        if (a.g.luma_mode == 2u) {
+            s2l_lds[t] = a.sc.s2l[t];
+            reinterpret_cast<uint4*>(l2s_lds)[t] = reinterpret_cast<const uint4*>(a.sc.l2s)[t];
+        }
         __syncthreads();
         // flow_scale_spatial[_srgb]_NxN on the block's 8x8 bytes: lane r < n produces output row r
         if (on && lane8 < n) {
@@ -378,7 +415,7 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const uint32_t byte = blk[i * 32 + j];
-                    v[j] += wr * (srgb ? static_cast<int32_t>(a.sc.s2l[byte]) : static_cast<int32_t>(byte));
+                    v[j] += wr * (srgb ? static_cast<int32_t>(s2l_lds[byte]) : static_cast<int32_t>(byte));
                 }
             }
             uint8_t* orow = plane + static_cast<size_t>(by * n + lane8) * a.g.pw[c] + bx * n;
@@ -390,7 +427,7 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
                 uint32_t o;
                 if (sum < 0) o = 0;
                 else if (static_cast<uint32_t>(sum) >= (4096u << sh)) o = 255;
-                else o = srgb ? a.sc.l2s[sum >> sh] : static_cast<uint32_t>(sum >> sh);
+                else o = srgb ? l2s_lds[sum >> sh] : static_cast<uint32_t>(sum >> sh);
                 orow[cc] = static_cast<uint8_t>(o);
             }
         }
@@ -407,10 +444,10 @@ __device__ __forceinline__ int32_t chroma_at(const uint8_t* p, uint32_t pw, uint
 __device__ __forceinline__ uint32_t clamp255(int32_t v) { return static_cast<uint32_t>(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
 __device__ __forceinline__ uint32_t ycc_to_bgra(int32_t Y, int32_t cbv, int32_t crv) {   // jdcolor.c tables, in place
-    const int32_t cb = cbv - 128, cr = crv - 128;
-    const int32_t r = Y + ((91881 * cr + 32768) >> 16);
-    const int32_t g = Y + ((-22554 * cb + 32768 + (-46802) * cr) >> 16);
-    const int32_t b = Y + ((116130 * cb + 32768) >> 16);
+    const int32_t cb = cbv - 128, cr = crv - 128;                     // |cb|, |cr| <= 128: 24-bit multiplies are exact
+    const int32_t r = Y + ((__mul24(91881, cr) + 32768) >> 16);
+    const int32_t g = Y + ((__mul24(-22554, cb) + 32768 + __mul24(-46802, cr)) >> 16);
+    const int32_t b = Y + ((__mul24(116130, cb) + 32768) >> 16);
     return clamp255(b) | (clamp255(g) << 8) | (clamp255(r) << 16) | 0xff000000u;
 }
 
@@ -432,6 +469,29 @@ __device__ __forceinline__ void chroma4(const uint8_t* P, uint32_t W, uint32_t D
             o[k] = row[x];
         }
     }
+}
+
+// the same four samples, packed into one word (byte k = sample k): lets the colour pass request every chroma row of its
+// 16-row tile up front and unpack at use
+__device__ __forceinline__ uint32_t chroma4_packed(const uint8_t* P, uint32_t W, uint32_t DW, uint32_t DH, int32_t c0, int32_t y) {
+    y = y < 0 ? 0 : (y >= static_cast<int32_t>(DH) ? static_cast<int32_t>(DH) - 1 : y);
+    const uint8_t* row = P + static_cast<size_t>(y) * W;
+    if (c0 >= 0 && c0 + 3 < static_cast<int32_t>(DW)) {
+        uint32_t v;
+        __builtin_memcpy(&v, row + c0, 4);
+        return v;
+    }
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int32_t x = c0 + k;
+        x = x < 0 ? 0 : (x >= static_cast<int32_t>(DW) ? static_cast<int32_t>(DW) - 1 : x);
+        v |= static_cast<uint32_t>(row[x]) << (8 * k);
+    }
+    return v;
+}
+__device__ __forceinline__ void unpack4(uint32_t v, int32_t (&o)[4]) {
+    o[0] = v & 255u; o[1] = (v >> 8) & 255u; o[2] = (v >> 16) & 255u; o[3] = v >> 24;
 }
 
 // One lane = 4 horizontally adjacent output pixels x kColorRows output rows (one 4-byte Y load and one 16-byte BGRA store
@@ -464,27 +524,42 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const JpegArgs a) {
         const uint16_t* q = a.qt + static_cast<size_t>(img) * a.g.ncomp * 64u + lane8 * 8u;
         const uint4 qv = *reinterpret_cast<const uint4*>(q);
         const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+        // All eight passes' coefficient rows are requested before the first pass runs (8 x 16 B per lane in flight): one
+        // load per pass, waited for on the spot, left a workgroup with 8 dependent HBM round trips and the CU with a few
+        // KB outstanding -- the kernel was bound by that latency, not by bandwidth or arithmetic.
+        uint4_nt cvs[8];
+#pragma unroll
+        for (uint32_t pass = 0; pass < 8u; ++pass) {
+            const uint32_t bl = pass * kBlocksPerWg + lb;
+            const uint32_t by = min(blockIdx.y * 2u + (bl >> 7), a.g.bh[0] - 1u), bx = min(blockIdx.x * 128u + (bl & 127u), a.g.bw[0] - 1u);
+            const int16_t* src = a.coef[0] + (static_cast<size_t>(img) * nblk + static_cast<size_t>(by) * a.g.bw[0] + bx) * 64u + lane8 * 8u;
+            cvs[pass] = __builtin_nontemporal_load(reinterpret_cast<const uint4_nt*>(src));
+        }
+#pragma unroll
         for (uint32_t pass = 0; pass < 8u; ++pass) {
             const uint32_t bl = pass * kBlocksPerWg + lb;                 // 0..255: block row bl >> 7, block column bl & 127
             const uint32_t by = blockIdx.y * 2u + (bl >> 7), bx = blockIdx.x * 128u + (bl & 127u);
             const bool on = bx < a.g.bw[0] && by < a.g.bh[0];
             if (on) {
-                const int16_t* src = a.coef[0] + (static_cast<size_t>(img) * nblk + static_cast<size_t>(by) * a.g.bw[0] + bx) * 64u + lane8 * 8u;
-                const uint4 cv = *reinterpret_cast<const uint4*>(src);
+                const uint4_nt cv = cvs[pass];
                 const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int32_t c0 = static_cast<int16_t>(cw[k] & 0xffffu), c1 = static_cast<int16_t>(cw[k] >> 16);
-                    w[lane8 * 8u + 2 * k] = c0 * static_cast<int32_t>(qw[k] & 0xffffu);
-                    w[lane8 * 8u + 2 * k + 1] = c1 * static_cast<int32_t>(qw[k] >> 16);
+                    w[lane8 * 8u + 2 * k] = __mul24(c0, static_cast<int32_t>(qw[k] & 0xffffu));
+                    w[lane8 * 8u + 2 * k + 1] = __mul24(c1, static_cast<int32_t>(qw[k] >> 16));
                 }
             }
             wave_sync_lds();
-            if (on) {                                                   // column pass: lane8 = column
-                int32_t in[8], out[8];
+            int32_t in[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (on) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) in[r] = w[r * 8 + lane8];
-                idct8(in, out, 11);
+            }
+            const bool small = wave_all_small(in, on);
+            if (on) {                                                   // column pass: lane8 = column
+                int32_t out[8];
+                idct8_pass1(in, out, small);
                 wave_sync_lds();
 #pragma unroll
                 for (int r = 0; r < 8; ++r) w[r * 8 + lane8] = out[r];
@@ -494,7 +569,7 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const JpegArgs a) {
                 int32_t in[8], out[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) in[k] = w[lane8 * 8u + k];
-                idct8(in, out, 18);
+                idct8<true>(in, out, 18);
                 uint32_t lo = 0, hi = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -598,18 +673,25 @@ __global__ void __launch_bounds__(256) jpeg_color_kernel(const JpegArgs a) {
         }
         return;
     }
-    // h2v2 fancy: triangle in both directions; y_begin is even (kColorRows is), rows come in pairs (2cy, 2cy+1)
-    int32_t prev[2][4], cur[2][4], next[2][4];
+    // h2v2 fancy: triangle in both directions; y_begin is even (kColorRows is), rows come in pairs (2cy, 2cy+1).
+    // The tile's chroma rows cy0 - 1 .. cy0 + kColorRows / 2 are requested up front (one packed word each).
+    constexpr int kCRows = kColorRows / 2 + 2;
+    uint32_t craw[2][kCRows];
     const int32_t cy0 = static_cast<int32_t>(y_begin >> 1);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        chroma4(P[k], a.g.pw[1 + k], a.g.dw[1 + k], a.g.dh[1 + k], c0, cy0 - 1, prev[k]);
-        chroma4(P[k], a.g.pw[1 + k], a.g.dw[1 + k], a.g.dh[1 + k], c0, cy0, cur[k]);
-    }
-    for (uint32_t y = y_begin; y < y_end; y += 2u) {
-        const int32_t cy = static_cast<int32_t>(y >> 1);
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) chroma4(P[k], a.g.pw[1 + k], a.g.dw[1 + k], a.g.dh[1 + k], c0, cy + 1, next[k]);
+        for (int r = 0; r < kCRows; ++r)
+            craw[k][r] = chroma4_packed(P[k], a.g.pw[1 + k], a.g.dw[1 + k], a.g.dh[1 + k], c0, cy0 - 1 + r);
+    int32_t prev[2][4], cur[2][4], next[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { unpack4(craw[k][0], prev[k]); unpack4(craw[k][1], cur[k]); }
+#pragma unroll
+    for (uint32_t pr = 0; pr < kColorRows / 2u; ++pr) {
+        const uint32_t y = y_begin + 2u * pr;
+        if (y >= y_end) break;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) unpack4(craw[k][pr + 2u], next[k]);
 #pragma unroll
         for (uint32_t r = 0; r < 2u; ++r) {
             if (y + r >= y_end) break;
@@ -823,8 +905,11 @@ int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d
     for (int c = fused_luma ? 1 : 0; c < a.g.ncomp; ++c) {
         a.comp = static_cast<uint32_t>(c);
         const uint32_t nblk = a.g.bw[c] * a.g.bh[c];
-        hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nblk + kBlocksPerWg - 1) / kBlocksPerWg, n_images), dim3(256), 0, st, a);
+        // the two chroma components have the same geometry: one launch covers both (blockIdx.z)
+        const bool both = c == 1 && a.g.ncomp == 3 && a.g.bw[1] == a.g.bw[2] && a.g.bh[1] == a.g.bh[2] && a.g.idct_n[1] == a.g.idct_n[2];
+        hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nblk + kBlocksPerWg - 1) / kBlocksPerWg, n_images, both ? 2u : 1u), dim3(256), 0, st, a);
         HIP_TRY(hipGetLastError());
+        if (both) ++c;
     }
     const dim3 cgrid((a.g.out_w + 1023u) / 1024u, (a.g.out_h + kColorRows - 1u) / kColorRows, n_images);
     if (fused_luma) hipLaunchKernelGGL((jpeg_color_kernel<true>), cgrid, dim3(256), 0, st, a);
