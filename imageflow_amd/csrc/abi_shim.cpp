@@ -10,8 +10,9 @@
 //
 // Two labelled EXTENSIONS, because the reference's JSON API has no raw-pixel I/O:
 //   * decode accepts, besides baseline JPEG, the container "IFBGRA1\0" + u32le w, h, stride, alpha_meaningful + rows;
-//   * encode always writes that container (preferred_extension "ifbgra", mime "application/x-imageflow-bgra"):
-//     entropy coding / PNG deflate are out of scope, the caller's encoder takes the frame.
+//   * encode writes a baseline JPEG for the libjpeg_turbo preset (device pixel stage + host Huffman coder, jpeg_write.cpp)
+//     and that container for every other preset (preferred_extension "ifbgra", mime "application/x-imageflow-bgra"):
+//     PNG deflate / GIF / WebP coders are out of scope, the caller's encoder takes the frame.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -317,7 +318,7 @@ const imageflow_json_response* respond_error(imageflow_context* c, int cat, cons
 }
 
 // ---- the job interpreter ---------------------------------------------------------------------------------------
-struct EncodeRecord { int32_t io_id; uint32_t w, h; };
+struct EncodeRecord { int32_t io_id; uint32_t w, h; const char* mime; const char* ext; };
 struct DecodeRecord { int32_t io_id; uint32_t w, h; const char* mime; const char* ext; };
 struct Job {
     imageflow_context* c;
@@ -526,19 +527,64 @@ struct Job {
         hints.t = JVal::Obj;
         if (srgb) { JVal cs; cs.t = JVal::Str; cs.s = "srgb"; hints.o.emplace_back("scaling_colorspace", cs); }
         FramePtr out = resample(in, ow, oh, &hints);
-        if (enc && enc->t == JVal::Num) encode(out, static_cast<int32_t>(enc->n));
+        if (enc && enc->t == JVal::Num) encode(out, static_cast<int32_t>(enc->n), nullptr);
         return out;
     }
 
-    void encode(const FramePtr& f, int32_t io_id) {                                      // EXTENSION: raw BGRA container
+    // encode: EncoderPreset::LibjpegTurbo without progressive / optimised tables is written as a real baseline JPEG
+    // (codecs/mozjpeg.rs:78-160, create_classic :62-77): apply_matte + forward DCT / quantisation on the device, the
+    // sequential Huffman coder and the markers on the host (csrc/jpeg_write.cpp).  The content-adaptive sampling choice
+    // (evalchroma, an external crate) is not reproduced: the file uses the maximum the reference allows (:133, 4:2:0).
+    // EXTENSION: every other preset writes the raw BGRA container (PNG / GIF / WebP coders are out of scope).
+    void encode(const FramePtr& f, int32_t io_id, const JVal* preset) {
         Io& o = output(io_id);
+        const JVal* classic = preset ? preset->get("libjpeg_turbo") : nullptr;
+        if (classic) {
+            auto flag = [&](const char* k) { const JVal* v = classic->get(k); return v && v->t == JVal::Bool && v->b; };
+            if (flag("progressive") || flag("optimize_huffman_coding"))
+                raise(kActionNotSupported, "ActionNotSupported: libjpeg_turbo preset with progressive or optimize_huffman_coding (this shim writes baseline files)");
+            const JVal* q = classic->get("quality");
+            int quality = 75;                                                            // mozjpeg.rs:32 DEFAULT_QUALITY
+            if (q && q->t == JVal::Num) quality = q->n > 100 ? 100 : (q->n < 0 ? 0 : static_cast<int>(q->n));
+            const JVal* m = classic->get("matte");
+            const uint32_t matte = m && !m->is_null() ? parse_color(m, "encode.preset.libjpeg_turbo.matte") : 0xFFFFFFFFu;   // :88-92
+            check(ifhip_apply_matte_batch_device(f->d, f->bytes(), 1, f->w, f->h, f->stride, f->alpha ? 1 : 0, matte, nullptr));
+            f->alpha = false;                                                            // :94 set_alpha_meaningful(false)
+            const uint8_t hs[3] = {2, 1, 1}, vs[3] = {2, 1, 1};
+            uint16_t qt2[2][64], qt3[3][64];
+            ifhip_jpeg_quality_tables(quality, &qt2[0][0]);
+            std::memcpy(qt3[0], qt2[0], 128); std::memcpy(qt3[1], qt2[1], 128); std::memcpy(qt3[2], qt2[1], 128);
+            ifhip_jpeg_fwd_stage* st = nullptr;
+            check(ifhip_jpeg_fwd_stage_create(&st, f->w, f->h, hs, vs, 1));
+            std::unique_ptr<ifhip_jpeg_fwd_stage, void (*)(ifhip_jpeg_fwd_stage*)> st_guard(st, ifhip_jpeg_fwd_stage_destroy);
+            uint32_t bw[3], bh[3];
+            check(ifhip_jpeg_fwd_stage_block_dims(st, bw, bh));
+            size_t off[4] = {0, 0, 0, 0};
+            for (int c = 0; c < 3; ++c) off[c + 1] = off[c] + static_cast<size_t>(bw[c]) * bh[c] * 64u;
+            int16_t* d_coef = nullptr;
+            uint16_t* d_qt = nullptr;
+            hip_check(hipMalloc(reinterpret_cast<void**>(&d_coef), off[3] * 2u + 384u), "hipMalloc(coefficients)");
+            std::unique_ptr<int16_t, void (*)(int16_t*)> coef_guard(d_coef, [](int16_t* p) { (void)hipFree(p); });
+            d_qt = reinterpret_cast<uint16_t*>(d_coef + off[3]);
+            hip_check(hipMemcpy(d_qt, qt3, 384, hipMemcpyHostToDevice), "upload(quant tables)");
+            check(ifhip_jpeg_forward_batch_device(st, f->d, f->bytes(), f->stride, d_qt, 1, d_coef + off[0], d_coef + off[1], d_coef + off[2], nullptr));
+            std::vector<int16_t> coef(off[3]);
+            hip_check(hipMemcpy(coef.data(), d_coef, off[3] * 2u, hipMemcpyDeviceToHost), "download(coefficients)");
+            size_t len = 0;
+            check(ifhip_jpeg_write_baseline(coef.data() + off[0], coef.data() + off[1], coef.data() + off[2], bw, bh, 3, hs, vs, f->w, f->h, quality, nullptr, 0, &len));
+            o.owned.assign(len, 0);
+            check(ifhip_jpeg_write_baseline(coef.data() + off[0], coef.data() + off[1], coef.data() + off[2], bw, bh, 3, hs, vs, f->w, f->h, quality, o.owned.data(), len, &len));
+            o.written = true;
+            encodes.push_back({io_id, f->w, f->h, "image/jpeg", "jpg"});
+            return;
+        }
         o.owned.assign(kRawHeader + f->bytes(), 0);
         std::memcpy(o.owned.data(), kRawMagic, 8);
         const uint32_t hdr[4] = {f->w, f->h, f->stride, f->alpha ? 1u : 0u};
         std::memcpy(o.owned.data() + 8, hdr, 16);
         hip_check(hipMemcpy(o.owned.data() + kRawHeader, f->d, f->bytes(), hipMemcpyDeviceToHost), "download(frame)");
         o.written = true;
-        encodes.push_back({io_id, f->w, f->h});
+        encodes.push_back({io_id, f->w, f->h, "application/x-imageflow-bgra", "ifbgra"});
     }
 
     FramePtr copy_into_canvas(const FramePtr& in, const FramePtr& canvas, uint32_t fx, uint32_t fy, uint32_t w, uint32_t h, uint32_t x, uint32_t y) {
@@ -586,7 +632,7 @@ struct Job {
         need_input();
         if (name == "resample_2d") return resample(in, want_u32(p, "w", "resample_2d"), want_u32(p, "h", "resample_2d"), p.get("hints"));
         if (name == "constrain") return constrain(in, p);
-        if (name == "encode") { encode(in, static_cast<int32_t>(want_int(p, "io_id", "encode"))); return in; }
+        if (name == "encode") { encode(in, static_cast<int32_t>(want_int(p, "io_id", "encode")), p.get("preset")); return in; }
         if (name == "fill_rect") {                                                    // clone_crop_fill_expand.rs:107-137
             in->compose = IFHIP_BLEND_WITH_SELF;                                      // :112: set before the fill, so matte canvases accept sub-rects
             check(ifhip_fill_rect_batch_device(in->d, in->bytes(), 1, in->w, in->h, in->stride, in->compose, want_u32(p, "x1", name.c_str()),
@@ -730,7 +776,7 @@ std::string job_result_json(const Job& job, const char* key) {
     std::string s = "{\n  \"code\": 200,\n  \"success\": true,\n  \"message\": \"OK\",\n  \"data\": {\n    \"" + std::string(key) + "\": {\n      \"encodes\": [";
     for (size_t i = 0; i < job.encodes.size(); ++i) {
         const EncodeRecord& e = job.encodes[i];
-        s += std::string(i ? "," : "") + "\n        {\"preferred_mime_type\": \"application/x-imageflow-bgra\", \"preferred_extension\": \"ifbgra\", \"io_id\": " +
+        s += std::string(i ? "," : "") + "\n        {\"preferred_mime_type\": \"" + e.mime + "\", \"preferred_extension\": \"" + e.ext + "\", \"io_id\": " +
              std::to_string(e.io_id) + ", \"w\": " + std::to_string(e.w) + ", \"h\": " + std::to_string(e.h) + ", \"bytes\": \"elsewhere\"}";
     }
     s += "\n      ],\n      \"decodes\": [";

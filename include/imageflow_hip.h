@@ -222,6 +222,16 @@ IFHIP_API int ifhip_jpeg_forward_batch_device(ifhip_jpeg_fwd_stage* stage, const
 IFHIP_API int ifhip_jpeg_forward(const uint8_t* bgra, uint32_t width, uint32_t height, uint32_t stride,
                                  const uint8_t* h_samp, const uint8_t* v_samp, const uint16_t* qt,
                                  int16_t* coef0, int16_t* coef1, int16_t* coef2);
+/* Host half of the same encoder: jpeg_set_quality's tables (jcparam.c: Annex K tables scaled, force_baseline; [0] luma,
+ * [1] chroma, natural order) and the baseline file writer -- markers in jcmarker.c's order plus the sequential Huffman
+ * coder with the Annex K tables (set_fastest_defaults: no optimised tables, not progressive).  Byte-identical to
+ * libjpeg-turbo for the same pixels, quality and sampling.  coef*: host planes in the layout of ifhip_jpeg_forward.
+ * out == NULL: only *len (the size needed) is written. */
+IFHIP_API int ifhip_jpeg_quality_tables(int quality, uint16_t* qt2x64);
+IFHIP_API int ifhip_jpeg_write_baseline(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2,
+                                        const uint32_t* blocks_w3, const uint32_t* blocks_h3, int n_components,
+                                        const uint8_t* h_samp, const uint8_t* v_samp, uint32_t width, uint32_t height,
+                                        int quality, uint8_t* out, size_t capacity, size_t* len);
 
 /* imageflow's 8x8 -> NxN spatial block scalers for the luma plane of a scaled decode: replaces
  * flow_scale_spatial[_srgb]_{1..7}x{1..7} (c_components/lib/codecs_jpeg_idct_fast.c, .h:17-43), the functions the IDCT

@@ -160,3 +160,61 @@ def test_progressive_jpeg_is_refused_not_mis_decoded():
         c.add_input_buffer(0, b.getvalue())
         status, r = c.send_json("v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}]}})
         assert status == 400 and c.error_code() == 5 and "ImageTypeNotSupported" in r["message"]
+
+
+@pytest.mark.parametrize("size,quality", [((1, 1), 75), ((17, 9), 90), ((203, 131), None), ((640, 427), 60)])
+def test_libjpeg_turbo_preset_writes_the_file_libjpeg_turbo_writes(size, quality):
+    """decode(raw frame) -> encode(libjpeg_turbo): matte, colour conversion, down-sampling, DCT and quantisation on the GPU,
+    markers + Huffman coding on the host -- byte for byte the file libjpeg-turbo (Pillow, same 4:2:0 sampling, standard
+    tables) writes from the same pixels.  Default quality is the reference's 75 (codecs/mozjpeg.rs:32)."""
+    Image = pytest.importorskip("PIL.Image")
+    w, h = size
+    rng = np.random.default_rng(w * 7 + h)
+    y, x = np.mgrid[0:h, 0:w]
+    rgb = np.stack([(x * 255 // max(w - 1, 1)), (y * 255 // max(h - 1, 1)), ((x * 5 + y * 3) % 256)], -1).astype(np.int32)
+    rgb = np.clip(rgb + rng.integers(-30, 30, rgb.shape), 0, 255).astype(np.uint8)
+    bgra = np.zeros((h, U.stride_for(w)), np.uint8)
+    bgra[:, :4 * w] = np.concatenate([rgb[:, :, ::-1], np.full((h, w, 1), 255, np.uint8)], -1).reshape(h, 4 * w)
+    preset = {"libjpeg_turbo": {} if quality is None else {"quality": quality}}
+    with Context() as c:
+        c.add_input_bytes(0, pack_raw_bgra(bgra, w, h, alpha_meaningful=False))
+        c.add_output_buffer(1)
+        r = _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"encode": {"io_id": 1, "preset": preset}}]}})
+        got = bytes(c.get_output_buffer(1))
+    enc = r["data"]["job_result"]["encodes"][0]
+    assert (enc["preferred_mime_type"], enc["preferred_extension"], enc["w"], enc["h"]) == ("image/jpeg", "jpg", w, h)
+    buf = io.BytesIO()
+    Image.fromarray(rgb).save(buf, "JPEG", quality=75 if quality is None else quality, subsampling="4:2:0", optimize=False)
+    assert got == buf.getvalue()
+
+
+def test_libjpeg_turbo_preset_flattens_alpha_onto_the_matte_first():
+    """mozjpeg.rs:88-94: apply_matte(matte or white) before compression; the flattened pixels come from the oracle."""
+    Image = pytest.importorskip("PIL.Image")
+    w, h = 97, 61
+    fr = U.random_frames(1, w, h, seed0=11, alpha=True)
+    stride = fr.shape[2]
+    for matte_json, matte32 in ((None, 0xFFFFFFFF), ({"srgb": {"hex": "336699FF"}}, 0xFF336699)):
+        flat = fr[0].copy()
+        O.apply_matte(flat, w, h, stride, matte32, True)
+        rgb = np.ascontiguousarray(flat[:, :4 * w].reshape(h, w, 4)[:, :, 2::-1])
+        params = {"quality": 85}
+        if matte_json:
+            params["matte"] = matte_json
+        with Context() as c:
+            c.add_input_bytes(0, pack_raw_bgra(fr[0], w, h, alpha_meaningful=True))
+            c.add_output_buffer(1)
+            _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"encode": {"io_id": 1, "preset": {"libjpeg_turbo": params}}}]}})
+            got = bytes(c.get_output_buffer(1))
+        buf = io.BytesIO()
+        Image.fromarray(rgb).save(buf, "JPEG", quality=85, subsampling="4:2:0", optimize=False)
+        assert got == buf.getvalue()
+
+
+def test_libjpeg_turbo_preset_rejects_what_the_baseline_writer_cannot_do():
+    with Context() as c:
+        c.add_input_bytes(0, pack_raw_bgra(np.zeros((8, 64), np.uint8), 8, 8, alpha_meaningful=False))
+        c.add_output_buffer(1)
+        for extra in ({"progressive": True}, {"optimize_huffman_coding": True}):
+            status, r = c.send_json("v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"encode": {"io_id": 1, "preset": {"libjpeg_turbo": extra}}}]}})
+            assert status == 400 and "ActionNotSupported" in r["message"], (status, r)

@@ -275,3 +275,41 @@ def test_several_frames_per_workgroup(case, alpha):
     iw, ih, ow, oh, n = case
     run_case(iw, ih, ow, oh, n=n, alpha=alpha, compose=BitmapCompositing.BlendWithSelf if alpha else BitmapCompositing.ReplaceSelf)
     run_case(iw, ih, ow, oh, n=1, alpha=alpha, x=3, y=2, cw=ow + 5, ch=oh + 4)
+
+
+def test_host_drop_in_from_several_threads():
+    """imageflow runs one Context per thread (imageflow_abi/src/lib.rs:20-27): the host-buffer entry point keeps a stream
+    and staging buffers per calling thread, so concurrent callers neither serialise on the null stream nor see each
+    other's pixels.  8 threads x 6 calls of different shapes and modes, every result equal to the oracle."""
+    import threading
+    from oracle import oracle as O
+    shapes = [(640, 360, 64, 36), (333, 222, 40, 27), (1920, 1080, 200, 113), (96, 64, 96, 64)]
+    errors = []
+
+    def worker(k):
+        try:
+            rng = np.random.default_rng(900 + k)
+            for i in range(6):
+                iw, ih, ow, oh = shapes[(k + i) % len(shapes)]
+                alpha = (k + i) % 2 == 1
+                compose = BitmapCompositing.BlendWithMatte if alpha and i % 3 == 0 else BitmapCompositing.ReplaceSelf
+                fr = U.random_frames(1, iw, ih, seed0=5000 + 10 * k + i, alpha=True)[0]
+                cst = U.stride_for(ow)
+                canvas0 = rng.integers(0, 256, size=(oh, cst), dtype=np.uint8)
+                exp = canvas0.copy()
+                rc, _ = O.scale_and_render(fr, iw, ih, exp, ow, oh, 0, 0, ow, oh, compositing=int(compose), matte_bgra=0xFF336699,
+                                           alpha_meaningful=alpha)
+                assert rc == 0
+                got = canvas0.copy()
+                scale_and_render_host(fr, iw, ih, fr.shape[1], alpha, got, ow, oh, cst, ScaleAndRenderParams(0, 0, ow, oh), compose, 0xFF336699)
+                if not np.array_equal(got[:, :4 * ow], exp[:, :4 * ow]):
+                    errors.append((k, i, "pixels differ"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
