@@ -177,7 +177,7 @@ def test_libjpeg_turbo_preset_writes_the_file_libjpeg_turbo_writes(size, quality
     bgra[:, :4 * w] = np.concatenate([rgb[:, :, ::-1], np.full((h, w, 1), 255, np.uint8)], -1).reshape(h, 4 * w)
     preset = {"libjpeg_turbo": {} if quality is None else {"quality": quality}}
     with Context() as c:
-        c.add_input_bytes(0, pack_raw_bgra(bgra, w, h, alpha_meaningful=False))
+        c.add_input_buffer(0, pack_raw_bgra(bgra, w, h, alpha_meaningful=False))
         c.add_output_buffer(1)
         r = _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"encode": {"io_id": 1, "preset": preset}}]}})
         got = bytes(c.get_output_buffer(1))
@@ -202,7 +202,7 @@ def test_libjpeg_turbo_preset_flattens_alpha_onto_the_matte_first():
         if matte_json:
             params["matte"] = matte_json
         with Context() as c:
-            c.add_input_bytes(0, pack_raw_bgra(fr[0], w, h, alpha_meaningful=True))
+            c.add_input_buffer(0, pack_raw_bgra(fr[0], w, h, alpha_meaningful=True))
             c.add_output_buffer(1)
             _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"encode": {"io_id": 1, "preset": {"libjpeg_turbo": params}}}]}})
             got = bytes(c.get_output_buffer(1))
@@ -213,7 +213,7 @@ def test_libjpeg_turbo_preset_flattens_alpha_onto_the_matte_first():
 
 def test_libjpeg_turbo_preset_rejects_what_the_baseline_writer_cannot_do():
     with Context() as c:
-        c.add_input_bytes(0, pack_raw_bgra(np.zeros((8, 64), np.uint8), 8, 8, alpha_meaningful=False))
+        c.add_input_buffer(0, pack_raw_bgra(np.zeros((8, 64), np.uint8), 8, 8, alpha_meaningful=False))
         c.add_output_buffer(1)
         for extra in ({"progressive": True}, {"optimize_huffman_coding": True}):
             status, r = c.send_json("v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"encode": {"io_id": 1, "preset": {"libjpeg_turbo": extra}}}]}})
