@@ -58,6 +58,23 @@ struct DerivedTab {                                  // one Huffman table, decod
     uint8_t val[256];
 };
 
+// The same table in the form the synchronisation and count passes read: everything a pass that only tracks the decoder
+// STATE needs from a symbol sits in one 32-bit entry, so a symbol costs one table read, two byte-adds and a compare.
+//   bits 0-7   bits to skip (code length + magnitude bits)
+//   bits 8-15  zigzag advance: DC 1; AC coefficient run + 1; ZRL 16; EOB 64 (reaching 64 ends the block)
+//   bits 16-23 code length, bits 24-31 the symbol.  0 = code longer than the lookup.
+struct FastTab {
+    uint32_t lut[1u << kLutBits];
+    int32_t maxcode[18];
+    int32_t valoff[18];
+    uint8_t val[256];
+};
+__host__ __device__ inline uint32_t fast_entry(bool ac, uint32_t len, uint32_t sym) {
+    const uint32_t sz = sym & 15u, r = sym >> 4;
+    const uint32_t adv = ac ? (sz ? r + 1u : (r == 15u ? 16u : 64u)) : 1u;
+    return (sym << 24) | (len << 16) | (adv << 8) | (len + sz);
+}
+
 constexpr uint32_t kMaxBlocksInMcu = 10;        // libjpeg's D_MAX_BLOCKS_IN_MCU: files with more are rejected by the parser
 struct EntropyGeom {
     uint32_t ncomp, blocks_per_mcu, mcus_w, mcus_h;
@@ -80,6 +97,7 @@ struct EntropyArgs {
     const Segment* segs;
     const uint32_t* sub_seg;                         // segment of every sub-sequence
     const DerivedTab* tabs;                          // [image][comp][dc, ac]
+    const FastTab* ftabs;                            // the same tables for the synchronisation / count passes
     uint32_t n_sub, n_seg;
     uint32_t uniform_tables;                         // every image carries the same Huffman tables (e.g. the standard ones)
     uint32_t* exit_p[2];                             // exit bit position, double buffered by round parity
@@ -220,89 +238,311 @@ __device__ __forceinline__ void with_tables(const EntropyArgs& a, const DerivedT
     else f(a.tabs + static_cast<size_t>(image) * 6u);
 }
 
-// One synchronisation launch.  Inside the workgroup the fixpoint iteration runs in LDS (a lane whose predecessor's exit
-// state moved decodes again, up to kInnerRounds times), so a launch propagates a correction through all 256
-// sub-sequences of a workgroup; the host only iterates for corrections that cross workgroup boundaries.
+// ---- synchronisation and count passes: the lean walker ----------------------------------------------------------
+// These passes need the decoder STATE only (bit position, block-in-MCU, zigzag index), not the coefficients.  A re-decode
+// iteration of the fixpoint is a handful of lanes walking 1 024 bits each, so its time is the DEPENDENT CHAIN of one
+// symbol times the symbols of a sub-sequence; a dense pass is bound by instruction issue.  Both shrink with:
+//   * a 64-bit window of the stream in registers (left-aligned, `cnt` valid bits), topped up from a word that was
+//     requested one top-up earlier -- the only LDS read on a symbol's chain is the table entry;
+//   * one 32-bit FastTab entry per symbol: bits to skip and zigzag advance are byte fields;
+//   * component / table registers touched only when a block ends.
+// The staged stream is COLUMN-MAJOR with pitch 33 (word j of sub-sequence t at t * 33 + j: lanes walking their own
+// sub-sequences at the same depth hit 32 different banks); positions are relative to the workgroup's first bit.
+#ifndef IFHIP_ENT_SYNC_LANES
+#define IFHIP_ENT_SYNC_LANES 1024
+#endif
+constexpr uint32_t kSyncLanes = IFHIP_ENT_SYNC_LANES;               // sub-sequences per workgroup in these passes
+constexpr uint32_t kSyncCols = kSyncLanes + 1u;                     // a walk stops within 31 bits of its end and looks 3 words ahead
+constexpr uint32_t kColPitch = kSubWords + 1u;
+constexpr uint32_t kFastStageDwords = kSyncCols * kColPitch;
+
+__device__ __forceinline__ void stage_stream_columns(const EntropyArgs& a, uint32_t* lds_words, uint32_t first_sub) {
+    const uint32_t word0 = first_sub * kSubWords;
+    const uint32_t total = (a.n_sub + 2u) * kSubWords;                 // the buffer carries 64 slack words
+    constexpr uint32_t kPer = (kSyncCols * kSubWords + kSyncLanes - 1u) / kSyncLanes;
+    uint32_t v[kPer];
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; ++i) {                              // all loads in flight before the first LDS store
+        const uint32_t w = word0 + threadIdx.x + i * kSyncLanes;
+        v[i] = w < total ? a.words[w] : 0u;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kPer; ++i) {
+        const uint32_t r = threadIdx.x + i * kSyncLanes;
+        if (r < kSyncCols * kSubWords) lds_words[r + r / kSubWords] = v[i];
+    }
+}
+__device__ __forceinline__ uint32_t stream_word(const uint32_t* lds_words, uint32_t i) { return lds_words[i + i / kSubWords]; }
+
+template <typename Tab>
+__device__ __forceinline__ uint32_t long_code_entry(const Tab* t, uint32_t bits, bool ac) {     // jdhuff.c's slow path, see decode_symbol
+    uint32_t l = kLutBits + 1u;
+#pragma unroll
+    for (uint32_t k = kLutBits + 1u; k <= 16u; ++k)
+        l += static_cast<int32_t>(bits >> (32u - k)) > t->maxcode[k] ? 1u : 0u;
+    if (l > 16u) return fast_entry(ac, 16u, 0u);                     // garbage: what decode_symbol does (length 16, symbol 0)
+    const int32_t code = static_cast<int32_t>(bits >> (32u - l));
+    return fast_entry(ac, l, t->val[(code + t->valoff[l]) & 255]);
+}
+
+// Walks the stream from (p, c, z) until p >= end.  kCount: also counts the blocks started and sums the DC differences
+// per component (the count pass; the synchronisation rounds do not need them).
+template <bool kCount, typename Tab>
+__device__ __forceinline__ void walk(const EntropyGeom& g, const uint32_t* lds_words, const Tab* tabs, uint32_t end, uint32_t& p,
+                                     uint32_t& c, uint32_t& z, int32_t& n, int32_t (&dc)[3]) {
+    uint32_t comp = (g.kcomp_packed >> (2u * c)) & 3u;
+    const Tab* tac = tabs + comp * 2u + 1u;
+    const Tab* tcur = z ? tac : tac - 1;
+    uint32_t w = p >> 5;
+    uint64_t buf = ((static_cast<uint64_t>(stream_word(lds_words, w)) << 32) | stream_word(lds_words, w + 1u)) << (p & 31u);
+    uint32_t cnt = 64u - (p & 31u);                                  // valid bits in buf, always > 32 at a symbol's start
+    w += 2u;
+    uint32_t next = stream_word(lds_words, w);
+    while (p < end) {
+        const uint32_t bits = static_cast<uint32_t>(buf >> 32);
+        uint32_t e = tcur->lut[bits >> (32u - kLutBits)];
+        if (e == 0u) e = long_code_entry(tcur, bits, tcur == tac);
+        if (kCount && tcur != tac) {                                 // DC symbol: jdhuff.c HUFF_EXTEND of the sz bits behind the code
+            const uint32_t len = (e >> 16) & 255u, sz = (e >> 24) & 15u;
+            const uint32_t v = ((bits << len) >> 1) >> (31u - sz);
+            const int32_t half = static_cast<int32_t>((1u << sz) >> 1);
+            const int32_t ext = static_cast<int32_t>(v) < half ? static_cast<int32_t>(v) - static_cast<int32_t>((1u << sz) - 1u) : static_cast<int32_t>(v);
+            ++n;
+            dc[comp] += sz ? ext : 0;
+        }
+        const uint32_t skip = e & 255u;
+        p += skip;
+        buf <<= skip;
+        cnt -= skip;
+        if (cnt <= 32u) {                                            // top up from the word requested at the previous top-up
+            buf |= static_cast<uint64_t>(next) << (32u - cnt);
+            cnt += 32u;
+            ++w;
+            next = stream_word(lds_words, w);
+        }
+        z += (e >> 8) & 255u;
+        tcur = tac;
+        if (z >= 64u) {                                              // block complete: next block of the MCU
+            z = 0u;
+            c = c + 1u == g.blocks_per_mcu ? 0u : c + 1u;
+            comp = (g.kcomp_packed >> (2u * c)) & 3u;
+            tcur = tabs + comp * 2u;
+            tac = tcur + 1;
+        }
+    }
+}
+
+// The same walk by a whole WAVE for one sub-sequence: lane d looks up the symbol that would start d bits behind the
+// current position (all 64 offsets at once: one LDS round trip), then the chain "symbol at 0 -> skip -> symbol at skip
+// -> ..." is resolved with scalar instructions and readlane -- no memory access on the dependent chain -- until the block
+// ends (the tables change), the 64 looked-up offsets are used up or the sub-sequence ends.  About one block per window.
+// A lone lane needs ~400 cycles per symbol (a wave issues one instruction per 4 cycles and every symbol waits for its
+// table entry); the late iterations of the fixpoint, where a few sub-sequences carry a correction forward one step per
+// iteration, are nothing but such lone walks.  p, c, z and end are wave-uniform.
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
+
+template <typename Tab>
+__device__ __forceinline__ void walk_wave(const EntropyGeom& g, const uint32_t* lds_words, const Tab* tabs, uint32_t end_, uint32_t& p_,
+                                          uint32_t& c_, uint32_t& z_) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t p = uniform(p_), c = uniform(c_), z = uniform(z_);     // scalar registers: the chain below is scalar code
+    const uint32_t end = uniform(end_), bpm = uniform(g.blocks_per_mcu), kc = uniform(g.kcomp_packed);
+    while (p < end) {
+        const Tab* tac = tabs + ((kc >> (2u * c)) & 3u) * 2u + 1u;
+        const uint32_t q = p + lane, w = q >> 5;
+        const uint64_t v = (static_cast<uint64_t>(stream_word(lds_words, w)) << 32) | stream_word(lds_words, w + 1u);
+        const uint32_t bits = static_cast<uint32_t>((v << (q & 31u)) >> 32);
+        const Tab* t = (lane == 0u && z == 0u) ? tac - 1 : tac;     // only the symbol at the current position can be a DC symbol
+        uint32_t e = t->lut[bits >> (32u - kLutBits)];
+        // The chain, in scalar registers: entry of the symbol at `pos`, advance pos and z, until the block ends (z >= 64),
+        // the window is used up (pos >= lim) or an entry is 0 (a code longer than the lookup ON the chain, 2 % of the
+        // symbols: the long codes of the window are resolved then, once, and the chain goes on).  Hand-written because
+        // the loop is the critical path of the late iterations: ten instructions and one taken branch per symbol.
+        const uint32_t lim = min(64u, end - p);
+        uint32_t pos = 0u, es, tmp;
+        for (;;) {
+            asm volatile(
+                "1:\n\t"
+                "v_readlane_b32 %[es], %[e], %[pos]\n\t"
+                "s_and_b32 %[tmp], %[es], 0xff\n\t"
+                "s_cbranch_scc0 2f\n\t"
+                "s_add_u32 %[pos], %[pos], %[tmp]\n\t"
+                "s_bfe_u32 %[tmp], %[es], 0x80008\n\t"
+                "s_add_u32 %[z], %[z], %[tmp]\n\t"
+                "s_cmp_ge_u32 %[z], 64\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "s_cmp_lt_u32 %[pos], %[lim]\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "2:"
+                : [pos] "+s"(pos), [z] "+s"(z), [es] "=&s"(es), [tmp] "=&s"(tmp)
+                : [e] "v"(e), [lim] "s"(lim)
+                : "scc");
+            if ((es & 255u) != 0u) break;
+            e = e == 0u ? long_code_entry(t, bits, t == tac) : e;
+        }
+        if (z >= 64u) {                                              // block complete: the lanes behind looked up the old tables
+            z = 0u;
+            c = c + 1u == bpm ? 0u : c + 1u;
+        }
+        p += pos;
+    }
+    p_ = p; c_ = c; z_ = z;
+}
+
+template <typename F>
+__device__ __forceinline__ void with_fast_tables(const EntropyArgs& a, const FastTab* lds_tabs, uint32_t lds_image, uint32_t image, F&& f) {
+    if (image == lds_image || a.uniform_tables) f(reinterpret_cast<const __attribute__((address_space(3))) FastTab*>(
+                                  static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_tabs))));
+    else f(a.ftabs + static_cast<size_t>(image) * 6u);
+}
+__device__ __forceinline__ void stage_fast_tables(const EntropyArgs& a, FastTab* lds_tabs, uint32_t image) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.ftabs + static_cast<size_t>(image) * 6u);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(lds_tabs);
+    for (uint32_t i = threadIdx.x; i < sizeof(FastTab) * 6u / 4u; i += kSyncLanes) dst[i] = src[i];
+}
+
+// One synchronisation launch.  Inside the workgroup the fixpoint iteration runs in LDS: in every iteration the
+// sub-sequences whose entry state (= the predecessor's exit) moved are decoded again, until nothing moves or
+// kInnerRounds is reached; the host only iterates for corrections that cross workgroup boundaries.
+// After the first two iterations few sub-sequences need another decode, but they are scattered -- a wave with one busy
+// lane costs as much as a full one -- so the iteration COMPACTS them: sub-sequence states live in LDS (one packed word:
+// relative bit position | block-in-MCU << 21 | zigzag index << 25), the lanes that need a decode enter a work list
+// through a ballot / prefix count, and lane k decodes the k-th entry.  An iteration then costs what its dense waves cost.
 #ifndef IFHIP_ENT_INNER
-#define IFHIP_ENT_INNER 10
+#define IFHIP_ENT_INNER 16
 #endif
 constexpr uint32_t kInnerRounds = IFHIP_ENT_INNER;
+#ifndef IFHIP_ENT_WAVEWALK
+#define IFHIP_ENT_WAVEWALK 48
+#endif
+constexpr uint32_t kWaveWalkMax = IFHIP_ENT_WAVEWALK;                          // at most this many pending sub-sequences: one wave per walk
+constexpr uint32_t kNever = 0xffffffffu;                                       // no decode yet (no real state packs to this)
+static_assert((kSyncLanes + 2u) * kSubBits < (1u << 21), "packed state: 21 bits of relative position");
 
-__global__ void __launch_bounds__(kLanes) entropy_round_kernel(const EntropyArgs a) {
-    __shared__ uint32_t lds_words[kStageDwords];
-    __shared__ DerivedTab lds_tabs[6];
-    __shared__ uint32_t ex_p[kLanes], ex_cz[kLanes];
-    const uint32_t first_sub = blockIdx.x * kLanes;
-    const uint32_t t = threadIdx.x, s = first_sub + t;
+__device__ __forceinline__ uint32_t pack_state(uint32_t p_rel, uint32_t cz) { return p_rel | ((cz >> 8) << 21) | ((cz & 255u) << 25); }
+
+__global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const EntropyArgs a) {
+    __shared__ uint32_t lds_words[kFastStageDwords];
+    __shared__ FastTab lds_tabs[6];
+    __shared__ uint32_t ex[kSyncLanes], used[kSyncLanes];            // exit state; entry state of the last decode
+    __shared__ uint16_t endinfo[kSyncLanes], work[kSyncLanes];       // end - t * 1024; sub-sequences to decode this iteration
+    __shared__ uint32_t wave_cnt[kSyncLanes / 64u];
+    const uint32_t first_sub = blockIdx.x * kSyncLanes;
+    const uint32_t t = threadIdx.x, s = first_sub + t, lane = t & 63u, wave = t >> 6;
     const bool on = s < a.n_sub;
     const uint32_t cur = a.round & 1u, prv = cur ^ 1u;
-    Segment sg = a.segs[a.sub_seg[on ? s : first_sub]];
+    const uint32_t bit0 = first_sub * kSubBits;
+    const Segment sg = a.segs[a.sub_seg[on ? s : first_sub]];
     const bool first = on && s == sg.first_sub;
-    // start state for this launch: exact for the first lane of a segment, speculative in round 0, else the
-    // predecessor's exit state of the previous launch
-    uint32_t p0 = s * kSubBits, cz0 = 0;
-    if (on && !first && a.round > 0u) { p0 = a.exit_p[prv][s - 1u]; cz0 = a.exit_cz[prv][s - 1u]; }
-    uint32_t used_p = on && a.round > 0u ? a.start_p[s] : 0xffffffffu, used_cz = on && a.round > 0u ? a.start_cz[s] : 0xffffffffu;
-    uint32_t my_p = on && a.round > 0u ? a.exit_p[prv][s] : 0u, my_cz = on && a.round > 0u ? a.exit_cz[prv][s] : 0u;
-    const uint32_t old_p = my_p, old_cz = my_cz;
-    int4 my_cnt = make_int4(0, 0, 0, 0);
-    bool have_cnt = false;
-    bool need = on && (p0 != used_p || cz0 != used_cz);
-    if (!__syncthreads_or(need ? 1 : 0)) {                           // nothing moved in front of this workgroup
-        if (on) { a.exit_p[cur][s] = my_p; a.exit_cz[cur][s] = my_cz; }
-        return;
+    // state carried over from the previous launch (none in round 0)
+    uint32_t st_ex = 0u, st_used = kNever;
+    if (on && a.round > 0u) {
+        st_ex = pack_state(a.exit_p[prv][s] - bit0, a.exit_cz[prv][s]);
+        st_used = a.start_p[s] == kNever ? kNever : pack_state(a.start_p[s] - bit0, a.start_cz[s]);
+    }
+    const uint32_t old_ex = st_ex;
+    // entry state of lane 0 of the workgroup comes from the previous workgroup's last launch; round 0 starts every
+    // sub-sequence speculatively at its own first bit
+    uint32_t fixed_entry = pack_state(t * kSubBits, 0u);
+    const bool fixed = first || a.round == 0u || t == 0u;
+    if (on && !first && a.round > 0u && t == 0u) fixed_entry = pack_state(a.exit_p[prv][s - 1u] - bit0, a.exit_cz[prv][s - 1u]);
+    if (a.round > 0u) {
+        const uint32_t entry = fixed ? fixed_entry : pack_state(a.exit_p[prv][s - 1u] - bit0, a.exit_cz[prv][s - 1u]);
+        if (!__syncthreads_or(on && entry != st_used ? 1 : 0)) {     // nothing moved in front of this workgroup
+            if (on) { a.exit_p[cur][s] = a.exit_p[prv][s]; a.exit_cz[cur][s] = a.exit_cz[prv][s]; }
+            return;
+        }
     }
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
-    stage_stream(a, lds_words, first_sub);
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.tabs + static_cast<size_t>(wg_image) * 6u);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(lds_tabs);
-        for (uint32_t i = t; i < sizeof(DerivedTab) * 6u / 4u; i += kLanes) dst[i] = src[i];
-    }
-    ex_p[t] = my_p; ex_cz[t] = my_cz;
+    stage_stream_columns(a, lds_words, first_sub);
+    stage_fast_tables(a, lds_tabs, wg_image);
+    ex[t] = st_ex; used[t] = st_used;
+    endinfo[t] = static_cast<uint16_t>(on ? min((s + 1u) * kSubBits, sg.bit_end) - s * kSubBits : 0u);
     __syncthreads();
-    const BitSrc src{lds_words, first_sub * kSubBits};
-    const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end);
     bool pending = false;
+#ifdef IFHIP_ENT_TRACE
+    unsigned long long tr_t[24]; uint32_t tr_n[24], tr_k = 0u;
+    const unsigned long long tr_0 = wall_clock64();
+#endif
     for (uint32_t it = 0; it < kInnerRounds; ++it) {
-        if (need) {
-            used_p = p0; used_cz = cz0;
-            uint32_t err = 0, c_out = 0, z_out = 0;
-            int32_t n = 0, dc[3] = {0, 0, 0};
-            BitReader br(src, p0);
-            with_tables(a, lds_tabs, wg_image, sg.image, [&](auto tabs) {
-                SymState<std::remove_cv_t<std::remove_pointer_t<decltype(tabs)>>> S;
-                S.z = cz0 & 255u;
-                S.set_block(a.g, tabs, cz0 >> 8);
-                while (br.p < end) {
-                    uint32_t kind, at = 0;
-                    int32_t value = 0;
-                    decode_symbol(a.g, br, tabs, S, kind, at, value, err);
-                    if (kind == 0u) { ++n; dc[at] += value; }
-                }
-                c_out = S.c; z_out = S.z;
-            });
-            my_p = br.p; my_cz = (c_out << 8) | z_out;
-            my_cnt = make_int4(n, dc[0], dc[1], dc[2]);
-            have_cnt = true;
-        }
-        __syncthreads();                                             // everyone has read ex[t-1] of the previous iteration
-        ex_p[t] = my_p; ex_cz[t] = my_cz;
+        // speculative first decode of round 0: from the sub-sequence's own first bit; afterwards from the predecessor's exit
+        const uint32_t entry = (fixed && !(a.round == 0u && it > 0u && !first && t > 0u)) ? fixed_entry : ex[t - 1u];
+        const bool need = on && entry != used[t];
+        const uint64_t vote = __ballot(need);
+        if (lane == 0u) wave_cnt[wave] = static_cast<uint32_t>(__popcll(vote));
         __syncthreads();
-        if (on && !first && t > 0u) { p0 = ex_p[t - 1u]; cz0 = ex_cz[t - 1u]; }
-        need = on && (p0 != used_p || cz0 != used_cz);
-        pending = __syncthreads_or(need ? 1 : 0) != 0;
+        uint32_t base = 0u, total = 0u;
+#pragma unroll
+        for (uint32_t w = 0; w < kSyncLanes / 64u; ++w) { const uint32_t n = wave_cnt[w]; base += w < wave ? n : 0u; total += n; }
+        pending = total != 0u;
+#ifdef IFHIP_ENT_TRACE
+        if (it < 24u) { tr_t[it] = wall_clock64(); tr_n[it] = total; tr_k = it + 1u; }
+#endif
         if (!pending) break;
+        if (need) {
+            used[t] = entry;
+            work[base + static_cast<uint32_t>(__popcll(vote & ((1ull << lane) - 1ull)))] = static_cast<uint16_t>(t);
+        }
+        __syncthreads();
+        if (total <= kWaveWalkMax) {                                 // few sub-sequences: one wave each, see walk_wave
+            for (uint32_t k = wave; k < total; k += kSyncLanes / 64u) {
+                const uint32_t j = work[k];
+                const uint32_t e0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(used[j])));
+                uint32_t p = e0 & 0x1fffffu, c = (e0 >> 21) & 15u, z = e0 >> 25;
+                const uint32_t end = j * kSubBits + endinfo[j];
+                const uint32_t image = a.uniform_tables ? wg_image : a.segs[a.sub_seg[first_sub + j]].image;
+                with_fast_tables(a, lds_tabs, wg_image, image, [&](auto tabs) { walk_wave(a.g, lds_words, tabs, end, p, c, z); });
+                if (lane == 0u) ex[j] = p | (c << 21) | (z << 25);
+            }
+        } else if (t < total) {
+            const uint32_t j = work[t];
+            const uint32_t e0 = used[j];
+            uint32_t p = e0 & 0x1fffffu, c = (e0 >> 21) & 15u, z = e0 >> 25;
+            const uint32_t end = j * kSubBits + endinfo[j];
+            int32_t n = 0, dc[3] = {0, 0, 0};
+            const uint32_t image = a.uniform_tables ? wg_image : a.segs[a.sub_seg[first_sub + j]].image;
+            with_fast_tables(a, lds_tabs, wg_image, image, [&](auto tabs) { walk<false>(a.g, lds_words, tabs, end, p, c, z, n, dc); });
+            ex[j] = p | (c << 21) | (z << 25);
+        }
+        __syncthreads();
     }
+#ifdef IFHIP_ENT_TRACE
+    if (t == 0u && (blockIdx.x % 60u) == 7u)
+        for (uint32_t i = 0; i < tr_k; ++i) printf("wg %u round %u it %u total %u us %.2f\n", blockIdx.x, a.round, i, tr_n[i], (double)(tr_t[i] - tr_0) / 100.0);
+#endif
     if (!on) return;
-    a.exit_p[cur][s] = my_p;
-    a.exit_cz[cur][s] = my_cz;
-    a.start_p[s] = used_p;
-    a.start_cz[s] = used_cz;
-    if (have_cnt) a.cnt[s] = my_cnt;
+    const uint32_t fin = ex[t], fu = used[t];
+    a.exit_p[cur][s] = (fin & 0x1fffffu) + bit0;
+    a.exit_cz[cur][s] = (((fin >> 21) & 15u) << 8) | (fin >> 25);
+    a.start_p[s] = fu == kNever ? kNever : (fu & 0x1fffffu) + bit0;
+    a.start_cz[s] = (((fu >> 21) & 15u) << 8) | (fu >> 25);
     // another launch is needed if this lane's exit moved (its successor may sit in the next workgroup) or the inner
     // iteration was cut short
-    if (a.round > 0u && (my_p != old_p || my_cz != old_cz || need)) atomicAdd(a.changed + (a.round & 15u), 1u);
+    if (a.round > 0u && (fin != old_ex || pending)) atomicAdd(a.changed + (a.round & 15u), 1u);
+}
+
+// Count pass, once the exit states are final: every lane walks its sub-sequence from its true entry state and records
+// {blocks started, DC difference sum per component} for the scan that gives the write pass its first block and its DC
+// predictors.  (The synchronisation rounds used to carry these sums through every re-decode.)
+__global__ void __launch_bounds__(kSyncLanes) entropy_count_kernel(const EntropyArgs a) {
+    __shared__ uint32_t lds_words[kFastStageDwords];
+    __shared__ FastTab lds_tabs[6];
+    const uint32_t first_sub = blockIdx.x * kSyncLanes;
+    const uint32_t s = first_sub + threadIdx.x;
+    const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
+    stage_stream_columns(a, lds_words, first_sub);
+    stage_fast_tables(a, lds_tabs, wg_image);
+    __syncthreads();
+    if (s >= a.n_sub) return;
+    const Segment sg = a.segs[a.sub_seg[s]];
+    const uint32_t fin = a.round & 1u;
+    const uint32_t bit0 = first_sub * kSubBits;
+    uint32_t p = s * kSubBits - bit0, c = 0, z = 0;
+    if (s != sg.first_sub) { p = a.exit_p[fin][s - 1u] - bit0; const uint32_t cz = a.exit_cz[fin][s - 1u]; c = cz >> 8; z = cz & 255u; }
+    const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end) - bit0;
+    int32_t n = 0, dc[3] = {0, 0, 0};
+    with_fast_tables(a, lds_tabs, wg_image, sg.image, [&](auto tabs) { walk<true>(a.g, lds_words, tabs, end, p, c, z, n, dc); });
+    a.cnt[s] = make_int4(n, dc[0], dc[1], dc[2]);
 }
 
 // exclusive scan of cnt over the sub-sequences of one segment: one workgroup of 1024 lanes per segment, every lane sums
@@ -569,6 +809,12 @@ void derive_table(const HuffSpec& h, DerivedTab* t) {
     }
     t->maxcode[17] = 0x7fffffff;
 }
+void derive_fast_table(const DerivedTab& d, bool ac, FastTab* f) {
+    std::memcpy(f->maxcode, d.maxcode, sizeof f->maxcode);
+    std::memcpy(f->valoff, d.valoff, sizeof f->valoff);
+    std::memcpy(f->val, d.val, sizeof f->val);
+    for (uint32_t i = 0; i < (1u << kLutBits); ++i) f->lut[i] = d.lut[i] ? fast_entry(ac, d.lut[i] >> 8, d.lut[i] & 255u) : 0u;
+}
 
 }  // namespace
 
@@ -830,11 +1076,15 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     uint32_t *d_words = nullptr, *d_sub = nullptr;
     Segment* d_segs = nullptr;
     DerivedTab* d_tabs = nullptr;
+    FastTab* d_ftabs = nullptr;
+    std::vector<FastTab> ftabs(tabs.size());
+    for (size_t i = 0; i < tabs.size(); ++i) derive_fast_table(tabs[i], (i & 1u) != 0u, &ftabs[i]);
     if ((rc = dev_alloc(e.get(), &d_words, n_words, words))) return rc;
     if ((rc = dev_alloc(e.get(), &d_segs, segs.size(), segs.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_sub, sub_seg.size(), sub_seg.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_tabs, tabs.size(), tabs.data()))) return rc;
-    a.words = d_words; a.segs = d_segs; a.sub_seg = d_sub; a.tabs = d_tabs;
+    if ((rc = dev_alloc(e.get(), &d_ftabs, ftabs.size(), ftabs.data()))) return rc;
+    a.words = d_words; a.segs = d_segs; a.sub_seg = d_sub; a.tabs = d_tabs; a.ftabs = d_ftabs;
     for (int b = 0; b < 2; ++b) {
         if ((rc = dev_alloc<uint32_t>(e.get(), &a.exit_p[b], a.n_sub))) return rc;
         if ((rc = dev_alloc<uint32_t>(e.get(), &a.exit_cz[b], a.n_sub))) return rc;
@@ -909,6 +1159,7 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: coefficient planes must be 16-byte aligned");
     HIP_TRY(hipMemsetAsync(a.changed, 0, 17 * sizeof(uint32_t), st));
     const dim3 grid((a.n_sub + 255u) / 256u), block(256);
+    const dim3 sync_grid((a.n_sub + kSyncLanes - 1u) / kSyncLanes), sync_block(kSyncLanes);
     const uint32_t max_rounds = a.n_sub + 2u;
     // Rounds 0..2 (speculative decode with the fixpoint iteration inside every workgroup; corrections that cross a
     // workgroup boundary; the confirmation that nothing moved any more), the scan and the write pass are enqueued
@@ -918,12 +1169,14 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
     uint32_t r = 0;
     for (; r < 3u; ++r) {
         a.round = r;
-        hipLaunchKernelGGL(entropy_round_kernel, grid, block, 0, st, a);
+        hipLaunchKernelGGL(entropy_round_kernel, sync_grid, sync_block, 0, st, a);
         HIP_TRY(hipGetLastError());
     }
     r = 2u;
     for (;;) {
         a.round = r;
+        hipLaunchKernelGGL(entropy_count_kernel, sync_grid, sync_block, 0, st, a);
+        HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(entropy_scan_kernel, dim3(a.n_seg), dim3(1024), 0, st, a);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(entropy_write_kernel, grid, block, 0, st, a);
@@ -936,7 +1189,7 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
             if (r >= max_rounds) return fail(IFHIP_INVALID_STATE, "InvalidState: entropy decode did not converge");
             HIP_TRY(hipMemsetAsync(a.changed + (r & 15u), 0, sizeof(uint32_t), st));
             a.round = r;
-            hipLaunchKernelGGL(entropy_round_kernel, grid, block, 0, st, a);
+            hipLaunchKernelGGL(entropy_round_kernel, sync_grid, sync_block, 0, st, a);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(e->h_flags, a.changed, 17 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
