@@ -256,31 +256,37 @@ constexpr uint32_t kSyncCols = kSyncLanes + 1u;                     // a walk st
 constexpr uint32_t kColPitch = kSubWords + 1u;
 constexpr uint32_t kFastStageDwords = kSyncCols * kColPitch;
 
+template <uint32_t kWg, uint32_t kColsT>
 __device__ __forceinline__ void stage_stream_columns(const EntropyArgs& a, uint32_t* lds_words, uint32_t first_sub) {
     const uint32_t word0 = first_sub * kSubWords;
     const uint32_t total = (a.n_sub + 2u) * kSubWords;                 // the buffer carries 64 slack words
-    constexpr uint32_t kPer = (kSyncCols * kSubWords + kSyncLanes - 1u) / kSyncLanes;
+    constexpr uint32_t kPer = (kColsT * kSubWords + kWg - 1u) / kWg;
     uint32_t v[kPer];
 #pragma unroll
     for (uint32_t i = 0; i < kPer; ++i) {                              // all loads in flight before the first LDS store
-        const uint32_t w = word0 + threadIdx.x + i * kSyncLanes;
+        const uint32_t w = word0 + threadIdx.x + i * kWg;
         v[i] = w < total ? a.words[w] : 0u;
     }
 #pragma unroll
     for (uint32_t i = 0; i < kPer; ++i) {
-        const uint32_t r = threadIdx.x + i * kSyncLanes;
-        if (r < kSyncCols * kSubWords) lds_words[r + r / kSubWords] = v[i];
+        const uint32_t r = threadIdx.x + i * kWg;
+        if (r < kColsT * kSubWords) lds_words[r + r / kSubWords] = v[i];
     }
 }
 __device__ __forceinline__ uint32_t stream_word(const uint32_t* lds_words, uint32_t i) { return lds_words[i + i / kSubWords]; }
 
+// jdhuff.c's slow path "l = min{l : code_l <= maxcode[l]}" without its dependent chain: all candidate lengths are compared at
+// once (the host stores a monotone maxcode, see derive_table), three LDS round trips instead of up to nine.
 template <typename Tab>
-__device__ __forceinline__ uint32_t long_code_entry(const Tab* t, uint32_t bits, bool ac) {     // jdhuff.c's slow path, see decode_symbol
+__device__ __forceinline__ uint32_t long_code_entry(const Tab* t, uint32_t bits, bool ac, uint32_t* err = nullptr) {
     uint32_t l = kLutBits + 1u;
 #pragma unroll
     for (uint32_t k = kLutBits + 1u; k <= 16u; ++k)
         l += static_cast<int32_t>(bits >> (32u - k)) > t->maxcode[k] ? 1u : 0u;
-    if (l > 16u) return fast_entry(ac, 16u, 0u);                     // garbage: what decode_symbol does (length 16, symbol 0)
+    if (l > 16u) {                                                   // no such code: length 16, symbol 0, reported by the write pass
+        if (err) *err |= 1u;
+        return fast_entry(ac, 16u, 0u);
+    }
     const int32_t code = static_cast<int32_t>(bits >> (32u - l));
     return fast_entry(ac, l, t->val[(code + t->valoff[l]) & 255]);
 }
@@ -395,10 +401,11 @@ __device__ __forceinline__ void with_fast_tables(const EntropyArgs& a, const Fas
                                   static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_tabs))));
     else f(a.ftabs + static_cast<size_t>(image) * 6u);
 }
+template <uint32_t kWg>
 __device__ __forceinline__ void stage_fast_tables(const EntropyArgs& a, FastTab* lds_tabs, uint32_t image) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(a.ftabs + static_cast<size_t>(image) * 6u);
     uint32_t* dst = reinterpret_cast<uint32_t*>(lds_tabs);
-    for (uint32_t i = threadIdx.x; i < sizeof(FastTab) * 6u / 4u; i += kSyncLanes) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < sizeof(FastTab) * 6u / 4u; i += kWg) dst[i] = src[i];
 }
 
 // One synchronisation launch.  Inside the workgroup the fixpoint iteration runs in LDS: in every iteration the
@@ -454,8 +461,8 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
         }
     }
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
-    stage_stream_columns(a, lds_words, first_sub);
-    stage_fast_tables(a, lds_tabs, wg_image);
+    stage_stream_columns<kSyncLanes, kSyncCols>(a, lds_words, first_sub);
+    stage_fast_tables<kSyncLanes>(a, lds_tabs, wg_image);
     ex[t] = st_ex; used[t] = st_used;
     endinfo[t] = static_cast<uint16_t>(on ? min((s + 1u) * kSubBits, sg.bit_end) - s * kSubBits : 0u);
     __syncthreads();
@@ -530,8 +537,8 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_count_kernel(const Entropy
     const uint32_t first_sub = blockIdx.x * kSyncLanes;
     const uint32_t s = first_sub + threadIdx.x;
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
-    stage_stream_columns(a, lds_words, first_sub);
-    stage_fast_tables(a, lds_tabs, wg_image);
+    stage_stream_columns<kSyncLanes, kSyncCols>(a, lds_words, first_sub);
+    stage_fast_tables<kSyncLanes>(a, lds_tabs, wg_image);
     __syncthreads();
     if (s >= a.n_sub) return;
     const Segment sg = a.segs[a.sub_seg[s]];
@@ -580,72 +587,118 @@ __global__ void __launch_bounds__(1024) entropy_scan_kernel(const EntropyArgs a)
 // past its sub-sequence if need be), assembles the 64 coefficients in a private LDS row (pitch 34 dwords: conflict-free
 // across lanes) and stores the whole block with eight 16-byte stores -- every block is written exactly once, zeros
 // included, so the planes need no clearing and no two lanes ever touch the same block.  A lane that starts inside a
-// block skips to its end without storing.
+// block skips to its end without storing.  Same reader and table entries as the walker above; workgroups of 512
+// sub-sequences (stream 66 KiB + rows 68 KiB + tables: one workgroup per CU).
+constexpr uint32_t kWriteLanes = 512;
+constexpr uint32_t kWriteCols = kWriteLanes + kMarginSubs;
 constexpr uint32_t kBlkPitch = 34;                   // dwords per lane row (32 + 2)
+struct BlockPlace { uint32_t hv, bw, bh, comp; };    // block k of an MCU: hs | vs << 8 | dx << 16 | dy << 24, plane dimensions in blocks
 
-__global__ void __launch_bounds__(kLanes) entropy_write_kernel(const EntropyArgs a) {
-    __shared__ uint32_t lds_words[kStageDwords];
-    __shared__ DerivedTab lds_tabs[6];
-    __shared__ __attribute__((aligned(8))) uint32_t lds_blk[kLanes * kBlkPitch];
+__global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const EntropyArgs a) {
+    __shared__ uint32_t lds_words[kWriteCols * kColPitch];
+    __shared__ FastTab lds_tabs[6];
+    __shared__ __attribute__((aligned(8))) uint32_t lds_blk[kWriteLanes * kBlkPitch];
+    __shared__ BlockPlace lds_place[kMaxBlocksInMcu];
+    __shared__ int16_t* lds_plane[3];
     __shared__ uint8_t lds_zz[64];                   // zigzag -> natural order (a divergent index into __constant__ memory is a
     if (threadIdx.x < 64u) lds_zz[threadIdx.x] = kZigzag[threadIdx.x];      // vector-memory load per coefficient)
-    const uint32_t first_sub = blockIdx.x * kLanes;
+    if (threadIdx.x < a.g.blocks_per_mcu) {
+        const uint32_t k = threadIdx.x, cm = a.g.kcomp[k];
+        lds_place[k] = BlockPlace{a.g.hs[cm] | (a.g.vs[cm] << 8) | (static_cast<uint32_t>(a.g.kdx[k]) << 16) | (static_cast<uint32_t>(a.g.kdy[k]) << 24),
+                                  a.g.bw[cm], a.g.bh[cm], cm};
+    }
+    if (threadIdx.x < 3u) lds_plane[threadIdx.x] = a.coef[threadIdx.x];
+    const uint32_t first_sub = blockIdx.x * kWriteLanes;
     const uint32_t s = first_sub + threadIdx.x;
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
-    stage_stream(a, lds_words, first_sub);
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.tabs + static_cast<size_t>(wg_image) * 6u);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(lds_tabs);
-        for (uint32_t i = threadIdx.x; i < sizeof(DerivedTab) * 6u / 4u; i += kLanes) dst[i] = src[i];
-    }
+    stage_stream_columns<kWriteLanes, kWriteCols>(a, lds_words, first_sub);
+    stage_fast_tables<kWriteLanes>(a, lds_tabs, wg_image);
     __syncthreads();
     if (s >= a.n_sub) return;
     const Segment sg = a.segs[a.sub_seg[s]];
     const uint32_t fin = a.round & 1u;                       // parity of the last round run
-    const bool first = s == sg.first_sub;
-    uint32_t p = s * kSubBits, cz = 0;
-    if (!first) { p = a.exit_p[fin][s - 1u]; cz = a.exit_cz[fin][s - 1u]; }
-    const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end);
+    const uint32_t bit0 = first_sub * kSubBits;
+    uint32_t p = s * kSubBits - bit0, c = 0u, z = 0u;
+    if (s != sg.first_sub) { p = a.exit_p[fin][s - 1u] - bit0; const uint32_t cz = a.exit_cz[fin][s - 1u]; c = cz >> 8; z = cz & 255u; }
+    const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end) - bit0;
     uint32_t err = 0;
     const int4 pre = a.prefix[s];
     int32_t dc[3] = {pre.y, pre.z, pre.w};
-    int32_t block = pre.x - 1;                               // last block started before this lane
-    const BitSrc src{lds_words, first_sub * kSubBits};
+    uint32_t block = static_cast<uint32_t>(pre.x);           // the next block this lane starts
+    const uint32_t B = a.g.blocks_per_mcu;
+    uint32_t my, mx;                                         // MCU of that block (the block-in-MCU is the decoder's c)
+    { const uint32_t m = sg.first_mcu + block / B; my = m / a.g.mcus_w; mx = m - my * a.g.mcus_w; }
     int16_t* row = reinterpret_cast<int16_t*>(lds_blk + threadIdx.x * kBlkPitch);
     uint2* row2 = reinterpret_cast<uint2*>(lds_blk + threadIdx.x * kBlkPitch);
-    const uint32_t B = a.g.blocks_per_mcu;
-    BitReader br(src, p);
-    with_tables(a, lds_tabs, wg_image, sg.image, [&](auto tabs) {
-        uint32_t kind, at = 0;
-        int32_t value = 0;
-        SymState<std::remove_cv_t<std::remove_pointer_t<decltype(tabs)>>> S;
-        S.z = cz & 255u;
-        S.set_block(a.g, tabs, cz >> 8);
-        while (S.z != 0u) decode_symbol(a.g, br, tabs, S, kind, at, value, err);           // tail of the predecessor's block
-        while (br.p < end) {
-            ++block;
-            if (static_cast<uint32_t>(block) >= sg.n_blocks) break;                        // pad bits behind the last block
+    with_fast_tables(a, lds_tabs, wg_image, sg.image, [&](auto tabs) {
+        using TabP = decltype(tabs);
+        uint32_t comp = (a.g.kcomp_packed >> (2u * c)) & 3u;
+        TabP tac = tabs + comp * 2u + 1u;
+        TabP tcur = z ? tac : tac - 1;
+        uint32_t w = p >> 5;
+        uint64_t buf = ((static_cast<uint64_t>(stream_word(lds_words, w)) << 32) | stream_word(lds_words, w + 1u)) << (p & 31u);
+        uint32_t cnt = 64u - (p & 31u);
+        w += 2u;
+        uint32_t next = stream_word(lds_words, w);
+        // one symbol: entry and the 32 bits it was decoded from; the reader moves on, z / tables are the caller's
+        auto symbol = [&](uint32_t& bits) {
+            bits = static_cast<uint32_t>(buf >> 32);
+            uint32_t e = tcur->lut[bits >> (32u - kLutBits)];
+            if (e == 0u) e = long_code_entry(tcur, bits, tcur == tac, &err);
+            const uint32_t skip = e & 255u;
+            p += skip; buf <<= skip; cnt -= skip;
+            if (cnt <= 32u) { buf |= static_cast<uint64_t>(next) << (32u - cnt); cnt += 32u; ++w; next = stream_word(lds_words, w); }
+            return e;
+        };
+        auto advance = [&](uint32_t e) {                     // -> true when the block is complete
+            z += (e >> 8) & 255u;
+            tcur = tac;
+            if (z < 64u) return false;
+            z = 0u;
+            c = c + 1u == B ? 0u : c + 1u;
+            comp = (a.g.kcomp_packed >> (2u * c)) & 3u;
+            tcur = tabs + comp * 2u;
+            tac = tcur + 1;
+            return true;
+        };
+        uint32_t bits;
+        while (z != 0u) advance(symbol(bits));               // tail of the predecessor's block
+        while (p < end && block < sg.n_blocks) {             // (pad bits may follow the last block)
 #pragma unroll
             for (uint32_t i = 0; i < 16u; ++i) row2[i] = make_uint2(0u, 0u);
+            const uint32_t k = c;
+            bool done;
             do {
-                decode_symbol(a.g, br, tabs, S, kind, at, value, err);
-                if (kind == 0u) { dc[at] += value; row[0] = static_cast<int16_t>(dc[at]); }
-                else if (kind == 1u) row[lds_zz[at]] = static_cast<int16_t>(value);
-            } while (S.z != 0u);
-            const uint32_t m = sg.first_mcu + static_cast<uint32_t>(block) / B, k = static_cast<uint32_t>(block) % B;
-            const uint32_t cm = a.g.kcomp[k];
-            const uint32_t my = m / a.g.mcus_w, mx = m - my * a.g.mcus_w;
-            const uint32_t bx = mx * a.g.hs[cm] + a.g.kdx[k], by = my * a.g.vs[cm] + a.g.kdy[k];
-            uint4* dst = reinterpret_cast<uint4*>(a.coef[cm] + ((static_cast<size_t>(sg.image) * a.g.bh[cm] + by) * a.g.bw[cm] + bx) * 64u);
+                const bool is_dc = tcur != tac;
+                const uint32_t e = symbol(bits);
+                const uint32_t len = (e >> 16) & 255u, sym = e >> 24, sz = sym & 15u;
+                const uint32_t v = ((bits << len) >> 1) >> (31u - sz);           // sz bits behind the code (sz = 0 -> 0)
+                const int32_t neg = static_cast<int32_t>((1u << sz) - 1u);
+                const int32_t value = static_cast<int32_t>(v) - ((static_cast<int32_t>(bits << len) < 0 || sz == 0u) ? 0 : neg);   // jdhuff.c HUFF_EXTEND
+                if (is_dc) {
+                    if (sym > 11u) err |= 2u;
+                    dc[comp] += value;
+                    row[0] = static_cast<int16_t>(dc[comp]);
+                } else if (sz != 0u) {
+                    const uint32_t pos = z + ((e >> 8) & 255u) - 1u;
+                    if (pos > 63u) err |= 4u; else row[lds_zz[pos]] = static_cast<int16_t>(value);
+                }
+                done = advance(e);
+            } while (!done);
+            const BlockPlace pl = lds_place[k];
+            const uint32_t bx = mx * (pl.hv & 255u) + ((pl.hv >> 16) & 255u), by = my * ((pl.hv >> 8) & 255u) + (pl.hv >> 24);
+            uint4* dst = reinterpret_cast<uint4*>(lds_plane[pl.comp] + (static_cast<size_t>(sg.image * pl.bh + by) * pl.bw + bx) * 64u);
 #pragma unroll
             for (uint32_t i = 0; i < 8u; ++i) {
                 const uint2 lo = row2[2u * i], hi = row2[2u * i + 1u];
                 dst[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
+            ++block;
+            if (c == 0u) { ++mx; if (mx == a.g.mcus_w) { mx = 0u; ++my; } }      // the MCU is complete
         }
     });
     const bool last = s + 1u == sg.first_sub + sg.n_sub;
-    if (last && static_cast<uint32_t>(block + 1) < sg.n_blocks) err |= 8u;     // the segment ran out of data
+    if (last && block < sg.n_blocks) err |= 8u;              // the segment ran out of data
     if (err) atomicOr(a.errors, err);
 }
 
@@ -1179,7 +1232,7 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(entropy_scan_kernel, dim3(a.n_seg), dim3(1024), 0, st, a);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(entropy_write_kernel, grid, block, 0, st, a);
+        hipLaunchKernelGGL(entropy_write_kernel, dim3((a.n_sub + kWriteLanes - 1u) / kWriteLanes), dim3(kWriteLanes), 0, st, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(e->h_flags, a.changed, 17 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
