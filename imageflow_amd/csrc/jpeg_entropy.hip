@@ -51,22 +51,27 @@ constexpr uint32_t kSubWords = kSubBits / 32;
 #endif
 constexpr uint32_t kLutBits = IFHIP_ENT_LUTBITS;
 
-struct DerivedTab {                                  // one Huffman table, decode form (jdhuff.c jpeg_make_d_derived_tbl)
-    uint16_t lut[1u << kLutBits];                    // (length << 8) | symbol for codes of length <= 9, else 0
-    int32_t maxcode[18];                             // largest code of each length, -1 if none; [17] = sentinel
-    int32_t valoff[18];                              // huffval index of the first code of each length minus that code
-    uint8_t val[256];
-};
-
-// The same table in the form the synchronisation and count passes read: everything a pass that only tracks the decoder
-// STATE needs from a symbol sits in one 32-bit entry, so a symbol costs one table read, two byte-adds and a compare.
-//   bits 0-7   bits to skip (code length + magnitude bits)
+// Huffman tables in the form every pass reads.  Everything a pass needs from a symbol sits in one 32-bit entry, found
+// with ONE lookup by the next kLutBits bits of the stream -- or two for the 2 % of the symbols whose code is longer:
+//   bits 0-7   bits to skip (code length + magnitude bits); 0 = the code is longer than the lookup
 //   bits 8-15  zigzag advance: DC 1; AC coefficient run + 1; ZRL 16; EOB 64 (reaching 64 ends the block)
-//   bits 16-23 code length, bits 24-31 the symbol.  0 = code longer than the lookup.
-struct FastTab {
-    uint32_t lut[1u << kLutBits];
-    int32_t maxcode[18];
-    int32_t valoff[18];
+//   bits 16-23 code length (17: no such code), bits 24-31 the symbol.
+// A first-level entry with skip 0 points into the image's second level (`pool`): bits 16-31 the offset of a sub-table
+// indexed by the n bits that follow the first kLutBits (n = longest code with this prefix - kLutBits), bits 8-15 hold
+// 32 - n.  jdhuff.c's slow path (the serial "first l with code_l <= maxcode[l]" search) survives only for sub-tables
+// that did not fit the pool (first-level entry 0): it reads SearchTab from global memory and no real file gets there.
+constexpr uint32_t kLutEntries = 1u << kLutBits;
+#ifndef IFHIP_ENT_POOL
+#define IFHIP_ENT_POOL 768
+#endif
+constexpr uint32_t kPoolEntries = IFHIP_ENT_POOL;
+struct FastTabs {                                    // one image: [comp][dc, ac] and their shared second level
+    uint32_t lut[6][kLutEntries];
+    uint32_t pool[kPoolEntries];
+};
+struct SearchTab {                                   // jdhuff.c jpeg_make_d_derived_tbl, global memory only
+    int32_t maxcode[18];                             // largest code of each length (monotone, see derive_search_table)
+    int32_t valoff[18];                              // huffval index of the first code of each length minus that code
     uint8_t val[256];
 };
 __host__ __device__ inline uint32_t fast_entry(bool ac, uint32_t len, uint32_t sym) {
@@ -74,6 +79,10 @@ __host__ __device__ inline uint32_t fast_entry(bool ac, uint32_t len, uint32_t s
     const uint32_t adv = ac ? (sz ? r + 1u : (r == 15u ? 16u : 64u)) : 1u;
     return (sym << 24) | (len << 16) | (adv << 8) | (len + sz);
 }
+// A bit pattern no code starts with (corrupt data, or a speculative decode off the symbol grid): 16 bits are skipped as
+// symbol 0, the length field says 17 and the write pass reports it.
+__host__ __device__ inline uint32_t invalid_entry(bool ac) { return (17u << 16) | ((ac ? 64u : 1u) << 8) | 16u; }
+
 
 constexpr uint32_t kMaxBlocksInMcu = 10;        // libjpeg's D_MAX_BLOCKS_IN_MCU: files with more are rejected by the parser
 struct EntropyGeom {
@@ -96,8 +105,8 @@ struct EntropyArgs {
     const uint32_t* words;                           // un-stuffed scan data, big-endian words, segments 1024-bit aligned
     const Segment* segs;
     const uint32_t* sub_seg;                         // segment of every sub-sequence
-    const DerivedTab* tabs;                          // [image][comp][dc, ac]
-    const FastTab* ftabs;                            // the same tables for the synchronisation / count passes
+    const FastTabs* ftabs;                           // [image]
+    const SearchTab* stabs;                          // [image][comp][dc, ac]: the serial search, for sub-tables that did not fit
     uint32_t n_sub, n_seg;
     uint32_t uniform_tables;                         // every image carries the same Huffman tables (e.g. the standard ones)
     uint32_t* exit_p[2];                             // exit bit position, double buffered by round parity
@@ -116,145 +125,12 @@ __constant__ uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18
                                     41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
                                     15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-// ---- per-workgroup staging -------------------------------------------------------------------------------------
-// A workgroup of 256 lanes owns 256 consecutive sub-sequences = 32 KiB of contiguous stream (plus kMarginSubs
-// sub-sequences of overshoot room), copied into LDS with coalesced loads.  The LDS copy is WORD-MAJOR: word j of
-// sub-sequence t sits at row j, column t (row pitch kRowPitch dwords), so that
-//   * the lanes of a wave, each walking its own sub-sequence, touch consecutive banks whatever their progress;
-//   * the two words a peek needs are one row apart, because row 32 repeats row 0 shifted by one column (word 0 of the
-//     NEXT sub-sequence), and a lane that runs past its own sub-sequence simply moves on to the next column.
-// The reader keeps nothing but the bit position: every symbol costs one two-word LDS read and one 64-bit shift instead
-// of a register bit buffer with its top-up arithmetic (the symbol loop is bound by instruction issue when the wave is
-// full and by its dependent chain when a lone lane carries a correction; both shrink with the instruction count).
-constexpr uint32_t kLanes = 256;
+// ---- per-workgroup staging and the bit reader ---------------------------------------------------------------------
+// A workgroup owns kWg consecutive sub-sequences of contiguous stream, copied into LDS with coalesced loads.  The copy
+// is COLUMN-MAJOR with pitch 33 (word j of sub-sequence t at t * 33 + j: lanes walking their own sub-sequences at the
+// same depth hit 32 different banks); bit positions are relative to the workgroup's first bit.
 constexpr uint32_t kMarginSubs = 3;                  // > the longest possible block (64 symbols x 31 bits) + lookahead
-constexpr uint32_t kCols = kLanes + kMarginSubs;     // staged sub-sequences
-constexpr uint32_t kRowPitch = kCols + 2u;           // dwords per row (odd: rows start in different banks)
-constexpr uint32_t kStageDwords = (kSubWords + 1u) * kRowPitch;
-static_assert(kCols + 1u <= kRowPitch, "row pitch");
-
-struct BitSrc {
-    const uint32_t* lds;         // staged words, word-major
-    uint32_t bit0;               // absolute bit position of column 0, row 0
-    // 32 bits of the stream starting at bit position p.  Every read of a lane stays inside the staged span: a lane
-    // starts inside its workgroup's 256 sub-sequences and runs at most one block (< 2 048 bits) plus 32 bits of
-    // lookahead past them; the clamp only matters for garbage.
-    __device__ __forceinline__ uint32_t peek32(uint32_t p) const {
-        const uint32_t rel = p - bit0;
-        const uint32_t col = min(rel / kSubBits, kCols - 1u), row = (rel >> 5) & (kSubWords - 1u);
-        const uint32_t* q = lds + row * kRowPitch + col;
-        const uint64_t v = (static_cast<uint64_t>(q[0]) << 32) | q[kRowPitch];
-        return static_cast<uint32_t>((v << (rel & 31u)) >> 32);
-    }
-};
-
-__device__ __forceinline__ void stage_stream(const EntropyArgs& a, uint32_t* lds_words, uint32_t first_sub) {
-    const uint32_t word0 = first_sub * kSubWords;
-    const uint32_t total = (a.n_sub + 2u) * kSubWords;                 // the buffer carries 64 slack words
-    for (uint32_t r = threadIdx.x; r < kCols * kSubWords; r += kLanes) {      // coalesced global reads, transposed LDS writes
-        const uint32_t w = word0 + r;
-        const uint32_t v = w < total ? a.words[w] : 0u;
-        const uint32_t col = r / kSubWords, row = r % kSubWords;
-        lds_words[row * kRowPitch + col] = v;
-        if (row == 0u && col > 0u) lds_words[kSubWords * kRowPitch + col - 1u] = v;      // row 32 = row 0 of the next column
-    }
-    if (threadIdx.x == 0u) {                                                             // word 0 behind the last staged column
-        const uint32_t w = word0 + kCols * kSubWords;
-        lds_words[kSubWords * kRowPitch + kCols - 1u] = w < total ? a.words[w] : 0u;
-    }
-}
-
-// Bit reader over the staged stream: just the position.
-struct BitReader {
-    const BitSrc& src;
-    uint32_t p;             // absolute bit position of the next unread bit
-    __device__ __forceinline__ BitReader(const BitSrc& s, uint32_t pos) : src(s), p(pos) {}
-    __device__ __forceinline__ uint32_t peek() const { return src.peek32(p); }
-    __device__ __forceinline__ void skip(uint32_t n) { p += n; }
-};
-
-// One symbol of the scan: updates (c, z) and the reader; reports what it was.  kind: 0 = DC (value = difference,
-// at = component), 1 = AC coefficient at zigzag index `at`, 2 = run / end of block (nothing to store).  DC and AC, run
-// and coefficient share one select-based path (a DC symbol is a category with run 0), so lanes at different places of
-// their blocks do not diverge; only codes longer than the 9-bit lookup and block ends branch.
-// Decoder state of a lane besides the bit position: block-in-MCU c, zigzag index z, and -- updated only when a block
-// ends, not per symbol -- the component of block c and its DC table (the AC table follows it).
-template <typename Tab>
-struct SymState {
-    uint32_t c, z, comp;
-    const Tab* tdc;
-    __device__ __forceinline__ void set_block(const EntropyGeom& g, const Tab* tabs, uint32_t cc) {
-        c = cc;
-        comp = (g.kcomp_packed >> (2u * cc)) & 3u;
-        tdc = tabs + comp * 2u;
-    }
-};
-
-template <typename Tab>
-__device__ __forceinline__ void decode_symbol(const EntropyGeom& g, BitReader& br, const Tab* tabs, SymState<Tab>& S,
-                                              uint32_t& kind, uint32_t& at, int32_t& value, uint32_t& err) {
-    const bool ac = S.z != 0u;
-    const Tab* t = S.tdc + (ac ? 1u : 0u);
-    const uint32_t bits = br.peek();
-    uint32_t e = t->lut[bits >> (32u - kLutBits)];
-    if (e == 0u) {                                                   // code longer than the lookup (2 % of the symbols), or garbage
-        // jdhuff.c's "l = min{l : code_l <= maxcode[l]}" without the dependent chain: all candidate lengths are compared
-        // at once (maxcode[] arrives in wide reads), so the slow path costs three LDS round trips instead of up to nine
-        // -- with 64 lanes per wave, three iterations in ten have at least one lane here.
-        uint32_t l = kLutBits + 1u;
-#pragma unroll
-        for (uint32_t k = kLutBits + 1u; k <= 16u; ++k)
-            l += static_cast<int32_t>(bits >> (32u - k)) > t->maxcode[k] ? 1u : 0u;      // monotone in k, see derive_table
-        if (l > 16u) { err |= 1u; e = 16u << 8; }
-        else {
-            const int32_t code = static_cast<int32_t>(bits >> (32u - l));
-            e = (l << 8) | t->val[(code + t->valoff[l]) & 255];
-        }
-    }
-    const uint32_t len = e >> 8, sym = e & 255u;
-    const uint32_t r = ac ? sym >> 4 : 0u, sz = sym & 15u;
-    const bool run = ac && sz == 0u;                                 // ZRL / EOB
-    const uint32_t v = ((bits << len) >> 1) >> (31u - sz);           // sz bits behind the code (sz = 0 -> top bit, unused)
-    const int32_t half = static_cast<int32_t>((1u << sz) >> 1);
-    const int32_t ext = static_cast<int32_t>(v) < half ? static_cast<int32_t>(v) - static_cast<int32_t>((1u << sz) - 1u) : static_cast<int32_t>(v);
-    value = sz ? ext : 0;                                            // jdhuff.c HUFF_EXTEND
-    br.skip(len + sz);                                               // (a run symbol has sz == 0)
-    const uint32_t pos = S.z + r;
-    const bool bad = !run && pos > 63u;
-    err |= (bad ? 4u : 0u) | ((!ac && sym > 11u) ? 2u : 0u);
-    kind = (run || bad) ? 2u : (ac ? 1u : 0u);
-    at = ac ? pos : S.comp;
-    S.z = run ? (r == 15u ? S.z + 16u : 64u) : pos + 1u;
-    if (S.z >= 64u) {                                                // block complete: next block of the MCU
-        S.z = 0u;
-        S.set_block(g, tabs, S.c + 1u == g.blocks_per_mcu ? 0u : S.c + 1u);
-    }
-}
-
-template <typename F>
-__device__ __forceinline__ void with_tables(const EntropyArgs& a, const DerivedTab* lds_tabs, uint32_t lds_image, uint32_t image, F&& f) {
-    if (image == lds_image || a.uniform_tables) f(reinterpret_cast<const __attribute__((address_space(3))) DerivedTab*>(
-                                  static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_tabs))));
-    else f(a.tabs + static_cast<size_t>(image) * 6u);
-}
-
-// ---- synchronisation and count passes: the lean walker ----------------------------------------------------------
-// These passes need the decoder STATE only (bit position, block-in-MCU, zigzag index), not the coefficients.  A re-decode
-// iteration of the fixpoint is a handful of lanes walking 1 024 bits each, so its time is the DEPENDENT CHAIN of one
-// symbol times the symbols of a sub-sequence; a dense pass is bound by instruction issue.  Both shrink with:
-//   * a 64-bit window of the stream in registers (left-aligned, `cnt` valid bits), topped up from a word that was
-//     requested one top-up earlier -- the only LDS read on a symbol's chain is the table entry;
-//   * one 32-bit FastTab entry per symbol: bits to skip and zigzag advance are byte fields;
-//   * component / table registers touched only when a block ends.
-// The staged stream is COLUMN-MAJOR with pitch 33 (word j of sub-sequence t at t * 33 + j: lanes walking their own
-// sub-sequences at the same depth hit 32 different banks); positions are relative to the workgroup's first bit.
-#ifndef IFHIP_ENT_SYNC_LANES
-#define IFHIP_ENT_SYNC_LANES 1024
-#endif
-constexpr uint32_t kSyncLanes = IFHIP_ENT_SYNC_LANES;               // sub-sequences per workgroup in these passes
-constexpr uint32_t kSyncCols = kSyncLanes + 1u;                     // a walk stops within 31 bits of its end and looks 3 words ahead
 constexpr uint32_t kColPitch = kSubWords + 1u;
-constexpr uint32_t kFastStageDwords = kSyncCols * kColPitch;
 
 template <uint32_t kWg, uint32_t kColsT>
 __device__ __forceinline__ void stage_stream_columns(const EntropyArgs& a, uint32_t* lds_words, uint32_t first_sub) {
@@ -275,66 +151,87 @@ __device__ __forceinline__ void stage_stream_columns(const EntropyArgs& a, uint3
 }
 __device__ __forceinline__ uint32_t stream_word(const uint32_t* lds_words, uint32_t i) { return lds_words[i + i / kSubWords]; }
 
-// jdhuff.c's slow path "l = min{l : code_l <= maxcode[l]}" without its dependent chain: all candidate lengths are compared at
-// once (the host stores a monotone maxcode, see derive_table), three LDS round trips instead of up to nine.
-template <typename Tab>
-__device__ __forceinline__ uint32_t long_code_entry(const Tab* t, uint32_t bits, bool ac, uint32_t* err = nullptr) {
+// The stream behind a bit position, in registers: the two words the 32-bit window straddles, the word after them
+// (requested one refill early, so the only LDS read on a symbol's dependent chain is the table entry) and the number
+// of unread bits left in the first word.  The window is one v_alignbit_b32; moving on is branch-free -- with 64 lanes
+// some lane refills in every iteration anyway, and a branch costs more than the four selects.
+struct Reader {
+    uint32_t w0, w1, next;
+    uint32_t left;                                   // unread bits of w0: 0..31 (0: the window is w1)
+    uint32_t at;                                     // word index of `next`
+    __device__ __forceinline__ void open(const uint32_t* lds_words, uint32_t p) {
+        const uint32_t i1 = (p + 31u) >> 5;
+        w0 = stream_word(lds_words, i1 ? i1 - 1u : 0u);
+        w1 = stream_word(lds_words, i1);
+        at = i1 + 1u;
+        next = stream_word(lds_words, at);
+        left = (0u - p) & 31u;
+    }
+    __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(w0, w1, left); }
+    __device__ __forceinline__ void skip(const uint32_t* lds_words, uint32_t n) {       // n <= 31
+        const int32_t rest = static_cast<int32_t>(left) - static_cast<int32_t>(n);
+        const bool over = rest < 0;
+        w0 = over ? w1 : w0;
+        w1 = over ? next : w1;
+        at += over ? 1u : 0u;
+        left = static_cast<uint32_t>(rest) & 31u;
+        next = stream_word(lds_words, at);
+    }
+};
+
+// Entry of a symbol whose code is longer than the first-level lookup (e = that lookup's entry, skip field 0).
+template <typename Tabs>
+__device__ __forceinline__ uint32_t long_entry(const Tabs* T, const SearchTab* S, uint32_t slot, uint32_t e, uint32_t bits) {
+    if (e != 0u) return T->pool[(e >> 16) + ((bits << kLutBits) >> ((e >> 8) & 255u))];
+    // jdhuff.c's slow path "l = min{l : code_l <= maxcode[l]}" without its dependent chain: all candidate lengths are
+    // compared at once (the host stores a monotone maxcode, see derive_search_table)
+    const SearchTab* t = S + slot;
+    const bool ac = (slot & 1u) != 0u;
     uint32_t l = kLutBits + 1u;
 #pragma unroll
     for (uint32_t k = kLutBits + 1u; k <= 16u; ++k)
         l += static_cast<int32_t>(bits >> (32u - k)) > t->maxcode[k] ? 1u : 0u;
-    if (l > 16u) {                                                   // no such code: length 16, symbol 0, reported by the write pass
-        if (err) *err |= 1u;
-        return fast_entry(ac, 16u, 0u);
-    }
+    if (l > 16u) return invalid_entry(ac);
     const int32_t code = static_cast<int32_t>(bits >> (32u - l));
     return fast_entry(ac, l, t->val[(code + t->valoff[l]) & 255]);
 }
 
-// Walks the stream from (p, c, z) until p >= end.  kCount: also counts the blocks started and sums the DC differences
-// per component (the count pass; the synchronisation rounds do not need them).
-template <bool kCount, typename Tab>
-__device__ __forceinline__ void walk(const EntropyGeom& g, const uint32_t* lds_words, const Tab* tabs, uint32_t end, uint32_t& p,
-                                     uint32_t& c, uint32_t& z, int32_t& n, int32_t (&dc)[3]) {
+// ---- synchronisation and count passes: the lean walker ----------------------------------------------------------
+// These passes need the decoder STATE only (bit position, block-in-MCU, zigzag index), not the coefficients.  A dense
+// pass is bound by instruction issue, a re-decode iteration of the fixpoint by the dependent chain of one symbol; both
+// shrink with the instruction count.  Per symbol: the window (1 instruction), the table entry (address + LDS read),
+// the reader's refill and the end-of-block bookkeeping as selects -- no divergent branch but the long-code lookup.
+// kCount: also count the blocks started and sum the DC differences per component (into the lane's LDS slots dcs[comp *
+// kDcPitch]: a dynamic index into three registers costs eight selects).
+template <bool kCount, uint32_t kDcPitch, typename Tabs>
+__device__ __forceinline__ void walk(const EntropyGeom& g, const uint32_t* lds_words, const Tabs* T, const SearchTab* S, uint32_t end,
+                                     uint32_t& p, uint32_t& c, uint32_t& z, int32_t& n, int32_t* dcs) {
+    const auto* lut0 = &T->lut[0][0];
     uint32_t comp = (g.kcomp_packed >> (2u * c)) & 3u;
-    const Tab* tac = tabs + comp * 2u + 1u;
-    const Tab* tcur = z ? tac : tac - 1;
-    uint32_t w = p >> 5;
-    uint64_t buf = ((static_cast<uint64_t>(stream_word(lds_words, w)) << 32) | stream_word(lds_words, w + 1u)) << (p & 31u);
-    uint32_t cnt = 64u - (p & 31u);                                  // valid bits in buf, always > 32 at a symbol's start
-    w += 2u;
-    uint32_t next = stream_word(lds_words, w);
+    const auto* tcur = lut0 + comp * (2u * kLutEntries) + (z ? kLutEntries : 0u);
+    Reader rd;
+    rd.open(lds_words, p);
     while (p < end) {
-        const uint32_t bits = static_cast<uint32_t>(buf >> 32);
-        uint32_t e = tcur->lut[bits >> (32u - kLutBits)];
-        if (e == 0u) e = long_code_entry(tcur, bits, tcur == tac);
-        if (kCount && tcur != tac) {                                 // DC symbol: jdhuff.c HUFF_EXTEND of the sz bits behind the code
+        const uint32_t bits = rd.peek();
+        uint32_t e = tcur[bits >> (32u - kLutBits)];
+        if ((e & 255u) == 0u) e = long_entry(T, S, static_cast<uint32_t>(tcur - lut0) / kLutEntries, e, bits);
+        if constexpr (kCount) if (z == 0u) {                                     // DC symbol: jdhuff.c HUFF_EXTEND of the sz bits behind the code
             const uint32_t len = (e >> 16) & 255u, sz = (e >> 24) & 15u;
             const uint32_t v = ((bits << len) >> 1) >> (31u - sz);
-            const int32_t half = static_cast<int32_t>((1u << sz) >> 1);
-            const int32_t ext = static_cast<int32_t>(v) < half ? static_cast<int32_t>(v) - static_cast<int32_t>((1u << sz) - 1u) : static_cast<int32_t>(v);
+            const int32_t ext = static_cast<int32_t>(v) - ((static_cast<int32_t>(bits << len) < 0 || sz == 0u) ? 0 : static_cast<int32_t>((1u << sz) - 1u));
             ++n;
-            dc[comp] += sz ? ext : 0;
+            __hip_atomic_fetch_add(dcs + comp * kDcPitch, ext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // ds_add, nothing returns
         }
         const uint32_t skip = e & 255u;
         p += skip;
-        buf <<= skip;
-        cnt -= skip;
-        if (cnt <= 32u) {                                            // top up from the word requested at the previous top-up
-            buf |= static_cast<uint64_t>(next) << (32u - cnt);
-            cnt += 32u;
-            ++w;
-            next = stream_word(lds_words, w);
-        }
+        rd.skip(lds_words, skip);
         z += (e >> 8) & 255u;
-        tcur = tac;
-        if (z >= 64u) {                                              // block complete: next block of the MCU
-            z = 0u;
-            c = c + 1u == g.blocks_per_mcu ? 0u : c + 1u;
-            comp = (g.kcomp_packed >> (2u * c)) & 3u;
-            tcur = tabs + comp * 2u;
-            tac = tcur + 1;
-        }
+        const bool done = z >= 64u;                                  // block complete: next block of the MCU
+        z = done ? 0u : z;
+        const uint32_t c1 = c + 1u == g.blocks_per_mcu ? 0u : c + 1u;
+        c = done ? c1 : c;
+        comp = (g.kcomp_packed >> (2u * c)) & 3u;
+        tcur = lut0 + comp * (2u * kLutEntries) + (done ? 0u : kLutEntries);
     }
 }
 
@@ -347,22 +244,23 @@ __device__ __forceinline__ void walk(const EntropyGeom& g, const uint32_t* lds_w
 // iteration, are nothing but such lone walks.  p, c, z and end are wave-uniform.
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
 
-template <typename Tab>
-__device__ __forceinline__ void walk_wave(const EntropyGeom& g, const uint32_t* lds_words, const Tab* tabs, uint32_t end_, uint32_t& p_,
-                                          uint32_t& c_, uint32_t& z_) {
+template <typename Tabs>
+__device__ __forceinline__ void walk_wave(const EntropyGeom& g, const uint32_t* lds_words, const Tabs* T, const SearchTab* S, uint32_t end_,
+                                          uint32_t& p_, uint32_t& c_, uint32_t& z_) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t p = uniform(p_), c = uniform(c_), z = uniform(z_);     // scalar registers: the chain below is scalar code
     const uint32_t end = uniform(end_), bpm = uniform(g.blocks_per_mcu), kc = uniform(g.kcomp_packed);
     while (p < end) {
-        const Tab* tac = tabs + ((kc >> (2u * c)) & 3u) * 2u + 1u;
+        const uint32_t slot_ac = ((kc >> (2u * c)) & 3u) * 2u + 1u;
         const uint32_t q = p + lane, w = q >> 5;
-        const uint64_t v = (static_cast<uint64_t>(stream_word(lds_words, w)) << 32) | stream_word(lds_words, w + 1u);
-        const uint32_t bits = static_cast<uint32_t>((v << (q & 31u)) >> 32);
-        const Tab* t = (lane == 0u && z == 0u) ? tac - 1 : tac;     // only the symbol at the current position can be a DC symbol
-        uint32_t e = t->lut[bits >> (32u - kLutBits)];
+        const uint32_t bits = __builtin_amdgcn_alignbit(stream_word(lds_words, w), stream_word(lds_words, w + 1u), (0u - q) & 31u);
+        // (alignbit by 0 returns its second word: q & 31 == 0 needs the first)
+        const uint32_t win = (q & 31u) ? bits : stream_word(lds_words, w);
+        const uint32_t slot = (lane == 0u && z == 0u) ? slot_ac - 1u : slot_ac;       // only the symbol at the current position can be a DC symbol
+        uint32_t e = T->lut[slot][win >> (32u - kLutBits)];
         // The chain, in scalar registers: entry of the symbol at `pos`, advance pos and z, until the block ends (z >= 64),
-        // the window is used up (pos >= lim) or an entry is 0 (a code longer than the lookup ON the chain, 2 % of the
-        // symbols: the long codes of the window are resolved then, once, and the chain goes on).  Hand-written because
+        // the window is used up (pos >= lim) or an entry has no skip (a code longer than the lookup ON the chain, 2 % of
+        // the symbols: the long codes of the window are resolved then, once, and the chain goes on).  Hand-written because
         // the loop is the critical path of the late iterations: ten instructions and one taken branch per symbol.
         const uint32_t lim = min(64u, end - p);
         uint32_t pos = 0u, es, tmp;
@@ -384,7 +282,7 @@ __device__ __forceinline__ void walk_wave(const EntropyGeom& g, const uint32_t* 
                 : [e] "v"(e), [lim] "s"(lim)
                 : "scc");
             if ((es & 255u) != 0u) break;
-            e = e == 0u ? long_code_entry(t, bits, t == tac) : e;
+            if ((e & 255u) == 0u) e = long_entry(T, S, slot, e, win);
         }
         if (z >= 64u) {                                              // block complete: the lanes behind looked up the old tables
             z = 0u;
@@ -396,17 +294,26 @@ __device__ __forceinline__ void walk_wave(const EntropyGeom& g, const uint32_t* 
 }
 
 template <typename F>
-__device__ __forceinline__ void with_fast_tables(const EntropyArgs& a, const FastTab* lds_tabs, uint32_t lds_image, uint32_t image, F&& f) {
-    if (image == lds_image || a.uniform_tables) f(reinterpret_cast<const __attribute__((address_space(3))) FastTab*>(
-                                  static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_tabs))));
-    else f(a.ftabs + static_cast<size_t>(image) * 6u);
+__device__ __forceinline__ void with_fast_tables(const EntropyArgs& a, const FastTabs* lds_tabs, uint32_t lds_image, uint32_t image, F&& f) {
+    const SearchTab* S = a.stabs + static_cast<size_t>(image) * 6u;
+    if (image == lds_image || a.uniform_tables) f(reinterpret_cast<const __attribute__((address_space(3))) FastTabs*>(
+                                  static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_tabs))), S);
+    else f(a.ftabs + image, S);
 }
 template <uint32_t kWg>
-__device__ __forceinline__ void stage_fast_tables(const EntropyArgs& a, FastTab* lds_tabs, uint32_t image) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.ftabs + static_cast<size_t>(image) * 6u);
+__device__ __forceinline__ void stage_fast_tables(const EntropyArgs& a, FastTabs* lds_tabs, uint32_t image) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.ftabs + image);
     uint32_t* dst = reinterpret_cast<uint32_t*>(lds_tabs);
-    for (uint32_t i = threadIdx.x; i < sizeof(FastTab) * 6u / 4u; i += kWg) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < sizeof(FastTabs) / 4u; i += kWg) dst[i] = src[i];
 }
+
+
+#ifndef IFHIP_ENT_SYNC_LANES
+#define IFHIP_ENT_SYNC_LANES 1024
+#endif
+constexpr uint32_t kSyncLanes = IFHIP_ENT_SYNC_LANES;               // sub-sequences per workgroup in these passes
+constexpr uint32_t kSyncCols = kSyncLanes + 1u;                     // a walk stops within 31 bits of its end and looks 3 words ahead
+constexpr uint32_t kFastStageDwords = kSyncCols * kColPitch;
 
 // One synchronisation launch.  Inside the workgroup the fixpoint iteration runs in LDS: in every iteration the
 // sub-sequences whose entry state (= the predecessor's exit) moved are decoded again, until nothing moves or
@@ -430,7 +337,7 @@ __device__ __forceinline__ uint32_t pack_state(uint32_t p_rel, uint32_t cz) { re
 
 __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const EntropyArgs a) {
     __shared__ uint32_t lds_words[kFastStageDwords];
-    __shared__ FastTab lds_tabs[6];
+    __shared__ FastTabs lds_tabs;
     __shared__ uint32_t ex[kSyncLanes], used[kSyncLanes];            // exit state; entry state of the last decode
     __shared__ uint16_t endinfo[kSyncLanes], work[kSyncLanes];       // end - t * 1024; sub-sequences to decode this iteration
     __shared__ uint32_t wave_cnt[kSyncLanes / 64u];
@@ -462,7 +369,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
     }
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
     stage_stream_columns<kSyncLanes, kSyncCols>(a, lds_words, first_sub);
-    stage_fast_tables<kSyncLanes>(a, lds_tabs, wg_image);
+    stage_fast_tables<kSyncLanes>(a, &lds_tabs, wg_image);
     ex[t] = st_ex; used[t] = st_used;
     endinfo[t] = static_cast<uint16_t>(on ? min((s + 1u) * kSubBits, sg.bit_end) - s * kSubBits : 0u);
     __syncthreads();
@@ -498,7 +405,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
                 uint32_t p = e0 & 0x1fffffu, c = (e0 >> 21) & 15u, z = e0 >> 25;
                 const uint32_t end = j * kSubBits + endinfo[j];
                 const uint32_t image = a.uniform_tables ? wg_image : a.segs[a.sub_seg[first_sub + j]].image;
-                with_fast_tables(a, lds_tabs, wg_image, image, [&](auto tabs) { walk_wave(a.g, lds_words, tabs, end, p, c, z); });
+                with_fast_tables(a, &lds_tabs, wg_image, image, [&](auto tabs, const SearchTab* S) { walk_wave(a.g, lds_words, tabs, S, end, p, c, z); });
                 if (lane == 0u) ex[j] = p | (c << 21) | (z << 25);
             }
         } else if (t < total) {
@@ -506,9 +413,9 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
             const uint32_t e0 = used[j];
             uint32_t p = e0 & 0x1fffffu, c = (e0 >> 21) & 15u, z = e0 >> 25;
             const uint32_t end = j * kSubBits + endinfo[j];
-            int32_t n = 0, dc[3] = {0, 0, 0};
+            int32_t n = 0;
             const uint32_t image = a.uniform_tables ? wg_image : a.segs[a.sub_seg[first_sub + j]].image;
-            with_fast_tables(a, lds_tabs, wg_image, image, [&](auto tabs) { walk<false>(a.g, lds_words, tabs, end, p, c, z, n, dc); });
+            with_fast_tables(a, &lds_tabs, wg_image, image, [&](auto tabs, const SearchTab* S) { walk<false, 0u>(a.g, lds_words, tabs, S, end, p, c, z, n, nullptr); });
             ex[j] = p | (c << 21) | (z << 25);
         }
         __syncthreads();
@@ -533,12 +440,15 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
 // predictors.  (The synchronisation rounds used to carry these sums through every re-decode.)
 __global__ void __launch_bounds__(kSyncLanes) entropy_count_kernel(const EntropyArgs a) {
     __shared__ uint32_t lds_words[kFastStageDwords];
-    __shared__ FastTab lds_tabs[6];
+    __shared__ FastTabs lds_tabs;
+    __shared__ int32_t lds_dc[3u * kSyncLanes];
     const uint32_t first_sub = blockIdx.x * kSyncLanes;
     const uint32_t s = first_sub + threadIdx.x;
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
     stage_stream_columns<kSyncLanes, kSyncCols>(a, lds_words, first_sub);
-    stage_fast_tables<kSyncLanes>(a, lds_tabs, wg_image);
+    stage_fast_tables<kSyncLanes>(a, &lds_tabs, wg_image);
+    int32_t* dcs = lds_dc + threadIdx.x;                     // this lane's three sums, kSyncLanes apart (one bank per lane)
+    dcs[0] = 0; dcs[kSyncLanes] = 0; dcs[2u * kSyncLanes] = 0;
     __syncthreads();
     if (s >= a.n_sub) return;
     const Segment sg = a.segs[a.sub_seg[s]];
@@ -547,9 +457,9 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_count_kernel(const Entropy
     uint32_t p = s * kSubBits - bit0, c = 0, z = 0;
     if (s != sg.first_sub) { p = a.exit_p[fin][s - 1u] - bit0; const uint32_t cz = a.exit_cz[fin][s - 1u]; c = cz >> 8; z = cz & 255u; }
     const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end) - bit0;
-    int32_t n = 0, dc[3] = {0, 0, 0};
-    with_fast_tables(a, lds_tabs, wg_image, sg.image, [&](auto tabs) { walk<true>(a.g, lds_words, tabs, end, p, c, z, n, dc); });
-    a.cnt[s] = make_int4(n, dc[0], dc[1], dc[2]);
+    int32_t n = 0;
+    with_fast_tables(a, &lds_tabs, wg_image, sg.image, [&](auto tabs, const SearchTab* S) { walk<true, kSyncLanes>(a.g, lds_words, tabs, S, end, p, c, z, n, dcs); });
+    a.cnt[s] = make_int4(n, dcs[0], dcs[kSyncLanes], dcs[2u * kSyncLanes]);
 }
 
 // exclusive scan of cnt over the sub-sequences of one segment: one workgroup of 1024 lanes per segment, every lane sums
@@ -596,7 +506,7 @@ struct BlockPlace { uint32_t hv, bw, bh, comp; };    // block k of an MCU: hs | 
 
 __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const EntropyArgs a) {
     __shared__ uint32_t lds_words[kWriteCols * kColPitch];
-    __shared__ FastTab lds_tabs[6];
+    __shared__ FastTabs lds_tabs;
     __shared__ __attribute__((aligned(8))) uint32_t lds_blk[kWriteLanes * kBlkPitch];
     __shared__ BlockPlace lds_place[kMaxBlocksInMcu];
     __shared__ int16_t* lds_plane[3];
@@ -612,7 +522,7 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
     const uint32_t s = first_sub + threadIdx.x;
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
     stage_stream_columns<kWriteLanes, kWriteCols>(a, lds_words, first_sub);
-    stage_fast_tables<kWriteLanes>(a, lds_tabs, wg_image);
+    stage_fast_tables<kWriteLanes>(a, &lds_tabs, wg_image);
     __syncthreads();
     if (s >= a.n_sub) return;
     const Segment sg = a.segs[a.sub_seg[s]];
@@ -630,36 +540,31 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
     { const uint32_t m = sg.first_mcu + block / B; my = m / a.g.mcus_w; mx = m - my * a.g.mcus_w; }
     int16_t* row = reinterpret_cast<int16_t*>(lds_blk + threadIdx.x * kBlkPitch);
     uint2* row2 = reinterpret_cast<uint2*>(lds_blk + threadIdx.x * kBlkPitch);
-    with_fast_tables(a, lds_tabs, wg_image, sg.image, [&](auto tabs) {
-        using TabP = decltype(tabs);
+    with_fast_tables(a, &lds_tabs, wg_image, sg.image, [&](auto T, const SearchTab* S) {
+        const auto* lut0 = &T->lut[0][0];
         uint32_t comp = (a.g.kcomp_packed >> (2u * c)) & 3u;
-        TabP tac = tabs + comp * 2u + 1u;
-        TabP tcur = z ? tac : tac - 1;
-        uint32_t w = p >> 5;
-        uint64_t buf = ((static_cast<uint64_t>(stream_word(lds_words, w)) << 32) | stream_word(lds_words, w + 1u)) << (p & 31u);
-        uint32_t cnt = 64u - (p & 31u);
-        w += 2u;
-        uint32_t next = stream_word(lds_words, w);
+        const auto* tcur = lut0 + comp * (2u * kLutEntries) + (z ? kLutEntries : 0u);
+        Reader rd;
+        rd.open(lds_words, p);
         // one symbol: entry and the 32 bits it was decoded from; the reader moves on, z / tables are the caller's
         auto symbol = [&](uint32_t& bits) {
-            bits = static_cast<uint32_t>(buf >> 32);
-            uint32_t e = tcur->lut[bits >> (32u - kLutBits)];
-            if (e == 0u) e = long_code_entry(tcur, bits, tcur == tac, &err);
+            bits = rd.peek();
+            uint32_t e = tcur[bits >> (32u - kLutBits)];
+            if ((e & 255u) == 0u) e = long_entry(T, S, static_cast<uint32_t>(tcur - lut0) / kLutEntries, e, bits);
             const uint32_t skip = e & 255u;
-            p += skip; buf <<= skip; cnt -= skip;
-            if (cnt <= 32u) { buf |= static_cast<uint64_t>(next) << (32u - cnt); cnt += 32u; ++w; next = stream_word(lds_words, w); }
+            p += skip;
+            rd.skip(lds_words, skip);
             return e;
         };
         auto advance = [&](uint32_t e) {                     // -> true when the block is complete
             z += (e >> 8) & 255u;
-            tcur = tac;
-            if (z < 64u) return false;
-            z = 0u;
-            c = c + 1u == B ? 0u : c + 1u;
+            const bool done = z >= 64u;
+            z = done ? 0u : z;
+            const uint32_t c1 = c + 1u == B ? 0u : c + 1u;
+            c = done ? c1 : c;
             comp = (a.g.kcomp_packed >> (2u * c)) & 3u;
-            tcur = tabs + comp * 2u;
-            tac = tcur + 1;
-            return true;
+            tcur = lut0 + comp * (2u * kLutEntries) + (done ? 0u : kLutEntries);
+            return done;
         };
         uint32_t bits;
         while (z != 0u) advance(symbol(bits));               // tail of the predecessor's block
@@ -669,12 +574,13 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
             const uint32_t k = c;
             bool done;
             do {
-                const bool is_dc = tcur != tac;
+                const bool is_dc = z == 0u;
                 const uint32_t e = symbol(bits);
                 const uint32_t len = (e >> 16) & 255u, sym = e >> 24, sz = sym & 15u;
                 const uint32_t v = ((bits << len) >> 1) >> (31u - sz);           // sz bits behind the code (sz = 0 -> 0)
                 const int32_t neg = static_cast<int32_t>((1u << sz) - 1u);
                 const int32_t value = static_cast<int32_t>(v) - ((static_cast<int32_t>(bits << len) < 0 || sz == 0u) ? 0 : neg);   // jdhuff.c HUFF_EXTEND
+                if (len > 16u) err |= 1u;                    // no such code
                 if (is_dc) {
                     if (sym > 11u) err |= 2u;
                     dc[comp] += value;
@@ -839,20 +745,15 @@ int parse_jpeg(const uint8_t* d, size_t len, ParsedJpeg* out) {
     return IFHIP_OK;
 }
 
-void derive_table(const HuffSpec& h, DerivedTab* t) {
+void derive_search_table(const HuffSpec& h, SearchTab* t) {
     std::memset(t, 0, sizeof *t);
     std::memcpy(t->val, h.vals, 256);
     int32_t code = 0;
     int k = 0;
     for (int l = 1; l <= 16; ++l) {
         t->valoff[l] = k - code;
-        for (int i = 0; i < h.bits[l]; ++i, ++k, ++code) {
-            if (l <= static_cast<int>(kLutBits)) {
-                const uint32_t first = static_cast<uint32_t>(code) << (kLutBits - l);
-                for (uint32_t f = 0; f < (1u << (kLutBits - l)); ++f)
-                    if (first + f < (1u << kLutBits)) t->lut[first + f] = static_cast<uint16_t>((l << 8) | h.vals[k]);
-            }
-        }
+        k += h.bits[l];
+        code += h.bits[l];
         // Largest code of this length.  A length without codes gets the previous bound extended by a 1 bit instead of
         // jdhuff's -1: the serial search "first l with code_l <= maxcode[l]" is unchanged (it only ever reaches l when
         // code_(l-1) > maxcode[l-1], and then code_l > (maxcode[l-1] << 1 | 1) as well), and "code_l > maxcode[l]" becomes
@@ -862,11 +763,61 @@ void derive_table(const HuffSpec& h, DerivedTab* t) {
     }
     t->maxcode[17] = 0x7fffffff;
 }
-void derive_fast_table(const DerivedTab& d, bool ac, FastTab* f) {
-    std::memcpy(f->maxcode, d.maxcode, sizeof f->maxcode);
-    std::memcpy(f->valoff, d.valoff, sizeof f->valoff);
-    std::memcpy(f->val, d.val, sizeof f->val);
-    for (uint32_t i = 0; i < (1u << kLutBits); ++i) f->lut[i] = d.lut[i] ? fast_entry(ac, d.lut[i] >> 8, d.lut[i] & 255u) : 0u;
+// First level of one table into F->lut[slot], its second level appended to the image's pool (*pool_used entries taken).
+void derive_fast_table(const HuffSpec& h, bool ac, FastTabs* F, uint32_t slot, uint32_t* pool_used) {
+    uint32_t* lut = F->lut[slot];
+    for (uint32_t i = 0; i < kLutEntries; ++i) lut[i] = invalid_entry(ac);
+    struct LongCode { uint32_t code; uint8_t len, sym; };
+    std::vector<LongCode> longs;
+    uint8_t maxlen[kLutEntries] = {};
+    uint32_t code = 0;
+    int k = 0;
+    for (uint32_t l = 1; l <= 16u; ++l) {
+        for (int i = 0; i < h.bits[l]; ++i, ++k, ++code) {
+            if (l <= kLutBits) {
+                const uint32_t first = code << (kLutBits - l);
+                for (uint32_t f = 0; f < (1u << (kLutBits - l)); ++f)
+                    if (first + f < kLutEntries) lut[first + f] = fast_entry(ac, l, h.vals[k & 255]);
+            } else {
+                const uint32_t prefix = code >> (l - kLutBits);
+                if (prefix >= kLutEntries) continue;                 // over-subscribed table: the pattern cannot occur
+                maxlen[prefix] = static_cast<uint8_t>(l);            // lengths ascend
+                longs.push_back(LongCode{code, static_cast<uint8_t>(l), h.vals[k & 255]});
+            }
+        }
+        code <<= 1;
+    }
+    for (uint32_t prefix = 0; prefix < kLutEntries; ++prefix) {
+        if (!maxlen[prefix]) continue;
+        const uint32_t n = maxlen[prefix] - kLutBits, size = 1u << n;
+        if (*pool_used + size > kPoolEntries) { lut[prefix] = 0u; continue; }        // left to the serial search
+        for (uint32_t i = 0; i < size; ++i) F->pool[*pool_used + i] = invalid_entry(ac);
+        lut[prefix] = (*pool_used << 16) | ((32u - n) << 8);
+        *pool_used += size;
+    }
+    for (const LongCode& lc : longs) {
+        const uint32_t prefix = lc.code >> (lc.len - kLutBits);
+        if (lut[prefix] == 0u) continue;
+        const uint32_t n = maxlen[prefix] - kLutBits, rem = lc.len - kLutBits, off = lut[prefix] >> 16;
+        const uint32_t sub = (lc.code & ((1u << rem) - 1u)) << (n - rem);
+        for (uint32_t f = 0; f < (1u << (n - rem)); ++f) F->pool[off + sub + f] = fast_entry(ac, lc.len, lc.sym);
+    }
+}
+// The six tables of one image; components that name the same table share its second level.
+void derive_image_tables(const ParsedJpeg& P, FastTabs* F, SearchTab* S6) {
+    std::memset(F, 0, sizeof *F);
+    std::memset(S6, 0, 6u * sizeof *S6);
+    uint32_t pool_used = 0;
+    for (int c = 0; c < P.ncomp; ++c)
+        for (uint32_t ac = 0; ac < 2u; ++ac) {
+            const uint32_t slot = 2u * static_cast<uint32_t>(c) + ac;
+            const uint8_t id = ac ? P.ta[c] : P.td[c];
+            derive_search_table(ac ? P.ac[id] : P.dc[id], &S6[slot]);
+            int same = -1;
+            for (int o = 0; o < c; ++o) if ((ac ? P.ta[o] : P.td[o]) == id) same = o;
+            if (same >= 0) std::memcpy(F->lut[slot], F->lut[2u * static_cast<uint32_t>(same) + ac], sizeof F->lut[slot]);
+            else derive_fast_table(ac ? P.ac[id] : P.dc[id], ac != 0u, F, slot, &pool_used);
+        }
 }
 
 }  // namespace
@@ -969,7 +920,8 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     e->n_images = n_images;
     std::vector<Segment> segs;
     std::vector<uint32_t> sub_seg;
-    std::vector<DerivedTab> tabs(static_cast<size_t>(n_images) * 6u);
+    std::vector<FastTabs> ftabs(n_images);
+    std::vector<SearchTab> stabs(static_cast<size_t>(n_images) * 6u);
     e->qt.assign(static_cast<size_t>(n_images) * 192u, 0);
 
     // Host preparation runs on a few threads, one file at a time each: parsing and un-stuffing are independent per file
@@ -1012,11 +964,8 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
         ParsedJpeg& P = R.P;
         R.rc = parse_jpeg(files[img], lengths[img], &P);
         if (R.rc) { R.message = last_error(); return; }
-        for (int c = 0; c < P.ncomp; ++c) {
-            std::memcpy(&e->qt[(static_cast<size_t>(img) * 3u + c) * 64u], P.qt[P.tq[c]], 128);
-            derive_table(P.dc[P.td[c]], &tabs[static_cast<size_t>(img) * 6u + 2u * c]);
-            derive_table(P.ac[P.ta[c]], &tabs[static_cast<size_t>(img) * 6u + 2u * c + 1u]);
-        }
+        for (int c = 0; c < P.ncomp; ++c) std::memcpy(&e->qt[(static_cast<size_t>(img) * 3u + c) * 64u], P.qt[P.tq[c]], 128);
+        derive_image_tables(P, &ftabs[img], &stabs[static_cast<size_t>(img) * 6u]);
         // un-stuff the scan and cut it at restart markers
         const uint8_t* d = files[img];
         const size_t len = lengths[img];
@@ -1124,20 +1073,19 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     a.n_seg = static_cast<uint32_t>(segs.size());
     a.uniform_tables = 1u;                           // batches of small files put many images into one workgroup: with
     for (uint32_t img = 1; img < n_images && a.uniform_tables; ++img)     // identical tables they all use the LDS copy
-        if (std::memcmp(&tabs[static_cast<size_t>(img) * 6u], &tabs[0], 6u * sizeof(DerivedTab)) != 0) a.uniform_tables = 0u;
+        if (std::memcmp(&ftabs[img], &ftabs[0], sizeof(FastTabs)) != 0 ||
+            std::memcmp(&stabs[static_cast<size_t>(img) * 6u], &stabs[0], 6u * sizeof(SearchTab)) != 0) a.uniform_tables = 0u;
     int rc;
     uint32_t *d_words = nullptr, *d_sub = nullptr;
     Segment* d_segs = nullptr;
-    DerivedTab* d_tabs = nullptr;
-    FastTab* d_ftabs = nullptr;
-    std::vector<FastTab> ftabs(tabs.size());
-    for (size_t i = 0; i < tabs.size(); ++i) derive_fast_table(tabs[i], (i & 1u) != 0u, &ftabs[i]);
+    FastTabs* d_ftabs = nullptr;
+    SearchTab* d_stabs = nullptr;
     if ((rc = dev_alloc(e.get(), &d_words, n_words, words))) return rc;
     if ((rc = dev_alloc(e.get(), &d_segs, segs.size(), segs.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_sub, sub_seg.size(), sub_seg.data()))) return rc;
-    if ((rc = dev_alloc(e.get(), &d_tabs, tabs.size(), tabs.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_ftabs, ftabs.size(), ftabs.data()))) return rc;
-    a.words = d_words; a.segs = d_segs; a.sub_seg = d_sub; a.tabs = d_tabs; a.ftabs = d_ftabs;
+    if ((rc = dev_alloc(e.get(), &d_stabs, stabs.size(), stabs.data()))) return rc;
+    a.words = d_words; a.segs = d_segs; a.sub_seg = d_sub; a.ftabs = d_ftabs; a.stabs = d_stabs;
     for (int b = 0; b < 2; ++b) {
         if ((rc = dev_alloc<uint32_t>(e.get(), &a.exit_p[b], a.n_sub))) return rc;
         if ((rc = dev_alloc<uint32_t>(e.get(), &a.exit_cz[b], a.n_sub))) return rc;
@@ -1211,7 +1159,6 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
     if ((reinterpret_cast<uintptr_t>(d_coef0) | reinterpret_cast<uintptr_t>(d_coef1) | reinterpret_cast<uintptr_t>(d_coef2)) & 15u)
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: coefficient planes must be 16-byte aligned");
     HIP_TRY(hipMemsetAsync(a.changed, 0, 17 * sizeof(uint32_t), st));
-    const dim3 grid((a.n_sub + 255u) / 256u), block(256);
     const dim3 sync_grid((a.n_sub + kSyncLanes - 1u) / kSyncLanes), sync_block(kSyncLanes);
     const uint32_t max_rounds = a.n_sub + 2u;
     // Rounds 0..2 (speculative decode with the fixpoint iteration inside every workgroup; corrections that cross a
