@@ -330,6 +330,15 @@ constexpr uint32_t kInnerRounds = IFHIP_ENT_INNER;
 #define IFHIP_ENT_WAVEWALK 48
 #endif
 constexpr uint32_t kWaveWalkMax = IFHIP_ENT_WAVEWALK;                          // at most this many pending sub-sequences: one wave per walk
+// The first kWarmLanes lanes of a workgroup decode the sub-sequences IN FRONT of its own range in round 0 and discard the
+// result: the workgroup's first own sub-sequence then starts from a state that has had kWarmLanes sub-sequences to
+// synchronise (one fails to with probability ~0.4), so corrections across workgroup boundaries -- a whole extra launch
+// of lone walks -- all but disappear.  Later rounds run without them.
+#ifndef IFHIP_ENT_WARM
+#define IFHIP_ENT_WARM 16
+#endif
+constexpr uint32_t kWarmLanes = IFHIP_ENT_WARM;
+constexpr uint32_t kOwnSubs = kSyncLanes - kWarmLanes;                         // sub-sequences a workgroup owns
 constexpr uint32_t kNever = 0xffffffffu;                                       // no decode yet (no real state packs to this)
 static_assert((kSyncLanes + 2u) * kSubBits < (1u << 21), "packed state: 21 bits of relative position");
 
@@ -341,12 +350,13 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
     __shared__ uint32_t ex[kSyncLanes], used[kSyncLanes];            // exit state; entry state of the last decode
     __shared__ uint16_t endinfo[kSyncLanes], work[kSyncLanes];       // end - t * 1024; sub-sequences to decode this iteration
     __shared__ uint32_t wave_cnt[kSyncLanes / 64u];
-    const uint32_t first_sub = blockIdx.x * kSyncLanes;
+    const uint32_t own_sub = blockIdx.x * kOwnSubs, first_sub = own_sub - kWarmLanes;     // (wraps for workgroup 0: those lanes are off)
     const uint32_t t = threadIdx.x, s = first_sub + t, lane = t & 63u, wave = t >> 6;
-    const bool on = s < a.n_sub;
+    const uint32_t t0 = a.round == 0u ? 0u : kWarmLanes;             // first lane at work
+    const bool on = s < a.n_sub && t >= t0;
     const uint32_t cur = a.round & 1u, prv = cur ^ 1u;
     const uint32_t bit0 = first_sub * kSubBits;
-    const Segment sg = a.segs[a.sub_seg[on ? s : first_sub]];
+    const Segment sg = a.segs[a.sub_seg[on ? s : own_sub]];
     const bool first = on && s == sg.first_sub;
     // state carried over from the previous launch (none in round 0)
     uint32_t st_ex = 0u, st_used = kNever;
@@ -358,16 +368,16 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
     // entry state of lane 0 of the workgroup comes from the previous workgroup's last launch; round 0 starts every
     // sub-sequence speculatively at its own first bit
     uint32_t fixed_entry = pack_state(t * kSubBits, 0u);
-    const bool fixed = first || a.round == 0u || t == 0u;
-    if (on && !first && a.round > 0u && t == 0u) fixed_entry = pack_state(a.exit_p[prv][s - 1u] - bit0, a.exit_cz[prv][s - 1u]);
+    const bool fixed = first || a.round == 0u || t == t0;
+    if (on && !first && a.round > 0u && t == t0) fixed_entry = pack_state(a.exit_p[prv][s - 1u] - bit0, a.exit_cz[prv][s - 1u]);
     if (a.round > 0u) {
-        const uint32_t entry = fixed ? fixed_entry : pack_state(a.exit_p[prv][s - 1u] - bit0, a.exit_cz[prv][s - 1u]);
+        const uint32_t entry = (fixed || !on) ? fixed_entry : pack_state(a.exit_p[prv][s - 1u] - bit0, a.exit_cz[prv][s - 1u]);
         if (!__syncthreads_or(on && entry != st_used ? 1 : 0)) {     // nothing moved in front of this workgroup
             if (on) { a.exit_p[cur][s] = a.exit_p[prv][s]; a.exit_cz[cur][s] = a.exit_cz[prv][s]; }
             return;
         }
     }
-    const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
+    const uint32_t wg_image = a.segs[a.sub_seg[own_sub]].image;
     stage_stream_columns<kSyncLanes, kSyncCols>(a, lds_words, first_sub);
     stage_fast_tables<kSyncLanes>(a, &lds_tabs, wg_image);
     ex[t] = st_ex; used[t] = st_used;
@@ -380,7 +390,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
 #endif
     for (uint32_t it = 0; it < kInnerRounds; ++it) {
         // speculative first decode of round 0: from the sub-sequence's own first bit; afterwards from the predecessor's exit
-        const uint32_t entry = (fixed && !(a.round == 0u && it > 0u && !first && t > 0u)) ? fixed_entry : ex[t - 1u];
+        const uint32_t entry = (fixed && !(a.round == 0u && it > 0u && !first && t > 0u)) ? fixed_entry : ex[t ? t - 1u : 0u];
         const bool need = on && entry != used[t];
         const uint64_t vote = __ballot(need);
         if (lane == 0u) wave_cnt[wave] = static_cast<uint32_t>(__popcll(vote));
@@ -424,7 +434,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
     if (t == 0u && (blockIdx.x % 60u) == 7u)
         for (uint32_t i = 0; i < tr_k; ++i) printf("wg %u round %u it %u total %u us %.2f\n", blockIdx.x, a.round, i, tr_n[i], (double)(tr_t[i] - tr_0) / 100.0);
 #endif
-    if (!on) return;
+    if (!on || t < kWarmLanes) return;
     const uint32_t fin = ex[t], fu = used[t];
     a.exit_p[cur][s] = (fin & 0x1fffffu) + bit0;
     a.exit_cz[cur][s] = (((fin >> 21) & 15u) << 8) | (fin >> 25);
@@ -494,20 +504,30 @@ __global__ void __launch_bounds__(1024) entropy_scan_kernel(const EntropyArgs a)
 }
 
 // Write pass.  A block belongs to the lane in whose sub-sequence it STARTS: that lane decodes it to the end (running
-// past its sub-sequence if need be), assembles the 64 coefficients in a private LDS row (pitch 34 dwords: conflict-free
-// across lanes) and stores the whole block with eight 16-byte stores -- every block is written exactly once, zeros
-// included, so the planes need no clearing and no two lanes ever touch the same block.  A lane that starts inside a
-// block skips to its end without storing.  Same reader and table entries as the walker above; workgroups of 512
-// sub-sequences (stream 66 KiB + rows 68 KiB + tables: one workgroup per CU).
+// past its sub-sequence if need be), assembles the 64 coefficients in a private LDS row (pitch 36 dwords: 16-byte
+// aligned, eight consecutive lanes cover all banks) and stores the whole block with eight 16-byte stores -- every block
+// is written exactly once, zeros included, so the planes need no clearing and no two lanes ever touch the same block.
+// A lane that starts inside a block skips to its end without storing.  Same reader and table entries as the walker;
+// workgroups of 512 sub-sequences (stream 66 KiB + rows 72 KiB + tables: one workgroup per CU).
+// Storing a block is ~40 instructions that every lane of the wave pays for whenever ONE lane needs them, and with 64
+// lanes a block ends somewhere in almost every symbol step; waiting for all lanes to finish their block (the loop
+// structure a compiler makes of "decode a block, store it") leaves most lanes idle, blocks differ that much in length.
+// So a lane that completed its block WAITS until kFlushLanes lanes of its wave wait (or nobody decodes any more) and
+// they store together: the store path runs every third or fourth symbol step and a lane idles ~2 steps per block.
 constexpr uint32_t kWriteLanes = 512;
 constexpr uint32_t kWriteCols = kWriteLanes + kMarginSubs;
-constexpr uint32_t kBlkPitch = 34;                   // dwords per lane row (32 + 2)
+constexpr uint32_t kBlkPitch = 36;                   // dwords per lane row (32 + 4)
+#ifndef IFHIP_ENT_FLUSH
+#define IFHIP_ENT_FLUSH 24
+#endif
+constexpr uint32_t kFlushLanes = IFHIP_ENT_FLUSH;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct BlockPlace { uint32_t hv, bw, bh, comp; };    // block k of an MCU: hs | vs << 8 | dx << 16 | dy << 24, plane dimensions in blocks
 
 __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const EntropyArgs a) {
     __shared__ uint32_t lds_words[kWriteCols * kColPitch];
     __shared__ FastTabs lds_tabs;
-    __shared__ __attribute__((aligned(8))) uint32_t lds_blk[kWriteLanes * kBlkPitch];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_blk[kWriteLanes * kBlkPitch];
     __shared__ BlockPlace lds_place[kMaxBlocksInMcu];
     __shared__ int16_t* lds_plane[3];
     __shared__ uint8_t lds_zz[64];                   // zigzag -> natural order (a divergent index into __constant__ memory is a
@@ -518,6 +538,10 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
                                   a.g.bw[cm], a.g.bh[cm], cm};
     }
     if (threadIdx.x < 3u) lds_plane[threadIdx.x] = a.coef[threadIdx.x];
+    int16_t* row = reinterpret_cast<int16_t*>(lds_blk + threadIdx.x * kBlkPitch);
+    u32x4* row4 = reinterpret_cast<u32x4*>(lds_blk + threadIdx.x * kBlkPitch);
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; ++i) row4[i] = u32x4{0u, 0u, 0u, 0u};               // a row is cleared again when it is stored
     const uint32_t first_sub = blockIdx.x * kWriteLanes;
     const uint32_t s = first_sub + threadIdx.x;
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
@@ -533,13 +557,11 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
     const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end) - bit0;
     uint32_t err = 0;
     const int4 pre = a.prefix[s];
-    int32_t dc[3] = {pre.y, pre.z, pre.w};
+    int32_t dc0 = pre.y, dc1 = pre.z, dc2 = pre.w;
     uint32_t block = static_cast<uint32_t>(pre.x);           // the next block this lane starts
     const uint32_t B = a.g.blocks_per_mcu;
     uint32_t my, mx;                                         // MCU of that block (the block-in-MCU is the decoder's c)
     { const uint32_t m = sg.first_mcu + block / B; my = m / a.g.mcus_w; mx = m - my * a.g.mcus_w; }
-    int16_t* row = reinterpret_cast<int16_t*>(lds_blk + threadIdx.x * kBlkPitch);
-    uint2* row2 = reinterpret_cast<uint2*>(lds_blk + threadIdx.x * kBlkPitch);
     with_fast_tables(a, &lds_tabs, wg_image, sg.image, [&](auto T, const SearchTab* S) {
         const auto* lut0 = &T->lut[0][0];
         uint32_t comp = (a.g.kcomp_packed >> (2u * c)) & 3u;
@@ -568,39 +590,47 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
         };
         uint32_t bits;
         while (z != 0u) advance(symbol(bits));               // tail of the predecessor's block
-        while (p < end && block < sg.n_blocks) {             // (pad bits may follow the last block)
-#pragma unroll
-            for (uint32_t i = 0; i < 16u; ++i) row2[i] = make_uint2(0u, 0u);
-            const uint32_t k = c;
-            bool done;
-            do {
+        bool run = p < end && block < sg.n_blocks;           // a block to decode (pad bits may follow the last block)
+        bool waiting = false;                                // block complete, not stored yet
+        uint32_t k = c;                                      // block-in-MCU of the block being decoded
+        for (;;) {
+            if (run && !waiting) {
                 const bool is_dc = z == 0u;
                 const uint32_t e = symbol(bits);
                 const uint32_t len = (e >> 16) & 255u, sym = e >> 24, sz = sym & 15u;
                 const uint32_t v = ((bits << len) >> 1) >> (31u - sz);           // sz bits behind the code (sz = 0 -> 0)
                 const int32_t neg = static_cast<int32_t>((1u << sz) - 1u);
                 const int32_t value = static_cast<int32_t>(v) - ((static_cast<int32_t>(bits << len) < 0 || sz == 0u) ? 0 : neg);   // jdhuff.c HUFF_EXTEND
-                if (len > 16u) err |= 1u;                    // no such code
-                if (is_dc) {
-                    if (sym > 11u) err |= 2u;
-                    dc[comp] += value;
-                    row[0] = static_cast<int16_t>(dc[comp]);
-                } else if (sz != 0u) {
-                    const uint32_t pos = z + ((e >> 8) & 255u) - 1u;
-                    if (pos > 63u) err |= 4u; else row[lds_zz[pos]] = static_cast<int16_t>(value);
-                }
-                done = advance(e);
-            } while (!done);
-            const BlockPlace pl = lds_place[k];
-            const uint32_t bx = mx * (pl.hv & 255u) + ((pl.hv >> 16) & 255u), by = my * ((pl.hv >> 8) & 255u) + (pl.hv >> 24);
-            uint4* dst = reinterpret_cast<uint4*>(lds_plane[pl.comp] + (static_cast<size_t>(sg.image * pl.bh + by) * pl.bw + bx) * 64u);
-#pragma unroll
-            for (uint32_t i = 0; i < 8u; ++i) {
-                const uint2 lo = row2[2u * i], hi = row2[2u * i + 1u];
-                dst[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                const uint32_t pos = z + ((e >> 8) & 255u) - 1u;                // zigzag index of an AC coefficient (DC: 0)
+                // DC and AC share one path: the three predictors are registers, selected by compares
+                const int32_t diff = is_dc ? value : 0;
+                dc0 += comp == 0u ? diff : 0; dc1 += comp == 1u ? diff : 0; dc2 += comp == 2u ? diff : 0;
+                const int32_t dcv = comp == 0u ? dc0 : (comp == 1u ? dc1 : dc2);
+                err |= (len > 16u ? 1u : 0u) | ((is_dc && sym > 11u) ? 2u : 0u) | ((!is_dc && sz != 0u && pos > 63u) ? 4u : 0u);
+                const uint32_t nat = lds_zz[pos & 63u];
+                if (is_dc || (sz != 0u && pos <= 63u)) row[nat] = static_cast<int16_t>(is_dc ? dcv : value);
+                waiting = advance(e);
             }
-            ++block;
-            if (c == 0u) { ++mx; if (mx == a.g.mcus_w) { mx = 0u; ++my; } }      // the MCU is complete
+            const uint32_t n_wait = static_cast<uint32_t>(__popcll(__ballot(waiting)));
+            const bool decoding = __ballot(run && !waiting) != 0ull;
+            if (n_wait < kFlushLanes && decoding) continue;
+            if (n_wait == 0u) break;                         // nobody decodes, nothing to store
+            if (waiting) {
+                const BlockPlace pl = lds_place[k];
+                const uint32_t bx = mx * (pl.hv & 255u) + ((pl.hv >> 16) & 255u), by = my * ((pl.hv >> 8) & 255u) + (pl.hv >> 24);
+                auto* dst = reinterpret_cast<__attribute__((address_space(1))) u32x4*>(reinterpret_cast<uintptr_t>(       // (global, not flat, stores)
+                    lds_plane[pl.comp] + (static_cast<size_t>(sg.image * pl.bh + by) * pl.bw + bx) * 64u));
+#pragma unroll
+                for (uint32_t i = 0; i < 8u; ++i) {
+                    dst[i] = row4[i];
+                    row4[i] = u32x4{0u, 0u, 0u, 0u};
+                }
+                ++block;
+                if (c == 0u) { ++mx; if (mx == a.g.mcus_w) { mx = 0u; ++my; } }      // the MCU is complete
+                k = c;
+                waiting = false;
+                run = p < end && block < sg.n_blocks;
+            }
         }
     });
     const bool last = s + 1u == sg.first_sub + sg.n_sub;
@@ -1160,6 +1190,7 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: coefficient planes must be 16-byte aligned");
     HIP_TRY(hipMemsetAsync(a.changed, 0, 17 * sizeof(uint32_t), st));
     const dim3 sync_grid((a.n_sub + kSyncLanes - 1u) / kSyncLanes), sync_block(kSyncLanes);
+    const dim3 round_grid((a.n_sub + kOwnSubs - 1u) / kOwnSubs);
     const uint32_t max_rounds = a.n_sub + 2u;
     // Rounds 0..2 (speculative decode with the fixpoint iteration inside every workgroup; corrections that cross a
     // workgroup boundary; the confirmation that nothing moved any more), the scan and the write pass are enqueued
@@ -1169,7 +1200,7 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
     uint32_t r = 0;
     for (; r < 3u; ++r) {
         a.round = r;
-        hipLaunchKernelGGL(entropy_round_kernel, sync_grid, sync_block, 0, st, a);
+        hipLaunchKernelGGL(entropy_round_kernel, round_grid, sync_block, 0, st, a);
         HIP_TRY(hipGetLastError());
     }
     r = 2u;
@@ -1189,7 +1220,7 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
             if (r >= max_rounds) return fail(IFHIP_INVALID_STATE, "InvalidState: entropy decode did not converge");
             HIP_TRY(hipMemsetAsync(a.changed + (r & 15u), 0, sizeof(uint32_t), st));
             a.round = r;
-            hipLaunchKernelGGL(entropy_round_kernel, sync_grid, sync_block, 0, st, a);
+            hipLaunchKernelGGL(entropy_round_kernel, round_grid, sync_block, 0, st, a);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(e->h_flags, a.changed, 17 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
