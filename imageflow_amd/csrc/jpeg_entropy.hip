@@ -55,7 +55,7 @@ constexpr uint32_t kLutBits = IFHIP_ENT_LUTBITS;
 // with ONE lookup by the next kLutBits bits of the stream -- or two for the 2 % of the symbols whose code is longer:
 //   bits 0-7   bits to skip (code length + magnitude bits); 0 = the code is longer than the lookup
 //   bits 8-15  zigzag advance: DC 1; AC coefficient run + 1; ZRL 16; EOB 64 (reaching 64 ends the block)
-//   bits 16-23 code length (17: no such code), bits 24-31 the symbol.
+//   bits 16-23 code length (32: no such code), bits 24-31 the symbol.
 // A first-level entry with skip 0 points into the image's second level (`pool`): bits 16-31 the offset of a sub-table
 // indexed by the n bits that follow the first kLutBits (n = longest code with this prefix - kLutBits), bits 8-15 hold
 // 32 - n.  jdhuff.c's slow path (the serial "first l with code_l <= maxcode[l]" search) survives only for sub-tables
@@ -80,8 +80,8 @@ __host__ __device__ inline uint32_t fast_entry(bool ac, uint32_t len, uint32_t s
     return (sym << 24) | (len << 16) | (adv << 8) | (len + sz);
 }
 // A bit pattern no code starts with (corrupt data, or a speculative decode off the symbol grid): 16 bits are skipped as
-// symbol 0, the length field says 17 and the write pass reports it.
-__host__ __device__ inline uint32_t invalid_entry(bool ac) { return (17u << 16) | ((ac ? 64u : 1u) << 8) | 16u; }
+// symbol 0, the length field says 32 (a bit no real length has) and the write pass reports it.
+__host__ __device__ inline uint32_t invalid_entry(bool ac) { return (32u << 16) | ((ac ? 64u : 1u) << 8) | 16u; }
 
 
 constexpr uint32_t kMaxBlocksInMcu = 10;        // libjpeg's D_MAX_BLOCKS_IN_MCU: files with more are rejected by the parser
@@ -193,7 +193,8 @@ __device__ __forceinline__ uint32_t long_entry(const Tabs* T, const SearchTab* S
         l += static_cast<int32_t>(bits >> (32u - k)) > t->maxcode[k] ? 1u : 0u;
     if (l > 16u) return invalid_entry(ac);
     const int32_t code = static_cast<int32_t>(bits >> (32u - l));
-    return fast_entry(ac, l, t->val[(code + t->valoff[l]) & 255]);
+    const uint32_t sym = t->val[(code + t->valoff[l]) & 255];
+    return (!ac && sym > 11u) ? invalid_entry(ac) : fast_entry(ac, l, sym);
 }
 
 // ---- synchronisation and count passes: the lean walker ----------------------------------------------------------
@@ -350,6 +351,9 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
     __shared__ uint32_t ex[kSyncLanes], used[kSyncLanes];            // exit state; entry state of the last decode
     __shared__ uint16_t endinfo[kSyncLanes], work[kSyncLanes];       // end - t * 1024; sub-sequences to decode this iteration
     __shared__ uint32_t wave_cnt[kSyncLanes / 64u];
+#ifdef IFHIP_ENT_TRACE
+    const unsigned long long tr_enter = wall_clock64();
+#endif
     const uint32_t own_sub = blockIdx.x * kOwnSubs, first_sub = own_sub - kWarmLanes;     // (wraps for workgroup 0: those lanes are off)
     const uint32_t t = threadIdx.x, s = first_sub + t, lane = t & 63u, wave = t >> 6;
     const uint32_t t0 = a.round == 0u ? 0u : kWarmLanes;             // first lane at work
@@ -431,7 +435,9 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
         __syncthreads();
     }
 #ifdef IFHIP_ENT_TRACE
-    if (t == 0u && (blockIdx.x % 60u) == 7u)
+    if (t == 0u && a.round == 0u)
+        printf("WG %u its %u staged_us %.2f done_us %.2f enter_tick %llu\n", blockIdx.x, tr_k, (double)(tr_0 - tr_enter) / 100.0, (double)(wall_clock64() - tr_enter) / 100.0, tr_enter);
+    if (t == 0u && ((blockIdx.x % 60u) == 7u || wall_clock64() - tr_enter > 60000ull))
         for (uint32_t i = 0; i < tr_k; ++i) printf("wg %u round %u it %u total %u us %.2f\n", blockIdx.x, a.round, i, tr_n[i], (double)(tr_t[i] - tr_0) / 100.0);
 #endif
     if (!on || t < kWarmLanes) return;
@@ -518,8 +524,9 @@ constexpr uint32_t kWriteLanes = 512;
 constexpr uint32_t kWriteCols = kWriteLanes + kMarginSubs;
 constexpr uint32_t kBlkPitch = 36;                   // dwords per lane row (32 + 4)
 #ifndef IFHIP_ENT_FLUSH
-#define IFHIP_ENT_FLUSH 24
+#define IFHIP_ENT_FLUSH 16
 #endif
+
 constexpr uint32_t kFlushLanes = IFHIP_ENT_FLUSH;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct BlockPlace { uint32_t hv, bw, bh, comp; };    // block k of an MCU: hs | vs << 8 | dx << 16 | dy << 24, plane dimensions in blocks
@@ -529,15 +536,15 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
     __shared__ FastTabs lds_tabs;
     __shared__ __attribute__((aligned(16))) uint32_t lds_blk[kWriteLanes * kBlkPitch];
     __shared__ BlockPlace lds_place[kMaxBlocksInMcu];
-    __shared__ int16_t* lds_plane[3];
+    __shared__ int16_t* lds_plane[kMaxBlocksInMcu];  // coefficient plane of block k's component
     __shared__ uint8_t lds_zz[64];                   // zigzag -> natural order (a divergent index into __constant__ memory is a
     if (threadIdx.x < 64u) lds_zz[threadIdx.x] = kZigzag[threadIdx.x];      // vector-memory load per coefficient)
     if (threadIdx.x < a.g.blocks_per_mcu) {
         const uint32_t k = threadIdx.x, cm = a.g.kcomp[k];
         lds_place[k] = BlockPlace{a.g.hs[cm] | (a.g.vs[cm] << 8) | (static_cast<uint32_t>(a.g.kdx[k]) << 16) | (static_cast<uint32_t>(a.g.kdy[k]) << 24),
                                   a.g.bw[cm], a.g.bh[cm], cm};
+        lds_plane[k] = a.coef[cm];
     }
-    if (threadIdx.x < 3u) lds_plane[threadIdx.x] = a.coef[threadIdx.x];
     int16_t* row = reinterpret_cast<int16_t*>(lds_blk + threadIdx.x * kBlkPitch);
     u32x4* row4 = reinterpret_cast<u32x4*>(lds_blk + threadIdx.x * kBlkPitch);
 #pragma unroll
@@ -593,38 +600,70 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
         bool run = p < end && block < sg.n_blocks;           // a block to decode (pad bits may follow the last block)
         bool waiting = false;                                // block complete, not stored yet
         uint32_t k = c;                                      // block-in-MCU of the block being decoded
+        // The DC predictors are touched when a block is stored, not per symbol; a coefficient goes into the row one symbol late: its natural-order index is an LDS lookup, and the wave would
+        // sit out that round trip; this way it overlaps the next symbol's table read.
+        bool pend = false;
+        uint32_t pend_nat = 0u;
+        int32_t pend_val = 0;
+#ifdef IFHIP_ENT_TRACE
+        const unsigned long long tw_0 = wall_clock64();
+        uint32_t tw_it = 0u, tw_fl = 0u, tw_sym = 0u;
+#endif
         for (;;) {
+#ifdef IFHIP_ENT_TRACE
+            ++tw_it; tw_sym += (run && !waiting) ? 1u : 0u;
+#endif
             if (run && !waiting) {
                 const bool is_dc = z == 0u;
-                const uint32_t e = symbol(bits);
-                const uint32_t len = (e >> 16) & 255u, sym = e >> 24, sz = sym & 15u;
+                bits = rd.peek();
+                uint32_t e = tcur[bits >> (32u - kLutBits)];
+                if (pend) row[pend_nat] = static_cast<int16_t>(pend_val);
+                if ((e & 255u) == 0u) e = long_entry(T, S, static_cast<uint32_t>(tcur - lut0) / kLutEntries, e, bits);
+                p += e & 255u;
+                rd.skip(lds_words, e & 255u);
+                const uint32_t len = (e >> 16) & 255u, sz = (e >> 24) & 15u;
                 const uint32_t v = ((bits << len) >> 1) >> (31u - sz);           // sz bits behind the code (sz = 0 -> 0)
                 const int32_t neg = static_cast<int32_t>((1u << sz) - 1u);
-                const int32_t value = static_cast<int32_t>(v) - ((static_cast<int32_t>(bits << len) < 0 || sz == 0u) ? 0 : neg);   // jdhuff.c HUFF_EXTEND
+                pend_val = static_cast<int32_t>(v) - ((static_cast<int32_t>(bits << len) < 0 || sz == 0u) ? 0 : neg);   // jdhuff.c HUFF_EXTEND
                 const uint32_t pos = z + ((e >> 8) & 255u) - 1u;                // zigzag index of an AC coefficient (DC: 0)
-                // DC and AC share one path: the three predictors are registers, selected by compares
-                const int32_t diff = is_dc ? value : 0;
-                dc0 += comp == 0u ? diff : 0; dc1 += comp == 1u ? diff : 0; dc2 += comp == 2u ? diff : 0;
-                const int32_t dcv = comp == 0u ? dc0 : (comp == 1u ? dc1 : dc2);
-                err |= (len > 16u ? 1u : 0u) | ((is_dc && sym > 11u) ? 2u : 0u) | ((!is_dc && sz != 0u && pos > 63u) ? 4u : 0u);
-                const uint32_t nat = lds_zz[pos & 63u];
-                if (is_dc || (sz != 0u && pos <= 63u)) row[nat] = static_cast<int16_t>(is_dc ? dcv : value);
+                const bool over = sz != 0u && pos > 63u;                         // a coefficient behind the block's end
+                err |= ((e >> 21) & 1u) | (over ? 4u : 0u);                      // (length field 32: no such code)
+                pend_nat = lds_zz[pos & 63u];
+                pend = is_dc || (sz != 0u && !over);                             // a DC entry holds the DIFFERENCE until the block is stored
                 waiting = advance(e);
             }
             const uint32_t n_wait = static_cast<uint32_t>(__popcll(__ballot(waiting)));
             const bool decoding = __ballot(run && !waiting) != 0ull;
             if (n_wait < kFlushLanes && decoding) continue;
             if (n_wait == 0u) break;                         // nobody decodes, nothing to store
+#ifdef IFHIP_ENT_TRACE
+            ++tw_fl;
+#endif
             if (waiting) {
+                if (pend) { row[pend_nat] = static_cast<int16_t>(pend_val); pend = false; }
+                // every LDS read of the store (the row, where the block goes) is requested before the first is used
                 const BlockPlace pl = lds_place[k];
+                int16_t* plane = lds_plane[k];
+                u32x4 r[8];
+#pragma unroll
+                for (uint32_t i = 0; i < 8u; ++i) r[i] = row4[i];
+                {                                            // DC: difference -> value (jdhuff.c last_dc_val)
+                    const int32_t diff = static_cast<int16_t>(r[0].x & 0xffffu);
+                    dc0 += pl.comp == 0u ? diff : 0; dc1 += pl.comp == 1u ? diff : 0; dc2 += pl.comp == 2u ? diff : 0;
+                    const int32_t dcv = pl.comp == 0u ? dc0 : (pl.comp == 1u ? dc1 : dc2);
+                    r[0].x = (r[0].x & 0xffff0000u) | (static_cast<uint32_t>(dcv) & 0xffffu);
+                }
                 const uint32_t bx = mx * (pl.hv & 255u) + ((pl.hv >> 16) & 255u), by = my * ((pl.hv >> 8) & 255u) + (pl.hv >> 24);
                 auto* dst = reinterpret_cast<__attribute__((address_space(1))) u32x4*>(reinterpret_cast<uintptr_t>(       // (global, not flat, stores)
-                    lds_plane[pl.comp] + (static_cast<size_t>(sg.image * pl.bh + by) * pl.bw + bx) * 64u));
+                    plane + (static_cast<size_t>(sg.image * pl.bh + by) * pl.bw + bx) * 64u));
+#ifndef IFHIP_ENT_DIAG_NOSTORE
 #pragma unroll
-                for (uint32_t i = 0; i < 8u; ++i) {
-                    dst[i] = row4[i];
-                    row4[i] = u32x4{0u, 0u, 0u, 0u};
-                }
+                for (uint32_t i = 0; i < 8u; ++i) dst[i] = r[i];
+#else
+                if (r[0].x == 0x12345678u && r[3].y == 0x9abcdef0u) dst[0] = r[1];
+#endif
+#pragma unroll
+                for (uint32_t i = 0; i < 8u; ++i) row4[i] = u32x4{0u, 0u, 0u, 0u};
                 ++block;
                 if (c == 0u) { ++mx; if (mx == a.g.mcus_w) { mx = 0u; ++my; } }      // the MCU is complete
                 k = c;
@@ -632,6 +671,11 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
                 run = p < end && block < sg.n_blocks;
             }
         }
+#ifdef IFHIP_ENT_TRACE
+        if ((threadIdx.x & 63u) == 0u && (blockIdx.x % 50u) == 3u)
+            printf("WR wg %u wave %u iters %u flushes %u lane0_symbols %u blocks %u us %.2f\n", blockIdx.x, threadIdx.x >> 6, tw_it, tw_fl, tw_sym,
+                   block - static_cast<uint32_t>(pre.x), (double)(wall_clock64() - tw_0) / 100.0);
+#endif
     });
     const bool last = s + 1u == sg.first_sub + sg.n_sub;
     if (last && block < sg.n_blocks) err |= 8u;              // the segment ran out of data
@@ -797,6 +841,8 @@ void derive_search_table(const HuffSpec& h, SearchTab* t) {
 void derive_fast_table(const HuffSpec& h, bool ac, FastTabs* F, uint32_t slot, uint32_t* pool_used) {
     uint32_t* lut = F->lut[slot];
     for (uint32_t i = 0; i < kLutEntries; ++i) lut[i] = invalid_entry(ac);
+    // a DC symbol is a magnitude category, at most 11 in baseline JPEG: larger ones decode as "no such code"
+    auto entry = [&](uint32_t l, uint32_t sym) { return (!ac && sym > 11u) ? invalid_entry(ac) : fast_entry(ac, l, sym); };
     struct LongCode { uint32_t code; uint8_t len, sym; };
     std::vector<LongCode> longs;
     uint8_t maxlen[kLutEntries] = {};
@@ -807,7 +853,7 @@ void derive_fast_table(const HuffSpec& h, bool ac, FastTabs* F, uint32_t slot, u
             if (l <= kLutBits) {
                 const uint32_t first = code << (kLutBits - l);
                 for (uint32_t f = 0; f < (1u << (kLutBits - l)); ++f)
-                    if (first + f < kLutEntries) lut[first + f] = fast_entry(ac, l, h.vals[k & 255]);
+                    if (first + f < kLutEntries) lut[first + f] = entry(l, h.vals[k & 255]);
             } else {
                 const uint32_t prefix = code >> (l - kLutBits);
                 if (prefix >= kLutEntries) continue;                 // over-subscribed table: the pattern cannot occur
@@ -830,7 +876,7 @@ void derive_fast_table(const HuffSpec& h, bool ac, FastTabs* F, uint32_t slot, u
         if (lut[prefix] == 0u) continue;
         const uint32_t n = maxlen[prefix] - kLutBits, rem = lc.len - kLutBits, off = lut[prefix] >> 16;
         const uint32_t sub = (lc.code & ((1u << rem) - 1u)) << (n - rem);
-        for (uint32_t f = 0; f < (1u << (n - rem)); ++f) F->pool[off + sub + f] = fast_entry(ac, lc.len, lc.sym);
+        for (uint32_t f = 0; f < (1u << (n - rem)); ++f) F->pool[off + sub + f] = entry(lc.len, lc.sym);
     }
 }
 // The six tables of one image; components that name the same table share its second level.
