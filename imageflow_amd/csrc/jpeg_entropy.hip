@@ -324,7 +324,7 @@ constexpr uint32_t kFastStageDwords = kSyncCols * kColPitch;
 // relative bit position | block-in-MCU << 21 | zigzag index << 25), the lanes that need a decode enter a work list
 // through a ballot / prefix count, and lane k decodes the k-th entry.  An iteration then costs what its dense waves cost.
 #ifndef IFHIP_ENT_INNER
-#define IFHIP_ENT_INNER 16
+#define IFHIP_ENT_INNER 24
 #endif
 constexpr uint32_t kInnerRounds = IFHIP_ENT_INNER;
 #ifndef IFHIP_ENT_WAVEWALK
@@ -348,8 +348,8 @@ __device__ __forceinline__ uint32_t pack_state(uint32_t p_rel, uint32_t cz) { re
 __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const EntropyArgs a) {
     __shared__ uint32_t lds_words[kFastStageDwords];
     __shared__ FastTabs lds_tabs;
-    __shared__ uint32_t ex[kSyncLanes], used[kSyncLanes];            // exit state; entry state of the last decode
-    __shared__ uint16_t endinfo[kSyncLanes], work[kSyncLanes];       // end - t * 1024; sub-sequences to decode this iteration
+    __shared__ uint2 st[kSyncLanes];                                 // .x exit state, .y the entry state it was decoded from (written as a pair)
+    __shared__ uint16_t endinfo[kSyncLanes], work[kSyncLanes];       // end - t * 1024 (| kChase); sub-sequences to decode this iteration
     __shared__ uint32_t wave_cnt[kSyncLanes / 64u];
 #ifdef IFHIP_ENT_TRACE
     const unsigned long long tr_enter = wall_clock64();
@@ -384,8 +384,9 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
     const uint32_t wg_image = a.segs[a.sub_seg[own_sub]].image;
     stage_stream_columns<kSyncLanes, kSyncCols>(a, lds_words, first_sub);
     stage_fast_tables<kSyncLanes>(a, &lds_tabs, wg_image);
-    ex[t] = st_ex; used[t] = st_used;
-    endinfo[t] = static_cast<uint16_t>(on ? min((s + 1u) * kSubBits, sg.bit_end) - s * kSubBits : 0u);
+    st[t] = make_uint2(st_ex, st_used);
+    constexpr uint32_t kChase = 0x8000u;                             // the entry is the predecessor's exit (not a segment's first sub-sequence)
+    endinfo[t] = static_cast<uint16_t>(on ? (min((s + 1u) * kSubBits, sg.bit_end) - s * kSubBits) | (first ? 0u : kChase) : 0u);
     __syncthreads();
     bool pending = false;
 #ifdef IFHIP_ENT_TRACE
@@ -394,8 +395,8 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
 #endif
     for (uint32_t it = 0; it < kInnerRounds; ++it) {
         // speculative first decode of round 0: from the sub-sequence's own first bit; afterwards from the predecessor's exit
-        const uint32_t entry = (fixed && !(a.round == 0u && it > 0u && !first && t > 0u)) ? fixed_entry : ex[t ? t - 1u : 0u];
-        const bool need = on && entry != used[t];
+        const uint32_t entry = (fixed && !(a.round == 0u && it > 0u && !first && t > 0u)) ? fixed_entry : st[t ? t - 1u : 0u].x;
+        const bool need = on && entry != st[t].y;
         const uint64_t vote = __ballot(need);
         if (lane == 0u) wave_cnt[wave] = static_cast<uint32_t>(__popcll(vote));
         __syncthreads();
@@ -408,29 +409,32 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
 #endif
         if (!pending) break;
         if (need) {
-            used[t] = entry;
+            st[t].y = entry;
             work[base + static_cast<uint32_t>(__popcll(vote & ((1ull << lane) - 1ull)))] = static_cast<uint16_t>(t);
         }
         __syncthreads();
         if (total <= kWaveWalkMax) {                                 // few sub-sequences: one wave each, see walk_wave
+            // (Letting the wave FOLLOW a correction into the next sub-sequence instead of leaving it to the next iteration
+            // was measured: 459 -> 576 us per launch -- a chain followed from an exit that is itself corrected later is
+            // walked twice, and the other work of the wave waits.)
             for (uint32_t k = wave; k < total; k += kSyncLanes / 64u) {
-                const uint32_t j = work[k];
-                const uint32_t e0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(used[j])));
+                const uint32_t j = uniform(work[k]);
+                const uint32_t e0 = uniform(st[j].y);
                 uint32_t p = e0 & 0x1fffffu, c = (e0 >> 21) & 15u, z = e0 >> 25;
-                const uint32_t end = j * kSubBits + endinfo[j];
+                const uint32_t end = j * kSubBits + (endinfo[j] & (kChase - 1u));
                 const uint32_t image = a.uniform_tables ? wg_image : a.segs[a.sub_seg[first_sub + j]].image;
                 with_fast_tables(a, &lds_tabs, wg_image, image, [&](auto tabs, const SearchTab* S) { walk_wave(a.g, lds_words, tabs, S, end, p, c, z); });
-                if (lane == 0u) ex[j] = p | (c << 21) | (z << 25);
+                if (lane == 0u) st[j].x = p | (c << 21) | (z << 25);
             }
         } else if (t < total) {
             const uint32_t j = work[t];
-            const uint32_t e0 = used[j];
+            const uint32_t e0 = st[j].y;
             uint32_t p = e0 & 0x1fffffu, c = (e0 >> 21) & 15u, z = e0 >> 25;
-            const uint32_t end = j * kSubBits + endinfo[j];
+            const uint32_t end = j * kSubBits + (endinfo[j] & (kChase - 1u));
             int32_t n = 0;
             const uint32_t image = a.uniform_tables ? wg_image : a.segs[a.sub_seg[first_sub + j]].image;
             with_fast_tables(a, &lds_tabs, wg_image, image, [&](auto tabs, const SearchTab* S) { walk<false, 0u>(a.g, lds_words, tabs, S, end, p, c, z, n, nullptr); });
-            ex[j] = p | (c << 21) | (z << 25);
+            st[j].x = p | (c << 21) | (z << 25);
         }
         __syncthreads();
     }
@@ -441,7 +445,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
         for (uint32_t i = 0; i < tr_k; ++i) printf("wg %u round %u it %u total %u us %.2f\n", blockIdx.x, a.round, i, tr_n[i], (double)(tr_t[i] - tr_0) / 100.0);
 #endif
     if (!on || t < kWarmLanes) return;
-    const uint32_t fin = ex[t], fu = used[t];
+    const uint32_t fin = st[t].x, fu = st[t].y;
     a.exit_p[cur][s] = (fin & 0x1fffffu) + bit0;
     a.exit_cz[cur][s] = (((fin >> 21) & 15u) << 8) | (fin >> 25);
     a.start_p[s] = fu == kNever ? kNever : (fu & 0x1fffffu) + bit0;
@@ -1238,18 +1242,19 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
     const dim3 sync_grid((a.n_sub + kSyncLanes - 1u) / kSyncLanes), sync_block(kSyncLanes);
     const dim3 round_grid((a.n_sub + kOwnSubs - 1u) / kOwnSubs);
     const uint32_t max_rounds = a.n_sub + 2u;
-    // Rounds 0..2 (speculative decode with the fixpoint iteration inside every workgroup; corrections that cross a
-    // workgroup boundary; the confirmation that nothing moved any more), the scan and the write pass are enqueued
-    // back to back, and the host looks at the flags once: the typical batch needs exactly these launches.  If round 2
-    // still moved something, more rounds run (one look per round) and scan + write are repeated -- the write pass
-    // stores every block in full, so the repeat simply overwrites.
+    // Round 0 (speculative decode with the fixpoint iteration inside every workgroup), round 1 (corrections that cross a
+    // workgroup boundary -- with the warm-up lanes of round 0 there are none, and the launch is the confirmation that
+    // nothing moves any more), the count, the scan and the write pass are enqueued back to back, and the host looks at
+    // the flags once: the typical batch needs exactly these launches.  If round 1 still moved something, more rounds run
+    // (one look per round) and count + scan + write are repeated -- the write pass stores every block in full, so the
+    // repeat simply overwrites.
     uint32_t r = 0;
-    for (; r < 3u; ++r) {
+    for (; r < 2u; ++r) {
         a.round = r;
         hipLaunchKernelGGL(entropy_round_kernel, round_grid, sync_block, 0, st, a);
         HIP_TRY(hipGetLastError());
     }
-    r = 2u;
+    r = 1u;
     for (;;) {
         a.round = r;
         hipLaunchKernelGGL(entropy_count_kernel, sync_grid, sync_block, 0, st, a);
