@@ -114,11 +114,14 @@ struct EntropyArgs {
     uint32_t* start_p;                               // start state the lane last decoded from
     uint32_t* start_cz;
     int4* cnt;                                       // per sub-sequence {blocks started, DC sum comp 0, 1, 2}
-    int4* prefix;                                    // exclusive per-segment scan of cnt
+    int4* tail;                                      // per chunk of kChunkSubs sub-sequences: sum of cnt over the part that belongs to the
+                                                     // segment of the chunk's last sub-sequence (what a segment carries into the next chunk)
     uint32_t* changed;                               // [16] lanes whose exit state moved in round r, at [r & 15]
-    uint32_t* errors;                                // bit 0 invalid code, 1 bad DC category, 2 run past 63, 3 short segment
+    uint32_t* errors;                                // [16] bit 0 invalid code, 2 run past 63, 3 short segment
+    uint32_t* unsettled;                             // [17] sub-sequences the count pass found decoded from another state than their predecessor's exit
     int16_t* coef[3];                                // [image][bh][bw][64]
     uint32_t round;
+    uint32_t inner_rounds;                           // fixpoint iterations inside a workgroup per launch (kInnerRounds; tests lower it)
 };
 
 __constant__ uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
@@ -340,7 +343,9 @@ constexpr uint32_t kWaveWalkMax = IFHIP_ENT_WAVEWALK;                          /
 #endif
 constexpr uint32_t kWarmLanes = IFHIP_ENT_WARM;
 constexpr uint32_t kOwnSubs = kSyncLanes - kWarmLanes;                         // sub-sequences a workgroup owns
-constexpr uint32_t kNever = 0xffffffffu;                                       // no decode yet (no real state packs to this)
+constexpr uint32_t kNever = 0xffffffffu;
+constexpr uint32_t kFlagWords = 18;                                             // changed[16], errors, unsettled
+constexpr uint32_t kChunkSubs = 512;                                            // sub-sequences per workgroup of the write pass                                       // no decode yet (no real state packs to this)
 static_assert((kSyncLanes + 2u) * kSubBits < (1u << 21), "packed state: 21 bits of relative position");
 
 __device__ __forceinline__ uint32_t pack_state(uint32_t p_rel, uint32_t cz) { return p_rel | ((cz >> 8) << 21) | ((cz & 255u) << 25); }
@@ -356,6 +361,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
 #endif
     const uint32_t own_sub = blockIdx.x * kOwnSubs, first_sub = own_sub - kWarmLanes;     // (wraps for workgroup 0: those lanes are off)
     const uint32_t t = threadIdx.x, s = first_sub + t, lane = t & 63u, wave = t >> 6;
+    if (a.round == 0u && blockIdx.x == 0u && t < kFlagWords) a.changed[t] = 0u;     // the flags of this decode (later launches set them)
     const uint32_t t0 = a.round == 0u ? 0u : kWarmLanes;             // first lane at work
     const bool on = s < a.n_sub && t >= t0;
     const uint32_t cur = a.round & 1u, prv = cur ^ 1u;
@@ -393,7 +399,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
     unsigned long long tr_t[24]; uint32_t tr_n[24], tr_k = 0u;
     const unsigned long long tr_0 = wall_clock64();
 #endif
-    for (uint32_t it = 0; it < kInnerRounds; ++it) {
+    for (uint32_t it = 0; it < a.inner_rounds; ++it) {
         // speculative first decode of round 0: from the sub-sequence's own first bit; afterwards from the predecessor's exit
         const uint32_t entry = (fixed && !(a.round == 0u && it > 0u && !first && t > 0u)) ? fixed_entry : st[t ? t - 1u : 0u].x;
         const bool need = on && entry != st[t].y;
@@ -456,12 +462,33 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
 }
 
 // Count pass, once the exit states are final: every lane walks its sub-sequence from its true entry state and records
-// {blocks started, DC difference sum per component} for the scan that gives the write pass its first block and its DC
-// predictors.  (The synchronisation rounds used to carry these sums through every re-decode.)
+// {blocks started, DC difference sum per component}; the write pass turns them into every lane's first block and DC
+// predictors (an exclusive scan over the sub-sequences of a segment).  To spare that scan a launch of its own, the
+// count pass also leaves, per chunk of kChunkSubs sub-sequences, what a segment carries out of the chunk (`tail`): a
+// write workgroup adds the tails of the chunks between its segment's start and itself (a 4K file: at most 26) and
+// scans its own 512 counts.  The pass also CHECKS the fixpoint: a sub-sequence that was last decoded from another state
+// than its predecessor's exit (a correction that crossed a workgroup boundary of round 0, or an iteration limit) is
+// counted in `unsettled`, and the host runs further rounds before it trusts count and write pass.
+__device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ int4 sub4(int4 a, int4 b) { return make_int4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ int4 shfl_up4(int4 v, uint32_t d) {
+    return make_int4(__shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64), __shfl_up(v.z, d, 64), __shfl_up(v.w, d, 64));
+}
+__device__ __forceinline__ int4 shfl_down4(int4 v, uint32_t d) {
+    return make_int4(__shfl_down(v.x, d, 64), __shfl_down(v.y, d, 64), __shfl_down(v.z, d, 64), __shfl_down(v.w, d, 64));
+}
+__device__ __forceinline__ int4 wave_sum4(int4 v) {                 // lane 0 gets the sum over the wave
+#pragma unroll
+    for (uint32_t d = 32u; d > 0u; d >>= 1) v = add4(v, shfl_down4(v, d));
+    return v;
+}
+static_assert(kSyncLanes % kChunkSubs == 0u, "a count workgroup covers whole chunks");
+
 __global__ void __launch_bounds__(kSyncLanes) entropy_count_kernel(const EntropyArgs a) {
     __shared__ uint32_t lds_words[kFastStageDwords];
     __shared__ FastTabs lds_tabs;
     __shared__ int32_t lds_dc[3u * kSyncLanes];
+    __shared__ int32_t lds_tail[kSyncLanes / kChunkSubs][4];
     const uint32_t first_sub = blockIdx.x * kSyncLanes;
     const uint32_t s = first_sub + threadIdx.x;
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
@@ -469,48 +496,42 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_count_kernel(const Entropy
     stage_fast_tables<kSyncLanes>(a, &lds_tabs, wg_image);
     int32_t* dcs = lds_dc + threadIdx.x;                     // this lane's three sums, kSyncLanes apart (one bank per lane)
     dcs[0] = 0; dcs[kSyncLanes] = 0; dcs[2u * kSyncLanes] = 0;
+    if (threadIdx.x < (kSyncLanes / kChunkSubs) * 4u) (&lds_tail[0][0])[threadIdx.x] = 0;
     __syncthreads();
-    if (s >= a.n_sub) return;
-    const Segment sg = a.segs[a.sub_seg[s]];
-    const uint32_t fin = a.round & 1u;
-    const uint32_t bit0 = first_sub * kSubBits;
-    uint32_t p = s * kSubBits - bit0, c = 0, z = 0;
-    if (s != sg.first_sub) { p = a.exit_p[fin][s - 1u] - bit0; const uint32_t cz = a.exit_cz[fin][s - 1u]; c = cz >> 8; z = cz & 255u; }
-    const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end) - bit0;
-    int32_t n = 0;
-    with_fast_tables(a, &lds_tabs, wg_image, sg.image, [&](auto tabs, const SearchTab* S) { walk<true, kSyncLanes>(a.g, lds_words, tabs, S, end, p, c, z, n, dcs); });
-    a.cnt[s] = make_int4(n, dcs[0], dcs[kSyncLanes], dcs[2u * kSyncLanes]);
-}
-
-// exclusive scan of cnt over the sub-sequences of one segment: one workgroup of 1024 lanes per segment, every lane sums
-// a contiguous run, the 1024 partial sums are scanned with wave shuffles + one LDS step, then every lane walks its run
-// again writing the prefixes (a 4K file is one segment of ~13 000 sub-sequences: 13 per lane)
-__device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ int4 shfl_up4(int4 v, uint32_t d) {
-    return make_int4(__shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64), __shfl_up(v.z, d, 64), __shfl_up(v.w, d, 64));
-}
-__global__ void __launch_bounds__(1024) entropy_scan_kernel(const EntropyArgs a) {
-    __shared__ int4 wave_tot[16];
-    const Segment sg = a.segs[blockIdx.x];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t per = (sg.n_sub + 1023u) / 1024u;
-    const uint32_t lo = min(t * per, sg.n_sub), hi = min(lo + per, sg.n_sub);
-    int4 sum = make_int4(0, 0, 0, 0);
-    for (uint32_t i = lo; i < hi; ++i) sum = add4(sum, a.cnt[sg.first_sub + i]);
-    int4 inc = sum;                                                  // inclusive scan inside the wave
-#pragma unroll
-    for (uint32_t d = 1; d < 64u; d <<= 1) {
-        const int4 o = shfl_up4(inc, d);
-        if (lane >= d) inc = add4(inc, o);
+    const bool on = s < a.n_sub;
+    int4 mine = make_int4(0, 0, 0, 0);
+    uint32_t my_seg = 0xffffffffu;
+    if (on) {
+        my_seg = a.sub_seg[s];
+        const Segment sg = a.segs[my_seg];
+        const uint32_t fin = a.round & 1u;
+        const uint32_t bit0 = first_sub * kSubBits;
+        uint32_t p = s * kSubBits - bit0, c = 0, z = 0;
+        if (s != sg.first_sub) {
+            const uint32_t ep = a.exit_p[fin][s - 1u], ecz = a.exit_cz[fin][s - 1u];
+            if (a.start_p[s] != ep || a.start_cz[s] != ecz) atomicAdd(a.unsettled, 1u);
+            p = ep - bit0; c = ecz >> 8; z = ecz & 255u;
+        }
+        const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end) - bit0;
+        int32_t n = 0;
+        with_fast_tables(a, &lds_tabs, wg_image, sg.image, [&](auto tabs, const SearchTab* S) { walk<true, kSyncLanes>(a.g, lds_words, tabs, S, end, p, c, z, n, dcs); });
+        mine = make_int4(n, dcs[0], dcs[kSyncLanes], dcs[2u * kSyncLanes]);
+        a.cnt[s] = mine;
     }
-    if (lane == 63u) wave_tot[wave] = inc;
+    // what the segment of each chunk's last sub-sequence carries out of the chunk
+    const uint32_t half = threadIdx.x / kChunkSubs;
+    const uint32_t chunk_first = first_sub + half * kChunkSubs;
+    const bool chunk_on = chunk_first < a.n_sub;
+    const uint32_t last_seg = chunk_on ? a.sub_seg[min(chunk_first + kChunkSubs, a.n_sub) - 1u] : 0xfffffffeu;
+    const int4 part = wave_sum4(my_seg == last_seg ? mine : make_int4(0, 0, 0, 0));
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicAdd(&lds_tail[half][0], part.x); atomicAdd(&lds_tail[half][1], part.y);
+        atomicAdd(&lds_tail[half][2], part.z); atomicAdd(&lds_tail[half][3], part.w);
+    }
     __syncthreads();
-    int4 run = make_int4(inc.x - sum.x, inc.y - sum.y, inc.z - sum.z, inc.w - sum.w);
-    for (uint32_t w = 0; w < wave; ++w) run = add4(run, wave_tot[w]);
-    for (uint32_t i = lo; i < hi; ++i) {
-        a.prefix[sg.first_sub + i] = run;
-        run = add4(run, a.cnt[sg.first_sub + i]);
-    }
+    if (threadIdx.x < kSyncLanes / kChunkSubs && first_sub + threadIdx.x * kChunkSubs < a.n_sub)
+        a.tail[blockIdx.x * (kSyncLanes / kChunkSubs) + threadIdx.x] =
+            make_int4(lds_tail[threadIdx.x][0], lds_tail[threadIdx.x][1], lds_tail[threadIdx.x][2], lds_tail[threadIdx.x][3]);
 }
 
 // Write pass.  A block belongs to the lane in whose sub-sequence it STARTS: that lane decodes it to the end (running
@@ -524,7 +545,7 @@ __global__ void __launch_bounds__(1024) entropy_scan_kernel(const EntropyArgs a)
 // structure a compiler makes of "decode a block, store it") leaves most lanes idle, blocks differ that much in length.
 // So a lane that completed its block WAITS until kFlushLanes lanes of its wave wait (or nobody decodes any more) and
 // they store together: the store path runs every third or fourth symbol step and a lane idles ~2 steps per block.
-constexpr uint32_t kWriteLanes = 512;
+constexpr uint32_t kWriteLanes = kChunkSubs;
 constexpr uint32_t kWriteCols = kWriteLanes + kMarginSubs;
 constexpr uint32_t kBlkPitch = 36;                   // dwords per lane row (32 + 4)
 #ifndef IFHIP_ENT_FLUSH
@@ -549,12 +570,46 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
                                   a.g.bw[cm], a.g.bh[cm], cm};
         lds_plane[k] = a.coef[cm];
     }
+    const uint32_t first_sub = blockIdx.x * kWriteLanes;
+    const uint32_t s = first_sub + threadIdx.x;
+    // This lane's first block and DC predictors: the exclusive scan of the counts over the sub-sequences of its segment
+    // = (what the segment carried through the chunks in front of this workgroup) + (the scan inside the workgroup).
+    int4 pre;
+    {
+        __shared__ int4 wave_tot[kWriteLanes / 64u], lead;
+        int4* excl_at = reinterpret_cast<int4*>(lds_blk);            // (the rows are not in use yet)
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const bool on = s < a.n_sub;
+        const Segment sg0 = a.segs[a.sub_seg[first_sub]], sgm = a.segs[a.sub_seg[on ? s : first_sub]];
+        const int4 mine = on ? a.cnt[s] : make_int4(0, 0, 0, 0);
+        int4 inc = mine;                                             // inclusive scan inside the wave
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const int4 o = shfl_up4(inc, d);
+            if (lane >= d) inc = add4(inc, o);
+        }
+        if (lane == 63u) wave_tot[wave] = inc;
+        if (wave == 0u) {                                            // the leading segment's counts in front of this chunk
+            int4 v = make_int4(0, 0, 0, 0);
+            if (sg0.first_sub < first_sub)
+                for (uint32_t i = sg0.first_sub / kChunkSubs + lane; i < blockIdx.x; i += 64u) v = add4(v, a.tail[i]);
+            v = wave_sum4(v);
+            if (lane == 0u) lead = v;
+        }
+        __syncthreads();
+        int4 excl = sub4(inc, mine);
+        for (uint32_t w = 0; w < wave; ++w) excl = add4(excl, wave_tot[w]);
+        excl_at[threadIdx.x] = excl;
+        __syncthreads();
+        const bool from_before = sgm.first_sub < first_sub;          // the lane's segment began in front of this workgroup
+        pre = sub4(excl, excl_at[from_before ? 0u : sgm.first_sub - first_sub]);
+        if (from_before) pre = add4(pre, lead);
+        __syncthreads();                                             // every lane has read: the rows may be cleared
+    }
     int16_t* row = reinterpret_cast<int16_t*>(lds_blk + threadIdx.x * kBlkPitch);
     u32x4* row4 = reinterpret_cast<u32x4*>(lds_blk + threadIdx.x * kBlkPitch);
 #pragma unroll
     for (uint32_t i = 0; i < 8u; ++i) row4[i] = u32x4{0u, 0u, 0u, 0u};               // a row is cleared again when it is stored
-    const uint32_t first_sub = blockIdx.x * kWriteLanes;
-    const uint32_t s = first_sub + threadIdx.x;
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
     stage_stream_columns<kWriteLanes, kWriteCols>(a, lds_words, first_sub);
     stage_fast_tables<kWriteLanes>(a, &lds_tabs, wg_image);
@@ -567,7 +622,6 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
     if (s != sg.first_sub) { p = a.exit_p[fin][s - 1u] - bit0; const uint32_t cz = a.exit_cz[fin][s - 1u]; c = cz >> 8; z = cz & 255u; }
     const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end) - bit0;
     uint32_t err = 0;
-    const int4 pre = a.prefix[s];
     int32_t dc0 = pre.y, dc1 = pre.z, dc2 = pre.w;
     uint32_t block = static_cast<uint32_t>(pre.x);           // the next block this lane starts
     const uint32_t B = a.g.blocks_per_mcu;
@@ -842,7 +896,7 @@ void derive_search_table(const HuffSpec& h, SearchTab* t) {
     t->maxcode[17] = 0x7fffffff;
 }
 // First level of one table into F->lut[slot], its second level appended to the image's pool (*pool_used entries taken).
-void derive_fast_table(const HuffSpec& h, bool ac, FastTabs* F, uint32_t slot, uint32_t* pool_used) {
+void derive_fast_table(const HuffSpec& h, bool ac, FastTabs* F, uint32_t slot, uint32_t* pool_used, uint32_t pool_limit) {
     uint32_t* lut = F->lut[slot];
     for (uint32_t i = 0; i < kLutEntries; ++i) lut[i] = invalid_entry(ac);
     // a DC symbol is a magnitude category, at most 11 in baseline JPEG: larger ones decode as "no such code"
@@ -870,7 +924,7 @@ void derive_fast_table(const HuffSpec& h, bool ac, FastTabs* F, uint32_t slot, u
     for (uint32_t prefix = 0; prefix < kLutEntries; ++prefix) {
         if (!maxlen[prefix]) continue;
         const uint32_t n = maxlen[prefix] - kLutBits, size = 1u << n;
-        if (*pool_used + size > kPoolEntries) { lut[prefix] = 0u; continue; }        // left to the serial search
+        if (*pool_used + size > pool_limit) { lut[prefix] = 0u; continue; }          // left to the serial search
         for (uint32_t i = 0; i < size; ++i) F->pool[*pool_used + i] = invalid_entry(ac);
         lut[prefix] = (*pool_used << 16) | ((32u - n) << 8);
         *pool_used += size;
@@ -884,7 +938,7 @@ void derive_fast_table(const HuffSpec& h, bool ac, FastTabs* F, uint32_t slot, u
     }
 }
 // The six tables of one image; components that name the same table share its second level.
-void derive_image_tables(const ParsedJpeg& P, FastTabs* F, SearchTab* S6) {
+void derive_image_tables(const ParsedJpeg& P, FastTabs* F, SearchTab* S6, uint32_t pool_limit) {
     std::memset(F, 0, sizeof *F);
     std::memset(S6, 0, 6u * sizeof *S6);
     uint32_t pool_used = 0;
@@ -896,7 +950,7 @@ void derive_image_tables(const ParsedJpeg& P, FastTabs* F, SearchTab* S6) {
             int same = -1;
             for (int o = 0; o < c; ++o) if ((ac ? P.ta[o] : P.td[o]) == id) same = o;
             if (same >= 0) std::memcpy(F->lut[slot], F->lut[2u * static_cast<uint32_t>(same) + ac], sizeof F->lut[slot]);
-            else derive_fast_table(ac ? P.ac[id] : P.dc[id], ac != 0u, F, slot, &pool_used);
+            else derive_fast_table(ac ? P.ac[id] : P.dc[id], ac != 0u, F, slot, &pool_used, pool_limit);
         }
 }
 
@@ -1015,6 +1069,14 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
         uint32_t first_seg = 0;
     };
     const bool timing = std::getenv("IFHIP_ENT_TIMING") != nullptr;        // development aid: phase times on stderr
+    // test hooks: the rarely taken paths (serial code search for sub-tables that overflow the pool; further rounds after an
+    // unsettled count pass) are forced by shrinking the pool / the iterations per launch
+    auto env_u32 = [](const char* name, uint32_t dflt, uint32_t hi) {
+        const char* v = std::getenv(name);
+        return v ? std::min<uint32_t>(static_cast<uint32_t>(std::strtoul(v, nullptr, 10)), hi) : dflt;
+    };
+    const uint32_t pool_limit = env_u32("IFHIP_ENT_TEST_POOL", kPoolEntries, kPoolEntries);
+    const uint32_t inner_rounds = std::max<uint32_t>(1u, env_u32("IFHIP_ENT_TEST_INNER", kInnerRounds, kInnerRounds));
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
     const auto t_start = now();
@@ -1045,7 +1107,7 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
         R.rc = parse_jpeg(files[img], lengths[img], &P);
         if (R.rc) { R.message = last_error(); return; }
         for (int c = 0; c < P.ncomp; ++c) std::memcpy(&e->qt[(static_cast<size_t>(img) * 3u + c) * 64u], P.qt[P.tq[c]], 128);
-        derive_image_tables(P, &ftabs[img], &stabs[static_cast<size_t>(img) * 6u]);
+        derive_image_tables(P, &ftabs[img], &stabs[static_cast<size_t>(img) * 6u], pool_limit);
         // un-stuff the scan and cut it at restart markers
         const uint8_t* d = files[img];
         const size_t len = lengths[img];
@@ -1149,6 +1211,7 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
                 a.g.kcomp_packed |= static_cast<uint32_t>(c) << (2u * k);
             }
     }
+    a.inner_rounds = inner_rounds;
     a.n_sub = static_cast<uint32_t>(sub_seg.size());
     a.n_seg = static_cast<uint32_t>(segs.size());
     a.uniform_tables = 1u;                           // batches of small files put many images into one workgroup: with
@@ -1173,10 +1236,11 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     if ((rc = dev_alloc<uint32_t>(e.get(), &a.start_p, a.n_sub))) return rc;
     if ((rc = dev_alloc<uint32_t>(e.get(), &a.start_cz, a.n_sub))) return rc;
     if ((rc = dev_alloc<int4>(e.get(), &a.cnt, a.n_sub))) return rc;
-    if ((rc = dev_alloc<int4>(e.get(), &a.prefix, a.n_sub))) return rc;
-    if ((rc = dev_alloc<uint32_t>(e.get(), &a.changed, 17))) return rc;
+    if ((rc = dev_alloc<int4>(e.get(), &a.tail, (a.n_sub + kChunkSubs - 1u) / kChunkSubs))) return rc;
+    if ((rc = dev_alloc<uint32_t>(e.get(), &a.changed, kFlagWords))) return rc;
     a.errors = a.changed + 16;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_flags), 17 * sizeof(uint32_t), hipHostMallocDefault));
+    a.unsettled = a.changed + 17;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_flags), kFlagWords * sizeof(uint32_t), hipHostMallocDefault));
     if (timing)
         std::fprintf(stderr, "[ifhip entropy create] threads %u (hw %u): parse+unstuff %.2f ms, +pack %.2f ms, +upload/alloc %.2f ms\n",
                      n_threads, hw, t_parse, t_pack, ms_since(t_start));
@@ -1222,9 +1286,9 @@ int ifhip_jpeg_entropy_quant_tables(const ifhip_jpeg_entropy* e, uint16_t* qt_n3
     return IFHIP_OK;
 }
 
-// Decodes the whole batch into d_coef* (each [n_images][bh_c][bw_c][64] int16, natural order).  The rounds need their
-// "anything changed?" answer on the host, so the call synchronises the stream; *rounds (optional) reports how many
-// synchronisation rounds ran.
+// Decodes the whole batch into d_coef* (each [n_images][bh_c][bw_c][64] int16, natural order).  The fixpoint check needs
+// its answer on the host, so the call synchronises the stream; *rounds (optional) reports how many synchronisation
+// rounds ran (1 unless a correction crossed a workgroup boundary).
 int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, int16_t* d_coef1, int16_t* d_coef2,
                                      uint32_t* rounds, void* hip_stream) {
     if (!e) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null handle");
@@ -1238,46 +1302,40 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
     a.coef[0] = d_coef0; a.coef[1] = d_coef1; a.coef[2] = d_coef2;
     if ((reinterpret_cast<uintptr_t>(d_coef0) | reinterpret_cast<uintptr_t>(d_coef1) | reinterpret_cast<uintptr_t>(d_coef2)) & 15u)
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: coefficient planes must be 16-byte aligned");
-    HIP_TRY(hipMemsetAsync(a.changed, 0, 17 * sizeof(uint32_t), st));
     const dim3 sync_grid((a.n_sub + kSyncLanes - 1u) / kSyncLanes), sync_block(kSyncLanes);
     const dim3 round_grid((a.n_sub + kOwnSubs - 1u) / kOwnSubs);
     const uint32_t max_rounds = a.n_sub + 2u;
-    // Round 0 (speculative decode with the fixpoint iteration inside every workgroup), round 1 (corrections that cross a
-    // workgroup boundary -- with the warm-up lanes of round 0 there are none, and the launch is the confirmation that
-    // nothing moves any more), the count, the scan and the write pass are enqueued back to back, and the host looks at
-    // the flags once: the typical batch needs exactly these launches.  If round 1 still moved something, more rounds run
-    // (one look per round) and count + scan + write are repeated -- the write pass stores every block in full, so the
-    // repeat simply overwrites.
+    // Round 0 (speculative decode with the fixpoint iteration inside every workgroup; it also clears the flags), the
+    // count pass (which checks that every sub-sequence was decoded from its predecessor's exit: with the warm-up lanes of
+    // round 0 no correction crosses a workgroup boundary) and the write pass are enqueued back to back -- three launches,
+    // every launch boundary costs ~8 us -- and the host looks at the flags once.  If the count pass found an unsettled
+    // sub-sequence, further rounds run (one look per round) and count + write are repeated: the write pass stores every
+    // block in full, so the repeat simply overwrites.
     uint32_t r = 0;
-    for (; r < 2u; ++r) {
-        a.round = r;
-        hipLaunchKernelGGL(entropy_round_kernel, round_grid, sync_block, 0, st, a);
-        HIP_TRY(hipGetLastError());
-    }
-    r = 1u;
+    a.round = 0u;
+    hipLaunchKernelGGL(entropy_round_kernel, round_grid, sync_block, 0, st, a);
+    HIP_TRY(hipGetLastError());
     for (;;) {
         a.round = r;
         hipLaunchKernelGGL(entropy_count_kernel, sync_grid, sync_block, 0, st, a);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(entropy_scan_kernel, dim3(a.n_seg), dim3(1024), 0, st, a);
-        HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(entropy_write_kernel, dim3((a.n_sub + kWriteLanes - 1u) / kWriteLanes), dim3(kWriteLanes), 0, st, a);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(e->h_flags, a.changed, 17 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(e->h_flags, a.changed, kFlagWords * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (e->h_flags[r & 15u] == 0u) break;                        // the last round confirmed the fixpoint
-        for (;;) {                                                   // rare: long-range corrections
+        if (e->h_flags[17] == 0u) break;                             // every sub-sequence starts where its predecessor ended
+        for (;;) {                                                   // rare: corrections across workgroups
             ++r;
             if (r >= max_rounds) return fail(IFHIP_INVALID_STATE, "InvalidState: entropy decode did not converge");
             HIP_TRY(hipMemsetAsync(a.changed + (r & 15u), 0, sizeof(uint32_t), st));
             a.round = r;
             hipLaunchKernelGGL(entropy_round_kernel, round_grid, sync_block, 0, st, a);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(e->h_flags, a.changed, 17 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(e->h_flags, a.changed, kFlagWords * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (e->h_flags[r & 15u] == 0u) break;
         }
-        HIP_TRY(hipMemsetAsync(a.errors, 0, sizeof(uint32_t), st));      // flags of the discarded write pass
+        HIP_TRY(hipMemsetAsync(a.errors, 0, 2u * sizeof(uint32_t), st));     // flags of the discarded count and write passes
     }
     if (rounds) *rounds = r + 1u;
     if (e->h_flags[16]) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: corrupt entropy-coded data (flags 0x%x)", e->h_flags[16]);

@@ -112,3 +112,27 @@ def test_many_small_files_in_one_batch(golden_dir):
             j = ref.setdefault(data, O.jpeg_read_coefficients(data))
             for c in range(3):
                 assert np.array_equal(coef[c][k].cpu().numpy(), j["coef"][c]), (k, c)
+
+
+@pytest.mark.parametrize("hook", [{"IFHIP_ENT_TEST_POOL": "0"}, {"IFHIP_ENT_TEST_POOL": "40"}, {"IFHIP_ENT_TEST_INNER": "1"},
+                                  {"IFHIP_ENT_TEST_INNER": "2", "IFHIP_ENT_TEST_POOL": "8"}])
+def test_rarely_taken_paths(golden_dir, monkeypatch, hook):
+    """The serial code search (sub-tables that overflow the second-level pool: forced by a pool of 0 / 40 / 8 entries) and the
+    rounds after an unsettled count pass (forced by one or two fixpoint iterations per launch) decode the same
+    coefficients as the normal path."""
+    for k, v in hook.items():
+        monkeypatch.setenv(k, v)
+    checked, most_rounds = 0, 0
+    for key, items in groups(golden_dir, "jpeg_entropy_cases.npz").items():
+        files = [d for _, d in items]
+        ent = D.JpegEntropyBatch(files, DEV)
+        coef = ent.read_coefficients()
+        most_rounds = max(most_rounds, ent.rounds)
+        for i, (name, data) in enumerate(items):
+            j = O.jpeg_read_coefficients(data)
+            for c in range(j["ncomp"]):
+                assert np.array_equal(coef[c][i].cpu().numpy(), j["coef"][c]), (name, c, hook)
+            checked += 1
+    assert checked == 62
+    if "IFHIP_ENT_TEST_INNER" in hook:
+        assert most_rounds > 4, most_rounds              # the host did iterate
