@@ -81,6 +81,11 @@ __host__ __device__ inline uint32_t fast_entry(bool ac, uint32_t len, uint32_t s
 }
 // A bit pattern no code starts with (corrupt data, or a speculative decode off the symbol grid): 16 bits are skipped as
 // symbol 0, the length field says 32 (a bit no real length has) and the write pass reports it.
+// The synchronisation rounds only track the decoder state, and at q85 a symbol is ~6 bits: their tables (`ptabs`) carry in
+// bits 16-31 the skip and zigzag advance of this symbol AND the next one where the next code still lies inside the lookup
+// window (both AC, same table; 31 % fewer table reads on 4K q85 files), else a copy of bits 0-15.  The pair applies when
+// the first symbol neither ends the block nor the sub-sequence.
+__host__ __device__ inline uint32_t pair_entry(uint32_t first, uint32_t both) { return (first & 0xffffu) | (both << 16); }
 __host__ __device__ inline uint32_t invalid_entry(bool ac) { return (32u << 16) | ((ac ? 64u : 1u) << 8) | 16u; }
 
 
@@ -106,6 +111,7 @@ struct EntropyArgs {
     const Segment* segs;
     const uint32_t* sub_seg;                         // segment of every sub-sequence
     const FastTabs* ftabs;                           // [image]
+    const FastTabs* ptabs;                           // [image] the same tables with pair entries, for the synchronisation rounds
     const SearchTab* stabs;                          // [image][comp][dc, ac]: the serial search, for sub-tables that did not fit
     uint32_t n_sub, n_seg;
     uint32_t uniform_tables;                         // every image carries the same Huffman tables (e.g. the standard ones)
@@ -183,7 +189,7 @@ struct Reader {
 };
 
 // Entry of a symbol whose code is longer than the first-level lookup (e = that lookup's entry, skip field 0).
-template <typename Tabs>
+template <bool kPairs = false, typename Tabs>
 __device__ __forceinline__ uint32_t long_entry(const Tabs* T, const SearchTab* S, uint32_t slot, uint32_t e, uint32_t bits) {
     if (e != 0u) return T->pool[(e >> 16) + ((bits << kLutBits) >> ((e >> 8) & 255u))];
     // jdhuff.c's slow path "l = min{l : code_l <= maxcode[l]}" without its dependent chain: all candidate lengths are
@@ -194,10 +200,13 @@ __device__ __forceinline__ uint32_t long_entry(const Tabs* T, const SearchTab* S
 #pragma unroll
     for (uint32_t k = kLutBits + 1u; k <= 16u; ++k)
         l += static_cast<int32_t>(bits >> (32u - k)) > t->maxcode[k] ? 1u : 0u;
-    if (l > 16u) return invalid_entry(ac);
-    const int32_t code = static_cast<int32_t>(bits >> (32u - l));
-    const uint32_t sym = t->val[(code + t->valoff[l]) & 255];
-    return (!ac && sym > 11u) ? invalid_entry(ac) : fast_entry(ac, l, sym);
+    uint32_t r = invalid_entry(ac);
+    if (l <= 16u) {
+        const int32_t code = static_cast<int32_t>(bits >> (32u - l));
+        const uint32_t sym = t->val[(code + t->valoff[l]) & 255];
+        if (ac || sym <= 11u) r = fast_entry(ac, l, sym);
+    }
+    return kPairs ? pair_entry(r, r) : r;
 }
 
 // ---- synchronisation and count passes: the lean walker ----------------------------------------------------------
@@ -207,7 +216,7 @@ __device__ __forceinline__ uint32_t long_entry(const Tabs* T, const SearchTab* S
 // the reader's refill and the end-of-block bookkeeping as selects -- no divergent branch but the long-code lookup.
 // kCount: also count the blocks started and sum the DC differences per component (into the lane's LDS slots dcs[comp *
 // kDcPitch]: a dynamic index into three registers costs eight selects).
-template <bool kCount, uint32_t kDcPitch, typename Tabs>
+template <bool kCount, uint32_t kDcPitch, bool kPairs, typename Tabs>
 __device__ __forceinline__ void walk(const EntropyGeom& g, const uint32_t* lds_words, const Tabs* T, const SearchTab* S, uint32_t end,
                                      uint32_t& p, uint32_t& c, uint32_t& z, int32_t& n, int32_t* dcs) {
     const auto* lut0 = &T->lut[0][0];
@@ -218,7 +227,11 @@ __device__ __forceinline__ void walk(const EntropyGeom& g, const uint32_t* lds_w
     while (p < end) {
         const uint32_t bits = rd.peek();
         uint32_t e = tcur[bits >> (32u - kLutBits)];
-        if ((e & 255u) == 0u) e = long_entry(T, S, static_cast<uint32_t>(tcur - lut0) / kLutEntries, e, bits);
+        if ((e & 255u) == 0u) e = long_entry<kPairs>(T, S, static_cast<uint32_t>(tcur - lut0) / kLutEntries, e, bits);
+        if constexpr (kPairs) {                                      // this symbol and the next, if this one ends neither block nor walk
+            const bool both = z + ((e >> 8) & 255u) < 64u && p + (e & 255u) < end;
+            e = both ? e >> 16 : e;
+        }
         if constexpr (kCount) if (z == 0u) {                                     // DC symbol: jdhuff.c HUFF_EXTEND of the sz bits behind the code
             const uint32_t len = (e >> 16) & 255u, sz = (e >> 24) & 15u;
             const uint32_t v = ((bits << len) >> 1) >> (31u - sz);
@@ -286,7 +299,7 @@ __device__ __forceinline__ void walk_wave(const EntropyGeom& g, const uint32_t* 
                 : [e] "v"(e), [lim] "s"(lim)
                 : "scc");
             if ((es & 255u) != 0u) break;
-            if ((e & 255u) == 0u) e = long_entry(T, S, slot, e, win);
+            if ((e & 255u) == 0u) e = long_entry<true>(T, S, slot, e, win);      // (only bits 0-15 of an entry are used here)
         }
         if (z >= 64u) {                                              // block complete: the lanes behind looked up the old tables
             z = 0u;
@@ -298,15 +311,16 @@ __device__ __forceinline__ void walk_wave(const EntropyGeom& g, const uint32_t* 
 }
 
 template <typename F>
-__device__ __forceinline__ void with_fast_tables(const EntropyArgs& a, const FastTabs* lds_tabs, uint32_t lds_image, uint32_t image, F&& f) {
+__device__ __forceinline__ void with_fast_tables(const EntropyArgs& a, const FastTabs* gtabs, const FastTabs* lds_tabs, uint32_t lds_image,
+                                                 uint32_t image, F&& f) {
     const SearchTab* S = a.stabs + static_cast<size_t>(image) * 6u;
     if (image == lds_image || a.uniform_tables) f(reinterpret_cast<const __attribute__((address_space(3))) FastTabs*>(
                                   static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_tabs))), S);
-    else f(a.ftabs + image, S);
+    else f(gtabs + image, S);
 }
 template <uint32_t kWg>
-__device__ __forceinline__ void stage_fast_tables(const EntropyArgs& a, FastTabs* lds_tabs, uint32_t image) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.ftabs + image);
+__device__ __forceinline__ void stage_fast_tables(const FastTabs* gtabs, FastTabs* lds_tabs, uint32_t image) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(gtabs + image);
     uint32_t* dst = reinterpret_cast<uint32_t*>(lds_tabs);
     for (uint32_t i = threadIdx.x; i < sizeof(FastTabs) / 4u; i += kWg) dst[i] = src[i];
 }
@@ -389,7 +403,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
     }
     const uint32_t wg_image = a.segs[a.sub_seg[own_sub]].image;
     stage_stream_columns<kSyncLanes, kSyncCols>(a, lds_words, first_sub);
-    stage_fast_tables<kSyncLanes>(a, &lds_tabs, wg_image);
+    stage_fast_tables<kSyncLanes>(a.ptabs, &lds_tabs, wg_image);
     st[t] = make_uint2(st_ex, st_used);
     constexpr uint32_t kChase = 0x8000u;                             // the entry is the predecessor's exit (not a segment's first sub-sequence)
     endinfo[t] = static_cast<uint16_t>(on ? (min((s + 1u) * kSubBits, sg.bit_end) - s * kSubBits) | (first ? 0u : kChase) : 0u);
@@ -429,7 +443,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
                 uint32_t p = e0 & 0x1fffffu, c = (e0 >> 21) & 15u, z = e0 >> 25;
                 const uint32_t end = j * kSubBits + (endinfo[j] & (kChase - 1u));
                 const uint32_t image = a.uniform_tables ? wg_image : a.segs[a.sub_seg[first_sub + j]].image;
-                with_fast_tables(a, &lds_tabs, wg_image, image, [&](auto tabs, const SearchTab* S) { walk_wave(a.g, lds_words, tabs, S, end, p, c, z); });
+                with_fast_tables(a, a.ptabs, &lds_tabs, wg_image, image, [&](auto tabs, const SearchTab* S) { walk_wave(a.g, lds_words, tabs, S, end, p, c, z); });
                 if (lane == 0u) st[j].x = p | (c << 21) | (z << 25);
             }
         } else if (t < total) {
@@ -439,7 +453,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
             const uint32_t end = j * kSubBits + (endinfo[j] & (kChase - 1u));
             int32_t n = 0;
             const uint32_t image = a.uniform_tables ? wg_image : a.segs[a.sub_seg[first_sub + j]].image;
-            with_fast_tables(a, &lds_tabs, wg_image, image, [&](auto tabs, const SearchTab* S) { walk<false, 0u>(a.g, lds_words, tabs, S, end, p, c, z, n, nullptr); });
+            with_fast_tables(a, a.ptabs, &lds_tabs, wg_image, image, [&](auto tabs, const SearchTab* S) { walk<false, 0u, true>(a.g, lds_words, tabs, S, end, p, c, z, n, nullptr); });
             st[j].x = p | (c << 21) | (z << 25);
         }
         __syncthreads();
@@ -493,7 +507,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_count_kernel(const Entropy
     const uint32_t s = first_sub + threadIdx.x;
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
     stage_stream_columns<kSyncLanes, kSyncCols>(a, lds_words, first_sub);
-    stage_fast_tables<kSyncLanes>(a, &lds_tabs, wg_image);
+    stage_fast_tables<kSyncLanes>(a.ftabs, &lds_tabs, wg_image);
     int32_t* dcs = lds_dc + threadIdx.x;                     // this lane's three sums, kSyncLanes apart (one bank per lane)
     dcs[0] = 0; dcs[kSyncLanes] = 0; dcs[2u * kSyncLanes] = 0;
     if (threadIdx.x < (kSyncLanes / kChunkSubs) * 4u) (&lds_tail[0][0])[threadIdx.x] = 0;
@@ -514,7 +528,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_count_kernel(const Entropy
         }
         const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end) - bit0;
         int32_t n = 0;
-        with_fast_tables(a, &lds_tabs, wg_image, sg.image, [&](auto tabs, const SearchTab* S) { walk<true, kSyncLanes>(a.g, lds_words, tabs, S, end, p, c, z, n, dcs); });
+        with_fast_tables(a, a.ftabs, &lds_tabs, wg_image, sg.image, [&](auto tabs, const SearchTab* S) { walk<true, kSyncLanes, false>(a.g, lds_words, tabs, S, end, p, c, z, n, dcs); });
         mine = make_int4(n, dcs[0], dcs[kSyncLanes], dcs[2u * kSyncLanes]);
         a.cnt[s] = mine;
     }
@@ -612,7 +626,7 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
     for (uint32_t i = 0; i < 8u; ++i) row4[i] = u32x4{0u, 0u, 0u, 0u};               // a row is cleared again when it is stored
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
     stage_stream_columns<kWriteLanes, kWriteCols>(a, lds_words, first_sub);
-    stage_fast_tables<kWriteLanes>(a, &lds_tabs, wg_image);
+    stage_fast_tables<kWriteLanes>(a.ftabs, &lds_tabs, wg_image);
     __syncthreads();
     if (s >= a.n_sub) return;
     const Segment sg = a.segs[a.sub_seg[s]];
@@ -627,7 +641,7 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
     const uint32_t B = a.g.blocks_per_mcu;
     uint32_t my, mx;                                         // MCU of that block (the block-in-MCU is the decoder's c)
     { const uint32_t m = sg.first_mcu + block / B; my = m / a.g.mcus_w; mx = m - my * a.g.mcus_w; }
-    with_fast_tables(a, &lds_tabs, wg_image, sg.image, [&](auto T, const SearchTab* S) {
+    with_fast_tables(a, a.ftabs, &lds_tabs, wg_image, sg.image, [&](auto T, const SearchTab* S) {
         const auto* lut0 = &T->lut[0][0];
         uint32_t comp = (a.g.kcomp_packed >> (2u * c)) & 3u;
         const auto* tcur = lut0 + comp * (2u * kLutEntries) + (z ? kLutEntries : 0u);
@@ -937,6 +951,24 @@ void derive_fast_table(const HuffSpec& h, bool ac, FastTabs* F, uint32_t slot, u
         for (uint32_t f = 0; f < (1u << (n - rem)); ++f) F->pool[off + sub + f] = entry(lc.len, lc.sym);
     }
 }
+// The pair form of an image's tables (see pair_entry): same first-level pointers and pool layout, every entry carries its
+// own skip / advance twice unless the next AC code is visible in the rest of the lookup window.
+void derive_pair_tables(const FastTabs& F, int ncomp, FastTabs* Pt) {
+    for (uint32_t i = 0; i < kPoolEntries; ++i) Pt->pool[i] = pair_entry(F.pool[i], F.pool[i]);
+    for (uint32_t slot = 0; slot < 6u; ++slot)
+        for (uint32_t i = 0; i < kLutEntries; ++i) {
+            const uint32_t e = F.lut[slot][i];
+            uint32_t out = (e & 255u) ? pair_entry(e, e) : e;                        // skip 0: pointer into the pool / serial search
+            const uint32_t skip1 = e & 255u, adv1 = (e >> 8) & 255u;
+            if ((slot & 1u) && slot < 2u * static_cast<uint32_t>(ncomp) && skip1 != 0u && skip1 < kLutBits && adv1 < 64u) {
+                const uint32_t e2 = F.lut[slot][(i << skip1) & (kLutEntries - 1u)];   // the window behind the first symbol
+                const uint32_t len2 = (e2 >> 16) & 255u;
+                if ((e2 & 255u) != 0u && len2 <= kLutBits - skip1)                   // a whole code (never the 32 of "no such code")
+                    out = pair_entry(e, (skip1 + (e2 & 255u)) | ((adv1 + ((e2 >> 8) & 255u)) << 8));
+            }
+            Pt->lut[slot][i] = out;
+        }
+}
 // The six tables of one image; components that name the same table share its second level.
 void derive_image_tables(const ParsedJpeg& P, FastTabs* F, SearchTab* S6, uint32_t pool_limit) {
     std::memset(F, 0, sizeof *F);
@@ -1054,7 +1086,7 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     e->n_images = n_images;
     std::vector<Segment> segs;
     std::vector<uint32_t> sub_seg;
-    std::vector<FastTabs> ftabs(n_images);
+    std::vector<FastTabs> ftabs(n_images), ptabs(n_images);
     std::vector<SearchTab> stabs(static_cast<size_t>(n_images) * 6u);
     e->qt.assign(static_cast<size_t>(n_images) * 192u, 0);
 
@@ -1108,6 +1140,7 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
         if (R.rc) { R.message = last_error(); return; }
         for (int c = 0; c < P.ncomp; ++c) std::memcpy(&e->qt[(static_cast<size_t>(img) * 3u + c) * 64u], P.qt[P.tq[c]], 128);
         derive_image_tables(P, &ftabs[img], &stabs[static_cast<size_t>(img) * 6u], pool_limit);
+        derive_pair_tables(ftabs[img], P.ncomp, &ptabs[img]);
         // un-stuff the scan and cut it at restart markers
         const uint8_t* d = files[img];
         const size_t len = lengths[img];
@@ -1221,14 +1254,15 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     int rc;
     uint32_t *d_words = nullptr, *d_sub = nullptr;
     Segment* d_segs = nullptr;
-    FastTabs* d_ftabs = nullptr;
+    FastTabs *d_ftabs = nullptr, *d_ptabs = nullptr;
     SearchTab* d_stabs = nullptr;
     if ((rc = dev_alloc(e.get(), &d_words, n_words, words))) return rc;
     if ((rc = dev_alloc(e.get(), &d_segs, segs.size(), segs.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_sub, sub_seg.size(), sub_seg.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_ftabs, ftabs.size(), ftabs.data()))) return rc;
+    if ((rc = dev_alloc(e.get(), &d_ptabs, ptabs.size(), ptabs.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_stabs, stabs.size(), stabs.data()))) return rc;
-    a.words = d_words; a.segs = d_segs; a.sub_seg = d_sub; a.ftabs = d_ftabs; a.stabs = d_stabs;
+    a.words = d_words; a.segs = d_segs; a.sub_seg = d_sub; a.ftabs = d_ftabs; a.ptabs = d_ptabs; a.stabs = d_stabs;
     for (int b = 0; b < 2; ++b) {
         if ((rc = dev_alloc<uint32_t>(e.get(), &a.exit_p[b], a.n_sub))) return rc;
         if ((rc = dev_alloc<uint32_t>(e.get(), &a.exit_cz[b], a.n_sub))) return rc;
