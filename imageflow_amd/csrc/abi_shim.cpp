@@ -10,7 +10,7 @@
 //
 // Two labelled EXTENSIONS, because the reference's JSON API has no raw-pixel I/O:
 //   * decode accepts, besides baseline JPEG, the container "IFBGRA1\0" + u32le w, h, stride, alpha_meaningful + rows;
-//   * encode writes a baseline JPEG for the libjpeg_turbo preset (device pixel stage + host Huffman coder, jpeg_write.cpp)
+//   * encode writes a real JPEG for the libjpeg_turbo preset -- baseline, optimised tables, progressive (device pixel stage + host Huffman coder, jpeg_write.cpp)
 //     and that container for every other preset (preferred_extension "ifbgra", mime "application/x-imageflow-bgra"):
 //     PNG deflate / GIF / WebP coders are out of scope, the caller's encoder takes the frame.
 #include <hip/hip_runtime.h>
@@ -531,9 +531,10 @@ struct Job {
         return out;
     }
 
-    // encode: EncoderPreset::LibjpegTurbo without progressive / optimised tables is written as a real baseline JPEG
-    // (codecs/mozjpeg.rs:78-160, create_classic :62-77): apply_matte + forward DCT / quantisation on the device, the
-    // sequential Huffman coder and the markers on the host (csrc/jpeg_write.cpp).  The content-adaptive sampling choice
+    // encode: EncoderPreset::LibjpegTurbo is written as a real JPEG (codecs/mozjpeg.rs:78-160, create_classic :62-77):
+    // apply_matte + forward DCT / quantisation on the device, the Huffman coder and the markers on the host
+    // (csrc/jpeg_write.cpp) -- baseline, with optimize_huffman_coding libjpeg's optimal tables, with progressive its
+    // standard scan script (:121-129).  The content-adaptive sampling choice
     // (evalchroma, an external crate) is not reproduced: the file uses the maximum the reference allows (:133, 4:2:0).
     // EXTENSION: every other preset writes the raw BGRA container (PNG / GIF / WebP coders are out of scope).
     void encode(const FramePtr& f, int32_t io_id, const JVal* preset) {
@@ -541,8 +542,7 @@ struct Job {
         const JVal* classic = preset ? preset->get("libjpeg_turbo") : nullptr;
         if (classic) {
             auto flag = [&](const char* k) { const JVal* v = classic->get(k); return v && v->t == JVal::Bool && v->b; };
-            if (flag("progressive") || flag("optimize_huffman_coding"))
-                raise(kActionNotSupported, "ActionNotSupported: libjpeg_turbo preset with progressive or optimize_huffman_coding (this shim writes baseline files)");
+            const int write_flags = (flag("progressive") ? IFHIP_JPEG_PROGRESSIVE : 0) | (flag("optimize_huffman_coding") ? IFHIP_JPEG_OPTIMIZE_HUFFMAN : 0);
             const JVal* q = classic->get("quality");
             int quality = 75;                                                            // mozjpeg.rs:32 DEFAULT_QUALITY
             if (q && q->t == JVal::Num) quality = q->n > 100 ? 100 : (q->n < 0 ? 0 : static_cast<int>(q->n));
@@ -571,9 +571,9 @@ struct Job {
             std::vector<int16_t> coef(off[3]);
             hip_check(hipMemcpy(coef.data(), d_coef, off[3] * 2u, hipMemcpyDeviceToHost), "download(coefficients)");
             size_t len = 0;
-            check(ifhip_jpeg_write_baseline(coef.data() + off[0], coef.data() + off[1], coef.data() + off[2], bw, bh, 3, hs, vs, f->w, f->h, quality, nullptr, 0, &len));
+            check(ifhip_jpeg_write(coef.data() + off[0], coef.data() + off[1], coef.data() + off[2], bw, bh, 3, hs, vs, f->w, f->h, quality, write_flags, nullptr, 0, &len));
             o.owned.assign(len, 0);
-            check(ifhip_jpeg_write_baseline(coef.data() + off[0], coef.data() + off[1], coef.data() + off[2], bw, bh, 3, hs, vs, f->w, f->h, quality, o.owned.data(), len, &len));
+            check(ifhip_jpeg_write(coef.data() + off[0], coef.data() + off[1], coef.data() + off[2], bw, bh, 3, hs, vs, f->w, f->h, quality, write_flags, o.owned.data(), len, &len));
             o.written = true;
             encodes.push_back({io_id, f->w, f->h, "image/jpeg", "jpg"});
             return;

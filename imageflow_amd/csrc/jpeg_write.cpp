@@ -5,7 +5,8 @@
 // jchuff.c (DC difference categories, AC run/size symbols with ZRL and EOB, byte stuffing, 1-padding of the last byte).
 // The quantised coefficients come from the GPU stage (ifhip_jpeg_forward*); entropy coding is serial bit packing and
 // stays on the host.  Output is byte-identical to libjpeg-turbo's for the same pixels,
-// quality and sampling (tests/test_gpu_abi_shim.py compares with Pillow's encoder).
+// quality and sampling (tests/test_gpu_abi_shim.py compares with Pillow's encoder).  The preset's two options are here
+// too: optimised Huffman tables (jpeg_gen_optimal_table) and progressive files (jpeg_simple_progression + jcphuff.c).
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -100,11 +101,216 @@ void jpeg_quality_tables(int quality, uint16_t qt[2][64]) {
     }
 }
 
-// coef[c]: [bh_c][bw_c][64] natural order, MCU padded (the layout of the GPU stage); 1 or 3 components; chroma tables = qt[1]
-int jpeg_write_baseline(const int16_t* const coef[3], const uint32_t bw[3], const uint32_t bh[3], int ncomp, const uint8_t hs[3],
-                        const uint8_t vs[3], uint32_t width, uint32_t height, const uint16_t qt[2][64], std::vector<uint8_t>* out) {
+// ---- optimal Huffman tables and progressive scans (jchuff.c jpeg_gen_optimal_table, jcparam.c jpeg_simple_progression,
+// jcphuff.c) -- what the classic preset's optimize_huffman_coding / progressive flags ask libjpeg for -----------------------
+namespace {
+struct HuffSpecW { uint8_t bits[17]; uint8_t vals[256]; int nvals; };
+
+// jpeg_gen_optimal_table: code lengths by pairwise merging of the least frequent symbols (ties go to the larger symbol
+// value), a reserved all-ones code point (pseudo-symbol 256), lengths limited to 16 bits by the Annex K.2 adjustment
+void gen_optimal_table(const long counts[256], HuffSpecW* t) {
+    long freq[257];
+    int codesize[257], others[257];
+    uint8_t bits[33];
+    std::memset(bits, 0, sizeof bits);
+    std::memset(codesize, 0, sizeof codesize);
+    for (int i = 0; i < 257; ++i) { others[i] = -1; freq[i] = i < 256 ? counts[i] : 1; }
+    for (;;) {
+        int c1 = -1, c2 = -1;
+        long v = 1000000000L;
+        for (int i = 0; i <= 256; ++i) if (freq[i] && freq[i] <= v) { v = freq[i]; c1 = i; }
+        v = 1000000000L;
+        for (int i = 0; i <= 256; ++i) if (freq[i] && freq[i] <= v && i != c1) { v = freq[i]; c2 = i; }
+        if (c2 < 0) break;
+        freq[c1] += freq[c2];
+        freq[c2] = 0;
+        codesize[c1]++;
+        while (others[c1] >= 0) { c1 = others[c1]; codesize[c1]++; }
+        others[c1] = c2;
+        codesize[c2]++;
+        while (others[c2] >= 0) { c2 = others[c2]; codesize[c2]++; }
+    }
+    for (int i = 0; i <= 256; ++i) if (codesize[i]) bits[codesize[i] > 32 ? 32 : codesize[i]]++;
+    int i;
+    for (i = 32; i > 16; --i)
+        while (bits[i] > 0) {
+            int j = i - 2;
+            while (bits[j] == 0) --j;
+            bits[i] -= 2; bits[i - 1]++; bits[j + 1] += 2; bits[j]--;
+        }
+    while (bits[i] == 0) --i;                        // the pseudo-symbol's code point: the longest code loses one
+    bits[i]--;
+    std::memcpy(t->bits, bits, 17);
+    t->nvals = 0;
+    for (int l = 1; l <= 32; ++l)
+        for (int j = 0; j <= 255; ++j) if (codesize[j] == l) t->vals[t->nvals++] = static_cast<uint8_t>(j);
+}
+
+// One pass over a scan either counts the symbols (tables to be optimised) or writes them.
+struct Coder {
+    BitWriter* w = nullptr;                          // null: gather statistics
+    const EncTab* dc[2] = {nullptr, nullptr};
+    const EncTab* ac[2] = {nullptr, nullptr};
+    long dc_count[2][256], ac_count[2][256];
+    void reset_counts() { std::memset(dc_count, 0, sizeof dc_count); std::memset(ac_count, 0, sizeof ac_count); }
+    void sym(bool is_ac, int tbl, int s) {
+        if (!w) { (is_ac ? ac_count : dc_count)[tbl][s]++; return; }
+        const EncTab& t = *(is_ac ? ac : dc)[tbl];
+        w->put(t.code[s], t.size[s]);
+    }
+    void bits(uint32_t v, int n) { if (w && n) w->put(v, n); }
+};
+
+struct Plane { const int16_t* coef; uint32_t pitch_blocks, wb, hb, H, V; int tbl; };   // wb x hb: the component's own size in blocks
+
+struct ScanSpec { int ncomp; int comp[3]; int Ss, Se, Ah, Al; };
+
+// jchuff.c encode_one_block / htest_one_block
+void sequential_block(Coder& C, const int16_t* blk, int tbl, int* pred) {
+    int diff = blk[0] - *pred;
+    *pred = blk[0];
+    int t = diff < 0 ? -diff : diff, t2 = diff < 0 ? diff - 1 : diff;
+    int nb = nbits(t);
+    C.sym(false, tbl, nb);
+    C.bits(static_cast<uint32_t>(t2), nb);
+    int r = 0;
+    for (int k = 1; k < 64; ++k) {
+        const int v = blk[kZigzag[k]];
+        if (v == 0) { ++r; continue; }
+        while (r > 15) { C.sym(true, tbl, 0xF0); r -= 16; }
+        t = v < 0 ? -v : v; t2 = v < 0 ? v - 1 : v;
+        nb = nbits(t);
+        C.sym(true, tbl, (r << 4) + nb);
+        C.bits(static_cast<uint32_t>(t2), nb);
+        r = 0;
+    }
+    if (r > 0) C.sym(true, tbl, 0);
+}
+
+// jcphuff.c: the four block coders of a progressive scan, with the end-of-band run and the buffered correction bits
+struct Progressive {
+    Coder& C;
+    int tbl = 0, Ss = 0, Se = 0, Al = 0;
+    uint32_t eobrun = 0;
+    std::vector<uint8_t> be;                         // correction bits waiting behind the end-of-band run
+    explicit Progressive(Coder& c) : C(c) {}
+    void buffered(const uint8_t* b, size_t n) { for (size_t i = 0; i < n; ++i) C.bits(b[i], 1); }
+    void emit_eobrun() {
+        if (eobrun > 0) {
+            int nb = 0;
+            for (uint32_t t = eobrun; (t >>= 1);) ++nb;
+            C.sym(true, tbl, nb << 4);
+            if (nb) C.bits(eobrun, nb);
+            eobrun = 0;
+            buffered(be.data(), be.size());
+            be.clear();
+        }
+    }
+    void ac_first(const int16_t* blk) {
+        int r = 0;
+        for (int k = Ss; k <= Se; ++k) {
+            int t = blk[kZigzag[k]], t2;
+            if (t == 0) { ++r; continue; }
+            if (t < 0) { t = -t; t >>= Al; t2 = ~t; } else { t >>= Al; t2 = t; }
+            if (t == 0) { ++r; continue; }
+            if (eobrun > 0) emit_eobrun();
+            while (r > 15) { C.sym(true, tbl, 0xF0); r -= 16; }
+            const int nb = nbits(t);
+            C.sym(true, tbl, (r << 4) + nb);
+            C.bits(static_cast<uint32_t>(t2), nb);
+            r = 0;
+        }
+        if (r > 0) { if (++eobrun == 0x7FFF) emit_eobrun(); }
+    }
+    void ac_refine(const int16_t* blk) {
+        int absv[64], eob = 0;
+        for (int k = Ss; k <= Se; ++k) {
+            int t = blk[kZigzag[k]];
+            if (t < 0) t = -t;
+            t >>= Al;
+            absv[k] = t;
+            if (t == 1) eob = k;
+        }
+        int r = 0;
+        std::vector<uint8_t> br;                     // correction bits of this block since the last newly nonzero coefficient
+        for (int k = Ss; k <= Se; ++k) {
+            const int t = absv[k];
+            if (t == 0) { ++r; continue; }
+            while (r > 15 && k <= eob) {
+                emit_eobrun();
+                C.sym(true, tbl, 0xF0);
+                r -= 16;
+                buffered(br.data(), br.size());
+                br.clear();
+            }
+            if (t > 1) { br.push_back(static_cast<uint8_t>(t & 1)); continue; }
+            emit_eobrun();
+            C.sym(true, tbl, (r << 4) + 1);
+            C.bits(blk[kZigzag[k]] < 0 ? 0u : 1u, 1);
+            buffered(br.data(), br.size());
+            br.clear();
+            r = 0;
+        }
+        if (r > 0 || !br.empty()) {
+            ++eobrun;
+            be.insert(be.end(), br.begin(), br.end());
+            if (eobrun == 0x7FFF || be.size() > 1000 - 64 + 1) emit_eobrun();
+        }
+    }
+};
+
+// one scan, counted or written; MCU order for interleaved scans, the component's own block raster otherwise
+void run_scan(Coder& C, const ScanSpec& sc, const Plane* planes, uint32_t mcus_w, uint32_t mcus_h) {
+    Progressive P(C);
+    P.Ss = sc.Ss; P.Se = sc.Se; P.Al = sc.Al;
+    const bool sequential = sc.Ss == 0 && sc.Se == 63;
+    int pred[3] = {0, 0, 0};
+    auto block = [&](int ci, const int16_t* blk) {
+        const Plane& pl = planes[ci];
+        if (sequential) { sequential_block(C, blk, pl.tbl, &pred[ci]); return; }
+        if (sc.Ss == 0) {                            // DC scan
+            if (sc.Ah == 0) {
+                const int t2 = blk[0] >> sc.Al;      // (arithmetic shift, jcphuff.c IRIGHT_SHIFT)
+                int diff = t2 - pred[ci];
+                pred[ci] = t2;
+                int t = diff < 0 ? -diff : diff, tb = diff < 0 ? diff - 1 : diff;
+                const int nb = nbits(t);
+                C.sym(false, pl.tbl, nb);
+                C.bits(static_cast<uint32_t>(tb), nb);
+            } else {
+                C.bits(static_cast<uint32_t>(blk[0] >> sc.Al) & 1u, 1);
+            }
+            return;
+        }
+        P.tbl = pl.tbl;
+        if (sc.Ah == 0) P.ac_first(blk); else P.ac_refine(blk);
+    };
+    if (sc.ncomp > 1) {
+        for (uint32_t my = 0; my < mcus_h; ++my)
+            for (uint32_t mx = 0; mx < mcus_w; ++mx)
+                for (int i = 0; i < sc.ncomp; ++i) {
+                    const Plane& pl = planes[sc.comp[i]];
+                    for (uint32_t dy = 0; dy < pl.V; ++dy)
+                        for (uint32_t dx = 0; dx < pl.H; ++dx)
+                            block(sc.comp[i], pl.coef + (static_cast<size_t>(my * pl.V + dy) * pl.pitch_blocks + (mx * pl.H + dx)) * 64u);
+                }
+    } else {
+        const Plane& pl = planes[sc.comp[0]];
+        for (uint32_t by = 0; by < pl.hb; ++by)
+            for (uint32_t bx = 0; bx < pl.wb; ++bx) block(sc.comp[0], pl.coef + (static_cast<size_t>(by) * pl.pitch_blocks + bx) * 64u);
+    }
+    P.emit_eobrun();
+}
+}  // namespace
+
+// coef[c]: [bh_c][bw_c][64] natural order, MCU padded (the layout of the GPU stage); 1 or 3 components; chroma tables = qt[1].
+// flags: IFHIP_JPEG_OPTIMIZE_HUFFMAN (two passes: symbol statistics, then jpeg_gen_optimal_table's codes),
+// IFHIP_JPEG_PROGRESSIVE (SOF2, jpeg_simple_progression's scan script, every scan with its own optimal tables).
+int jpeg_write(const int16_t* const coef[3], const uint32_t bw[3], const uint32_t bh[3], int ncomp, const uint8_t hs[3],
+               const uint8_t vs[3], uint32_t width, uint32_t height, const uint16_t qt[2][64], int flags, std::vector<uint8_t>* out) {
     if (!out || (ncomp != 1 && ncomp != 3) || width == 0 || height == 0 || width > 65535u || height > 65535u)
-        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: jpeg_write_baseline geometry");
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: jpeg_write geometry");
+    const bool progressive = (flags & 2) != 0, optimize = progressive || (flags & 1) != 0;
     std::vector<uint8_t>& o = *out;
     o.clear();
     o.push_back(0xFF); o.push_back(0xD8);                                                        // SOI
@@ -119,11 +325,31 @@ int jpeg_write_baseline(const int16_t* const coef[3], const uint32_t bw[3], cons
         std::vector<uint8_t> b = {8, static_cast<uint8_t>(height >> 8), static_cast<uint8_t>(height), static_cast<uint8_t>(width >> 8),
                                   static_cast<uint8_t>(width), static_cast<uint8_t>(ncomp)};
         for (int c = 0; c < ncomp; ++c) { b.push_back(static_cast<uint8_t>(c + 1)); b.push_back(static_cast<uint8_t>((hs[c] << 4) | vs[c])); b.push_back(c ? 1 : 0); }
-        marker(o, 0xC0, b);                                                                       // SOF0
+        marker(o, progressive ? 0xC2 : 0xC0, b);                                                  // SOF0 / SOF2
     }
-    EncTab dc[2], ac[2];
-    build(kDcLumaBits, kDcVals, &dc[0]); build(kAcLumaBits, kAcLumaVals, &ac[0]);
-    build(kDcChromaBits, kDcVals, &dc[1]); build(kAcChromaBits, kAcChromaVals, &ac[1]);
+    const uint32_t hmax = ncomp == 3 ? std::max<uint32_t>(hs[0], std::max<uint32_t>(hs[1], hs[2])) : 1u;
+    const uint32_t vmax = ncomp == 3 ? std::max<uint32_t>(vs[0], std::max<uint32_t>(vs[1], vs[2])) : 1u;
+    const uint32_t mw = (width + 8u * hmax - 1u) / (8u * hmax), mh = (height + 8u * vmax - 1u) / (8u * vmax);
+    Plane planes[3];
+    for (int c = 0; c < ncomp; ++c) {
+        const uint32_t H = ncomp == 3 ? hs[c] : 1u, V = ncomp == 3 ? vs[c] : 1u;
+        // jcmaster.c: a component's own size in blocks (non-interleaved scans cover exactly these)
+        const uint32_t wb = (width * H + hmax * 8u - 1u) / (hmax * 8u), hb = (height * V + vmax * 8u - 1u) / (vmax * 8u);
+        planes[c] = Plane{coef[c], bw[c], wb, hb, H, V, c ? 1 : 0};
+        if (bw[c] < mw * H || bh[c] < mh * V) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: coefficient plane %d smaller than the MCU grid", c);
+    }
+    std::vector<ScanSpec> script;
+    if (!progressive) {
+        ScanSpec s{ncomp, {0, 1, 2}, 0, 63, 0, 0};
+        script.push_back(s);
+    } else if (ncomp == 3) {                                                                      // jpeg_simple_progression, YCbCr
+        script = {{3, {0, 1, 2}, 0, 0, 0, 1}, {1, {0, 0, 0}, 1, 5, 0, 2}, {1, {2, 0, 0}, 1, 63, 0, 1}, {1, {1, 0, 0}, 1, 63, 0, 1},
+                  {1, {0, 0, 0}, 6, 63, 0, 2}, {1, {0, 0, 0}, 1, 63, 2, 1}, {3, {0, 1, 2}, 0, 0, 1, 0}, {1, {2, 0, 0}, 1, 63, 1, 0},
+                  {1, {1, 0, 0}, 1, 63, 1, 0}, {1, {0, 0, 0}, 1, 63, 1, 0}};
+    } else {
+        script = {{1, {0, 0, 0}, 0, 0, 0, 1}, {1, {0, 0, 0}, 1, 5, 0, 2}, {1, {0, 0, 0}, 6, 63, 0, 2}, {1, {0, 0, 0}, 1, 63, 2, 1},
+                  {1, {0, 0, 0}, 0, 0, 1, 0}, {1, {0, 0, 0}, 1, 63, 1, 0}};
+    }
     auto dht = [&](int cls, int id, const uint8_t* bits, const uint8_t* vals, int nvals) {
         std::vector<uint8_t> b;
         b.push_back(static_cast<uint8_t>((cls << 4) | id));
@@ -131,54 +357,67 @@ int jpeg_write_baseline(const int16_t* const coef[3], const uint32_t bw[3], cons
         b.insert(b.end(), vals, vals + nvals);
         marker(o, 0xC4, b);
     };
-    dht(0, 0, kDcLumaBits, kDcVals, 12); dht(1, 0, kAcLumaBits, kAcLumaVals, 162);
-    if (ncomp == 3) { dht(0, 1, kDcChromaBits, kDcVals, 12); dht(1, 1, kAcChromaBits, kAcChromaVals, 162); }
-    {
-        std::vector<uint8_t> b = {static_cast<uint8_t>(ncomp)};
-        for (int c = 0; c < ncomp; ++c) { b.push_back(static_cast<uint8_t>(c + 1)); b.push_back(c ? 0x11 : 0x00); }
-        b.push_back(0); b.push_back(63); b.push_back(0);
-        marker(o, 0xDA, b);                                                                       // SOS
-    }
-    // scan: MCUs in raster order, blocks of a component in raster order inside the MCU (a single component is not interleaved)
-    const uint32_t hmax = ncomp == 3 ? std::max<uint32_t>(hs[0], std::max<uint32_t>(hs[1], hs[2])) : 1u;
-    const uint32_t vmax = ncomp == 3 ? std::max<uint32_t>(vs[0], std::max<uint32_t>(vs[1], vs[2])) : 1u;
-    const uint32_t mw = ncomp == 3 ? (width + 8u * hmax - 1u) / (8u * hmax) : (width + 7u) / 8u;
-    const uint32_t mh = ncomp == 3 ? (height + 8u * vmax - 1u) / (8u * vmax) : (height + 7u) / 8u;
-    BitWriter bwr{o};
-    int pred[3] = {0, 0, 0};
-    for (uint32_t my = 0; my < mh; ++my)
-        for (uint32_t mx = 0; mx < mw; ++mx)
-            for (int c = 0; c < ncomp; ++c) {
-                const uint32_t H = ncomp == 3 ? hs[c] : 1u, V = ncomp == 3 ? vs[c] : 1u;
-                const EncTab &D = dc[c ? 1 : 0], &A = ac[c ? 1 : 0];
-                for (uint32_t dy = 0; dy < V; ++dy)
-                    for (uint32_t dx = 0; dx < H; ++dx) {
-                        const int16_t* blk = coef[c] + (static_cast<size_t>(my * V + dy) * bw[c] + (mx * H + dx)) * 64u;
-                        int diff = blk[0] - pred[c];                                              // jchuff.c encode_one_block
-                        pred[c] = blk[0];
-                        int t = diff < 0 ? -diff : diff, t2 = diff < 0 ? diff - 1 : diff;
-                        int nb = nbits(t);
-                        bwr.put(D.code[nb], D.size[nb]);
-                        if (nb) bwr.put(static_cast<uint32_t>(t2), nb);
-                        int r = 0;
-                        for (int k = 1; k < 64; ++k) {
-                            const int v = blk[kZigzag[k]];
-                            if (v == 0) { ++r; continue; }
-                            while (r > 15) { bwr.put(A.code[0xF0], A.size[0xF0]); r -= 16; }
-                            t = v < 0 ? -v : v; t2 = v < 0 ? v - 1 : v;
-                            nb = nbits(t);
-                            const int sym = (r << 4) + nb;
-                            bwr.put(A.code[sym], A.size[sym]);
-                            bwr.put(static_cast<uint32_t>(t2), nb);
-                            r = 0;
-                        }
-                        if (r > 0) bwr.put(A.code[0], A.size[0]);                                 // EOB
-                    }
+    for (const ScanSpec& sc : script) {
+        const bool dc_scan = sc.Ss == 0, ac_scan = sc.Se > 0;
+        const bool needs_dc = dc_scan && sc.Ah == 0, needs_ac = ac_scan;                          // (a DC refinement scan is raw bits)
+        EncTab dct[2], act[2];
+        Coder C;
+        C.dc[0] = &dct[0]; C.dc[1] = &dct[1]; C.ac[0] = &act[0]; C.ac[1] = &act[1];
+        bool used[2] = {false, false};
+        for (int i = 0; i < sc.ncomp; ++i) used[planes[sc.comp[i]].tbl] = true;
+        HuffSpecW od[2], oa[2];
+        if (optimize) {
+            C.reset_counts();
+            run_scan(C, sc, planes, mw, mh);                                                      // statistics pass
+            for (int t = 0; t < 2; ++t) {
+                if (!used[t]) continue;
+                if (needs_dc) { gen_optimal_table(C.dc_count[t], &od[t]); build(od[t].bits, od[t].vals, &dct[t]); }
+                if (needs_ac) { gen_optimal_table(C.ac_count[t], &oa[t]); build(oa[t].bits, oa[t].vals, &act[t]); }
             }
-    bwr.flush();
+        } else {
+            build(kDcLumaBits, kDcVals, &dct[0]); build(kAcLumaBits, kAcLumaVals, &act[0]);
+            build(kDcChromaBits, kDcVals, &dct[1]); build(kAcChromaBits, kAcChromaVals, &act[1]);
+        }
+        // jcmarker.c write_scan_header: the tables of the scan's components in component order, DC then AC, each once
+        bool sent_dc[2] = {false, false}, sent_ac[2] = {false, false};
+        for (int i = 0; i < sc.ncomp; ++i) {
+            const int t = planes[sc.comp[i]].tbl;
+            if (needs_dc && !sent_dc[t]) {
+                sent_dc[t] = true;
+                if (optimize) dht(0, t, od[t].bits, od[t].vals, od[t].nvals);
+                else dht(0, t, t ? kDcChromaBits : kDcLumaBits, kDcVals, 12);
+            }
+            if (needs_ac && !sent_ac[t]) {
+                sent_ac[t] = true;
+                if (optimize) dht(1, t, oa[t].bits, oa[t].vals, oa[t].nvals);
+                else dht(1, t, t ? kAcChromaBits : kAcLumaBits, t ? kAcChromaVals : kAcLumaVals, 162);
+            }
+        }
+        {
+            std::vector<uint8_t> b = {static_cast<uint8_t>(sc.ncomp)};
+            for (int i = 0; i < sc.ncomp; ++i) {
+                const int c = sc.comp[i], t = planes[c].tbl;
+                b.push_back(static_cast<uint8_t>(c + 1));
+                // jcmarker.c emit_sos: a progressive scan names only the table it uses (DC scans: no AC table; AC scans: no DC table)
+                const int td = progressive ? (dc_scan && sc.Ah == 0 ? t : 0) : t, ta = progressive ? (ac_scan ? t : 0) : t;
+                b.push_back(static_cast<uint8_t>((td << 4) | ta));
+            }
+            b.push_back(static_cast<uint8_t>(sc.Ss)); b.push_back(static_cast<uint8_t>(sc.Se));
+            b.push_back(static_cast<uint8_t>((sc.Ah << 4) | sc.Al));
+            marker(o, 0xDA, b);                                                                   // SOS
+        }
+        BitWriter bwr{o};
+        C.w = &bwr;
+        run_scan(C, sc, planes, mw, mh);
+        bwr.flush();
+    }
     o.push_back(0xFF); o.push_back(0xD9);                                                        // EOI
-    (void)bh;
     return IFHIP_OK;
+}
+
+int jpeg_write_baseline(const int16_t* const coef[3], const uint32_t bw[3], const uint32_t bh[3], int ncomp, const uint8_t hs[3],
+                        const uint8_t vs[3], uint32_t width, uint32_t height, const uint16_t qt[2][64], std::vector<uint8_t>* out) {
+    return jpeg_write(coef, bw, bh, ncomp, hs, vs, width, height, qt, 0, out);
 }
 
 }  // namespace ifhip
@@ -192,9 +431,9 @@ int ifhip_jpeg_quality_tables(int quality, uint16_t* qt2x64) {
 // Entropy-codes quantised coefficient planes (the output of ifhip_jpeg_forward*) into a baseline JFIF file with the
 // Annex K tables: the host half of MozjpegEncoder::write_frame's classic preset.  Two-call pattern: out == NULL or
 // capacity too small -> *len receives the size needed and IFHIP_INVALID_ARGUMENT is returned for the short case.
-int ifhip_jpeg_write_baseline(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2, const uint32_t* blocks_w3,
-                              const uint32_t* blocks_h3, int n_components, const uint8_t* h_samp, const uint8_t* v_samp, uint32_t width,
-                              uint32_t height, int quality, uint8_t* out, size_t capacity, size_t* len) {
+int ifhip_jpeg_write(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2, const uint32_t* blocks_w3,
+                     const uint32_t* blocks_h3, int n_components, const uint8_t* h_samp, const uint8_t* v_samp, uint32_t width,
+                     uint32_t height, int quality, int flags, uint8_t* out, size_t capacity, size_t* len) {
     if (!coef0 || !blocks_w3 || !blocks_h3 || !len || (n_components == 3 && (!coef1 || !coef2 || !h_samp || !v_samp)))
         return ifhip::fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
     uint16_t qt[2][64];
@@ -203,8 +442,9 @@ int ifhip_jpeg_write_baseline(const int16_t* coef0, const int16_t* coef1, const 
     const uint8_t one[3] = {1, 1, 1};
     std::vector<uint8_t> bytes;
     try {
-        const int rc = ifhip::jpeg_write_baseline(coef, blocks_w3, blocks_h3, n_components, n_components == 3 ? h_samp : one,
-                                                  n_components == 3 ? v_samp : one, width, height, qt, &bytes);
+        if (flags & ~3) return ifhip::fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: unknown flags 0x%x", flags);
+        const int rc = ifhip::jpeg_write(coef, blocks_w3, blocks_h3, n_components, n_components == 3 ? h_samp : one,
+                                         n_components == 3 ? v_samp : one, width, height, qt, flags, &bytes);
         if (rc) return rc;
     } catch (const std::bad_alloc&) { return ifhip::fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: host memory"); }
     *len = bytes.size();
@@ -212,5 +452,10 @@ int ifhip_jpeg_write_baseline(const int16_t* coef0, const int16_t* coef1, const 
     if (capacity < bytes.size()) return ifhip::fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: output capacity %zu < %zu", capacity, bytes.size());
     std::memcpy(out, bytes.data(), bytes.size());
     return IFHIP_OK;
+}
+int ifhip_jpeg_write_baseline(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2, const uint32_t* blocks_w3,
+                              const uint32_t* blocks_h3, int n_components, const uint8_t* h_samp, const uint8_t* v_samp, uint32_t width,
+                              uint32_t height, int quality, uint8_t* out, size_t capacity, size_t* len) {
+    return ifhip_jpeg_write(coef0, coef1, coef2, blocks_w3, blocks_h3, n_components, h_samp, v_samp, width, height, quality, 0, out, capacity, len);
 }
 }

@@ -232,6 +232,18 @@ IFHIP_API int ifhip_jpeg_write_baseline(const int16_t* coef0, const int16_t* coe
                                         const uint32_t* blocks_w3, const uint32_t* blocks_h3, int n_components,
                                         const uint8_t* h_samp, const uint8_t* v_samp, uint32_t width, uint32_t height,
                                         int quality, uint8_t* out, size_t capacity, size_t* len);
+/* The same writer with the classic preset's two options (codecs/mozjpeg.rs:121-129: set_progressive_mode,
+ * set_optimize_coding over set_fastest_defaults).  IFHIP_JPEG_OPTIMIZE_HUFFMAN: two passes per scan -- symbol statistics,
+ * then jchuff.c jpeg_gen_optimal_table's codes in the DHT segments.  IFHIP_JPEG_PROGRESSIVE: SOF2 and jcparam.c
+ * jpeg_simple_progression's scan script (10 scans for YCbCr, 6 for gray; spectral selection + successive approximation,
+ * jcphuff.c's end-of-band runs and correction bits), every scan with its own optimal tables as libjpeg does.
+ * Byte-identical to libjpeg-turbo (Pillow optimize=True / progressive=True) for the same coefficients. */
+#define IFHIP_JPEG_OPTIMIZE_HUFFMAN 1
+#define IFHIP_JPEG_PROGRESSIVE 2
+IFHIP_API int ifhip_jpeg_write(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2,
+                               const uint32_t* blocks_w3, const uint32_t* blocks_h3, int n_components,
+                               const uint8_t* h_samp, const uint8_t* v_samp, uint32_t width, uint32_t height,
+                               int quality, int flags, uint8_t* out, size_t capacity, size_t* len);
 
 /* imageflow's 8x8 -> NxN spatial block scalers for the luma plane of a scaled decode: replaces
  * flow_scale_spatial[_srgb]_{1..7}x{1..7} (c_components/lib/codecs_jpeg_idct_fast.c, .h:17-43), the functions the IDCT

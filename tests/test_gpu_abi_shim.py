@@ -211,10 +211,28 @@ def test_libjpeg_turbo_preset_flattens_alpha_onto_the_matte_first():
         assert got == buf.getvalue()
 
 
-def test_libjpeg_turbo_preset_rejects_what_the_baseline_writer_cannot_do():
+@pytest.mark.parametrize("extra,pillow", [({"progressive": True}, {"progressive": True}),
+                                          ({"optimize_huffman_coding": True}, {"optimize": True}),
+                                          ({"progressive": True, "optimize_huffman_coding": True}, {"progressive": True, "optimize": True})])
+def test_libjpeg_turbo_preset_progressive_and_optimised_tables(extra, pillow):
+    """mozjpeg.rs:121-129 set_progressive_mode / set_optimize_coding over set_fastest_defaults: the files equal
+    libjpeg-turbo's (Pillow) byte for byte -- optimal Huffman tables, the standard scan script, end-of-band runs."""
+    PIL = pytest.importorskip("PIL.Image")
+    from PIL import ImageFile
+    ImageFile.MAXBLOCK = 1 << 24
+    w, h = 203, 131
+    rng = np.random.default_rng(7)
+    y, x = np.mgrid[0:h, 0:w]
+    rgb = np.stack([x * 255 // (w - 1), y * 255 // (h - 1), (x + y) * 3 % 256], -1).astype(np.int32)
+    rgb = np.clip(rgb + rng.integers(-30, 30, rgb.shape), 0, 255).astype(np.uint8)
+    bgra = np.zeros((h, U.stride_for(w)), np.uint8)
+    bgra[:, :4 * w] = np.concatenate([rgb[:, :, ::-1], np.full((h, w, 1), 255, np.uint8)], -1).reshape(h, 4 * w)
     with Context() as c:
-        c.add_input_buffer(0, pack_raw_bgra(np.zeros((8, 64), np.uint8), 8, 8, alpha_meaningful=False))
+        c.add_input_buffer(0, pack_raw_bgra(bgra, w, h, alpha_meaningful=False))
         c.add_output_buffer(1)
-        for extra in ({"progressive": True}, {"optimize_huffman_coding": True}):
-            status, r = c.send_json("v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"encode": {"io_id": 1, "preset": {"libjpeg_turbo": extra}}}]}})
-            assert status == 400 and "ActionNotSupported" in r["message"], (status, r)
+        _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}},
+                                                        {"encode": {"io_id": 1, "preset": {"libjpeg_turbo": dict(quality=88, **extra)}}}]}})
+        got = bytes(c.get_output_buffer(1))
+    buf = io.BytesIO()
+    PIL.fromarray(rgb).save(buf, "JPEG", quality=88, subsampling="4:2:0", **pillow)
+    assert got == buf.getvalue()

@@ -7,7 +7,9 @@ import io
 
 import numpy as np
 import pytest
-from PIL import Image
+from PIL import Image, ImageFile
+
+ImageFile.MAXBLOCK = 1 << 24          # Pillow's encoder buffer: optimised / progressive files of tiny images need more than the default
 
 from imageflow_amd import _native
 from oracle import oracle as O
@@ -20,6 +22,21 @@ def _photo(w, h, seed):
     y, x = np.mgrid[0:h, 0:w]
     base = np.stack([(x * 255 // max(w - 1, 1)), (y * 255 // max(h - 1, 1)), ((x + y) * 3 % 256)], -1).astype(np.int32)
     return np.clip(base + rng.integers(-40, 40, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+def _write_flags(j, quality, flags):
+    L = _native.lib()
+    L.ifhip_jpeg_write.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    bw, bh = np.array(j["bw"], np.uint32), np.array(j["bh"], np.uint32)
+    hs, vs = np.array(j["hs"], np.uint8), np.array(j["vs"], np.uint8)
+    n = C.c_size_t(0)
+    planes = [j["coef"][c].ctypes.data if c < j["ncomp"] else None for c in range(3)]
+    args = planes + [bw.ctypes.data, bh.ctypes.data, j["ncomp"], hs.ctypes.data, vs.ctypes.data, j["width"], j["height"], quality, flags]
+    assert L.ifhip_jpeg_write(*args, None, 0, C.byref(n)) == 0
+    out = np.zeros(n.value, np.uint8)
+    assert L.ifhip_jpeg_write(*args, out.ctypes.data, n.value, C.byref(n)) == 0
+    return out.tobytes()
 
 
 def _write(j, quality):
@@ -71,3 +88,53 @@ def test_quality_tables_match_libjpeg(quality):
     Image.fromarray(_photo(16, 16, 0)).save(buf, "JPEG", quality=quality, subsampling="4:2:0", optimize=False)
     j = O.jpeg_read_coefficients(buf.getvalue())
     assert np.array_equal(j["qt"][0], qt[0]) and np.array_equal(j["qt"][1], qt[1]) and np.array_equal(j["qt"][2], qt[1])
+
+
+OPTIONS = [(1, dict(optimize=True)), (2, dict(progressive=True)), (3, dict(progressive=True, optimize=True))]
+
+
+@pytest.mark.parametrize("sampling", ["4:2:0", "4:2:2", "4:4:4"])
+@pytest.mark.parametrize("size", [(1, 1), (17, 9), (64, 48), (203, 131), (333, 77)])
+@pytest.mark.parametrize("quality", [5, 75, 100])
+def test_optimised_and_progressive_files_are_byte_identical(sampling, size, quality):
+    """The classic preset's two options (codecs/mozjpeg.rs:121-129): jpeg_gen_optimal_table's codes, jpeg_simple_progression's
+    ten scans with jcphuff.c's end-of-band runs and correction bits.  The coefficients come from the baseline file of the
+    same pixels (same quality -> same quantised coefficients); the bytes must equal libjpeg-turbo's for every option."""
+    w, h = size
+    img = Image.fromarray(_photo(w, h, w * 31 + h + quality))
+    buf = io.BytesIO()
+    img.save(buf, "JPEG", quality=quality, subsampling=sampling, optimize=False)
+    j = O.jpeg_read_coefficients(buf.getvalue())
+    for flags, kw in OPTIONS:
+        ref = io.BytesIO()
+        img.save(ref, "JPEG", quality=quality, subsampling=sampling, **kw)
+        assert _write_flags(j, quality, flags) == ref.getvalue(), (flags, kw)
+    assert _write_flags(j, quality, 0) == buf.getvalue()
+
+
+@pytest.mark.parametrize("size", [(1, 1), (50, 37), (129, 64)])
+def test_grayscale_optimised_and_progressive(size):
+    w, h = size
+    img = Image.fromarray(_photo(w, h, 3)[:, :, 0])
+    buf = io.BytesIO()
+    img.save(buf, "JPEG", quality=80, optimize=False)
+    j = O.jpeg_read_coefficients(buf.getvalue())
+    assert j["ncomp"] == 1
+    for flags, kw in OPTIONS:
+        ref = io.BytesIO()
+        img.save(ref, "JPEG", quality=80, **kw)
+        assert _write_flags(j, 80, flags) == ref.getvalue(), (flags, kw)
+
+
+def test_unknown_writer_flags_are_refused():
+    buf = io.BytesIO()
+    Image.fromarray(_photo(16, 16, 1)).save(buf, "JPEG", quality=75, subsampling="4:2:0", optimize=False)
+    j = O.jpeg_read_coefficients(buf.getvalue())
+    L = _native.lib()
+    n = C.c_size_t(0)
+    bw, bh = np.array(j["bw"], np.uint32), np.array(j["bh"], np.uint32)
+    hs, vs = np.array(j["hs"], np.uint8), np.array(j["vs"], np.uint8)
+    L.ifhip_jpeg_write.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    assert L.ifhip_jpeg_write(j["coef"][0].ctypes.data, j["coef"][1].ctypes.data, j["coef"][2].ctypes.data, bw.ctypes.data, bh.ctypes.data,
+                              3, hs.ctypes.data, vs.ctypes.data, 16, 16, 75, 4, None, 0, C.byref(n)) != 0
