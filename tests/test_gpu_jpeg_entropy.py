@@ -136,3 +136,31 @@ def test_rarely_taken_paths(golden_dir, monkeypatch, hook):
     assert checked == 62
     if "IFHIP_ENT_TEST_INNER" in hook:
         assert most_rounds > 4, most_rounds              # the host did iterate
+
+
+def test_corrupted_scans_never_crash(golden_dir):
+    """Untrusted bytes on the device: random bytes written into the entropy-coded data (and Huffman tables swapped for
+    another file's) decode to SOMETHING or are refused -- no fault, no hang -- and the next clean decode is exact."""
+    z = np.load(os.path.join(golden_dir, "jpeg_entropy_cases.npz"))
+    names = [str(n) for n in z["names"]]
+    rng = np.random.default_rng(9)
+    picks = [i for i, n in enumerate(names) if "64x" in n or "640x" in n or "203x" in n][:6] or list(range(6))
+    outcomes = {"ok": 0, "refused": 0}
+    for i in picks:
+        data = z[f"jpg_{i}"].tobytes()
+        sos = data.find(b"\xff\xda")
+        for _ in range(12):
+            m = bytearray(data)
+            for _ in range(int(rng.integers(1, 12))):
+                m[int(rng.integers(sos + 14, len(m) - 2))] = int(rng.integers(0, 256))
+            try:
+                D.JpegEntropyBatch([bytes(m)], DEV).read_coefficients()
+                outcomes["ok"] += 1
+            except FlowError:
+                outcomes["refused"] += 1
+        ent = D.JpegEntropyBatch([data], DEV)
+        coef = ent.read_coefficients()
+        j = O.jpeg_read_coefficients(data)
+        for c in range(j["ncomp"]):
+            assert np.array_equal(coef[c][0].cpu().numpy(), j["coef"][c]), names[i]
+    assert outcomes["ok"] + outcomes["refused"] == 12 * len(picks) and outcomes["refused"] > 0, outcomes

@@ -98,3 +98,30 @@ def test_oversized_mcu_is_rejected_by_the_parser(golden_dir):
         with pytest.raises(FlowError) as e:
             D.get_image_info(_patch_sampling(data, factors))
         assert "MethodNotImplemented" in str(e.value) or "ImageMalformed" in str(e.value), str(e.value)
+
+
+def test_parser_survives_mutated_headers(golden_dir):
+    """Untrusted bytes: every single-byte mutation of the marker segments (and truncations) of a few files either parses or
+    is refused with a FlowError -- never a crash, never geometry the decoder's tables cannot hold."""
+    z = np.load(os.path.join(golden_dir, "jpeg_entropy_cases.npz"))
+    rng = np.random.default_rng(5)
+    tried = refused = 0
+    for i in (0, 7, 20, 33):
+        data = bytearray(z[f"jpg_{i}"].tobytes())
+        sos = bytes(data).find(b"\xff\xda")
+        assert sos > 0
+        for _ in range(150):
+            m = bytearray(data)
+            for _ in range(int(rng.integers(1, 4))):
+                m[int(rng.integers(2, sos + 14))] = int(rng.integers(0, 256))
+            if rng.integers(0, 5) == 0:
+                m = m[: int(rng.integers(4, len(m)))]
+            tried += 1
+            try:
+                info = D.get_image_info(bytes(m))
+            except FlowError:
+                refused += 1
+                continue
+            assert 1 <= info["ncomp"] <= 3 and 0 < info["width"] <= 65535 and 0 < info["height"] <= 65535
+            assert sum(h * v for h, v in zip(info["hs"][:info["ncomp"]], info["vs"][:info["ncomp"]])) <= 10
+    assert tried == 600 and 0 < refused < tried
