@@ -268,7 +268,7 @@ constexpr int kBlockPitch = 72;     // dwords per 8x8 workspace in LDS (64 + 8: 
 constexpr int kBigPitch = 104;      // jpeg_idct_kernel: up to 12 workspace rows of 8 (the 10x10 / 12x12 IDCTs) + 8
 
 __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
-    __shared__ int32_t ws[kBlocksPerWg * kBigPitch];
+    __shared__ __attribute__((aligned(16))) int32_t ws[kBlocksPerWg * kBigPitch];
     // grid: x = groups of 32 blocks of component a.comp, y = image
     const uint32_t t = threadIdx.x, lane8 = t & 7u, lb = t >> 3;
     const uint32_t c = a.comp + blockIdx.z, img = blockIdx.y;          // blockIdx.z: the two chroma components in one launch
@@ -396,39 +396,66 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
         }
     }
     if (spatial) {
-        // the scalers' two tables (12-bit sRGB <-> linear) go to LDS: 64 + n*n lookups per block
+        // flow_scale_spatial[_srgb]_NxN on the block's 8x8 bytes (codecs_jpeg_idct_fast.c): rows are combined with the
+        // integer weights of output row r, then columns with those of output column cc, rounded by the two divisors'
+        // shift; the _srgb forms do it in 12-bit linear light (two lookup tables).  All eight lanes of the block work:
+        //   lane = source COLUMN j: its 8 bytes -> linear (8 lookups, not 8 per output row), V[r][j] for r < n with the
+        //   weights on the scalar path;  then lane = output (r, cc), ceil(n*n / 8) each: 8 multiply-adds over V[r][.];
+        //   then lane = output row r: one store of n bytes.
+        // |weight| <= 117, linear <= 4095, sums of weights <= 512: every product fits 24 x 24 -> 32 bits.
+        // The 8 lanes of a block sit in one wave, whose LDS operations execute in program order: no barrier between
+        // the phases, only the compiler has to keep the order (it cannot prove the accesses distinct).
         __shared__ uint16_t s2l_lds[256];
         __shared__ uint8_t l2s_lds[4096];
-        if (a.g.luma_mode == 2u) {
+        __shared__ __attribute__((aligned(16))) int32_t wts_lds[64];     // [cc][j] weights, [56 + r] log2 divisors
+        const bool srgb = a.g.luma_mode == 2u;
+        if (srgb) {
             s2l_lds[t] = a.sc.s2l[t];
             reinterpret_cast<uint4*>(l2s_lds)[t] = reinterpret_cast<const uint4*>(a.sc.l2s)[t];
         }
+        if (t < 56u) wts_lds[t] = a.sc.w[t >> 3][t & 7u];
+        else if (t < 63u) wts_lds[t] = static_cast<int32_t>(a.sc.log2_div[t - 56u]);
         __syncthreads();
-        // flow_scale_spatial[_srgb]_NxN on the block's 8x8 bytes: lane r < n produces output row r
-        if (on && lane8 < n) {
-            const uint8_t* blk = bytes;                      // row i of the block: bytes [32*i, 32*i + 8)
-            const bool srgb = a.g.luma_mode == 2u;
-            int32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (on) {
+            int32_t lin[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int32_t wr = a.sc.w[lane8][i];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t byte = blk[i * 32 + j];
-                    v[j] += wr * (srgb ? static_cast<int32_t>(s2l_lds[byte]) : static_cast<int32_t>(byte));
-                }
+                const uint32_t byte = bytes[i * 32 + lane8];
+                lin[i] = srgb ? static_cast<int32_t>(s2l_lds[byte]) : static_cast<int32_t>(byte);
             }
-            uint8_t* orow = plane + static_cast<size_t>(by * n + lane8) * a.g.pw[c] + bx * n;
-            for (uint32_t cc = 0; cc < n; ++cc) {
-                const uint32_t sh = a.sc.log2_div[lane8] + a.sc.log2_div[cc];
-                int32_t sum = static_cast<int32_t>(1u << (sh - 1u));
+            asm volatile("" ::: "memory");                   // the byte reads stay in front of the stores below
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sum += v[j] * a.sc.w[cc][j];
-                uint32_t o;
-                if (sum < 0) o = 0;
-                else if (static_cast<uint32_t>(sum) >= (4096u << sh)) o = 255;
-                else o = srgb ? l2s_lds[sum >> sh] : static_cast<uint32_t>(sum >> sh);
-                orow[cc] = static_cast<uint8_t>(o);
+            for (uint32_t r = 0; r < 7u; ++r)
+                if (r < n) {
+                    int32_t acc = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc += __mul24(a.sc.w[r][i], lin[i]);
+                    w[r * 8u + lane8] = acc;                 // V[r][j]
+                }
+            asm volatile("" ::: "memory");
+            uint8_t* otile = reinterpret_cast<uint8_t*>(w + 64);          // n x n output bytes (the workspace has 104 dwords)
+            const uint32_t inv_n = (65536u + n - 1u) / n;                 // o / n for o < 49: (o * ceil(2^16 / n)) >> 16
+            for (uint32_t o = lane8; o < n * n; o += 8u) {
+                const uint32_t r = (o * inv_n) >> 16, cc = o - r * n;
+                const int4 v0 = *reinterpret_cast<const int4*>(w + r * 8u), v1 = *reinterpret_cast<const int4*>(w + r * 8u + 4u);
+                const int4 g0 = *reinterpret_cast<const int4*>(wts_lds + cc * 8u), g1 = *reinterpret_cast<const int4*>(wts_lds + cc * 8u + 4u);
+                const uint32_t sh = static_cast<uint32_t>(wts_lds[56u + r] + wts_lds[56u + cc]);
+                int32_t sum = static_cast<int32_t>(1u << (sh - 1u));
+                sum = (__mul24(v0.x, g0.x) + sum); sum = (__mul24(v0.y, g0.y) + sum); sum = (__mul24(v0.z, g0.z) + sum); sum = (__mul24(v0.w, g0.w) + sum);
+                sum = (__mul24(v1.x, g1.x) + sum); sum = (__mul24(v1.y, g1.y) + sum); sum = (__mul24(v1.z, g1.z) + sum); sum = (__mul24(v1.w, g1.w) + sum);
+                uint32_t ob;
+                if (sum < 0) ob = 0;
+                else if (static_cast<uint32_t>(sum) >= (4096u << sh)) ob = 255;
+                else ob = srgb ? l2s_lds[sum >> sh] : static_cast<uint32_t>(sum >> sh);
+                otile[o] = static_cast<uint8_t>(ob);
+            }
+            asm volatile("" ::: "memory");
+            if (lane8 < n) {
+                uint8_t* orow = plane + static_cast<size_t>(by * n + lane8) * a.g.pw[c] + bx * n;
+                const uint8_t* src = otile + lane8 * n;
+                if (n == 4u) *reinterpret_cast<uint32_t*>(orow) = *reinterpret_cast<const uint32_t*>(src);        // (plane pitch and bx * 4: 4-byte aligned)
+                else if (n == 2u) *reinterpret_cast<uint16_t*>(orow) = *reinterpret_cast<const uint16_t*>(src);
+                else for (uint32_t cc = 0; cc < n; ++cc) orow[cc] = src[cc];
             }
         }
     }
