@@ -2,7 +2,7 @@
 # kernel statistics of the JPEG pixel stage bench (8/8, 4/8 spatial sRGB, 1/8) -- per-kernel averages
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-OUT=gpurun_out/r2m
+OUT=gpurun_out/jpeg_kernels
 rm -rf $OUT; mkdir -p $OUT
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python tools/bench_jpeg.py 32 > $OUT/bench_jpeg.json 2> $OUT/err.txt
 t=$(find $OUT/t -name '*kernel_trace.csv' | head -1)
