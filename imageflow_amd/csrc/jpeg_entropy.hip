@@ -10,11 +10,14 @@
 // Device: the self-synchronising parallel decode (Klein & Wiseman; Weissenberger & Schmidt, ICPP 2018):
 //   * the stream is cut into sub-sequences of 1024 bits, one lane each;
 //   * round 0 decodes every sub-sequence speculatively from state (block 0 of the MCU, coefficient 0); because Huffman
-//     codes re-synchronise, most lanes end in the true state;
-//   * round r > 0 restarts each lane from its predecessor's exit state; lanes whose start did not change skip; the
-//     rounds stop when no exit state changes (first lanes of a segment are exact, so the fixpoint is the true decode);
-//   * a per-segment scan of (blocks started, DC sums per component) gives every lane its output block and DC predictors;
-//   * the write pass decodes once more and stores coefficients (natural order) straight into the planes.
+//     codes re-synchronise, most lanes end in the true state; then, inside the workgroup, every lane whose predecessor's
+//     exit state moved decodes again from it, until nothing moves (first lanes of a segment are exact, so the fixpoint is
+//     the serial decode); workgroups warm up on the sub-sequences in front of their range, so nothing crosses them;
+//   * the count pass walks every sub-sequence from its final entry state: blocks started and DC sums per component (and
+//     it checks the fixpoint: only if a sub-sequence was decoded from another state than its predecessor's exit does the
+//     host run further rounds);
+//   * the write pass scans those counts (every lane's output block and DC predictors), decodes once more and stores
+//     coefficients (natural order) straight into the planes.
 // Integer / table work, bound by dependent bit-serial decoding per lane and L1/L2 latency, not by HBM (no MFMA).
 // Coefficient-exact against oracle/jpeg_oracle.c jo_jpeg_read_coefficients (itself pinned to libjpeg-turbo).
 #include <hip/hip_runtime.h>
