@@ -108,3 +108,50 @@ def jpeg_forward_host(bgra, width, height, stride, h_samp, v_samp, qt):
     _native.check(L.ifhip_jpeg_forward(src.ctypes.data, width, height, stride, hs.ctypes.data, vs.ctypes.data, q.ctypes.data,
                                        coef[0].ctypes.data, coef[1].ctypes.data, coef[2].ctypes.data))
     return coef
+
+
+JPEG_OPTIMIZE_HUFFMAN, JPEG_PROGRESSIVE = 1, 2          # include/imageflow_hip.h IFHIP_JPEG_*
+
+
+def write_jpeg(coef, width, height, h_samp, v_samp, quality, progressive=False, optimize_coding=False):
+    """The entropy-coding half (host code of the library, csrc/jpeg_write.cpp): quantised coefficient planes
+    [bh_c][bw_c][64] (numpy int16, 1 or 3 of them) -> the bytes libjpeg-turbo would write for them."""
+    L = _native.lib()
+    L.ifhip_jpeg_write.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    planes = [np.ascontiguousarray(c, np.int16) for c in coef]
+    n = len(planes)
+    bw, bh = np.array([p.shape[1] for p in planes] + [0] * (3 - n), np.uint32), np.array([p.shape[0] for p in planes] + [0] * (3 - n), np.uint32)
+    hs, vs = np.array(list(h_samp) + [1] * (3 - n), np.uint8), np.array(list(v_samp) + [1] * (3 - n), np.uint8)
+    flags = (JPEG_PROGRESSIVE if progressive else 0) | (JPEG_OPTIMIZE_HUFFMAN if optimize_coding else 0)
+    ptrs = [p.ctypes.data for p in planes] + [None] * (3 - n)
+    size = C.c_size_t(0)
+    args = ptrs + [bw.ctypes.data, bh.ctypes.data, n, hs.ctypes.data, vs.ctypes.data, width, height, int(quality), flags]
+    _native.check(L.ifhip_jpeg_write(*args, None, 0, C.byref(size)))
+    out = np.zeros(size.value, np.uint8)
+    _native.check(L.ifhip_jpeg_write(*args, out.ctypes.data, size.value, C.byref(size)))
+    return out.tobytes()
+
+
+class MozjpegEncoder:
+    """MozjpegEncoder::create_classic + write_frame (mozjpeg.rs:60-77, :78-160) over the device stages: apply_matte
+    (default white, :88-92), the forward pixel stage at 4:2:0 (the maximum evalchroma may choose, :133) and the file
+    writer with the preset's progressive / optimize_coding options.  Returns the file's bytes."""
+
+    def __init__(self, quality=None, progressive=None, optimize_coding=None, matte=0xFFFFFFFF):
+        self.quality = min(100, DEFAULT_QUALITY if quality is None else int(quality))
+        self.progressive, self.optimize_coding, self.matte = bool(progressive), bool(optimize_coding), matte
+
+    @classmethod
+    def create_classic(cls, quality=None, progressive=None, optimize_coding=None, matte=None):
+        return cls(quality, progressive, optimize_coding, 0xFFFFFFFF if matte is None else matte)
+
+    def write_frame(self, bitmap: Bitmap, frame=0):
+        from ..graphics.blend import apply_matte
+        apply_matte(bitmap, self.matte)
+        bitmap.alpha_meaningful = False                                       # :94
+        hs, vs = sampling_factors((2, 2), (2, 2))
+        stage = JpegForwardStage(bitmap.w, bitmap.h, hs, vs, bitmap.n, bitmap.data.device)
+        qt = torch.from_numpy(np.stack([quant_tables_for_quality(self.quality)] * bitmap.n).view(np.int16)).to(bitmap.data.device)
+        coef = [c[frame].cpu().numpy() for c in stage.write_frames(bitmap, qt)]
+        return write_jpeg(coef, bitmap.w, bitmap.h, hs, vs, self.quality, self.progressive, self.optimize_coding)

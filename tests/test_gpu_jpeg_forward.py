@@ -102,3 +102,26 @@ def test_error_behaviour():
     qt = torch.zeros((2, 3, 64), dtype=torch.int16, device="cuda:0")
     with pytest.raises(FlowError):
         st.write_frames(bm, qt)                                       # more frames than the stage was created for
+
+
+@pytest.mark.parametrize("options,pillow", [({}, {"optimize": False}), ({"progressive": True}, {"progressive": True}),
+                                            ({"optimize_coding": True}, {"optimize": True})])
+def test_mozjpeg_encoder_mirror_writes_libjpeg_turbo_files(options, pillow):
+    """MozjpegEncoder::create_classic + write_frame (mozjpeg.rs:60-160) through the Python mirror: flatten on white, forward
+    stage at 4:2:0, the host writer with the preset's options -- the file Pillow writes from the flattened pixels."""
+    import io
+    PIL = pytest.importorskip("PIL.Image")
+    from PIL import ImageFile
+    from tests import util as U
+    ImageFile.MAXBLOCK = 1 << 24
+    w, h = 157, 93
+    fr = U.random_frames(1, w, h, seed0=21, alpha=True)
+    flat = fr[0].copy()
+    O.apply_matte(flat, w, h, fr.shape[2], 0xFFFFFFFF, True)
+    rgb = np.ascontiguousarray(flat[:, :4 * w].reshape(h, w, 4)[:, :, 2::-1])
+    bmp = Bitmap.from_numpy(fr, w, h, fr.shape[2], DEV, alpha_meaningful=True)
+    got = M.MozjpegEncoder.create_classic(quality=77, **options).write_frame(bmp)
+    ref = io.BytesIO()
+    PIL.fromarray(rgb).save(ref, "JPEG", quality=77, subsampling="4:2:0", **pillow)
+    assert got == ref.getvalue()
+    assert not bmp.alpha_meaningful

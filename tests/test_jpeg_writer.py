@@ -138,3 +138,15 @@ def test_unknown_writer_flags_are_refused():
                                    C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     assert L.ifhip_jpeg_write(j["coef"][0].ctypes.data, j["coef"][1].ctypes.data, j["coef"][2].ctypes.data, bw.ctypes.data, bh.ctypes.data,
                               3, hs.ctypes.data, vs.ctypes.data, 16, 16, 75, 4, None, 0, C.byref(n)) != 0
+
+
+def test_python_mirror_write_jpeg():
+    from imageflow_amd.codecs.mozjpeg import write_jpeg
+    img = Image.fromarray(_photo(90, 61, 4))
+    buf = io.BytesIO()
+    img.save(buf, "JPEG", quality=82, subsampling="4:2:0", optimize=False)
+    j = O.jpeg_read_coefficients(buf.getvalue())
+    for kw, pil in (({}, dict(optimize=False)), ({"optimize_coding": True}, dict(optimize=True)), ({"progressive": True}, dict(progressive=True))):
+        ref = io.BytesIO()
+        img.save(ref, "JPEG", quality=82, subsampling="4:2:0", **pil)
+        assert write_jpeg(j["coef"], 90, 61, j["hs"], j["vs"], 82, **kw) == ref.getvalue(), kw
