@@ -119,7 +119,7 @@ def test_mozjpeg_encoder_mirror_writes_libjpeg_turbo_files(options, pillow):
     flat = fr[0].copy()
     O.apply_matte(flat, w, h, fr.shape[2], 0xFFFFFFFF, True)
     rgb = np.ascontiguousarray(flat[:, :4 * w].reshape(h, w, 4)[:, :, 2::-1])
-    bmp = Bitmap.from_numpy(fr, w, h, fr.shape[2], DEV, alpha_meaningful=True)
+    bmp = Bitmap.from_numpy(fr, w, h, fr.shape[2], "cuda:0", alpha_meaningful=True)
     got = M.MozjpegEncoder.create_classic(quality=77, **options).write_frame(bmp)
     ref = io.BytesIO()
     PIL.fromarray(rgb).save(ref, "JPEG", quality=77, subsampling="4:2:0", **pillow)
