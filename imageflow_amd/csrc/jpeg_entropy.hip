@@ -564,7 +564,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_count_kernel(const Entropy
 // they store together: the store path runs every third or fourth symbol step and a lane idles ~2 steps per block.
 constexpr uint32_t kWriteLanes = kChunkSubs;
 constexpr uint32_t kWriteCols = kWriteLanes + kMarginSubs;
-constexpr uint32_t kBlkPitch = 36;                   // dwords per lane row (32 + 4)
+constexpr uint32_t kBlkPitch = 36;                   // dwords per lane row (32 + 4: int16 slots 64..71 are padding)
 #ifndef IFHIP_ENT_FLUSH
 #define IFHIP_ENT_FLUSH 16
 #endif
@@ -677,8 +677,8 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
         uint32_t k = c;                                      // block-in-MCU of the block being decoded
         // The DC predictors are touched when a block is stored, not per symbol; a coefficient goes into the row one symbol late: its natural-order index is an LDS lookup, and the wave would
         // sit out that round trip; this way it overlaps the next symbol's table read.
-        bool pend = false;
-        uint32_t pend_nat = 0u;
+        constexpr uint32_t kNoStore = 64u;                   // a slot in the row's padding: "nothing to store" without a branch
+        uint32_t pend_nat = kNoStore;
         int32_t pend_val = 0;
 #ifdef IFHIP_ENT_TRACE
         const unsigned long long tw_0 = wall_clock64();
@@ -692,7 +692,7 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
                 const bool is_dc = z == 0u;
                 bits = rd.peek();
                 uint32_t e = tcur[bits >> (32u - kLutBits)];
-                if (pend) row[pend_nat] = static_cast<int16_t>(pend_val);
+                row[pend_nat] = static_cast<int16_t>(pend_val);
                 if ((e & 255u) == 0u) e = long_entry(T, S, static_cast<uint32_t>(tcur - lut0) / kLutEntries, e, bits);
                 p += e & 255u;
                 rd.skip(lds_words, e & 255u);
@@ -703,8 +703,8 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
                 const uint32_t pos = z + ((e >> 8) & 255u) - 1u;                // zigzag index of an AC coefficient (DC: 0)
                 const bool over = sz != 0u && pos > 63u;                         // a coefficient behind the block's end
                 err |= ((e >> 21) & 1u) | (over ? 4u : 0u);                      // (length field 32: no such code)
-                pend_nat = lds_zz[pos & 63u];
-                pend = is_dc || (sz != 0u && !over);                             // a DC entry holds the DIFFERENCE until the block is stored
+                const uint32_t nat = lds_zz[pos & 63u];
+                pend_nat = (is_dc || (sz != 0u && !over)) ? nat : kNoStore;      // a DC entry holds the DIFFERENCE until the block is stored
                 waiting = advance(e);
             }
             const uint32_t n_wait = static_cast<uint32_t>(__popcll(__ballot(waiting)));
@@ -715,7 +715,8 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
             ++tw_fl;
 #endif
             if (waiting) {
-                if (pend) { row[pend_nat] = static_cast<int16_t>(pend_val); pend = false; }
+                row[pend_nat] = static_cast<int16_t>(pend_val);
+                pend_nat = kNoStore;
                 // every LDS read of the store (the row, where the block goes) is requested before the first is used
                 const BlockPlace pl = lds_place[k];
                 int16_t* plane = lds_plane[k];
