@@ -81,6 +81,25 @@ def main():
         scale_and_render(out, small, info)
     torch.cuda.synchronize()
     t_px = (time.perf_counter() - t0) / reps
+    # the same target the way the reference's querystring path reaches it (ir4/mod.rs:155-197, mozjpeg_decoder.rs:588-618):
+    # min_precise_scaling_ratio 2.1 -> the decoder is asked for >= 1680 px -> 4/8 IDCT with the spatial sRGB luma scaler
+    stage4 = D.JpegPixelStage(w, h, 3, ent.h_samp, ent.v_samp, n, scale_num=4, luma_spatial=True, luma_srgb=True)
+    out4 = stage4.read_frames(coef, qt)
+    scale_and_render(out4, small, info)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        stage4.read_frames(coef, qt, out4)
+        scale_and_render(out4, small, info)
+    torch.cuda.synchronize()
+    t_px4 = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ent.read_coefficients(coef)
+        stage4.read_frames(coef, qt, out4)
+        scale_and_render(out4, small, info)
+    torch.cuda.synchronize()
+    t_cfg4_ref = (time.perf_counter() - t0) / reps
     t0 = time.perf_counter()
     Image.open(io.BytesIO(files[0])).convert("RGB").load()
     t_cpu = time.perf_counter() - t0
@@ -100,12 +119,15 @@ def main():
         "entropy_compressed_GBps": round(size / 1e9 / t_dec, 2),
         "file_to_bgra_ms": round(t_all * 1e3, 3), "file_to_bgra_MPps": round(mp / t_all, 1),
         "cfg4_file_to_800px_ms": round(t_cfg4 * 1e3, 3), "cfg4_MPps": round(mp / t_cfg4, 1),
+        "cfg4_file_to_800px_via_4_8_idct_ms": round(t_cfg4_ref * 1e3, 3), "cfg4_via_4_8_idct_MPps": round(mp / t_cfg4_ref, 1),
         "libjpeg_turbo_one_core_MPps": round(w * h / 1e6 / t_cpu, 1),
         "roofline": {
             "entropy_stage": roof(size + coef_bytes, t_dec, "compressed scan in + coefficient planes out; wall clock over all launches "
                                   "of one decode; the stage is bound by dependent bit-serial decoding, not by HBM"),
             "cfg4_pixel_stage_and_resize": roof(n * 26323584, t_px, "SURVEY 8d fused minimum per frame (coefficients + quant tables in, "
                                                 "800x450 BGRA out); the full-size BGRA intermediate is still materialised"),
+            "cfg4_pixel_stage_4_8_idct_and_resize": roof(n * 26323584, t_px4, "the same fused minimum, decoded at 4/8 with the spatial sRGB "
+                                                         "luma scaler (what the reference's querystring path asks its decoder for), 1920x1080 intermediate"),
             "file_to_800px_chain": roof(size + n * 800 * 450 * 4, t_cfg4, "compressed files in, 800x450 BGRA out")}}, indent=1))
 
 
