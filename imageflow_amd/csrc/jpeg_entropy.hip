@@ -348,7 +348,7 @@ constexpr uint32_t kFastStageDwords = kSyncCols * kColPitch;
 #endif
 constexpr uint32_t kInnerRounds = IFHIP_ENT_INNER;
 #ifndef IFHIP_ENT_WAVEWALK
-#define IFHIP_ENT_WAVEWALK 48
+#define IFHIP_ENT_WAVEWALK 16
 #endif
 constexpr uint32_t kWaveWalkMax = IFHIP_ENT_WAVEWALK;                          // at most this many pending sub-sequences: one wave per walk
 // The first kWarmLanes lanes of a workgroup decode the sub-sequences IN FRONT of its own range in round 0 and discard the
