@@ -115,6 +115,7 @@ struct EntropyArgs {
     const uint32_t* sub_seg;                         // segment of every sub-sequence
     const FastTabs* ftabs;                           // [image]
     const FastTabs* ptabs;                           // [image] the same tables with pair entries, for the synchronisation rounds
+    const FastTabs* ctabs;                           // [image] pair entries in the AC tables only, for the count pass (it reads the DC symbols)
     const SearchTab* stabs;                          // [image][comp][dc, ac]: the serial search, for sub-tables that did not fit
     uint32_t n_sub, n_seg;
     uint32_t uniform_tables;                         // every image carries the same Huffman tables (e.g. the standard ones)
@@ -192,7 +193,8 @@ struct Reader {
 };
 
 // Entry of a symbol whose code is longer than the first-level lookup (e = that lookup's entry, skip field 0).
-template <bool kPairs = false, typename Tabs>
+// kPairs: 0 plain entries, 1 pair entries everywhere (ptabs), 2 pair entries in the AC tables only (ctabs)
+template <int kPairs = 0, typename Tabs>
 __device__ __forceinline__ uint32_t long_entry(const Tabs* T, const SearchTab* S, uint32_t slot, uint32_t e, uint32_t bits) {
     if (e != 0u) return T->pool[(e >> 16) + ((bits << kLutBits) >> ((e >> 8) & 255u))];
     // jdhuff.c's slow path "l = min{l : code_l <= maxcode[l]}" without its dependent chain: all candidate lengths are
@@ -209,7 +211,7 @@ __device__ __forceinline__ uint32_t long_entry(const Tabs* T, const SearchTab* S
         const uint32_t sym = t->val[(code + t->valoff[l]) & 255];
         if (ac || sym <= 11u) r = fast_entry(ac, l, sym);
     }
-    return kPairs ? pair_entry(r, r) : r;
+    return (kPairs == 1 || (kPairs == 2 && ac)) ? pair_entry(r, r) : r;
 }
 
 // ---- synchronisation and count passes: the lean walker ----------------------------------------------------------
@@ -219,7 +221,7 @@ __device__ __forceinline__ uint32_t long_entry(const Tabs* T, const SearchTab* S
 // the reader's refill and the end-of-block bookkeeping as selects -- no divergent branch but the long-code lookup.
 // kCount: also count the blocks started and sum the DC differences per component (into the lane's LDS slots dcs[comp *
 // kDcPitch]: a dynamic index into three registers costs eight selects).
-template <bool kCount, uint32_t kDcPitch, bool kPairs, typename Tabs>
+template <bool kCount, uint32_t kDcPitch, int kPairs, typename Tabs>
 __device__ __forceinline__ void walk(const EntropyGeom& g, const uint32_t* lds_words, const Tabs* T, const SearchTab* S, uint32_t end,
                                      uint32_t& p, uint32_t& c, uint32_t& z, int32_t& n, int32_t* dcs) {
     const auto* lut0 = &T->lut[0][0];
@@ -231,7 +233,7 @@ __device__ __forceinline__ void walk(const EntropyGeom& g, const uint32_t* lds_w
         const uint32_t bits = rd.peek();
         uint32_t e = tcur[bits >> (32u - kLutBits)];
         if ((e & 255u) == 0u) e = long_entry<kPairs>(T, S, static_cast<uint32_t>(tcur - lut0) / kLutEntries, e, bits);
-        if constexpr (kPairs) {                                      // this symbol and the next, if this one ends neither block nor walk
+        if constexpr (kPairs == 1) {                                 // this symbol and the next, if this one ends neither block nor walk
             const bool both = z + ((e >> 8) & 255u) < 64u && p + (e & 255u) < end;
             e = both ? e >> 16 : e;
         }
@@ -241,6 +243,10 @@ __device__ __forceinline__ void walk(const EntropyGeom& g, const uint32_t* lds_w
             const int32_t ext = static_cast<int32_t>(v) - ((static_cast<int32_t>(bits << len) < 0 || sz == 0u) ? 0 : static_cast<int32_t>((1u << sz) - 1u));
             ++n;
             __hip_atomic_fetch_add(dcs + comp * kDcPitch, ext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // ds_add, nothing returns
+        }
+        if constexpr (kPairs == 2) {                                 // (the DC entries of these tables are plain: the count pass reads them)
+            const bool both = z != 0u && z + ((e >> 8) & 255u) < 64u && p + (e & 255u) < end;
+            e = both ? e >> 16 : e;
         }
         const uint32_t skip = e & 255u;
         p += skip;
@@ -302,7 +308,7 @@ __device__ __forceinline__ void walk_wave(const EntropyGeom& g, const uint32_t* 
                 : [e] "v"(e), [lim] "s"(lim)
                 : "scc");
             if ((es & 255u) != 0u) break;
-            if ((e & 255u) == 0u) e = long_entry<true>(T, S, slot, e, win);      // (only bits 0-15 of an entry are used here)
+            if ((e & 255u) == 0u) e = long_entry<1>(T, S, slot, e, win);         // (only bits 0-15 of an entry are used here)
         }
         if (z >= 64u) {                                              // block complete: the lanes behind looked up the old tables
             z = 0u;
@@ -456,7 +462,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
             const uint32_t end = j * kSubBits + (endinfo[j] & (kChase - 1u));
             int32_t n = 0;
             const uint32_t image = a.uniform_tables ? wg_image : a.segs[a.sub_seg[first_sub + j]].image;
-            with_fast_tables(a, a.ptabs, &lds_tabs, wg_image, image, [&](auto tabs, const SearchTab* S) { walk<false, 0u, true>(a.g, lds_words, tabs, S, end, p, c, z, n, nullptr); });
+            with_fast_tables(a, a.ptabs, &lds_tabs, wg_image, image, [&](auto tabs, const SearchTab* S) { walk<false, 0u, 1>(a.g, lds_words, tabs, S, end, p, c, z, n, nullptr); });
             st[j].x = p | (c << 21) | (z << 25);
         }
         __syncthreads();
@@ -510,7 +516,12 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_count_kernel(const Entropy
     const uint32_t s = first_sub + threadIdx.x;
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
     stage_stream_columns<kSyncLanes, kSyncCols>(a, lds_words, first_sub);
-    stage_fast_tables<kSyncLanes>(a.ftabs, &lds_tabs, wg_image);
+#ifndef IFHIP_ENT_COUNT_PAIRS
+#define IFHIP_ENT_COUNT_PAIRS 1
+#endif
+    constexpr int kCountPairs = IFHIP_ENT_COUNT_PAIRS ? 2 : 0;
+    const FastTabs* gtabs = kCountPairs ? a.ctabs : a.ftabs;
+    stage_fast_tables<kSyncLanes>(gtabs, &lds_tabs, wg_image);
     int32_t* dcs = lds_dc + threadIdx.x;                     // this lane's three sums, kSyncLanes apart (one bank per lane)
     dcs[0] = 0; dcs[kSyncLanes] = 0; dcs[2u * kSyncLanes] = 0;
     if (threadIdx.x < (kSyncLanes / kChunkSubs) * 4u) (&lds_tail[0][0])[threadIdx.x] = 0;
@@ -531,7 +542,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_count_kernel(const Entropy
         }
         const uint32_t end = min((s + 1u) * kSubBits, sg.bit_end) - bit0;
         int32_t n = 0;
-        with_fast_tables(a, a.ftabs, &lds_tabs, wg_image, sg.image, [&](auto tabs, const SearchTab* S) { walk<true, kSyncLanes, false>(a.g, lds_words, tabs, S, end, p, c, z, n, dcs); });
+        with_fast_tables(a, gtabs, &lds_tabs, wg_image, sg.image, [&](auto tabs, const SearchTab* S) { walk<true, kSyncLanes, kCountPairs>(a.g, lds_words, tabs, S, end, p, c, z, n, dcs); });
         mine = make_int4(n, dcs[0], dcs[kSyncLanes], dcs[2u * kSyncLanes]);
         a.cnt[s] = mine;
     }
@@ -973,6 +984,19 @@ void derive_pair_tables(const FastTabs& F, int ncomp, FastTabs* Pt) {
             Pt->lut[slot][i] = out;
         }
 }
+// The count pass's form: pair entries in the AC tables, the DC tables (and their parts of the pool) as they are.
+void derive_count_tables(const FastTabs& F, const FastTabs& Pt, FastTabs* Ct) {
+    *Ct = Pt;
+    for (uint32_t slot = 0; slot < 6u; slot += 2u)
+        for (uint32_t i = 0; i < kLutEntries; ++i) {
+            const uint32_t e = F.lut[slot][i];
+            Ct->lut[slot][i] = e;
+            if ((e & 255u) == 0u && e != 0u) {
+                const uint32_t off = e >> 16, size = 1u << (32u - ((e >> 8) & 255u));
+                for (uint32_t k = 0; k < size && off + k < kPoolEntries; ++k) Ct->pool[off + k] = F.pool[off + k];
+            }
+        }
+}
 // The six tables of one image; components that name the same table share its second level.
 void derive_image_tables(const ParsedJpeg& P, FastTabs* F, SearchTab* S6, uint32_t pool_limit) {
     std::memset(F, 0, sizeof *F);
@@ -1090,7 +1114,7 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     e->n_images = n_images;
     std::vector<Segment> segs;
     std::vector<uint32_t> sub_seg;
-    std::vector<FastTabs> ftabs(n_images), ptabs(n_images);
+    std::vector<FastTabs> ftabs(n_images), ptabs(n_images), ctabs(n_images);
     std::vector<SearchTab> stabs(static_cast<size_t>(n_images) * 6u);
     e->qt.assign(static_cast<size_t>(n_images) * 192u, 0);
 
@@ -1145,6 +1169,7 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
         for (int c = 0; c < P.ncomp; ++c) std::memcpy(&e->qt[(static_cast<size_t>(img) * 3u + c) * 64u], P.qt[P.tq[c]], 128);
         derive_image_tables(P, &ftabs[img], &stabs[static_cast<size_t>(img) * 6u], pool_limit);
         derive_pair_tables(ftabs[img], P.ncomp, &ptabs[img]);
+        derive_count_tables(ftabs[img], ptabs[img], &ctabs[img]);
         // un-stuff the scan and cut it at restart markers
         const uint8_t* d = files[img];
         const size_t len = lengths[img];
@@ -1258,15 +1283,16 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     int rc;
     uint32_t *d_words = nullptr, *d_sub = nullptr;
     Segment* d_segs = nullptr;
-    FastTabs *d_ftabs = nullptr, *d_ptabs = nullptr;
+    FastTabs *d_ftabs = nullptr, *d_ptabs = nullptr, *d_ctabs = nullptr;
     SearchTab* d_stabs = nullptr;
     if ((rc = dev_alloc(e.get(), &d_words, n_words, words))) return rc;
     if ((rc = dev_alloc(e.get(), &d_segs, segs.size(), segs.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_sub, sub_seg.size(), sub_seg.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_ftabs, ftabs.size(), ftabs.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_ptabs, ptabs.size(), ptabs.data()))) return rc;
+    if ((rc = dev_alloc(e.get(), &d_ctabs, ctabs.size(), ctabs.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_stabs, stabs.size(), stabs.data()))) return rc;
-    a.words = d_words; a.segs = d_segs; a.sub_seg = d_sub; a.ftabs = d_ftabs; a.ptabs = d_ptabs; a.stabs = d_stabs;
+    a.words = d_words; a.segs = d_segs; a.sub_seg = d_sub; a.ftabs = d_ftabs; a.ptabs = d_ptabs; a.ctabs = d_ctabs; a.stabs = d_stabs;
     for (int b = 0; b < 2; ++b) {
         if ((rc = dev_alloc<uint32_t>(e.get(), &a.exit_p[b], a.n_sub))) return rc;
         if ((rc = dev_alloc<uint32_t>(e.get(), &a.exit_cz[b], a.n_sub))) return rc;
