@@ -998,7 +998,7 @@ void derive_count_tables(const FastTabs& F, const FastTabs& Pt, FastTabs* Ct) {
         }
 }
 // The six tables of one image; components that name the same table share its second level.
-void derive_image_tables(const ParsedJpeg& P, FastTabs* F, SearchTab* S6, uint32_t pool_limit) {
+void derive_image_tables(const ParsedJpeg& P, FastTabs* F, SearchTab* S6, uint32_t pool_limit, uint32_t* pool_used_out = nullptr) {
     std::memset(F, 0, sizeof *F);
     std::memset(S6, 0, 6u * sizeof *S6);
     uint32_t pool_used = 0;
@@ -1012,6 +1012,42 @@ void derive_image_tables(const ParsedJpeg& P, FastTabs* F, SearchTab* S6, uint32
             if (same >= 0) std::memcpy(F->lut[slot], F->lut[2u * static_cast<uint32_t>(same) + ac], sizeof F->lut[slot]);
             else derive_fast_table(ac ? P.ac[id] : P.dc[id], ac != 0u, F, slot, &pool_used, pool_limit);
         }
+    if (pool_used_out) *pool_used_out = pool_used;
+}
+
+// Un-stuffs the scan (runs between 0xFF bytes are copied whole) and cuts it at restart markers into segments.
+// Returns the number of MCUs the segments cover (fewer than the image has: the scan ended early).
+uint32_t unstuff_scan(const uint8_t* d, size_t len, const ParsedJpeg& P, std::vector<std::vector<uint8_t>>* seg_bytes,
+                      std::vector<uint32_t>* seg_mcu0, std::vector<uint32_t>* seg_mcus) {
+    const uint32_t total_mcus = P.mcus_w * P.mcus_h;
+    const uint32_t per_seg = P.restart_interval ? P.restart_interval : total_mcus;
+    uint32_t mcu0 = 0;
+    size_t i = P.scan_begin;
+    bool more = true;
+    while (more && mcu0 < total_mcus) {
+        seg_bytes->emplace_back();
+        std::vector<uint8_t>& bytes = seg_bytes->back();
+        more = false;
+        while (i < len) {
+            const uint8_t* ff = static_cast<const uint8_t*>(std::memchr(d + i, 0xFF, len - i));
+            const size_t run_end = ff ? static_cast<size_t>(ff - d) : len;
+            bytes.insert(bytes.end(), d + i, d + run_end);
+            i = run_end;
+            if (i >= len) break;
+            ++i;                                                           // the 0xFF
+            while (i < len && d[i] == 0xFF) ++i;                           // fill bytes before a marker
+            if (i >= len) break;
+            const uint8_t m = d[i++];
+            if (m == 0x00) { bytes.push_back(0xFF); continue; }
+            if (m >= 0xD0 && m <= 0xD7) { more = true; break; }            // restart: next segment
+            break;                                                         // EOI or any other marker: scan ends
+        }
+        const uint32_t mcus = std::min(per_seg, total_mcus - mcu0);
+        seg_mcu0->push_back(mcu0);
+        seg_mcus->push_back(mcus);
+        mcu0 += mcus;
+    }
+    return mcu0;
 }
 
 }  // namespace
@@ -1170,37 +1206,8 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
         derive_image_tables(P, &ftabs[img], &stabs[static_cast<size_t>(img) * 6u], pool_limit);
         derive_pair_tables(ftabs[img], P.ncomp, &ptabs[img]);
         derive_count_tables(ftabs[img], ptabs[img], &ctabs[img]);
-        // un-stuff the scan and cut it at restart markers
-        const uint8_t* d = files[img];
-        const size_t len = lengths[img];
         const uint32_t total_mcus = P.mcus_w * P.mcus_h;
-        const uint32_t per_seg = P.restart_interval ? P.restart_interval : total_mcus;
-        uint32_t mcu0 = 0;
-        size_t i = P.scan_begin;
-        bool more = true;
-        while (more && mcu0 < total_mcus) {
-            R.seg_bytes.emplace_back();
-            std::vector<uint8_t>& bytes = R.seg_bytes.back();
-            more = false;
-            while (i < len) {                                                   // runs between 0xFF bytes are copied whole
-                const uint8_t* ff = static_cast<const uint8_t*>(std::memchr(d + i, 0xFF, len - i));
-                const size_t run_end = ff ? static_cast<size_t>(ff - d) : len;
-                bytes.insert(bytes.end(), d + i, d + run_end);
-                i = run_end;
-                if (i >= len) break;
-                ++i;                                                           // the 0xFF
-                while (i < len && d[i] == 0xFF) ++i;                           // fill bytes before a marker
-                if (i >= len) break;
-                const uint8_t m = d[i++];
-                if (m == 0x00) { bytes.push_back(0xFF); continue; }
-                if (m >= 0xD0 && m <= 0xD7) { more = true; break; }            // restart: next segment
-                break;                                                         // EOI or any other marker: scan ends
-            }
-            const uint32_t mcus = std::min(per_seg, total_mcus - mcu0);
-            R.seg_mcu0.push_back(mcu0);
-            R.seg_mcus.push_back(mcus);
-            mcu0 += mcus;
-        }
+        const uint32_t mcu0 = unstuff_scan(files[img], lengths[img], P, &R.seg_bytes, &R.seg_mcu0, &R.seg_mcus);
         if (mcu0 < total_mcus) {
             R.rc = IFHIP_INVALID_ARGUMENT;
             char buf[160];
@@ -1322,6 +1329,135 @@ int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* fi
         return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: host memory while preparing the batch");
     } catch (const std::exception& ex) {
         if (out) *out = nullptr;
+        return fail(IFHIP_INVALID_STATE, "InvalidState: %s", ex.what());
+    }
+}
+
+// ---- diagnostic (host only, no GPU): the tables and the scan layout of one file, checked against each other ------------
+// Everything the kernels rely on that can be checked without them: the two-level tables decode the scan to exactly the
+// blocks the geometry asks for (and to the DC values returned in dc_last: the caller compares them with a serial decoder's),
+// and a walk with the pair tables / the count tables passes through the same state at every sub-sequence boundary as the
+// plain walk -- the property that lets the synchronisation rounds, the count pass and the write pass hand states to
+// each other.  Host mirrors of long_entry / walk (same entry formats, same rules); nothing here produces coefficients.
+namespace {
+struct HostStream {
+    const std::vector<uint8_t>& b;
+    uint32_t peek(uint64_t p) const {                                // 32 bits behind bit position p, zero behind the end
+        uint64_t v = 0;
+        const size_t at = static_cast<size_t>(p >> 3);
+        for (size_t i = 0; i < 5; ++i) v = (v << 8) | (at + i < b.size() ? b[at + i] : 0u);
+        return static_cast<uint32_t>((v << (p & 7u)) >> 8);
+    }
+};
+uint32_t host_long_entry(const FastTabs& T, const SearchTab* S6, uint32_t slot, uint32_t e, uint32_t bits, int pairs) {
+    if (e != 0u) return T.pool[(e >> 16) + ((bits << kLutBits) >> ((e >> 8) & 255u))];
+    const SearchTab& t = S6[slot];
+    const bool ac = (slot & 1u) != 0u;
+    uint32_t l = kLutBits + 1u;
+    for (uint32_t k = kLutBits + 1u; k <= 16u; ++k) l += static_cast<int32_t>(bits >> (32u - k)) > t.maxcode[k] ? 1u : 0u;
+    uint32_t r = invalid_entry(ac);
+    if (l <= 16u) {
+        const uint32_t sym = t.val[(static_cast<int32_t>(bits >> (32u - l)) + t.valoff[l]) & 255];
+        if (ac || sym <= 11u) r = fast_entry(ac, l, sym);
+    }
+    return (pairs == 1 || (pairs == 2 && ac)) ? pair_entry(r, r) : r;
+}
+struct HostState { uint64_t p; uint32_t c, z; };
+struct HostCounts { uint64_t reads = 0, blocks = 0; int32_t dc[3] = {0, 0, 0}; bool bad = false; };
+// mirror of walk(): from state s to the first symbol boundary at or behind `end` (or until `max_blocks` blocks started)
+HostState host_walk(const EntropyGeom& g, const HostStream& in, const FastTabs& T, const SearchTab* S6, int pairs, HostState s, uint64_t end,
+                    uint64_t max_blocks, HostCounts* n) {
+    while (s.p < end) {
+        const uint32_t comp = (g.kcomp_packed >> (2u * s.c)) & 3u, slot = comp * 2u + (s.z ? 1u : 0u);
+        if (s.z == 0u && n->blocks >= max_blocks) break;             // pad bits behind the last block
+        const uint32_t bits = in.peek(s.p);
+        uint32_t e = T.lut[slot][bits >> (32u - kLutBits)];
+        if ((e & 255u) == 0u) e = host_long_entry(T, S6, slot, e, bits, pairs);
+        ++n->reads;
+        if (s.z == 0u) {
+            ++n->blocks;
+            if (pairs != 1) {                                        // DC entries are plain in the plain and the count tables
+                const uint32_t len = (e >> 16) & 255u, sz = (e >> 24) & 15u;
+                if (len > 16u) n->bad = true;
+                else if (sz) {
+                    const uint32_t v = (bits << len) >> (32u - sz);
+                    n->dc[comp] += static_cast<int32_t>(v) - ((v >> (sz - 1u)) ? 0 : static_cast<int32_t>((1u << sz) - 1u));
+                }
+            }
+        }
+        bool both = false;
+        if (pairs == 1 || (pairs == 2 && s.z != 0u)) both = s.z + ((e >> 8) & 255u) < 64u && s.p + (e & 255u) < end;
+        if (pairs == 0 && ((e >> 21) & 1u)) n->bad = true;
+        if (both) e >>= 16;
+        s.p += e & 255u;
+        s.z += (e >> 8) & 255u;
+        if (s.z >= 64u) { s.z = 0u; s.c = s.c + 1u == g.blocks_per_mcu ? 0u : s.c + 1u; }
+    }
+    return s;
+}
+}  // namespace
+
+int ifhip_jpeg_debug_scan_report(const uint8_t* jpeg, size_t len, ifhip_jpeg_scan_report* out) {
+    if (!jpeg || !out) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
+    try {
+        std::memset(out, 0, sizeof *out);
+        ParsedJpeg P;
+        if (int rc = parse_jpeg(jpeg, len, &P)) return rc;
+        auto F = std::make_unique<FastTabs>(), Pt = std::make_unique<FastTabs>(), Ct = std::make_unique<FastTabs>();
+        SearchTab S6[6];
+        const char* lim = std::getenv("IFHIP_ENT_TEST_POOL");
+        const uint32_t pool_limit = lim ? std::min<uint32_t>(static_cast<uint32_t>(std::strtoul(lim, nullptr, 10)), kPoolEntries) : kPoolEntries;
+        derive_image_tables(P, F.get(), S6, pool_limit, &out->pool_entries_used);
+        derive_pair_tables(*F, P.ncomp, Pt.get());
+        derive_count_tables(*F, *Pt, Ct.get());
+        out->pool_entries = kPoolEntries;
+        for (uint32_t slot = 0; slot < 2u * static_cast<uint32_t>(P.ncomp); ++slot)
+            for (uint32_t i = 0; i < kLutEntries; ++i) {
+                if (F->lut[slot][i] == 0u) ++out->prefixes_left_to_search;
+                if ((slot & 1u) && (Pt->lut[slot][i] >> 16) != (Pt->lut[slot][i] & 0xffffu)) ++out->pair_entries;
+            }
+        EntropyGeom g;
+        std::memset(&g, 0, sizeof g);
+        g.blocks_per_mcu = P.blocks_per_mcu;
+        uint32_t k = 0;
+        for (int c = 0; c < P.ncomp; ++c)
+            for (uint32_t b = 0; b < static_cast<uint32_t>(P.hs[c]) * P.vs[c]; ++b, ++k) g.kcomp_packed |= static_cast<uint32_t>(c) << (2u * k);
+        std::vector<std::vector<uint8_t>> seg_bytes;
+        std::vector<uint32_t> seg_mcu0, seg_mcus;
+        const uint32_t covered = unstuff_scan(jpeg, len, P, &seg_bytes, &seg_mcu0, &seg_mcus);
+        out->segments = static_cast<uint32_t>(seg_bytes.size());
+        out->scan_complete = covered == P.mcus_w * P.mcus_h ? 1u : 0u;
+        for (size_t sgi = 0; sgi < seg_bytes.size(); ++sgi) {
+            const HostStream in{seg_bytes[sgi]};
+            const uint64_t bit_end = static_cast<uint64_t>(seg_bytes[sgi].size()) * 8u, want = static_cast<uint64_t>(seg_mcus[sgi]) * P.blocks_per_mcu;
+            const uint64_t n_sub = std::max<uint64_t>(1u, (bit_end + kSubBits - 1u) / kSubBits);
+            out->sub_sequences += static_cast<uint32_t>(n_sub);
+            HostCounts plain, paired, counted;
+            HostState s{0u, 0u, 0u};
+            for (uint64_t t = 0; t < n_sub; ++t) {                   // every sub-sequence from its true entry state, three ways
+                const uint64_t end = std::min<uint64_t>((t + 1u) * kSubBits, bit_end);
+                const HostState a0 = host_walk(g, in, *F, S6, 0, s, end, want, &plain);
+                const HostState a1 = host_walk(g, in, *Pt, S6, 1, s, end, want, &paired);
+                const HostState a2 = host_walk(g, in, *Ct, S6, 2, s, end, want, &counted);
+                if (a1.p != a0.p || a1.c != a0.c || a1.z != a0.z) ++out->pair_walk_mismatches;
+                if (a2.p != a0.p || a2.c != a0.c || a2.z != a0.z) ++out->count_walk_mismatches;
+                s = a0;
+            }
+            out->symbols += plain.reads;
+            out->table_reads_with_pairs += paired.reads;
+            out->blocks += plain.blocks;
+            if (plain.blocks != want) ++out->segments_with_wrong_block_count;
+            if (plain.bad) ++out->segments_with_invalid_codes;
+            for (int c = 0; c < 3; ++c) {
+                if (counted.dc[c] != plain.dc[c]) ++out->count_walk_mismatches;
+                out->dc_sum[c] += plain.dc[c];                       // (per segment the predictor restarts at 0: sums of the last segment
+                if (sgi + 1 == seg_bytes.size()) out->dc_last_segment[c] = plain.dc[c];        // give the last block's DC value)
+            }
+        }
+        return IFHIP_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: host memory");
+    } catch (const std::exception& ex) {
         return fail(IFHIP_INVALID_STATE, "InvalidState: %s", ex.what());
     }
 }

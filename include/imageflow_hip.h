@@ -191,6 +191,17 @@ IFHIP_API int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const 
  * ([n][blocks_h][blocks_w][64] int16, natural order) and synchronises the stream.  Progressive, arithmetic-coded,
  * 12-bit, multi-scan and CMYK files return IFHIP_METHOD_NOT_IMPLEMENTED: keep those on libjpeg. */
 typedef struct ifhip_jpeg_entropy ifhip_jpeg_entropy;
+/* Diagnostic, host only (no GPU, nothing decoded into coefficients): the decode tables and the scan layout of one file,
+ * checked against each other -- what tests/test_jpeg_headers.py asserts on every committed file without a device. */
+typedef struct ifhip_jpeg_scan_report {
+    uint32_t segments, sub_sequences, scan_complete;       /* restart segments; 1 024-bit sub-sequences; every MCU is covered */
+    uint32_t pool_entries, pool_entries_used, prefixes_left_to_search, pair_entries;   /* second-level pool; first-level entries */
+    uint32_t segments_with_wrong_block_count, segments_with_invalid_codes;           /* a serial walk with the tables */
+    uint32_t pair_walk_mismatches, count_walk_mismatches;  /* sub-sequence boundaries where a pair-table walk differs from the plain one */
+    uint64_t symbols, table_reads_with_pairs, blocks;
+    int32_t dc_sum[3], dc_last_segment[3];                 /* sums of the DC differences per component (all segments / the last one) */
+} ifhip_jpeg_scan_report;
+IFHIP_API int ifhip_jpeg_debug_scan_report(const uint8_t* jpeg, size_t len, ifhip_jpeg_scan_report* out);
 IFHIP_API int ifhip_jpeg_parse_headers(const uint8_t* jpeg, size_t len, uint32_t* width, uint32_t* height,
                                        int* n_components, uint8_t* h_samp3, uint8_t* v_samp3, uint32_t* blocks_w3,
                                        uint32_t* blocks_h3, uint16_t* qt3x64, uint32_t* restart_interval);

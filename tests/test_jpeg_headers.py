@@ -125,3 +125,55 @@ def test_parser_survives_mutated_headers(golden_dir):
             assert 1 <= info["ncomp"] <= 3 and 0 < info["width"] <= 65535 and 0 < info["height"] <= 65535
             assert sum(h * v for h, v in zip(info["hs"][:info["ncomp"]], info["vs"][:info["ncomp"]])) <= 10
     assert tried == 600 and 0 < refused < tried
+
+
+import ctypes as _C
+
+
+class _ScanReport(_C.Structure):
+    _fields_ = ([(n, _C.c_uint32) for n in ("segments", "sub_sequences", "scan_complete", "pool_entries", "pool_entries_used",
+                                            "prefixes_left_to_search", "pair_entries", "segments_with_wrong_block_count",
+                                            "segments_with_invalid_codes", "pair_walk_mismatches", "count_walk_mismatches")]
+                + [("_pad", _C.c_uint32)] + [(n, _C.c_uint64) for n in ("symbols", "table_reads_with_pairs", "blocks")]
+                + [("dc_sum", _C.c_int32 * 3), ("dc_last_segment", _C.c_int32 * 3)])
+
+
+def _scan_report(data):
+    import ctypes as C
+    from imageflow_amd import _native
+    L = _native.lib()
+    L.ifhip_jpeg_debug_scan_report.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_ScanReport)]
+    r = _ScanReport()
+    _native.check(L.ifhip_jpeg_debug_scan_report(data, len(data), C.byref(r)))
+    return r
+
+
+@pytest.mark.parametrize("pool", [None, "0", "40"])
+def test_decode_tables_and_scan_layout_without_a_device(golden_dir, monkeypatch, pool):
+    """What the entropy kernels rely on, checked on the host for every committed file (ifhip_jpeg_debug_scan_report):
+    a serial walk with the two-level tables starts exactly the blocks the geometry asks for and ends on the DC values of
+    the oracle's decode; walks with the pair tables (synchronisation rounds) and with the count tables pass through the
+    same state at every sub-sequence boundary as the plain walk.  Also with a second-level pool of 0 / 40 entries, which
+    leaves long prefixes to the serial code search."""
+    if pool is not None:
+        monkeypatch.setenv("IFHIP_ENT_TEST_POOL", pool)
+    files = searched = paired = 0
+    reads = symbols = 0
+    for name, data in all_files(golden_dir):
+        r = _scan_report(data)
+        j = O.jpeg_read_coefficients(data)
+        n = j["ncomp"]
+        assert r.scan_complete == 1 and r.segments >= 1, name
+        assert (r.segments_with_wrong_block_count, r.segments_with_invalid_codes) == (0, 0), name
+        assert (r.pair_walk_mismatches, r.count_walk_mismatches) == (0, 0), name
+        assert r.blocks == sum(j["bw"][c] * j["bh"][c] for c in range(n)), name
+        assert list(r.dc_last_segment)[:n] == [int(j["coef"][c][-1, -1, 0]) for c in range(n)], name
+        assert r.pool_entries_used <= r.pool_entries == 768 and r.table_reads_with_pairs <= r.symbols, name
+        files += 1
+        searched += r.prefixes_left_to_search > 0
+        paired += r.pair_entries > 0
+        reads += r.table_reads_with_pairs
+        symbols += r.symbols
+    assert files == 206 and paired == files
+    assert (searched > 0) == (pool is not None)          # the committed files fit the pool; the shrunken pools do not hold them
+    assert reads < 0.8 * symbols                          # one read covers two symbols often enough
