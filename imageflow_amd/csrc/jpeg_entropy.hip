@@ -68,6 +68,8 @@ constexpr uint32_t kLutEntries = 1u << kLutBits;
 #define IFHIP_ENT_POOL 768
 #endif
 constexpr uint32_t kPoolEntries = IFHIP_ENT_POOL;
+static_assert(kLutBits >= 8u && kLutBits <= 11u, "first-level lookup: the pair entries assume a code + magnitude of < 32 bits behind it");
+static_assert(kPoolEntries >= 128u && kPoolEntries <= 65535u, "a first-level pointer holds the pool offset in 16 bits; one sub-table is up to 128 entries");
 struct FastTabs {                                    // one image: [comp][dc, ac] and their shared second level
     uint32_t lut[6][kLutEntries];
     uint32_t pool[kPoolEntries];
@@ -366,6 +368,7 @@ constexpr uint32_t kWaveWalkMax = IFHIP_ENT_WAVEWALK;                          /
 #endif
 constexpr uint32_t kWarmLanes = IFHIP_ENT_WARM;
 constexpr uint32_t kOwnSubs = kSyncLanes - kWarmLanes;                         // sub-sequences a workgroup owns
+static_assert(kWarmLanes < kSyncLanes && kSyncLanes % 64u == 0u && kSyncLanes <= 1024u, "whole waves, one workgroup");
 constexpr uint32_t kNever = 0xffffffffu;
 constexpr uint32_t kFlagWords = 18;                                             // changed[16], errors, unsettled
 constexpr uint32_t kChunkSubs = 512;                                            // sub-sequences per workgroup of the write pass                                       // no decode yet (no real state packs to this)
