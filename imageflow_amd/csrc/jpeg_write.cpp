@@ -135,11 +135,11 @@ void gen_optimal_table(const long counts[256], HuffSpecW* t) {
     for (i = 32; i > 16; --i)
         while (bits[i] > 0) {
             int j = i - 2;
-            while (bits[j] == 0) --j;
+            while (j > 0 && bits[j] == 0) --j;
             bits[i] -= 2; bits[i - 1]++; bits[j + 1] += 2; bits[j]--;
         }
-    while (bits[i] == 0) --i;                        // the pseudo-symbol's code point: the longest code loses one
-    bits[i]--;
+    while (i > 0 && bits[i] == 0) --i;               // the pseudo-symbol's code point: the longest code loses one
+    if (i > 0) bits[i]--;                            // (i == 0: no symbol was counted at all -- an empty table)
     std::memcpy(t->bits, bits, 17);
     t->nvals = 0;
     for (int l = 1; l <= 32; ++l)
