@@ -127,10 +127,15 @@ def write_jpeg(coef, width, height, h_samp, v_samp, quality, progressive=False, 
     ptrs = [p.ctypes.data for p in planes] + [None] * (3 - n)
     size = C.c_size_t(0)
     args = ptrs + [bw.ctypes.data, bh.ctypes.data, n, hs.ctypes.data, vs.ctypes.data, width, height, int(quality), flags]
-    _native.check(L.ifhip_jpeg_write(*args, None, 0, C.byref(size)))
-    out = np.zeros(size.value, np.uint8)
-    _native.check(L.ifhip_jpeg_write(*args, out.ctypes.data, size.value, C.byref(size)))
-    return out.tobytes()
+    # one pass when the guess is large enough (a file is far smaller than its coefficients); the entry point reports the
+    # size it needs otherwise
+    out = np.empty(max(4096, sum(p.size for p in planes) // 2), np.uint8)
+    rc = L.ifhip_jpeg_write(*args, out.ctypes.data, out.size, C.byref(size))
+    if rc != 0 and size.value > out.size:
+        out = np.empty(size.value, np.uint8)
+        rc = L.ifhip_jpeg_write(*args, out.ctypes.data, out.size, C.byref(size))
+    _native.check(rc)
+    return out[:size.value].tobytes()
 
 
 class MozjpegEncoder:

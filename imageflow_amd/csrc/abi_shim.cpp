@@ -571,9 +571,16 @@ struct Job {
             std::vector<int16_t> coef(off[3]);
             hip_check(hipMemcpy(coef.data(), d_coef, off[3] * 2u, hipMemcpyDeviceToHost), "download(coefficients)");
             size_t len = 0;
-            check(ifhip_jpeg_write(coef.data() + off[0], coef.data() + off[1], coef.data() + off[2], bw, bh, 3, hs, vs, f->w, f->h, quality, write_flags, nullptr, 0, &len));
-            o.owned.assign(len, 0);
-            check(ifhip_jpeg_write(coef.data() + off[0], coef.data() + off[1], coef.data() + off[2], bw, bh, 3, hs, vs, f->w, f->h, quality, write_flags, o.owned.data(), len, &len));
+            o.owned.assign(std::max<size_t>(4096u, off[3]), 0);                          // a file is smaller than its coefficients: one pass
+            int wrc = ifhip_jpeg_write(coef.data() + off[0], coef.data() + off[1], coef.data() + off[2], bw, bh, 3, hs, vs, f->w, f->h, quality, write_flags,
+                                       o.owned.data(), o.owned.size(), &len);
+            if (wrc != IFHIP_OK && len > o.owned.size()) {
+                o.owned.assign(len, 0);
+                wrc = ifhip_jpeg_write(coef.data() + off[0], coef.data() + off[1], coef.data() + off[2], bw, bh, 3, hs, vs, f->w, f->h, quality, write_flags,
+                                       o.owned.data(), o.owned.size(), &len);
+            }
+            check(wrc);
+            o.owned.resize(len);
             o.written = true;
             encodes.push_back({io_id, f->w, f->h, "image/jpeg", "jpg"});
             return;

@@ -50,32 +50,64 @@ const uint8_t kAcChromaVals[162] = {
     0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
     0xfa};
 
-struct EncTab { uint16_t code[256]; uint8_t size[256]; };
+struct EncTab { uint32_t cs[256]; };                                          // code | length << 16: one load per symbol
 void build(const uint8_t* bits, const uint8_t* vals, EncTab* t) {              // jchuff.c jpeg_make_c_derived_tbl
     std::memset(t, 0, sizeof *t);
     uint32_t code = 0;
     int k = 0;
     for (int l = 1; l <= 16; ++l) {
-        for (int i = 0; i < bits[l]; ++i, ++k, ++code) { t->code[vals[k]] = static_cast<uint16_t>(code); t->size[vals[k]] = static_cast<uint8_t>(l); }
+        for (int i = 0; i < bits[l]; ++i, ++k, ++code) t->cs[vals[k]] = code | (static_cast<uint32_t>(l) << 16);
         code <<= 1;
     }
 }
 
+// Bit packing into the output vector: a 64-bit accumulator, four bytes at a time, byte stuffing only on the (rare)
+// words that contain an 0xFF byte.  The vector is grown ahead of the write position and cut to size by finish().
 struct BitWriter {
     std::vector<uint8_t>& out;
-    uint32_t acc = 0;
-    int n = 0;
-    void put(uint32_t code, int size) {
+    uint8_t* p;                                      // write position and end of the vector's storage (raw pointers: byte stores
+    uint8_t* lim;                                    // through the vector would make the compiler reload its fields every time)
+    uint64_t acc = 0;
+    int n = 0;                                       // bits waiting in acc (< 32 between calls)
+    BitWriter(std::vector<uint8_t>& o, size_t expected_bytes) : out(o) {
+        const size_t at = o.size();
+        out.resize(at + expected_bytes + 64);
+        p = out.data() + at;
+        lim = out.data() + out.size();
+    }
+    void grow() {
+        const size_t at = static_cast<size_t>(p - out.data());
+        out.resize(out.size() * 2 + 64);
+        p = out.data() + at;
+        lim = out.data() + out.size();
+    }
+    void byte(uint8_t b) {
+        *p++ = b;
+        if (b == 0xFF) *p++ = 0;
+    }
+    void put(uint32_t code, int size) {              // size 0..31; bits of `code` above `size` are ignored
         acc = (acc << size) | (code & ((1u << size) - 1u));
         n += size;
-        while (n >= 8) {
-            const uint8_t b = static_cast<uint8_t>(acc >> (n - 8));
-            out.push_back(b);
-            if (b == 0xFF) out.push_back(0);
-            n -= 8;
+        if (n >= 32) {
+            if (lim - p < 16) grow();
+            const uint32_t w = static_cast<uint32_t>(acc >> (n - 32));
+            n -= 32;
+            const uint32_t inv = ~w;
+            if (((inv - 0x01010101u) & ~inv & 0x80808080u) == 0u) {           // no byte of w is 0xFF
+                const uint32_t be = __builtin_bswap32(w);
+                std::memcpy(p, &be, 4);
+                p += 4;
+            } else {
+                byte(static_cast<uint8_t>(w >> 24)); byte(static_cast<uint8_t>(w >> 16)); byte(static_cast<uint8_t>(w >> 8)); byte(static_cast<uint8_t>(w));
+            }
         }
     }
-    void flush() { if (n > 0) put(0x7F, 8 - n); }                                 // pad with 1 bits (jchuff.c flush_bits)
+    void finish() {                                  // pad the last byte with 1 bits (jchuff.c flush_bits), cut the vector
+        if (n & 7) put(0x7F, 8 - (n & 7));
+        if (lim - p < 16) grow();
+        while (n >= 8) { byte(static_cast<uint8_t>(acc >> (n - 8))); n -= 8; }
+        out.resize(static_cast<size_t>(p - out.data()));
+    }
 };
 
 void marker(std::vector<uint8_t>& o, uint8_t m, const std::vector<uint8_t>& body) {
@@ -84,7 +116,7 @@ void marker(std::vector<uint8_t>& o, uint8_t m, const std::vector<uint8_t>& body
     o.push_back(static_cast<uint8_t>(len >> 8)); o.push_back(static_cast<uint8_t>(len));
     o.insert(o.end(), body.begin(), body.end());
 }
-int nbits(int v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
+inline int nbits(int v) { return v ? 32 - __builtin_clz(static_cast<unsigned>(v)) : 0; }
 
 }  // namespace
 
@@ -146,45 +178,73 @@ void gen_optimal_table(const long counts[256], HuffSpecW* t) {
         for (int j = 0; j <= 255; ++j) if (codesize[j] == l) t->vals[t->nvals++] = static_cast<uint8_t>(j);
 }
 
-// One pass over a scan either counts the symbols (tables to be optimised) or writes them.
+// A scan's symbols go either straight into the bit stream (tables known: the Annex K ones) or -- tables to be optimised --
+// into statistics plus a token list that is replayed once the tables exist, so that the coefficients are walked once.
+// token: value (extra bits) | n extra bits << 16 | symbol << 21 | is_ac << 29 | table << 30 | has symbol << 31
 struct Coder {
-    BitWriter* w = nullptr;                          // null: gather statistics
+    BitWriter* w = nullptr;                          // null: gather statistics + tokens
     const EncTab* dc[2] = {nullptr, nullptr};
     const EncTab* ac[2] = {nullptr, nullptr};
     long dc_count[2][256], ac_count[2][256];
-    void reset_counts() { std::memset(dc_count, 0, sizeof dc_count); std::memset(ac_count, 0, sizeof ac_count); }
-    void sym(bool is_ac, int tbl, int s) {
-        if (!w) { (is_ac ? ac_count : dc_count)[tbl][s]++; return; }
-        const EncTab& t = *(is_ac ? ac : dc)[tbl];
-        w->put(t.code[s], t.size[s]);
+    std::vector<uint32_t> tokens;
+    void reset() { std::memset(dc_count, 0, sizeof dc_count); std::memset(ac_count, 0, sizeof ac_count); tokens.clear(); }
+    void sym(bool is_ac, int tbl, int s, uint32_t extra, int n_extra) {
+        if (w) {                                     // code and extra bits as one field (<= 16 + 11 bits)
+            const uint32_t cs = (is_ac ? ac : dc)[tbl]->cs[s];
+            w->put(((cs & 0xffffu) << n_extra) | (extra & ((1u << n_extra) - 1u)), static_cast<int>(cs >> 16) + n_extra);
+        } else {
+            (is_ac ? ac_count : dc_count)[tbl][s]++;
+            tokens.push_back((extra & ((1u << n_extra) - 1u)) | (static_cast<uint32_t>(n_extra) << 16) | (static_cast<uint32_t>(s) << 21) |
+                             (is_ac ? 1u << 29 : 0u) | (static_cast<uint32_t>(tbl) << 30) | (1u << 31));
+        }
     }
-    void bits(uint32_t v, int n) { if (w && n) w->put(v, n); }
+    void raw(uint32_t v, int n) {                    // bits without a symbol (DC refinement, correction bits)
+        if (w) w->put(v, n);
+        else tokens.push_back((v & ((1u << n) - 1u)) | (static_cast<uint32_t>(n) << 16));
+    }
+    void replay(BitWriter& bw) const {
+        for (const uint32_t t : tokens) {
+            const int n_extra = static_cast<int>((t >> 16) & 31u);
+            if (t >> 31) {
+                const uint32_t cs = ((t >> 29) & 1u ? ac : dc)[(t >> 30) & 1u]->cs[(t >> 21) & 255u];
+                bw.put(((cs & 0xffffu) << n_extra) | (t & 0xffffu), static_cast<int>(cs >> 16) + n_extra);
+            } else {
+                bw.put(t & 0xffffu, n_extra);
+            }
+        }
+    }
 };
 
 struct Plane { const int16_t* coef; uint32_t pitch_blocks, wb, hb, H, V; int tbl; };   // wb x hb: the component's own size in blocks
 
 struct ScanSpec { int ncomp; int comp[3]; int Ss, Se, Ah, Al; };
 
+// The coefficient loops below never branch on "is this coefficient zero" (on photographic data that branch is a coin
+// toss, and a misprediction costs more than the symbol): the band is gathered in zigzag order, a bit mask of its
+// nonzero positions is built without branches, and the set bits are walked with count-trailing-zeros.
 // jchuff.c encode_one_block / htest_one_block
 void sequential_block(Coder& C, const int16_t* blk, int tbl, int* pred) {
     int diff = blk[0] - *pred;
     *pred = blk[0];
     int t = diff < 0 ? -diff : diff, t2 = diff < 0 ? diff - 1 : diff;
     int nb = nbits(t);
-    C.sym(false, tbl, nb);
-    C.bits(static_cast<uint32_t>(t2), nb);
-    int r = 0;
-    for (int k = 1; k < 64; ++k) {
-        const int v = blk[kZigzag[k]];
-        if (v == 0) { ++r; continue; }
-        while (r > 15) { C.sym(true, tbl, 0xF0); r -= 16; }
+    C.sym(false, tbl, nb, static_cast<uint32_t>(t2), nb);
+    int16_t z[64];
+    uint64_t m = 0;
+    for (int k = 1; k < 64; ++k) { z[k] = blk[kZigzag[k]]; m |= static_cast<uint64_t>(z[k] != 0) << k; }
+    int prev = 0;
+    while (m) {
+        const int k = __builtin_ctzll(m);
+        m &= m - 1;
+        int r = k - prev - 1;
+        prev = k;
+        while (r > 15) { C.sym(true, tbl, 0xF0, 0, 0); r -= 16; }
+        const int v = z[k];
         t = v < 0 ? -v : v; t2 = v < 0 ? v - 1 : v;
         nb = nbits(t);
-        C.sym(true, tbl, (r << 4) + nb);
-        C.bits(static_cast<uint32_t>(t2), nb);
-        r = 0;
+        C.sym(true, tbl, (r << 4) + nb, static_cast<uint32_t>(t2), nb);
     }
-    if (r > 0) C.sym(true, tbl, 0);
+    if (prev < 63) C.sym(true, tbl, 0, 0, 0);
 }
 
 // jcphuff.c: the four block coders of a progressive scan, with the end-of-band run and the buffered correction bits
@@ -193,67 +253,86 @@ struct Progressive {
     int tbl = 0, Ss = 0, Se = 0, Al = 0;
     uint32_t eobrun = 0;
     std::vector<uint8_t> be;                         // correction bits waiting behind the end-of-band run
-    explicit Progressive(Coder& c) : C(c) {}
-    void buffered(const uint8_t* b, size_t n) { for (size_t i = 0; i < n; ++i) C.bits(b[i], 1); }
+    explicit Progressive(Coder& c) : C(c) { be.reserve(1024); }
+    void buffered(const uint8_t* b, size_t n) {      // up to 16 one-bit values per token / put
+        for (size_t i = 0; i < n;) {
+            uint32_t v = 0;
+            int m = 0;
+            for (; m < 16 && i < n; ++m, ++i) v = (v << 1) | b[i];
+            C.raw(v, m);
+        }
+    }
     void emit_eobrun() {
         if (eobrun > 0) {
             int nb = 0;
             for (uint32_t t = eobrun; (t >>= 1);) ++nb;
-            C.sym(true, tbl, nb << 4);
-            if (nb) C.bits(eobrun, nb);
+            C.sym(true, tbl, nb << 4, eobrun, nb);
             eobrun = 0;
             buffered(be.data(), be.size());
             be.clear();
         }
     }
     void ac_first(const int16_t* blk) {
-        int r = 0;
+        int mag[64], ext[64];                        // |coefficient| >> Al and the bits emitted for it (jcphuff.c: ~magnitude when negative)
+        uint64_t m = 0;
         for (int k = Ss; k <= Se; ++k) {
-            int t = blk[kZigzag[k]], t2;
-            if (t == 0) { ++r; continue; }
-            if (t < 0) { t = -t; t >>= Al; t2 = ~t; } else { t >>= Al; t2 = t; }
-            if (t == 0) { ++r; continue; }
-            if (eobrun > 0) emit_eobrun();
-            while (r > 15) { C.sym(true, tbl, 0xF0); r -= 16; }
-            const int nb = nbits(t);
-            C.sym(true, tbl, (r << 4) + nb);
-            C.bits(static_cast<uint32_t>(t2), nb);
-            r = 0;
+            const int v = blk[kZigzag[k]], a = (v < 0 ? -v : v) >> Al;
+            mag[k] = a;
+            ext[k] = v < 0 ? ~a : a;
+            m |= static_cast<uint64_t>(a != 0) << k;
         }
-        if (r > 0) { if (++eobrun == 0x7FFF) emit_eobrun(); }
+        int prev = Ss - 1;
+        while (m) {
+            const int k = __builtin_ctzll(m);
+            m &= m - 1;
+            int r = k - prev - 1;
+            prev = k;
+            if (eobrun > 0) emit_eobrun();
+            while (r > 15) { C.sym(true, tbl, 0xF0, 0, 0); r -= 16; }
+            const int nb = nbits(mag[k]);
+            C.sym(true, tbl, (r << 4) + nb, static_cast<uint32_t>(ext[k]), nb);
+        }
+        if (prev < Se) { if (++eobrun == 0x7FFF) emit_eobrun(); }
     }
     void ac_refine(const int16_t* blk) {
         int absv[64], eob = 0;
+        uint64_t nz = 0;                             // positions whose magnitude (>> Al) is not zero
         for (int k = Ss; k <= Se; ++k) {
             int t = blk[kZigzag[k]];
             if (t < 0) t = -t;
             t >>= Al;
             absv[k] = t;
-            if (t == 1) eob = k;
+            nz |= static_cast<uint64_t>(t != 0) << k;
+            eob = t == 1 ? k : eob;
         }
-        int r = 0;
-        std::vector<uint8_t> br;                     // correction bits of this block since the last newly nonzero coefficient
-        for (int k = Ss; k <= Se; ++k) {
+        int r = 0, prev = Ss - 1;
+        uint8_t br[64];                              // correction bits of this block since the last newly nonzero coefficient
+        size_t nbr = 0;
+        uint64_t m = nz;
+        while (m) {
+            const int k = __builtin_ctzll(m);
+            m &= m - 1;
+            r += k - prev - 1;                       // the zero-history coefficients passed on the way
+            prev = k;
             const int t = absv[k];
-            if (t == 0) { ++r; continue; }
             while (r > 15 && k <= eob) {
                 emit_eobrun();
-                C.sym(true, tbl, 0xF0);
+                C.sym(true, tbl, 0xF0, 0, 0);
                 r -= 16;
-                buffered(br.data(), br.size());
-                br.clear();
+                buffered(br, nbr);
+                nbr = 0;
             }
-            if (t > 1) { br.push_back(static_cast<uint8_t>(t & 1)); continue; }
+            if (t > 1) { br[nbr++] = static_cast<uint8_t>(t & 1); continue; }
             emit_eobrun();
-            C.sym(true, tbl, (r << 4) + 1);
-            C.bits(blk[kZigzag[k]] < 0 ? 0u : 1u, 1);
-            buffered(br.data(), br.size());
-            br.clear();
+            C.sym(true, tbl, (r << 4) + 1, blk[kZigzag[k]] < 0 ? 0u : 1u, 1);
+            buffered(br, nbr);
+            nbr = 0;
             r = 0;
         }
-        if (r > 0 || !br.empty()) {
+        r += Se - prev;                              // zeros behind the last nonzero position
+        if (r > 0 || nbr > 0) {
             ++eobrun;
-            be.insert(be.end(), br.begin(), br.end());
+            be.insert(be.end(), br, br + nbr);
             if (eobrun == 0x7FFF || be.size() > 1000 - 64 + 1) emit_eobrun();
         }
     }
@@ -275,10 +354,9 @@ void run_scan(Coder& C, const ScanSpec& sc, const Plane* planes, uint32_t mcus_w
                 pred[ci] = t2;
                 int t = diff < 0 ? -diff : diff, tb = diff < 0 ? diff - 1 : diff;
                 const int nb = nbits(t);
-                C.sym(false, pl.tbl, nb);
-                C.bits(static_cast<uint32_t>(tb), nb);
+                C.sym(false, pl.tbl, nb, static_cast<uint32_t>(tb), nb);
             } else {
-                C.bits(static_cast<uint32_t>(blk[0] >> sc.Al) & 1u, 1);
+                C.raw(static_cast<uint32_t>(blk[0] >> sc.Al) & 1u, 1);
             }
             return;
         }
@@ -357,18 +435,19 @@ int jpeg_write(const int16_t* const coef[3], const uint32_t bw[3], const uint32_
         b.insert(b.end(), vals, vals + nvals);
         marker(o, 0xC4, b);
     };
+    Coder C;                                                                                      // (its token list keeps its capacity from scan to scan)
     for (const ScanSpec& sc : script) {
         const bool dc_scan = sc.Ss == 0, ac_scan = sc.Se > 0;
         const bool needs_dc = dc_scan && sc.Ah == 0, needs_ac = ac_scan;                          // (a DC refinement scan is raw bits)
         EncTab dct[2], act[2];
-        Coder C;
+        C.w = nullptr;
         C.dc[0] = &dct[0]; C.dc[1] = &dct[1]; C.ac[0] = &act[0]; C.ac[1] = &act[1];
         bool used[2] = {false, false};
         for (int i = 0; i < sc.ncomp; ++i) used[planes[sc.comp[i]].tbl] = true;
         HuffSpecW od[2], oa[2];
         if (optimize) {
-            C.reset_counts();
-            run_scan(C, sc, planes, mw, mh);                                                      // statistics pass
+            C.reset();
+            run_scan(C, sc, planes, mw, mh);                                                      // statistics + tokens
             for (int t = 0; t < 2; ++t) {
                 if (!used[t]) continue;
                 if (needs_dc) { gen_optimal_table(C.dc_count[t], &od[t]); build(od[t].bits, od[t].vals, &dct[t]); }
@@ -406,10 +485,10 @@ int jpeg_write(const int16_t* const coef[3], const uint32_t bw[3], const uint32_
             b.push_back(static_cast<uint8_t>((sc.Ah << 4) | sc.Al));
             marker(o, 0xDA, b);                                                                   // SOS
         }
-        BitWriter bwr{o};
-        C.w = &bwr;
-        run_scan(C, sc, planes, mw, mh);
-        bwr.flush();
+        BitWriter bwr(o, optimize ? C.tokens.size() * 2u : static_cast<size_t>(mw) * mh * 24u);
+        if (optimize) C.replay(bwr);
+        else { C.w = &bwr; run_scan(C, sc, planes, mw, mh); }
+        bwr.finish();
     }
     o.push_back(0xFF); o.push_back(0xD9);                                                        // EOI
     return IFHIP_OK;
