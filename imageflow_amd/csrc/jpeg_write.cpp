@@ -10,6 +10,9 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include "common.hpp"
 
@@ -220,8 +223,44 @@ struct Plane { const int16_t* coef; uint32_t pitch_blocks, wb, hb, H, V; int tbl
 struct ScanSpec { int ncomp; int comp[3]; int Ss, Se, Ah, Al; };
 
 // The coefficient loops below never branch on "is this coefficient zero" (on photographic data that branch is a coin
-// toss, and a misprediction costs more than the symbol): the band is gathered in zigzag order, a bit mask of its
-// nonzero positions is built without branches, and the set bits are walked with count-trailing-zeros.
+// toss, and a misprediction costs more than the symbol): a bit mask of the block's positions with |coefficient| above a
+// threshold is built eight coefficients at a time in natural order, permuted to zigzag order through a table, and its
+// set bits are walked with count-trailing-zeros -- only coefficients that produce a symbol are ever loaded singly.
+struct ZigzagMaskTable {
+    uint64_t t[8][256];                              // natural row r, 8-bit mask of its columns -> the zigzag positions
+    ZigzagMaskTable() {
+        uint8_t zz_of[64];
+        for (int k = 0; k < 64; ++k) zz_of[kZigzag[k]] = static_cast<uint8_t>(k);
+        for (int r = 0; r < 8; ++r)
+            for (int b = 0; b < 256; ++b) {
+                uint64_t m = 0;
+                for (int j = 0; j < 8; ++j) if (b & (1 << j)) m |= 1ull << zz_of[r * 8 + j];
+                t[r][b] = m;
+            }
+    }
+};
+const ZigzagMaskTable kZzMask;
+
+// zigzag positions k with |blk[k]| > above (above = 0: nonzero)
+inline uint64_t zigzag_mask(const int16_t* blk, int above) {
+    uint64_t nat = 0;                                // natural-order mask, bit i = coefficient i qualifies
+#if defined(__SSE2__)
+    const __m128i zero = _mm_setzero_si128(), lim = _mm_set1_epi16(static_cast<short>(above));
+    for (int r = 0; r < 8; r += 2) {
+        __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(blk + r * 8)), b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(blk + r * 8 + 8));
+        a = _mm_max_epi16(a, _mm_sub_epi16(zero, a));                                 // |x| (coefficients are far from -32768)
+        b = _mm_max_epi16(b, _mm_sub_epi16(zero, b));
+        const __m128i q = _mm_packs_epi16(_mm_cmpgt_epi16(a, lim), _mm_cmpgt_epi16(b, lim));
+        nat |= static_cast<uint64_t>(static_cast<uint32_t>(_mm_movemask_epi8(q))) << (r * 8);
+    }
+#else
+    for (int i = 0; i < 64; ++i) { const int v = blk[i]; nat |= static_cast<uint64_t>((v < 0 ? -v : v) > above) << i; }
+#endif
+    uint64_t zz = 0;
+    for (int r = 0; r < 8; ++r) zz |= kZzMask.t[r][(nat >> (8 * r)) & 255u];
+    return zz;
+}
+
 // jchuff.c encode_one_block / htest_one_block
 void sequential_block(Coder& C, const int16_t* blk, int tbl, int* pred) {
     int diff = blk[0] - *pred;
@@ -229,9 +268,7 @@ void sequential_block(Coder& C, const int16_t* blk, int tbl, int* pred) {
     int t = diff < 0 ? -diff : diff, t2 = diff < 0 ? diff - 1 : diff;
     int nb = nbits(t);
     C.sym(false, tbl, nb, static_cast<uint32_t>(t2), nb);
-    int16_t z[64];
-    uint64_t m = 0;
-    for (int k = 1; k < 64; ++k) { z[k] = blk[kZigzag[k]]; m |= static_cast<uint64_t>(z[k] != 0) << k; }
+    uint64_t m = zigzag_mask(blk, 0) & ~1ull;
     int prev = 0;
     while (m) {
         const int k = __builtin_ctzll(m);
@@ -239,7 +276,7 @@ void sequential_block(Coder& C, const int16_t* blk, int tbl, int* pred) {
         int r = k - prev - 1;
         prev = k;
         while (r > 15) { C.sym(true, tbl, 0xF0, 0, 0); r -= 16; }
-        const int v = z[k];
+        const int v = blk[kZigzag[k]];
         t = v < 0 ? -v : v; t2 = v < 0 ? v - 1 : v;
         nb = nbits(t);
         C.sym(true, tbl, (r << 4) + nb, static_cast<uint32_t>(t2), nb);
@@ -272,38 +309,30 @@ struct Progressive {
             be.clear();
         }
     }
+    uint64_t band() const { return (Se == 63 ? ~0ull : (1ull << (Se + 1)) - 1ull) & ~((1ull << Ss) - 1ull); }
     void ac_first(const int16_t* blk) {
-        int mag[64], ext[64];                        // |coefficient| >> Al and the bits emitted for it (jcphuff.c: ~magnitude when negative)
-        uint64_t m = 0;
-        for (int k = Ss; k <= Se; ++k) {
-            const int v = blk[kZigzag[k]], a = (v < 0 ? -v : v) >> Al;
-            mag[k] = a;
-            ext[k] = v < 0 ? ~a : a;
-            m |= static_cast<uint64_t>(a != 0) << k;
-        }
+        uint64_t m = zigzag_mask(blk, (1 << Al) - 1) & band();        // |v| >> Al != 0
         int prev = Ss - 1;
         while (m) {
             const int k = __builtin_ctzll(m);
             m &= m - 1;
             int r = k - prev - 1;
             prev = k;
+            const int v = blk[kZigzag[k]], a = (v < 0 ? -v : v) >> Al;
             if (eobrun > 0) emit_eobrun();
             while (r > 15) { C.sym(true, tbl, 0xF0, 0, 0); r -= 16; }
-            const int nb = nbits(mag[k]);
-            C.sym(true, tbl, (r << 4) + nb, static_cast<uint32_t>(ext[k]), nb);
+            const int nb = nbits(a);
+            C.sym(true, tbl, (r << 4) + nb, static_cast<uint32_t>(v < 0 ? ~a : a), nb);       // (jcphuff.c: ~magnitude when negative)
         }
         if (prev < Se) { if (++eobrun == 0x7FFF) emit_eobrun(); }
     }
     void ac_refine(const int16_t* blk) {
+        const uint64_t nz = zigzag_mask(blk, (1 << Al) - 1) & band();  // positions whose magnitude (>> Al) is not zero
         int absv[64], eob = 0;
-        uint64_t nz = 0;                             // positions whose magnitude (>> Al) is not zero
-        for (int k = Ss; k <= Se; ++k) {
-            int t = blk[kZigzag[k]];
-            if (t < 0) t = -t;
-            t >>= Al;
-            absv[k] = t;
-            nz |= static_cast<uint64_t>(t != 0) << k;
-            eob = t == 1 ? k : eob;
+        for (uint64_t m = nz; m; m &= m - 1) {
+            const int k = __builtin_ctzll(m), v = blk[kZigzag[k]];
+            absv[k] = (v < 0 ? -v : v) >> Al;
+            if (absv[k] == 1) eob = k;               // ascending k: the last newly nonzero coefficient
         }
         int r = 0, prev = Ss - 1;
         uint8_t br[64];                              // correction bits of this block since the last newly nonzero coefficient
