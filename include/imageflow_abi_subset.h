@@ -7,8 +7,10 @@
  * What a job may contain (anything else answers ActionNotSupported, HTTP 400): decode (baseline JPEG, or the raw
  * BGRA container EXTENSION), create_canvas, fill_rect, expand_canvas, crop, flip_h/flip_v, transpose, rotate_90/180/270,
  * resample_2d, constrain (within | fit | distort), command_string (ir4: width/height, mode=max), encode.
- * `encode` writes the raw BGRA container EXTENSION whatever the preset says (this library has no entropy/deflate
- * encoder): 8 bytes "IFBGRA1\0", u32le w, h, stride, alpha_meaningful, then h rows of `stride` bytes.
+ * `encode` with the libjpeg_turbo preset writes a real JPEG (quality, matte, progressive, optimize_huffman_coding:
+ * byte-identical to libjpeg-turbo's file for the same pixels at 4:2:0); every other preset writes the raw BGRA container
+ * EXTENSION (this library has no deflate / GIF / WebP coder): 8 bytes "IFBGRA1\0", u32le w, h, stride,
+ * alpha_meaningful, then h rows of `stride` bytes.
  * Implementation: imageflow_amd/csrc/abi_shim.cpp.
  */
 #ifndef IMAGEFLOW_ABI_SUBSET_H
