@@ -190,6 +190,8 @@ struct Coder {
     const EncTab* ac[2] = {nullptr, nullptr};
     long dc_count[2][256], ac_count[2][256];
     std::vector<uint32_t> tokens;
+    bool bad = false;                                // a coefficient with more magnitude bits than 8-bit JPEG has (jchuff.c JERR_BAD_DCT_COEF)
+    void range(int nb, int limit) { bad |= nb > limit; }
     void reset() { std::memset(dc_count, 0, sizeof dc_count); std::memset(ac_count, 0, sizeof ac_count); tokens.clear(); }
     void sym(bool is_ac, int tbl, int s, uint32_t extra, int n_extra) {
         if (w) {                                     // code and extra bits as one field (<= 16 + 11 bits)
@@ -267,6 +269,7 @@ void sequential_block(Coder& C, const int16_t* blk, int tbl, int* pred) {
     *pred = blk[0];
     int t = diff < 0 ? -diff : diff, t2 = diff < 0 ? diff - 1 : diff;
     int nb = nbits(t);
+    C.range(nb, 11);
     C.sym(false, tbl, nb, static_cast<uint32_t>(t2), nb);
     uint64_t m = zigzag_mask(blk, 0) & ~1ull;
     int prev = 0;
@@ -279,6 +282,7 @@ void sequential_block(Coder& C, const int16_t* blk, int tbl, int* pred) {
         const int v = blk[kZigzag[k]];
         t = v < 0 ? -v : v; t2 = v < 0 ? v - 1 : v;
         nb = nbits(t);
+        C.range(nb, 10);
         C.sym(true, tbl, (r << 4) + nb, static_cast<uint32_t>(t2), nb);
     }
     if (prev < 63) C.sym(true, tbl, 0, 0, 0);
@@ -322,6 +326,7 @@ struct Progressive {
             if (eobrun > 0) emit_eobrun();
             while (r > 15) { C.sym(true, tbl, 0xF0, 0, 0); r -= 16; }
             const int nb = nbits(a);
+            C.range(nb, 10);
             C.sym(true, tbl, (r << 4) + nb, static_cast<uint32_t>(v < 0 ? ~a : a), nb);       // (jcphuff.c: ~magnitude when negative)
         }
         if (prev < Se) { if (++eobrun == 0x7FFF) emit_eobrun(); }
@@ -383,6 +388,7 @@ void run_scan(Coder& C, const ScanSpec& sc, const Plane* planes, uint32_t mcus_w
                 pred[ci] = t2;
                 int t = diff < 0 ? -diff : diff, tb = diff < 0 ? diff - 1 : diff;
                 const int nb = nbits(t);
+                C.range(nb, 11);
                 C.sym(false, pl.tbl, nb, static_cast<uint32_t>(tb), nb);
             } else {
                 C.raw(static_cast<uint32_t>(blk[0] >> sc.Al) & 1u, 1);
@@ -518,6 +524,7 @@ int jpeg_write(const int16_t* const coef[3], const uint32_t bw[3], const uint32_
         if (optimize) C.replay(bwr);
         else { C.w = &bwr; run_scan(C, sc, planes, mw, mh); }
         bwr.finish();
+        if (C.bad) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: coefficient out of range for 8-bit JPEG (more than 11 DC / 10 AC magnitude bits)");
     }
     o.push_back(0xFF); o.push_back(0xD9);                                                        // EOI
     return IFHIP_OK;

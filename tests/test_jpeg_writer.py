@@ -150,3 +150,20 @@ def test_python_mirror_write_jpeg():
         ref = io.BytesIO()
         img.save(ref, "JPEG", quality=82, subsampling="4:2:0", **pil)
         assert write_jpeg(j["coef"], 90, 61, j["hs"], j["vs"], 82, **kw) == ref.getvalue(), kw
+
+
+def test_out_of_range_coefficients_are_refused():
+    """jchuff.c JERR_BAD_DCT_COEF: more than 10 AC / 11 DC magnitude bits cannot be coded with 8-bit JPEG's symbols."""
+    from imageflow_amd.codecs.mozjpeg import write_jpeg
+    from imageflow_amd.errors import FlowError
+    ok = np.zeros((1, 1, 64), np.int16)
+    ok[0, 0, 0], ok[0, 0, 5] = 2047, -1023
+    # (a progressive file codes DC >> 1 and AC >> 2 in its first scans and single bits afterwards: the limits move with the shift)
+    for kw, cases in (({}, ((5, 1024), (5, -2000), (0, 2048), (0, -4000))), ({"optimize_coding": True}, ((5, 1024), (0, -2048))),
+                      ({"progressive": True}, ((5, 4096), (5, -5000), (0, 4096)))):
+        assert write_jpeg([ok], 8, 8, [1], [1], 90, **kw)[:2] == b"\xff\xd8"
+        for pos, v in cases:
+            bad = ok.copy()
+            bad[0, 0, pos] = v
+            with pytest.raises(FlowError):
+                write_jpeg([bad], 8, 8, [1], [1], 90, **kw)
