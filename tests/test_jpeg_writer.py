@@ -14,6 +14,8 @@ ImageFile.MAXBLOCK = 1 << 24          # Pillow's encoder buffer: optimised / pro
 from imageflow_amd import _native
 from oracle import oracle as O
 
+_ZIGZAG = (0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56,
+           57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63)
 ZIGZAG_SAMPLINGS = {"4:2:0": ([2, 1, 1], [2, 1, 1]), "4:2:2": ([2, 1, 1], [1, 1, 1]), "4:4:4": ([1, 1, 1], [1, 1, 1])}
 
 
@@ -167,3 +169,26 @@ def test_out_of_range_coefficients_are_refused():
             bad[0, 0, pos] = v
             with pytest.raises(FlowError):
                 write_jpeg([bad], 8, 8, [1], [1], 90, **kw)
+
+
+def test_long_end_of_band_runs_and_zero_runs():
+    """jcphuff.c flushes an end-of-band run at 0x7FFF blocks: a flat 2048x2048 gray image has 65 536 blocks with empty AC
+    bands.  And a checkerboard of isolated high-frequency content at low quality codes ZRL symbols (runs of 16 zeros)."""
+    flat = Image.fromarray(np.full((2048, 2048), 90, np.uint8))
+    y, x = np.mgrid[0:96, 0:128]
+    wave = 128 + 100 * np.cos((2 * (x % 8) + 1) * 7 * np.pi / 16) * np.cos((2 * (y % 8) + 1) * 7 * np.pi / 16)
+    stripes = Image.fromarray(np.clip(np.rint(wave), 0, 255).astype(np.uint8))  # the (7, 7) basis function alone: zigzag position 63 behind 62 zeros
+    for img, q in ((flat, 75), (stripes, 30), (stripes, 95)):
+        buf = io.BytesIO()
+        img.save(buf, "JPEG", quality=q, optimize=False)
+        j = O.jpeg_read_coefficients(buf.getvalue())
+        assert _write_flags(j, q, 0) == buf.getvalue()
+        for flags, kw in OPTIONS:
+            ref = io.BytesIO()
+            img.save(ref, "JPEG", quality=q, **kw)
+            assert _write_flags(j, q, flags) == ref.getvalue(), (img.size, q, flags)
+    zrl = 0xF0                                                                   # the stripes do use ZRL: symbol F0 occurs in the baseline scan
+    data = io.BytesIO(); stripes.save(data, "JPEG", quality=95, optimize=False)
+    blk = O.jpeg_read_coefficients(data.getvalue())["coef"][0][0, 0]
+    nz = [0] + [k for k in range(1, 64) if blk[_ZIGZAG[k]] != 0]
+    assert any(b - a > 16 for a, b in zip(nz, nz[1:])), (nz, zrl)
