@@ -1,0 +1,26 @@
+#!/bin/bash
+# Host code of the JPEG stages under AddressSanitizer + UndefinedBehaviorSanitizer (no GPU): the file writer on random
+# coefficient planes with every option, and the header parser + un-stuffing + decode-table builders + host walkers
+# (ifhip_jpeg_debug_scan_report) on mutated copies of committed files.  Builds into /tmp; prints one summary line each.
+set -eu
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
+W=/tmp/ifhip_sanitize; rm -rf $W; mkdir -p $W; cd $W
+INC="-I$ROOT/imageflow_amd/csrc -I$ROOT/include"
+SAN="-O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -std=c++17"
+g++ $SAN $INC -o writer_fuzz "$ROOT/tools/sanitize/writer_fuzz.cpp" "$ROOT/imageflow_amd/csrc/jpeg_write.cpp" "$ROOT/tools/sanitize/stubs.cpp"
+./writer_fuzz
+# the entropy file's host half: host-only compile of the .hip source; the device blob it would embed is an empty stand-in
+/opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 --cuda-host-only $SAN $INC -c "$ROOT/imageflow_amd/csrc/jpeg_entropy.hip" -o entropy_host.o 2>/dev/null
+SYM=$(nm entropy_host.o | awk '/__hip_fatbin_/ {print $2; exit}')
+printf '__attribute__((section(".hip_fatbin"))) const char %s[64] = {0};\n' "$SYM" > fatbin_stub.c
+gcc -c fatbin_stub.c -o fatbin_stub.o
+g++ $SAN $INC -c "$ROOT/tools/sanitize/parser_fuzz.cpp" -o parser_fuzz.o
+g++ $SAN -c "$ROOT/tools/sanitize/stubs.cpp" -o stubs.o
+/opt/rocm/lib/llvm/bin/clang++ -fsanitize=address,undefined -o parser_fuzz parser_fuzz.o entropy_host.o stubs.o fatbin_stub.o -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lpthread
+python3 - "$ROOT" <<'PY'
+import sys, numpy as np
+z = np.load(sys.argv[1] + "/tests/golden/jpeg_entropy_cases.npz")
+for i in (0, 5, 17, 33, 48, 60):
+    open(f"/tmp/ifhip_sanitize/case_{i}.jpg", "wb").write(z[f"jpg_{i}"].tobytes())
+PY
+ASAN_OPTIONS=detect_leaks=0 ./parser_fuzz case_*.jpg

@@ -1,0 +1,7 @@
+#include <cstdarg>
+#include <cstdio>
+namespace ifhip {   // the two functions of api.cpp the stage files call
+static thread_local char g_msg[512];
+int fail(int status, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_msg, sizeof g_msg, fmt, ap); va_end(ap); return status; }
+const char* last_error() { return g_msg; }
+}
