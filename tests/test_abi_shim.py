@@ -93,3 +93,44 @@ def test_context_memory():
     with Context() as c:
         p = c.L.imageflow_context_memory_allocate(c.p, 100, None, 0)
         assert p and c.L.imageflow_context_memory_free(c.p, p, None, 0) and not c.L.imageflow_context_memory_free(c.p, p, None, 0)
+
+
+def test_json_reader_survives_mutated_jobs():
+    """Untrusted bytes in `send_json`: byte mutations, truncations and deep nesting of real job bodies answer with an error
+    envelope (or get as far as needing the device) -- the process stays up and the context stays usable."""
+    import json
+    import random
+    rnd = random.Random(11)
+    jobs = [
+        {"io": [{"io_id": 0, "direction": "in", "io": "placeholder"}, {"io_id": 1, "direction": "out", "io": "output_buffer"}],
+         "framewise": {"steps": [{"decode": {"io_id": 0, "commands": [{"jpeg_downscale_hints": {"width": 800, "height": 600, "scale_luma_spatially": True,
+                                                                                                "gamma_correct_for_srgb_during_spatial_luma_scaling": True}}]}},
+                                 {"resample_2d": {"w": 200, "h": 200, "hints": {"down_filter": "robidoux", "scaling_colorspace": "linear", "sharpen_percent": 15,
+                                                                                  "background_color": {"srgb": {"hex": "FFFFFFFF"}}}}},
+                                 {"encode": {"io_id": 1, "preset": {"libjpeg_turbo": {"quality": 90, "progressive": True}}}}]}},
+        {"framewise": {"graph": {"nodes": {"0": {"create_canvas": {"w": 64, "h": 64, "format": "bgra_32", "color": "transparent"}},
+                                           "1": {"fill_rect": {"x1": 0, "y1": 0, "x2": 10, "y2": 10, "color": {"srgb": {"hex": "EECCFFFF"}}}},
+                                           "2": {"constrain": {"mode": "within", "w": 32}}, "3": {"command_string": {"kind": "ir4", "value": "width=20&mode=max"}}},
+                                 "edges": [{"from": 0, "to": 1, "kind": "input"}, {"from": 1, "to": 2, "kind": "input"}, {"from": 2, "to": 3, "kind": "input"}]}}},
+    ]
+    answered = 0
+    for job in jobs:
+        body = json.dumps(job).encode()
+        with Context() as c:
+            c.add_input_buffer(0, b"\xff\xd8\xff" + bytes(16))
+            c.add_output_buffer(1)
+            for _ in range(600):
+                m = bytearray(body)
+                for _ in range(rnd.randint(1, 5)):
+                    m[rnd.randrange(len(m))] = rnd.choice(b'{}[]",:0123456789truefalsn\\ \x00\xff' + bytes([rnd.randrange(256)]))
+                if rnd.random() < 0.2:
+                    m = m[:rnd.randrange(1, len(m))]
+                status, r = c.send_json(rnd.choice(["v1/execute", "v1/build"]), bytes(m))
+                assert status in (200, 400, 404, 500, 501, 503), status
+                assert r is None or "success" in r
+                answered += 1
+                c.L.imageflow_context_error_try_clear(c.p)
+            status, r = c.send_json("v1/execute", b"[" * 5000)          # nesting far beyond any job
+            assert status == 400
+            assert c.send_json("v1/get_version_info", {})[0] in (200, 400)      # still answering
+    assert answered == 1200

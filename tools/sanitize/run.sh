@@ -24,3 +24,28 @@ for i in (0, 5, 17, 33, 48, 60):
     open(f"/tmp/ifhip_sanitize/case_{i}.jpg", "wb").write(z[f"jpg_{i}"].tobytes())
 PY
 ASAN_OPTIONS=detect_leaks=0 ./parser_fuzz case_*.jpg
+# the whole library host-only (every translation unit, device blobs replaced by empty stand-ins) behind the libimageflow
+# ABI subset: damaged JSON jobs
+mkdir -p lib && : > fatbin_stubs.c
+OBJS=""
+for src in "$ROOT"/imageflow_amd/csrc/*.cpp "$ROOT"/imageflow_amd/csrc/*.hip; do
+  base=$(basename "$src")
+  if [ "$base" = "resample_fused.hip" ]; then
+    for k in 1 2 3 4 5 6 7 8; do
+      /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 --cuda-host-only $SAN $INC -DIFHIP_FUSED_K=$k -c "$src" -o lib/fused_$k.o 2>/dev/null &
+      OBJS="$OBJS lib/fused_$k.o"
+    done
+  else
+    /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 --cuda-host-only $SAN $INC -c "$src" -o lib/$base.o 2>/dev/null &
+    OBJS="$OBJS lib/$base.o"
+  fi
+done
+wait
+for o in $OBJS; do
+  for sym in $(nm $o | awk '/ U __hip_fatbin_/ {print $2}'); do printf '__attribute__((section(".hip_fatbin"))) const char %s[64] = {0};\n' "$sym" >> fatbin_stubs.c; done
+done
+sort -u fatbin_stubs.c -o fatbin_stubs.c
+gcc -c fatbin_stubs.c -o fatbin_stubs.o
+g++ $SAN $INC -c "$ROOT/tools/sanitize/json_fuzz.cpp" -o json_fuzz.o
+/opt/rocm/lib/llvm/bin/clang++ -fsanitize=address,undefined -o json_fuzz json_fuzz.o $OBJS fatbin_stubs.o -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lpthread
+ASAN_OPTIONS=detect_leaks=0 ./json_fuzz
