@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include "imageflow_abi_subset.h"
+#include "imageflow_hip.h"
 int main() {
     srand(5);
     const std::string jobs[2] = {
@@ -35,4 +36,17 @@ int main() {
         imageflow_context_destroy(c);
     }
     printf("answered %ld, errors %ld\n", answered, errors);
+    // filter-weight tables (graphics/weights.rs populate_weights) for random shapes, every filter id and a few outside
+    long tables = 0, refused = 0;
+    std::vector<uint32_t> left(8192), count(8192);
+    std::vector<float> w(1 << 20);
+    for (int it = 0; it < 3000; ++it) {
+        const int filter = rand() % 36 - 2, lobe = rand() % 4 - 1;
+        const uint32_t out_n = 1 + rand() % 4000, in_n = 1 + rand() % 8000;
+        uint32_t n = 0;
+        const int rc = ifhip_populate_weights(filter, lobe, static_cast<float>(rand() % 200) / 100.0f, (rand() % 4) ? 1.0 : 0.2 + (rand() % 300) / 100.0,
+                                              out_n, in_n, left.data(), count.data(), w.data(), static_cast<uint32_t>((rand() % 3) ? w.size() : rand() % 1000), &n);
+        if (rc == 0) ++tables; else ++refused;
+    }
+    printf("weight tables %ld, refused %ld\n", tables, refused);
 }
