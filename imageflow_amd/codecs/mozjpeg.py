@@ -138,6 +138,31 @@ def write_jpeg(coef, width, height, h_samp, v_samp, quality, progressive=False, 
     return out[:size.value].tobytes()
 
 
+def write_jpeg_batch(coef, width, height, h_samp, v_samp, quality, progressive=False, optimize_coding=False, threads=0):
+    """n images of one geometry: coef = planes [n][bh_c][bw_c][64] (numpy int16, 1 or 3 of them), coded on `threads` host
+    threads (0: one per core).  Returns the n files."""
+    L = _native.lib()
+    L.ifhip_jpeg_write_batch.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                         C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+    planes = [np.ascontiguousarray(c, np.int16) for c in coef]
+    ncomp, n = len(planes), planes[0].shape[0]
+    bw = np.array([p.shape[2] for p in planes] + [0] * (3 - ncomp), np.uint32)
+    bh = np.array([p.shape[1] for p in planes] + [0] * (3 - ncomp), np.uint32)
+    hs, vs = np.array(list(h_samp) + [1] * (3 - ncomp), np.uint8), np.array(list(v_samp) + [1] * (3 - ncomp), np.uint8)
+    flags = (JPEG_PROGRESSIVE if progressive else 0) | (JPEG_OPTIMIZE_HUFFMAN if optimize_coding else 0)
+    ptrs = [p.ctypes.data for p in planes] + [None] * (3 - ncomp)
+    total = C.c_size_t(0)
+    offsets, lengths = np.zeros(n, np.uintp), np.zeros(n, np.uintp)
+    args = ptrs + [bw.ctypes.data, bh.ctypes.data, ncomp, hs.ctypes.data, vs.ctypes.data, width, height, int(quality), flags, n, int(threads)]
+    out = np.empty(max(4096, sum(p.size for p in planes) // 2), np.uint8)
+    rc = L.ifhip_jpeg_write_batch(*args, out.ctypes.data, out.size, offsets.ctypes.data, lengths.ctypes.data, C.byref(total))
+    if rc != 0 and total.value > out.size:
+        out = np.empty(total.value, np.uint8)
+        rc = L.ifhip_jpeg_write_batch(*args, out.ctypes.data, out.size, offsets.ctypes.data, lengths.ctypes.data, C.byref(total))
+    _native.check(rc)
+    return [out[int(o):int(o) + int(k)].tobytes() for o, k in zip(offsets, lengths)]
+
+
 class MozjpegEncoder:
     """MozjpegEncoder::create_classic + write_frame (mozjpeg.rs:60-77, :78-160) over the device stages: apply_matte
     (default white, :88-92), the forward pixel stage at 4:2:0 (the maximum evalchroma may choose, :133) and the file
@@ -160,3 +185,14 @@ class MozjpegEncoder:
         qt = torch.from_numpy(np.stack([quant_tables_for_quality(self.quality)] * bitmap.n).view(np.int16)).to(bitmap.data.device)
         coef = [c[frame].cpu().numpy() for c in stage.write_frames(bitmap, qt)]
         return write_jpeg(coef, bitmap.w, bitmap.h, hs, vs, self.quality, self.progressive, self.optimize_coding)
+
+    def write_frames(self, bitmap: Bitmap, threads=0):
+        """Every frame of the bitmap: one device launch for the pixel stage, the files coded in parallel on the host."""
+        from ..graphics.blend import apply_matte
+        apply_matte(bitmap, self.matte)
+        bitmap.alpha_meaningful = False
+        hs, vs = sampling_factors((2, 2), (2, 2))
+        stage = JpegForwardStage(bitmap.w, bitmap.h, hs, vs, bitmap.n, bitmap.data.device)
+        qt = torch.from_numpy(np.stack([quant_tables_for_quality(self.quality)] * bitmap.n).view(np.int16)).to(bitmap.data.device)
+        coef = [c.cpu().numpy() for c in stage.write_frames(bitmap, qt)]
+        return write_jpeg_batch(coef, bitmap.w, bitmap.h, hs, vs, self.quality, self.progressive, self.optimize_coding, threads)

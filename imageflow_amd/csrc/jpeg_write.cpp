@@ -9,6 +9,8 @@
 // too: optimised Huffman tables (jpeg_gen_optimal_table) and progressive files (jpeg_simple_progression + jcphuff.c).
 #include <cstdint>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 #if defined(__SSE2__)
 #include <emmintrin.h>
@@ -567,6 +569,65 @@ int ifhip_jpeg_write(const int16_t* coef0, const int16_t* coef1, const int16_t* 
     if (capacity < bytes.size()) return ifhip::fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: output capacity %zu < %zu", capacity, bytes.size());
     std::memcpy(out, bytes.data(), bytes.size());
     return IFHIP_OK;
+}
+// A batch: n images of one geometry, coefficient planes [n][bh_c][bw_c][64] as the device stage leaves them (downloaded
+// to the host), coded on up to `threads` host threads (0: one per core, at most n) -- entropy coding is the serial part of
+// an encode, but serial per image only.  Files land in `out` at offsets[i] .. offsets[i] + lengths[i], packed in image
+// order; out == NULL or a short capacity: *total receives the size needed (and IFHIP_INVALID_ARGUMENT for the short case).
+int ifhip_jpeg_write_batch(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2, const uint32_t* blocks_w3,
+                           const uint32_t* blocks_h3, int n_components, const uint8_t* h_samp, const uint8_t* v_samp, uint32_t width,
+                           uint32_t height, int quality, int flags, uint32_t n_images, uint32_t threads, uint8_t* out, size_t capacity,
+                           size_t* offsets, size_t* lengths, size_t* total) {
+    if (!coef0 || !blocks_w3 || !blocks_h3 || !total || n_images == 0 || (n_components == 3 && (!coef1 || !coef2 || !h_samp || !v_samp)))
+        return ifhip::fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer or empty batch");
+    if (flags & ~3) return ifhip::fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: unknown flags 0x%x", flags);
+    if (n_components != 1 && n_components != 3) return ifhip::fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: 1 or 3 components");
+    try {
+        uint16_t qt[2][64];
+        ifhip::jpeg_quality_tables(quality, qt);
+        const uint8_t one[3] = {1, 1, 1};
+        size_t plane[3] = {0, 0, 0};
+        for (int c = 0; c < n_components; ++c) plane[c] = static_cast<size_t>(blocks_w3[c]) * blocks_h3[c] * 64u;
+        std::vector<std::vector<uint8_t>> files(n_images);
+        std::vector<int> rcs(n_images, IFHIP_OK);
+        std::vector<std::string> messages(n_images);
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const uint32_t n_threads = std::min<uint32_t>(n_images, threads ? threads : hw);
+        auto work = [&](uint32_t t) {
+            for (uint32_t i = t; i < n_images; i += n_threads) {
+                try {
+                    const int16_t* coef[3] = {coef0 + plane[0] * i, coef1 ? coef1 + plane[1] * i : nullptr, coef2 ? coef2 + plane[2] * i : nullptr};
+                    rcs[i] = ifhip::jpeg_write(coef, blocks_w3, blocks_h3, n_components, n_components == 3 ? h_samp : one,
+                                               n_components == 3 ? v_samp : one, width, height, qt, flags, &files[i]);
+                    if (rcs[i]) messages[i] = ifhip::last_error();
+                } catch (const std::bad_alloc&) { rcs[i] = IFHIP_ALLOCATION_FAILED; messages[i] = "AllocationFailed: host memory"; }
+            }
+        };
+        std::vector<std::thread> pool;
+        std::vector<uint32_t> inline_lanes{0u};
+        for (uint32_t t = 1; t < n_threads; ++t) {
+            try { pool.emplace_back(work, t); } catch (const std::exception&) { inline_lanes.push_back(t); }     // thread limits: the caller's thread takes the share
+        }
+        for (uint32_t t : inline_lanes) work(t);
+        for (auto& th : pool) th.join();
+        size_t sum = 0;
+        for (uint32_t i = 0; i < n_images; ++i) {
+            if (rcs[i]) return ifhip::fail(rcs[i], "%s (image %u of the batch)", messages[i].c_str(), i);
+            sum += files[i].size();
+        }
+        *total = sum;
+        if (!out) return IFHIP_OK;
+        if (capacity < sum) return ifhip::fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: output capacity %zu < %zu", capacity, sum);
+        size_t at = 0;
+        for (uint32_t i = 0; i < n_images; ++i) {
+            std::memcpy(out + at, files[i].data(), files[i].size());
+            if (offsets) offsets[i] = at;
+            if (lengths) lengths[i] = files[i].size();
+            at += files[i].size();
+        }
+        return IFHIP_OK;
+    } catch (const std::bad_alloc&) { return ifhip::fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: host memory"); }
+      catch (const std::exception& ex) { return ifhip::fail(IFHIP_INVALID_STATE, "InvalidState: %s", ex.what()); }
 }
 int ifhip_jpeg_write_baseline(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2, const uint32_t* blocks_w3,
                               const uint32_t* blocks_h3, int n_components, const uint8_t* h_samp, const uint8_t* v_samp, uint32_t width,

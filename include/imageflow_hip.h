@@ -255,6 +255,14 @@ IFHIP_API int ifhip_jpeg_write(const int16_t* coef0, const int16_t* coef1, const
                                const uint32_t* blocks_w3, const uint32_t* blocks_h3, int n_components,
                                const uint8_t* h_samp, const uint8_t* v_samp, uint32_t width, uint32_t height,
                                int quality, int flags, uint8_t* out, size_t capacity, size_t* len);
+/* The batch form: n_images of one geometry, planes [n_images][bh_c][bw_c][64] (what ifhip_jpeg_forward_batch_device leaves,
+ * downloaded), coded on up to `threads` host threads (0: one per core, at most n_images).  Files are packed into `out`
+ * in image order at offsets[i], lengths[i] long; out == NULL queries *total. */
+IFHIP_API int ifhip_jpeg_write_batch(const int16_t* coef0, const int16_t* coef1, const int16_t* coef2,
+                                     const uint32_t* blocks_w3, const uint32_t* blocks_h3, int n_components,
+                                     const uint8_t* h_samp, const uint8_t* v_samp, uint32_t width, uint32_t height,
+                                     int quality, int flags, uint32_t n_images, uint32_t threads,
+                                     uint8_t* out, size_t capacity, size_t* offsets, size_t* lengths, size_t* total);
 
 /* imageflow's 8x8 -> NxN spatial block scalers for the luma plane of a scaled decode: replaces
  * flow_scale_spatial[_srgb]_{1..7}x{1..7} (c_components/lib/codecs_jpeg_idct_fast.c, .h:17-43), the functions the IDCT

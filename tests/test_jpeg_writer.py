@@ -192,3 +192,34 @@ def test_long_end_of_band_runs_and_zero_runs():
     blk = O.jpeg_read_coefficients(data.getvalue())["coef"][0][0, 0]
     nz = [0] + [k for k in range(1, 64) if blk[_ZIGZAG[k]] != 0]
     assert any(b - a > 16 for a, b in zip(nz, nz[1:])), (nz, zrl)
+
+
+def test_batch_writer_equals_single_files_and_uses_threads():
+    """ifhip_jpeg_write_batch: n images of one geometry coded on host threads -- each file equals the single-image call."""
+    import time
+    from imageflow_amd.codecs.mozjpeg import write_jpeg, write_jpeg_batch
+    w, h, n = 320, 240, 12
+    planes = None
+    singles = []
+    for k in range(n):
+        buf = io.BytesIO()
+        Image.fromarray(_photo(w, h, 100 + k)).save(buf, "JPEG", quality=85, subsampling="4:2:0", optimize=False)
+        j = O.jpeg_read_coefficients(buf.getvalue())
+        if planes is None:
+            planes = [np.zeros((n,) + j["coef"][c].shape, np.int16) for c in range(3)]
+        for c in range(3):
+            planes[c][k] = j["coef"][c]
+        singles.append(buf.getvalue())
+    for kw in ({}, {"progressive": True}, {"optimize_coding": True}):
+        files = write_jpeg_batch(planes, w, h, j["hs"], j["vs"], 85, threads=4, **kw)
+        assert len(files) == n
+        for k in range(n):
+            assert files[k] == write_jpeg([p[k] for p in planes], w, h, j["hs"], j["vs"], 85, **kw), (k, kw)
+        if not kw:
+            assert files == singles
+    assert write_jpeg_batch(planes, w, h, j["hs"], j["vs"], 85, threads=1) == singles
+    planes[1][5, 0, 0, 3] = 5000                                     # one bad image fails the batch, and says which
+    from imageflow_amd.errors import FlowError
+    with pytest.raises(FlowError) as e:
+        write_jpeg_batch(planes, w, h, j["hs"], j["vs"], 85, threads=3)
+    assert "image 5" in str(e.value)
