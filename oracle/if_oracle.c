@@ -442,6 +442,19 @@ static void row_to_float(const uint8_t* row, uint32_t w, int alpha_meaningful, c
     }
 }
 
+/* Per-thread scratch, kept between calls: the batch leg (one frame per OpenMP thread, bench.py's cpu_baseline) used to
+ * malloc / free a few megabytes per frame, i.e. mmap / munmap and a thousand page faults per frame under the process's
+ * one address-space lock -- with a hundred threads that lock, not the arithmetic, set the rate. */
+static __thread struct { void* p; size_t cap; } tls_scratch[3];
+static void* scratch(int slot, size_t bytes) {
+    if (tls_scratch[slot].cap < bytes) {
+        free(tls_scratch[slot].p);
+        tls_scratch[slot].p = malloc(bytes);
+        tls_scratch[slot].cap = tls_scratch[slot].p ? bytes : 0;
+    }
+    return tls_scratch[slot].p;
+}
+
 /*
  * Resample to the f32 working buffer: out_f32[out_h][out_w][4], premultiplied working-space floats.
  */
@@ -451,10 +464,10 @@ static int resample_to_f32(const uint8_t* in, uint32_t in_w, uint32_t in_h, uint
     const float* lut = linear ? g_s2l : g_s2f;
     uint32_t ring_n = P->wv.max_taps + 1;
     size_t rowf = (size_t)in_w * 4;
-    float* ring = (float*)malloc(sizeof(float) * rowf * ring_n);
+    float* ring = (float*)scratch(0, sizeof(float) * rowf * ring_n);
     int64_t* tag = (int64_t*)malloc(sizeof(int64_t) * ring_n);
-    float* vrow = (float*)malloc(sizeof(float) * rowf);
-    if (!ring || !tag || !vrow) { free(ring); free(tag); free(vrow); return IFO_ERR_ALLOC; }
+    float* vrow = (float*)scratch(1, sizeof(float) * rowf);
+    if (!ring || !tag || !vrow) { free(tag); return IFO_ERR_ALLOC; }
     for (uint32_t i = 0; i < ring_n; i++) tag[i] = -1;
 
     for (uint32_t j = 0; j < out_h; j++) {
@@ -489,7 +502,7 @@ static int resample_to_f32(const uint8_t* in, uint32_t in_w, uint32_t in_h, uint
             orow[4 * u + 3] = alpha_meaningful ? a3 : 1.0f;
         }
     }
-    free(ring); free(tag); free(vrow);
+    free(tag);
     return IFO_OK;
 }
 
@@ -596,7 +609,7 @@ int ifo_scale_and_render(const uint8_t* in, uint32_t in_w, uint32_t in_h, uint32
     ifo_plan P;
     int rc = make_plan(&P, in_w, in_h, w, h, filter, sharpen_percent_goal);
     if (rc) return rc;
-    float* buf = f32_dump ? f32_dump : (float*)malloc(sizeof(float) * (size_t)w * h * 4);
+    float* buf = f32_dump ? f32_dump : (float*)scratch(2, sizeof(float) * (size_t)w * h * 4);
     if (!buf) { ifo_weights_free(&P.wv); ifo_weights_free(&P.wh); return IFO_ERR_ALLOC; }
     rc = resample_to_f32(in, in_w, in_h, in_stride, in_alpha_meaningful, linear, &P, w, h, buf);
     if (rc == IFO_OK) {
@@ -608,7 +621,6 @@ int ifo_scale_and_render(const uint8_t* in, uint32_t in_w, uint32_t in_h, uint32
             else composite_premul_f32_over_srgb_u8(linear, srow, crow, w, in_alpha_meaningful);
         }
     }
-    if (!f32_dump) free(buf);
     ifo_weights_free(&P.wv); ifo_weights_free(&P.wh);
     return rc;
 }
