@@ -46,6 +46,18 @@ def _bind():
     L.imageflow_context_add_output_buffer.restype = C.c_bool
     L.imageflow_context_get_output_buffer_by_id.argtypes = [vp, C.c_int32, u8pp, szp]
     L.imageflow_context_get_output_buffer_by_id.restype = C.c_bool
+    L.imageflow_context_take_output_buffer.argtypes = [vp, C.c_int32, u8pp, szp]
+    L.imageflow_context_take_output_buffer.restype = C.c_bool
+    L.imageflow_buffer_free.argtypes = [C.POINTER(C.c_uint8), C.c_size_t]
+    L.imageflow_buffer_free.restype = C.c_bool
+    L.imageflow_context_request_cancellation.argtypes = [vp]
+    L.imageflow_context_request_cancellation.restype = None
+    L.imageflow_context_print_and_exit_if_error.argtypes = [vp]
+    L.imageflow_context_print_and_exit_if_error.restype = C.c_bool
+    L.ifhip_shim_request_cancellation_after_n_polls.argtypes = [vp, C.c_int64]
+    L.ifhip_shim_request_cancellation_after_n_polls.restype = None
+    L.ifhip_shim_cancellation_polls_remaining.argtypes = [vp]
+    L.ifhip_shim_cancellation_polls_remaining.restype = C.c_int64
     L.imageflow_context_memory_allocate.argtypes = [vp, C.c_size_t, C.c_char_p, C.c_int32]
     L.imageflow_context_memory_allocate.restype = vp
     L.imageflow_context_memory_free.argtypes = [vp, vp, C.c_char_p, C.c_int32]
@@ -114,6 +126,18 @@ class Context:
         if not self.L.imageflow_context_get_output_buffer_by_id(self.p, io_id, C.byref(buf), C.byref(n)):
             return None
         return C.string_at(buf, n.value)
+
+    def take_output_buffer(self, io_id):
+        """imageflow_context_take_output_buffer + imageflow_buffer_free: the bytes, owned by the caller; None on error."""
+        buf, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+        if not self.L.imageflow_context_take_output_buffer(self.p, io_id, C.byref(buf), C.byref(n)):
+            return None
+        data = C.string_at(buf, n.value)
+        assert self.L.imageflow_buffer_free(buf, n.value)
+        return data
+
+    def request_cancellation(self):
+        self.L.imageflow_context_request_cancellation(self.p)
 
     def has_error(self):
         return self.L.imageflow_context_has_error(self.p)

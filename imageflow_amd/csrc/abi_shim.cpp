@@ -16,6 +16,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -35,13 +38,15 @@ namespace {
 
 // ---- errors: ErrorCategory (imageflow_core/src/errors.rs:779-838) with its exit / HTTP maps (:849-902) -----------
 enum Cat { kOk = 0, kOutOfMemory = 1, kArgumentInvalid = 2, kInvalidJson = 3, kImageMalformed = 4, kImageTypeNotSupported = 5,
-           kNodeArgumentInvalid = 6, kGraphInvalid = 7, kActionNotSupported = 8, kIoError = 16, kInternalError = 18 };
+           kNodeArgumentInvalid = 6, kGraphInvalid = 7, kActionNotSupported = 8, kIoError = 16, kInternalError = 18,
+           kOperationCancelled = 21 };
 int http_code(int c) {
     switch (c) {
     case kOk: return 200;
     case kArgumentInvalid: case kGraphInvalid: case kNodeArgumentInvalid: case kActionNotSupported: case kInvalidJson:
     case kImageMalformed: case kImageTypeNotSupported: return 400;
     case kOutOfMemory: return 503;
+    case kOperationCancelled: return 499;
     default: return 500;
     }
 }
@@ -52,6 +57,7 @@ int exit_code(int c) {
     case kInvalidJson: case kImageMalformed: case kImageTypeNotSupported: return 65;
     case kOutOfMemory: return 71;
     case kIoError: return 74;
+    case kOperationCancelled: return 130;
     default: return 70;
     }
 }
@@ -174,11 +180,23 @@ struct JParser {
         else if (c == 'f') { lit("false"); v.t = JVal::Bool; }
         else if (c == 'n') { lit("null"); }
         else {
-            char* e = nullptr;
-            const std::string tmp(p, static_cast<size_t>(std::min<long>(end - p, 64)));
-            v.n = std::strtod(tmp.c_str(), &e);
-            if (e == tmp.c_str()) bad("unexpected character");
-            p += e - tmp.c_str();
+            // RFC 8259 number grammar only: strtod alone would also take "inf", "nan", hex floats and leading '+'
+            const char* q = p;
+            if (q < end && *q == '-') ++q;
+            if (q >= end || *q < '0' || *q > '9') bad("unexpected character");
+            if (*q == '0') ++q; else while (q < end && *q >= '0' && *q <= '9') ++q;
+            if (q < end && *q == '.') { ++q; if (q >= end || *q < '0' || *q > '9') bad("bad number"); while (q < end && *q >= '0' && *q <= '9') ++q; }
+            if (q < end && (*q == 'e' || *q == 'E')) {
+                ++q;
+                if (q < end && (*q == '+' || *q == '-')) ++q;
+                if (q >= end || *q < '0' || *q > '9') bad("bad number");
+                while (q < end && *q >= '0' && *q <= '9') ++q;
+            }
+            if (q - p > 64) bad("number too long");
+            const std::string tmp(p, static_cast<size_t>(q - p));
+            v.n = std::strtod(tmp.c_str(), nullptr);
+            if (!std::isfinite(v.n)) bad("number out of range");
+            p = q;
             v.t = JVal::Num;
         }
         --depth;
@@ -194,7 +212,8 @@ JVal parse_json(const uint8_t* buf, size_t n) {
 }
 int64_t want_int(const JVal& o, const char* key, const char* node) {
     const JVal* v = o.get(key);
-    if (!v || v->t != JVal::Num || v->n != std::floor(v->n)) raise(kInvalidJson, "InvalidJson: %s.%s must be an integer", node, key);
+    if (!v || v->t != JVal::Num || v->n != std::floor(v->n) || std::fabs(v->n) > 9007199254740992.0)
+        raise(kInvalidJson, "InvalidJson: %s.%s must be an integer", node, key);
     return static_cast<int64_t>(v->n);
 }
 uint32_t want_u32(const JVal& o, const char* key, const char* node) {
@@ -218,13 +237,13 @@ uint32_t parse_color(const JVal* v, const char* node) {
     if (!s.empty() && s[0] == '#') s.erase(0, 1);
     if (s.size() == 3 || s.size() == 4) { std::string d; for (char c : s) { d.push_back(c); d.push_back(c); } s = d; }
     if (s.size() == 6) s += "FF";
-    if (s.size() != 8) raise(kNodeArgumentInvalid, "InvalidNodeParams: %s: bad colour '%s'", node, hex->s.c_str());
+    if (s.size() != 8) raise(kArgumentInvalid, "InvalidNodeParams: %s: bad colour '%s'", node, hex->s.c_str());
     uint32_t ch[4];
     for (int i = 0; i < 4; ++i) {
         char* e = nullptr;
         const std::string part = s.substr(static_cast<size_t>(2 * i), 2);
         ch[i] = static_cast<uint32_t>(std::strtoul(part.c_str(), &e, 16));
-        if (e != part.c_str() + 2) raise(kNodeArgumentInvalid, "InvalidNodeParams: %s: bad colour '%s'", node, hex->s.c_str());
+        if (e != part.c_str() + 2) raise(kArgumentInvalid, "InvalidNodeParams: %s: bad colour '%s'", node, hex->s.c_str());
     }
     return (ch[3] << 24) | (ch[0] << 16) | (ch[1] << 8) | ch[2];
 }
@@ -251,29 +270,36 @@ struct Frame {                                   // graphics/bitmaps.rs Bitmap: 
     ~Frame() { if (d) (void)hipFree(d); }
 };
 using FramePtr = std::shared_ptr<Frame>;
-FramePtr new_frame(uint32_t w, uint32_t h, bool alpha, uint32_t fill_color32 = 0, bool zero = true) {
-    if (w == 0 || h == 0) raise(kArgumentInvalid, "InvalidArgument: Bitmap dimensions cannot be zero");
-    auto f = std::make_shared<Frame>();
-    f->w = w; f->h = h; f->stride = ifhip_stride_for_width(w); f->alpha = alpha;
-    hip_check(hipMalloc(reinterpret_cast<void**>(&f->d), f->bytes() + 64), "hipMalloc(frame)");
-    if (zero) hip_check(hipMemsetAsync(f->d, 0, f->bytes() + 64, nullptr), "hipMemset(frame)");
-    if (fill_color32 >> 24) {                    // create_canvas.rs:77-103 / bitmaps.rs:829-837: matte canvases start filled
-        f->compose = IFHIP_BLEND_WITH_MATTE; f->matte = fill_color32;
-        check(ifhip_fill_rect_batch_device(f->d, f->bytes(), 1, w, h, f->stride, IFHIP_REPLACE_SELF, 0, 0, w, h, fill_color32, nullptr));
-    }
-    return f;
+
+// ExecutionSecurity (imageflow_types/src/lib.rs:1199-1236): the two limits that bound what this library allocates;
+// defaults = sane_defaults(), a job may override them with `security` (v1/execute) / `builder_config.security` (v1/build)
+struct SizeLimit { uint32_t w, h; float megapixels; };
+struct Security {
+    SizeLimit max_decode_size{12000, 12000, 100.f};
+    SizeLimit max_frame_size{10000, 10000, 100.f};
+};
+// Engine::validate_frame_size (flow/execution_engine.rs:286-325); ErrorKind::SizeLimitExceeded -> ArgumentInvalid
+void check_size(const SizeLimit& lim, const char* what, uint64_t w, uint64_t h) {
+    if (w > lim.w) raise(kArgumentInvalid, "SizeLimitExceeded: Frame width %llu exceeds %s.w %u", static_cast<unsigned long long>(w), what, lim.w);
+    if (h > lim.h) raise(kArgumentInvalid, "SizeLimitExceeded: Frame height %llu exceeds %s.h %u", static_cast<unsigned long long>(h), what, lim.h);
+    const float mp = static_cast<float>(w) * static_cast<float>(h) / 1000000.f;
+    if (mp > lim.megapixels) raise(kArgumentInvalid, "SizeLimitExceeded: Frame megapixels %f exceeds %s.megapixels %f", static_cast<double>(mp), what, static_cast<double>(lim.megapixels));
 }
 
 constexpr char kRawMagic[8] = {'I', 'F', 'B', 'G', 'R', 'A', '1', '\0'};
 constexpr size_t kRawHeader = 8 + 16;
 
 // ---- context -----------------------------------------------------------------------------------------------------
+// Output buffers: Ready -> (get_output_buffer_by_id) Lent -> stays Lent; Ready -> (take_output_buffer) Taken
+// (CodecInstanceContainer, imageflow_core/src/codecs/mod.rs:421-436,560-626)
+enum class OutState { Ready, Lent, Taken };
 struct Io {
     bool is_output = false;
     const uint8_t* in = nullptr;
     size_t in_len = 0;
     std::vector<uint8_t> owned;                  // copied inputs (lifetime_outlives_function_call) / output bytes
     bool written = false;
+    OutState out_state = OutState::Ready;
 };
 struct Response {
     int64_t status;
@@ -291,6 +317,15 @@ struct imageflow_context {
     std::string err_msg;
     std::vector<std::unique_ptr<imageflow_json_response>> responses;
     std::vector<std::unique_ptr<uint8_t[]>> allocations;
+    // CancellationToken (imageflow_core/src/context.rs:50-131): a flag another thread may set while a job holds `mu`,
+    // and the reference's debug-build poll countdown ("cancel at the n-th poll", :96-104) as a test hook
+    std::atomic<bool> cancel{false};
+    std::atomic<int64_t> poll_countdown{INT64_MAX};
+    bool cancellation_requested() {
+        if (cancel.load(std::memory_order_relaxed)) return true;
+        if (poll_countdown.load(std::memory_order_relaxed) == INT64_MAX) return false;
+        return poll_countdown.fetch_sub(1, std::memory_order_relaxed) < 1;
+    }
     void set_error(int cat, const std::string& m) { if (err_cat == kOk) { err_cat = cat; err_msg = m; } }   // first error sticks
 };
 
@@ -317,13 +352,117 @@ const imageflow_json_response* respond_error(imageflow_context* c, int cat, cons
                                 json_escape(msg) + "\",\n  \"data\": {\n    \"none\": null\n  }\n}");
 }
 
+// ---- sizing: AspectRatio::proportional (imageflow_riapi/src/sizing.rs:118-185) ------------------------------------
+// The other side of a box that keeps `sw x sh`'s ratio, snapping to the source's own side or to the requested box when
+// the rounding loss of the requested box explains the difference (:83-116).
+double rust_round(double v) { return std::round(v); }            // f64::round: half away from zero, as C's round()
+int64_t proportional(int64_t sw, int64_t sh, int64_t basis, bool basis_is_width, bool have_target, int64_t tw, int64_t th) {
+    const double ratio = static_cast<double>(sw) / static_cast<double>(sh);
+    double snap_amount = 1.0 - 2.220446049250313e-16;
+    if (have_target) {
+        if (!basis_is_width) {                                    // rounding_loss_based_on_target_width (:83-98)
+            const double recreate_y = static_cast<double>(sh) * (static_cast<double>(tw) / static_cast<double>(sw));
+            snap_amount = std::fabs(static_cast<double>(tw) - rust_round(recreate_y) * ratio);
+        } else {                                                  // rounding_loss_based_on_target_height (:99-115)
+            const double recreate_x = static_cast<double>(sw) * (static_cast<double>(th) / static_cast<double>(sh));
+            snap_amount = std::fabs(static_cast<double>(th) - rust_round(recreate_x) / ratio);
+        }
+    }
+    const int64_t snap_a = basis_is_width ? sh : sw;
+    const int64_t snap_b = have_target ? (basis_is_width ? th : tw) : snap_a;
+    const double f = basis_is_width ? static_cast<double>(basis) / ratio : ratio * static_cast<double>(basis);
+    const double da = std::fabs(f - static_cast<double>(snap_a)), db = std::fabs(f - static_cast<double>(snap_b));
+    int64_t v;
+    if (da <= snap_amount && da <= db) v = snap_a;
+    else if (db <= snap_amount) v = snap_b;
+    else {
+        const double r = rust_round(f);
+        if (r <= -2147483648.0 || r >= 2147483647.0) raise(kArgumentInvalid, "LayoutError: ValueScalingFailed");
+        v = static_cast<int64_t>(r);
+    }
+    if (v < 0) raise(kArgumentInvalid, "LayoutError: ValueScalingFailed");
+    return v == 0 ? 1 : v;
+}
+// AspectRatio::box_of(target, Inner) (:189-197): the largest sw:sh box inside tw x th
+void inner_box(int64_t sw, int64_t sh, int64_t tw, int64_t th, int64_t* ow, int64_t* oh) {
+    const double rs = static_cast<double>(sw) / static_cast<double>(sh), rt = static_cast<double>(tw) / static_cast<double>(th);
+    if (rs > rt) { *ow = tw; *oh = proportional(sw, sh, tw, true, true, tw, th); }
+    else { *ow = proportional(sw, sh, th, false, true, tw, th); *oh = th; }
+}
+
 // ---- the job interpreter ---------------------------------------------------------------------------------------
 struct EncodeRecord { int32_t io_id; uint32_t w, h; const char* mime; const char* ext; };
 struct DecodeRecord { int32_t io_id; uint32_t w, h; const char* mime; const char* ext; };
+struct NodePerf { const char* name; uint64_t wall_ns; float gpu_ms; };        // s::NodePerf (imageflow_types/src/lib.rs:1999-2002)
+struct ResampleHints {                                                        // s::ResampleHints (lib.rs:925-933), parsed
+    bool has_sharpen = false;
+    float sharpen = 0.f;
+    int down = IFHIP_FILTER_ROBIDOUX, up = IFHIP_FILTER_GINSENG, space = IFHIP_SPACE_LINEAR;   // scale_render.rs:257-261,278-279
+    bool has_bg = false, bg_keyword_transparent = false;
+    uint32_t bg = 0;
+    enum When { kDefault, kSizeDiffers, kSizeDiffersOrSharpen, kAlways } resample_when = kDefault;
+    enum SWhen { kSAlways, kSDown, kSUp, kSSizeDiffers } sharpen_when = kSAlways;
+};
+
 struct Job {
     imageflow_context* c;
     std::vector<EncodeRecord> encodes;
     std::vector<DecodeRecord> decodes;
+    std::vector<NodePerf> perf;
+    Security sec;
+    std::chrono::steady_clock::time_point t_start = std::chrono::steady_clock::now();
+
+    // return_if_cancelled! (imageflow_core/src/errors.rs:124-140; polled in Engine::graph_execute before every node,
+    // execution_engine.rs:502, at every bitmap borrow, context.rs:389-401, and inside the codecs)
+    void poll_cancel() {
+        if (c->cancellation_requested()) raise(kOperationCancelled, "OperationCancelled: the job was cancelled");
+    }
+
+    // one executed primitive: wall clock as the reference's per-node cost (execution_engine.rs:506-538) plus the time
+    // the device spent on it (hipEvents on the stream every node of this interpreter launches on)
+    struct Timed {
+        Job* j; const char* name; std::chrono::steady_clock::time_point t0; hipEvent_t e0 = nullptr, e1 = nullptr;
+        Timed(Job* job, const char* n) : j(job), name(n), t0(std::chrono::steady_clock::now()) {
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, nullptr) != hipSuccess) {
+                (void)hipGetLastError();
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+                e0 = e1 = nullptr;
+            }
+        }
+        ~Timed() {
+            float ms = 0.f;
+            if (e0) {
+                if (hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
+            }
+            const auto ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            j->perf.push_back({name, static_cast<uint64_t>(ns), ms});
+        }
+    };
+
+    FramePtr new_frame(uint32_t w, uint32_t h, bool alpha, uint32_t fill_color32 = 0, bool zero = true) {
+        if (w == 0 || h == 0) raise(kArgumentInvalid, "InvalidArgument: Bitmap dimensions cannot be zero");
+        check_size(sec.max_frame_size, "max_frame_size", w, h);
+        poll_cancel();                                               // borrow_bitmaps_mut (context.rs:389)
+        auto f = std::make_shared<Frame>();
+        f->w = w; f->h = h; f->stride = ifhip_stride_for_width(w); f->alpha = alpha;
+        if (f->stride == 0) raise(kArgumentInvalid, "InvalidArgument: Bitmap width %u has no 32-bit stride", w);
+        hip_check(hipMalloc(reinterpret_cast<void**>(&f->d), f->bytes() + 64), "hipMalloc(frame)");
+        if (zero) hip_check(hipMemsetAsync(f->d, 0, f->bytes() + 64, nullptr), "hipMemset(frame)");
+        if (fill_color32 >> 24) {                    // create_canvas.rs:77-103 / bitmaps.rs:829-837: matte canvases start filled
+            f->compose = IFHIP_BLEND_WITH_MATTE; f->matte = fill_color32;
+            check(ifhip_fill_rect_batch_device(f->d, f->bytes(), 1, w, h, f->stride, IFHIP_REPLACE_SELF, 0, 0, w, h, fill_color32, nullptr));
+        }
+        return f;
+    }
+    FramePtr clone(const FramePtr& in) {                              // flow/nodes/clone_crop_fill_expand.rs:140-175
+        FramePtr c2 = new_frame(in->w, in->h, in->alpha, 0, false);
+        hip_check(hipMemcpyAsync(c2->d, in->d, in->bytes(), hipMemcpyDeviceToDevice, nullptr), "clone");
+        c2->compose = in->compose; c2->matte = in->matte;
+        return c2;
+    }
 
     Io& input(int32_t id) {
         auto it = c->io.find(id);
@@ -336,8 +475,27 @@ struct Job {
         return it->second;
     }
 
+    // header facts of an input (get_scaled_rotated_image_info's part that watermark / command_string need)
+    void image_size(int32_t io_id, uint32_t* w, uint32_t* h) {
+        Io& in = input(io_id);
+        if (in.in_len >= kRawHeader && std::memcmp(in.in, kRawMagic, 8) == 0) {
+            uint32_t hdr[4];
+            std::memcpy(hdr, in.in + 8, 16);
+            *w = hdr[0]; *h = hdr[1];
+            return;
+        }
+        int nc = 0;
+        uint8_t hs[3], vs[3];
+        uint32_t bw[3], bh[3], ri = 0;
+        uint16_t qt[192];
+        if (in.in_len < 3 || in.in[0] != 0xFF || in.in[1] != 0xD8)
+            raise(kImageTypeNotSupported, "ImageTypeNotSupported: io_id %d is neither a JPEG nor the raw BGRA extension", io_id);
+        check(ifhip_jpeg_parse_headers(in.in, in.in_len, w, h, &nc, hs, vs, bw, bh, qt, &ri));
+    }
+
     // decode: MozJpegDecoder::read_frame (codecs/mozjpeg_decoder.rs:295-420) on the device, or the raw extension
     FramePtr decode(int32_t io_id, uint32_t hint_w, uint32_t hint_h, bool luma_spatial, bool luma_srgb) {
+        Timed t(this, "primitive_decoder");
         Io& in = input(io_id);
         if (in.in_len >= kRawHeader && std::memcmp(in.in, kRawMagic, 8) == 0) {
             uint32_t hdr[4];
@@ -345,6 +503,7 @@ struct Job {
             const uint32_t w = hdr[0], h = hdr[1], stride = hdr[2];
             if (w == 0 || h == 0 || stride < w * 4ull || (stride & 3u) || in.in_len < kRawHeader + static_cast<size_t>(h - 1) * stride + w * 4ull)
                 raise(kImageMalformed, "ImageMalformed: raw BGRA container header does not match its length");
+            check_size(sec.max_decode_size, "max_decode_size", w, h);
             FramePtr f = new_frame(w, h, hdr[3] != 0, 0, true);
             hip_check(hipMemcpy2D(f->d, f->stride, in.in + kRawHeader, stride, w * 4ull, h, hipMemcpyHostToDevice), "upload(raw frame)");
             decodes.push_back({io_id, w, h, "application/x-imageflow-bgra", "ifbgra"});
@@ -352,6 +511,11 @@ struct Job {
         }
         if (in.in_len < 3 || in.in[0] != 0xFF || in.in[1] != 0xD8)                        // codecs/mod.rs:398-415 sniffing
             raise(kImageTypeNotSupported, "ImageTypeNotSupported: io_id %d is neither a JPEG nor the raw BGRA extension", io_id);
+        {   // limits before anything is staged (mozjpeg_decoder.rs:196-214 checks max_decode_size on the header)
+            uint32_t hw = 0, hh = 0;
+            image_size(io_id, &hw, &hh);
+            check_size(sec.max_decode_size, "max_decode_size", hw, hh);
+        }
         ifhip_jpeg_entropy* ent = nullptr;
         const uint8_t* files[1] = {in.in};
         const size_t lens[1] = {in.in_len};
@@ -375,6 +539,7 @@ struct Job {
         struct CoefGuard { int16_t** p; ~CoefGuard() { for (int i = 0; i < 3; ++i) if (p[i]) (void)hipFree(p[i]); } } cg{coef};
         for (int k = 0; k < 3; ++k)
             hip_check(hipMalloc(reinterpret_cast<void**>(&coef[k]), std::max<size_t>(1, static_cast<size_t>(bw[k]) * bh[k]) * 128), "hipMalloc(coefficients)");
+        poll_cancel();                                               // the decoder's cancellation point (mozjpeg_decoder.rs:346-362 loop)
         uint32_t rounds = 0;
         check(ifhip_jpeg_entropy_decode_device(ent, coef[0], coef[1], coef[2], &rounds, nullptr));
         uint16_t qt[192];
@@ -396,68 +561,141 @@ struct Job {
         return f;
     }
 
-    // Resample2D -> CreateCanvas + Scale2d -> DrawImageExact.render -> scale_and_render (scale_render.rs:30-320)
-    FramePtr resample(const FramePtr& in, uint32_t w, uint32_t h, const JVal* hints) {
-        if (w == 0 || h == 0) raise(kNodeArgumentInvalid, "InvalidNodeParams: resample_2d target size must be non-zero");
-        float sharpen = 0.f;
-        int down = IFHIP_FILTER_ROBIDOUX, up = IFHIP_FILTER_GINSENG, space = IFHIP_SPACE_LINEAR;     // :255-259, :276-277
-        uint32_t bg = 0;
-        bool when_always = false;
-        if (hints && !hints->is_null()) {
-            if (const JVal* s = hints->get("sharpen_percent")) if (s->t == JVal::Num) sharpen = static_cast<float>(s->n);
-            down = parse_filter(hints->get("down_filter"), down);
-            up = parse_filter(hints->get("up_filter"), up);
-            if (const JVal* cs = hints->get("scaling_colorspace"))
-                if (cs->t == JVal::Str) {
-                    if (cs->s == "srgb") space = IFHIP_SPACE_SRGB;
-                    else if (cs->s != "linear") raise(kInvalidJson, "InvalidJson: scaling_colorspace must be srgb or linear");
-                }
-            bg = parse_color(hints->get("background_color"), "resample_2d.hints.background_color");
-            if (const JVal* rw = hints->get("resample_when")) when_always = rw->t == JVal::Str && rw->s == "always";
+    static ResampleHints parse_hints(const JVal* hints, const char* node) {
+        ResampleHints r;
+        if (!hints || hints->is_null()) return r;
+        if (hints->t != JVal::Obj) raise(kInvalidJson, "InvalidJson: %s.hints must be an object", node);
+        if (const JVal* s = hints->get("sharpen_percent")) if (s->t == JVal::Num) { r.has_sharpen = true; r.sharpen = static_cast<float>(s->n); }
+        r.down = parse_filter(hints->get("down_filter"), r.down);
+        r.up = parse_filter(hints->get("up_filter"), r.up);
+        if (const JVal* cs = hints->get("scaling_colorspace"))
+            if (cs->t == JVal::Str) {
+                if (cs->s == "srgb") r.space = IFHIP_SPACE_SRGB;
+                else if (cs->s != "linear") raise(kInvalidJson, "InvalidJson: scaling_colorspace must be srgb or linear");
+            }
+        if (const JVal* b = hints->get("background_color"))
+            if (!b->is_null()) {
+                r.has_bg = true;
+                r.bg_keyword_transparent = b->t == JVal::Str && b->s == "transparent";
+                r.bg = parse_color(b, "hints.background_color");
+            }
+        if (const JVal* rw = hints->get("resample_when"))
+            if (rw->t == JVal::Str) {                                                // s::ResampleWhen (lib.rs:899-907)
+                if (rw->s == "always") r.resample_when = ResampleHints::kAlways;
+                else if (rw->s == "size_differs") r.resample_when = ResampleHints::kSizeDiffers;
+                else if (rw->s == "size_differs_or_sharpening_requested") r.resample_when = ResampleHints::kSizeDiffersOrSharpen;
+                else raise(kInvalidJson, "InvalidJson: unknown resample_when '%s'", rw->s.c_str());
+            }
+        if (const JVal* sw = hints->get("sharpen_when"))
+            if (sw->t == JVal::Str) {                                                // s::SharpenWhen
+                if (sw->s == "always") r.sharpen_when = ResampleHints::kSAlways;
+                else if (sw->s == "downscaling") r.sharpen_when = ResampleHints::kSDown;
+                else if (sw->s == "upscaling") r.sharpen_when = ResampleHints::kSUp;
+                else if (sw->s == "size_differs") r.sharpen_when = ResampleHints::kSSizeDiffers;
+                else raise(kInvalidJson, "InvalidJson: unknown sharpen_when '%s'", sw->s.c_str());
+            }
+        return r;
+    }
+    static float gated_sharpen(const ResampleHints& hi, uint32_t w, uint32_t h, uint32_t in_w, uint32_t in_h) {   // scale_render.rs:55-65, 263-274
+        const bool size_differs = w != in_w || h != in_h, downscaling = w < in_w || h < in_h, upscaling = w > in_w || h > in_h;
+        const float raw = hi.has_sharpen ? hi.sharpen : 0.f;
+        switch (hi.sharpen_when) {
+        case ResampleHints::kSAlways: return raw;
+        case ResampleHints::kSDown: return downscaling ? raw : 0.f;
+        case ResampleHints::kSUp: return upscaling ? raw : 0.f;
+        case ResampleHints::kSSizeDiffers: return size_differs ? raw : 0.f;
         }
-        const bool matte = (bg >> 24) != 0;
-        // resample_when default SizeDiffersOrSharpeningRequested: a same-size, unsharpened resample is removed from the
-        // graph unless a matte has to be applied to a Bgra32 parent (scale_render.rs:38-49,68-80,113-115)
-        if (!when_always && w == in->w && h == in->h && sharpen <= 0.f && !(matte && in->alpha)) return in;
-        const bool downscale = w < in->w || h < in->h;                                // :255-259
-        FramePtr canvas = new_frame(w, h, in->alpha, matte ? bg : 0u, true);
-        const int compose = matte ? IFHIP_BLEND_WITH_MATTE : IFHIP_REPLACE_SELF;      // blend: Overwrite when bg transparent (:169-192)
+        return raw;
+    }
+
+    // DrawImageDef::render (flow/nodes/scale_render.rs:221-320): the one caller of the hot path.  compose = the
+    // node's `blend` (None = Compose).
+    void draw_image_exact(const FramePtr& canvas, const FramePtr& in, uint32_t x, uint32_t y, uint32_t w, uint32_t h, bool compose, const ResampleHints& hi) {
+        Timed t(this, "draw_image_to_canvas");
+        if (canvas == in) raise(kGraphInvalid, "InvalidNodeConnections: Canvas and Input are the same bitmap!");
+        if (static_cast<uint64_t>(x) + w > canvas->w || static_cast<uint64_t>(y) + h > canvas->h)                       // :237-240
+            raise(kArgumentInvalid, "InvalidNodeParams: DrawImageExact target rect x1=%u,y1=%u,w=%u,h=%u does not fit canvas size %ux%u.", x, y, w, h, canvas->w, canvas->h);
+        if (w == 0 || h == 0) raise(kArgumentInvalid, "InvalidNodeParams: DrawImageExact target size must be non-zero");
+        if (hi.resample_when != ResampleHints::kDefault && hi.resample_when != ResampleHints::kAlways)                 // :246-251
+            raise(kArgumentInvalid, "InvalidNodeParams: DrawImageExact already has a canvas and cannot honor ResampleWhen");
+        const bool upscaling = w > in->w || h > in->h;                                                                 // :253
+        const int filter = upscaling ? hi.up : hi.down;                                                                // :257-261
+        const float sharpen = gated_sharpen(hi, w, h, in->w, in->h);
+        if (canvas->compose == IFHIP_REPLACE_SELF && compose) canvas->compose = IFHIP_BLEND_WITH_SELF;                 // :284-286
+        if (canvas->compose == IFHIP_BLEND_WITH_MATTE && !compose && canvas->alpha) canvas->compose = IFHIP_REPLACE_SELF;   // :287-292
+        poll_cancel();
         ifhip_resample_plan* plan = nullptr;
-        check(ifhip_resample_plan_create(&plan, in->w, in->h, w, h, downscale ? down : up, sharpen));
+        check(ifhip_resample_plan_create(&plan, in->w, in->h, w, h, filter, sharpen));
         struct PlanGuard { ifhip_resample_plan* p; ~PlanGuard() { ifhip_resample_plan_destroy(p); } } pg{plan};
         check(ifhip_scale_and_render_batch_device(plan, in->d, in->bytes(), in->stride, in->alpha ? 1 : 0, 1, canvas->d, canvas->bytes(),
-                                                  w, h, canvas->stride, 0, 0, space, compose, bg, nullptr, -1, nullptr));
-        hip_check(hipStreamSynchronize(nullptr), "resample_2d");
-        if (matte && (bg >> 24) == 255) canvas->alpha = false;                        // an opaque matte leaves no meaningful alpha
-        canvas->compose = IFHIP_BLEND_WITH_SELF;                                      // :314
+                                                  canvas->w, canvas->h, canvas->stride, x, y, hi.space, canvas->compose, canvas->matte, nullptr, -1, nullptr));
+        hip_check(hipStreamSynchronize(nullptr), "draw_image_exact");
+        canvas->compose = IFHIP_BLEND_WITH_SELF;                                                                       // :314
+    }
+
+    // Resample2D (scale_render.rs:30-120): removed from the graph unless it resamples or has a matte to apply to a
+    // Bgra32 parent; otherwise CreateCanvas{parent.fmt, background_color} + Scale2d, which becomes DrawImageExact with
+    // blend = Overwrite when the background is transparent (:139-201)
+    FramePtr resample(const FramePtr& in, uint32_t w, uint32_t h, const JVal* hints_json) {
+        if (w == 0 || h == 0) raise(kArgumentInvalid, "InvalidNodeParams: resample_2d target size must be non-zero");
+        ResampleHints hi = parse_hints(hints_json, "resample_2d");
+        const bool size_differs = w != in->w || h != in->h;
+        const bool apply_matte = in->alpha && hi.has_bg && !hi.bg_keyword_transparent;                                 // :44-47
+        const float sharpen = gated_sharpen(hi, w, h, in->w, in->h);
+        const bool sharpen_requested = sharpen != 0.f;                                                                 // :67
+        bool do_resample = false;
+        switch (hi.resample_when) {                                                                                    // :69-78
+        case ResampleHints::kAlways: do_resample = true; break;
+        case ResampleHints::kSizeDiffers: do_resample = size_differs; break;
+        default: do_resample = size_differs || sharpen_requested; break;
+        }
+        if (!do_resample && !apply_matte) return in;                                                                   // delete_node_and_snap_together (:115)
+        hi.has_sharpen = true; hi.sharpen = sharpen;                                                                   // Some(sharpen_percent), sharpen_when passed on (:84-94)
+        hi.resample_when = ResampleHints::kAlways;
+        const uint32_t bg = hi.has_bg ? hi.bg : 0u;
+        FramePtr canvas;
+        {
+            Timed t(this, "create_canvas");
+            canvas = new_frame(w, h, in->alpha, bg, true);                                                             // format: parent.fmt (:96-105)
+        }
+        draw_image_exact(canvas, in, 0, 0, w, h, (bg >> 24) != 0, hi);                                                 // blend Overwrite iff bgcolor.is_transparent() (:176-184)
+        if ((bg >> 24) == 255) canvas->alpha = false;                                 // an opaque matte leaves no meaningful alpha
         return canvas;
     }
 
     // constrain (flow/nodes/constrain.rs:41-98 -> imageflow_riapi process_constraint): the aspect-preserving modes that
-    // need neither crop nor pad; target rounding as AspectRatio::proportional (imageflow_riapi/src/sizing.rs:118-185).
-    FramePtr constrain(const FramePtr& in, const JVal& p) {
-        const JVal* mode = p.get("mode");
-        const std::string m = mode && mode->t == JVal::Str ? mode->s : "";
+    // need neither crop nor pad; sizes by AspectRatio::proportional / box_of (imageflow_riapi/src/sizing.rs:118-197).
+    static void constrain_size(const std::string& m, uint32_t sw, uint32_t sh, bool has_w, bool has_h, int64_t tw, int64_t th, uint32_t* ow, uint32_t* oh) {
+        int64_t w = sw, h = sh;
+        if (m == "distort") { w = has_w ? tw : (has_h ? proportional(sw, sh, th, false, false, 0, 0) : sw); h = has_h ? th : (has_w ? proportional(sw, sh, tw, true, false, 0, 0) : sh); }
+        else if (has_w && has_h) {
+            if (m == "fit" || sw > tw || sh > th) inner_box(sw, sh, tw, th, &w, &h);         // within never up-scales
+        } else if (has_w) {
+            if (m == "fit" || sw > tw) { w = tw; h = proportional(sw, sh, tw, true, false, 0, 0); }
+        } else if (has_h) {
+            if (m == "fit" || sh > th) { h = th; w = proportional(sw, sh, th, false, false, 0, 0); }
+        }
+        *ow = static_cast<uint32_t>(w); *oh = static_cast<uint32_t>(h);
+    }
+    static void constrain_params(const JVal& p, const char* node, std::string* mode, bool* has_w, bool* has_h, int64_t* tw, int64_t* th) {
+        const JVal* jm = p.get("mode");
+        *mode = jm && jm->t == JVal::Str ? jm->s : "";
         const JVal *jw = p.get("w"), *jh = p.get("h");
-        const bool has_w = jw && jw->t == JVal::Num, has_h = jh && jh->t == JVal::Num;
+        *has_w = jw && jw->t == JVal::Num; *has_h = jh && jh->t == JVal::Num;
+        *tw = *has_w ? want_u32(p, "w", node) : 0; *th = *has_h ? want_u32(p, "h", node) : 0;
+        if ((*has_w && *tw < 1) || (*has_h && *th < 1)) raise(kArgumentInvalid, "InvalidNodeParams: %s w/h must be >= 1", node);
+    }
+    FramePtr constrain(const FramePtr& in, const JVal& p) {
+        std::string m;
+        bool has_w, has_h;
+        int64_t tw, th;
+        constrain_params(p, "constrain", &m, &has_w, &has_h, &tw, &th);
         if (m != "within" && m != "fit" && m != "distort")
             raise(kActionNotSupported, "ActionNotSupported: constrain mode '%s' (this shim: within, fit, distort)", m.c_str());
         if (!has_w && !has_h) return in;
-        double tw = has_w ? jw->n : 0, th = has_h ? jh->n : 0;
-        if ((has_w && tw < 1) || (has_h && th < 1)) raise(kNodeArgumentInvalid, "InvalidNodeParams: constrain w/h must be >= 1");
         uint32_t ow, oh;
-        if (m == "distort") { ow = has_w ? static_cast<uint32_t>(tw) : in->w; oh = has_h ? static_cast<uint32_t>(th) : in->h; }
-        else {
-            const double sx = has_w ? tw / in->w : 1e300, sy = has_h ? th / in->h : 1e300;
-            double s = std::min(sx, sy);
-            if (m == "within" && s >= 1.0) return in;                                 // never up-scales
-            const bool basis_is_width = sx <= sy;
-            if (basis_is_width) { ow = static_cast<uint32_t>(tw); oh = static_cast<uint32_t>(std::max(1.0, std::round(tw * in->h / in->w))); }
-            else { oh = static_cast<uint32_t>(th); ow = static_cast<uint32_t>(std::max(1.0, std::round(th * in->w / in->h))); }
-            if (has_w && has_h) { ow = std::min<uint32_t>(ow, static_cast<uint32_t>(tw)); oh = std::min<uint32_t>(oh, static_cast<uint32_t>(th)); }
-        }
-        const JVal* hints = p.get("hints");
-        return resample(in, ow, oh, hints);
+        constrain_size(m, in->w, in->h, has_w, has_h, tw, th, &ow, &oh);
+        return resample(in, ow, oh, p.get("hints"));
     }
 
     // command_string {kind: "ir4", value: "width=200&..."}: the querystring form of BASELINE config 1.  Only the sizing
@@ -487,27 +725,16 @@ struct Job {
             else if (k == "format" || k == "quality" || k == "down.filter") {}           // encode-side / default keys
             else raise(kActionNotSupported, "ActionNotSupported: querystring key '%s'", k.c_str());
         }
+        if (!(qw >= 0 && qw <= 2147483647.0) || !(qh >= 0 && qh <= 2147483647.0)) raise(kArgumentInvalid, "InvalidNodeParams: querystring width/height out of range");
+        if (p.get("watermarks") && !p.get("watermarks")->is_null()) raise(kActionNotSupported, "ActionNotSupported: command_string.watermarks (use watermark nodes)");
         const JVal* dec = p.get("decode");
         const JVal* enc = p.get("encode");
         uint32_t src_w = 0, src_h = 0;
-        if (dec && dec->t == JVal::Num) {
-            Io& io = input(static_cast<int32_t>(dec->n));
-            int nc = 0;
-            uint8_t hs[3], vs[3];
-            uint32_t bw[3], bh[3], ri = 0;
-            uint16_t qt[192];
-            const bool is_jpeg = io.in_len > 2 && io.in[0] == 0xFF && io.in[1] == 0xD8;
-            if (is_jpeg) check(ifhip_jpeg_parse_headers(io.in, io.in_len, &src_w, &src_h, &nc, hs, vs, bw, bh, qt, &ri));
-        } else if (in) { src_w = in->w; src_h = in->h; }
+        if (dec && dec->t == JVal::Num) image_size(static_cast<int32_t>(want_int(p, "decode", "command_string")), &src_w, &src_h);
+        else if (in) { src_w = in->w; src_h = in->h; }
         else raise(kGraphInvalid, "GraphInvalid: command_string has neither a decode io nor an input frame");
         auto target = [&](uint32_t sw, uint32_t sh, uint32_t* ow, uint32_t* oh) {        // mode=max: fit inside, never up-scale
-            double s = 1.0;
-            if (qw > 0) s = std::min(s, qw / sw);
-            if (qh > 0) s = std::min(s, qh / sh);
-            const bool by_w = qw > 0 && (qh <= 0 || qw / sw <= qh / sh);
-            if (s >= 1.0) { *ow = sw; *oh = sh; return; }
-            if (by_w) { *ow = static_cast<uint32_t>(qw); *oh = static_cast<uint32_t>(std::max(1.0, std::round(qw * sh / sw))); }
-            else { *oh = static_cast<uint32_t>(qh); *ow = static_cast<uint32_t>(std::max(1.0, std::round(qh * sw / sh))); }
+            constrain_size("within", sw, sh, qw >= 1, qh >= 1, static_cast<int64_t>(qw), static_cast<int64_t>(qh), ow, oh);
         };
         if (dec && dec->t == JVal::Num) {
             uint32_t hint_w = 0, hint_h = 0;
@@ -527,7 +754,7 @@ struct Job {
         hints.t = JVal::Obj;
         if (srgb) { JVal cs; cs.t = JVal::Str; cs.s = "srgb"; hints.o.emplace_back("scaling_colorspace", cs); }
         FramePtr out = resample(in, ow, oh, &hints);
-        if (enc && enc->t == JVal::Num) encode(out, static_cast<int32_t>(enc->n), nullptr);
+        if (enc && enc->t == JVal::Num) encode(out, static_cast<int32_t>(want_int(p, "encode", "command_string")), nullptr, false);
         return out;
     }
 
@@ -537,8 +764,12 @@ struct Job {
     // standard scan script (:121-129).  The content-adaptive sampling choice
     // (evalchroma, an external crate) is not reproduced: the file uses the maximum the reference allows (:133, 4:2:0).
     // EXTENSION: every other preset writes the raw BGRA container (PNG / GIF / WebP coders are out of scope).
-    void encode(const FramePtr& f, int32_t io_id, const JVal* preset) {
+    // `shared`: other consumers still read this frame -- the matte is then applied to a private copy.
+    void encode(FramePtr f, int32_t io_id, const JVal* preset, bool shared) {
+        Timed t(this, "primitive_encoder");
         Io& o = output(io_id);
+        if (o.out_state == OutState::Taken) raise(kArgumentInvalid, "InvalidArgument: Output buffer for io_id %d has already been taken", io_id);
+        poll_cancel();
         const JVal* classic = preset ? preset->get("libjpeg_turbo") : nullptr;
         if (classic) {
             auto flag = [&](const char* k) { const JVal* v = classic->get(k); return v && v->t == JVal::Bool && v->b; };
@@ -548,6 +779,7 @@ struct Job {
             if (q && q->t == JVal::Num) quality = q->n > 100 ? 100 : (q->n < 0 ? 0 : static_cast<int>(q->n));
             const JVal* m = classic->get("matte");
             const uint32_t matte = m && !m->is_null() ? parse_color(m, "encode.preset.libjpeg_turbo.matte") : 0xFFFFFFFFu;   // :88-92
+            if (shared && f->alpha) f = clone(f);
             check(ifhip_apply_matte_batch_device(f->d, f->bytes(), 1, f->w, f->h, f->stride, f->alpha ? 1 : 0, matte, nullptr));
             f->alpha = false;                                                            // :94 set_alpha_meaningful(false)
             const uint8_t hs[3] = {2, 1, 1}, vs[3] = {2, 1, 1};
@@ -560,7 +792,7 @@ struct Job {
             uint32_t bw[3], bh[3];
             check(ifhip_jpeg_fwd_stage_block_dims(st, bw, bh));
             size_t off[4] = {0, 0, 0, 0};
-            for (int c = 0; c < 3; ++c) off[c + 1] = off[c] + static_cast<size_t>(bw[c]) * bh[c] * 64u;
+            for (int k = 0; k < 3; ++k) off[k + 1] = off[k] + static_cast<size_t>(bw[k]) * bh[k] * 64u;
             int16_t* d_coef = nullptr;
             uint16_t* d_qt = nullptr;
             hip_check(hipMalloc(reinterpret_cast<void**>(&d_coef), off[3] * 2u + 384u), "hipMalloc(coefficients)");
@@ -570,6 +802,7 @@ struct Job {
             check(ifhip_jpeg_forward_batch_device(st, f->d, f->bytes(), f->stride, d_qt, 1, d_coef + off[0], d_coef + off[1], d_coef + off[2], nullptr));
             std::vector<int16_t> coef(off[3]);
             hip_check(hipMemcpy(coef.data(), d_coef, off[3] * 2u, hipMemcpyDeviceToHost), "download(coefficients)");
+            poll_cancel();
             size_t len = 0;
             o.owned.assign(std::max<size_t>(4096u, off[3]), 0);                          // a file is smaller than its coefficients: one pass
             int wrc = ifhip_jpeg_write(coef.data() + off[0], coef.data() + off[1], coef.data() + off[2], bw, bh, 3, hs, vs, f->w, f->h, quality, write_flags,
@@ -594,7 +827,13 @@ struct Job {
         encodes.push_back({io_id, f->w, f->h, "application/x-imageflow-bgra", "ifbgra"});
     }
 
+    // CopyRectNodeDef::render (flow/nodes/clone_crop_fill_expand.rs:31-90)
     FramePtr copy_into_canvas(const FramePtr& in, const FramePtr& canvas, uint32_t fx, uint32_t fy, uint32_t w, uint32_t h, uint32_t x, uint32_t y) {
+        if (in == canvas) raise(kGraphInvalid, "InvalidNodeConnections: Canvas and Input are the same bitmap!");
+        if (in->w <= fx || in->h <= fy || in->w < static_cast<uint64_t>(fx) + w || in->h < static_cast<uint64_t>(fy) + h ||
+            canvas->w < static_cast<uint64_t>(x) + w || canvas->h < static_cast<uint64_t>(y) + h)
+            raise(kArgumentInvalid, "InvalidNodeParams: Invalid coordinates. Canvas is %ux%u, Input is %ux%u, Params provided: from_x=%u from_y=%u w=%u h=%u x=%u y=%u",
+                  canvas->w, canvas->h, in->w, in->h, fx, fy, w, h, x, y);
         int canvas_alpha = canvas->alpha ? 1 : 0;
         check(ifhip_copy_rect_batch_device(in->d, in->bytes(), in->w, in->h, in->stride, in->alpha ? 1 : 0, canvas->d, canvas->bytes(),
                                            canvas->w, canvas->h, canvas->stride, &canvas_alpha, fx, fy, x, y, w, h, 1, nullptr));
@@ -612,10 +851,124 @@ struct Job {
                        : ifhip_flip_horizontal_batch_device(in->d, in->bytes(), 1, in->w, in->h, in->stride, nullptr));
         return in;
     }
+    // ColorMatrixSrgbMutDef::mutate (flow/nodes/color.rs:20-38)
+    FramePtr color_matrix(const FramePtr& in, const float m[25]) {
+        check(ifhip_apply_color_matrix_batch_device(in->d, in->bytes(), 1, in->w, in->h, in->stride, m, nullptr));
+        in->compose = IFHIP_BLEND_WITH_SELF;
+        return in;
+    }
+    // ColorFilterSrgb::expand (flow/nodes/color.rs:49-83) with the matrices of :86-230
+    FramePtr color_filter(const FramePtr& in, const JVal& p) {
+        float m[25] = {1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1};
+        auto gray = [&](float r, float g, float b) { const float v[25] = {r, r, r, 0, 0, g, g, g, 0, 0, b, b, b, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1}; std::memcpy(m, v, sizeof v); };
+        std::string name;
+        float a = 0.f;
+        if (p.t == JVal::Str) name = p.s;
+        else if (p.t == JVal::Obj && p.o.size() == 1 && p.o[0].second.t == JVal::Num) { name = p.o[0].first; a = static_cast<float>(p.o[0].second.n); }
+        else raise(kInvalidJson, "InvalidJson: color_filter_srgb is a name or {name: value}");
+        if (name == "sepia") { const float v[25] = {0.393f, 0.349f, 0.272f, 0, 0, 0.769f, 0.686f, 0.534f, 0, 0, 0.189f, 0.168f, 0.131f, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0}; std::memcpy(m, v, sizeof v); }
+        else if (name == "grayscale_ntsc") gray(0.229f, 0.587f, 0.114f);
+        else if (name == "grayscale_ry") gray(0.5f, 0.419f, 0.081f);
+        else if (name == "grayscale_flat") gray(0.5f, 0.5f, 0.5f);
+        else if (name == "grayscale_bt709") gray(0.2125f, 0.7154f, 0.0721f);
+        else if (name == "invert") { m[0] = m[6] = m[12] = -1.f; m[20] = m[21] = m[22] = 1.f; }
+        else if (name == "alpha") m[18] = a;
+        else if (name == "contrast") { const float c2 = a + 1.f, t = 0.5f * (1.f - c2); m[0] = m[6] = m[12] = c2; m[20] = m[21] = m[22] = t; }
+        else if (name == "brightness") m[20] = m[21] = m[22] = a;
+        else if (name == "saturation") {
+            const float s = std::max(a + 1.f, 0.f), c2 = 1.f - s, cr = 0.3086f * c2, cg = 0.6094f * c2, cb = 0.0820f * c2;
+            const float v[25] = {cr + s, cr, cr, 0, 0, cg, cg + s, cg, 0, 0, cb, cb, cb + s, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1};
+            std::memcpy(m, v, sizeof v);
+        } else raise(kInvalidJson, "InvalidJson: unknown color_filter_srgb '%s'", name.c_str());
+        if (name == "alpha" && !in->alpha) {                                          // EnableTransparency (enable_transparency.rs:68-95)
+            check(ifhip_normalize_unused_alpha_batch_device(in->d, in->bytes(), 1, in->w, in->h, in->stride, 0, nullptr));
+            in->alpha = true;
+        }
+        return color_matrix(in, m);
+    }
 
-    // one node: `in` is the frame of its (single) input edge, or null for source nodes
-    FramePtr run_node(const std::string& name, const JVal& p, FramePtr in) {
+    // WatermarkDef::expand (flow/nodes/watermark.rs:100-196): decode -> [crop] -> [alpha(opacity)] -> DrawImageExact
+    // (Compose) onto the input frame.  As the reference, the constraint is built with `hints: None`, so the node's
+    // own `hints` never reach the resampler (:121-128, :176).
+    FramePtr watermark(const FramePtr& canvas, const JVal& p) {
+        const int32_t io_id = static_cast<int32_t>(want_int(p, "io_id", "watermark"));
+        auto opt_u32 = [&](const char* k) -> uint32_t { const JVal* v = p.get(k); return v && v->t == JVal::Num ? want_u32(p, k, "watermark") : 0u; };
+        if (!(opt_u32("min_canvas_width") < canvas->w && opt_u32("min_canvas_height") < canvas->h)) return canvas;       // :109-111
+        // get_bounding_box (:11-58)
+        int64_t bx1 = 0, by1 = 0, bx2 = canvas->w, by2 = canvas->h;
+        if (const JVal* fb = p.get("fit_box"))
+            if (!fb->is_null()) {
+                const JVal* margins = fb->get("image_margins") ? fb->get("image_margins") : fb->get("canvas_margins");
+                const JVal* pct = fb->get("image_percentage") ? fb->get("image_percentage") : fb->get("canvas_percentage");
+                if (margins) {
+                    const int64_t l = want_u32(*margins, "left", "fit_box"), t = want_u32(*margins, "top", "fit_box"), r = want_u32(*margins, "right", "fit_box"), b = want_u32(*margins, "bottom", "fit_box");
+                    if (!(l + r < canvas->w && t + b < canvas->h)) return canvas;
+                    bx1 = l; by1 = t; bx2 = static_cast<int64_t>(canvas->w) - r; by2 = static_cast<int64_t>(canvas->h) - b;
+                } else if (pct) {
+                    auto num = [&](const char* k) { const JVal* v = pct->get(k); if (!v || v->t != JVal::Num) raise(kInvalidJson, "InvalidJson: fit_box.%s must be a number", k); return static_cast<float>(v->n); };
+                    auto to_px = [](float percent, uint32_t size) { const float ratio = std::min(std::max(percent, 0.f), 100.f) / 100.f; return static_cast<int64_t>(std::round(ratio * static_cast<float>(size))); };
+                    bx1 = to_px(num("x1"), canvas->w); by1 = to_px(num("y1"), canvas->h); bx2 = to_px(num("x2"), canvas->w); by2 = to_px(num("y2"), canvas->h);
+                    if (!(bx1 < bx2 && by1 < by2)) return canvas;
+                } else raise(kInvalidJson, "InvalidJson: unknown watermark fit_box");
+            }
+        const JVal* fm = p.get("fit_mode");
+        const std::string mode = fm && fm->t == JVal::Str ? fm->s : "within";                                            // :121
+        if (mode != "within" && mode != "fit" && mode != "distort")
+            raise(kActionNotSupported, "ActionNotSupported: watermark fit_mode '%s' (this shim: within, fit, distort -- the crop / pad modes need imageflow_riapi's layout engine)", mode.c_str());
+        uint32_t mw = 0, mh = 0;
+        image_size(io_id, &mw, &mh);
+        uint32_t w, h;
+        constrain_size(mode, mw, mh, true, true, bx2 - bx1, by2 - by1, &w, &h);
+        float gx = 50.f, gy = 50.f;                                                                                       // obey_gravity (:69-86)
+        if (const JVal* g = p.get("gravity"))
+            if (!g->is_null() && !(g->t == JVal::Str && g->s == "center")) {
+                const JVal* pc = g->get("percentage");
+                const JVal *jx = pc ? pc->get("x") : nullptr, *jy = pc ? pc->get("y") : nullptr;
+                if (!jx || !jy || jx->t != JVal::Num || jy->t != JVal::Num) raise(kInvalidJson, "InvalidJson: gravity is \"center\" or {\"percentage\":{x,y}}");
+                gx = static_cast<float>(jx->n); gy = static_cast<float>(jy->n);
+            }
+        auto gravity1d = [](float pct, int64_t inner, int64_t outer) -> int64_t {                                         // :60-67
+            const float ratio = std::min(std::max(pct, 0.f), 100.f) / 100.f;
+            if ((outer < inner && inner < 1) || outer < 1) raise(kArgumentInvalid, "InvalidNodeParams: Watermark fit_box does not work");
+            return static_cast<int64_t>(std::round(static_cast<float>(outer - inner) * ratio));
+        };
+        const int64_t x1 = gravity1d(gx, w, bx2 - bx1) + bx1, y1 = gravity1d(gy, h, by2 - by1) + by1;
+        if (x1 < 0 || y1 < 0) raise(kArgumentInvalid, "InvalidNodeParams: Watermark fit_box does not work");
+        FramePtr mark = decode(io_id, 0, 0, false, false);
+        float opacity = 1.f;
+        if (const JVal* o = p.get("opacity")) if (o->t == JVal::Num) opacity = std::min(std::max(static_cast<float>(o->n), 0.f), 1.f);
+        if (opacity < 1.f) {                                                                                             // :166-172
+            Timed t(this, "color_matrix_srgb_mut");
+            JVal f; f.t = JVal::Obj;
+            JVal v; v.t = JVal::Num; v.n = static_cast<double>(opacity);
+            f.o.emplace_back("alpha", v);
+            color_filter(mark, f);
+        }
+        draw_image_exact(canvas, mark, static_cast<uint32_t>(x1), static_cast<uint32_t>(y1), w, h, true, ResampleHints{});
+        return canvas;
+    }
+
+    // one node: `in` is the frame of its input edge (null for source nodes), `canvas` the frame of its canvas edge
+    FramePtr run_node(const std::string& name, const JVal& p, FramePtr in, FramePtr canvas, bool in_shared) {
         auto need_input = [&] { if (!in) raise(kGraphInvalid, "GraphInvalid: node '%s' has no input frame", name.c_str()); };
+        auto need_canvas = [&] { if (!canvas) raise(kGraphInvalid, "InvalidNodeConnections: node '%s' needs a canvas edge", name.c_str()); };
+        poll_cancel();                                                                // execution_engine.rs:502
+        if (name == "draw_image_exact") {                                             // s::Node::DrawImageExact (lib.rs:1328-1336)
+            need_input(); need_canvas();
+            const JVal* blend = p.get("blend");
+            bool compose = true;
+            if (blend && blend->t == JVal::Str) { if (blend->s == "overwrite") compose = false; else if (blend->s != "compose") raise(kInvalidJson, "InvalidJson: blend is compose or overwrite"); }
+            draw_image_exact(canvas, in, want_u32(p, "x", "draw_image_exact"), want_u32(p, "y", "draw_image_exact"), want_u32(p, "w", "draw_image_exact"),
+                             want_u32(p, "h", "draw_image_exact"), compose, parse_hints(p.get("hints"), "draw_image_exact"));
+            return canvas;
+        }
+        if (name == "copy_rect_to_canvas") {
+            need_input(); need_canvas();
+            Timed t(this, "copy_rect_to_canvas");
+            return copy_into_canvas(in, canvas, want_u32(p, "from_x", name.c_str()), want_u32(p, "from_y", name.c_str()), want_u32(p, "w", name.c_str()),
+                                    want_u32(p, "h", name.c_str()), want_u32(p, "x", name.c_str()), want_u32(p, "y", name.c_str()));
+        }
+        if (canvas) raise(kGraphInvalid, "InvalidNodeConnections: node '%s' does not take a canvas edge", name.c_str());
         if (name == "decode") {
             uint32_t hw = 0, hh = 0;
             bool spatial = false, gamma = false;
@@ -630,6 +983,7 @@ struct Job {
             return decode(static_cast<int32_t>(want_int(p, "io_id", "decode")), hw, hh, spatial, gamma);
         }
         if (name == "create_canvas") {
+            Timed t(this, "create_canvas");
             const JVal* fmt = p.get("format");
             const std::string f = fmt && fmt->t == JVal::Str ? fmt->s : "bgra_32";
             if (f != "bgra_32" && f != "bgr_32") raise(kActionNotSupported, "ActionNotSupported: create_canvas format %s", f.c_str());
@@ -639,7 +993,11 @@ struct Job {
         need_input();
         if (name == "resample_2d") return resample(in, want_u32(p, "w", "resample_2d"), want_u32(p, "h", "resample_2d"), p.get("hints"));
         if (name == "constrain") return constrain(in, p);
-        if (name == "encode") { encode(in, static_cast<int32_t>(want_int(p, "io_id", "encode")), p.get("preset")); return in; }
+        if (name == "watermark") return watermark(in, p);
+        if (name == "encode") { encode(in, static_cast<int32_t>(want_int(p, "io_id", "encode")), p.get("preset"), in_shared); return in; }
+        Timed t(this, name == "fill_rect" ? "fill_rect_mutate" : name == "crop" ? "crop_mutate" : name == "flip_v" ? "flip_vertical_mutate" : name == "flip_h" ? "flip_vertical_mutate" /* sic: rotate_flip_transpose.rs:206 */
+                      : name == "color_matrix_srgb" || name == "color_filter_srgb" ? "color_matrix_srgb_mut" : name == "expand_canvas" ? "expand_canvas" : name == "transpose" ? "transpose_mut"
+                      : name == "rotate_90" ? "rotate_90" : name == "rotate_180" ? "rotate_180" : name == "rotate_270" ? "rotate_270" : name == "apply_orientation" ? "apply_orientation" : "node");
         if (name == "fill_rect") {                                                    // clone_crop_fill_expand.rs:107-137
             in->compose = IFHIP_BLEND_WITH_SELF;                                      // :112: set before the fill, so matte canvases accept sub-rects
             check(ifhip_fill_rect_batch_device(in->d, in->bytes(), 1, in->w, in->h, in->stride, in->compose, want_u32(p, "x1", name.c_str()),
@@ -648,23 +1006,49 @@ struct Job {
             return in;
         }
         if (name == "expand_canvas") {                                                // :224-262
-            const uint32_t l = want_u32(p, "left", "expand_canvas"), t = want_u32(p, "top", "expand_canvas"), r = want_u32(p, "right", "expand_canvas"),
+            const uint32_t l = want_u32(p, "left", "expand_canvas"), t2 = want_u32(p, "top", "expand_canvas"), r = want_u32(p, "right", "expand_canvas"),
                            b = want_u32(p, "bottom", "expand_canvas"), color = parse_color(p.get("color"), "expand_canvas.color");
-            FramePtr canvas = new_frame(in->w + l + r, in->h + t + b, (color >> 24) == 255 ? in->alpha : true, color, true);
-            return copy_into_canvas(in, canvas, 0, 0, in->w, in->h, l, t);
+            const uint64_t nw = static_cast<uint64_t>(in->w) + l + r, nh = static_cast<uint64_t>(in->h) + t2 + b;
+            check_size(sec.max_frame_size, "max_frame_size", nw, nh);                 // before the 32-bit sums can wrap
+            FramePtr cv = new_frame(static_cast<uint32_t>(nw), static_cast<uint32_t>(nh), (color >> 24) == 255 ? in->alpha : true, color, true);
+            return copy_into_canvas(in, cv, 0, 0, in->w, in->h, l, t2);
         }
         if (name == "crop") {                                                         // :519-541 (materialised: a copy)
             const uint32_t x1 = want_u32(p, "x1", "crop"), y1 = want_u32(p, "y1", "crop"), x2 = want_u32(p, "x2", "crop"), y2 = want_u32(p, "y2", "crop");
-            if (x2 <= x1 || y2 <= y1 || x2 > in->w || y2 > in->h) raise(kNodeArgumentInvalid, "InvalidNodeParams: Invalid crop bounds");
-            FramePtr canvas = new_frame(x2 - x1, y2 - y1, in->alpha, 0, true);
-            return copy_into_canvas(in, canvas, x1, y1, x2 - x1, y2 - y1, 0, 0);
+            if (x2 <= x1 || y2 <= y1 || x2 > in->w || y2 > in->h) raise(kArgumentInvalid, "InvalidNodeParams: Invalid crop bounds");
+            FramePtr cv = new_frame(x2 - x1, y2 - y1, in->alpha, 0, true);
+            return copy_into_canvas(in, cv, x1, y1, x2 - x1, y2 - y1, 0, 0);
         }
+        if (name == "color_matrix_srgb") {                                            // s::Node::ColorMatrixSrgb {matrix: [[f32;5];5]}
+            const JVal* mj = p.get("matrix");
+            float m[25];
+            if (!mj || mj->t != JVal::Arr || mj->a.size() != 5) raise(kInvalidJson, "InvalidJson: color_matrix_srgb.matrix is 5 rows of 5 numbers");
+            for (int r = 0; r < 5; ++r) {
+                const JVal& row = mj->a[static_cast<size_t>(r)];
+                if (row.t != JVal::Arr || row.a.size() != 5) raise(kInvalidJson, "InvalidJson: color_matrix_srgb.matrix is 5 rows of 5 numbers");
+                for (int k = 0; k < 5; ++k) { if (row.a[static_cast<size_t>(k)].t != JVal::Num) raise(kInvalidJson, "InvalidJson: color_matrix_srgb.matrix is 5 rows of 5 numbers"); m[r * 5 + k] = static_cast<float>(row.a[static_cast<size_t>(k)].n); }
+            }
+            return color_matrix(in, m);
+        }
+        if (name == "color_filter_srgb") return color_filter(in, p);
         if (name == "flip_v") return flip(in, true);
         if (name == "flip_h") return flip(in, false);
         if (name == "transpose") return transposed(in);
         if (name == "rotate_90") return flip(transposed(in), false);                  // rotate_flip_transpose.rs:51-66
         if (name == "rotate_180") return flip(flip(in, true), false);
         if (name == "rotate_270") return flip(transposed(in), true);
+        if (name == "apply_orientation") {                                            // ApplyOrientationDef::expand (:44-66)
+            switch (want_int(p, "flag", "apply_orientation")) {
+            case 2: return flip(in, false);
+            case 3: return flip(flip(in, true), false);
+            case 4: return flip(in, true);
+            case 5: return transposed(in);
+            case 6: return flip(transposed(in), false);
+            case 7: return transposed(flip(flip(in, true), false));
+            case 8: return flip(transposed(in), true);
+            default: return in;
+            }
+        }
         raise(kActionNotSupported, "ActionNotSupported: node '%s' is outside the pixel hot path this library replaces", name.c_str());
     }
 
@@ -673,6 +1057,10 @@ struct Job {
         if (n.t != JVal::Obj || n.o.size() != 1) raise(kInvalidJson, "InvalidJson: a node is {\"name\": {params}}");
         *name = n.o[0].first;
         *params = &n.o[0].second;
+    }
+    static bool mutates_input(const std::string& nm) {
+        return nm == "fill_rect" || nm == "flip_v" || nm == "flip_h" || nm == "rotate_180" || nm == "color_matrix_srgb" || nm == "color_filter_srgb" ||
+               nm == "apply_orientation" || nm == "watermark";
     }
 
     void run_framewise(const JVal& fw) {
@@ -683,7 +1071,7 @@ struct Job {
                 std::string name;
                 const JVal* params;
                 node_of(n, &name, &params);
-                cur = run_node(name, *params, cur);
+                cur = run_node(name, *params, cur, nullptr, false);
             }
             return;
         }
@@ -692,46 +1080,47 @@ struct Job {
         const JVal *nodes = graph->get("nodes"), *edges = graph->get("edges");
         if (!nodes || nodes->t != JVal::Obj || !edges || edges->t != JVal::Arr) raise(kInvalidJson, "InvalidJson: graph needs nodes{} and edges[]");
         std::map<int64_t, const JVal*> node_by_id;
-        std::map<int64_t, int64_t> parent;
+        std::map<int64_t, int64_t> parent, canvas_parent;                              // EdgeKind::Input / EdgeKind::Canvas
         for (const auto& kv : nodes->o) node_by_id[std::atoll(kv.first.c_str())] = &kv.second;
         for (const JVal& e : edges->a) {
             const int64_t from = want_int(e, "from", "edge"), to = want_int(e, "to", "edge");
             const JVal* kind = e.get("kind");
-            if (!kind || kind->t != JVal::Str || kind->s != "input") raise(kActionNotSupported, "ActionNotSupported: only `input` edges (canvas edges are outside this shim)");
+            const bool is_canvas = kind && kind->t == JVal::Str && kind->s == "canvas";
+            if (!kind || kind->t != JVal::Str || (kind->s != "input" && !is_canvas)) raise(kInvalidJson, "InvalidJson: edge kind is input or canvas");
             if (!node_by_id.count(from) || !node_by_id.count(to)) raise(kGraphInvalid, "GraphInvalid: edge names a missing node");
-            if (parent.count(to)) raise(kGraphInvalid, "GraphInvalid: node %lld has two input edges", static_cast<long long>(to));
-            parent[to] = from;
+            auto& slot = is_canvas ? canvas_parent : parent;
+            if (slot.count(to)) raise(kGraphInvalid, "GraphInvalid: node %lld has two %s edges", static_cast<long long>(to), is_canvas ? "canvas" : "input");
+            slot[to] = from;
         }
         std::map<int64_t, FramePtr> done;
         std::map<int64_t, int> state;                                                  // 1 = on the stack (cycle check)
-        // nodes that mutate their input in place must not see a frame another consumer still needs: give every node
-        // with a shared parent its own copy
+        // nodes that mutate a parent's frame in place (their input, or the canvas they draw on) must not see a frame
+        // another consumer still needs: every such node with a shared parent works on its own copy
         std::map<int64_t, int> consumers;
         for (const auto& kv : parent) ++consumers[kv.second];
+        for (const auto& kv : canvas_parent) ++consumers[kv.second];
         std::function<FramePtr(int64_t)> eval = [&](int64_t id) -> FramePtr {
             auto it = done.find(id);
             if (it != done.end()) return it->second;
             if (state[id] == 1) raise(kGraphInvalid, "GraphInvalid: cycle through node %lld", static_cast<long long>(id));
             state[id] = 1;
-            FramePtr in;
-            auto pit = parent.find(id);
-            if (pit != parent.end()) {
-                in = eval(pit->second);
-                std::string nm;
-                const JVal* pp;
-                node_of(*node_by_id[id], &nm, &pp);
-                const bool mutates = nm == "fill_rect" || nm == "flip_v" || nm == "flip_h" || nm == "rotate_180";
-                if (in && mutates && consumers[pit->second] > 1) {
-                    FramePtr c = new_frame(in->w, in->h, in->alpha, 0, false);
-                    hip_check(hipMemcpy(c->d, in->d, in->bytes(), hipMemcpyDeviceToDevice), "clone");
-                    c->compose = in->compose; c->matte = in->matte;
-                    in = c;
-                }
-            }
             std::string name;
             const JVal* params;
             node_of(*node_by_id[id], &name, &params);
-            FramePtr out = run_node(name, *params, in);
+            FramePtr in, canvas;
+            bool in_shared = false;
+            auto pit = parent.find(id);
+            if (pit != parent.end()) {
+                in = eval(pit->second);
+                in_shared = consumers[pit->second] > 1;
+                if (in && in_shared && mutates_input(name)) in = clone(in);
+            }
+            auto cit = canvas_parent.find(id);
+            if (cit != canvas_parent.end()) {
+                canvas = eval(cit->second);
+                if (canvas && consumers[cit->second] > 1) canvas = clone(canvas);
+            }
+            FramePtr out = run_node(name, *params, in, canvas, in_shared);
             state[id] = 2;
             done[id] = out;
             return out;
@@ -792,8 +1181,37 @@ std::string job_result_json(const Job& job, const char* key) {
         s += std::string(i ? "," : "") + "\n        {\"preferred_mime_type\": \"" + d.mime + "\", \"preferred_extension\": \"" + d.ext + "\", \"io_id\": " +
              std::to_string(d.io_id) + ", \"w\": " + std::to_string(d.w) + ", \"h\": " + std::to_string(d.h) + "}";
     }
-    s += "\n      ],\n      \"performance\": null\n    }\n  }\n}";
+    // s::BuildPerformance {frames: [FramePerformance {nodes: [NodePerf {wall_microseconds, name}], wall_microseconds,
+    // overhead_microseconds}]} (imageflow_types/src/lib.rs:1999-2016), filled as Engine::execute_many does
+    // (flow/execution_engine.rs:179-199: nodes sorted by cost, largest first).  `gpu_microseconds` is an added field:
+    // the time the device spent between the node's first and last launch (hipEvents).
+    std::vector<NodePerf> nodes = job.perf;
+    std::stable_sort(nodes.begin(), nodes.end(), [](const NodePerf& a, const NodePerf& b) { return a.wall_ns > b.wall_ns; });
+    uint64_t total_node_ns = 0;
+    for (const NodePerf& n : job.perf) total_node_ns += n.wall_ns;
+    const int64_t total_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - job.t_start).count();
+    s += "\n      ],\n      \"performance\": {\"frames\": [{\"nodes\": [";
+    for (size_t i = 0; i < nodes.size(); ++i)
+        s += std::string(i ? ", " : "") + "{\"wall_microseconds\": " + std::to_string(static_cast<uint64_t>(std::llround(static_cast<double>(nodes[i].wall_ns) / 1000.0))) +
+             ", \"name\": \"" + nodes[i].name + "\", \"gpu_microseconds\": " + std::to_string(static_cast<uint64_t>(std::llround(static_cast<double>(nodes[i].gpu_ms) * 1000.0))) + "}";
+    s += "], \"wall_microseconds\": " + std::to_string(static_cast<uint64_t>(std::llround(static_cast<double>(total_ns) / 1000.0))) +
+         ", \"overhead_microseconds\": " + std::to_string(static_cast<int64_t>(std::llround(static_cast<double>(total_ns - static_cast<int64_t>(total_node_ns)) / 1000.0))) + "}]}\n    }\n  }\n}";
     return s;
+}
+
+// ExecutionSecurity overrides a job may carry (imageflow_core/src/context.rs:640-653)
+void parse_security(const JVal* sec, Security* out) {
+    if (!sec || sec->t != JVal::Obj) return;
+    auto limit = [&](const char* key, SizeLimit* l) {
+        const JVal* v = sec->get(key);
+        if (!v || v->t != JVal::Obj) return;
+        l->w = want_u32(*v, "w", key); l->h = want_u32(*v, "h", key);
+        const JVal* mp = v->get("megapixels");
+        if (!mp || mp->t != JVal::Num) raise(kInvalidJson, "InvalidJson: %s.megapixels must be a number", key);
+        l->megapixels = static_cast<float>(mp->n);
+    };
+    limit("max_decode_size", &out->max_decode_size);
+    limit("max_frame_size", &out->max_frame_size);
 }
 
 [[noreturn]] void abort_null_context() {                          // imageflow_abi/src/lib.rs:309-325
@@ -822,18 +1240,43 @@ bool imageflow_context_has_error(struct imageflow_context* c) { CTX_OR_ABORT(c);
 int32_t imageflow_context_error_code(struct imageflow_context* c) { CTX_OR_ABORT(c); std::lock_guard<std::mutex> lk(c->mu); return c->err_cat; }
 int32_t imageflow_context_error_as_exit_code(struct imageflow_context* c) { CTX_OR_ABORT(c); std::lock_guard<std::mutex> lk(c->mu); return exit_code(c->err_cat); }
 int32_t imageflow_context_error_as_http_code(struct imageflow_context* c) { CTX_OR_ABORT(c); std::lock_guard<std::mutex> lk(c->mu); return http_code(c->err_cat); }
+// OutwardErrorBuffer::recoverable / try_clear (imageflow_core/src/errors.rs:953-969) over FlowError::recoverable, which
+// is `false` for every error today (:656-658): "recoverable" is true only while there is no error, and an error, once
+// set, is never cleared -- a caller that wants to go on creates a new context.
 bool imageflow_context_error_recoverable(struct imageflow_context* c) {
     CTX_OR_ABORT(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    return c->err_cat != kOk && c->err_cat != kOutOfMemory && c->err_cat != kInternalError;
+    return c->err_cat == kOk;
 }
 bool imageflow_context_error_try_clear(struct imageflow_context* c) {
     CTX_OR_ABORT(c);
     std::lock_guard<std::mutex> lk(c->mu);
-    if (c->err_cat == kOutOfMemory || c->err_cat == kInternalError) return false;
-    c->err_cat = kOk;
-    c->err_msg.clear();
-    return true;
+    return c->err_cat == kOk;
+}
+// lib.rs:744: print the error to stderr and exit with its exit code; returns false when there is none
+bool imageflow_context_print_and_exit_if_error(struct imageflow_context* c) {
+    CTX_OR_ABORT(c);
+    int cat;
+    std::string msg;
+    { std::lock_guard<std::mutex> lk(c->mu); cat = c->err_cat; msg = c->err_msg; }
+    if (cat == kOk) return false;
+    fprintf(stderr, "%s\n", msg.c_str());
+    std::exit(exit_code(cat));
+}
+// lib.rs:878: the one call meant for another thread while a job runs -- it takes no lock
+void imageflow_context_request_cancellation(struct imageflow_context* c) {
+    CTX_OR_ABORT(c);
+    c->cancel.store(true, std::memory_order_relaxed);
+}
+// Context::request_cancellation_after_n_polls[_remaining] (context.rs:96-104,167-172; debug builds of the reference): the
+// hook its own test_job_with_cancellation_at_every_point uses (imageflow_abi/src/lib.rs:1669-1743)
+void ifhip_shim_request_cancellation_after_n_polls(struct imageflow_context* c, int64_t polls) {
+    CTX_OR_ABORT(c);
+    c->poll_countdown.store(polls, std::memory_order_seq_cst);
+}
+int64_t ifhip_shim_cancellation_polls_remaining(struct imageflow_context* c) {
+    CTX_OR_ABORT(c);
+    return c->poll_countdown.load(std::memory_order_seq_cst);
 }
 bool imageflow_context_error_write_to_buffer(struct imageflow_context* c, char* buffer, size_t buffer_length, size_t* bytes_written) {   // lib.rs:684
     CTX_OR_ABORT(c);
@@ -885,8 +1328,35 @@ bool imageflow_context_get_output_buffer_by_id(struct imageflow_context* c, int3
     if (!result_buffer || !result_buffer_length) { c->set_error(kArgumentInvalid, "NullArgument: result pointers are null"); return false; }
     auto it = c->io.find(io_id);
     if (it == c->io.end() || !it->second.is_output) { c->set_error(kArgumentInvalid, "InvalidArgument: io_id " + std::to_string(io_id) + " is not an output buffer"); return false; }
+    if (it->second.out_state == OutState::Taken) { c->set_error(kArgumentInvalid, "InvalidArgument: Output buffer for io_id " + std::to_string(io_id) + " has already been taken"); return false; }
+    it->second.out_state = OutState::Lent;                          // codecs/mod.rs:602-626: a lent pointer blocks take()
     *result_buffer = it->second.owned.data();
     *result_buffer_length = it->second.owned.size();
+    return true;
+}
+// lib.rs:1335: the bytes move out of the context into a heap block the caller frees with imageflow_buffer_free
+bool imageflow_context_take_output_buffer(struct imageflow_context* c, int32_t io_id, uint8_t** result_buffer, size_t* result_buffer_length) {
+    CTX_OR_ABORT(c);
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!result_buffer) { c->set_error(kArgumentInvalid, "NullArgument: The argument 'result_buffer' is null."); return false; }
+    if (!result_buffer_length) { c->set_error(kArgumentInvalid, "NullArgument: The argument 'result_buffer_length' is null."); return false; }
+    auto it = c->io.find(io_id);
+    if (it == c->io.end() || !it->second.is_output) { c->set_error(kArgumentInvalid, "InvalidArgument: io_id " + std::to_string(io_id) + " is not an output buffer"); return false; }
+    Io& o = it->second;
+    if (o.out_state == OutState::Lent) { c->set_error(kArgumentInvalid, "InvalidArgument: Cannot take output buffer for io_id " + std::to_string(io_id) + ": a raw pointer was already lent out"); return false; }   // codecs/mod.rs:565-571
+    if (o.out_state == OutState::Taken) { c->set_error(kArgumentInvalid, "InvalidArgument: Output buffer for io_id " + std::to_string(io_id) + " has already been taken"); return false; }   // :572-578
+    uint8_t* p = static_cast<uint8_t*>(std::malloc(o.owned.size() ? o.owned.size() : 1));
+    if (!p) { c->set_error(kOutOfMemory, "AllocationFailed: output buffer"); return false; }
+    std::memcpy(p, o.owned.data(), o.owned.size());
+    *result_buffer = p;
+    *result_buffer_length = o.owned.size();
+    std::vector<uint8_t>().swap(o.owned);
+    o.out_state = OutState::Taken;
+    return true;
+}
+// lib.rs:1385: NULL is a no-op; always true.  (`length` is what Rust's Box<[u8]> needs to rebuild the slice; malloc'd here.)
+bool imageflow_buffer_free(uint8_t* buffer, size_t /*length*/) {
+    std::free(buffer);
     return true;
 }
 
@@ -906,9 +1376,11 @@ const struct imageflow_json_response* imageflow_context_send_json(struct imagefl
             c->set_error(kArgumentInvalid, "InvalidMessageEndpoint: " + m);
             return respond(c, 404, "{\n  \"success\": \"false\",\n  \"code\": 404,\n  \"message\": \"Endpoint name not understood\"}");   // json/mod.rs:158-168
         }
+        if (json_buffer_size > 64u * 1024u * 1024u) raise(kArgumentInvalid, "SizeLimitExceeded: JSON payload exceeds max_json_bytes");   // ExecutionSecurity::max_json_bytes
         const JVal root = parse_json(json_buffer, json_buffer_size);
         if (root.t != JVal::Obj) raise(kInvalidJson, "InvalidJson: the message must be an object");
-        Job job{c, {}, {}};
+        Job job{c};
+        job.poll_cancel();
         if (!build && !execute) {                                    // get_image_info {io_id}: header facts only
             Io& in = job.input(static_cast<int32_t>(want_int(root, "io_id", "get_image_info")));
             uint32_t w = 0, h = 0, bw[3], bh[3], ri = 0;
@@ -920,6 +1392,8 @@ const struct imageflow_json_response* imageflow_context_send_json(struct imagefl
                                    "\"preferred_extension\": \"jpg\", \"image_width\": " + std::to_string(w) + ", \"image_height\": " + std::to_string(h) +
                                    ", \"frame_decodes_into\": \"bgr_32\"}\n  }\n}");
         }
+        if (build) { if (const JVal* bc = root.get("builder_config")) parse_security(bc->get("security"), &job.sec); }
+        else parse_security(root.get("security"), &job.sec);
         if (build) if (const JVal* ios = root.get("io")) add_io_from_json(c, *ios);
         const JVal* fw = root.get("framewise");
         if (!fw || fw->t != JVal::Obj) raise(kInvalidJson, "InvalidJson: missing framewise");

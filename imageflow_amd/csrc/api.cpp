@@ -456,8 +456,8 @@ int ifhip_set_device(int ordinal) {
 }
 
 uint32_t ifhip_stride_for_width(uint32_t w) {
-    const uint64_t row = static_cast<uint64_t>(w) * 4u;
-    return static_cast<uint32_t>((row + 63u) / 64u * 64u);
+    const uint64_t row = (static_cast<uint64_t>(w) * 4u + 63u) / 64u * 64u;
+    return row > 0xFFFFFFC0ull ? 0u : static_cast<uint32_t>(row);          // 0 = the width has no 32-bit stride
 }
 
 int ifhip_populate_weights(int filter, int lobe_mode, float lobe_value, double kernel_width_scale,

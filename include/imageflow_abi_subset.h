@@ -1,12 +1,15 @@
 /*
- * imageflow_abi_subset.h -- the part of libimageflow's C ABI v3.2 that libimageflow_hip.so re-exports, so that a C
- * caller (or any language binding generated from bindings/headers/imageflow_default.h) can run resize jobs on the
- * MI355X path without the Rust host.  Same names, argument order and ownership rules as the reference:
- *   imageflow_abi/src/lib.rs (line numbers per function below), ABI version imageflow_abi/src/abi_version.rs:4,7.
+ * imageflow_abi_subset.h -- libimageflow's C ABI v3.2 as libimageflow_hip.so re-exports it: all 25 functions of
+ * bindings/headers/imageflow_default.h, so that a C caller (or any language binding generated from that header) can run
+ * resize jobs on the MI355X path without the Rust host.  Same names, argument order and ownership rules as the
+ * reference: imageflow_abi/src/lib.rs (line numbers per function below), ABI version imageflow_abi/src/abi_version.rs:4,7.
+ * "Subset" is what a JOB may contain, not the function list.
  *
  * What a job may contain (anything else answers ActionNotSupported, HTTP 400): decode (baseline JPEG, or the raw
  * BGRA container EXTENSION), create_canvas, fill_rect, expand_canvas, crop, flip_h/flip_v, transpose, rotate_90/180/270,
- * resample_2d, constrain (within | fit | distort), command_string (ir4: width/height, mode=max), encode.
+ * apply_orientation, color_matrix_srgb, color_filter_srgb, resample_2d, draw_image_exact and copy_rect_to_canvas (graph
+ * form, with a `canvas` edge), watermark (fit_mode within | fit | distort), constrain (within | fit | distort),
+ * command_string (ir4: width/height, mode=max), encode.
  * `encode` with the libjpeg_turbo preset writes a real JPEG (quality, matte, progressive, optimize_huffman_coding:
  * byte-identical to libjpeg-turbo's file for the same pixels at 4:2:0); every other preset writes the raw BGRA container
  * EXTENSION (this library has no deflate / GIF / WebP coder): 8 bytes "IFBGRA1\0", u32le w, h, stride,
@@ -54,6 +57,11 @@ IMAGEFLOW_SHIM_API int32_t imageflow_context_error_as_exit_code(struct imageflow
 IMAGEFLOW_SHIM_API int32_t imageflow_context_error_as_http_code(struct imageflow_context *context);                    /* :645 */
 IMAGEFLOW_SHIM_API bool imageflow_context_error_write_to_buffer(struct imageflow_context *context, char *buffer,
                                                                 size_t buffer_length, size_t *bytes_written);          /* :684 */
+/* prints the error and calls exit(imageflow_context_error_as_exit_code) -- does not return when there is one */
+IMAGEFLOW_SHIM_API bool imageflow_context_print_and_exit_if_error(struct imageflow_context *context);                  /* :744 */
+/* the one call made from another thread while a job runs: sets the flag the job polls before every node, at every frame
+ * allocation and inside decode / encode; the job then fails with category 21 (HTTP 499, exit 130) */
+IMAGEFLOW_SHIM_API void imageflow_context_request_cancellation(struct imageflow_context *context);                     /* :878 */
 
 IMAGEFLOW_SHIM_API const struct imageflow_json_response *imageflow_context_send_json(struct imageflow_context *context,
                                                                                      const char *method,
@@ -75,10 +83,20 @@ IMAGEFLOW_SHIM_API bool imageflow_context_get_output_buffer_by_id(struct imagefl
                                                                   const uint8_t **result_buffer,
                                                                   size_t *result_buffer_length);                       /* :1272 */
 
+/* ownership of the output bytes moves to the caller; refused once get_output_buffer_by_id lent a pointer, or twice */
+IMAGEFLOW_SHIM_API bool imageflow_context_take_output_buffer(struct imageflow_context *context, int32_t io_id,
+                                                             uint8_t **result_buffer, size_t *result_buffer_length);   /* :1335 */
+IMAGEFLOW_SHIM_API bool imageflow_buffer_free(uint8_t *buffer, size_t length);                                         /* :1385 */
+
 IMAGEFLOW_SHIM_API void *imageflow_context_memory_allocate(struct imageflow_context *context, size_t bytes,
                                                            const char *filename, int32_t line);                        /* :1424 */
 IMAGEFLOW_SHIM_API bool imageflow_context_memory_free(struct imageflow_context *context, void *pointer,
                                                       const char *filename, int32_t line);                             /* :1484 */
+
+/* Not part of libimageflow's header: the poll countdown debug builds of the reference carry for their own cancellation
+ * test (Context::request_cancellation_after_n_polls, imageflow_core/src/context.rs:96-104,167-172). */
+IMAGEFLOW_SHIM_API void ifhip_shim_request_cancellation_after_n_polls(struct imageflow_context *context, int64_t polls);
+IMAGEFLOW_SHIM_API int64_t ifhip_shim_cancellation_polls_remaining(struct imageflow_context *context);
 
 #ifdef __cplusplus
 }

@@ -72,7 +72,7 @@ IFHIP_API int ifhip_device_count(void);            /* number of usable gfx950 de
 IFHIP_API int ifhip_set_device(int ordinal);       /* one process per GPU: call once with LOCAL_RANK       */
 
 /* ---- host-side tables (no GPU needed) ---------------------------------------------------------------- */
-/* graphics/bitmaps.rs:712-740 Bitmap::get_stride::<u8>(w, h, 4, 64). */
+/* graphics/bitmaps.rs:712-740 Bitmap::get_stride::<u8>(w, h, 4, 64); 0 when the row does not fit 32 bits. */
 IFHIP_API uint32_t ifhip_stride_for_width(uint32_t w);
 /* graphics/weights.rs:681-788 populate_weights + PixelWeightIndexes (:555-571).  left[u]/count[u] give the first
  * source pixel and tap count of output pixel u; weights are concatenated in output order.  Pass

@@ -236,3 +236,282 @@ def test_libjpeg_turbo_preset_progressive_and_optimised_tables(extra, pillow):
     buf = io.BytesIO()
     PIL.fromarray(rgb).save(buf, "JPEG", quality=88, subsampling="4:2:0", **pillow)
     assert got == buf.getvalue()
+
+
+# ---- round 3: the compose nodes at the boundary the reference exposes, the node semantics ADVICE flagged ---------------
+def _canvas_rows(w, h, fill=None):
+    can = np.zeros((h, U.stride_for(w)), np.uint8)
+    if fill is not None:
+        can[:, :4 * w] = np.tile(np.array(fill, np.uint8), w)
+    return can
+
+
+def test_same_size_and_mixed_ratio_resamples_pick_the_filter_like_the_reference():
+    """scale_render.rs:253-261: `upscaling = w > in.w || h > in.h` picks up_filter (Ginseng), everything else -- same
+    size, or smaller in both -- down_filter (Robidoux).  Same-size + sharpen must blur/sharpen with Robidoux, and a
+    wider-but-shorter target must use the UP filter."""
+    src = U.random_frames(1, 120, 90, seed0=5, alpha=False)[0]
+
+    def run(w, h, hints):
+        with Context() as c:
+            c.add_input_buffer(0, pack_raw_bgra(src, 120, 90, alpha_meaningful=False))
+            c.add_output_buffer(1)
+            _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"resample_2d": {"w": w, "h": h, "hints": hints}},
+                                                            {"encode": {"io_id": 1, "preset": "gif"}}]}})
+            return unpack_raw_bgra(c.get_output_buffer(1))[0]
+    same = run(120, 90, {"sharpen_percent": 30})
+    assert np.array_equal(same, _oracle_resize(src, 120, 90, 120, 90, filter_id=2, sharpen=30.0))            # Robidoux, not Ginseng
+    assert not np.array_equal(same, _oracle_resize(src, 120, 90, 120, 90, filter_id=4, sharpen=30.0))
+    always = run(120, 90, {"resample_when": "always"})
+    assert np.array_equal(always, _oracle_resize(src, 120, 90, 120, 90, filter_id=2))
+    mixed = run(200, 45, {})                                                                                   # wider, shorter
+    assert np.array_equal(mixed, _oracle_resize(src, 120, 90, 200, 45, filter_id=4))                          # Ginseng
+    mixed2 = run(200, 45, {"up_filter": "hermite", "down_filter": "box"})
+    assert np.array_equal(mixed2, _oracle_resize(src, 120, 90, 200, 45, filter_id=16))
+    # sharpen_when / resample_when gates (scale_render.rs:55-78): sharpening asked for down-scaling only, size unchanged,
+    # default resample_when -> the node disappears
+    assert np.array_equal(run(120, 90, {"sharpen_percent": 30, "sharpen_when": "downscaling"}), src)
+    assert np.array_equal(run(120, 90, {"sharpen_percent": 30, "resample_when": "size_differs"}), src)
+    assert np.array_equal(run(60, 45, {"sharpen_percent": 30, "sharpen_when": "upscaling"}), _oracle_resize(src, 120, 90, 60, 45, filter_id=2))
+
+
+def test_same_size_matte_job_on_a_bgra_parent():
+    """scale_render.rs:44-47,80: a Bgra32 parent with a background_color is resampled even at the same size (matte)."""
+    src = U.random_frames(1, 64, 48, seed0=6, alpha=True)[0]
+    with Context() as c:
+        c.add_input_buffer(0, pack_raw_bgra(src, 64, 48, alpha_meaningful=True))
+        c.add_output_buffer(1)
+        _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}},
+                                                        {"resample_2d": {"w": 64, "h": 48, "hints": {"background_color": {"srgb": {"hex": "336699"}}}}},
+                                                        {"encode": {"io_id": 1, "preset": "gif"}}]}})
+        rows, w, h, alpha = unpack_raw_bgra(c.get_output_buffer(1))
+    can = _canvas_rows(64, 48, (0x99, 0x66, 0x33, 0xFF))
+    rc, _ = O.scale_and_render(src, 64, 48, can, 64, 48, 0, 0, 64, 48, filter_id=2, compositing=O.BLEND_WITH_MATTE, matte_bgra=0xFF336699, alpha_meaningful=True)
+    assert rc == 0 and not alpha and np.array_equal(rows, can)
+
+
+def _graph(nodes, edges):
+    return {"framewise": {"graph": {"nodes": {str(k): v for k, v in nodes.items()},
+                                    "edges": [{"from": a, "to": b, "kind": k} for a, b, k in edges]}}}
+
+
+def test_graph_draw_image_exact_matches_the_oracle_chain():
+    """visuals/composition.rs:175-230 (test_graph_draw_image_exact): overlay (alpha) drawn at (200,200) 100x100 with blend
+    compose onto a background that was first resized to 400x400 -- the JSON the reference builds, checked against
+    oracle(resize) -> oracle(scale_and_render BlendWithSelf at x,y)."""
+    overlay = U.random_frames(1, 160, 120, seed0=31, alpha=True)[0]
+    back = U.random_frames(1, 500, 430, seed0=32, alpha=False)[0]
+    hints = {"down_filter": "robidoux", "up_filter": "robidoux"}                      # ResampleHints::with_bi_filter
+    job = _graph({0: {"decode": {"io_id": 0}}, 1: {"decode": {"io_id": 1}}, 2: {"resample_2d": {"w": 400, "h": 400, "hints": hints}},
+                  3: {"draw_image_exact": {"x": 200, "y": 200, "w": 100, "h": 100, "blend": "compose", "hints": hints}},
+                  4: {"encode": {"io_id": 2, "preset": {"lodepng": {"maximum_deflate": None}}}}},
+                 [(1, 2, "input"), (0, 3, "input"), (2, 3, "canvas"), (3, 4, "input")])
+    with Context() as c:
+        c.add_input_buffer(0, pack_raw_bgra(overlay, 160, 120, alpha_meaningful=True))
+        c.add_input_buffer(1, pack_raw_bgra(back, 500, 430, alpha_meaningful=False))
+        c.add_output_buffer(2)
+        r = _run(c, "v1/execute", job)
+        rows, w, h, alpha = unpack_raw_bgra(c.take_output_buffer(2))
+        names = [n["name"] for n in r["data"]["job_result"]["performance"]["frames"][0]["nodes"]]
+    assert sorted(names) == sorted(["primitive_decoder", "primitive_decoder", "create_canvas", "draw_image_to_canvas", "draw_image_to_canvas", "primitive_encoder"])
+    can = _oracle_resize(back, 500, 430, 400, 400, filter_id=2)
+    rc, _ = O.scale_and_render(overlay, 160, 120, can, 400, 400, 200, 200, 100, 100, filter_id=2, compositing=O.BLEND_WITH_SELF, alpha_meaningful=True)
+    assert rc == 0 and (w, h) == (400, 400) and np.array_equal(rows, can)
+    # blend overwrite: the rect is replaced, alpha and all
+    job["framewise"]["graph"]["nodes"]["3"]["draw_image_exact"]["blend"] = "overwrite"
+    with Context() as c:
+        c.add_input_buffer(0, pack_raw_bgra(overlay, 160, 120, alpha_meaningful=True))
+        c.add_input_buffer(1, pack_raw_bgra(back, 500, 430, alpha_meaningful=False))
+        c.add_output_buffer(2)
+        _run(c, "v1/execute", job)
+        rows2 = unpack_raw_bgra(c.get_output_buffer(2))[0]
+    can2 = _oracle_resize(back, 500, 430, 400, 400, filter_id=2)
+    rc, _ = O.scale_and_render(overlay, 160, 120, can2, 400, 400, 200, 200, 100, 100, filter_id=2, compositing=O.REPLACE_SELF, alpha_meaningful=True)
+    assert rc == 0 and np.array_equal(rows2, can2) and not np.array_equal(rows2, rows)
+    # a rect outside the canvas is InvalidNodeParams (scale_render.rs:237-240)
+    job["framewise"]["graph"]["nodes"]["3"]["draw_image_exact"]["x"] = 350
+    with Context() as c:
+        c.add_input_buffer(0, pack_raw_bgra(overlay, 160, 120, alpha_meaningful=True))
+        c.add_input_buffer(1, pack_raw_bgra(back, 500, 430, alpha_meaningful=False))
+        c.add_output_buffer(2)
+        status, r = c.send_json("v1/execute", job)
+        assert status == 400 and c.error_code() == 2 and "does not fit canvas size 400x400" in r["message"]
+
+
+def test_graph_copy_rect_to_canvas_matches_the_oracle():
+    """visuals/composition.rs:111-160 (test_graph_copy_rect_to_canvas): 100x100 of the input copied to (50,50) of a red
+    300x300 Bgra32 canvas."""
+    src = U.random_frames(1, 220, 140, seed0=41, alpha=False)[0]
+    job = _graph({0: {"decode": {"io_id": 0}}, 1: {"create_canvas": {"w": 300, "h": 300, "format": "bgra_32", "color": {"srgb": {"hex": "FF0000FF"}}}},
+                  2: {"copy_rect_to_canvas": {"x": 50, "y": 50, "from_x": 0, "from_y": 0, "w": 100, "h": 100}},
+                  3: {"encode": {"io_id": 1, "preset": {"lodepng": {"maximum_deflate": None}}}}},
+                 [(0, 2, "input"), (1, 2, "canvas"), (2, 3, "input")])
+    with Context() as c:
+        c.add_input_buffer(0, pack_raw_bgra(src, 220, 140, alpha_meaningful=False))
+        c.add_output_buffer(1)
+        _run(c, "v1/execute", job)
+        rows, w, h, alpha = unpack_raw_bgra(c.get_output_buffer(1))
+    can = _canvas_rows(300, 300, (0, 0, 255, 255))
+    inp = src.copy()
+    rc, can_alpha = O.copy_rect(inp, 220, 140, inp.shape[1], False, can, 300, 300, can.shape[1], True, 0, 0, 50, 50, 100, 100)
+    assert rc == 0 and (w, h) == (300, 300) and alpha == can_alpha and np.array_equal(rows[:, :1200], can[:, :1200])
+    job["framewise"]["graph"]["nodes"]["2"]["copy_rect_to_canvas"]["from_x"] = 200          # 200 + 100 > 220
+    with Context() as c:
+        c.add_input_buffer(0, pack_raw_bgra(src, 220, 140, alpha_meaningful=False))
+        c.add_output_buffer(1)
+        status, r = c.send_json("v1/execute", job)
+        assert status == 400 and "Invalid coordinates" in r["message"]
+
+
+@pytest.mark.parametrize("wm,place", [
+    ({"io_id": 1}, None),                                                                                   # defaults: whole canvas, within, centre
+    ({"io_id": 1, "fit_box": {"image_percentage": {"x1": 60, "y1": 60, "x2": 95, "y2": 95}}, "fit_mode": "fit", "gravity": {"percentage": {"x": 100, "y": 100}}, "opacity": 0.6}, None),
+    ({"io_id": 1, "fit_box": {"image_margins": {"left": 10, "top": 20, "right": 150, "bottom": 100}}, "fit_mode": "distort", "opacity": 0.25}, None),
+    ({"io_id": 1, "min_canvas_width": 500}, "skipped"),
+])
+def test_watermark_node_through_the_job_interface(wm, place):
+    """flow/nodes/watermark.rs:100-196 sent as JSON: bounding box, constraint, gravity, [alpha(opacity)], DrawImageExact
+    (Compose).  Expected pixels: the same placement arithmetic restated here + the oracle chain."""
+    import math
+    cw, ch, mw, mh = 320, 200, 90, 40
+    back = U.random_frames(1, cw, ch, seed0=51, alpha=False)[0]
+    mark = U.random_frames(1, mw, mh, seed0=52, alpha=True)[0]
+    with Context() as c:
+        c.add_input_buffer(0, pack_raw_bgra(back, cw, ch, alpha_meaningful=False))
+        c.add_input_buffer(1, pack_raw_bgra(mark, mw, mh, alpha_meaningful=True))
+        c.add_output_buffer(2)
+        _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"watermark": wm}, {"encode": {"io_id": 2, "preset": "gif"}}]}})
+        rows, w, h, _ = unpack_raw_bgra(c.get_output_buffer(2))
+    if place == "skipped":
+        assert np.array_equal(rows, back)
+        return
+    f32 = np.float32
+
+    def rnd(v):                                                       # f32::round
+        return int(math.copysign(math.floor(abs(float(v)) + 0.5), float(v)))
+    box = (0, 0, cw, ch)
+    fb = wm.get("fit_box")
+    if fb and "image_percentage" in fb:
+        p = fb["image_percentage"]
+        box = tuple(rnd(f32(min(max(p[k], 0), 100)) / f32(100) * f32(s)) for k, s in (("x1", cw), ("y1", ch), ("x2", cw), ("y2", ch)))
+    elif fb:
+        m = fb["image_margins"]
+        box = (m["left"], m["top"], cw - m["right"], ch - m["bottom"])
+    bw, bh = box[2] - box[0], box[3] - box[1]
+    mode = wm.get("fit_mode", "within")
+    if mode == "distort":
+        tw, th = bw, bh
+    elif mode == "within" and mw <= bw and mh <= bh:
+        tw, th = mw, mh
+    elif mw / mh > bw / bh:
+        tw, th = bw, max(1, rnd(bw / (mw / mh)))
+    else:
+        tw, th = max(1, rnd(bh * (mw / mh))), bh
+    g = wm.get("gravity", {}).get("percentage", {"x": 50, "y": 50}) if isinstance(wm.get("gravity"), dict) else {"x": 50, "y": 50}
+    x = rnd(f32(bw - tw) * (f32(min(max(g["x"], 0), 100)) / f32(100))) + box[0]
+    y = rnd(f32(bh - th) * (f32(min(max(g["y"], 0), 100)) / f32(100))) + box[1]
+    m2 = mark.copy()
+    op = wm.get("opacity", 1.0)
+    if op < 1.0:
+        mat = np.eye(5, dtype=np.float32)
+        mat[3, 3] = op
+        O.apply_color_matrix(m2, mw, mh, m2.shape[1], mat)
+    can = back.copy()
+    rc, _ = O.scale_and_render(m2, mw, mh, can, cw, ch, x, y, tw, th, filter_id=4 if (tw > mw or th > mh) else 2,
+                               compositing=O.BLEND_WITH_SELF, alpha_meaningful=True)
+    assert rc == 0 and np.array_equal(rows, can), (box, tw, th, x, y)
+    assert not np.array_equal(rows, back)
+
+
+def test_color_and_orientation_nodes_equal_the_oracle():
+    src = U.random_frames(1, 50, 30, seed0=61, alpha=True)[0]
+    with Context() as c:
+        c.add_input_buffer(0, pack_raw_bgra(src, 50, 30, alpha_meaningful=True))
+        c.add_output_buffer(1)
+        _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"color_filter_srgb": "sepia"}, {"color_filter_srgb": {"contrast": 0.3}},
+                                                        {"apply_orientation": {"flag": 7}}, {"encode": {"io_id": 1, "preset": "gif"}}]}})
+        rows, w, h, _ = unpack_raw_bgra(c.get_output_buffer(1))
+    from imageflow_amd.flow.nodes import color as CN
+    exp = src.copy()
+    O.apply_color_matrix(exp, 50, 30, exp.shape[1], CN.sepia())
+    O.apply_color_matrix(exp, 50, 30, exp.shape[1], CN.contrast(0.3))
+    O.flip_vertical(exp, 50, 30, exp.shape[1])                           # flag 7 = rotate_180, transpose
+    O.flip_horizontal(exp, 50, 30, exp.shape[1])
+    t = np.zeros((50, U.stride_for(30)), np.uint8)
+    O.transpose(exp, 50, 30, exp.shape[1], t, 30, 50, t.shape[1])
+    assert (w, h) == (30, 50) and np.array_equal(rows[:, :120], t[:, :120])
+
+
+JOB_STEPS = [{"decode": {"io_id": 0}}, "flip_h", "rotate_90", {"resample_2d": {"w": 30, "h": 20, "hints": {"sharpen_percent": None}}},
+             {"constrain": {"mode": "within", "w": 5, "h": 5}}, {"encode": {"io_id": 1, "preset": "gif"}}]
+
+
+def test_job_with_cancellation_at_every_point():
+    """imageflow_abi/src/lib.rs:1669-1743: cancel at the n-th poll for n = 1, 2, ... -- every run either ends in category
+    21 with the countdown used up, or (first n beyond the job's poll count) completes without error."""
+    src = U.random_frames(1, 80, 60, seed0=71, alpha=True)[0]
+    n = 1
+    while True:
+        assert n < 200, "the job never ran out of cancellation points"
+        with Context() as c:
+            c.add_input_buffer(0, pack_raw_bgra(src, 80, 60))
+            c.add_output_buffer(1)
+            c.L.ifhip_shim_request_cancellation_after_n_polls(c.p, n)
+            status, r = c.send_json("v1/execute", {"framewise": {"steps": JOB_STEPS}})
+            left = c.L.ifhip_shim_cancellation_polls_remaining(c.p)
+            if left > 0:
+                assert status == 200 and not c.has_error() and left < n
+                assert len(c.get_output_buffer(1)) > 24
+                break
+            assert status == 499 and c.error_code() == 21, (n, status, r)
+        n += 1
+    assert n > 8                                                                     # at least one poll per node
+
+
+def test_cancellation_from_another_thread_while_a_job_runs():
+    import threading
+    src = U.random_frames(1, 2000, 1500, seed0=72, alpha=False)[0]
+    steps = [{"decode": {"io_id": 0}}] + [{"resample_2d": {"w": 1000 + (i % 2), "h": 750, "hints": {"resample_when": "always"}}} for i in range(400)]
+    with Context() as c:
+        c.add_input_buffer(0, pack_raw_bgra(src, 2000, 1500, alpha_meaningful=False))
+        t = threading.Timer(0.05, c.request_cancellation)
+        t.start()
+        status, r = c.send_json("v1/execute", {"framewise": {"steps": steps}})
+        t.join()
+        assert status == 499 and c.error_code() == 21
+
+
+def test_performance_block_and_take_output_buffer():
+    src = U.random_frames(1, 640, 480, seed0=81, alpha=False)[0]
+    with Context() as c:
+        c.add_input_buffer(0, pack_raw_bgra(src, 640, 480, alpha_meaningful=False))
+        c.add_output_buffer(1)
+        r = _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"resample_2d": {"w": 64, "h": 48}}, {"encode": {"io_id": 1, "preset": "gif"}}]}})
+        perf = r["data"]["job_result"]["performance"]["frames"]
+        assert len(perf) == 1
+        f = perf[0]
+        walls = [n["wall_microseconds"] for n in f["nodes"]]
+        assert walls == sorted(walls, reverse=True)                                   # execution_engine.rs:188-189
+        assert {n["name"] for n in f["nodes"]} == {"primitive_decoder", "create_canvas", "draw_image_to_canvas", "primitive_encoder"}
+        assert f["wall_microseconds"] >= sum(walls) + f["overhead_microseconds"] - len(walls)
+        draw = [n for n in f["nodes"] if n["name"] == "draw_image_to_canvas"][0]
+        assert 0 < draw["gpu_microseconds"] <= draw["wall_microseconds"] + 1
+        taken = c.take_output_buffer(1)
+        assert taken is not None and np.array_equal(unpack_raw_bgra(taken)[0], _oracle_resize(src, 640, 480, 64, 48))
+        assert c.take_output_buffer(1) is None and c.get_output_buffer(1) is None
+
+
+def test_matte_applying_encode_does_not_touch_a_frame_other_nodes_still_read():
+    """graph mode: libjpeg_turbo's encode flattens in place (mozjpeg.rs:88-94) -- on a private copy when the frame has
+    other consumers."""
+    src = U.random_frames(1, 48, 32, seed0=91, alpha=True)[0]
+    job = _graph({0: {"decode": {"io_id": 0}}, 1: {"encode": {"io_id": 1, "preset": {"libjpeg_turbo": {"quality": 80}}}}, 2: {"encode": {"io_id": 2, "preset": "gif"}}},
+                 [(0, 1, "input"), (0, 2, "input")])
+    with Context() as c:
+        c.add_input_buffer(0, pack_raw_bgra(src, 48, 32, alpha_meaningful=True))
+        c.add_output_buffer(1)
+        c.add_output_buffer(2)
+        _run(c, "v1/execute", job)
+        rows, w, h, alpha = unpack_raw_bgra(c.get_output_buffer(2))
+        assert alpha and np.array_equal(rows[:, :4 * w], src[:, :4 * w])
+        assert c.get_output_buffer(1)[:2] == b"\xff\xd8"
