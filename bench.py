@@ -9,7 +9,10 @@ JPEG decode).  One "step" = one pass of the hot path over the rank's whole batch
 
 Multi-GPU: images are independent, so frame i of a job belongs to rank floor(i * N / total)
 (imageflow_amd/sharding.py) and nothing is exchanged on the data path; the job's only collective is the RCCL gather of
-the finished outputs to rank 0, issued once inside the timed region.
+the finished outputs to rank 0, issued once inside the timed region -- after the same gather (same tensors, same call) ran
+once during warm-up, so that RCCL's lazy peer-to-peer set-up is not what gets timed.  The line carries `gather_ms`,
+`value_without_gather` and, for the default workload, `strong_1024`: the north_star job (1 024 images cut into N blocks)
+measured the same way in the same run, so one series of runs at N = 1, 2, 4, 8 gives both scaling curves.
   --scaling weak   (default) every rank owns --frames frames (256): per-GPU work fixed.
   --scaling strong the job is --total-frames frames (1024, the north_star batch) cut into N contiguous blocks.
 `--gpus N` with no torch.distributed environment re-executes this file under `python -m torch.distributed.run` with N
@@ -31,6 +34,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_PROC_BIND", "spread")                    # cpu_baseline: one frame per core, threads pinned apart
+os.environ.setdefault("OMP_PLACES", "cores")
 
 FRAMES_PER_GPU = 256
 HBM_PEAK = 8.0e12                                                   # MI355X_MICROARCH.md: 8 TB/s spec
@@ -94,7 +99,7 @@ def cpu_baseline(sample_seconds=15.0):
     O.scale_and_render_batch(fr.reshape(1, -1), can.reshape(1, -1), in_w, in_h, fr.shape[2], out_w, out_h, cst,
                              0, 0, out_w, out_h, n_threads=1)
     t1 = time.perf_counter() - t0
-    n = min(4 * cores, 96)
+    n = max(cores, 8)                                    # every thread has a frame in every pass (33 MB each)
     frames = np.concatenate([U.gradient_frames(n // 2, in_w, in_h), U.random_frames(n - n // 2, in_w, in_h, alpha=False)])
     cans = np.zeros((n, out_h * cst), np.uint8)
     flat = frames.reshape(n, -1)
@@ -117,7 +122,10 @@ def cpu_baseline(sample_seconds=15.0):
     return {"value": round(mp / total, 2), "unit": "MP/s", "cores": cores, "kind": "port",
             "single_thread_MPps": round(in_w * in_h / 1e6 / t1, 2),
             "sample": f"{reps} passes over {n} frames 3840x2160->200x200 Robidoux linear (half gradient, half random), "
-                      f"{total:.1f} s wall, oracle/if_oracle.c -O3 x86-64-v3, {cores} OpenMP threads (one frame per thread)",
+                      f"{total:.1f} s wall, oracle/if_oracle.c -O3 x86-64-v3, {cores} OpenMP threads (one frame per thread, "
+                      f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')})",
+            "note": "a NAIVE scalar port of the reference's arithmetic (test infrastructure), not a tuned resizer: expect it "
+                    ">= 10x below the reference's own SIMD (zenresize) path on the same cores; never a target, never credit",
             "reference_leg": ("cargo present but the reference tree is not on this box" if cargo and not ref_tree else
                               "not run: no Rust toolchain on this box (cargo not found)" if not cargo else
                               "cargo and tree present: run `cargo bench -p imageflow_core --bench bench_graphics -- full_scale_pipeline` by hand")}
@@ -171,6 +179,8 @@ def parse_args(argv=None):
                          "buffered against the next step; none: results stay sharded")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-strong-field", action="store_true",
+                    help="skip the extra `strong_1024` measurement (the --total-frames job cut into N blocks) of a weak cfg2 run")
     return ap.parse_args(argv)
 
 
@@ -233,95 +243,156 @@ def main():
     if n < 1:
         raise SystemExit(f"rank {rank} owns no frames ({total} frames over {world} ranks)")
     n_max = -(-total // world)                           # gather slots are sized by the largest block
+    # the extra north_star measurement of a default run: --total-frames images cut into `world` blocks
+    strong_field = (args.scaling == "weak" and args.workload == "cfg2" and not args.no_strong_field and not pyramid)
+    s_lo, s_hi = shard_range(args.total_frames, rank, world) if strong_field else (0, 0)
+    n_strong = s_hi - s_lo
+    if strong_field and n_strong < 1:
+        strong_field = False
+    n_alloc = max(n, n_strong)
 
-    inp = make_frames(torch, n, lo, rank, dev, args.pattern, in_w, in_h)
-    inp.alpha_meaningful = wl[6]
+    ranks_info = [{"rank": rank, "device": torch.cuda.get_device_name(local_rank), "local_rank": local_rank}]
+    if distributed:
+        objs = [None] * world
+        dist.all_gather_object(objs, ranks_info[0])
+        ranks_info = objs
+
+    inp_all = make_frames(torch, n_alloc, lo, rank, dev, args.pattern, in_w, in_h)
+    inp_all.alpha_meaningful = wl[6]
     if wl[6]:
-        inp.data.view(n, in_h, -1)[:, :, 3::4] = torch.randint(0, 256, (n, in_h, inp.stride // 4), dtype=torch.uint8, device=dev)
-    if pyramid:
-        sizes = {name: (w, h) for _, name, w, h in PYRAMID}
-        levels = {name: Bitmap.create_u8(n_max, w, h, dev) for name, (w, h) in sizes.items()}
-        for b in levels.values():
-            b.data = b.data[:n]
-        chain = []
-        for a, b, w, h in PYRAMID:
-            s = inp if a == "src" else levels[a]
-            chain.append((s, levels[b], ScaleAndRenderParams(0, 0, w, h), plan_for(s.w, s.h, w, h, Filter.Robidoux, 0.0, dev)))
-        out_bytes_per_frame = sum(b.image_bytes for b in levels.values())
-        packed = torch.empty((n_max, out_bytes_per_frame), dtype=torch.uint8, device=dev)     # the four outputs of a frame, side by side
-        canv = None
-    else:
-        canv = [Bitmap.create_u8(n_max, out_w, out_h, dev, compose=BitmapCompositing[wl[7]], matte=wl[8]) for _ in range(2)]
-        views = [Bitmap(c.data[:n], c.w, c.h, c.stride, c.alpha_meaningful, c.compose, c.matte) for c in canv]
-        info = ScaleAndRenderParams(0, 0, out_w, out_h, wl[5], Filter[wl[4]])
-        plan = plan_for(in_w, in_h, out_w, out_h, info.interpolation_filter, wl[5], dev)
-        out_bytes_per_frame = canv[0].image_bytes
+        inp_all.data.view(n_alloc, in_h, -1)[:, :, 3::4] = torch.randint(0, 256, (n_alloc, in_h, inp_all.stride // 4), dtype=torch.uint8, device=dev)
+
+    def first_frames(b, k):
+        return Bitmap(b.data[:k], b.w, b.h, b.stride, b.alpha_meaningful, b.compose, b.matte)
+    inp = first_frames(inp_all, n)
     mode = "none" if (not distributed or args.no_gather or os.environ.get("IFHIP_BENCH_GATHER", "1") == "0") else args.gather
     if pyramid and mode == "every":
         raise SystemExit("--workload cfg3 gathers once per job: use --gather final or none")
     if dryrun and mode == "every":  # gloo cannot gather device tensors; the dry run only walks the final gather (via the host)
         raise SystemExit("dry run: pass --gather final or none")
-    gathered = None
-    if mode != "none" and rank == 0:
-        gathered = [torch.empty((world, n_max, out_bytes_per_frame), dtype=torch.uint8, device="cpu" if dryrun else dev)
-                    for _ in range(2 if mode == "every" else 1)]
     gather_note = {"none": "none",
                    "every": "rccl gather of the outputs to rank 0 every step, asynchronous, double buffered",
-                   "final": "rccl gather of the outputs to rank 0 once, at the end of the timed region"}[mode]
+                   "final": "rccl gather of the outputs to rank 0 once, at the end of the timed region "
+                            "(the same gather ran once during warm-up)"}[mode]
+    gather_calls = {"warmup": 0, "timed": 0}
 
-    def step(i, pending):
-        if pyramid:
-            for s, d, inf, pl in chain:
-                scale_and_render(s, d, inf, plan=pl)
-            return
-        if mode == "every" and pending[i & 1] is not None:
-            pending[i & 1].wait()                  # the buffer we are about to overwrite has been gathered
-            pending[i & 1] = None
-        scale_and_render(inp, views[i & 1], info, plan=plan)
-        if mode == "every":
-            pending[i & 1], _ = gather_to_root(canv[i & 1].data, 0, async_op=True, out=gathered[i & 1] if rank == 0 else None)
+    class Job:
+        """One measured job: `nj` frames on this rank out of `total_j`; owns its canvases and gather buffers."""
 
-    def sync_all(pending):
-        for k in range(2):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
-        torch.cuda.synchronize()
+        def __init__(self, nj, total_j):
+            self.n, self.total = nj, total_j
+            self.n_max = -(-total_j // world)
+            self.inp = first_frames(inp_all, nj)
+            if pyramid:
+                sizes = {name: (w, h) for _, name, w, h in PYRAMID}
+                self.levels = {name: Bitmap.create_u8(self.n_max, w, h, dev) for name, (w, h) in sizes.items()}
+                for b in self.levels.values():
+                    b.data = b.data[:nj]
+                self.chain = []
+                for a, b, w, h in PYRAMID:
+                    s = self.inp if a == "src" else self.levels[a]
+                    self.chain.append((s, self.levels[b], ScaleAndRenderParams(0, 0, w, h), plan_for(s.w, s.h, w, h, Filter.Robidoux, 0.0, dev)))
+                self.out_bytes_per_frame = sum(b.image_bytes for b in self.levels.values())
+                self.packed = torch.empty((self.n_max, self.out_bytes_per_frame), dtype=torch.uint8, device=dev)   # the four outputs of a frame, side by side
+            else:
+                self.canv = [Bitmap.create_u8(self.n_max, out_w, out_h, dev, compose=BitmapCompositing[wl[7]], matte=wl[8]) for _ in range(2)]
+                self.views = [first_frames(c, nj) for c in self.canv]
+                self.info = ScaleAndRenderParams(0, 0, out_w, out_h, wl[5], Filter[wl[4]])
+                self.plan = plan_for(in_w, in_h, out_w, out_h, self.info.interpolation_filter, wl[5], dev)
+                self.out_bytes_per_frame = self.canv[0].image_bytes
+            self.gathered = None
+            if mode != "none" and rank == 0:
+                self.gathered = [torch.empty((world, self.n_max, self.out_bytes_per_frame), dtype=torch.uint8, device="cpu" if dryrun else dev)
+                                 for _ in range(2 if mode == "every" else 1)]
+            self.pending = [None, None]
+            self.note = gather_note
 
-    def final_payload():
-        if not pyramid:
-            return canv[(args.steps - 1) & 1].data
-        off = 0
-        for b in levels.values():                                  # device-side packing: one message per rank
-            packed[:n, off:off + b.image_bytes] = b.data
-            off += b.image_bytes
-        return packed
+        def step(self, i):
+            if pyramid:
+                for s, d, inf, pl in self.chain:
+                    scale_and_render(s, d, inf, plan=pl)
+                return
+            if mode == "every" and self.pending[i & 1] is not None:
+                self.pending[i & 1].wait()             # the buffer we are about to overwrite has been gathered
+                self.pending[i & 1] = None
+            scale_and_render(self.inp, self.views[i & 1], self.info, plan=self.plan)
+            if mode == "every":
+                self.pending[i & 1], _ = gather_to_root(self.canv[i & 1].data, 0, async_op=True, out=self.gathered[i & 1] if rank == 0 else None)
 
-    pending = [None, None]
-    for i in range(args.warmup):
-        step(i, pending)
-    sync_all(pending)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, pending)
-    sync_all(pending)
-    if mode == "final":
-        # The frames never meet before this point (no data-path collective).  A gather kernel running beside the
-        # resample kernel would take CUs from a grid that is exactly one workgroup per CU, so the job's one exchange
-        # happens after the last batch; a failure here is reported, it does not cost the measurement.
-        try:
-            last = final_payload()
-            gather_to_root(last.cpu() if dryrun else last, 0, async_op=False, out=gathered[0] if rank == 0 else None)
-        except Exception as e:  # noqa: BLE001
-            gather_note = f"final rccl gather failed: {type(e).__name__}: {e}"
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, dev)
+        def sync_all(self):
+            for k in range(2):
+                if self.pending[k] is not None:
+                    self.pending[k].wait()
+                    self.pending[k] = None
+            torch.cuda.synchronize()
+
+        def final_payload(self, steps):
+            if not pyramid:
+                return self.canv[(steps - 1) & 1].data
+            off = 0
+            for b in self.levels.values():                             # device-side packing: one message per rank
+                self.packed[:self.n, off:off + b.image_bytes] = b.data
+                off += b.image_bytes
+            return self.packed
+
+        def final_gather(self, steps, phase):
+            # The frames never meet before this point (no data-path collective).  A gather kernel running beside the
+            # resample kernel would take CUs from a grid that is exactly one workgroup per CU, so the job's one exchange
+            # happens after the last batch; a failure here is reported, it does not cost the measurement.
+            try:
+                last = self.final_payload(steps)
+                gather_to_root(last.cpu() if dryrun else last, 0, async_op=False, out=self.gathered[0] if rank == 0 else None)
+                gather_calls[phase] += 1
+            except Exception as e:  # noqa: BLE001
+                self.note = f"final rccl gather failed: {type(e).__name__}: {e}"
+
+        def measure(self, steps, warmup):
+            """-> (whole-job seconds, seconds without the final gather), both max over ranks."""
+            for i in range(warmup):
+                self.step(i)
+            self.sync_all()
+            if mode == "final":
+                # RCCL sets its peer-to-peer channels up lazily on the first send/recv between two ranks (tens of ms): the
+                # job's gather runs once here, on the tensors and through the call the timed region uses
+                self.final_gather(steps, "warmup")
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                self.step(i)
+            self.sync_all()
+            t_compute = time.perf_counter() - t0
+            if mode == "final":
+                self.final_gather(steps, "timed")
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            return max_over_ranks(elapsed, dev), max_over_ranks(t_compute, dev)
+
+    job = Job(n, total)
+    elapsed, compute_s = job.measure(args.steps, args.warmup)
+    views, chain = (None, job.chain) if pyramid else (job.views, None)
+    info, plan = (None, None) if pyramid else (job.info, job.plan)
+    gather_note = job.note
+    main_gather_calls = dict(gather_calls)
+
+    strong = None
+    if strong_field:
+        gather_calls.update(warmup=0, timed=0)
+        sj = Job(n_strong, args.total_frames)
+        s_steps = max(1, min(args.steps, 20))
+        s_elapsed, s_compute = sj.measure(s_steps, max(1, min(args.warmup, 3)))
+        strong = {"total_frames": args.total_frames, "frames_per_gpu": n_strong, "steps": s_steps,
+                  "ms_per_step": round(s_elapsed / s_steps * 1e3, 4),
+                  "value": round(args.total_frames * in_w * in_h / 1e6 * s_steps / s_elapsed, 1),
+                  "value_without_gather": round(args.total_frames * in_w * in_h / 1e6 * s_steps / s_compute, 1),
+                  "gather_ms": round((s_elapsed - s_compute) * 1e3, 4), "unit": "MP/s", "scaling": "strong", "gather": sj.note,
+                  "gathers": dict(gather_calls),
+                  "what": f"north_star job: {args.total_frames} images cut into {world} contiguous blocks, same kernel, same timing rule; "
+                          f"speed-up over 1 GPU = this value at N divided by this value at N = 1"}
+        del sj
 
     # dominant-kernel duration: hipEvents on the launch stream around back-to-back launches of the same op
     launches = max(5, min(args.steps, 50))
@@ -366,16 +437,25 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "gather_ms": round((elapsed - compute_s) * 1e3, 4),
+            "value_without_gather": round(mp_per_step * args.steps / compute_s, 1),
             "config": {"workload": f"BASELINE {args.workload}: {total} frames ({n} on rank 0) {shape} {wl[4]}"
                                    f"{' sharpen ' + str(wl[5]) if wl[5] else ''}, linear light, {wl[7]}, "
                                    f"alpha {'meaningful' if wl[6] else 'not meaningful'}, device resident, pattern={args.pattern}",
-                       "frames_per_gpu": n, "total_frames": total, "kernel": kernel_name, "gather": gather_note},
+                       "frames_per_gpu": n, "total_frames": total, "kernel": kernel_name, "gather": gather_note,
+                       "gathers": main_gather_calls, "rccl_ranks": dist.get_world_size() if distributed else 1,
+                       "backend": (dist.get_backend() if distributed else "none"), "ranks": ranks_info},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": round(achieved / HBM_PEAK, 4),
+                         # the same bytes over the TIMED loop's step time (launch gaps, clock ramp and, at N > 1, the gather included)
+                         "frac_timed": round(algo_bytes / (compute_s / args.steps) / HBM_PEAK, 4),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
                          "measured_read_GBps": round(measured_read / 1e9, 1) if measured_read else None,
                          "frac_of_measured_read": round(achieved / measured_read, 4) if measured_read else None},
         }
+        if strong is not None:
+            out["strong_1024"] = strong
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":
             try:
                 out["cpu_baseline"] = cpu_baseline()

@@ -58,7 +58,7 @@ def test_sharded_hip_render_equals_single_process(tmp_path, world):
     assert np.array_equal(got.reshape(exp.shape), exp)
 
 
-@pytest.mark.parametrize("extra,scaling,total", [([], "weak", 16), (["--scaling", "strong", "--total-frames", "9"], "strong", 9),
+@pytest.mark.parametrize("extra,scaling,total", [(["--total-frames", "9"], "weak", 16), (["--scaling", "strong", "--total-frames", "9"], "strong", 9),
                                                  (["--workload", "cfg3", "--frames", "3"], "weak", 6)])
 def test_bench_launches_its_own_ranks(extra, scaling, total):
     env = _clean_env()
@@ -72,7 +72,16 @@ def test_bench_launches_its_own_ranks(extra, scaling, total):
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["scaling"] == scaling and j["config"]["total_frames"] == total, j
     assert "failed" not in j["config"]["gather"], j["config"]["gather"]
-    assert j["value"] > 0 and j["roofline"]["frac"] > 0
+    assert j["value"] > 0 and j["roofline"]["frac"] > 0 and j["roofline"]["frac_timed"] > 0
+    # the job's gather ran once during warm-up (RCCL's lazy channel set-up is not timed) and exactly once in the timed region
+    assert j["config"]["gathers"] == {"warmup": 1, "timed": 1}, j["config"]
+    assert j["config"]["rccl_ranks"] == 2 and len(j["config"]["ranks"]) == 2 and j["config"]["ranks"][1]["rank"] == 1
+    assert j["gather_ms"] >= 0 and j["value_without_gather"] >= j["value"]
+    if scaling == "weak" and "--workload" not in extra:              # the north_star job rides along with the default run
+        st = j["strong_1024"]
+        assert st["total_frames"] == 9 and st["frames_per_gpu"] == 5 and st["gathers"] == {"warmup": 1, "timed": 1} and st["value"] > 0
+    else:
+        assert "strong_1024" not in j
 
 
 def test_bench_refuses_a_mismatched_launcher():
