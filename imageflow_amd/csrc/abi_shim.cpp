@@ -490,7 +490,10 @@ struct Job {
         uint16_t qt[192];
         if (in.in_len < 3 || in.in[0] != 0xFF || in.in[1] != 0xD8)
             raise(kImageTypeNotSupported, "ImageTypeNotSupported: io_id %d is neither a JPEG nor the raw BGRA extension", io_id);
-        check(ifhip_jpeg_parse_headers(in.in, in.in_len, w, h, &nc, hs, vs, bw, bh, qt, &ri));
+        const int rc = ifhip_jpeg_parse_headers(in.in, in.in_len, w, h, &nc, hs, vs, bw, bh, qt, &ri);
+        if (rc == IFHIP_METHOD_NOT_IMPLEMENTED)
+            raise(kImageTypeNotSupported, "ImageTypeNotSupported: %s (baseline sequential JPEG only; keep other files on libjpeg)", ifhip_last_error_message());
+        check(rc);
     }
 
     // decode: MozJpegDecoder::read_frame (codecs/mozjpeg_decoder.rs:295-420) on the device, or the raw extension

@@ -28,6 +28,9 @@
 #ifndef IFHIP_HP_UNROLL
 #define IFHIP_HP_UNROLL 1    // per-pixel horizontal loop
 #endif
+#ifndef IFHIP_DOT4_LUT
+#define IFHIP_DOT4_LUT 1     // table addresses of the vertical pass by v_dot4_u32_u8 (0: byte extract + shift-add, for A/B)
+#endif
 #ifndef IFHIP_H_UNROLL
 #define IFHIP_H_UNROLL 1     // measured: 1 beats 2 and 3 (-1.7%); the chain is not latency-bound per group, code size matters
 #endif
@@ -157,14 +160,37 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     };
 
     // sample -> working float for the 4 pixels of one 16-byte load (arithmetic contract step 1)
+    // The LDS byte address of channel k's table entry, byte_k * (4 << copies_log2) + 4 * copy + table base, is ONE
+    // instruction: v_dot4_u32_u8(px, multiplier placed in byte k, lane constant) -- the other three byte products are
+    // zero.  (Byte extract + shift-add took two per gather: 12 of the 28 instructions a source pixel cost on cfg5.)
+    const uint32_t lut_mul = 4u << a.lut_copies_log2;                       // <= 128: fits the byte operand
+    // (the table's LDS address goes into the lane constant as an integer: an address the compiler forms itself costs an
+    // extra add of the dynamic-LDS base per gather)
+    typedef __attribute__((address_space(3))) const float lds_cfloat;
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    const uint32_t lut_lane = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(smem + L.lut))) + (lut.lane_off << 2);
     auto convert = [&](const raw_t& q, f32x2 (&vv)[NP]) {
         float v[PX][C];
+#if IFHIP_DOT4_LUT
+        // all addresses first, then all reads: a gather issued right behind its own address costs wait states
+        uint32_t ad[PX][3];
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ad[p][k] = __builtin_amdgcn_udot4(q[p], lut_mul << (8 * k), lut_lane, false);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int p = 0; p < PX; ++p) {
             const uint32_t px = q[p];
+#if IFHIP_DOT4_LUT
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[p][k] = *reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(ad[p][k]));
+#else
             v[p][0] = lut[px & 255u];
             v[p][1] = lut[(px >> 8) & 255u];
             v[p][2] = lut[(px >> 16) & 255u];
+#endif
             if (ALPHA) {
                 const float af = static_cast<float>(px >> 24) * (1.0f / 255.0f);
                 v[p][0] = v[p][0] * af;

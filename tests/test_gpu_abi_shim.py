@@ -270,8 +270,8 @@ def test_same_size_and_mixed_ratio_resamples_pick_the_filter_like_the_reference(
     assert np.array_equal(mixed2, _oracle_resize(src, 120, 90, 200, 45, filter_id=16))
     # sharpen_when / resample_when gates (scale_render.rs:55-78): sharpening asked for down-scaling only, size unchanged,
     # default resample_when -> the node disappears
-    assert np.array_equal(run(120, 90, {"sharpen_percent": 30, "sharpen_when": "downscaling"}), src)
-    assert np.array_equal(run(120, 90, {"sharpen_percent": 30, "resample_when": "size_differs"}), src)
+    assert np.array_equal(run(120, 90, {"sharpen_percent": 30, "sharpen_when": "downscaling"})[:, :480], src[:, :480])
+    assert np.array_equal(run(120, 90, {"sharpen_percent": 30, "resample_when": "size_differs"})[:, :480], src[:, :480])
     assert np.array_equal(run(60, 45, {"sharpen_percent": 30, "sharpen_when": "upscaling"}), _oracle_resize(src, 120, 90, 60, 45, filter_id=2))
 
 
@@ -383,7 +383,7 @@ def test_watermark_node_through_the_job_interface(wm, place):
         _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"watermark": wm}, {"encode": {"io_id": 2, "preset": "gif"}}]}})
         rows, w, h, _ = unpack_raw_bgra(c.get_output_buffer(2))
     if place == "skipped":
-        assert np.array_equal(rows, back)
+        assert np.array_equal(rows[:, :4 * cw], back[:, :4 * cw])
         return
     f32 = np.float32
 
@@ -419,8 +419,8 @@ def test_watermark_node_through_the_job_interface(wm, place):
     can = back.copy()
     rc, _ = O.scale_and_render(m2, mw, mh, can, cw, ch, x, y, tw, th, filter_id=4 if (tw > mw or th > mh) else 2,
                                compositing=O.BLEND_WITH_SELF, alpha_meaningful=True)
-    assert rc == 0 and np.array_equal(rows, can), (box, tw, th, x, y)
-    assert not np.array_equal(rows, back)
+    assert rc == 0 and np.array_equal(rows[:, :4 * cw], can[:, :4 * cw]), (box, tw, th, x, y)
+    assert not np.array_equal(rows[:, :4 * cw], back[:, :4 * cw])
 
 
 def test_color_and_orientation_nodes_equal_the_oracle():
