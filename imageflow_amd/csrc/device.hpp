@@ -88,6 +88,17 @@ constexpr FusedShape fused_shape(int K, int channels) {
          : (channels == 3 ? K <= 5 : K <= 4) ? FusedShape{1024, IFHIP_PLAIN_D, 0, 4}
                                              : FusedShape{IFHIP_NARROW_PX == 2 ? 1024 : 512, (IFHIP_NARROW_PX == 2 && K == 8) ? 6 : IFHIP_NARROW_D, 1, IFHIP_NARROW_PX};   // (K = 8: 6 rows, else the alpha variants spill)
 }
+// Ring slots whose vertical accumulation runs on the matrix pipe (v_mfma_f32_4x4x1: four slots per instruction, exact
+// fmaf -- see resample_fused.hip).  IFHIP_MFMA_MODE: 0 none, 1 every slot (rounded up to 4: unused slots carry weight +0),
+// 2 the whole groups of four only (the rest on v_pk_fma_f32), 3 the per-shape choice measured on MI355X.
+#ifndef IFHIP_MFMA_MODE
+#define IFHIP_MFMA_MODE 0
+#endif
+constexpr int fused_mfma_slots(int K, int channels) {
+    return IFHIP_MFMA_MODE == 1 ? 4 * ((K + 3) / 4)
+         : IFHIP_MFMA_MODE == 2 ? 4 * (K / 4)
+         : 0;
+}
 constexpr int fused_max_threads(int K, int channels) { return fused_shape(K, channels).threads; }
 constexpr int fused_max_quads(int K, int channels) { return fused_shape(K, channels).threads * fused_shape(K, channels).px / 4; }
 // the step whose row the kernel requests while working on step i (see build_vschedule)

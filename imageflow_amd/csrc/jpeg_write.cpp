@@ -196,6 +196,7 @@ struct Coder {
     void range(int nb, int limit) { bad |= nb > limit; }
     void reset() { std::memset(dc_count, 0, sizeof dc_count); std::memset(ac_count, 0, sizeof ac_count); tokens.clear(); }
     void sym(bool is_ac, int tbl, int s, uint32_t extra, int n_extra) {
+        if (s > 255) { bad = true; s = 255; }        // run 15 with 16 magnitude bits (a coefficient of -32768): refused by range(), never indexed
         if (w) {                                     // code and extra bits as one field (<= 16 + 11 bits)
             const uint32_t cs = (is_ac ? ac : dc)[tbl]->cs[s];
             w->put(((cs & 0xffffu) << n_extra) | (extra & ((1u << n_extra) - 1u)), static_cast<int>(cs >> 16) + n_extra);
@@ -252,8 +253,8 @@ inline uint64_t zigzag_mask(const int16_t* blk, int above) {
     const __m128i zero = _mm_setzero_si128(), lim = _mm_set1_epi16(static_cast<short>(above));
     for (int r = 0; r < 8; r += 2) {
         __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(blk + r * 8)), b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(blk + r * 8 + 8));
-        a = _mm_max_epi16(a, _mm_sub_epi16(zero, a));                                 // |x| (coefficients are far from -32768)
-        b = _mm_max_epi16(b, _mm_sub_epi16(zero, b));
+        a = _mm_max_epi16(a, _mm_subs_epi16(zero, a));                                // |x|, saturating: -32768 counts as 32767 (and is refused later)
+        b = _mm_max_epi16(b, _mm_subs_epi16(zero, b));
         const __m128i q = _mm_packs_epi16(_mm_cmpgt_epi16(a, lim), _mm_cmpgt_epi16(b, lim));
         nat |= static_cast<uint64_t>(static_cast<uint32_t>(_mm_movemask_epi8(q))) << (r * 8);
     }

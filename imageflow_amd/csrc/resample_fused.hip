@@ -143,13 +143,39 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     // f = p*C + c, so that the vertical pass issues v_pk_fma_f32 (two IEEE fmaf per instruction, the weight broadcast
     // from its SGPR): half the VALU issue slots of scalar v_fma_f32 for bit-identical results.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int NP = PX * C / 2;                  // pairs per lane and ring slot (PX pixels x C channels)
-    f32x2 acc[K][NP];
+    // Ring slots [0, KM) accumulate on the MATRIX pipe: v_mfma_f32_4x4x1_16b_f32 with the step's four slot weights as the
+    // A operand (lane 4b+i holds w[i]) and one converted sample per lane as B computes d[i] = w[i] * v + c[i] for four
+    // slots -- a rank-1 update with k = 1, i.e. four single-rounding fmaf (bit for bit, tools/probes/mfma_fma_probe.hip:
+    // 16.7 M cases on MI355X).  Not a GEMM: no sums inside the instruction, the chains stay strictly ascending.  What it
+    // was meant to buy: the K x PX x C multiply-adds per source row leave the VALU, which keeps the table gathers, the
+    // premultiply and the horizontal pass.  MEASURED (MI355X, round 3, gpurun_out r3_c): bit-exact on the whole resample
+    // suite, and slower on every shape -- cfg5 2.32 -> 2.65 ms with all slots (32 MFMA per row), 2.54 ms with slots 0..3
+    // (16 MFMA + 16 v_pk_fma); cfg2 with alpha 1.85 -> 1.93; cfg2 1.36 -> 1.43.  A 4x4x1 MFMA retires 256 multiply-adds
+    // in 8 cycles of its SIMD's matrix pipe, exactly the rate of v_pk_fma_f32 on the VALU, and the two waves a SIMD holds
+    // here run the same phases at the same time (row barrier), so the pipes take turns instead of overlapping.  Kept as
+    // a build switch (IFHIP_MFMA_MODE, default 0 = off) like IFHIP_PK_FMA; slots [KM, K) stay on v_pk_fma_f32.
+    constexpr int KM = fused_mfma_slots(K, C);
+    constexpr int KQ = KM / 4;                      // MFMA slot groups
+    constexpr int KV = K > KM ? K - KM : 0;         // slots on the VALU
+    constexpr int NV = PX * C;                      // samples per lane and source row
+    f32x4 accm[KQ ? KQ : 1][NV];
+    f32x2 acc[KV ? KV : 1][NP];
 #pragma unroll
-    for (int s = 0; s < K; ++s)
+    for (int s = 0; s < (KQ ? KQ : 1); ++s)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) accm[s][i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < (KV ? KV : 1); ++s)
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc[s][i] = f32x2{0.0f, 0.0f};
-    auto acc_at = [&](int s, int p, int c) -> float { const int f = p * C + c; return (f & 1) ? acc[s][f >> 1].y : acc[s][f >> 1].x; };
+    auto acc_at = [&](int s, int p, int c) -> float {
+        const int f = p * C + c;
+        if (s < KM) return accm[s >> 2][f][s & 3];
+        return (f & 1) ? acc[s - KM][f >> 1].y : acc[s - KM][f >> 1].x;
+    };
+    const uint32_t lane4 = threadIdx.x & 3u;        // this lane's row of the A operand
 
     typedef uint32_t raw_t __attribute__((ext_vector_type(PX)));        // one lane's PX source pixels
     auto fetch_row = [&](int y) -> raw_t {                               // y is wave-uniform; -1 = nothing needed
@@ -356,7 +382,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             const VStep& st = rec[cur];
             f32x2 (&v)[NP] = vbuf[cur];
 #if defined(IFHIP_EXP_LOAD_ONLY)   // experiment: stream rows, no arithmetic (NOT a product path)
-            acc[0][0] += v[0] + v[1] + v[2] + v[NP - 1];
+            acc[0][0] += v[0] + v[1] + v[2] + v[NP - 1];   // (builds with IFHIP_MFMA_MODE=0 only)
 #else
             // Every ring slot accumulates unconditionally: a slot outside its window holds exactly +0.0f (initial
             // value / reset at flush) and has weight +0.0f in the step record, and fmaf(+0, v, +0) == +0 for the
@@ -364,8 +390,17 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             // K scalar branches (and their instruction-fetch bubbles) per source row.
             if (st.y >= 0) {
 #pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    const float w = st.w[s];
+                for (int q = 0; q < KQ; ++q) {
+                    const float w01 = (lane4 & 1u) ? st.w[4 * q + 1] : st.w[4 * q];
+                    const float w23 = (lane4 & 1u) ? st.w[4 * q + 3] : st.w[4 * q + 2];
+                    const float wa = (lane4 & 2u) ? w23 : w01;
+#pragma unroll
+                    for (int f = 0; f < NV; ++f)
+                        accm[q][f] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa, (f & 1) ? v[f >> 1].y : v[f >> 1].x, accm[q][f], 0, 0, 0);
+                }
+#pragma unroll
+                for (int s = 0; s < KV; ++s) {
+                    const float w = st.w[KM + s];
 #pragma unroll
                     for (int i = 0; i < NP; ++i) {
 #if IFHIP_PK_FMA
@@ -421,8 +456,13 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                                 else *reinterpret_cast<float2*>(dst_row + 2u * plane_pitch + 2u * tid) = make_float2(acc_at(s, 0, 2), acc_at(s, 1, 2));
                             }
                         }
+                        if (s < KM) {
 #pragma unroll
-                        for (int i = 0; i < NP; ++i) acc[s][i] = f32x2{0.0f, 0.0f};
+                            for (int i = 0; i < NV; ++i) accm[s >> 2][i][s & 3] = 0.0f;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < NP; ++i) acc[s - KM][i] = f32x2{0.0f, 0.0f};
+                        }
                     }
                 }
                 // One barrier per output row.  After it: row j's vertical result (inter[j&1]) and row j-1's horizontal

@@ -317,7 +317,8 @@ def test_graph_draw_image_exact_matches_the_oracle_chain():
     can = _oracle_resize(back, 500, 430, 400, 400, filter_id=2)
     rc, _ = O.scale_and_render(overlay, 160, 120, can, 400, 400, 200, 200, 100, 100, filter_id=2, compositing=O.BLEND_WITH_SELF, alpha_meaningful=True)
     assert rc == 0 and (w, h) == (400, 400) and np.array_equal(rows, can)
-    # blend overwrite: the rect is replaced, alpha and all
+    # blend overwrite on THIS canvas changes nothing: the resample that produced it left it BlendWithSelf
+    # (scale_render.rs:314), and :284-292 only rewrites ReplaceSelf (compose) and BlendWithMatte (overwrite) canvases
     job["framewise"]["graph"]["nodes"]["3"]["draw_image_exact"]["blend"] = "overwrite"
     with Context() as c:
         c.add_input_buffer(0, pack_raw_bgra(overlay, 160, 120, alpha_meaningful=True))
@@ -325,9 +326,23 @@ def test_graph_draw_image_exact_matches_the_oracle_chain():
         c.add_output_buffer(2)
         _run(c, "v1/execute", job)
         rows2 = unpack_raw_bgra(c.get_output_buffer(2))[0]
-    can2 = _oracle_resize(back, 500, 430, 400, 400, filter_id=2)
-    rc, _ = O.scale_and_render(overlay, 160, 120, can2, 400, 400, 200, 200, 100, 100, filter_id=2, compositing=O.REPLACE_SELF, alpha_meaningful=True)
-    assert rc == 0 and np.array_equal(rows2, can2) and not np.array_equal(rows2, rows)
+    assert np.array_equal(rows2, rows)
+    # blend overwrite on a matte canvas from create_canvas (Bgra32): :287-292 turns it into ReplaceSelf -- the rect is
+    # replaced, alpha and all; with compose the same canvas blends with its matte
+    for blend, mode in (("overwrite", O.REPLACE_SELF), ("compose", O.BLEND_WITH_MATTE)):
+        job2 = _graph({0: {"decode": {"io_id": 0}}, 1: {"create_canvas": {"w": 400, "h": 400, "format": "bgra_32", "color": {"srgb": {"hex": "3366CCFF"}}}},
+                       3: {"draw_image_exact": {"x": 200, "y": 200, "w": 100, "h": 100, "blend": blend, "hints": hints}},
+                       4: {"encode": {"io_id": 2, "preset": {"lodepng": {"maximum_deflate": None}}}}},
+                      [(0, 3, "input"), (1, 3, "canvas"), (3, 4, "input")])
+        with Context() as c:
+            c.add_input_buffer(0, pack_raw_bgra(overlay, 160, 120, alpha_meaningful=True))
+            c.add_output_buffer(2)
+            _run(c, "v1/execute", job2)
+            rows3 = unpack_raw_bgra(c.get_output_buffer(2))[0]
+        can3 = _canvas_rows(400, 400, (0xCC, 0x66, 0x33, 0xFF))
+        rc, _ = O.scale_and_render(overlay, 160, 120, can3, 400, 400, 200, 200, 100, 100, filter_id=2, compositing=mode,
+                                   matte_bgra=0xFF3366CC, alpha_meaningful=True)
+        assert rc == 0 and np.array_equal(rows3[:, :1600], can3[:, :1600]), blend
     # a rect outside the canvas is InvalidNodeParams (scale_render.rs:237-240)
     job["framewise"]["graph"]["nodes"]["3"]["draw_image_exact"]["x"] = 350
     with Context() as c:
