@@ -478,7 +478,12 @@ def test_job_with_cancellation_at_every_point():
                 assert status == 200 and not c.has_error() and left < n
                 assert len(c.get_output_buffer(1)) > 24
                 break
-            assert status == 499 and c.error_code() == 21, (n, status, r)
+            if left == 0 and status == 200:
+                # the countdown ran out on the job's very last poll: `fetch_sub(1) < 1` (context.rs:63-71) cancels at poll
+                # n + 1, which this job does not have -- the reference's own loop just moves on here (lib.rs:1728-1740)
+                assert not c.has_error()
+            else:
+                assert left < 0 and status == 499 and c.error_code() == 21, (n, left, status, r)
         n += 1
     assert n > 8                                                                     # at least one poll per node
 
