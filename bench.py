@@ -51,6 +51,8 @@ WORKLOADS = {
     "cfg3-l3": (1200, 675, 400, 225, "Robidoux", 0.0, False, "ReplaceSelf", 0, 1024),
     "cfg4-resize": (1920, 1080, 800, 450, "Robidoux", 0.0, False, "ReplaceSelf", 0, 1024),
     "cfg1-resize": (480, 270, 200, 113, "Robidoux", 0.0, False, "ReplaceSelf", 0, 4096),
+    # one strip of cfg5 as a frame of its own (same ring, same taps, rows contiguous in memory): tells strip access from arithmetic
+    "cfg5-quarter": (1920, 4320, 100, 225, "Lanczos", 15.0, True, "BlendWithMatte", 0xFFFFFFFF, 256),
     # up-scaling (no BASELINE config; the shapes of the reference's offline-replayable tests, visuals/canvas.rs:8-33 and
     # trim.rs:131-158): 2x stays on the fused kernel, 3x has more than 8 live rows and takes the generic two-pass kernels
     "up2-hermite": (200, 200, 400, 400, "Hermite", 0.0, True, "ReplaceSelf", 0, 4096),

@@ -20,6 +20,8 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "
 
 
 FUSED = "resample_fused.hip"          # compiled once per ring size K (-DIFHIP_FUSED_K=K), in parallel
+# its step loop is unrolled by hand-over depth (up to 16 rows): past clang's default size limit for `#pragma unroll`
+FUSED_FLAGS = ["-mllvm", "-pragma-unroll-threshold=131072"]
 FUSED_KS = range(1, 9)
 
 
@@ -36,7 +38,7 @@ def compile_jobs(extra_defines=()):
         jobs.append(([HIPCC, "-x", "hip", "--offload-arch=gfx950"] + COMMON + defs + ["-c", src, "-o", obj], obj))
     for k in FUSED_KS:
         obj = os.path.join(HERE, "lib", f"resample_fused_k{k}.o")
-        jobs.append(([HIPCC, "-x", "hip", "--offload-arch=gfx950"] + COMMON + defs + [f"-DIFHIP_FUSED_K={k}", "-c",
+        jobs.append(([HIPCC, "-x", "hip", "--offload-arch=gfx950"] + COMMON + FUSED_FLAGS + defs + [f"-DIFHIP_FUSED_K={k}", "-c",
                      os.path.join(CSRC, FUSED), "-o", obj], obj))
     return jobs
 

@@ -71,12 +71,14 @@ struct ResampleArgs {
 //                      per-lane overhead costs more than the occupancy buys.)
 // D is sized by bytes in flight: a CU needs ~46 KB outstanding to cover HBM latency at its share of the bandwidth
 // (1024 lanes x 4 rows x 16 B = 64 KB; 512 lanes need 8 rows for the same).  Measured: cfg5 2.78 -> 2.46 ms with
-// D = 8 on the narrow shape, cfg2 with alpha 2.05 -> 2.03 ms with D = 4 on the plain shape.
+// D = 8 on the narrow shape, cfg2 with alpha 2.05 -> 2.03 ms with D = 4 on the plain shape; round 3: 12 rows -1.3 %,
+// 16 rows -2.0 % on cfg5 (216 / 232 registers; the step loop must then be unrolled past clang's pragma threshold,
+// build.py passes -pragma-unroll-threshold) -- rings up to K = 6 take 16, the larger ones keep 8.
 #ifndef IFHIP_PLAIN_D
 #define IFHIP_PLAIN_D 4
 #endif
 #ifndef IFHIP_NARROW_D
-#define IFHIP_NARROW_D 8
+#define IFHIP_NARROW_D 16
 #endif
 #ifndef IFHIP_NARROW_PX
 #define IFHIP_NARROW_PX 4    // 2 = 1024 lanes x 2 pixels (8-byte loads): parity-tested, measured 1.3 % slower on cfg5 (instruction-bound)
@@ -86,7 +88,7 @@ constexpr FusedShape fused_shape(int K, int channels) {
     // thresholds read off the compiler's register report (python -m imageflow_amd.kernel_report): no variant spills
     return (channels == 3 ? K <= 4 : K <= 2) ? FusedShape{1024, 4, 1, 4}
          : (channels == 3 ? K <= 5 : K <= 4) ? FusedShape{1024, IFHIP_PLAIN_D, 0, 4}
-                                             : FusedShape{IFHIP_NARROW_PX == 2 ? 1024 : 512, (IFHIP_NARROW_PX == 2 && K == 8) ? 6 : IFHIP_NARROW_D, 1, IFHIP_NARROW_PX};   // (K = 8: 6 rows, else the alpha variants spill)
+                                             : FusedShape{IFHIP_NARROW_PX == 2 ? 1024 : 512, (IFHIP_NARROW_PX == 2 && K == 8) ? 6 : (K <= 6 ? IFHIP_NARROW_D : 8), 1, IFHIP_NARROW_PX};   // (K = 8: 6 rows, else the alpha variants spill)
 }
 // Ring slots whose vertical accumulation runs on the matrix pipe (v_mfma_f32_4x4x1: four slots per instruction, exact
 // fmaf -- see resample_fused.hip).  IFHIP_MFMA_MODE: 0 none, 1 every slot (rounded up to 4: unused slots carry weight +0),

@@ -50,6 +50,9 @@ namespace ifhip {
 // LDS offsets from two base addresses, a 4-byte record per output, groups of the vertically filtered row interleaved.
 template <int K, bool ALPHA, bool WLDS, bool PERPIXEL, int FG = 0>
 __global__ void __launch_bounds__(fused_max_threads(K, ALPHA ? 4 : 3))
+// one workgroup per CU (LDS): the register budget is the one of exactly its waves, say so (without it the register
+// allocator aims at one more wave per SIMD than can ever be resident)
+__attribute__((amdgpu_waves_per_eu(fused_max_threads(K, ALPHA ? 4 : 3) / 256, fused_max_threads(K, ALPHA ? 4 : 3) / 256)))
 fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     static_assert(FG == 0 || (WLDS && PERPIXEL), "the fast horizontal pass keeps its weights in LDS and maps one lane per pixel");
     // `steps` is a separate __restrict__ argument (not a field of `a`) so that the compiler can prove the canvas
@@ -281,7 +284,10 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             const uint32_t pp4 = plane_pitch >> 2;
             f32x2 h01 = {0.0f, 0.0f}, h23 = {0.0f, 0.0f};
             float h2 = 0.0f;
-#pragma unroll IFHIP_HP_UNROLL
+            // (narrow shapes, two waves per SIMD: the reads of group q + 1 under the chains of group q -- cfg5 2.27 -> 2.18 ms;
+            // at four waves per SIMD the other waves cover that latency and the longer code costs: cfg2 1.416 -> 1.428)
+            constexpr int HPU = IFHIP_HP_UNROLL > 1 ? IFHIP_HP_UNROLL : (fused_shape(K, C).threads == 512 ? 2 : 1);
+#pragma unroll HPU
             for (uint32_t q = 0; q < m.y; ++q) {
                 const float4 w = wp[q];
                 h_pair_group(h01, w, sp[q], sp[pp4 + q]);

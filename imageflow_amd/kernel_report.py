@@ -9,7 +9,7 @@ from . import build as B
 def report(src=None, k=4):
     import os
     src = src or os.path.join(B.CSRC, B.FUSED)
-    cmd = [B.HIPCC, "-x", "hip", "--offload-arch=gfx950"] + B.COMMON + [f"-DIFHIP_FUSED_K={k}", "-c", src, "-o", "/dev/null",
+    cmd = [B.HIPCC, "-x", "hip", "--offload-arch=gfx950"] + B.COMMON + B.FUSED_FLAGS + [f"-DIFHIP_FUSED_K={k}", "-c", src, "-o", "/dev/null",
                                                                       "-Rpass-analysis=kernel-resource-usage"]
     out = subprocess.run(cmd, capture_output=True, text=True).stderr
     rows, cur = [], None

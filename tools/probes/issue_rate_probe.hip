@@ -12,9 +12,9 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum Mode { FMA, PK_FMA, PK_FMA_SGPR, DOT4, CVT_UB3, MUL, PK_MUL, CNDMASK, MOV, MFMA, MFMA_PKFMA, MFMA_FMA, MFMA_2FMA, DS_READ, SPLIT_MFMA_PKFMA,
+enum Mode { CND64, CMP_CND, ADD_U32, LSHL_ADD, AND_B32, BFE, ALIGNBIT, MAD_U24, MUL_I24, MUL_LO, MAD_U64, ADD3, PERM, SDWA_AND, DS_READ_B128, DS_WRITE_B32, FMA, PK_FMA, PK_FMA_SGPR, DOT4, CVT_UB3, MUL, PK_MUL, CNDMASK, MOV, MFMA, MFMA_PKFMA, MFMA_FMA, MFMA_2FMA, DS_READ, SPLIT_MFMA_PKFMA,
             SPLIT_PKFMA_PKFMA, SPLIT_MFMA_MFMA, N_MODES };
-static const char* kNames[N_MODES] = {"v_fma_f32", "v_pk_fma_f32 (vgpr)", "v_pk_fma_f32 (sgpr weight)", "v_dot4_u32_u8", "v_cvt_f32_ubyte3", "v_mul_f32", "v_pk_mul_f32",
+static const char* kNames[N_MODES] = {"v_cndmask_b32_e64 (sgpr mask)", "v_cmp_lt_u32 + v_cndmask (vcc)", "v_add_u32", "v_lshl_add_u32", "v_and_b32", "v_bfe_u32", "v_alignbit_b32", "v_mad_u32_u24", "v_mul_i32_i24", "v_mul_lo_u32", "v_mad_u64_u32", "v_add3_u32", "v_perm_b32", "v_and_b32 sdwa byte", "ds_read_b128 (16 in flight)", "ds_write_b32", "v_fma_f32", "v_pk_fma_f32 (vgpr)", "v_pk_fma_f32 (sgpr weight)", "v_dot4_u32_u8", "v_cvt_f32_ubyte3", "v_mul_f32", "v_pk_mul_f32",
                                       "v_cndmask_b32", "v_mov_b32", "v_mfma_f32_4x4x1", "mfma + pk_fma alternating", "mfma + fma alternating",
                                       "mfma + 2 fma", "ds_read_b32 (16 in flight)", "waves 0-3 mfma | waves 4-7 pk_fma ",
                                       "waves 0-3 pk_fma | waves 4-7 pk_fma", "waves 0-3 mfma | waves 4-7 mfma"};
@@ -23,8 +23,8 @@ static const char* kNames[N_MODES] = {"v_fma_f32", "v_pk_fma_f32 (vgpr)", "v_pk_
 
 template <int MODE>
 __global__ void __launch_bounds__(1024) probe(uint64_t* cycles, float* sink, int iters, float wv, uint32_t seed) {
-    __shared__ float lds[4096];
-    for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = static_cast<float>(i);
+    __shared__ float lds[16384];
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = static_cast<float>(i);
     __syncthreads();
     f32x2 a[16];
     f32x4 m[16];
@@ -40,6 +40,10 @@ __global__ void __launch_bounds__(1024) probe(uint64_t* cycles, float* sink, int
     const float b1 = 1.0001f;
     const uint64_t wpair = __builtin_amdgcn_readfirstlane(__float_as_uint(wv));     // low dword of an SGPR pair, broadcast by op_sel_hi
     const uint32_t addr = (threadIdx.x & 63u) * 4u + (threadIdx.x >> 6) * 256u;
+    const uint32_t addr4 = (threadIdx.x & 63u) * 16u;
+    const uint64_t mask64 = __builtin_amdgcn_readfirstlane(seed) * 0x100000001ull;
+    uint64_t w64[16];
+    for (int i = 0; i < 16; ++i) w64[i] = seed + i;
     const int wave = threadIdx.x >> 6;
     int mode = MODE;
     if (MODE == SPLIT_MFMA_PKFMA) mode = wave < 4 ? MFMA : PK_FMA;
@@ -48,7 +52,79 @@ __global__ void __launch_bounds__(1024) probe(uint64_t* cycles, float* sink, int
     uint64_t t0, t1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0));
     for (int it = 0; it < iters; ++it) {
-        if (mode == FMA) {
+        if (mode == CND64) {
+#define X(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(s[i]) : "v"(b1), "s"(mask64));
+            REP16(X) REP16(X) REP16(X) REP16(X)
+#undef X
+        } else if (mode == CMP_CND) {
+#define X(i) asm volatile("v_cmp_lt_u32 vcc, %1, %2\n v_cndmask_b32 %0, %0, %2, vcc" : "+v"(u[i]) : "v"(seed), "v"(addr) : "vcc");
+            REP16(X) REP16(X)
+#undef X
+        } else if (mode == ADD_U32) {
+#define X(i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(u[i]) : "v"(seed));
+            REP16(X) REP16(X) REP16(X) REP16(X)
+#undef X
+        } else if (mode == LSHL_ADD) {
+#define X(i) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(u[i]) : "v"(seed));
+            REP16(X) REP16(X) REP16(X) REP16(X)
+#undef X
+        } else if (mode == AND_B32) {
+#define X(i) asm volatile("v_and_b32 %0, %1, %0" : "+v"(u[i]) : "v"(seed));
+            REP16(X) REP16(X) REP16(X) REP16(X)
+#undef X
+        } else if (mode == BFE) {
+#define X(i) asm volatile("v_bfe_u32 %0, %0, 3, 9" : "+v"(u[i]));
+            REP16(X) REP16(X) REP16(X) REP16(X)
+#undef X
+        } else if (mode == ALIGNBIT) {
+#define X(i) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(seed), "v"(addr));
+            REP16(X) REP16(X) REP16(X) REP16(X)
+#undef X
+        } else if (mode == MAD_U24) {
+#define X(i) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(u[i]) : "v"(seed), "v"(addr));
+            REP16(X) REP16(X) REP16(X) REP16(X)
+#undef X
+        } else if (mode == MUL_I24) {
+#define X(i) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(u[i]) : "v"(seed));
+            REP16(X) REP16(X) REP16(X) REP16(X)
+#undef X
+        } else if (mode == MUL_LO) {
+#define X(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(seed));
+            REP16(X) REP16(X) REP16(X) REP16(X)
+#undef X
+        } else if (mode == MAD_U64) {
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w64[i]) : "v"(seed), "v"(addr) : "vcc");
+            REP16(X) REP16(X) REP16(X) REP16(X)
+#undef X
+        } else if (mode == ADD3) {
+#define X(i) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(seed), "v"(addr));
+            REP16(X) REP16(X) REP16(X) REP16(X)
+#undef X
+        } else if (mode == PERM) {
+#define X(i) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(seed), "v"(addr));
+            REP16(X) REP16(X) REP16(X) REP16(X)
+#undef X
+        } else if (mode == SDWA_AND) {
+#define X(i) asm volatile("v_and_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(u[i]) : "v"(seed));
+            REP16(X) REP16(X) REP16(X) REP16(X)
+#undef X
+        } else if (mode == DS_READ_B128) {
+#define X(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(m[i]) : "v"(addr4), "n"((i) * 1024));
+            REP16(X)
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            REP16(X)
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            REP16(X)
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            REP16(X)
+            asm volatile("s_waitcnt lgkmcnt(0)");
+#undef X
+        } else if (mode == DS_WRITE_B32) {
+#define X(i) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(addr), "v"(s[i]), "n"((i) * 1024) : "memory");
+            REP16(X) REP16(X) REP16(X) REP16(X)
+            asm volatile("s_waitcnt lgkmcnt(0)");
+#undef X
+        } else if (mode == FMA) {
 #define X(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s[i]) : "v"(b1), "v"(wv));
             REP16(X) REP16(X) REP16(X) REP16(X)
 #undef X
@@ -115,7 +191,7 @@ __global__ void __launch_bounds__(1024) probe(uint64_t* cycles, float* sink, int
     }
     asm volatile("s_nop 7\n s_nop 7\n s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1));
     float acc = 0.f;
-    for (int i = 0; i < 16; ++i) acc += a[i].x + a[i].y + m[i].x + m[i].y + m[i].z + m[i].w + s[i] + static_cast<float>(u[i]);
+    for (int i = 0; i < 16; ++i) acc += static_cast<float>(w64[i]) + a[i].x + a[i].y + m[i].x + m[i].y + m[i].z + m[i].w + s[i] + static_cast<float>(u[i]);
     if (acc == 12345.678f) sink[0] = acc + lds[threadIdx.x & 4095];
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x >> 6) + wave] = t1 - t0;
 }
@@ -135,7 +211,7 @@ static void run(int block, uint64_t* d_cycles, float* d_sink) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
     hipEventDestroy(e0); hipEventDestroy(e1);
-    const int per_iter = (MODE == MFMA_2FMA) ? 64 * 3 : (MODE == MFMA_PKFMA || MODE == MFMA_FMA) ? 64 * 2 : 64;
+    const int per_iter = (MODE == MFMA_2FMA) ? 64 * 3 : (MODE == MFMA_PKFMA || MODE == MFMA_FMA) ? 64 * 2 : 64;   // (CMP_CND: 32 pairs = 64)
     double lo[2] = {0, 0};
     int n[2] = {0, 0};
     for (size_t i = 0; i < h.size(); ++i) {
@@ -163,6 +239,10 @@ int main() {
     float* d_sink;
     hipMalloc(&d_cycles, 256 * 16 * 8);
     hipMalloc(&d_sink, 64);
+    sweep<CND64>(d_cycles, d_sink); sweep<CMP_CND>(d_cycles, d_sink); sweep<ADD_U32>(d_cycles, d_sink); sweep<LSHL_ADD>(d_cycles, d_sink);
+    sweep<AND_B32>(d_cycles, d_sink); sweep<BFE>(d_cycles, d_sink); sweep<ALIGNBIT>(d_cycles, d_sink); sweep<MAD_U24>(d_cycles, d_sink);
+    sweep<MUL_I24>(d_cycles, d_sink); sweep<MUL_LO>(d_cycles, d_sink); sweep<MAD_U64>(d_cycles, d_sink); sweep<ADD3>(d_cycles, d_sink);
+    sweep<PERM>(d_cycles, d_sink); sweep<SDWA_AND>(d_cycles, d_sink); sweep<DS_READ_B128>(d_cycles, d_sink); sweep<DS_WRITE_B32>(d_cycles, d_sink);
     sweep<FMA>(d_cycles, d_sink);
     sweep<PK_FMA>(d_cycles, d_sink);
     sweep<PK_FMA_SGPR>(d_cycles, d_sink);
