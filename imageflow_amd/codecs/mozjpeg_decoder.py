@@ -25,6 +25,9 @@ def _bind():
     L.ifhip_jpeg_stage_block_dims.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ifhip_jpeg_idct_color_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                                      C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+    L.ifhip_jpeg_decode_resample_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                          C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
     L._jpeg_bound = True
     return L
 
@@ -89,6 +92,26 @@ class JpegPixelStage:
                                                                out.data.data_ptr(), out.image_bytes, out.stride,
                                                                C.c_void_p(stream)))
         return out
+
+    def read_frames_into(self, coef, qt, canvas: Bitmap, info, plan=None):
+        """read_frame (mozjpeg_decoder.rs:346-362) + DrawImageDef::render's scale_and_render (scale_render.rs:304-313) as one
+        device call: the decoded frames are rendered into the (info.x, info.y, info.w, info.h) rect of `canvas`.  Returns
+        True when no decoded BGRA frame went through HBM (component planes at output resolution: the resampler reads them and
+        converts the colours in its row fetch), False when the call ran the two-step chain through a scratch bitmap."""
+        from ..graphics.scaling import plan_for
+        L = _bind()
+        n = coef[0].shape[0]
+        assert canvas.n == n
+        plan = plan or plan_for(self.out_w, self.out_h, info.w, info.h, info.interpolation_filter, info.sharpen_percent_goal, self.device)
+        ptr = [coef[c].data_ptr() if c < self.n else None for c in range(3)]
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        fused = C.c_int(0)
+        with torch.cuda.device(self.device):
+            _native.check(L.ifhip_jpeg_decode_resample_batch_device(
+                self._h, ptr[0], ptr[1], ptr[2], qt.data_ptr(), n, plan.handle, canvas.data.data_ptr(), canvas.image_bytes,
+                canvas.w, canvas.h, canvas.stride, info.x, info.y, int(info.scale_in_colorspace), int(canvas.compose),
+                int(canvas.matte), C.addressof(fused), C.c_void_p(stream)))
+        return bool(fused.value)
 
     def __del__(self):
         try:

@@ -260,8 +260,17 @@ uint32_t choose_bands(const ifhip_resample_plan* p, uint32_t n_images, size_t n_
     return best;
 }
 
-bool fused_usable(const ifhip_resample_plan* p, int alpha, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride) {
+bool fused_usable(const ifhip_resample_plan* p, int alpha, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride,
+                  const uint8_t* d_cb = nullptr, const uint8_t* d_cr = nullptr) {
     if (!p->fused_possible || !p->sets[alpha ? 1 : 0].ok) return false;
+    if (d_cb) {                         // three component planes: 4-byte reads of 4 samples
+        if (alpha || fused_shape(p->slots, 3).px != 4) return false;
+        if (((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_cb) | reinterpret_cast<uintptr_t>(d_cr)) & 3u) ||
+            (in_image_bytes & 3u) || (in_stride & 3u)) return false;
+        for (const Strip& s : p->sets[0].strips)
+            if (static_cast<uint64_t>(s.cx0) + 4u * s.nquads > in_stride) return false;
+        return true;
+    }
     if ((reinterpret_cast<uintptr_t>(d_in) & 15u) || (in_image_bytes & 15u) || (in_stride & 15u)) return false;
     for (const Strip& s : p->sets[alpha ? 1 : 0].strips)
         if (static_cast<uint64_t>(s.cx0 + 4u * s.nquads) * 4u > in_stride) return false;   // 16-byte row reads stay inside the row
@@ -269,12 +278,12 @@ bool fused_usable(const ifhip_resample_plan* p, int alpha, const uint8_t* d_in, 
 }
 
 int validate_render(uint32_t in_w, uint32_t in_h, uint32_t in_stride, uint32_t cw, uint32_t ch, uint32_t c_stride,
-                    uint32_t x, uint32_t y, uint32_t w, uint32_t h, int working_space, int compositing) {
+                    uint32_t x, uint32_t y, uint32_t w, uint32_t h, int working_space, int compositing, uint32_t in_px_bytes = 4) {
     if (static_cast<uint64_t>(h) + y > ch || static_cast<uint64_t>(w) + x > cw)                 // scaling.rs:24-29
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: Destination rectangle for scale2d is out of bounds");
     if (w == 0 || h == 0 || in_w == 0 || in_h == 0)                                              // bitmaps.rs:700-702
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: Bitmap dimensions cannot be zero");
-    if (static_cast<uint64_t>(in_w) * 4u > in_stride || static_cast<uint64_t>(cw) * 4u > c_stride)
+    if (static_cast<uint64_t>(in_w) * in_px_bytes > in_stride || static_cast<uint64_t>(cw) * 4u > c_stride)
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: stride smaller than a BGRA row");
     if (c_stride & 3u)
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: canvas stride must be a multiple of 4 bytes");
@@ -288,12 +297,15 @@ int validate_render(uint32_t in_w, uint32_t in_h, uint32_t in_stride, uint32_t c
 int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride,
                   int alpha, uint32_t n_images, uint8_t* d_canvas, size_t canvas_image_bytes, uint32_t cw, uint32_t ch,
                   uint32_t c_stride, uint32_t x, uint32_t y, int working_space, int compositing, uint32_t matte,
-                  float* d_f32, int force_kernel, hipStream_t st) {
+                  float* d_f32, int force_kernel, hipStream_t st, const uint8_t* d_cb = nullptr, const uint8_t* d_cr = nullptr) {
+    // d_cb / d_cr: planar YCbCr source (d_in = the Y plane, in_stride = sample pitch, in_image_bytes = plane size).  That form
+    // exists only on the fused kernel: kNotFusable tells the caller to go through a BGRA bitmap instead.
     if (!p) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null plan");
-    int rc = validate_render(p->in_w, p->in_h, in_stride, cw, ch, c_stride, x, y, p->out_w, p->out_h, working_space, compositing);
+    const bool ycc = d_cb != nullptr;
+    int rc = validate_render(p->in_w, p->in_h, in_stride, cw, ch, c_stride, x, y, p->out_w, p->out_h, working_space, compositing, ycc ? 1u : 4u);
     if (rc) return rc;
     if (n_images == 0) return IFHIP_OK;
-    if (!d_in || !d_canvas) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null bitmap pointer");
+    if (!d_in || !d_canvas || (ycc && !d_cr)) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null bitmap pointer");
     if ((reinterpret_cast<uintptr_t>(d_canvas) & 3u) || (canvas_image_bytes & 3u))
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: canvas pixels must be 4-byte aligned");
     int dev = -1;
@@ -307,6 +319,7 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
     ResampleArgs a;
     std::memset(&a, 0, sizeof a);
     a.in = d_in; a.in_image_bytes = in_image_bytes; a.in_stride = in_stride; a.in_w = p->in_w; a.in_h = p->in_h;
+    a.in_cb = d_cb; a.in_cr = d_cr; a.ycc = ycc ? 1u : 0u;
     a.canvas = d_canvas; a.canvas_image_bytes = canvas_image_bytes; a.c_stride = c_stride; a.x = x; a.y = y;
     a.out_w = p->out_w; a.out_h = p->out_h; a.f32_dump = d_f32;
     a.h_meta = p->d_h_meta; a.h_wu = p->d_h_wu; a.h_wu_floats = p->h_wu_floats;
@@ -323,7 +336,8 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
     a.matte_a = static_cast<float>(matte >> 24) * (1.0f / 255.0f);
     a.n_images = n_images;
 
-    bool fused = fused_usable(p, alpha, d_in, in_image_bytes, in_stride);
+    bool fused = fused_usable(p, alpha, d_in, in_image_bytes, in_stride, d_cb, d_cr);
+    if (ycc && !fused) return kNotFusable;
     if (force_kernel == 0 && !fused)
         return fail(IFHIP_INVALID_STATE, "InvalidState: fused kernel requested but its preconditions do not hold "
                     "(live rows %d > %d, or rows not 16-byte aligned / padded)", p->slots, kMaxSlots);
@@ -390,6 +404,7 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
             }
             if (!fast_g || w_in_lds) break;
         }
+        if (ycc && !(w_in_lds && per_pixel)) return kNotFusable;     // the planar source is instantiated for that form only
         a.h_groups = fast_g;
         if (fast_g) { a.h_wu = p->d_h_wg; a.h_wu_floats = p->h_wg_floats; a.h_meta2 = p->d_h_meta2; }
         a.lut_copies_log2 = copies_log2;
@@ -429,6 +444,20 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
 }
 
 }  // namespace
+
+namespace ifhip {
+// The resampler fed by the JPEG stage's component planes (jpeg_kernels.hip).  IFHIP_OK, an error, or kNotFusable.
+int resample_from_ycc_planes_v(const ifhip_resample_plan* plan, const uint8_t* d_y, const uint8_t* d_cb, const uint8_t* d_cr,
+                             size_t plane_bytes, uint32_t pitch, uint32_t n_images, uint8_t* d_canvas, size_t canvas_image_bytes,
+                             uint32_t cw, uint32_t ch, uint32_t c_stride, uint32_t x, uint32_t y, int working_space, int compositing,
+                             uint32_t matte, void* hip_stream) {
+    return enqueue_batch(plan, d_y, plane_bytes, pitch, 0, n_images, d_canvas, canvas_image_bytes, cw, ch, c_stride, x, y,
+                         working_space, compositing, matte, nullptr, -1, static_cast<hipStream_t>(hip_stream), d_cb, d_cr);
+}
+void resample_plan_shape(const ifhip_resample_plan* plan, uint32_t* in_w, uint32_t* in_h, uint32_t* out_w, uint32_t* out_h) {
+    *in_w = plan->in_w; *in_h = plan->in_h; *out_w = plan->out_w; *out_h = plan->out_h;
+}
+}  // namespace ifhip
 
 // ======================================================================================================
 // extern "C"

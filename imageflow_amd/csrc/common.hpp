@@ -84,6 +84,15 @@ struct VSchedule {
 // `group`: bands are padded to a multiple of `group` steps (the kernel's unroll); `ahead`: steps[i].y_ahead = row of step
 // i + ahead (the load the kernel issues while working on step i).
 bool build_vschedule(const AxisWeights& wv, int n_bands, int group, int ahead, VSchedule* out);
+
+// internal status of the planar-source resample call: this shape / these pointers cannot run on the fused kernel
+constexpr int kNotFusable = -1000;
+// (api.cpp; hipStream_t passes as void* so that this header stays free of hip_runtime.h)
+int resample_from_ycc_planes_v(const ifhip_resample_plan* plan, const uint8_t* d_y, const uint8_t* d_cb, const uint8_t* d_cr,
+                               size_t plane_bytes, uint32_t pitch, uint32_t n_images, uint8_t* d_canvas, size_t canvas_image_bytes,
+                               uint32_t cw, uint32_t ch, uint32_t c_stride, uint32_t x, uint32_t y, int working_space, int compositing,
+                               uint32_t matte, void* hip_stream);
+void resample_plan_shape(const ifhip_resample_plan* plan, uint32_t* in_w, uint32_t* in_h, uint32_t* out_w, uint32_t* out_h);
 int max_live_rows(const AxisWeights& wv);
 
 }  // namespace ifhip

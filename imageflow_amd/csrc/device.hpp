@@ -19,6 +19,11 @@ struct ResampleArgs {
     const uint8_t* in;
     size_t in_image_bytes;
     uint32_t in_stride, in_w, in_h;
+    // planar YCbCr source (ycc != 0; the JPEG stage's component planes, decode fused into the row fetch): `in` is the Y
+    // plane, in_stride the sample pitch and in_image_bytes the plane size shared by the three planes
+    const uint8_t* in_cb;
+    const uint8_t* in_cr;
+    uint32_t ycc;
     // canvases
     uint8_t* canvas;
     size_t canvas_image_bytes;

@@ -887,29 +887,26 @@ int ifhip_jpeg_stage_block_dims(const ifhip_jpeg_stage* stage, uint32_t* blocks_
     return IFHIP_OK;
 }
 
-int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d_coef0, const int16_t* d_coef1,
-                                       const int16_t* d_coef2, const uint16_t* d_qt, uint32_t n_images,
-                                       uint8_t* d_bgra, size_t image_bytes, uint32_t stride, void* hip_stream) {
+// Arguments of a stage call, validated; the launches of the component IDCTs (planes in HBM).
+static int stage_args(ifhip_jpeg_stage* stage, const int16_t* d_coef0, const int16_t* d_coef1, const int16_t* d_coef2,
+                      const uint16_t* d_qt, uint32_t n_images, JpegArgs* out) {
     if (!stage) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null stage");
-    if (n_images == 0) return IFHIP_OK;
     if (n_images > stage->max_images) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: %u images exceed the stage capacity %u", n_images, stage->max_images);
-    if (!d_coef0 || !d_qt || !d_bgra || (stage->g.ncomp == 3 && (!d_coef1 || !d_coef2)))
+    if (!d_coef0 || !d_qt || (stage->g.ncomp == 3 && (!d_coef1 || !d_coef2)))
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null coefficient / table / bitmap pointer");
-    if (static_cast<uint64_t>(stage->g.out_w) * 4u > stride || (stride & 3u) || (image_bytes & 3u) || (reinterpret_cast<uintptr_t>(d_bgra) & 3u))
-        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: BGRA rows must be 4-byte aligned and stride >= 4*w");
     if ((reinterpret_cast<uintptr_t>(d_coef0) | reinterpret_cast<uintptr_t>(d_coef1) | reinterpret_cast<uintptr_t>(d_coef2)
          | reinterpret_cast<uintptr_t>(d_qt)) & 15u)
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: coefficient planes and quantisation tables must be 16-byte aligned");
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != stage->device) return fail(IFHIP_INVALID_STATE, "InvalidState: stage belongs to device %d, current device is %d", stage->device, dev);
-    JpegArgs a;
+    JpegArgs& a = *out;
     std::memset(&a, 0, sizeof a);
     a.g = stage->g;
     a.coef[0] = d_coef0; a.coef[1] = d_coef1; a.coef[2] = d_coef2;
     a.qt = d_qt;
     for (int c = 0; c < 3; ++c) a.plane[c] = stage->planes[c];
-    a.bgra = d_bgra; a.image_bytes = image_bytes; a.stride = stride; a.n_images = n_images;
+    a.n_images = n_images;
     if (a.g.luma_mode != 0u) {
         ScalerDeviceTables dt;
         int rc = scaler_device_tables(&dt);
@@ -922,26 +919,95 @@ int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d
         }
         a.sc.s2l = dt.s2l; a.sc.l2s = dt.l2s;
     }
-    hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const uint64_t total_blocks = static_cast<uint64_t>(a.g.blocks_before[a.g.ncomp]) * n_images;
-    const uint64_t wgs = (total_blocks + kBlocksPerWg - 1) / kBlocksPerWg;
-    if (wgs > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
-    (void)wgs;
-    // full-size colour decode: the luma IDCT runs inside the colour kernel (no luma plane in HBM)
-    const bool fused_luma = a.g.ncomp == 3 && a.g.scale_num == 8u && a.g.luma_mode == 0u && std::getenv("IFHIP_JPEG_UNFUSED") == nullptr;
-    for (int c = fused_luma ? 1 : 0; c < a.g.ncomp; ++c) {
+    if ((total_blocks + kBlocksPerWg - 1) / kBlocksPerWg > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
+    return IFHIP_OK;
+}
+
+static int launch_idct_planes(JpegArgs a, int first_component, hipStream_t st) {
+    for (int c = first_component; c < a.g.ncomp; ++c) {
         a.comp = static_cast<uint32_t>(c);
         const uint32_t nblk = a.g.bw[c] * a.g.bh[c];
         // the two chroma components have the same geometry: one launch covers both (blockIdx.z)
         const bool both = c == 1 && a.g.ncomp == 3 && a.g.bw[1] == a.g.bw[2] && a.g.bh[1] == a.g.bh[2] && a.g.idct_n[1] == a.g.idct_n[2];
-        hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nblk + kBlocksPerWg - 1) / kBlocksPerWg, n_images, both ? 2u : 1u), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nblk + kBlocksPerWg - 1) / kBlocksPerWg, a.n_images, both ? 2u : 1u), dim3(256), 0, st, a);
         HIP_TRY(hipGetLastError());
         if (both) ++c;
     }
+    return IFHIP_OK;
+}
+
+int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d_coef0, const int16_t* d_coef1,
+                                       const int16_t* d_coef2, const uint16_t* d_qt, uint32_t n_images,
+                                       uint8_t* d_bgra, size_t image_bytes, uint32_t stride, void* hip_stream) {
+    if (!stage) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null stage");
+    if (n_images == 0) return IFHIP_OK;
+    if (!d_bgra) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null coefficient / table / bitmap pointer");
+    if (static_cast<uint64_t>(stage->g.out_w) * 4u > stride || (stride & 3u) || (image_bytes & 3u) || (reinterpret_cast<uintptr_t>(d_bgra) & 3u))
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: BGRA rows must be 4-byte aligned and stride >= 4*w");
+    JpegArgs a;
+    int rc = stage_args(stage, d_coef0, d_coef1, d_coef2, d_qt, n_images, &a);
+    if (rc) return rc;
+    a.bgra = d_bgra; a.image_bytes = image_bytes; a.stride = stride;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    // full-size colour decode: the luma IDCT runs inside the colour kernel (no luma plane in HBM)
+    const bool fused_luma = a.g.ncomp == 3 && a.g.scale_num == 8u && a.g.luma_mode == 0u && std::getenv("IFHIP_JPEG_UNFUSED") == nullptr;
+    rc = launch_idct_planes(a, fused_luma ? 1 : 0, st);
+    if (rc) return rc;
     const dim3 cgrid((a.g.out_w + 1023u) / 1024u, (a.g.out_h + kColorRows - 1u) / kColorRows, n_images);
     if (fused_luma) hipLaunchKernelGGL((jpeg_color_kernel<true>), cgrid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((jpeg_color_kernel<false>), cgrid, dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
+    return IFHIP_OK;
+}
+
+// MozJpegDecoder::read_frame (mozjpeg_decoder.rs:346-362) feeding DrawImageDef::render (scale_render.rs:304-313) as ONE
+// device call: coefficient planes in, the resampled canvas out.  When the component planes come out of the IDCT at output
+// resolution (every 4:2:0 file decoded at 1/8 .. 4/8 -- chroma then runs the twice-larger IDCT -- and 4:4:4 at any scale),
+// the resampler reads them directly and converts YCbCr -> RGB in its row fetch: the decoded BGRA frame never exists in
+// HBM (*fused = 1).  Everything else (fancy up-sampling, grayscale, shapes the fused resampler does not take) goes through a
+// stream-ordered BGRA scratch and the two calls this replaces (*fused = 0): same bytes either way.
+int ifhip_jpeg_decode_resample_batch_device(ifhip_jpeg_stage* stage, const int16_t* d_coef0, const int16_t* d_coef1,
+                                            const int16_t* d_coef2, const uint16_t* d_qt, uint32_t n_images,
+                                            const ifhip_resample_plan* plan, uint8_t* d_canvas, size_t canvas_image_bytes,
+                                            uint32_t canvas_w, uint32_t canvas_h, uint32_t canvas_stride, uint32_t x, uint32_t y,
+                                            int working_space, int compositing, uint32_t matte_bgra, int* fused, void* hip_stream) {
+    if (fused) *fused = 0;
+    if (!stage || !plan) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null stage / plan");
+    uint32_t pin_w = 0, pin_h = 0, pout_w = 0, pout_h = 0;
+    resample_plan_shape(plan, &pin_w, &pin_h, &pout_w, &pout_h);
+    if (pin_w != stage->g.out_w || pin_h != stage->g.out_h)
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: the plan resamples %ux%u frames, the stage decodes to %ux%u", pin_w, pin_h, stage->g.out_w, stage->g.out_h);
+    if (n_images == 0) return IFHIP_OK;
+    JpegArgs a;
+    int rc = stage_args(stage, d_coef0, d_coef1, d_coef2, d_qt, n_images, &a);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const JpegGeom& g = a.g;
+    const bool planes_at_output = g.ncomp == 3 && g.upsample == 0u && g.pw[0] == g.pw[1] && g.pw[0] == g.pw[2] &&
+                                  g.ph[0] == g.ph[1] && g.ph[0] == g.ph[2] && std::getenv("IFHIP_JPEG_UNFUSED") == nullptr;
+    if (planes_at_output) {
+        rc = launch_idct_planes(a, 0, st);
+        if (rc) return rc;
+        rc = resample_from_ycc_planes_v(plan, a.plane[0], a.plane[1], a.plane[2], static_cast<size_t>(g.pw[0]) * g.ph[0], g.pw[0], n_images,
+                                      d_canvas, canvas_image_bytes, canvas_w, canvas_h, canvas_stride, x, y, working_space, compositing,
+                                      matte_bgra, hip_stream);
+        if (rc != kNotFusable) {
+            if (rc == IFHIP_OK && fused) *fused = 1;
+            return rc;
+        }
+    }
+    const uint32_t stride = ifhip_stride_for_width(g.out_w);
+    const size_t image_bytes = static_cast<size_t>(stride) * g.out_h;
+    uint8_t* scratch = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), image_bytes * n_images, st));
+    rc = ifhip_jpeg_idct_color_batch_device(stage, d_coef0, d_coef1, d_coef2, d_qt, n_images, scratch, image_bytes, stride, hip_stream);
+    if (rc == IFHIP_OK)
+        rc = ifhip_scale_and_render_batch_device(plan, scratch, image_bytes, stride, 0, n_images, d_canvas, canvas_image_bytes, canvas_w,
+                                                 canvas_h, canvas_stride, x, y, working_space, compositing, matte_bgra, nullptr, -1, hip_stream);
+    const hipError_t fe = hipFreeAsync(scratch, st);
+    if (rc) return rc;
+    HIP_TRY(fe);
     return IFHIP_OK;
 }
 

@@ -48,13 +48,18 @@ namespace ifhip {
 // FG > 0: the fast horizontal pass (moderate ratios: no output needs more than 4 groups).  Every output runs exactly FG
 // 4-tap groups -- its weight row is zero-padded to FG groups, +0 weights are exact -- fully unrolled with immediate
 // LDS offsets from two base addresses, a 4-byte record per output, groups of the vertically filtered row interleaved.
-template <int K, bool ALPHA, bool WLDS, bool PERPIXEL, int FG = 0>
+// YCC: the source is the JPEG stage's three component planes at output resolution (ResampleArgs::in / in_cb / in_cr) instead
+// of a BGRA bitmap: the row fetch reads 4 samples of each plane and jdcolor.c's fixed-point YCbCr -> RGB runs in
+// registers in front of the table gathers, so a decoded BGRA frame never exists in HBM (mozjpeg_decoder.rs:346-362 feeding
+// scale_render.rs:304-313).  No alpha (a JPEG has none), 4 pixels per lane.
+template <int K, bool ALPHA, bool WLDS, bool PERPIXEL, int FG = 0, bool YCC = false>
 __global__ void __launch_bounds__(fused_max_threads(K, ALPHA ? 4 : 3))
 // one workgroup per CU (LDS): the register budget is the one of exactly its waves, say so (without it the register
 // allocator aims at one more wave per SIMD than can ever be resident)
 __attribute__((amdgpu_waves_per_eu(fused_max_threads(K, ALPHA ? 4 : 3) / 256, fused_max_threads(K, ALPHA ? 4 : 3) / 256)))
 fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     static_assert(FG == 0 || (WLDS && PERPIXEL), "the fast horizontal pass keeps its weights in LDS and maps one lane per pixel");
+    static_assert(!YCC || (!ALPHA && fused_shape(K, 3).px == 4), "planar source: three channels, four pixels per lane");
     // `steps` is a separate __restrict__ argument (not a field of `a`) so that the compiler can prove the canvas
     // stores never clobber it and keeps the per-step 64-byte records on the scalar path.
     constexpr int C = ALPHA ? 4 : 3;
@@ -139,8 +144,12 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     // lanes past the strip re-read its last quad instead of branching: every row load is unconditional, so the
     // number of loads in flight is known statically and the compiler can wait with vmcnt(D-1) instead of vmcnt(0)
     const uint32_t quad = lane_on ? tid : n_groups - 1u;
-    const uint8_t* src = a.in + static_cast<size_t>(img) * a.in_image_bytes
-                         + static_cast<size_t>(strip.cx0 + static_cast<uint32_t>(PX) * quad) * 4u;
+    // bytes per source pixel in the plane(s) read: 4 (BGRA) or 1 (one of three component planes)
+    const size_t src_off = static_cast<size_t>(img) * a.in_image_bytes
+                           + static_cast<size_t>(strip.cx0 + static_cast<uint32_t>(PX) * quad) * (YCC ? 1u : 4u);
+    const uint8_t* src = a.in + src_off;
+    const uint8_t* src_cb = YCC ? a.in_cb + src_off : nullptr;
+    const uint8_t* src_cr = YCC ? a.in_cr + src_off : nullptr;
 
     // Ring accumulators and converted samples live as float2 pairs over the flattened (pixel, channel) index
     // f = p*C + c, so that the vertical pass issues v_pk_fma_f32 (two IEEE fmaf per instruction, the weight broadcast
@@ -180,12 +189,21 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     };
     const uint32_t lane4 = threadIdx.x & 3u;        // this lane's row of the A operand
 
-    typedef uint32_t raw_t __attribute__((ext_vector_type(PX)));        // one lane's PX source pixels
+    typedef uint32_t bgra_raw_t __attribute__((ext_vector_type(PX)));   // one lane's PX source pixels
+    struct YccRaw { uint32_t y, cb, cr; };                              // 4 samples of each component plane
+    typedef std::conditional_t<YCC, YccRaw, bgra_raw_t> raw_t;
     auto fetch_row = [&](int y) -> raw_t {                               // y is wave-uniform; -1 = nothing needed
         const uint32_t yy = y < 0 ? 0u : static_cast<uint32_t>(y);      // (row 0 is re-read: stays in L2)
+        const size_t ro = static_cast<size_t>(yy) * a.in_stride;
         // source frames are streamed exactly once: non-temporal loads keep them from displacing the tables in L2
         // (measured -1.7% kernel time, profiles/r1_notes.md)
-        return __builtin_nontemporal_load(reinterpret_cast<const raw_t*>(src + static_cast<size_t>(yy) * a.in_stride));
+        if constexpr (YCC) {
+            return YccRaw{__builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src + ro)),
+                          __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src_cb + ro)),
+                          __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src_cr + ro))};
+        } else {
+            return __builtin_nontemporal_load(reinterpret_cast<const bgra_raw_t*>(src + ro));
+        }
     };
 
     // sample -> working float for the 4 pixels of one 16-byte load (arithmetic contract step 1)
@@ -200,6 +218,31 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     const uint32_t lut_lane = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(smem + L.lut))) + (lut.lane_off << 2);
     auto convert = [&](const raw_t& q, f32x2 (&vv)[NP]) {
         float v[PX][C];
+        if constexpr (YCC) {
+            // jdcolor.c ycc_rgb_convert with its 16-bit fixed-point tables evaluated in place (as jpeg_color_kernel does:
+            // Cr_r = (91881 cr + 32768) >> 16, Cb_b = (116130 cb + 32768) >> 16, g = (-22554 cb - 46802 cr + 32768) >> 16,
+            // range-limited), then the same table gathers a BGRA byte would get
+            uint32_t ad[PX][3];
+#pragma unroll
+            for (int p = 0; p < PX; ++p) {
+                const int32_t Y = static_cast<int32_t>((q.y >> (8 * p)) & 255u);
+                const int32_t cb = static_cast<int32_t>((q.cb >> (8 * p)) & 255u) - 128, cr = static_cast<int32_t>((q.cr >> (8 * p)) & 255u) - 128;
+                const int32_t r = Y + ((__mul24(91881, cr) + 32768) >> 16);
+                const int32_t g = Y + ((__mul24(-22554, cb) + 32768 + __mul24(-46802, cr)) >> 16);
+                const int32_t b = Y + ((__mul24(116130, cb) + 32768) >> 16);
+                const int32_t ch[3] = {b, g, r};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int32_t c8 = ch[k] < 0 ? 0 : (ch[k] > 255 ? 255 : ch[k]);
+                    ad[p][k] = __umul24(static_cast<uint32_t>(c8), lut_mul) + lut_lane;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < PX; ++p)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[p][k] = *reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(ad[p][k]));
+        } else {
 #if IFHIP_DOT4_LUT
         // all addresses first, then all reads: a gather issued right behind its own address costs wait states
         uint32_t ad[PX][3];
@@ -227,6 +270,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                 v[p][2] = v[p][2] * af;
                 v[p][C - 1] = af;
             }
+        }
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) vv[i] = f32x2{v[(2 * i) / C][(2 * i) % C], v[(2 * i + 1) / C][(2 * i + 1) % C]};
@@ -501,7 +545,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
 }
 
 
-template <int K, bool ALPHA, bool WLDS, bool PERPIXEL, int FG = 0>
+template <int K, bool ALPHA, bool WLDS, bool PERPIXEL, int FG = 0, bool YCC = false>
 static hipError_t launch_variant(const ResampleArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
     // raise the dynamic-LDS cap once per kernel variant and device (it is sticky), not on every launch
     static std::atomic<size_t> cap[16];      // (one per instantiation of this function template)
@@ -509,11 +553,11 @@ static hipError_t launch_variant(const ResampleArgs& a, dim3 grid, dim3 block, s
     (void)hipGetDevice(&dev);
     std::atomic<size_t>& c = cap[dev & 15];
     if (c.load(std::memory_order_relaxed) < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_resample_kernel<K, ALPHA, WLDS, PERPIXEL, FG>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_resample_kernel<K, ALPHA, WLDS, PERPIXEL, FG, YCC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsCap));
         c.store(kFusedLdsCap, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((fused_resample_kernel<K, ALPHA, WLDS, PERPIXEL, FG>), grid, block, lds, st, a, a.steps);
+    hipLaunchKernelGGL((fused_resample_kernel<K, ALPHA, WLDS, PERPIXEL, FG, YCC>), grid, block, lds, st, a, a.steps);
     return hipGetLastError();
 }
 
@@ -525,6 +569,20 @@ static hipError_t launch_variant(const ResampleArgs& a, dim3 grid, dim3 block, s
 hipError_t IFHIP_CAT(launch_fused_k, IFHIP_FUSED_K)(const ResampleArgs& a, bool alpha, bool per_pixel, dim3 grid, dim3 block,
                                                     size_t lds, hipStream_t st) {
     constexpr int K = IFHIP_FUSED_K;
+    if (a.ycc) {                               // planar YCbCr source: no alpha, weights in LDS, one lane per pixel (host guarantees all three)
+        if constexpr (fused_shape(K, 3).px == 4) {
+            if (!alpha && a.h_w_in_lds && per_pixel) {
+                switch (a.h_groups) {
+                case 0: return launch_variant<K, false, true, true, 0, true>(a, grid, block, lds, st);
+                case 2: return launch_variant<K, false, true, true, 2, true>(a, grid, block, lds, st);
+                case 3: return launch_variant<K, false, true, true, 3, true>(a, grid, block, lds, st);
+                case 4: return launch_variant<K, false, true, true, 4, true>(a, grid, block, lds, st);
+                default: break;
+                }
+            }
+        }
+        return hipErrorInvalidValue;
+    }
     if (a.h_groups) {                          // fast horizontal pass: weights in LDS, one lane per pixel (host guarantees both)
         if constexpr (fused_shape(K, 3).px == 4 && fused_shape(K, 4).px == 4) {
             switch ((alpha ? 8 : 0) | a.h_groups) {

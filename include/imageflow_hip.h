@@ -183,6 +183,23 @@ IFHIP_API int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const 
                                                  const uint16_t* d_qt, uint32_t n_images,
                                                  uint8_t* d_bgra, size_t image_bytes, uint32_t stride, void* hip_stream);
 
+/* Decode and resample as one device call: replaces MzDec::read_frame (codecs/mozjpeg_decoder.rs:346-362) producing the
+ * bitmap that DrawImageDef::render (flow/nodes/scale_render.rs:304-313) hands to scale_and_render -- the pair every
+ * `decode -> resample_2d / constrain` job runs.  `plan` must resample the stage's output size (ifhip_jpeg_stage_output_size).
+ * When the component planes leave the IDCT at output resolution (4:2:0 decoded at 1/8 .. 4/8, where chroma takes the
+ * twice-larger IDCT; 4:4:4 at any scale) the resampler reads the three planes and converts YCbCr -> RGB in its row fetch:
+ * no decoded BGRA frame is written to or read from HBM, *fused = 1.  Every other case (fancy up-sampling, grayscale,
+ * shapes the fused resampler does not take) runs ifhip_jpeg_idct_color_batch_device into a stream-ordered scratch
+ * and ifhip_scale_and_render_batch_device, *fused = 0.  The canvas bytes are the same either way.  `fused` may be NULL. */
+IFHIP_API int ifhip_jpeg_decode_resample_batch_device(ifhip_jpeg_stage* stage, const int16_t* d_coef0,
+                                                      const int16_t* d_coef1, const int16_t* d_coef2,
+                                                      const uint16_t* d_qt, uint32_t n_images,
+                                                      const ifhip_resample_plan* plan,
+                                                      uint8_t* d_canvas, size_t canvas_image_bytes, uint32_t canvas_w,
+                                                      uint32_t canvas_h, uint32_t canvas_stride, uint32_t x, uint32_t y,
+                                                      int working_space, int compositing, uint32_t matte_bgra,
+                                                      int* fused, void* hip_stream);
+
 /* Entropy stage: baseline sequential-Huffman decode of whole files on the GPU, in place of
  * the serial jpeg_read_coefficients / decode_mcu loop MzDec::read_frame drives on the host
  * (codecs/mozjpeg_decoder.rs:346-362).  ifhip_jpeg_parse_headers is host-only (no GPU): the SOF / DQT / DRI facts the

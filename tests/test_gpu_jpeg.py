@@ -177,3 +177,90 @@ def test_unsupported_scales():
         assert e.value.kind == ErrorKind.MethodNotImplemented
     st = JpegPixelStage(64, 64, 3, (2, 1, 1), (1, 1, 1), 1, DEV, scale_num=4)      # 4:2:2 reduced: chroma stays 4x4, h2v1 up-sampled
     assert (st.out_w, st.out_h) == (32, 32)
+
+
+# ---- decode + resample as one call: component planes -> resampler (no decoded BGRA frame in HBM) -----------------------
+def _decode_resample_case(j, n, scale_num, luma_mode, tw, th, compose="ReplaceSelf", matte=0, x=0, y=0, cw=None, ch=None):
+    """-> (canvas bytes of the one-call form, canvas bytes of read_frames + scale_and_render, fused flag)."""
+    from imageflow_amd.graphics.bitmaps import Bitmap, BitmapCompositing
+    from imageflow_amd.graphics.scaling import ScaleAndRenderParams, scale_and_render
+    st = JpegPixelStage(j["width"], j["height"], j["ncomp"], j["hs"], j["vs"], n, DEV, scale_num=scale_num,
+                        luma_spatial=luma_mode != 0, luma_srgb=luma_mode == 2)
+    coef = [torch.from_numpy(np.stack([j["coef"][c]] * n)).to(DEV) for c in range(3)]
+    for c in range(j["ncomp"]):
+        coef[c][1:] = torch.roll(coef[c][1:], 1, dims=2)                # frames of a batch differ
+    qt = torch.from_numpy(np.stack([j["qt"]] * n).astype(np.int16)).to(DEV)
+    cw, ch = cw or tw, ch or th
+    info = ScaleAndRenderParams(x, y, tw, th)
+    canv = [Bitmap.create_u8(n, cw, ch, DEV, compose=BitmapCompositing[compose], matte=matte) for _ in range(2)]
+    for c in canv:
+        c.data.fill_(0x5A)
+    fused = st.read_frames_into(coef, qt, canv[0], info)
+    decoded = st.read_frames(coef, qt)
+    scale_and_render(decoded, canv[1], info)
+    torch.cuda.synchronize()
+    return canv[0].to_numpy(), canv[1].to_numpy(), fused, decoded
+
+
+@pytest.mark.parametrize("scale_num,luma_mode", [(4, 0), (4, 1), (4, 2), (2, 2), (1, 0)])
+def test_decode_resample_one_call_equals_the_two_calls_420(scale_num, luma_mode):
+    """4:2:0 decoded at 1/8 .. 4/8: chroma runs the twice-larger IDCT, the three planes have the output size -> fused."""
+    rng = np.random.default_rng(100 + scale_num * 3 + luma_mode)
+    for (w, h, tw, th) in ((1001, 653, 211, 137), (640, 480, 100, 75), (2000, 1504, 333, 250)):
+        j = _random_case(rng, w, h, (2, 1, 1), (2, 1, 1), 3, 300)
+        ow, oh = -(-w * scale_num // 8), -(-h * scale_num // 8)
+        tw, th = min(tw, ow), min(th, oh)
+        one, two, fused, decoded = _decode_resample_case(j, 3, scale_num, luma_mode, tw, th)
+        pitch = -(-w // 16) * 2 * scale_num                              # samples per plane row: MCUs x 2 luma blocks x n
+        assert fused == (pitch % 4 == 0), (w, h, scale_num)             # 4-byte reads of 4 samples need a 4-aligned pitch
+        assert np.array_equal(one, two), (w, h, scale_num, luma_mode)
+        assert np.array_equal(decoded.to_numpy()[0], O.jpeg_idct_color_scaled(j, scale_num, luma_mode))     # and the chain is the oracle's
+
+
+def test_decode_resample_one_call_444_sub_rect_and_matte():
+    """4:4:4 at full size is fused too; the rect / compositing arguments behave as in scale_and_render."""
+    rng = np.random.default_rng(7)
+    j = _random_case(rng, 517, 389, (1, 1, 1), (1, 1, 1), 3, 250)
+    one, two, fused, _ = _decode_resample_case(j, 2, 8, 0, 120, 90, x=16, y=9, cw=200, ch=120)
+    assert fused and np.array_equal(one, two)
+    assert np.all(one[:, 0, :64] == 0x5A)                                # outside the rect: untouched
+    one, two, fused, _ = _decode_resample_case(j, 2, 8, 0, 120, 90, compose="BlendWithMatte", matte=0xFF336699)
+    assert fused and np.array_equal(one, two)
+
+
+def test_decode_resample_falls_back_where_planes_are_not_at_output_size():
+    """Full-size 4:2:0 needs the fancy up-sampler, grayscale has one plane: same call, two-step chain inside, same bytes."""
+    rng = np.random.default_rng(9)
+    j = _random_case(rng, 640, 400, (2, 1, 1), (2, 1, 1), 3, 200)
+    one, two, fused, _ = _decode_resample_case(j, 2, 8, 0, 160, 100)
+    assert not fused and np.array_equal(one, two)
+    g = _random_case(rng, 320, 200, (1, 0, 0), (1, 0, 0), 1, 200)
+    one, two, fused, _ = _decode_resample_case(g, 2, 4, 0, 80, 50)
+    assert not fused and np.array_equal(one, two)
+    # an up-scale the fused resampler does not take (more than 8 live rows): planes at output size, chain nevertheless
+    j2 = _random_case(rng, 160, 96, (2, 1, 1), (2, 1, 1), 3, 200)
+    one, two, fused, _ = _decode_resample_case(j2, 2, 4, 0, 320, 192)
+    assert np.array_equal(one, two)
+
+
+def test_decode_resample_cfg4_shape():
+    """BASELINE config 4 as the reference decodes it: 3840x2160 4:2:0 at 4/8 with the spatial sRGB luma scaler -> 800x450."""
+    rng = np.random.default_rng(44)
+    j = _random_case(rng, 3840, 2160, (2, 1, 1), (2, 1, 1), 3, 60)
+    one, two, fused, _ = _decode_resample_case(j, 2, 4, 2, 800, 450)
+    assert fused and np.array_equal(one, two)
+
+
+def test_decode_resample_rejects_a_plan_of_another_size():
+    from imageflow_amd.graphics.bitmaps import Bitmap
+    from imageflow_amd.graphics.scaling import ScaleAndRenderParams, plan_for
+    from imageflow_amd.graphics.weights import Filter
+    rng = np.random.default_rng(3)
+    j = _random_case(rng, 320, 240, (2, 1, 1), (2, 1, 1), 3, 100)
+    st = JpegPixelStage(320, 240, 3, j["hs"], j["vs"], 1, DEV, scale_num=4)
+    coef = [torch.from_numpy(j["coef"][c][None]).to(DEV) for c in range(3)]
+    qt = torch.from_numpy(j["qt"][None].astype(np.int16)).to(DEV)
+    out = Bitmap.create_u8(1, 40, 30, DEV)
+    with pytest.raises(FlowError) as e:
+        st.read_frames_into(coef, qt, out, ScaleAndRenderParams(0, 0, 40, 30), plan=plan_for(320, 240, 40, 30, Filter.Robidoux, 0.0, torch.device(DEV)))
+    assert e.value.kind == ErrorKind.InvalidArgument

@@ -54,8 +54,23 @@ def main():
             scale_and_render(out, small, info)
         torch.cuda.synchronize()
         t_all = (time.perf_counter() - t0) / reps
+        # the same chain as ONE call (ifhip_jpeg_decode_resample_batch_device): at reduced scales the resampler reads the
+        # component planes, no decoded BGRA frame goes through HBM
+        fused = False
+        t_one = None
+        if (st.out_w, st.out_h) != (800, 450):
+            for _ in range(3):
+                fused = st.read_frames_into(coef, qt, small, info)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                st.read_frames_into(coef, qt, small, info)
+            torch.cuda.synchronize()
+            t_one = (time.perf_counter() - t0) / reps
         coef_bytes = sum(int(np.prod(c.shape)) * 2 for c in coef)
         res[f"scale_{scale_num}_8{'_spatial_srgb' if spatial else ''}"] = {
+            "one_call_ms": None if t_one is None else round(t_one * 1e3, 3), "one_call_fused": fused,
+            "one_call_algorithmic_GBps": None if t_one is None else round((coef_bytes + n * 800 * 450 * 4) / t_one / 1e9, 1),
             "frames": n, "decoded_size": [st.out_w, st.out_h],
             "decode_ms": round(t_dec * 1e3, 3), "decode_source_MPps": round(n * w * h / 1e6 / t_dec, 1),
             "decode_algorithmic_GBps": round((coef_bytes + n * st.out_w * st.out_h * 4) / t_dec / 1e9, 1),
