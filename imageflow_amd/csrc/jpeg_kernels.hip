@@ -461,6 +461,211 @@ __global__ void __launch_bounds__(256) jpeg_idct_kernel(const JpegArgs a) {
     }
 }
 
+__device__ __forceinline__ void wave_sync_lds() {       // lanes of ONE wave hand data over through LDS: order its LDS traffic, no s_barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- one lane = one 8x8 block --------------------------------------------------------------------------------------------
+// The common block routines -- islow 8x8 (MODE 0), jidctred's 4x4 (MODE 1), islow followed by imageflow's
+// flow_scale_spatial[_srgb]_NxN (MODE 2) -- with the whole block in the registers of ONE lane: both passes run on
+// compile-time register indices, nothing goes through LDS, no wave-scope ordering, and the per-lane overhead of the
+// eight-lanes-per-block form (de-quantising 8 values, 24 LDS accesses, index arithmetic, packing -- about 190 of its 250
+// instructions per lane, i.e. 1 500 of 2 000 per block) is paid once per block instead of eight times.  A wave reads 64
+// consecutive blocks = 8 KiB (every line is consumed by the lane's eight 16-byte loads) and stores 512 contiguous bytes
+// per output row.  Same integer arithmetic as jpeg_idct_kernel (which keeps the rarer sizes 1, 2, 3, 5, 6, 10, 12).
+__device__ __forceinline__ uint32_t range_limit_fast(int32_t v) {    // == range_limit(v) for v in [-384, 383]
+    const int32_t x = v + 128;
+    return static_cast<uint32_t>(x < 0 ? 0 : (x > 255 ? 255 : x));        // (v_med3_i32)
+}
+
+typedef uint4_nt (*BplStage)[64 * 9];
+template <int MODE>
+__device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t c, uint32_t img, uint32_t wg, BplStage stage,
+                                                    const uint16_t* s2l_lds, const uint8_t* l2s_lds) {
+    const uint32_t t = threadIdx.x;
+    const bool srgb = MODE == 2 && a.g.luma_mode == 2u;
+    const uint32_t nblk = a.g.bw[c] * a.g.bh[c];
+    const uint32_t bidx = wg * 256u + t;
+    // A wave's 64 blocks are 8 KiB of consecutive coefficients: read them with 8 fully coalesced 16-byte loads per lane and
+    // hand each lane its own block through LDS (block pitch 9 x 16 B: the 16-byte row reads of neighbouring lanes fall 4
+    // banks apart).  Lanes reading their blocks straight from global memory -- 16 bytes of 64 different cache lines per
+    // instruction -- made this kernel 1.6x slower than the eight-lanes form it replaces (profiles/r3_jpeg_kernels_*.txt).
+    const uint32_t wv = t >> 6, ln = t & 63u;
+    const uint32_t wave_block0 = wg * 256u + wv * 64u;
+    if (wave_block0 >= nblk) return;                           // (whole wave: nothing below is a workgroup barrier)
+    const uint32_t wave_vecs = min(64u, nblk - wave_block0) * 8u;    // 16-byte rows this wave owns
+    const uint4_nt* wsrc = reinterpret_cast<const uint4_nt*>(a.coef[c] + (static_cast<size_t>(img) * nblk + wave_block0) * 64u);
+    uint4_nt rowv[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t g = k * 64u + ln;
+        rowv[k] = __builtin_nontemporal_load(wsrc + (g < wave_vecs ? g : wave_vecs - 1u));
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t g = k * 64u + ln;
+        stage[wv][(g >> 3) * 9u + (g & 7u)] = rowv[k];
+    }
+    wave_sync_lds();
+    if (bidx >= nblk) return;
+    // the luma scalers' islow runs with the FIRST component's table, as jpeg_idct_islow(cinfo, compptr, ...) does
+    const uint32_t* q32 = reinterpret_cast<const uint32_t*>(a.qt + (static_cast<size_t>(img) * a.g.ncomp + c) * 64u);   // wave-uniform: scalar loads
+    int32_t ws[8][8];
+    uint32_t mag = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (MODE == 1 && r == 4) {                              // jpeg_idct_4x4 never reads coefficient row 4
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ws[r][k] = 0;
+            continue;
+        }
+        const uint4_nt cv = stage[wv][ln * 9u + static_cast<uint32_t>(r)];
+        const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t qq = q32[r * 4 + k];
+            const int32_t d0 = __mul24(static_cast<int32_t>(static_cast<int16_t>(cw[k] & 0xffffu)), static_cast<int32_t>(qq & 0xffffu));   // 16-bit operands: exact
+            const int32_t d1 = __mul24(static_cast<int32_t>(static_cast<int16_t>(cw[k] >> 16)), static_cast<int32_t>(qq >> 16));
+            ws[r][2 * k] = d0; ws[r][2 * k + 1] = d1;
+            mag |= static_cast<uint32_t>(d0 < 0 ? -d0 : d0) | static_cast<uint32_t>(d1 < 0 ? -d1 : d1);
+        }
+    }
+    const bool small = __all(mag < (1u << 21)) != 0;           // 24-bit multiplies in the first pass (see mulc)
+    uint8_t* plane = a.plane[c] + static_cast<size_t>(img) * a.g.pw[c] * a.g.ph[c];
+    const uint32_t by = bidx / a.g.bw[c], bx = bidx - by * a.g.bw[c];
+
+    if constexpr (MODE == 1) {
+        // jidctred.c jpeg_idct_4x4: columns 0-3, 5-7 (column 4 is not used by the second pass), rows 0-3
+        int32_t col[4][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k == 4) continue;
+            int32_t o[4];
+            if (small) idct4_pass<true>(ws[0][k], ws[1][k], ws[2][k], ws[3][k], ws[5][k], ws[6][k], ws[7][k], o, 12);
+            else idct4_pass<false>(ws[0][k], ws[1][k], ws[2][k], ws[3][k], ws[5][k], ws[6][k], ws[7][k], o, 12);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) col[r][k] = o[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int32_t o[4];
+            idct4_pass<true>(col[r][0], col[r][1], col[r][2], col[r][3], col[r][5], col[r][6], col[r][7], o, 19);
+            const uint32_t v = range_limit(o[0]) | (range_limit(o[1]) << 8) | (range_limit(o[2]) << 16) | (range_limit(o[3]) << 24);
+            *reinterpret_cast<uint32_t*>(plane + static_cast<size_t>(by * 4u + r) * a.g.pw[c] + bx * 4u) = v;
+        }
+        return;
+    } else {
+        // column pass (CONST_BITS - PASS1_BITS), in place
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int32_t in[8], out[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) in[r] = ws[r][k];
+            idct8_pass1(in, out, small);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ws[r][k] = out[r];
+        }
+        // row pass (CONST_BITS + PASS1_BITS + 3: always in 24-bit range) + libjpeg's range-limit table.  The table wraps
+        // beyond [-384, 383]; inside, it is a clamp of v + 128 -- a wave whose 64 blocks all stay inside takes the clamp.
+        int32_t (&px)[8][8] = ws;                               // in place: a row's eight inputs are consumed before its outputs land
+        int32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            int32_t in[8], out[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) in[k] = ws[r][k];
+            idct8<true>(in, out, 18);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { px[r][k] = out[k]; lo = out[k] < lo ? out[k] : lo; hi = out[k] > hi ? out[k] : hi; }
+        }
+        const bool tame = __all(lo >= -384 && hi <= 383) != 0;
+        uint32_t bytes[8][2];                                   // row r: bytes 0-3, 4-7
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                w0 |= (tame ? range_limit_fast(px[r][k]) : range_limit(px[r][k])) << (8 * k);
+                w1 |= (tame ? range_limit_fast(px[r][4 + k]) : range_limit(px[r][4 + k])) << (8 * k);
+            }
+            bytes[r][0] = w0; bytes[r][1] = w1;
+        }
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                *reinterpret_cast<uint2*>(plane + static_cast<size_t>(by * 8u + r) * a.g.pw[c] + bx * 8u) = make_uint2(bytes[r][0], bytes[r][1]);
+            return;
+        } else {
+            // flow_scale_spatial[_srgb]_NxN (codecs_jpeg_idct_fast.c): rows combined with the integer weights of output row
+            // r, then columns with those of output column cc, rounded by the two divisors' shift; the _srgb forms work in
+            // 12-bit linear light through two lookup tables.  |weight| <= 117, linear <= 4095, sums of weights <= 512:
+            // every product fits 24 x 24 -> 32 bits.
+            const uint32_t n = a.g.idct_n[0];
+            int32_t lin[8][8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t b = (bytes[i][j >> 2] >> (8 * (j & 3))) & 255u;
+                    lin[i][j] = srgb ? static_cast<int32_t>(s2l_lds[b]) : static_cast<int32_t>(b);
+                }
+#pragma unroll
+            for (uint32_t r = 0; r < 7u; ++r) {
+                if (r >= n) break;                              // wave-uniform
+                int32_t V[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int32_t acc = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc += __mul24(a.sc.w[r][i], lin[i][j]);
+                    V[j] = acc;
+                }
+                uint32_t packed = 0;
+                uint8_t* orow = plane + static_cast<size_t>(by * n + r) * a.g.pw[c] + bx * n;
+#pragma unroll
+                for (uint32_t cc = 0; cc < 7u; ++cc) {
+                    if (cc >= n) break;
+                    const uint32_t sh = a.sc.log2_div[r] + a.sc.log2_div[cc];
+                    int32_t sum = static_cast<int32_t>(1u << (sh - 1u));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sum += __mul24(V[j], a.sc.w[cc][j]);
+                    uint32_t ob;
+                    if (sum < 0) ob = 0;
+                    else if (static_cast<uint32_t>(sum) >= (4096u << sh)) ob = 255;
+                    else ob = srgb ? l2s_lds[sum >> sh] : static_cast<uint32_t>(sum >> sh);
+                    ob &= 255u;
+                    if (n == 4u || n == 2u) packed |= ob << (8u * cc);
+                    else orow[cc] = static_cast<uint8_t>(ob);
+                }
+                if (n == 4u) *reinterpret_cast<uint32_t*>(orow) = packed;               // (plane pitch and bx * 4: 4-byte aligned)
+                else if (n == 2u) *reinterpret_cast<uint16_t*>(orow) = static_cast<uint16_t>(packed);
+            }
+        }
+    }
+}
+
+// One launch per component (blockIdx.z: the two chroma components).  (One launch for all three with luma and chroma
+// workgroups interleaved -- traffic-bound plain IDCTs beside the arithmetic-bound spatial scalers -- was measured: 410 us
+// against 254 + 110 us for the 4/8 decode of 32 4K frames; every workgroup then carries the larger routine's registers.)
+__device__ __forceinline__ void bpl_tables(const JpegArgs& a, bool needed, uint16_t* s2l_lds, uint8_t* l2s_lds) {
+    if (needed) {
+        s2l_lds[threadIdx.x] = a.sc.s2l[threadIdx.x];
+        reinterpret_cast<uint4*>(l2s_lds)[threadIdx.x] = reinterpret_cast<const uint4*>(a.sc.l2s)[threadIdx.x];
+    }
+    __syncthreads();
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 4) jpeg_idct_block_per_lane_kernel(const JpegArgs a) {      // 4 waves per SIMD: <= 128 registers
+    __shared__ __attribute__((aligned(16))) uint4_nt stage[4][64 * 9];
+    __shared__ uint16_t s2l_lds[MODE == 2 ? 256 : 1];
+    __shared__ __attribute__((aligned(16))) uint8_t l2s_lds[MODE == 2 ? 4096 : 16];
+    if (MODE == 2) bpl_tables(a, a.g.luma_mode == 2u, s2l_lds, l2s_lds);
+    idct_block_per_lane<MODE>(a, a.comp + blockIdx.z, blockIdx.y, blockIdx.x, stage, s2l_lds, l2s_lds);
+}
+
 // ---- up-sample + colour ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int32_t chroma_at(const uint8_t* p, uint32_t pw, uint32_t dw, uint32_t dh, int32_t x, int32_t y) {
     x = x < 0 ? 0 : (x >= static_cast<int32_t>(dw) ? static_cast<int32_t>(dw) - 1 : x);   // edge duplication (jdmainct.c)
@@ -529,11 +734,6 @@ constexpr uint32_t kColorRows = 16;
 
 constexpr uint32_t kTilePx = 1024, kYsPitch = kTilePx + 16;      // luma tile of the fused form: 16 rows x 1024 pixels
 
-__device__ __forceinline__ void wave_sync_lds() {       // the 8 lanes of a block share a wave: order LDS traffic, no s_barrier
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // FUSED_LUMA (full-size decode of 3-component files): the workgroup first runs the islow IDCT of the 2 x 128 luma
 // blocks under its 1024 x 16 pixel tile into LDS -- 8 passes of 32 blocks, 8 lanes per block as in jpeg_idct_kernel, ordered
@@ -924,13 +1124,28 @@ static int stage_args(ifhip_jpeg_stage* stage, const int16_t* d_coef0, const int
     return IFHIP_OK;
 }
 
+// block-per-lane routine of component c: 0 islow 8x8, 1 jidctred 4x4, 2 islow + spatial scaler; -1: the eight-lanes kernel
+static int bpl_mode(const JpegGeom& g, int c) {
+    if (std::getenv("IFHIP_JPEG_IDCT8")) return -1;             // experiment switch: everything on the eight-lanes kernel
+    const uint32_t n = g.idct_n[c];
+    if (c == 0 && g.luma_mode != 0u && n < 8u) return 2;
+    return n == 8u ? 0 : n == 4u ? 1 : -1;
+}
+
 static int launch_idct_planes(JpegArgs a, int first_component, hipStream_t st) {
-    for (int c = first_component; c < a.g.ncomp; ++c) {
+    const JpegGeom& g = a.g;
+    for (int c = first_component; c < g.ncomp; ++c) {
         a.comp = static_cast<uint32_t>(c);
-        const uint32_t nblk = a.g.bw[c] * a.g.bh[c];
+        const uint32_t nblk = g.bw[c] * g.bh[c];
         // the two chroma components have the same geometry: one launch covers both (blockIdx.z)
-        const bool both = c == 1 && a.g.ncomp == 3 && a.g.bw[1] == a.g.bw[2] && a.g.bh[1] == a.g.bh[2] && a.g.idct_n[1] == a.g.idct_n[2];
-        hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nblk + kBlocksPerWg - 1) / kBlocksPerWg, a.n_images, both ? 2u : 1u), dim3(256), 0, st, a);
+        const bool both = c == 1 && g.ncomp == 3 && g.bw[1] == g.bw[2] && g.bh[1] == g.bh[2] && g.idct_n[1] == g.idct_n[2];
+        // the common block routines run one lane per block; the rarer sizes keep the eight-lanes-per-block kernel
+        const int bpl = bpl_mode(g, c);
+        const dim3 bgrid((nblk + 255u) / 256u, a.n_images, both ? 2u : 1u);
+        if (bpl == 0) hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<0>), bgrid, dim3(256), 0, st, a);
+        else if (bpl == 1) hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<1>), bgrid, dim3(256), 0, st, a);
+        else if (bpl == 2) hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2>), bgrid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nblk + kBlocksPerWg - 1) / kBlocksPerWg, a.n_images, both ? 2u : 1u), dim3(256), 0, st, a);
         HIP_TRY(hipGetLastError());
         if (both) ++c;
     }
