@@ -581,21 +581,18 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
             for (int k = 0; k < 8; ++k) { px[r][k] = out[k]; lo = out[k] < lo ? out[k] : lo; hi = out[k] > hi ? out[k] : hi; }
         }
         const bool tame = __all(lo >= -384 && hi <= 383) != 0;
-        uint32_t bytes[8][2];                                   // row r: bytes 0-3, 4-7
+        // range-limited samples, in place (0 .. 255)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            uint32_t w0 = 0, w1 = 0;
+        for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                w0 |= (tame ? range_limit_fast(px[r][k]) : range_limit(px[r][k])) << (8 * k);
-                w1 |= (tame ? range_limit_fast(px[r][4 + k]) : range_limit(px[r][4 + k])) << (8 * k);
-            }
-            bytes[r][0] = w0; bytes[r][1] = w1;
-        }
+            for (int k = 0; k < 8; ++k) px[r][k] = static_cast<int32_t>(tame ? range_limit_fast(px[r][k]) : range_limit(px[r][k]));
         if constexpr (MODE == 0) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                *reinterpret_cast<uint2*>(plane + static_cast<size_t>(by * 8u + r) * a.g.pw[c] + bx * 8u) = make_uint2(bytes[r][0], bytes[r][1]);
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t w0 = static_cast<uint32_t>(px[r][0]) | (static_cast<uint32_t>(px[r][1]) << 8) | (static_cast<uint32_t>(px[r][2]) << 16) | (static_cast<uint32_t>(px[r][3]) << 24);
+                const uint32_t w1 = static_cast<uint32_t>(px[r][4]) | (static_cast<uint32_t>(px[r][5]) << 8) | (static_cast<uint32_t>(px[r][6]) << 16) | (static_cast<uint32_t>(px[r][7]) << 24);
+                *reinterpret_cast<uint2*>(plane + static_cast<size_t>(by * 8u + r) * a.g.pw[c] + bx * 8u) = make_uint2(w0, w1);
+            }
             return;
         } else {
             // flow_scale_spatial[_srgb]_NxN (codecs_jpeg_idct_fast.c): rows combined with the integer weights of output row
@@ -603,14 +600,13 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
             // 12-bit linear light through two lookup tables.  |weight| <= 117, linear <= 4095, sums of weights <= 512:
             // every product fits 24 x 24 -> 32 bits.
             const uint32_t n = a.g.idct_n[0];
-            int32_t lin[8][8];
+            int32_t (&lin)[8][8] = px;                          // in place again: sample -> 12-bit linear light (or itself)
+            if (srgb) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t b = (bytes[i][j >> 2] >> (8 * (j & 3))) & 255u;
-                    lin[i][j] = srgb ? static_cast<int32_t>(s2l_lds[b]) : static_cast<int32_t>(b);
-                }
+                    for (int j = 0; j < 8; ++j) lin[i][j] = static_cast<int32_t>(s2l_lds[px[i][j]]);
+            }
 #pragma unroll
             for (uint32_t r = 0; r < 7u; ++r) {
                 if (r >= n) break;                              // wave-uniform
@@ -658,7 +654,8 @@ __device__ __forceinline__ void bpl_tables(const JpegArgs& a, bool needed, uint1
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(256, 4) jpeg_idct_block_per_lane_kernel(const JpegArgs a) {      // 4 waves per SIMD: <= 128 registers
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))                   // 4 waves per SIMD: <= 128 registers
+jpeg_idct_block_per_lane_kernel(const JpegArgs a) {
     __shared__ __attribute__((aligned(16))) uint4_nt stage[4][64 * 9];
     __shared__ uint16_t s2l_lds[MODE == 2 ? 256 : 1];
     __shared__ __attribute__((aligned(16))) uint8_t l2s_lds[MODE == 2 ? 4096 : 16];
