@@ -48,7 +48,7 @@ def test_headline_resample_kernel_keeps_its_shape(k):
     """fused_resample_kernel<4, false, true, true, 0> is the BASELINE cfg2 kernel: 1 024 lanes need <= 128 VGPRs; the fast
     horizontal forms (cfg3 / cfg4 / cfg1 resizes) must stay out of scratch."""
     rows = resource_usage(os.path.join(B.CSRC, B.FUSED), [f"-DIFHIP_FUSED_K={k}"])
-    head = [r for n, r in rows.items() if n.startswith("void fused_resample_kernel<4, false, true, true, 0>")]
+    head = [r for n, r in rows.items() if n.startswith("void fused_resample_kernel<4, false, true, true, 0, false>")]      # (.., planar source)
     assert head and all(_int(r, "VGPRs") <= 128 for r in head), head
-    fast = [r for n, r in rows.items() if re.search(r"fused_resample_kernel<4, (false|true), true, true, [234]>", n)]
+    fast = [r for n, r in rows.items() if re.search(r"fused_resample_kernel<4, (false|true), true, true, [234], (false|true)>", n)]
     assert len(fast) >= 3 and all(_int(r, "ScratchSize [bytes/lane]") == 0 and _int(r, "VGPRs") <= 128 for r in fast), fast
