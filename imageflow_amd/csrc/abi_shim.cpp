@@ -260,12 +260,26 @@ int parse_filter(const JVal* v, int dflt) {                      // imageflow_ty
 }
 
 // ---- frames in HBM ---------------------------------------------------------------------------------------------
+// A decoded JPEG whose pixel stage has not run: when the frame's one consumer is a resample, decode and resample run as ONE
+// device call (ifhip_jpeg_decode_resample_batch_device: no decoded BGRA bitmap in HBM); any other consumer gets the bitmap
+// through Job::dev(), which runs the pixel stage then.
+struct PendingJpeg {
+    ifhip_jpeg_stage* st = nullptr;
+    int16_t* coef[3] = {nullptr, nullptr, nullptr};
+    uint16_t* d_qt = nullptr;
+    ~PendingJpeg() {
+        if (st) ifhip_jpeg_stage_destroy(st);
+        for (int16_t* p : coef) if (p) (void)hipFree(p);
+        if (d_qt) (void)hipFree(d_qt);
+    }
+};
 struct Frame {                                   // graphics/bitmaps.rs Bitmap: BGRA8, 64-byte row stride
-    uint8_t* d = nullptr;
+    uint8_t* d = nullptr;                        // (null while `pending`: read it through Job::dev())
     uint32_t w = 0, h = 0, stride = 0;
     bool alpha = false;
     int compose = IFHIP_REPLACE_SELF;
     uint32_t matte = 0;
+    std::unique_ptr<PendingJpeg> pending;
     size_t bytes() const { return static_cast<size_t>(h) * stride; }
     ~Frame() { if (d) (void)hipFree(d); }
 };
@@ -321,6 +335,7 @@ struct imageflow_context {
     // and the reference's debug-build poll countdown ("cancel at the n-th poll", :96-104) as a test hook
     std::atomic<bool> cancel{false};
     std::atomic<int64_t> poll_countdown{INT64_MAX};
+    std::atomic<int64_t> fused_decode_resamples{0};
     bool cancellation_requested() {
         if (cancel.load(std::memory_order_relaxed)) return true;
         if (poll_countdown.load(std::memory_order_relaxed) == INT64_MAX) return false;
@@ -457,9 +472,21 @@ struct Job {
         }
         return f;
     }
+    // the frame's pixels on the device; a pending JPEG gets its pixel stage now (IDCT + colour into a bitmap)
+    uint8_t* dev(const FramePtr& f) {
+        if (f->pending) {
+            hip_check(hipMalloc(reinterpret_cast<void**>(&f->d), f->bytes() + 64), "hipMalloc(frame)");
+            PendingJpeg& p = *f->pending;
+            check(ifhip_jpeg_idct_color_batch_device(p.st, p.coef[0], p.coef[1], p.coef[2], p.d_qt, 1, f->d, f->bytes(), f->stride, nullptr));
+            hip_check(hipStreamSynchronize(nullptr), "decode");
+            f->pending.reset();
+        }
+        return f->d;
+    }
+    bool lazy_decode = false;                                        // the decode node being run has exactly one consumer
     FramePtr clone(const FramePtr& in) {                              // flow/nodes/clone_crop_fill_expand.rs:140-175
         FramePtr c2 = new_frame(in->w, in->h, in->alpha, 0, false);
-        hip_check(hipMemcpyAsync(c2->d, in->d, in->bytes(), hipMemcpyDeviceToDevice, nullptr), "clone");
+        hip_check(hipMemcpyAsync(c2->d, dev(in), in->bytes(), hipMemcpyDeviceToDevice, nullptr), "clone");
         c2->compose = in->compose; c2->matte = in->matte;
         return c2;
     }
@@ -549,17 +576,24 @@ struct Job {
         check(ifhip_jpeg_entropy_quant_tables(ent, qt));
         uint16_t* d_qt = nullptr;
         hip_check(hipMalloc(reinterpret_cast<void**>(&d_qt), sizeof qt), "hipMalloc(qt)");
-        struct QtGuard { uint16_t* p; ~QtGuard() { (void)hipFree(p); } } qg{d_qt};
+        struct QtGuard { uint16_t* p; ~QtGuard() { if (p) (void)hipFree(p); } } qg{d_qt};
         hip_check(hipMemcpy(d_qt, qt, static_cast<size_t>(ncomp) * 128, hipMemcpyHostToDevice), "upload(qt)");
         ifhip_jpeg_stage* st = nullptr;
         const bool spatial = scale < 8 && luma_spatial;
         check(ifhip_jpeg_stage_create(&st, w, h, ncomp, hs, vs, scale, spatial ? 1 : 0, spatial && luma_srgb ? 1 : 0, 1));
-        struct StGuard { ifhip_jpeg_stage* s; ~StGuard() { ifhip_jpeg_stage_destroy(s); } } sg{st};
+        auto pend = std::make_unique<PendingJpeg>();                                  // owns stage, coefficients, tables from here
+        pend->st = st;
+        for (int k = 0; k < 3; ++k) { pend->coef[k] = coef[k]; coef[k] = nullptr; }
+        pend->d_qt = d_qt; qg.p = nullptr;
         uint32_t ow = 0, oh = 0;
         check(ifhip_jpeg_stage_output_size(st, &ow, &oh));
-        FramePtr f = new_frame(ow, oh, false, 0, false);                              // alpha not meaningful (:101-123)
-        check(ifhip_jpeg_idct_color_batch_device(st, coef[0], coef[1], coef[2], d_qt, 1, f->d, f->bytes(), f->stride, nullptr));
-        hip_check(hipStreamSynchronize(nullptr), "decode");
+        if (ow == 0 || oh == 0) raise(kArgumentInvalid, "InvalidArgument: Bitmap dimensions cannot be zero");
+        check_size(sec.max_frame_size, "max_frame_size", ow, oh);
+        poll_cancel();                                                                // borrow_bitmaps_mut (context.rs:389), as new_frame
+        auto f = std::make_shared<Frame>();                                           // alpha not meaningful (:101-123)
+        f->w = ow; f->h = oh; f->stride = ifhip_stride_for_width(ow); f->alpha = false;
+        f->pending = std::move(pend);
+        if (!lazy_decode) (void)dev(f);                                               // several consumers: one bitmap for all of them
         decodes.push_back({io_id, w, h, "image/jpeg", "jpg"});
         return f;
     }
@@ -630,7 +664,14 @@ struct Job {
         ifhip_resample_plan* plan = nullptr;
         check(ifhip_resample_plan_create(&plan, in->w, in->h, w, h, filter, sharpen));
         struct PlanGuard { ifhip_resample_plan* p; ~PlanGuard() { ifhip_resample_plan_destroy(p); } } pg{plan};
-        check(ifhip_scale_and_render_batch_device(plan, in->d, in->bytes(), in->stride, in->alpha ? 1 : 0, 1, canvas->d, canvas->bytes(),
+        if (in->pending) {                            // MzDec::read_frame + scale_and_render as one device call (mozjpeg_decoder.rs:346-362 -> :304-313)
+            PendingJpeg& pj = *in->pending;
+            int fused_call = 0;
+            check(ifhip_jpeg_decode_resample_batch_device(pj.st, pj.coef[0], pj.coef[1], pj.coef[2], pj.d_qt, 1, plan, dev(canvas), canvas->bytes(), canvas->w,
+                                                          canvas->h, canvas->stride, x, y, hi.space, canvas->compose, canvas->matte, &fused_call, nullptr));
+            if (fused_call) c->fused_decode_resamples.fetch_add(1, std::memory_order_relaxed);
+        } else
+        check(ifhip_scale_and_render_batch_device(plan, in->d, in->bytes(), in->stride, in->alpha ? 1 : 0, 1, dev(canvas), canvas->bytes(),
                                                   canvas->w, canvas->h, canvas->stride, x, y, hi.space, canvas->compose, canvas->matte, nullptr, -1, nullptr));
         hip_check(hipStreamSynchronize(nullptr), "draw_image_exact");
         canvas->compose = IFHIP_BLEND_WITH_SELF;                                                                       // :314
@@ -783,7 +824,7 @@ struct Job {
             const JVal* m = classic->get("matte");
             const uint32_t matte = m && !m->is_null() ? parse_color(m, "encode.preset.libjpeg_turbo.matte") : 0xFFFFFFFFu;   // :88-92
             if (shared && f->alpha) f = clone(f);
-            check(ifhip_apply_matte_batch_device(f->d, f->bytes(), 1, f->w, f->h, f->stride, f->alpha ? 1 : 0, matte, nullptr));
+            check(ifhip_apply_matte_batch_device(dev(f), f->bytes(), 1, f->w, f->h, f->stride, f->alpha ? 1 : 0, matte, nullptr));
             f->alpha = false;                                                            // :94 set_alpha_meaningful(false)
             const uint8_t hs[3] = {2, 1, 1}, vs[3] = {2, 1, 1};
             uint16_t qt2[2][64], qt3[3][64];
@@ -802,7 +843,7 @@ struct Job {
             std::unique_ptr<int16_t, void (*)(int16_t*)> coef_guard(d_coef, [](int16_t* p) { (void)hipFree(p); });
             d_qt = reinterpret_cast<uint16_t*>(d_coef + off[3]);
             hip_check(hipMemcpy(d_qt, qt3, 384, hipMemcpyHostToDevice), "upload(quant tables)");
-            check(ifhip_jpeg_forward_batch_device(st, f->d, f->bytes(), f->stride, d_qt, 1, d_coef + off[0], d_coef + off[1], d_coef + off[2], nullptr));
+            check(ifhip_jpeg_forward_batch_device(st, dev(f), f->bytes(), f->stride, d_qt, 1, d_coef + off[0], d_coef + off[1], d_coef + off[2], nullptr));
             std::vector<int16_t> coef(off[3]);
             hip_check(hipMemcpy(coef.data(), d_coef, off[3] * 2u, hipMemcpyDeviceToHost), "download(coefficients)");
             poll_cancel();
@@ -825,7 +866,7 @@ struct Job {
         std::memcpy(o.owned.data(), kRawMagic, 8);
         const uint32_t hdr[4] = {f->w, f->h, f->stride, f->alpha ? 1u : 0u};
         std::memcpy(o.owned.data() + 8, hdr, 16);
-        hip_check(hipMemcpy(o.owned.data() + kRawHeader, f->d, f->bytes(), hipMemcpyDeviceToHost), "download(frame)");
+        hip_check(hipMemcpy(o.owned.data() + kRawHeader, dev(f), f->bytes(), hipMemcpyDeviceToHost), "download(frame)");
         o.written = true;
         encodes.push_back({io_id, f->w, f->h, "application/x-imageflow-bgra", "ifbgra"});
     }
@@ -838,7 +879,7 @@ struct Job {
             raise(kArgumentInvalid, "InvalidNodeParams: Invalid coordinates. Canvas is %ux%u, Input is %ux%u, Params provided: from_x=%u from_y=%u w=%u h=%u x=%u y=%u",
                   canvas->w, canvas->h, in->w, in->h, fx, fy, w, h, x, y);
         int canvas_alpha = canvas->alpha ? 1 : 0;
-        check(ifhip_copy_rect_batch_device(in->d, in->bytes(), in->w, in->h, in->stride, in->alpha ? 1 : 0, canvas->d, canvas->bytes(),
+        check(ifhip_copy_rect_batch_device(dev(in), in->bytes(), in->w, in->h, in->stride, in->alpha ? 1 : 0, dev(canvas), canvas->bytes(),
                                            canvas->w, canvas->h, canvas->stride, &canvas_alpha, fx, fy, x, y, w, h, 1, nullptr));
         canvas->alpha = canvas_alpha != 0;
         hip_check(hipStreamSynchronize(nullptr), "copy_rect");
@@ -846,17 +887,17 @@ struct Job {
     }
     FramePtr transposed(const FramePtr& in) {
         FramePtr t = new_frame(in->h, in->w, in->alpha, 0, true);
-        check(ifhip_transpose_batch_device(in->d, in->bytes(), in->w, in->h, in->stride, t->d, t->bytes(), t->w, t->h, t->stride, 1, nullptr));
+        check(ifhip_transpose_batch_device(dev(in), in->bytes(), in->w, in->h, in->stride, t->d, t->bytes(), t->w, t->h, t->stride, 1, nullptr));
         return t;
     }
     FramePtr flip(const FramePtr& in, bool vertical) {
-        check(vertical ? ifhip_flip_vertical_batch_device(in->d, in->bytes(), 1, in->w, in->h, in->stride, nullptr)
-                       : ifhip_flip_horizontal_batch_device(in->d, in->bytes(), 1, in->w, in->h, in->stride, nullptr));
+        check(vertical ? ifhip_flip_vertical_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, nullptr)
+                       : ifhip_flip_horizontal_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, nullptr));
         return in;
     }
     // ColorMatrixSrgbMutDef::mutate (flow/nodes/color.rs:20-38)
     FramePtr color_matrix(const FramePtr& in, const float m[25]) {
-        check(ifhip_apply_color_matrix_batch_device(in->d, in->bytes(), 1, in->w, in->h, in->stride, m, nullptr));
+        check(ifhip_apply_color_matrix_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, m, nullptr));
         in->compose = IFHIP_BLEND_WITH_SELF;
         return in;
     }
@@ -884,7 +925,7 @@ struct Job {
             std::memcpy(m, v, sizeof v);
         } else raise(kInvalidJson, "InvalidJson: unknown color_filter_srgb '%s'", name.c_str());
         if (name == "alpha" && !in->alpha) {                                          // EnableTransparency (enable_transparency.rs:68-95)
-            check(ifhip_normalize_unused_alpha_batch_device(in->d, in->bytes(), 1, in->w, in->h, in->stride, 0, nullptr));
+            check(ifhip_normalize_unused_alpha_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, 0, nullptr));
             in->alpha = true;
         }
         return color_matrix(in, m);
@@ -1003,7 +1044,7 @@ struct Job {
                       : name == "rotate_90" ? "rotate_90" : name == "rotate_180" ? "rotate_180" : name == "rotate_270" ? "rotate_270" : name == "apply_orientation" ? "apply_orientation" : "node");
         if (name == "fill_rect") {                                                    // clone_crop_fill_expand.rs:107-137
             in->compose = IFHIP_BLEND_WITH_SELF;                                      // :112: set before the fill, so matte canvases accept sub-rects
-            check(ifhip_fill_rect_batch_device(in->d, in->bytes(), 1, in->w, in->h, in->stride, in->compose, want_u32(p, "x1", name.c_str()),
+            check(ifhip_fill_rect_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, in->compose, want_u32(p, "x1", name.c_str()),
                                                want_u32(p, "y1", name.c_str()), want_u32(p, "x2", name.c_str()), want_u32(p, "y2", name.c_str()),
                                                parse_color(p.get("color"), "fill_rect.color"), nullptr));
             return in;
@@ -1074,6 +1115,7 @@ struct Job {
                 std::string name;
                 const JVal* params;
                 node_of(n, &name, &params);
+                lazy_decode = true;                                                    // a chain: every frame has one consumer
                 cur = run_node(name, *params, cur, nullptr, false);
             }
             return;
@@ -1123,6 +1165,7 @@ struct Job {
                 canvas = eval(cit->second);
                 if (canvas && consumers[cit->second] > 1) canvas = clone(canvas);
             }
+            lazy_decode = consumers[id] == 1;
             FramePtr out = run_node(name, *params, in, canvas, in_shared);
             state[id] = 2;
             done[id] = out;
@@ -1280,6 +1323,10 @@ void ifhip_shim_request_cancellation_after_n_polls(struct imageflow_context* c, 
 int64_t ifhip_shim_cancellation_polls_remaining(struct imageflow_context* c) {
     CTX_OR_ABORT(c);
     return c->poll_countdown.load(std::memory_order_seq_cst);
+}
+int64_t ifhip_shim_fused_decode_resamples(struct imageflow_context* c) {
+    CTX_OR_ABORT(c);
+    return c->fused_decode_resamples.load(std::memory_order_relaxed);
 }
 bool imageflow_context_error_write_to_buffer(struct imageflow_context* c, char* buffer, size_t buffer_length, size_t* bytes_written) {   // lib.rs:684
     CTX_OR_ABORT(c);

@@ -97,6 +97,9 @@ IMAGEFLOW_SHIM_API bool imageflow_context_memory_free(struct imageflow_context *
  * test (Context::request_cancellation_after_n_polls, imageflow_core/src/context.rs:96-104,167-172). */
 IMAGEFLOW_SHIM_API void ifhip_shim_request_cancellation_after_n_polls(struct imageflow_context *context, int64_t polls);
 IMAGEFLOW_SHIM_API int64_t ifhip_shim_cancellation_polls_remaining(struct imageflow_context *context);
+/* Diagnostic: how many decode -> resample pairs of this context's jobs ran as ONE device call without a decoded bitmap in
+ * HBM (ifhip_jpeg_decode_resample_batch_device reporting fused = 1). */
+IMAGEFLOW_SHIM_API int64_t ifhip_shim_fused_decode_resamples(struct imageflow_context *context);
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,7 @@ def test_config1_querystring_width_200_on_a_4k_jpeg():
         _run(c, "v1/build", {"io": [{"io_id": 0, "direction": "in", "io": "placeholder"}, {"io_id": 1, "direction": "out", "io": "placeholder"}],
                              "framewise": {"steps": [{"command_string": {"kind": "ir4", "value": "width=200", "decode": 0, "encode": 1}}]}})
         rows, w, h, _ = unpack_raw_bgra(c.get_output_buffer(1))
+        assert c.L.ifhip_shim_fused_decode_resamples(c.p) == 1          # decode + resample ran as one call: no 960x540 bitmap in HBM
     assert (w, h) == (200, 113)
     j = O.jpeg_read_coefficients(data)
     small = O.jpeg_idct_color_scaled(j, 2, 2)

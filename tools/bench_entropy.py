@@ -84,20 +84,18 @@ def main():
     # the same target the way the reference's querystring path reaches it (ir4/mod.rs:155-197, mozjpeg_decoder.rs:588-618):
     # min_precise_scaling_ratio 2.1 -> the decoder is asked for >= 1680 px -> 4/8 IDCT with the spatial sRGB luma scaler
     stage4 = D.JpegPixelStage(w, h, 3, ent.h_samp, ent.v_samp, n, scale_num=4, luma_spatial=True, luma_srgb=True)
-    out4 = stage4.read_frames(coef, qt)
-    scale_and_render(out4, small, info)
+    # one device call (ifhip_jpeg_decode_resample_batch_device): the resampler reads the component planes, no BGRA bitmap
+    fused4 = stage4.read_frames_into(coef, qt, small, info)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        stage4.read_frames(coef, qt, out4)
-        scale_and_render(out4, small, info)
+        stage4.read_frames_into(coef, qt, small, info)
     torch.cuda.synchronize()
     t_px4 = (time.perf_counter() - t0) / reps
     t0 = time.perf_counter()
     for _ in range(reps):
         ent.read_coefficients(coef)
-        stage4.read_frames(coef, qt, out4)
-        scale_and_render(out4, small, info)
+        stage4.read_frames_into(coef, qt, small, info)
     torch.cuda.synchronize()
     t_cfg4_ref = (time.perf_counter() - t0) / reps
     t0 = time.perf_counter()
@@ -125,9 +123,10 @@ def main():
             "entropy_stage": roof(size + coef_bytes, t_dec, "compressed scan in + coefficient planes out; wall clock over all launches "
                                   "of one decode; the stage is bound by dependent bit-serial decoding, not by HBM"),
             "cfg4_pixel_stage_and_resize": roof(n * 26323584, t_px, "SURVEY 8d fused minimum per frame (coefficients + quant tables in, "
-                                                "800x450 BGRA out); the full-size BGRA intermediate is still materialised"),
+                                                "800x450 BGRA out); full-size decode needs the fancy up-sampler: two calls, the BGRA frame goes through HBM"),
             "cfg4_pixel_stage_4_8_idct_and_resize": roof(n * 26323584, t_px4, "the same fused minimum, decoded at 4/8 with the spatial sRGB "
-                                                         "luma scaler (what the reference's querystring path asks its decoder for), 1920x1080 intermediate"),
+                                                         "luma scaler (what the reference's querystring path asks its decoder for), as ONE call: "
+                                                         + ("component planes -> resampler, no BGRA bitmap in HBM" if fused4 else "two-step chain inside")),
             "file_to_800px_chain": roof(size + n * 800 * 450 * 4, t_cfg4, "compressed files in, 800x450 BGRA out")}}, indent=1))
 
 

@@ -19,6 +19,10 @@ from imageflow_amd.graphics.scaling import ScaleAndRenderParams, scale_and_rende
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    # --chain N: only the cfg4 chain (4/8 decode with the spatial sRGB luma scaler -> 800x450), N calls and nothing else --
+    # the command the counter passes profile; one_call = 0 runs the two-call form (BGRA bitmap in HBM) instead
+    chain_calls = int(sys.argv[sys.argv.index("--chain") + 1]) if "--chain" in sys.argv else 0
+    two_call = "--two-call" in sys.argv
     dev = "cuda:0"
     w, h = 3840, 2160
     res = {}
@@ -37,6 +41,18 @@ def main():
         out = Bitmap.create_u8(n, st.out_w, st.out_h, dev)
         small = Bitmap.create_u8(n, 800, 450, dev)
         info = ScaleAndRenderParams(0, 0, 800, 450)
+        if chain_calls:
+            if scale_num != 4:
+                continue
+            for _ in range(chain_calls):
+                if two_call:
+                    st.read_frames(coef, qt, out)
+                    scale_and_render(out, small, info)
+                else:
+                    st.read_frames_into(coef, qt, small, info)
+            torch.cuda.synchronize()
+            print(json.dumps({"chain_calls": chain_calls, "two_call": two_call, "frames": n}))
+            return
         for _ in range(3):
             st.read_frames(coef, qt, out)
             if (st.out_w, st.out_h) != (800, 450):

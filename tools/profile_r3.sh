@@ -1,0 +1,84 @@
+#!/bin/bash
+# Round-3 evidence run (on the GPU box through gpurun).  Raw output under gpurun_out/prof3, the summaries kept under
+# gpurun_out/prof3_summary (copied to profiles/r3_* afterwards).  Counter passes are separate runs with --kernel-trace only.
+set -u
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+OUT=gpurun_out/prof3
+SUM=gpurun_out/prof3_summary
+rm -rf $OUT $SUM; mkdir -p $OUT $SUM
+
+pmc_pass() {   # pmc_pass <tag> <kernel substring> <counters> -- cmd...
+  local tag=$1 ksub=$2 ctr=$3; shift 4
+  timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$tag -- "$@" > /dev/null 2> $OUT/pmc_$tag.err
+  local f=$(find $OUT/pmc_$tag -name '*counter_collection.csv' | head -1)
+  if [ -n "$f" ]; then
+    python - "$f" "$ksub" <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(lambda: [0.0, 0])
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r.get("Kernel_Name", "")
+    if sys.argv[2] not in k:
+        continue
+    key = (k.split("(")[0][-52:], r["Counter_Name"])
+    agg[key][0] += float(r["Counter_Value"]); agg[key][1] += 1
+for (k, name), (tot, n) in sorted(agg.items()):
+    print(f"{k:54s} {name:24s} per-dispatch avg {tot / max(n, 1):.6g}  (dispatches {n})")
+PY
+  else echo "($ctr): no counter csv: $(tail -1 $OUT/pmc_$tag.err)"; fi
+  rm -rf $OUT/pmc_$tag
+}
+
+# 1. headline: bench line, the same command under kernel-trace, HBM traffic + SQ counters
+python bench.py > $SUM/bench_cfg2.json 2> $SUM/bench_cfg2.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg2 -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-strong-field > $SUM/bench_cfg2_under_trace.json 2> $OUT/trace_cfg2.err
+find $OUT/trace_cfg2 -name '*kernel_stats.csv' -exec cp {} $SUM/cfg2_kernel_stats.csv \;
+{ echo "# rocprofv3 --pmc passes (one counter group per run), python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strong-field, kernel fused_resample"
+  for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
+    pmc_pass cfg2 fused_resample "$C" -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strong-field
+  done; } > $SUM/cfg2_pmc.txt
+
+# 2. cfg5 (BASELINE's HBM-roofline config) and cfg2 with alpha: bench line + kernel stats + counters
+for W in cfg5 cfg2-alpha; do
+  python bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline > $SUM/bench_$W.json 2> /dev/null
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- python bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2> $OUT/trace_$W.err
+  find $OUT/trace_$W -name '*kernel_stats.csv' -exec sh -c "head -1 {} > $SUM/${W}_kernel_stats.csv; grep fused_resample {} >> $SUM/${W}_kernel_stats.csv" \;
+  { echo "# rocprofv3 --pmc passes, python bench.py --workload $W --steps 6 --warmup 2 --no-cpu-baseline, kernel fused_resample"
+    for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
+      pmc_pass $W fused_resample "$C" -- python bench.py --workload $W --steps 6 --warmup 2 --no-cpu-baseline
+    done; } > $SUM/${W}_pmc.txt
+  rm -rf $OUT/trace_$W
+done
+
+# 3. the other resample shapes (kernel unchanged since round 2 apart from the gather addresses): bench line + kernel stats
+for W in cfg3-l0 cfg3-l1 cfg3-l2 cfg3-l3 cfg4-resize cfg1-resize up2-hermite up3-robidoux; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- python bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline > $SUM/bench_$W.json 2> $OUT/trace_$W.err
+  find $OUT/trace_$W -name '*kernel_stats.csv' -exec sh -c "head -1 {} > $SUM/${W}_kernel_stats.csv; grep -E 'fused_resample|generic' {} >> $SUM/${W}_kernel_stats.csv" \;
+  rm -rf $OUT/trace_$W
+done
+
+# 4. jobs: export_4_sizes, 1024-frame strong-scaling job on one GPU
+python bench.py --workload cfg3 --steps 50 --warmup 5 --no-cpu-baseline > $SUM/bench_cfg3_job.json 2>/dev/null
+python bench.py --scaling strong --total-frames 1024 --steps 30 --warmup 5 --no-cpu-baseline > $SUM/bench_strong_1024_1gpu.json 2>/dev/null
+
+# 5. JPEG: pixel stage (cfg4 chain as one call / two calls), per-kernel statistics, HBM traffic of the chain; entropy chain
+python tools/bench_jpeg.py 32 > $SUM/bench_jpeg.json 2> /dev/null
+tools/profile_jpeg_kernels.sh > /dev/null 2>&1; cp gpurun_out/jpeg_kernels/kernels.txt $SUM/bench_jpeg_kernels.txt
+{ echo "# cfg4 chain (32 frames 3840x2160 4:2:0 -> 4/8 decode, spatial sRGB luma -> 800x450), HBM traffic per chain call, summed over its kernels"
+  echo "# rocprofv3 --pmc <counter> --kernel-trace -- python tools/bench_jpeg.py 32 --chain 6 [--two-call]; FETCH_SIZE / WRITE_SIZE in KB per dispatch"
+  for MODE in "" "--two-call"; do
+    echo "## one call (planes -> resampler)${MODE:+ -- NO: two calls (BGRA bitmap in HBM)}"
+    for C in "FETCH_SIZE" "WRITE_SIZE"; do
+      pmc_pass chain "" "$C" -- python tools/bench_jpeg.py 32 --chain 6 $MODE
+    done
+  done; } > $SUM/cfg4_chain_traffic.txt
+python tools/bench_entropy.py 16 > $SUM/bench_entropy.json 2> /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_jpeg -- python tools/bench_entropy.py 16 > /dev/null 2> $OUT/trace_jpeg.err
+find $OUT/trace_jpeg -name '*kernel_stats.csv' -exec sh -c "head -9 {} > $SUM/jpeg_chain_kernel_stats.csv" \;
+{ echo "# rocprofv3 --pmc passes on the entropy stage, python tools/bench_entropy.py 1 (one file)"
+  for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"; do
+    pmc_pass ent "entropy_" "$C" -- python tools/bench_entropy.py 1
+  done; } > $SUM/entropy_pmc.txt
+tools/probes/issue_rate_probe > $SUM/issue_rate_probe.txt 2>&1
+rm -rf $OUT
+ls -la $SUM
