@@ -264,3 +264,38 @@ def test_decode_resample_rejects_a_plan_of_another_size():
     with pytest.raises(FlowError) as e:
         st.read_frames_into(coef, qt, out, ScaleAndRenderParams(0, 0, 40, 30), plan=plan_for(320, 240, 40, 30, Filter.Robidoux, 0.0, torch.device(DEV)))
     assert e.value.kind == ErrorKind.InvalidArgument
+
+
+@pytest.mark.parametrize("scale_num,luma_mode", [(8, 0), (4, 0), (4, 2), (2, 1)])
+def test_outputs_beyond_the_range_limit_tables_clamp_region(scale_num, luma_mode):
+    """IDCT outputs far outside [-384, 383]: libjpeg's range-limit table wraps there, so the block-per-lane kernels must
+    take the table form, not the clamp -- mixed in one batch with tame blocks so that both wave-uniform choices occur.
+    (Values stay below what overflows the 32-bit first pass: beyond that libjpeg's own 64-bit JLONG arithmetic and any
+    32-bit restatement part ways, and no 8-bit file gets there.)"""
+    rng = np.random.default_rng(77 + scale_num + luma_mode)
+    for hs, vs in (((2, 1, 1), (2, 1, 1)), ((1, 1, 1), (1, 1, 1))):
+        j = _random_case(rng, 200, 120, hs, vs, 3, 30)
+        j["qt"] = np.ones((3, 64), np.uint16)
+        for c in range(3):
+            co = j["coef"][c]
+            wild = rng.random(size=co.shape[:2]) < 0.3                     # 30 % of the blocks
+            big = np.zeros(co.shape, np.int16)
+            big[..., 0] = rng.integers(1500, 3000, size=co.shape[:2]) * rng.choice([-1, 1], size=co.shape[:2])
+            for k in (1, 8, 9):
+                big[..., k] = rng.integers(-1200, 1201, size=co.shape[:2])
+            co[wild] = big[wild]
+        got = run_stage_scaled([j, j], scale_num, luma_mode) if scale_num != 8 else run_stage([j, j])
+        exp = O.jpeg_idct_color_scaled(j, scale_num, luma_mode) if scale_num != 8 else O.jpeg_idct_color(j)
+        assert np.array_equal(got[0], exp) and np.array_equal(got[1], exp), (hs, scale_num, luma_mode)
+
+
+def test_decode_resample_one_call_wide_source_strips_and_blend_with_self():
+    """A source wider than one workgroup's strip (two column strips, XCD renumbering) and BlendWithSelf onto a canvas that
+    already holds pixels, sRGB working space excluded: same bytes as the two calls."""
+    rng = np.random.default_rng(12)
+    j = _random_case(rng, 5000, 304, (1, 1, 1), (1, 1, 1), 3, 120)
+    one, two, fused, _ = _decode_resample_case(j, 3, 8, 0, 700, 43, compose="BlendWithSelf")
+    assert fused and np.array_equal(one, two)
+    j = _random_case(rng, 4096, 2048, (2, 1, 1), (2, 1, 1), 3, 80)                    # 4/8 -> 2048x1024 -> 333x167: bands
+    one, two, fused, _ = _decode_resample_case(j, 5, 4, 1, 333, 167)
+    assert fused and np.array_equal(one, two)
