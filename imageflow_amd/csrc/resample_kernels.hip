@@ -36,27 +36,35 @@ vpass_generic_kernel(const ResampleArgs a, float4* scratch, uint32_t img0) {
     scratch[(static_cast<size_t>(blockIdx.z) * a.out_h + j) * a.in_w + xcol] = make_float4(s0, s1, s2, ALPHA ? s3 : 1.0f);
 }
 
+constexpr uint32_t kHpassRows = 16;      // output rows per workgroup of the generic horizontal pass (amortises its table fill)
 template <bool ALPHA>
 __global__ void __launch_bounds__(256)
 hpass_generic_kernel(const ResampleArgs a, const float4* scratch, uint32_t img0) {
+    // The output stage's encode table in LDS: its three dependent lookups per pixel in global memory were most of this
+    // kernel's time.  One fill (16 KiB) serves 256 columns x kHpassRows rows.
+    __shared__ __attribute__((aligned(16))) uint8_t l2s_lds[16384];
+    for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x) reinterpret_cast<uint4*>(l2s_lds)[i] = reinterpret_cast<const uint4*>(a.l2s)[i];
+    __syncthreads();
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t j = blockIdx.y;
     const uint32_t img = img0 + blockIdx.z;
     if (u >= a.out_w) return;
-    const float4* row = scratch + (static_cast<size_t>(blockIdx.z) * a.out_h + j) * a.in_w;
     const uint32_t left = a.h_left[u], n = a.h_count[u];
     const float* w = a.h_w + a.h_off[u];
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (uint32_t k = 0; k < n; ++k) {
-        const float4 v = row[left + k];
-        const float wk = w[k];
-        s0 = __builtin_fmaf(wk, v.x, s0);
-        s1 = __builtin_fmaf(wk, v.y, s1);
-        s2 = __builtin_fmaf(wk, v.z, s2);
-        if (ALPHA) s3 = __builtin_fmaf(wk, v.w, s3);
+    const OutTables<const float*, const uint8_t*> tb{a.lut_in, l2s_lds};
+    const uint32_t j_end = min((blockIdx.y + 1u) * kHpassRows, a.out_h);
+    for (uint32_t j = blockIdx.y * kHpassRows; j < j_end; ++j) {
+        const float4* row = scratch + (static_cast<size_t>(blockIdx.z) * a.out_h + j) * a.in_w;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (uint32_t k = 0; k < n; ++k) {
+            const float4 v = row[left + k];
+            const float wk = w[k];
+            s0 = __builtin_fmaf(wk, v.x, s0);
+            s1 = __builtin_fmaf(wk, v.y, s1);
+            s2 = __builtin_fmaf(wk, v.z, s2);
+            if (ALPHA) s3 = __builtin_fmaf(wk, v.w, s3);
+        }
+        store_pixel<ALPHA>(a, img, j, u, s0, s1, s2, ALPHA ? s3 : 1.0f, tb);
     }
-    const OutTables<const float*, const uint8_t*> tb{a.lut_in, a.l2s};
-    store_pixel<ALPHA>(a, img, j, u, s0, s1, s2, ALPHA ? s3 : 1.0f, tb);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -153,7 +161,7 @@ hipError_t launch_fused(const ResampleArgs& a, int slots, bool alpha, bool per_p
 hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, uint32_t img0, uint32_t n_img,
                           hipStream_t st) {
     const dim3 bv(256), gv((a.in_w + 255u) / 256u, a.out_h, n_img);
-    const dim3 bh(256), gh((a.out_w + 255u) / 256u, a.out_h, n_img);
+    const dim3 bh(256), gh((a.out_w + 255u) / 256u, (a.out_h + kHpassRows - 1u) / kHpassRows, n_img);
     if (alpha) {
         hipLaunchKernelGGL((vpass_generic_kernel<true>), gv, bv, 0, st, a, scratch, img0);
         hipLaunchKernelGGL((hpass_generic_kernel<true>), gh, bh, 0, st, a, scratch, img0);
