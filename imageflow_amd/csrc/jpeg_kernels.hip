@@ -475,13 +475,26 @@ __device__ __forceinline__ void wave_sync_lds() {       // lanes of ONE wave han
 // instructions per lane, i.e. 1 500 of 2 000 per block) is paid once per block instead of eight times.  A wave reads 64
 // consecutive blocks = 8 KiB (every line is consumed by the lane's eight 16-byte loads) and stores 512 contiguous bytes
 // per output row.  Same integer arithmetic as jpeg_idct_kernel (which keeps the rarer sizes 1, 2, 3, 5, 6, 10, 12).
+// flow_scale_spatial weights as compile-time data (the same rows block_scalers.cpp serves to the host and, through
+// JpegScalerTab, to the eight-lanes kernel): with the block size N a template parameter every multiply by a zero weight --
+// 18 of the 32 weights at N = 4 -- disappears, the others become literals.
+struct ScalerRowC { int n, r, log2_div; int w[8]; };
+__device__ constexpr ScalerRowC kScalerRowsC[] = {
+#include "block_scaler_weights.inc"
+};
+constexpr int scaler_row_index(int n, int r) {
+    for (int i = 0; i < static_cast<int>(sizeof(kScalerRowsC) / sizeof(kScalerRowsC[0])); ++i)
+        if (kScalerRowsC[i].n == n && kScalerRowsC[i].r == r) return i;
+    return 0;
+}
+
 __device__ __forceinline__ uint32_t range_limit_fast(int32_t v) {    // == range_limit(v) for v in [-384, 383]
     const int32_t x = v + 128;
     return static_cast<uint32_t>(x < 0 ? 0 : (x > 255 ? 255 : x));        // (v_med3_i32)
 }
 
 typedef uint4_nt (*BplStage)[64 * 9];
-template <int MODE>
+template <int MODE, int N>
 __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t c, uint32_t img, uint32_t wg, BplStage stage,
                                                     const uint16_t* s2l_lds, const uint8_t* l2s_lds) {
     const uint32_t t = threadIdx.x;
@@ -599,7 +612,7 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
             // r, then columns with those of output column cc, rounded by the two divisors' shift; the _srgb forms work in
             // 12-bit linear light through two lookup tables.  |weight| <= 117, linear <= 4095, sums of weights <= 512:
             // every product fits 24 x 24 -> 32 bits.
-            const uint32_t n = a.g.idct_n[0];
+            constexpr uint32_t n = N;                           // == a.g.idct_n[0] (the launcher picks the instantiation)
             int32_t (&lin)[8][8] = px;                          // in place again: sample -> 12-bit linear light (or itself)
             if (srgb) {
 #pragma unroll
@@ -607,26 +620,27 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
 #pragma unroll
                     for (int j = 0; j < 8; ++j) lin[i][j] = static_cast<int32_t>(s2l_lds[px[i][j]]);
             }
+            constexpr int base = scaler_row_index(N, 0);        // the N rows of size N are consecutive in the table
 #pragma unroll
-            for (uint32_t r = 0; r < 7u; ++r) {
-                if (r >= n) break;                              // wave-uniform
+            for (uint32_t r = 0; r < n; ++r) {
                 int32_t V[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     int32_t acc = 0;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) acc += __mul24(a.sc.w[r][i], lin[i][j]);
+                    for (int i = 0; i < 8; ++i)
+                        if (kScalerRowsC[base + r].w[i] != 0) acc += __mul24(kScalerRowsC[base + r].w[i], lin[i][j]);
                     V[j] = acc;
                 }
                 uint32_t packed = 0;
                 uint8_t* orow = plane + static_cast<size_t>(by * n + r) * a.g.pw[c] + bx * n;
 #pragma unroll
-                for (uint32_t cc = 0; cc < 7u; ++cc) {
-                    if (cc >= n) break;
-                    const uint32_t sh = a.sc.log2_div[r] + a.sc.log2_div[cc];
+                for (uint32_t cc = 0; cc < n; ++cc) {
+                    const uint32_t sh = static_cast<uint32_t>(kScalerRowsC[base + r].log2_div + kScalerRowsC[base + cc].log2_div);
                     int32_t sum = static_cast<int32_t>(1u << (sh - 1u));
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) sum += __mul24(V[j], a.sc.w[cc][j]);
+                    for (int j = 0; j < 8; ++j)
+                        if (kScalerRowsC[base + cc].w[j] != 0) sum += __mul24(V[j], kScalerRowsC[base + cc].w[j]);
                     uint32_t ob;
                     if (sum < 0) ob = 0;
                     else if (static_cast<uint32_t>(sum) >= (4096u << sh)) ob = 255;
@@ -653,14 +667,14 @@ __device__ __forceinline__ void bpl_tables(const JpegArgs& a, bool needed, uint1
     __syncthreads();
 }
 
-template <int MODE>
+template <int MODE, int N = 1>       // N: block size of the spatial scaler (MODE 2)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))                   // 4 waves per SIMD: <= 128 registers
 jpeg_idct_block_per_lane_kernel(const JpegArgs a) {
     __shared__ __attribute__((aligned(16))) uint4_nt stage[4][64 * 9];
     __shared__ uint16_t s2l_lds[MODE == 2 ? 256 : 1];
     __shared__ __attribute__((aligned(16))) uint8_t l2s_lds[MODE == 2 ? 4096 : 16];
     if (MODE == 2) bpl_tables(a, a.g.luma_mode == 2u, s2l_lds, l2s_lds);
-    idct_block_per_lane<MODE>(a, a.comp + blockIdx.z, blockIdx.y, blockIdx.x, stage, s2l_lds, l2s_lds);
+    idct_block_per_lane<MODE, N>(a, a.comp + blockIdx.z, blockIdx.y, blockIdx.x, stage, s2l_lds, l2s_lds);
 }
 
 // ---- up-sample + colour ------------------------------------------------------------------------------------------
@@ -1141,7 +1155,17 @@ static int launch_idct_planes(JpegArgs a, int first_component, hipStream_t st) {
         const dim3 bgrid((nblk + 255u) / 256u, a.n_images, both ? 2u : 1u);
         if (bpl == 0) hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<0>), bgrid, dim3(256), 0, st, a);
         else if (bpl == 1) hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<1>), bgrid, dim3(256), 0, st, a);
-        else if (bpl == 2) hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2>), bgrid, dim3(256), 0, st, a);
+        else if (bpl == 2) {
+            switch (g.idct_n[0]) {                              // the scaler's weights are compile-time data of each instantiation
+            case 1: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 1>), bgrid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 2>), bgrid, dim3(256), 0, st, a); break;
+            case 3: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 3>), bgrid, dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 4>), bgrid, dim3(256), 0, st, a); break;
+            case 5: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 5>), bgrid, dim3(256), 0, st, a); break;
+            case 6: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 6>), bgrid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 7>), bgrid, dim3(256), 0, st, a); break;
+            }
+        }
         else hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nblk + kBlocksPerWg - 1) / kBlocksPerWg, a.n_images, both ? 2u : 1u), dim3(256), 0, st, a);
         HIP_TRY(hipGetLastError());
         if (both) ++c;
