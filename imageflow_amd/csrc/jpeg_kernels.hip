@@ -493,6 +493,9 @@ __device__ __forceinline__ uint32_t range_limit_fast(int32_t v) {    // == range
     return static_cast<uint32_t>(x < 0 ? 0 : (x > 255 ? 255 : x));        // (v_med3_i32)
 }
 
+// lanes per workgroup: with the scaler's tables 8 waves (2 workgroups x 78 KiB of LDS = 4 waves per SIMD; 4-wave workgroups of
+// 41.5 KiB fit only three times), the plain routines 4 waves (4 x 37 KiB)
+constexpr uint32_t bpl_threads(int mode) { return mode == 2 ? 512u : 256u; }
 typedef uint4_nt (*BplStage)[64 * 9];
 template <int MODE, int N>
 __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t c, uint32_t img, uint32_t wg, BplStage stage,
@@ -500,13 +503,13 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
     const uint32_t t = threadIdx.x;
     const bool srgb = MODE == 2 && a.g.luma_mode == 2u;
     const uint32_t nblk = a.g.bw[c] * a.g.bh[c];
-    const uint32_t bidx = wg * 256u + t;
+    const uint32_t bidx = wg * bpl_threads(MODE) + t;
     // A wave's 64 blocks are 8 KiB of consecutive coefficients: read them with 8 fully coalesced 16-byte loads per lane and
     // hand each lane its own block through LDS (block pitch 9 x 16 B: the 16-byte row reads of neighbouring lanes fall 4
     // banks apart).  Lanes reading their blocks straight from global memory -- 16 bytes of 64 different cache lines per
     // instruction -- made this kernel 1.6x slower than the eight-lanes form it replaces (profiles/r3_jpeg_kernels_*.txt).
     const uint32_t wv = t >> 6, ln = t & 63u;
-    const uint32_t wave_block0 = wg * 256u + wv * 64u;
+    const uint32_t wave_block0 = wg * bpl_threads(MODE) + wv * 64u;
     if (wave_block0 >= nblk) return;                           // (whole wave: nothing below is a workgroup barrier)
     const uint32_t wave_vecs = min(64u, nblk - wave_block0) * 8u;    // 16-byte rows this wave owns
     const uint4_nt* wsrc = reinterpret_cast<const uint4_nt*>(a.coef[c] + (static_cast<size_t>(img) * nblk + wave_block0) * 64u);
@@ -526,7 +529,7 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
     // the luma scalers' islow runs with the FIRST component's table, as jpeg_idct_islow(cinfo, compptr, ...) does
     const uint32_t* q32 = reinterpret_cast<const uint32_t*>(a.qt + (static_cast<size_t>(img) * a.g.ncomp + c) * 64u);   // wave-uniform: scalar loads
     int32_t ws[8][8];
-    uint32_t mag = 0;
+    int32_t dmax = 0, dmin = 0;                                 // extremes of the de-quantised coefficients (v_max3 / v_min3: one pair each)
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         if (MODE == 1 && r == 4) {                              // jpeg_idct_4x4 never reads coefficient row 4
@@ -542,10 +545,11 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
             const int32_t d0 = __mul24(static_cast<int32_t>(static_cast<int16_t>(cw[k] & 0xffffu)), static_cast<int32_t>(qq & 0xffffu));   // 16-bit operands: exact
             const int32_t d1 = __mul24(static_cast<int32_t>(static_cast<int16_t>(cw[k] >> 16)), static_cast<int32_t>(qq >> 16));
             ws[r][2 * k] = d0; ws[r][2 * k + 1] = d1;
-            mag |= static_cast<uint32_t>(d0 < 0 ? -d0 : d0) | static_cast<uint32_t>(d1 < 0 ? -d1 : d1);
+            dmax = max(dmax, max(d0, d1));
+            dmin = min(dmin, min(d0, d1));
         }
     }
-    const bool small = __all(mag < (1u << 21)) != 0;           // 24-bit multiplies in the first pass (see mulc)
+    const bool small = __all(dmax < (1 << 21) && dmin > -(1 << 21)) != 0;      // 24-bit multiplies in the first pass (see mulc)
     uint8_t* plane = a.plane[c] + static_cast<size_t>(img) * a.g.pw[c] * a.g.ph[c];
     const uint32_t by = bidx / a.g.bw[c], bx = bidx - by * a.g.bw[c];
 
@@ -583,22 +587,30 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
         // row pass (CONST_BITS + PASS1_BITS + 3: always in 24-bit range) + libjpeg's range-limit table.  The table wraps
         // beyond [-384, 383]; inside, it is a clamp of v + 128 -- a wave whose 64 blocks all stay inside takes the clamp.
         int32_t (&px)[8][8] = ws;                               // in place: a row's eight inputs are consumed before its outputs land
-        int32_t lo = 0, hi = 0;
+        int32_t lo = 128, hi = 128;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             int32_t in[8], out[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) in[k] = ws[r][k];
-            idct8<true>(in, out, 18);
+            in[0] += 4096;                                      // the table's + 128, once per row: (4096 << 13) = 128 << 18 goes through
+            idct8<true>(in, out, 18);                           // the even part into every output, and descale(x + 128 * 2^18, 18) = descale(x, 18) + 128
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { px[r][k] = out[k]; lo = out[k] < lo ? out[k] : lo; hi = out[k] > hi ? out[k] : hi; }
+            for (int k = 0; k < 8; k += 2) {
+                px[r][k] = out[k]; px[r][k + 1] = out[k + 1];
+                lo = min(lo, min(out[k], out[k + 1]));
+                hi = max(hi, max(out[k], out[k + 1]));
+            }
         }
-        const bool tame = __all(lo >= -384 && hi <= 383) != 0;
-        // range-limited samples, in place (0 .. 255)
+        const bool tame = __all(lo >= -384 + 128 && hi <= 383 + 128) != 0;
+        // range-limited samples, in place (0 .. 255); px holds v + 128 here
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) px[r][k] = static_cast<int32_t>(tame ? range_limit_fast(px[r][k]) : range_limit(px[r][k]));
+            for (int k = 0; k < 8; ++k) {
+                const int32_t x = px[r][k];
+                px[r][k] = tame ? (x < 0 ? 0 : (x > 255 ? 255 : x)) : static_cast<int32_t>(range_limit(x - 128));
+            }
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -660,7 +672,7 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
 // workgroups interleaved -- traffic-bound plain IDCTs beside the arithmetic-bound spatial scalers -- was measured: 410 us
 // against 254 + 110 us for the 4/8 decode of 32 4K frames; every workgroup then carries the larger routine's registers.)
 __device__ __forceinline__ void bpl_tables(const JpegArgs& a, bool needed, uint16_t* s2l_lds, uint8_t* l2s_lds) {
-    if (needed) {
+    if (needed && threadIdx.x < 256u) {
         s2l_lds[threadIdx.x] = a.sc.s2l[threadIdx.x];
         reinterpret_cast<uint4*>(l2s_lds)[threadIdx.x] = reinterpret_cast<const uint4*>(a.sc.l2s)[threadIdx.x];
     }
@@ -668,9 +680,9 @@ __device__ __forceinline__ void bpl_tables(const JpegArgs& a, bool needed, uint1
 }
 
 template <int MODE, int N = 1>       // N: block size of the spatial scaler (MODE 2)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))                   // 4 waves per SIMD: <= 128 registers
+__global__ void __launch_bounds__(bpl_threads(MODE)) __attribute__((amdgpu_waves_per_eu(4, 4)))     // 4 waves per SIMD: <= 128 registers
 jpeg_idct_block_per_lane_kernel(const JpegArgs a) {
-    __shared__ __attribute__((aligned(16))) uint4_nt stage[4][64 * 9];
+    __shared__ __attribute__((aligned(16))) uint4_nt stage[bpl_threads(MODE) / 64][64 * 9];
     __shared__ uint16_t s2l_lds[MODE == 2 ? 256 : 1];
     __shared__ __attribute__((aligned(16))) uint8_t l2s_lds[MODE == 2 ? 4096 : 16];
     if (MODE == 2) bpl_tables(a, a.g.luma_mode == 2u, s2l_lds, l2s_lds);
@@ -1152,18 +1164,19 @@ static int launch_idct_planes(JpegArgs a, int first_component, hipStream_t st) {
         const bool both = c == 1 && g.ncomp == 3 && g.bw[1] == g.bw[2] && g.bh[1] == g.bh[2] && g.idct_n[1] == g.idct_n[2];
         // the common block routines run one lane per block; the rarer sizes keep the eight-lanes-per-block kernel
         const int bpl = bpl_mode(g, c);
-        const dim3 bgrid((nblk + 255u) / 256u, a.n_images, both ? 2u : 1u);
-        if (bpl == 0) hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<0>), bgrid, dim3(256), 0, st, a);
-        else if (bpl == 1) hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<1>), bgrid, dim3(256), 0, st, a);
+        const uint32_t bt = bpl_threads(bpl);
+        const dim3 bgrid((nblk + bt - 1u) / bt, a.n_images, both ? 2u : 1u);
+        if (bpl == 0) hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<0>), bgrid, dim3(bt), 0, st, a);
+        else if (bpl == 1) hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<1>), bgrid, dim3(bt), 0, st, a);
         else if (bpl == 2) {
             switch (g.idct_n[0]) {                              // the scaler's weights are compile-time data of each instantiation
-            case 1: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 1>), bgrid, dim3(256), 0, st, a); break;
-            case 2: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 2>), bgrid, dim3(256), 0, st, a); break;
-            case 3: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 3>), bgrid, dim3(256), 0, st, a); break;
-            case 4: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 4>), bgrid, dim3(256), 0, st, a); break;
-            case 5: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 5>), bgrid, dim3(256), 0, st, a); break;
-            case 6: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 6>), bgrid, dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 7>), bgrid, dim3(256), 0, st, a); break;
+            case 1: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 1>), bgrid, dim3(bt), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 2>), bgrid, dim3(bt), 0, st, a); break;
+            case 3: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 3>), bgrid, dim3(bt), 0, st, a); break;
+            case 4: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 4>), bgrid, dim3(bt), 0, st, a); break;
+            case 5: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 5>), bgrid, dim3(bt), 0, st, a); break;
+            case 6: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 6>), bgrid, dim3(bt), 0, st, a); break;
+            default: hipLaunchKernelGGL((jpeg_idct_block_per_lane_kernel<2, 7>), bgrid, dim3(bt), 0, st, a); break;
             }
         }
         else hipLaunchKernelGGL(jpeg_idct_kernel, dim3((nblk + kBlocksPerWg - 1) / kBlocksPerWg, a.n_images, both ? 2u : 1u), dim3(256), 0, st, a);
