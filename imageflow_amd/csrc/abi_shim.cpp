@@ -314,6 +314,11 @@ struct Io {
     std::vector<uint8_t> owned;                  // copied inputs (lifetime_outlives_function_call) / output bytes
     bool written = false;
     OutState out_state = OutState::Ready;
+    // v1/tell_decoder {jpeg_downscale_hints} (Context::tell_decoder -> MzDec::tell_decoder, mozjpeg_decoder.rs:560-586): kept
+    // with the input until its decoder runs; a decode node's own `commands` are told after these and win
+    bool told = false;
+    uint32_t told_w = 0, told_h = 0;
+    bool told_spatial = false, told_gamma = false;
 };
 struct Response {
     int64_t status;
@@ -364,7 +369,7 @@ const imageflow_json_response* respond_error(imageflow_context* c, int cat, cons
     c->set_error(cat, msg);                                      // imageflow_abi/src/lib.rs:1001-1008
     const int code = http_code(cat);                             // JsonResponse::fail_with_message, json/mod.rs:170-181
     return respond(c, code, "{\n  \"code\": " + std::to_string(code) + ",\n  \"success\": false,\n  \"message\": \"" +
-                                json_escape(msg) + "\",\n  \"data\": {\n    \"none\": null\n  }\n}");
+                                json_escape(msg) + "\",\n  \"data\": {}\n}");                 // TellDecoderV1Response {} (v1.rs:177)
 }
 
 // ---- sizing: AspectRatio::proportional (imageflow_riapi/src/sizing.rs:118-185) ------------------------------------
@@ -1016,6 +1021,10 @@ struct Job {
         if (name == "decode") {
             uint32_t hw = 0, hh = 0;
             bool spatial = false, gamma = false;
+            {
+                const Io& told = input(static_cast<int32_t>(want_int(p, "io_id", "decode")));
+                if (told.told) { hw = told.told_w; hh = told.told_h; spatial = told.told_spatial; gamma = told.told_gamma; }
+            }
             if (const JVal* cmds = p.get("commands"))
                 if (cmds->t == JVal::Arr)
                     for (const JVal& cmd : cmds->a)
@@ -1422,7 +1431,8 @@ const struct imageflow_json_response* imageflow_context_send_json(struct imagefl
             return respond(c, 200, std::string("{\n  \"code\": 200,\n  \"success\": true,\n  \"message\": \"OK\",\n  \"data\": {\n    \"version_info\": {\"long_version_string\": \"") +
                                        ifhip_version() + " (libimageflow ABI subset " + std::to_string(IMAGEFLOW_ABI_VER_MAJOR) + "." + std::to_string(IMAGEFLOW_ABI_VER_MINOR) + ")\"}\n  }\n}");
         const bool build = m == "v1/build" || m == "v0.1/build", execute = m == "v1/execute" || m == "v0.1/execute";
-        if (!build && !execute && m != "v1/get_image_info" && m != "v0.1/get_image_info") {
+        const bool tell = m == "v1/tell_decoder" || m == "v0.1/tell_decoder", scaled_info = m == "v1/get_scaled_image_info";
+        if (!build && !execute && !tell && !scaled_info && m != "v1/get_image_info" && m != "v0.1/get_image_info") {
             c->set_error(kArgumentInvalid, "InvalidMessageEndpoint: " + m);
             return respond(c, 404, "{\n  \"success\": \"false\",\n  \"code\": 404,\n  \"message\": \"Endpoint name not understood\"}");   // json/mod.rs:158-168
         }
@@ -1431,13 +1441,37 @@ const struct imageflow_json_response* imageflow_context_send_json(struct imagefl
         if (root.t != JVal::Obj) raise(kInvalidJson, "InvalidJson: the message must be an object");
         Job job{c};
         job.poll_cancel();
-        if (!build && !execute) {                                    // get_image_info {io_id}: header facts only
+        if (tell) {                                                  // v1/tell_decoder {io_id, command} (json/endpoints/v1.rs:365-371)
+            Io& in = job.input(static_cast<int32_t>(want_int(root, "io_id", "tell_decoder")));
+            const JVal* cmd = root.get("command");
+            if (!cmd) raise(kInvalidJson, "InvalidJson: tell_decoder needs a command");
+            if (cmd->t == JVal::Obj && cmd->get("jpeg_downscale_hints")) {           // s::DecoderCommand::JpegDownscaleHints
+                const JVal& j = *cmd->get("jpeg_downscale_hints");
+                in.told = true;
+                in.told_w = want_u32(j, "width", "jpeg_downscale_hints"); in.told_h = want_u32(j, "height", "jpeg_downscale_hints");
+                const JVal* b = j.get("scale_luma_spatially");
+                in.told_spatial = b && b->t == JVal::Bool && b->b;
+                b = j.get("gamma_correct_for_srgb_during_spatial_luma_scaling");
+                in.told_gamma = b && b->t == JVal::Bool && b->b;
+            } else if (!(cmd->t == JVal::Str && (cmd->s == "discard_color_profile" || cmd->s == "ignore_color_profile_errors")) &&
+                       !(cmd->t == JVal::Obj && cmd->get("webp_decoder_hints"))) {   // colour profiles / WebP: nothing here acts on them
+                raise(kInvalidJson, "InvalidJson: unknown decoder command");
+            }
+            return respond(c, 200, "{\n  \"code\": 200,\n  \"success\": true,\n  \"message\": \"OK\",\n  \"data\": {}\n}");                 // TellDecoderV1Response {} (v1.rs:177)
+        }
+        if (!build && !execute) {                                    // get_image_info / get_scaled_image_info {io_id}: header facts only
             Io& in = job.input(static_cast<int32_t>(want_int(root, "io_id", "get_image_info")));
             uint32_t w = 0, h = 0, bw[3], bh[3], ri = 0;
             int nc = 0;
             uint8_t hs[3], vs[3];
             uint16_t qt[192];
             check(ifhip_jpeg_parse_headers(in.in, in.in_len, &w, &h, &nc, hs, vs, bw, bh, qt, &ri));
+            if (scaled_info && in.told && in.told_w > 0 && in.told_h > 0)             // MzDec::apply_downscaling on the told hints (:588-618)
+                for (uint32_t i = 1; i < 8; ++i) {
+                    if (i == 7) continue;
+                    const uint32_t sw = static_cast<uint32_t>((static_cast<uint64_t>(w) * i + 7) / 8), sh = static_cast<uint32_t>((static_cast<uint64_t>(h) * i + 7) / 8);
+                    if (sw >= in.told_w && sh >= in.told_h) { w = sw; h = sh; break; }
+                }
             return respond(c, 200, "{\n  \"code\": 200,\n  \"success\": true,\n  \"message\": \"OK\",\n  \"data\": {\n    \"image_info\": {\"preferred_mime_type\": \"image/jpeg\", "
                                    "\"preferred_extension\": \"jpg\", \"image_width\": " + std::to_string(w) + ", \"image_height\": " + std::to_string(h) +
                                    ", \"frame_decodes_into\": \"bgr_32\"}\n  }\n}");

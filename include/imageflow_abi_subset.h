@@ -5,6 +5,9 @@
  * reference: imageflow_abi/src/lib.rs (line numbers per function below), ABI version imageflow_abi/src/abi_version.rs:4,7.
  * "Subset" is what a JOB may contain, not the function list.
  *
+ * Endpoints of imageflow_context_send_json: v1/build, v1/execute, v1/get_image_info, v1/tell_decoder (+ v0.1/ aliases),
+ * v1/get_scaled_image_info, v1/get_version_info; everything else answers 404 as json/mod.rs:158-168.
+ *
  * What a job may contain (anything else answers ActionNotSupported, HTTP 400): decode (baseline JPEG, or the raw
  * BGRA container EXTENSION), create_canvas, fill_rect, expand_canvas, crop, flip_h/flip_v, transpose, rotate_90/180/270,
  * apply_orientation, color_matrix_srgb, color_filter_srgb, resample_2d, draw_image_exact and copy_rect_to_canvas (graph

@@ -248,3 +248,36 @@ def test_frame_size_limits_are_the_reference_defaults():
             {"create_canvas": {"w": 2 ** 31 - 1, "h": 4, "format": "bgra_32", "color": "transparent"}}]}})
         assert status == 400
     assert abi._bind().ifhip_stride_for_width(2 ** 30) == 0 and abi._bind().ifhip_stride_for_width(200) == 832
+
+
+def test_tell_decoder_and_get_scaled_image_info():
+    """json/endpoints/v1.rs:347-371: v1/tell_decoder stores the jpeg_downscale_hints with the input's decoder,
+    v1/get_scaled_image_info answers with the size MzDec::apply_downscaling (mozjpeg_decoder.rs:588-618) would decode at --
+    header parsing only, no GPU."""
+    import numpy as np
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "jpeg_entropy_cases.npz"))
+    data = z["jpg_0"].tobytes()
+    with Context() as c:
+        c.add_input_buffer(0, data)
+        status, r = c.send_json("v1/get_image_info", {"io_id": 0})
+        assert status == 200
+        w, h = r["data"]["image_info"]["image_width"], r["data"]["image_info"]["image_height"]
+        status, r = c.send_json("v1/get_scaled_image_info", {"io_id": 0})                  # nothing told yet: the full size
+        assert status == 200 and (r["data"]["image_info"]["image_width"], r["data"]["image_info"]["image_height"]) == (w, h)
+        hints = {"width": max(1, w // 3), "height": max(1, h // 3), "scale_luma_spatially": True,
+                 "gamma_correct_for_srgb_during_spatial_luma_scaling": True}
+        status, r = c.send_json("v1/tell_decoder", {"io_id": 0, "command": {"jpeg_downscale_hints": hints}})
+        assert status == 200 and r["success"] is True and r["data"] == {}
+        status, r = c.send_json("v1/get_scaled_image_info", {"io_id": 0})
+        sw, sh = r["data"]["image_info"]["image_width"], r["data"]["image_info"]["image_height"]
+        exp = next(((-(-w * i // 8), -(-h * i // 8)) for i in (1, 2, 3, 4, 5, 6) if -(-w * i // 8) >= hints["width"] and -(-h * i // 8) >= hints["height"]),
+                   (w, h))
+        assert status == 200 and (sw, sh) == exp and (sw, sh) != (w, h)
+        status, r = c.send_json("v0.1/tell_decoder", {"io_id": 0, "command": "discard_color_profile"})     # accepted, nothing to act on
+        assert status == 200 and not c.has_error()
+        status, r = c.send_json("v1/tell_decoder", {"io_id": 0, "command": {"make_coffee": {}}})
+        assert status == 400 and c.error_code() == 3
+    with Context() as c:
+        status, r = c.send_json("v1/tell_decoder", {"io_id": 5, "command": "discard_color_profile"})        # no such input
+        assert status == 400 and c.has_error()

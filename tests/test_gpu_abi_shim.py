@@ -536,3 +536,26 @@ def test_matte_applying_encode_does_not_touch_a_frame_other_nodes_still_read():
         rows, w, h, alpha = unpack_raw_bgra(c.get_output_buffer(2))
         assert alpha and np.array_equal(rows[:, :4 * w], src[:, :4 * w])
         assert c.get_output_buffer(1)[:2] == b"\xff\xd8"
+
+
+def test_tell_decoder_hints_apply_to_a_later_job():
+    """v1/tell_decoder before v1/execute (the reference's two-call pattern, json/endpoints/v1.rs:365-371): the decoder runs
+    at the told size with the told luma scaler, exactly as if the decode node carried the command itself."""
+    data = _jpeg(1280, 720)
+    hints = {"width": 600, "height": 330, "scale_luma_spatially": True, "gamma_correct_for_srgb_during_spatial_luma_scaling": True}
+    steps_plain = [{"decode": {"io_id": 0}}, {"resample_2d": {"w": 320, "h": 180}}, {"encode": {"io_id": 1, "preset": "gif"}}]
+    steps_cmd = [{"decode": {"io_id": 0, "commands": [{"jpeg_downscale_hints": hints}]}}] + steps_plain[1:]
+    outs = []
+    for told, steps in ((True, steps_plain), (False, steps_cmd), (False, steps_plain)):
+        with Context() as c:
+            c.add_input_buffer(0, data)
+            c.add_output_buffer(1)
+            if told:
+                status, _ = c.send_json("v1/tell_decoder", {"io_id": 0, "command": {"jpeg_downscale_hints": hints}})
+                assert status == 200
+            _run(c, "v1/execute", {"framewise": {"steps": steps}})
+            outs.append(unpack_raw_bgra(c.get_output_buffer(1))[0])
+    assert np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2])
+    j = O.jpeg_read_coefficients(data)
+    small = O.jpeg_idct_color_scaled(j, 4, 2)                                          # 640x360 covers 600x330
+    assert np.array_equal(outs[0], _oracle_resize(small, 640, 360, 320, 180, filter_id=2))
