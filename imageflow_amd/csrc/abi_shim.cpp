@@ -316,6 +316,7 @@ struct Io {
     OutState out_state = OutState::Ready;
     // v1/tell_decoder {jpeg_downscale_hints} (Context::tell_decoder -> MzDec::tell_decoder, mozjpeg_decoder.rs:560-586): kept
     // with the input until its decoder runs; a decode node's own `commands` are told after these and win
+    bool out_base64 = false;                     // IoEnum::OutputBase64: the job result carries the bytes as {"base_64": ...}
     bool told = false;
     uint32_t told_w = 0, told_h = 0;
     bool told_spatial = false, told_gamma = false;
@@ -1201,7 +1202,18 @@ void add_io_from_json(imageflow_context* c, const JVal& ios) {
         if (c->io.count(id)) raise(kArgumentInvalid, "InvalidArgument: io_id %d is already in use", id);
         Io e;
         e.is_output = out;
-        if (io->t == JVal::Str && io->s == "output_buffer") { if (!out) raise(kInvalidJson, "InvalidJson: output_buffer on an input"); }
+        if (io->t == JVal::Str && (io->s == "output_buffer" || io->s == "output_base_64")) {
+            if (!out) raise(kInvalidJson, "InvalidJson: %s on an input", io->s.c_str());
+            e.out_base64 = io->s == "output_base_64";
+        } else if (const JVal* arr = io->get("byte_array")) {                          // IoEnum::ByteArray(Vec<u8>)
+            if (out || arr->t != JVal::Arr) raise(kInvalidJson, "InvalidJson: bad byte_array");
+            e.owned.reserve(arr->a.size());
+            for (const JVal& v : arr->a) {
+                if (v.t != JVal::Num || v.n < 0 || v.n > 255 || v.n != std::floor(v.n)) raise(kInvalidJson, "InvalidJson: byte_array holds integers 0..255");
+                e.owned.push_back(static_cast<uint8_t>(v.n));
+            }
+            e.in_len = e.owned.size();
+        }
         else if (const JVal* hex = io->get("bytes_hex")) {
             if (out || hex->t != JVal::Str || (hex->s.size() & 1)) raise(kInvalidJson, "InvalidJson: bad bytes_hex");
             for (size_t i = 0; i < hex->s.size(); i += 2) e.owned.push_back(static_cast<uint8_t>(std::strtoul(hex->s.substr(i, 2).c_str(), nullptr, 16)));
@@ -1217,10 +1229,26 @@ void add_io_from_json(imageflow_context* c, const JVal& ios) {
                 if (bits >= 8) { bits -= 8; e.owned.push_back(static_cast<uint8_t>(acc >> bits)); }
             }
             e.in_len = e.owned.size();
-        } else raise(kActionNotSupported, "ActionNotSupported: io kind (this shim: placeholder, output_buffer, bytes_hex, base_64)");
+        } else raise(kActionNotSupported, "ActionNotSupported: io kind (this shim: placeholder, output_buffer, output_base_64, bytes_hex, base_64, byte_array)");
         auto& slot = c->io[id] = std::move(e);
         if (!slot.is_output) slot.in = slot.owned.data();
     }
+}
+
+// s::ResultBytes (imageflow_types/src/lib.rs): "elsewhere" for output buffers, {"base_64": ...} for IoEnum::OutputBase64
+std::string result_bytes(const Job& job, int32_t io_id) {
+    auto it = job.c->io.find(io_id);
+    if (it == job.c->io.end() || !it->second.out_base64) return "\"elsewhere\"";
+    static const char kB64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    const std::vector<uint8_t>& b = it->second.owned;
+    std::string o = "{\"base_64\": \"";
+    o.reserve(o.size() + (b.size() + 2) / 3 * 4 + 4);
+    for (size_t i = 0; i < b.size(); i += 3) {
+        const uint32_t n = (static_cast<uint32_t>(b[i]) << 16) | (i + 1 < b.size() ? static_cast<uint32_t>(b[i + 1]) << 8 : 0u) | (i + 2 < b.size() ? b[i + 2] : 0u);
+        o.push_back(kB64[(n >> 18) & 63]); o.push_back(kB64[(n >> 12) & 63]);
+        o.push_back(i + 1 < b.size() ? kB64[(n >> 6) & 63] : '='); o.push_back(i + 2 < b.size() ? kB64[n & 63] : '=');
+    }
+    return o + "\"}";
 }
 
 std::string job_result_json(const Job& job, const char* key) {
@@ -1228,7 +1256,7 @@ std::string job_result_json(const Job& job, const char* key) {
     for (size_t i = 0; i < job.encodes.size(); ++i) {
         const EncodeRecord& e = job.encodes[i];
         s += std::string(i ? "," : "") + "\n        {\"preferred_mime_type\": \"" + e.mime + "\", \"preferred_extension\": \"" + e.ext + "\", \"io_id\": " +
-             std::to_string(e.io_id) + ", \"w\": " + std::to_string(e.w) + ", \"h\": " + std::to_string(e.h) + ", \"bytes\": \"elsewhere\"}";
+             std::to_string(e.io_id) + ", \"w\": " + std::to_string(e.w) + ", \"h\": " + std::to_string(e.h) + ", \"bytes\": " + result_bytes(job, e.io_id) + "}";
     }
     s += "\n      ],\n      \"decodes\": [";
     for (size_t i = 0; i < job.decodes.size(); ++i) {

@@ -281,3 +281,12 @@ def test_tell_decoder_and_get_scaled_image_info():
     with Context() as c:
         status, r = c.send_json("v1/tell_decoder", {"io_id": 5, "command": "discard_color_profile"})        # no such input
         assert status == 400 and c.has_error()
+
+
+def test_byte_array_io_is_validated():
+    with Context() as c:
+        status, r = c.send_json("v1/build", {"io": [{"io_id": 0, "direction": "in", "io": {"byte_array": [1, 2, 300]}}], "framewise": {"steps": []}})
+        assert status == 400 and c.error_code() == 3                                       # InvalidJson
+    with Context() as c:
+        status, r = c.send_json("v1/build", {"io": [{"io_id": 0, "direction": "in", "io": "output_base_64"}], "framewise": {"steps": []}})
+        assert status == 400 and c.error_code() == 3

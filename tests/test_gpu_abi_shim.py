@@ -559,3 +559,21 @@ def test_tell_decoder_hints_apply_to_a_later_job():
     j = O.jpeg_read_coefficients(data)
     small = O.jpeg_idct_color_scaled(j, 4, 2)                                          # 640x360 covers 600x330
     assert np.array_equal(outs[0], _oracle_resize(small, 640, 360, 320, 180, filter_id=2))
+
+
+def test_build_with_byte_array_input_and_base64_output():
+    """IoEnum::ByteArray in, IoEnum::OutputBase64 out (imageflow_types/src/lib.rs:1433-1456): the job result carries the
+    encoded bytes as ResultBytes::Base64."""
+    import base64
+    src = U.random_frames(1, 24, 16, seed0=91, alpha=False)[0]
+    raw = pack_raw_bgra(src, 24, 16, alpha_meaningful=False)
+    with Context() as c:
+        r = _run(c, "v1/build", {"io": [{"io_id": 0, "direction": "in", "io": {"byte_array": list(raw)}},
+                                        {"io_id": 1, "direction": "out", "io": "output_base_64"}],
+                                 "framewise": {"steps": [{"decode": {"io_id": 0}}, {"resample_2d": {"w": 12, "h": 8}},
+                                                         {"encode": {"io_id": 1, "preset": "gif"}}]}})
+        enc = r["data"]["build_result"]["encodes"][0]
+        got = base64.b64decode(enc["bytes"]["base_64"])
+        assert got == bytes(c.get_output_buffer(1)) and (enc["w"], enc["h"]) == (12, 8)
+        rows = unpack_raw_bgra(got)[0]
+    assert np.array_equal(rows, _oracle_resize(src, 24, 16, 12, 8, filter_id=2))
