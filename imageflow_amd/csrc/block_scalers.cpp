@@ -52,7 +52,8 @@ void build_tables() {
         s.log2_div[row.r] = static_cast<uint8_t>(row.log2_div);
         ++rows;
     }
-    g_bs_ok = rows == 28;                                    // 1 + 2 + ... + 7
+    // (the kernels' output clamp relies on the table's ends: below 0 -> entry 0 = 0, above 4095 -> entry 4095 = 255)
+    g_bs_ok = rows == 28 && g_bs.linear_to_srgb[0] == 0 && g_bs.linear_to_srgb[4095] == 255;      // 28 = 1 + 2 + ... + 7
 }
 
 }  // namespace

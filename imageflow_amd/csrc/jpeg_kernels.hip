@@ -83,7 +83,7 @@ template <bool M24>
 __device__ __forceinline__ int32_t mulc(int32_t x, int32_t c) { return M24 ? __mul24(x, c) : x * c; }
 
 // one 8-point pass; in[] are the 8 inputs, sh the descale amount; out via callback-free arrays
-template <bool M24>
+template <bool M24, bool RAW = false>
 __device__ __forceinline__ void idct8(const int32_t (&in)[8], int32_t (&out)[8], int sh) {
     constexpr int32_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633,
                       F1_501 = 12299, F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
@@ -91,8 +91,11 @@ __device__ __forceinline__ void idct8(const int32_t (&in)[8], int32_t (&out)[8],
     int32_t z1 = mulc<M24>(z2 + z3, F0_541);
     int32_t tmp2 = z1 + mulc<M24>(z3, -F1_847);
     int32_t tmp3 = z1 + mulc<M24>(z2, F0_765);
-    int32_t tmp0 = static_cast<int32_t>(static_cast<uint32_t>(in[0] + in[4]) << 13);
-    int32_t tmp1 = static_cast<int32_t>(static_cast<uint32_t>(in[0] - in[4]) << 13);
+    // descale()'s rounding constant goes into the even part once (one shift-add each) instead of into the eight outputs:
+    // int32 addition wraps the same way in any order, so every sum below is the oracle's plus 2^(sh-1), bit for bit
+    const uint32_t half = 1u << (sh - 1);
+    int32_t tmp0 = static_cast<int32_t>((static_cast<uint32_t>(in[0] + in[4]) << 13) + half);
+    int32_t tmp1 = static_cast<int32_t>((static_cast<uint32_t>(in[0] - in[4]) << 13) + half);
     const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
     z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
@@ -102,10 +105,11 @@ __device__ __forceinline__ void idct8(const int32_t (&in)[8], int32_t (&out)[8],
     z1 = mulc<M24>(z1, -F0_899); z2 = mulc<M24>(z2, -F2_562); z3 = mulc<M24>(z3, -F1_961); z4 = mulc<M24>(z4, -F0_390);
     z3 += z5; z4 += z5;
     tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-    out[0] = descale(tmp10 + tmp3, sh); out[7] = descale(tmp10 - tmp3, sh);
-    out[1] = descale(tmp11 + tmp2, sh); out[6] = descale(tmp11 - tmp2, sh);
-    out[2] = descale(tmp12 + tmp1, sh); out[5] = descale(tmp12 - tmp1, sh);
-    out[3] = descale(tmp13 + tmp0, sh); out[4] = descale(tmp13 - tmp0, sh);
+    if (RAW) sh = 0;                                      // the caller takes its bits out of the sums itself
+    out[0] = (tmp10 + tmp3) >> sh; out[7] = (tmp10 - tmp3) >> sh;
+    out[1] = (tmp11 + tmp2) >> sh; out[6] = (tmp11 - tmp2) >> sh;
+    out[2] = (tmp12 + tmp1) >> sh; out[5] = (tmp12 - tmp1) >> sh;
+    out[3] = (tmp13 + tmp0) >> sh; out[4] = (tmp13 - tmp0) >> sh;
 }
 // first (column) pass: 24-bit multiplies when the whole wave's blocks are in range (wave-uniform choice)
 __device__ __forceinline__ void idct8_pass1(const int32_t (&in)[8], int32_t (&out)[8], bool small) {
@@ -123,19 +127,19 @@ __device__ __forceinline__ bool wave_all_small(const int32_t (&d)[8], bool lane_
 template <bool M24>
 __device__ __forceinline__ void idct4_pass(int32_t d0, int32_t d1, int32_t d2, int32_t d3, int32_t d5, int32_t d6, int32_t d7,
                                            int32_t (&out)[4], int sh) {
-    const int32_t t0 = static_cast<int32_t>(static_cast<uint32_t>(d0) << 14);
+    const int32_t t0 = static_cast<int32_t>((static_cast<uint32_t>(d0) << 14) + (1u << (sh - 1)));     // rounding folded as in idct8
     const int32_t t2 = mulc<M24>(d2, 15137) + mulc<M24>(d6, -6270);
     const int32_t t10 = t0 + t2, t12 = t0 - t2;
     const int32_t o0 = mulc<M24>(d7, -1730) + mulc<M24>(d5, 11893) + mulc<M24>(d3, -17799) + mulc<M24>(d1, 8697);
     const int32_t o2 = mulc<M24>(d7, -4176) + mulc<M24>(d5, -4926) + mulc<M24>(d3, 7373) + mulc<M24>(d1, 20995);
-    out[0] = descale(t10 + o2, sh); out[3] = descale(t10 - o2, sh);
-    out[1] = descale(t12 + o0, sh); out[2] = descale(t12 - o0, sh);
+    out[0] = (t10 + o2) >> sh; out[3] = (t10 - o2) >> sh;
+    out[1] = (t12 + o0) >> sh; out[2] = (t12 - o0) >> sh;
 }
 template <bool M24>
 __device__ __forceinline__ void idct2_pass(int32_t d0, int32_t d1, int32_t d3, int32_t d5, int32_t d7, int32_t (&out)[2], int sh) {
-    const int32_t t10 = static_cast<int32_t>(static_cast<uint32_t>(d0) << 15);
+    const int32_t t10 = static_cast<int32_t>((static_cast<uint32_t>(d0) << 15) + (1u << (sh - 1)));
     const int32_t t0 = mulc<M24>(d7, -5906) + mulc<M24>(d5, 6967) + mulc<M24>(d3, -10426) + mulc<M24>(d1, 29692);
-    out[0] = descale(t10 + t0, sh); out[1] = descale(t10 - t0, sh);
+    out[0] = (t10 + t0) >> sh; out[1] = (t10 - t0) >> sh;
 }
 
 // libjpeg's other scaled IDCTs (jidctint.c jpeg_idct_3x3 / 5x5 / 6x6 / 10x10 / 12x12): the block routines behind
@@ -493,13 +497,71 @@ __device__ __forceinline__ uint32_t range_limit_fast(int32_t v) {    // == range
     return static_cast<uint32_t>(x < 0 ? 0 : (x > 255 ? 255 : x));        // (v_med3_i32)
 }
 
+template <bool M24>
+__device__ __forceinline__ void bpl_column_pass(int32_t (&ws)[8][8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int32_t in[8], out[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            in[r] = ws[r][k];
+            // (the 32-bit form is the rare one: hidden from value numbering, or the sums it has in common with the 24-bit
+            // form are hoisted above the wave's choice for all eight columns at once -- 64 live values, spilled)
+            if (!M24) asm volatile("" : "+v"(in[r]));
+        }
+        idct8<M24>(in, out, 11);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ws[r][k] = out[r];
+        __builtin_amdgcn_sched_barrier(0);                      // one column at a time: interleaved, the eight passes' temporaries spill
+    }
+}
+// flow_scale_spatial[_srgb]_NxN on one block of (linear) samples.  SRGB: the result goes back through the 4 096-entry
+// linear -> sRGB table, whose ends are 0 and 255 (block_scalers.cpp checks), so the reference's two range tests are a clamp
+// of the index.
+template <int N, bool SRGB>
+__device__ __forceinline__ void bpl_scale_block(const int32_t (&lin)[8][8], uint8_t* plane, uint32_t by, uint32_t bx, uint32_t pitch,
+                                                const uint8_t* l2s_lds) {
+    constexpr uint32_t n = N;
+    constexpr int base = scaler_row_index(N, 0);                // the N rows of size N are consecutive in the table
+#pragma unroll
+    for (uint32_t r = 0; r < n; ++r) {
+        int32_t V[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int32_t acc = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (kScalerRowsC[base + r].w[i] != 0) acc += __mul24(kScalerRowsC[base + r].w[i], lin[i][j]);
+            V[j] = acc;
+        }
+        uint32_t packed = 0;
+        uint8_t* orow = plane + static_cast<size_t>(by * n + r) * pitch + bx * n;
+#pragma unroll
+        for (uint32_t cc = 0; cc < n; ++cc) {
+            const uint32_t sh = static_cast<uint32_t>(kScalerRowsC[base + r].log2_div + kScalerRowsC[base + cc].log2_div);
+            int32_t sum = static_cast<int32_t>(1u << (sh - 1u));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (kScalerRowsC[base + cc].w[j] != 0) sum += __mul24(V[j], kScalerRowsC[base + cc].w[j]);
+            const int32_t q = sum >> sh;                        // (sum < 0 <=> q < 0; sum >= 4096 << sh <=> q >= 4096)
+            uint32_t ob;
+            if (SRGB) ob = l2s_lds[q < 0 ? 0 : (q > 4095 ? 4095 : q)];
+            else ob = q < 0 ? 0u : (q > 4095 ? 255u : static_cast<uint32_t>(q) & 255u);
+            if (n == 4u || n == 2u) packed |= ob << (8u * cc);
+            else orow[cc] = static_cast<uint8_t>(ob);
+        }
+        if (n == 4u) *reinterpret_cast<uint32_t*>(orow) = packed;               // (plane pitch and bx * 4: 4-byte aligned)
+        else if (n == 2u) *reinterpret_cast<uint16_t*>(orow) = static_cast<uint16_t>(packed);
+    }
+}
+
 // lanes per workgroup: with the scaler's tables 8 waves (2 workgroups x 78 KiB of LDS = 4 waves per SIMD; 4-wave workgroups of
-// 41.5 KiB fit only three times), the plain routines 4 waves (4 x 37 KiB)
+// 41.5 KiB fit only three times), the plain routines 4 waves (4 x 38 KiB)
 constexpr uint32_t bpl_threads(int mode) { return mode == 2 ? 512u : 256u; }
 typedef uint4_nt (*BplStage)[64 * 9];
 template <int MODE, int N>
 __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t c, uint32_t img, uint32_t wg, BplStage stage,
-                                                    const uint16_t* s2l_lds, const uint8_t* l2s_lds) {
+                                                    const uint16_t* lim_lds, const uint8_t* l2s_lds, const uint8_t* lim8_lds) {
     const uint32_t t = threadIdx.x;
     const bool srgb = MODE == 2 && a.g.luma_mode == 2u;
     const uint32_t nblk = a.g.bw[c] * a.g.bh[c];
@@ -574,96 +636,49 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
         }
         return;
     } else {
-        // column pass (CONST_BITS - PASS1_BITS), in place
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            int32_t in[8], out[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) in[r] = ws[r][k];
-            idct8_pass1(in, out, small);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) ws[r][k] = out[r];
-        }
-        // row pass (CONST_BITS + PASS1_BITS + 3: always in 24-bit range) + libjpeg's range-limit table.  The table wraps
-        // beyond [-384, 383]; inside, it is a clamp of v + 128 -- a wave whose 64 blocks all stay inside takes the clamp.
-        int32_t (&px)[8][8] = ws;                               // in place: a row's eight inputs are consumed before its outputs land
-        int32_t lo = 128, hi = 128;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            int32_t in[8], out[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) in[k] = ws[r][k];
-            in[0] += 4096;                                      // the table's + 128, once per row: (4096 << 13) = 128 << 18 goes through
-            idct8<true>(in, out, 18);                           // the even part into every output, and descale(x + 128 * 2^18, 18) = descale(x, 18) + 128
-#pragma unroll
-            for (int k = 0; k < 8; k += 2) {
-                px[r][k] = out[k]; px[r][k + 1] = out[k + 1];
-                lo = min(lo, min(out[k], out[k + 1]));
-                hi = max(hi, max(out[k], out[k + 1]));
-            }
-        }
-        const bool tame = __all(lo >= -384 + 128 && hi <= 383 + 128) != 0;
-        // range-limited samples, in place (0 .. 255); px holds v + 128 here
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int32_t x = px[r][k];
-                px[r][k] = tame ? (x < 0 ? 0 : (x > 255 ? 255 : x)) : static_cast<int32_t>(range_limit(x - 128));
-            }
+        // column pass (CONST_BITS - PASS1_BITS), in place; the multiply width is the wave's choice, made once
+        if (small) bpl_column_pass<true>(ws);
+        else bpl_column_pass<false>(ws);
         if constexpr (MODE == 0) {
+            // row pass (CONST_BITS + PASS1_BITS + 3: always in 24-bit range) + libjpeg's range-limit table: bits 18..27 of
+            // a row-pass sum (rounding constant inside) are the table's index (v & 1023), the table is 1 KiB of LDS -- one
+            // bit-field extract and one byte read per sample, no clamp, no special case for values beyond the clamp range
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const uint32_t w0 = static_cast<uint32_t>(px[r][0]) | (static_cast<uint32_t>(px[r][1]) << 8) | (static_cast<uint32_t>(px[r][2]) << 16) | (static_cast<uint32_t>(px[r][3]) << 24);
-                const uint32_t w1 = static_cast<uint32_t>(px[r][4]) | (static_cast<uint32_t>(px[r][5]) << 8) | (static_cast<uint32_t>(px[r][6]) << 16) | (static_cast<uint32_t>(px[r][7]) << 24);
+                int32_t in[8], out[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) in[k] = ws[r][k];
+                idct8<true, true>(in, out, 18);
+                uint32_t b[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) b[k] = lim8_lds[(static_cast<uint32_t>(out[k]) >> 18) & 1023u];
+                const uint32_t w0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24), w1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
                 *reinterpret_cast<uint2*>(plane + static_cast<size_t>(by * 8u + r) * a.g.pw[c] + bx * 8u) = make_uint2(w0, w1);
+                __builtin_amdgcn_sched_barrier(0);
             }
             return;
         } else {
-            // flow_scale_spatial[_srgb]_NxN (codecs_jpeg_idct_fast.c): rows combined with the integer weights of output row
-            // r, then columns with those of output column cc, rounded by the two divisors' shift; the _srgb forms work in
-            // 12-bit linear light through two lookup tables.  |weight| <= 117, linear <= 4095, sums of weights <= 512:
-            // every product fits 24 x 24 -> 32 bits.
-            constexpr uint32_t n = N;                           // == a.g.idct_n[0] (the launcher picks the instantiation)
-            int32_t (&lin)[8][8] = px;                          // in place again: sample -> 12-bit linear light (or itself)
-            if (srgb) {
+            // row pass, then flow_scale_spatial[_srgb]_NxN (codecs_jpeg_idct_fast.c).  The sample never exists: bits 18..27
+            // of a row-pass sum (rounding constant already inside) ARE the index (v & 1023) of libjpeg's range-limit table,
+            // and the workgroup's table holds, under that index, the 12-bit linear light of the limited sample (_srgb
+            // forms) or the limited sample itself -- one bit-field extract and one LDS read per sample, no clamp, no
+            // special case for wrapped values.
+            int32_t (&lin)[8][8] = ws;
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+            for (int r = 0; r < 8; ++r) {
+                int32_t in[8], out[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) lin[i][j] = static_cast<int32_t>(s2l_lds[px[i][j]]);
+                for (int k = 0; k < 8; ++k) in[k] = ws[r][k];
+                idct8<true, true>(in, out, 18);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) lin[r][k] = static_cast<int32_t>(lim_lds[(static_cast<uint32_t>(out[k]) >> 18) & 1023u]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            constexpr int base = scaler_row_index(N, 0);        // the N rows of size N are consecutive in the table
-#pragma unroll
-            for (uint32_t r = 0; r < n; ++r) {
-                int32_t V[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    int32_t acc = 0;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (kScalerRowsC[base + r].w[i] != 0) acc += __mul24(kScalerRowsC[base + r].w[i], lin[i][j]);
-                    V[j] = acc;
-                }
-                uint32_t packed = 0;
-                uint8_t* orow = plane + static_cast<size_t>(by * n + r) * a.g.pw[c] + bx * n;
-#pragma unroll
-                for (uint32_t cc = 0; cc < n; ++cc) {
-                    const uint32_t sh = static_cast<uint32_t>(kScalerRowsC[base + r].log2_div + kScalerRowsC[base + cc].log2_div);
-                    int32_t sum = static_cast<int32_t>(1u << (sh - 1u));
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (kScalerRowsC[base + cc].w[j] != 0) sum += __mul24(V[j], kScalerRowsC[base + cc].w[j]);
-                    uint32_t ob;
-                    if (sum < 0) ob = 0;
-                    else if (static_cast<uint32_t>(sum) >= (4096u << sh)) ob = 255;
-                    else ob = srgb ? l2s_lds[sum >> sh] : static_cast<uint32_t>(sum >> sh);
-                    ob &= 255u;
-                    if (n == 4u || n == 2u) packed |= ob << (8u * cc);
-                    else orow[cc] = static_cast<uint8_t>(ob);
-                }
-                if (n == 4u) *reinterpret_cast<uint32_t*>(orow) = packed;               // (plane pitch and bx * 4: 4-byte aligned)
-                else if (n == 2u) *reinterpret_cast<uint16_t*>(orow) = static_cast<uint16_t>(packed);
-            }
+            // rows combined with the integer weights of output row r, then columns with those of output column cc, rounded
+            // by the two divisors' shift.  |weight| <= 117, linear <= 4095, sums of weights <= 512: every product fits
+            // 24 x 24 -> 32 bits.
+            if (srgb) bpl_scale_block<N, true>(lin, plane, by, bx, a.g.pw[c], l2s_lds);
+            else bpl_scale_block<N, false>(lin, plane, by, bx, a.g.pw[c], l2s_lds);
         }
     }
 }
@@ -671,22 +686,34 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
 // One launch per component (blockIdx.z: the two chroma components).  (One launch for all three with luma and chroma
 // workgroups interleaved -- traffic-bound plain IDCTs beside the arithmetic-bound spatial scalers -- was measured: 410 us
 // against 254 + 110 us for the 4/8 decode of 32 4K frames; every workgroup then carries the larger routine's registers.)
-__device__ __forceinline__ void bpl_tables(const JpegArgs& a, bool needed, uint16_t* s2l_lds, uint8_t* l2s_lds) {
-    if (needed && threadIdx.x < 256u) {
-        s2l_lds[threadIdx.x] = a.sc.s2l[threadIdx.x];
-        reinterpret_cast<uint4*>(l2s_lds)[threadIdx.x] = reinterpret_cast<const uint4*>(a.sc.l2s)[threadIdx.x];
+// The scaler's two tables: lim[i], i = (v & 1023) as libjpeg indexes its range-limit table, holds what the scaler reads of
+// the limited sample -- its 12-bit linear light (_srgb forms) or the sample; l2s is lut_linear_to_srgb.
+__device__ __forceinline__ void bpl_tables(const JpegArgs& a, bool srgb, uint16_t* lim_lds, uint8_t* l2s_lds) {
+    for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x) {
+        const uint32_t sample = range_limit(static_cast<int32_t>(i));
+        lim_lds[i] = srgb ? a.sc.s2l[sample] : static_cast<uint16_t>(sample);
     }
+    if (srgb && threadIdx.x < 256u) reinterpret_cast<uint4*>(l2s_lds)[threadIdx.x] = reinterpret_cast<const uint4*>(a.sc.l2s)[threadIdx.x];
     __syncthreads();
 }
 
 template <int MODE, int N = 1>       // N: block size of the spatial scaler (MODE 2)
 __global__ void __launch_bounds__(bpl_threads(MODE)) __attribute__((amdgpu_waves_per_eu(4, 4)))     // 4 waves per SIMD: <= 128 registers
 jpeg_idct_block_per_lane_kernel(const JpegArgs a) {
-    __shared__ __attribute__((aligned(16))) uint4_nt stage[bpl_threads(MODE) / 64][64 * 9];
-    __shared__ uint16_t s2l_lds[MODE == 2 ? 256 : 1];
-    __shared__ __attribute__((aligned(16))) uint8_t l2s_lds[MODE == 2 ? 4096 : 16];
-    if (MODE == 2) bpl_tables(a, a.g.luma_mode == 2u, s2l_lds, l2s_lds);
-    idct_block_per_lane<MODE, N>(a, a.comp + blockIdx.z, blockIdx.y, blockIdx.x, stage, s2l_lds, l2s_lds);
+    // one block, tables first: their LDS addresses fit the 16-bit offset field of the table reads
+    struct Lds {
+        uint16_t lim[MODE == 2 ? 1024 : 8];
+        uint8_t l2s[MODE == 2 ? 4096 : 16];
+        uint8_t lim8[MODE == 0 ? 1024 : 16];
+        uint4_nt stage[bpl_threads(MODE) / 64][64 * 9];
+    };
+    __shared__ __attribute__((aligned(16))) Lds lds;
+    if (MODE == 2) bpl_tables(a, a.g.luma_mode == 2u, lds.lim, lds.l2s);
+    if (MODE == 0) {
+        for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x) lds.lim8[i] = static_cast<uint8_t>(range_limit(static_cast<int32_t>(i)));
+        __syncthreads();
+    }
+    idct_block_per_lane<MODE, N>(a, a.comp + blockIdx.z, blockIdx.y, blockIdx.x, lds.stage, lds.lim, lds.l2s, lds.lim8);
 }
 
 // ---- up-sample + colour ------------------------------------------------------------------------------------------

@@ -7,6 +7,9 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof3
 SUM=gpurun_out/prof3_summary
 rm -rf $OUT $SUM; mkdir -p $OUT $SUM
+# SECTIONS="5" tools/profile_r3.sh re-measures one part only (default: all five)
+SECTIONS=${SECTIONS:-"1 2 3 4 5"}
+want() { case " $SECTIONS " in *" $1 "*) return 0;; esac; return 1; }
 
 pmc_pass() {   # pmc_pass <tag> <kernel substring> <counters> -- cmd...
   local tag=$1 ksub=$2 ctr=$3; shift 4
@@ -30,6 +33,7 @@ PY
 }
 
 # 1. headline: bench line, the same command under kernel-trace, HBM traffic + SQ counters
+if want 1; then
 python bench.py > $SUM/bench_cfg2.json 2> $SUM/bench_cfg2.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg2 -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-strong-field > $SUM/bench_cfg2_under_trace.json 2> $OUT/trace_cfg2.err
 find $OUT/trace_cfg2 -name '*kernel_stats.csv' -exec cp {} $SUM/cfg2_kernel_stats.csv \;
@@ -37,8 +41,10 @@ find $OUT/trace_cfg2 -name '*kernel_stats.csv' -exec cp {} $SUM/cfg2_kernel_stat
   for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE"; do
     pmc_pass cfg2 fused_resample "$C" -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-strong-field
   done; } > $SUM/cfg2_pmc.txt
+fi
 
 # 2. cfg5 (BASELINE's HBM-roofline config) and cfg2 with alpha: bench line + kernel stats + counters
+if want 2; then
 for W in cfg5 cfg2-alpha; do
   python bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline > $SUM/bench_$W.json 2> /dev/null
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- python bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2> $OUT/trace_$W.err
@@ -49,19 +55,25 @@ for W in cfg5 cfg2-alpha; do
     done; } > $SUM/${W}_pmc.txt
   rm -rf $OUT/trace_$W
 done
+fi
 
 # 3. the other resample shapes (kernel unchanged since round 2 apart from the gather addresses): bench line + kernel stats
+if want 3; then
 for W in cfg3-l0 cfg3-l1 cfg3-l2 cfg3-l3 cfg4-resize cfg1-resize up2-hermite up3-robidoux; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- python bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline > $SUM/bench_$W.json 2> $OUT/trace_$W.err
   find $OUT/trace_$W -name '*kernel_stats.csv' -exec sh -c "head -1 {} > $SUM/${W}_kernel_stats.csv; grep -E 'fused_resample|generic' {} >> $SUM/${W}_kernel_stats.csv" \;
   rm -rf $OUT/trace_$W
 done
+fi
 
 # 4. jobs: export_4_sizes, 1024-frame strong-scaling job on one GPU
+if want 4; then
 python bench.py --workload cfg3 --steps 50 --warmup 5 --no-cpu-baseline > $SUM/bench_cfg3_job.json 2>/dev/null
 python bench.py --scaling strong --total-frames 1024 --steps 30 --warmup 5 --no-cpu-baseline > $SUM/bench_strong_1024_1gpu.json 2>/dev/null
+fi
 
 # 5. JPEG: pixel stage (cfg4 chain as one call / two calls), per-kernel statistics, HBM traffic of the chain; entropy chain
+if want 5; then
 python tools/bench_jpeg.py 32 > $SUM/bench_jpeg.json 2> /dev/null
 tools/profile_jpeg_kernels.sh > /dev/null 2>&1; cp gpurun_out/jpeg_kernels/kernels.txt $SUM/bench_jpeg_kernels.txt
 { echo "# cfg4 chain (32 frames 3840x2160 4:2:0 -> 4/8 decode, spatial sRGB luma -> 800x450), HBM traffic per chain call, summed over its kernels"
@@ -79,6 +91,8 @@ find $OUT/trace_jpeg -name '*kernel_stats.csv' -exec sh -c "head -9 {} > $SUM/jp
   for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE"; do
     pmc_pass ent "entropy_" "$C" -- python tools/bench_entropy.py 1
   done; } > $SUM/entropy_pmc.txt
-tools/probes/issue_rate_probe > $SUM/issue_rate_probe.txt 2>&1
+fi
+
+want 1 && tools/probes/issue_rate_probe > $SUM/issue_rate_probe.txt 2>&1
 rm -rf $OUT
 ls -la $SUM
