@@ -418,6 +418,12 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         a.lanes_per_frame = block;
         const uint64_t grid = static_cast<uint64_t>((n_images + frames - 1u) / frames) * sd.n_bands * a.n_strips;
         if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
+        if (std::getenv("IFHIP_TRACE_LAUNCH"))                        // experiment aid: the shape this call launches
+            std::fprintf(stderr, "ifhip fused launch: %ux%u -> %ux%u K=%d alpha=%d ycc=%d lanes/frame=%u frames/wg=%u bands=%u strips=%u "
+                         "grid=%llu lds=%zu fast_g=%u w_in_lds=%d l2s_in_lds=%d lut_copies=%u per_pixel=%d images=%u\n",
+                         p->in_w, p->in_h, p->out_w, p->out_h, p->slots, alpha, ycc ? 1 : 0, block, frames, sd.n_bands, a.n_strips,
+                         static_cast<unsigned long long>(grid), lds, fast_g, w_in_lds ? 1 : 0, l2s_in_lds ? 1 : 0, 1u << copies_log2,
+                         per_pixel ? 1 : 0, n_images);
         HIP_TRY(launch_fused(a, p->slots, alpha != 0, per_pixel, static_cast<uint32_t>(grid), block * frames, lds, st));
         return IFHIP_OK;
     }

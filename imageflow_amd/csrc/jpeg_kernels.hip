@@ -613,9 +613,18 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
     }
     const bool small = __all(dmax < (1 << 21) && dmin > -(1 << 21)) != 0;      // 24-bit multiplies in the first pass (see mulc)
     uint8_t* plane = a.plane[c] + static_cast<size_t>(img) * a.g.pw[c] * a.g.ph[c];
-    const uint32_t by = bidx / a.g.bw[c], bx = bidx - by * a.g.bw[c];
+    // where the block goes is worked out behind the passes (the division's temporaries and results would otherwise sit in
+    // registers next to the 64 coefficients and push some of them into scratch)
+    uint32_t by = 0, bx = 0;
+    auto locate = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t b = bidx;
+        asm volatile("" : "+v"(b));
+        by = b / a.g.bw[c]; bx = b - by * a.g.bw[c];
+    };
 
     if constexpr (MODE == 1) {
+        locate();
         // jidctred.c jpeg_idct_4x4: columns 0-3, 5-7 (column 4 is not used by the second pass), rows 0-3
         int32_t col[4][8];
 #pragma unroll
@@ -639,6 +648,7 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
         // column pass (CONST_BITS - PASS1_BITS), in place; the multiply width is the wave's choice, made once
         if (small) bpl_column_pass<true>(ws);
         else bpl_column_pass<false>(ws);
+        locate();
         if constexpr (MODE == 0) {
             // row pass (CONST_BITS + PASS1_BITS + 3: always in 24-bit range) + libjpeg's range-limit table: bits 18..27 of
             // a row-pass sum (rounding constant inside) are the table's index (v & 1023), the table is 1 KiB of LDS -- one

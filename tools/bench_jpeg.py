@@ -44,14 +44,20 @@ def main():
         if chain_calls:
             if scale_num != 4:
                 continue
-            for _ in range(chain_calls):
+            def chain():
                 if two_call:
                     st.read_frames(coef, qt, out)
                     scale_and_render(out, small, info)
                 else:
                     st.read_frames_into(coef, qt, small, info)
+            chain()
             torch.cuda.synchronize()
-            print(json.dumps({"chain_calls": chain_calls, "two_call": two_call, "frames": n}))
+            t0 = time.perf_counter()
+            for _ in range(chain_calls):
+                chain()
+            torch.cuda.synchronize()
+            print(json.dumps({"chain_calls": chain_calls, "two_call": two_call, "frames": n,
+                              "ms_per_call": round((time.perf_counter() - t0) / chain_calls * 1e3, 4)}))
             return
         for _ in range(3):
             st.read_frames(coef, qt, out)
