@@ -52,3 +52,21 @@ def test_headline_resample_kernel_keeps_its_shape(k):
     assert head and all(_int(r, "VGPRs") <= 128 for r in head), head
     fast = [r for n, r in rows.items() if re.search(r"fused_resample_kernel<4, (false|true), true, true, [234], (false|true)>", n)]
     assert len(fast) >= 3 and all(_int(r, "ScratchSize [bytes/lane]") == 0 and _int(r, "VGPRs") <= 128 for r in fast), fast
+
+
+def test_jpeg_block_routines_keep_their_occupancy():
+    """jpeg_idct_block_per_lane_kernel: the scaler forms (MODE 2) run two 512-lane workgroups per CU -- <= 80 KiB of LDS each
+    and <= 128 registers (4 waves per SIMD); the plain 8x8 form four 256-lane workgroups of <= 40 KiB.  The routines are
+    bound by instruction issue, so a lost wave per SIMD or a spill-heavy build shows up as time."""
+    rows = resource_usage(os.path.join(B.CSRC, "jpeg_kernels.hip"))
+    seen = 0
+    for name, r in rows.items():
+        m = re.match(r"void jpeg_idct_block_per_lane_kernel<(\d), (\d)>", name)
+        if not m:
+            continue
+        seen += 1
+        mode = int(m.group(1))
+        assert _int(r, "VGPRs") <= 128, (name, r)
+        assert _int(r, "LDS Size [bytes/block]") <= (80 if mode == 2 else 40) * 1024, (name, r)
+        assert _int(r, "ScratchSize [bytes/lane]") <= 64, (name, r)            # a handful of values at the column -> row turn
+    assert seen == 9
