@@ -561,7 +561,7 @@ constexpr uint32_t bpl_threads(int mode) { return mode == 2 ? 512u : 256u; }
 typedef uint4_nt (*BplStage)[64 * 9];
 template <int MODE, int N>
 __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t c, uint32_t img, uint32_t wg, BplStage stage,
-                                                    const uint16_t* lim_lds, const uint8_t* l2s_lds, const uint8_t* lim8_lds) {
+                                                    const uint32_t* lim_lds, const uint8_t* l2s_lds, const uint8_t* lim8_lds) {
     const uint32_t t = threadIdx.x;
     const bool srgb = MODE == 2 && a.g.luma_mode == 2u;
     const uint32_t nblk = a.g.bw[c] * a.g.bh[c];
@@ -681,7 +681,9 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
                 for (int k = 0; k < 8; ++k) in[k] = ws[r][k];
                 idct8<true, true>(in, out, 18);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) lin[r][k] = static_cast<int32_t>(lim_lds[(static_cast<uint32_t>(out[k]) >> 18) & 1023u]);
+                for (int k = 0; k < 8; ++k)      // 4-byte entries: the byte offset (sum >> 16) & 0xffc is one SDWA and (upper word, mask)
+                    lin[r][k] = static_cast<int32_t>(*reinterpret_cast<const uint32_t*>(
+                        reinterpret_cast<const uint8_t*>(lim_lds) + ((static_cast<uint32_t>(out[k]) >> 16) & 0xffcu)));
                 __builtin_amdgcn_sched_barrier(0);
             }
             // rows combined with the integer weights of output row r, then columns with those of output column cc, rounded
@@ -698,10 +700,10 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
 // against 254 + 110 us for the 4/8 decode of 32 4K frames; every workgroup then carries the larger routine's registers.)
 // The scaler's two tables: lim[i], i = (v & 1023) as libjpeg indexes its range-limit table, holds what the scaler reads of
 // the limited sample -- its 12-bit linear light (_srgb forms) or the sample; l2s is lut_linear_to_srgb.
-__device__ __forceinline__ void bpl_tables(const JpegArgs& a, bool srgb, uint16_t* lim_lds, uint8_t* l2s_lds) {
+__device__ __forceinline__ void bpl_tables(const JpegArgs& a, bool srgb, uint32_t* lim_lds, uint8_t* l2s_lds) {
     for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x) {
         const uint32_t sample = range_limit(static_cast<int32_t>(i));
-        lim_lds[i] = srgb ? a.sc.s2l[sample] : static_cast<uint16_t>(sample);
+        lim_lds[i] = srgb ? static_cast<uint32_t>(a.sc.s2l[sample]) : sample;
     }
     if (srgb && threadIdx.x < 256u) reinterpret_cast<uint4*>(l2s_lds)[threadIdx.x] = reinterpret_cast<const uint4*>(a.sc.l2s)[threadIdx.x];
     __syncthreads();
@@ -711,12 +713,15 @@ template <int MODE, int N = 1>       // N: block size of the spatial scaler (MOD
 __global__ void __launch_bounds__(bpl_threads(MODE)) __attribute__((amdgpu_waves_per_eu(4, 4)))     // 4 waves per SIMD: <= 128 registers
 jpeg_idct_block_per_lane_kernel(const JpegArgs a) {
     // one block, tables first: their LDS addresses fit the 16-bit offset field of the table reads
-    struct Lds {
-        uint16_t lim[MODE == 2 ? 1024 : 8];
+    struct Lds {                                                // MODE 2: 4 + 4 + 72 KiB = exactly half of a CU's 160 KiB
+        union {
+            uint32_t lim[MODE == 2 ? 1024 : 4];
+            uint8_t lim8[MODE == 0 ? 1024 : 16];
+        };
         uint8_t l2s[MODE == 2 ? 4096 : 16];
-        uint8_t lim8[MODE == 0 ? 1024 : 16];
         uint4_nt stage[bpl_threads(MODE) / 64][64 * 9];
     };
+    static_assert(sizeof(Lds) <= (MODE == 2 ? 80 : 40) * 1024, "two (scaler forms) / four (plain forms) workgroups per CU");
     __shared__ __attribute__((aligned(16))) Lds lds;
     if (MODE == 2) bpl_tables(a, a.g.luma_mode == 2u, lds.lim, lds.l2s);
     if (MODE == 0) {
