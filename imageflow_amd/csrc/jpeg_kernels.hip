@@ -518,6 +518,21 @@ __device__ __forceinline__ void bpl_column_pass(int32_t (&ws)[8][8]) {
 // flow_scale_spatial[_srgb]_NxN on one block of (linear) samples.  SRGB: the result goes back through the 4 096-entry
 // linear -> sRGB table, whose ends are 0 and 255 (block_scalers.cpp checks), so the reference's two range tests are a clamp
 // of the index.
+// The scaler's multiply-adds, spelled as the instruction.  Left to the optimiser a 24-bit multiply by a weight gets
+// rewritten -- factored into weight * (a + b), or, once an operand's range is known, into a plain 32-bit multiply the
+// instruction selector cannot prove narrow again -- and comes out as v_mul_lo_u32 / v_mad_u64_u32, which issue at a
+// quarter of the rate (25 of them per block in the 4x4 scaler).  w is a compile-time weight (scalar operand).
+__device__ __forceinline__ int32_t mad24(int32_t x, int32_t w, int32_t acc) {
+    int32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(w), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ int32_t mul24c(int32_t x, int32_t w) {
+    int32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, 0" : "=v"(d) : "v"(x), "s"(w));
+    return d;
+}
+
 template <int N, bool SRGB>
 __device__ __forceinline__ void bpl_scale_block(const int32_t (&lin)[8][8], uint8_t* plane, uint32_t by, uint32_t bx, uint32_t pitch,
                                                 const uint8_t* l2s_lds) {
@@ -529,9 +544,13 @@ __device__ __forceinline__ void bpl_scale_block(const int32_t (&lin)[8][8], uint
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             int32_t acc = 0;
+            bool first = true;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (kScalerRowsC[base + r].w[i] != 0) acc += __mul24(kScalerRowsC[base + r].w[i], lin[i][j]);
+                if (kScalerRowsC[base + r].w[i] != 0) {
+                    acc = first ? mul24c(lin[i][j], kScalerRowsC[base + r].w[i]) : mad24(lin[i][j], kScalerRowsC[base + r].w[i], acc);
+                    first = false;
+                }
             V[j] = acc;
         }
         uint32_t packed = 0;
@@ -542,7 +561,7 @@ __device__ __forceinline__ void bpl_scale_block(const int32_t (&lin)[8][8], uint
             int32_t sum = static_cast<int32_t>(1u << (sh - 1u));
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (kScalerRowsC[base + cc].w[j] != 0) sum += __mul24(V[j], kScalerRowsC[base + cc].w[j]);
+                if (kScalerRowsC[base + cc].w[j] != 0) sum = mad24(V[j], kScalerRowsC[base + cc].w[j], sum);
             const int32_t q = sum >> sh;                        // (sum < 0 <=> q < 0; sum >= 4096 << sh <=> q >= 4096)
             uint32_t ob;
             if (SRGB) ob = l2s_lds[q < 0 ? 0 : (q > 4095 ? 4095 : q)];
@@ -681,9 +700,10 @@ __device__ __forceinline__ void idct_block_per_lane(const JpegArgs& a, uint32_t 
                 for (int k = 0; k < 8; ++k) in[k] = ws[r][k];
                 idct8<true, true>(in, out, 18);
 #pragma unroll
-                for (int k = 0; k < 8; ++k)      // 4-byte entries: the byte offset (sum >> 16) & 0xffc is one SDWA and (upper word, mask)
+                for (int k = 0; k < 8; ++k) {    // 4-byte entries: the byte offset (sum >> 16) & 0xffc is one SDWA and (upper word, mask)
                     lin[r][k] = static_cast<int32_t>(*reinterpret_cast<const uint32_t*>(
                         reinterpret_cast<const uint8_t*>(lim_lds) + ((static_cast<uint32_t>(out[k]) >> 16) & 0xffcu)));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             // rows combined with the integer weights of output row r, then columns with those of output column cc, rounded
