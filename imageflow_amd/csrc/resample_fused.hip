@@ -148,8 +148,6 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     const size_t src_off = static_cast<size_t>(img) * a.in_image_bytes
                            + static_cast<size_t>(strip.cx0 + static_cast<uint32_t>(PX) * quad) * (YCC ? 1u : 4u);
     const uint8_t* src = a.in + src_off;
-    const uint8_t* src_cb = YCC ? a.in_cb + src_off : nullptr;
-    const uint8_t* src_cr = YCC ? a.in_cr + src_off : nullptr;
 
     // Ring accumulators and converted samples live as float2 pairs over the flattened (pixel, channel) index
     // f = p*C + c, so that the vertical pass issues v_pk_fma_f32 (two IEEE fmaf per instruction, the weight broadcast
@@ -198,9 +196,11 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
         // source frames are streamed exactly once: non-temporal loads keep them from displacing the tables in L2
         // (measured -1.7% kernel time, profiles/r1_notes.md)
         if constexpr (YCC) {
-            return YccRaw{__builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src + ro)),
-                          __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src_cb + ro)),
-                          __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src_cr + ro))};
+            // one 64-bit multiply-add (quarter rate) for the row, the other two planes by their (wave-uniform) distance
+            const uint8_t* py = src + ro;
+            return YccRaw{__builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(py)),
+                          __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(py + (a.in_cb - a.in))),
+                          __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(py + (a.in_cr - a.in)))};
         } else {
             return __builtin_nontemporal_load(reinterpret_cast<const bgra_raw_t*>(src + ro));
         }
