@@ -94,13 +94,16 @@ __device__ __forceinline__ void fdct8(const int32_t (&e)[8], int32_t (&o)[8], bo
 
 // jcdctmgr.c quantize: round-half-up division of |v| by 8*Q, sign restored.  The quotient is estimated with one f32
 // multiply and corrected by the exact integer remainder (|v| + 4Q < 2^24, so the estimate is off by at most one).
-__device__ __forceinline__ int32_t quantize_coef(int32_t v, int32_t qv, float rq) {
-    const bool neg = v < 0;
-    const uint32_t u = static_cast<uint32_t>(neg ? -v : v) + static_cast<uint32_t>(qv >> 1);
-    uint32_t q = static_cast<uint32_t>(static_cast<float>(u) * rq);
-    const int32_t r = static_cast<int32_t>(u) - static_cast<int32_t>(__umul24(q, static_cast<uint32_t>(qv)));   // both < 2^24
-    q = r < 0 ? q - 1u : (r >= qv ? q + 1u : q);
-    return neg ? -static_cast<int32_t>(q) : static_cast<int32_t>(q);
+// Everything that depends on Q alone comes from the workgroup's table: e = (8Q - 1, bits of 1 / 8Q, 4Q, -8Q).  No compare
+// + select pairs: on gfx950 a VALU compare into an SGPR pair costs two wait states before the select may read it, and this
+// runs 64 times per block.
+__device__ __forceinline__ int32_t quantize_coef(int32_t v, const uint4& e) {
+    const int32_t s = v >> 31;                                   // 0 / -1
+    const int32_t u = ((v ^ s) - s) + static_cast<int32_t>(e.z); // |v| + 4Q
+    int32_t q = static_cast<int32_t>(static_cast<uint32_t>(static_cast<float>(static_cast<uint32_t>(u)) * __uint_as_float(e.y)));
+    const int32_t r = __mul24(q, static_cast<int32_t>(e.w)) + u; // u - q * 8Q (both factors < 2^24)
+    q += (r >> 31) - ((static_cast<int32_t>(e.x) - r) >> 31);    // r < 0: one too many; r >= 8Q: one too few
+    return (q ^ s) - s;
 }
 
 __device__ __forceinline__ void wave_lds_sync() {       // the 8 lanes of a block share a wave: order LDS traffic, no s_barrier
@@ -122,9 +125,17 @@ __global__ void __launch_bounds__(256) jpeg_forward_fused_kernel(const FwdArgs a
     __shared__ __attribute__((aligned(16))) uint8_t ys[8 * VS * YP];
     __shared__ __attribute__((aligned(16))) uint8_t cs[2][8 * CP];
     __shared__ int32_t ws[kFwdBlocksPerWg * kFwdBlockPitch];
+    // what the quantiser needs of the image's three tables (quantize_coef): the reciprocal is a quarter-rate instruction and
+    // depends on the table entry only -- once per workgroup instead of once per coefficient
+    __shared__ uint4 qtab[3 * 64];
     const uint32_t t = threadIdx.x, img = blockIdx.z;
     const uint32_t W = a.g.width, H = a.g.height;
     const uint8_t* src = a.bgra + static_cast<size_t>(img) * a.image_bytes;
+    if (t < 192u) {
+        const int32_t qv = static_cast<int32_t>(a.qt[static_cast<size_t>(img) * 192u + t]) << 3;
+        qtab[t] = make_uint4(static_cast<uint32_t>(qv - 1), __float_as_uint(__builtin_amdgcn_rcpf(static_cast<float>(qv))),   // 1 ulp is enough
+                             static_cast<uint32_t>(qv >> 1), static_cast<uint32_t>(-qv));
+    }
 
     // ---- phase 1: colour conversion + down-sampling.  Edge expansion = clamped source coordinates (jcsample.c
     //      expand_right_edge, jcprepct.c expand_bottom_edge); chroma rows past the last down-sampled row repeat it ----
@@ -230,12 +241,9 @@ __global__ void __launch_bounds__(256) jpeg_forward_fused_kernel(const FwdArgs a
         }
         wave_lds_sync();
         if (real) {
-            const uint16_t* q = a.qt + (static_cast<size_t>(img) * 3u + c) * 64u;
+            const uint4* q = qtab + c * 64u + lane8;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int32_t qv = static_cast<int32_t>(q[r * 8 + lane8]) << 3;
-                w[r * 8 + lane8] = quantize_coef(o[r], qv, __builtin_amdgcn_rcpf(static_cast<float>(qv)));   // 1 ulp is enough
-            }
+            for (int r = 0; r < 8; ++r) w[r * 8 + lane8] = quantize_coef(o[r], q[r * 8]);
         }
         wave_lds_sync();
         if (real) {
