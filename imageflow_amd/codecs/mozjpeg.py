@@ -2,7 +2,8 @@
 classic preset: Defaults::LibJPEGv6 -> set_fastest_defaults, so no trellis quantisation and no overshoot deringing):
 what libjpeg runs between write_scanlines and the entropy coder -- BGRA -> YCbCr, chroma down-sampling with edge
 expansion, islow forward DCT, quantisation, dummy blocks -- runs in libimageflow_hip.so on frames that stay in HBM.
-The entropy coder (and evalchroma's sampling decision) stay on the host."""
+The entropy coder runs on the device too for the preset's default (baseline, Annex K tables: JpegEntropyStage), on the
+host for its progressive / optimize_coding options (write_jpeg*); evalchroma's sampling decision stays on the host."""
 import ctypes as C
 
 import numpy as np
@@ -91,6 +92,70 @@ class JpegForwardStage:
         try:
             if self._h:
                 _bind().ifhip_jpeg_fwd_stage_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+ENC_BAD_COEFFICIENT, ENC_SCAN_OVERFLOW, ENC_FILE_OVERFLOW = 1, 2, 4     # include/imageflow_hip.h IFHIP_ENC_*
+
+
+class JpegEntropyStage:
+    """ifhip_jpeg_enc_stage: the device entropy coder (csrc/jpeg_encode.hip) -- what compressor.write_scanlines / finish run
+    behind the pixel stage (mozjpeg.rs:155-175) for a baseline file with the Annex K tables: coefficient planes in HBM in,
+    complete files in HBM out."""
+
+    def __init__(self, width, height, h_samp, v_samp, blocks_w, blocks_h, max_images, device="cuda:0", scan_capacity=0):
+        L = _bind()
+        L.ifhip_jpeg_enc_stage_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_uint32, C.c_size_t]
+        L.ifhip_jpeg_enc_stage_destroy.argtypes = [C.c_void_p]
+        L.ifhip_jpeg_enc_stage_destroy.restype = None
+        L.ifhip_jpeg_enc_stage_max_file_bytes.argtypes = [C.c_void_p]
+        L.ifhip_jpeg_enc_stage_max_file_bytes.restype = C.c_size_t
+        L.ifhip_jpeg_encode_batch_device.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p]
+        self.device = torch.device(device)
+        self.ncomp = len(list(blocks_w))
+        self.max_images = max_images
+        self._h = C.c_void_p()
+        pad = [1] * (3 - self.ncomp)
+        hs, vs = np.array(list(h_samp)[:self.ncomp] + pad, np.uint8), np.array(list(v_samp)[:self.ncomp] + pad, np.uint8)
+        bw, bh = np.array(list(blocks_w) + [0] * (3 - self.ncomp), np.uint32), np.array(list(blocks_h) + [0] * (3 - self.ncomp), np.uint32)
+        with torch.cuda.device(self.device):
+            _native.check(L.ifhip_jpeg_enc_stage_create(C.byref(self._h), width, height, self.ncomp, hs.ctypes.data, vs.ctypes.data,
+                                                        bw.ctypes.data, bh.ctypes.data, max_images, scan_capacity))
+        self.max_file_bytes = int(L.ifhip_jpeg_enc_stage_max_file_bytes(self._h))
+
+    def encode_device(self, coef, quality, file_pitch=None, files=None):
+        """coef: 1 or 3 int16 cuda tensors [n, bh_c, bw_c, 64].  Returns (files [n, file_pitch] uint8, lengths [n] int32,
+        status [n] int32), all cuda tensors; nothing is synchronised."""
+        L = _bind()
+        n = coef[0].shape[0]
+        if file_pitch is None:
+            file_pitch = files.shape[1] if files is not None else self.max_file_bytes
+        if files is None:
+            files = torch.empty((n, file_pitch), dtype=torch.uint8, device=self.device)
+        lengths = torch.zeros(n, dtype=torch.int32, device=self.device)
+        status = torch.zeros(n, dtype=torch.int32, device=self.device)
+        ptrs = [c.data_ptr() for c in coef] + [None] * (3 - len(coef))
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _native.check(L.ifhip_jpeg_encode_batch_device(self._h, *ptrs, int(quality), n, files.data_ptr(), file_pitch,
+                                                           lengths.data_ptr(), status.data_ptr(), C.c_void_p(stream)))
+        return files, lengths, status
+
+    def encode(self, coef, quality, file_pitch=None):
+        """The n files as bytes (None for a dropped image) and the status words."""
+        files, lengths, status = self.encode_device(coef, quality, file_pitch)
+        lengths, status = lengths.cpu().numpy(), status.cpu().numpy()
+        host = files[:, :max(int(lengths.max()), 1)].cpu().numpy()
+        return [host[i, :int(k)].tobytes() if k else None for i, k in enumerate(lengths)], [int(s) for s in status]
+
+    def __del__(self):
+        try:
+            if self._h:
+                _bind().ifhip_jpeg_enc_stage_destroy(self._h)
                 self._h = C.c_void_p()
         except Exception:
             pass
@@ -186,13 +251,21 @@ class MozjpegEncoder:
         coef = [c[frame].cpu().numpy() for c in stage.write_frames(bitmap, qt)]
         return write_jpeg(coef, bitmap.w, bitmap.h, hs, vs, self.quality, self.progressive, self.optimize_coding)
 
-    def write_frames(self, bitmap: Bitmap, threads=0):
-        """Every frame of the bitmap: one device launch for the pixel stage, the files coded in parallel on the host."""
+    def write_frames(self, bitmap: Bitmap, threads=0, device_entropy=True):
+        """Every frame of the bitmap: one device launch for the pixel stage; the files coded on the device (the preset's
+        default: baseline, Annex K tables) or -- progressive / optimize_coding, or device_entropy=False -- in parallel on
+        the host.  The two coders write the same bytes."""
         from ..graphics.blend import apply_matte
         apply_matte(bitmap, self.matte)
         bitmap.alpha_meaningful = False
         hs, vs = sampling_factors((2, 2), (2, 2))
         stage = JpegForwardStage(bitmap.w, bitmap.h, hs, vs, bitmap.n, bitmap.data.device)
         qt = torch.from_numpy(np.stack([quant_tables_for_quality(self.quality)] * bitmap.n).view(np.int16)).to(bitmap.data.device)
+        if device_entropy and not self.progressive and not self.optimize_coding:
+            coder = JpegEntropyStage(bitmap.w, bitmap.h, hs, vs, stage.blocks_w, stage.blocks_h, bitmap.n, bitmap.data.device)
+            files, status = coder.encode(stage.write_frames(bitmap, qt), self.quality)
+            if any(status):                                                   # (cannot happen with coefficients of the forward stage)
+                raise RuntimeError(f"device entropy coder dropped images: status {status}")
+            return files
         coef = [c.cpu().numpy() for c in stage.write_frames(bitmap, qt)]
         return write_jpeg_batch(coef, bitmap.w, bitmap.h, hs, vs, self.quality, self.progressive, self.optimize_coding, threads)

@@ -1,0 +1,437 @@
+// jpeg_encode.hip -- gfx950 kernels + C ABI of the device entropy coder: quantised coefficient planes in HBM (what
+// ifhip_jpeg_forward_batch_device leaves) -> complete baseline JPEG files in HBM, byte-identical to the host writer
+// (csrc/jpeg_write.cpp ifhip_jpeg_write_baseline) and so to libjpeg-turbo for the same pixels.
+//
+// Replaces, for the classic preset's default (codecs/mozjpeg.rs:108-129 with neither progressive nor optimize_coding:
+// set_fastest_defaults), the serial loop jchuff.c encode_mcu_huff -> encode_one_block -> emit_bits / emit_byte that
+// compressor.write_scanlines / finish run (mozjpeg.rs:155-175).  Huffman coding is serial only through two running
+// values, and both are prefix sums:
+//   * the bit position of a block = the sum of the code lengths of the blocks before it  -> count pass, scan, write pass;
+//   * the byte position after stuffing = position + the number of 0xFF bytes before it   -> count pass, scan, write pass;
+//   * the DC predictor is the previous block's DC value, which lies in the plane (no running state at all).
+// Launches per batch (all images of a batch in each): count (blocks), scan (per-workgroup bit sums), write (bits into a
+// zeroed big-endian word stream: a lane ORs its first and last word, owns the ones between), count 0xFF (per 4 KiB of the
+// stream), scan, write bytes (stuffed, behind the marker segments; the same pass zeroes the word stream for the next call
+// and writes EOI and the file's length).  Bound by instruction issue of the block walk, not by HBM (coefficients are
+// read twice, 256 B per block; the files are a tenth of that).
+//
+// The block routine and the placement rules live in jpeg_encode_core.hpp, shared with the CPU emulation of the tests.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "common.hpp"
+#include "jpeg_encode_core.hpp"
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(IFHIP_GPU_ERROR, "GpuError: %s failed: %s", #expr, hipGetErrorString(e__));     \
+    } while (0)
+
+namespace ifhip {
+
+// jpeg_write.cpp
+int jpeg_baseline_header(int ncomp, const uint8_t hs[3], const uint8_t vs[3], uint32_t width, uint32_t height,
+                         const uint16_t qt[2][64], std::vector<uint8_t>* out);
+void jpeg_std_encode_tables(uint32_t tabs[4][256]);
+void jpeg_quality_tables(int quality, uint16_t qt[2][64]);
+
+struct EncArgs {
+    EncGeom g;
+    const int16_t* coef[3];
+    size_t plane_blocks[3];         // blocks per image in each plane
+    uint32_t n_images, n_wg;        // n_wg: count / write workgroups per image
+    const uint32_t* tabs;           // [4][256] dc0, ac0, dc1, ac1
+    uint16_t* nbits;                // [n_images][nblocks]
+    uint32_t* wg_bits;              // [n_images][n_wg] sums, then (scan) exclusive prefixes
+    uint32_t* tot_bits;             // [n_images]
+    uint32_t* words;                // [n_images][cap_words] the unstuffed stream, zero between calls
+    size_t cap_words;
+    uint32_t max_chunks;            // cap_words * 4 / kEncChunkBytes
+    uint32_t* ff;                   // [n_images][max_chunks] 0xFF counts per chunk, then exclusive prefixes
+    uint32_t* tot_ff;               // [n_images]
+    uint32_t* status;               // [n_images] what the count pass and the scan found (read by every later pass)
+    uint32_t* status_out;           // [n_images] the caller's copy, written once by the last pass (+ kEncFileOverflow)
+    const uint8_t* header;
+    uint32_t header_len;
+    uint8_t* files;
+    size_t file_pitch;
+    uint32_t* lengths;              // [n_images]
+};
+
+constexpr uint32_t kBlkPitch = 33;  // dwords per staged block in LDS: 64 lanes reading the same coefficient of their own blocks hit 64 banks
+
+struct DeviceStore {
+    __device__ __forceinline__ static void shared(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+    __device__ __forceinline__ static void owned(uint32_t* p, uint32_t v) { *p = v; }
+};
+
+struct LdsCoef {                    // a lane's block in LDS, natural order
+    const int16_t* b;
+    __device__ __forceinline__ int32_t operator()(int k) const { return b[enc_zigzag(k)]; }
+};
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t u = __shfl_up(v, d, 64);
+        if (lane >= static_cast<uint32_t>(d)) v += u;
+    }
+    return v;
+}
+
+// exclusive scan over the T lanes of a workgroup (T a multiple of 64, <= 1024); *total = the sum.  `scratch`: T / 64 + 1 dwords.
+template <uint32_t T>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* scratch, uint32_t* total) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t incl = wave_inclusive_scan(v, lane);
+    __syncthreads();                                       // (scratch may still be read from a previous call)
+    if (lane == 63u) scratch[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, sum = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < T / 64u; ++w) {
+        const uint32_t t = scratch[w];
+        if (w < wave) before += t;
+        sum += t;
+    }
+    *total = sum;
+    return before + incl - v;
+}
+
+// Stage the workgroup's 256 scan-order blocks into LDS with coalesced 16-byte loads (eight lanes per block), tables too.
+// Returns this lane's DC predictor.
+__device__ __forceinline__ int32_t stage_blocks(const EncArgs& a, uint32_t img, uint32_t s0, uint32_t* blk, const int16_t** addr,
+                                                uint32_t* tabs) {
+    const uint32_t tid = threadIdx.x, s = s0 + tid;
+    for (uint32_t i = tid; i < 1024u; i += kEncBlocksPerWg) tabs[i] = a.tabs[i];
+    int32_t pred = 0;
+    const int16_t* mine = nullptr;
+    if (s < a.g.nblocks) {
+        const EncBlockRef r = enc_locate(a.g, s);
+        mine = (r.comp == 0u ? a.coef[0] : r.comp == 1u ? a.coef[1] : a.coef[2])
+               + (static_cast<size_t>(img) * (r.comp == 0u ? a.plane_blocks[0] : r.comp == 1u ? a.plane_blocks[1] : a.plane_blocks[2]) + r.offset) * 64u;
+        const uint32_t ps = enc_predecessor(a.g, s);
+        if (ps != 0xFFFFFFFFu) {
+            const EncBlockRef q = enc_locate(a.g, ps);     // (same component)
+            pred = mine[(static_cast<ptrdiff_t>(q.offset) - static_cast<ptrdiff_t>(r.offset)) * 64];
+        }
+    }
+    addr[tid] = mine;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t it = 0; it < 8u; ++it) {
+        const uint32_t idx = it * kEncBlocksPerWg + tid, b = idx >> 3, piece = idx & 7u;
+        const int16_t* p = addr[b];
+        if (p) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p + piece * 8u);
+            uint32_t* d = blk + b * kBlkPitch + piece * 4u;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+    __syncthreads();
+    return pred;
+}
+
+__global__ __launch_bounds__(256) void enc_count_kernel(const EncArgs a) {
+    __shared__ uint32_t blk[kEncBlocksPerWg * kBlkPitch];
+    __shared__ const int16_t* addr[kEncBlocksPerWg];
+    __shared__ uint32_t tabs[1024];
+    __shared__ uint32_t scratch[8];
+    const uint32_t tid = threadIdx.x, img = blockIdx.y, s0 = blockIdx.x * kEncBlocksPerWg, s = s0 + tid;
+    const int32_t pred = stage_blocks(a, img, s0, blk, addr, tabs);
+    uint32_t bits = 0, bad = 0;
+    if (s < a.g.nblocks) {
+        const uint32_t t = enc_locate(a.g, s).comp ? 512u : 0u;
+        EncCountSink sink;
+        bad = enc_block(LdsCoef{reinterpret_cast<const int16_t*>(blk + tid * kBlkPitch)}, pred, tabs + t, tabs + t + 256u, sink);
+        bits = sink.bits;
+        a.nbits[static_cast<size_t>(img) * a.g.nblocks + s] = static_cast<uint16_t>(bits);
+    }
+    uint32_t total;
+    block_exclusive_scan<256>(bits, scratch, &total);
+    if (tid == 0u) a.wg_bits[static_cast<size_t>(img) * a.n_wg + blockIdx.x] = total;
+    if (bad) atomicOr(a.status + img, kEncBadCoef);
+}
+
+// Exclusive scan, one workgroup of 1024 lanes per image.  mode 0: the n_wg per-workgroup bit sums -> tot_bits (and the
+// capacity check of the word stream); mode 1: the per-chunk 0xFF counts of the image's stream -> tot_ff.
+__global__ __launch_bounds__(1024) void enc_scan_kernel(const EncArgs a, const int mode) {
+    __shared__ uint32_t scratch[20];
+    const uint32_t tid = threadIdx.x, img = blockIdx.x;
+    uint32_t n;
+    uint32_t* v;
+    if (mode == 0) {
+        n = a.n_wg;
+        v = a.wg_bits + static_cast<size_t>(img) * a.n_wg;
+    } else {
+        const uint32_t bytes = a.status[img] ? 0u : (a.tot_bits[img] + 7u) >> 3;
+        n = (bytes + kEncChunkBytes - 1u) / kEncChunkBytes;
+        v = a.ff + static_cast<size_t>(img) * a.max_chunks;
+    }
+    uint32_t carry = 0;
+    bool overflow = false;
+    for (uint32_t base = 0; base < n; base += 1024u) {
+        const uint32_t i = base + tid, x = i < n ? v[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan<1024>(x, scratch, &total);
+        if (i < n) v[i] = carry + ex;
+        overflow |= carry + total < carry;
+        carry += total;
+    }
+    if (tid == 0u) {
+        if (mode == 0) {
+            a.tot_bits[img] = carry;
+            if (overflow || (static_cast<uint64_t>(carry) + 7u) / 8u > a.cap_words * 4u) atomicOr(a.status + img, kEncScanOverflow);
+        } else {
+            a.tot_ff[img] = carry;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void enc_write_kernel(const EncArgs a) {
+    __shared__ uint32_t blk[kEncBlocksPerWg * kBlkPitch];
+    __shared__ const int16_t* addr[kEncBlocksPerWg];
+    __shared__ uint32_t tabs[1024];
+    __shared__ uint32_t scratch[8];
+    const uint32_t tid = threadIdx.x, img = blockIdx.y, s0 = blockIdx.x * kEncBlocksPerWg, s = s0 + tid;
+    if (a.status[img]) return;                             // (uniform: out-of-range coefficient or stream capacity; nothing is written)
+    const int32_t pred = stage_blocks(a, img, s0, blk, addr, tabs);
+    const bool valid = s < a.g.nblocks;
+    const uint32_t mine = valid ? a.nbits[static_cast<size_t>(img) * a.g.nblocks + s] : 0u;
+    uint32_t total;
+    const uint32_t off = a.wg_bits[static_cast<size_t>(img) * a.n_wg + blockIdx.x] + block_exclusive_scan<256>(mine, scratch, &total);
+    if (!valid) return;
+    const uint32_t t = enc_locate(a.g, s).comp ? 512u : 0u;
+    EncWordSink<DeviceStore> sink(a.words + static_cast<size_t>(img) * a.cap_words, off);
+    enc_block(LdsCoef{reinterpret_cast<const int16_t*>(blk + tid * kBlkPitch)}, pred, tabs + t, tabs + t + 256u, sink);
+    if (s == a.g.nblocks - 1u) {                           // jchuff.c flush_bits: the last byte is filled with 1 bits
+        const uint32_t pad = (8u - (sink.n & 7u)) & 7u;
+        if (pad) sink.put((1u << pad) - 1u, pad);
+    }
+    sink.finish();
+}
+
+// the stream bytes of an image: 0 when the image is dropped
+__device__ __forceinline__ uint32_t stream_bytes(const EncArgs& a, uint32_t img) { return a.status[img] ? 0u : (a.tot_bits[img] + 7u) >> 3; }
+
+__global__ __launch_bounds__(256) void enc_ff_count_kernel(const EncArgs a) {
+    __shared__ uint32_t scratch[8];
+    const uint32_t tid = threadIdx.x, img = blockIdx.y;
+    const uint32_t bytes = stream_bytes(a, img), chunks = (bytes + kEncChunkBytes - 1u) / kEncChunkBytes;
+    const uint4* w = reinterpret_cast<const uint4*>(a.words + static_cast<size_t>(img) * a.cap_words);
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        const uint32_t at = chunk * kEncChunkBytes + tid * 16u;
+        uint32_t c = 0;
+        if (at < bytes) {                                  // (bytes behind the stream's end inside the last 16 are zero)
+            const uint4 v = w[at >> 4];
+            c = enc_count_ff(v.x) + enc_count_ff(v.y) + enc_count_ff(v.z) + enc_count_ff(v.w);
+        }
+        uint32_t total;
+        block_exclusive_scan<256>(c, scratch, &total);
+        if (tid == 0u) a.ff[static_cast<size_t>(img) * a.max_chunks + chunk] = total;
+    }
+}
+
+__global__ __launch_bounds__(256) void enc_stuff_kernel(const EncArgs a) {
+    __shared__ uint32_t scratch[8];
+    const uint32_t tid = threadIdx.x, img = blockIdx.y;
+    const uint32_t st = a.status[img];
+    // (a dropped image has written no word, its stream is still zero; nothing to clean)
+    const uint32_t bytes = st ? 0u : (a.tot_bits[img] + 7u) >> 3, chunks = (bytes + kEncChunkBytes - 1u) / kEncChunkBytes;
+    const uint64_t file_len = static_cast<uint64_t>(a.header_len) + bytes + a.tot_ff[img] + 2u;
+    const bool fits = !st && file_len <= a.file_pitch;
+    uint4* w = reinterpret_cast<uint4*>(a.words + static_cast<size_t>(img) * a.cap_words);
+    uint8_t* out = a.files + static_cast<size_t>(img) * a.file_pitch;
+    if (blockIdx.x == 0u) {
+        if (fits) {
+            for (uint32_t i = tid; i < a.header_len; i += 256u) out[i] = a.header[i];
+            if (tid == 0u) { out[file_len - 2u] = 0xFF; out[file_len - 1u] = 0xD9; }
+        }
+        if (tid == 0u) {
+            a.lengths[img] = fits ? static_cast<uint32_t>(file_len) : 0u;
+            if (a.status_out) a.status_out[img] = st | (!fits && !st ? kEncFileOverflow : 0u);
+        }
+    }
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        const uint32_t at = chunk * kEncChunkBytes + tid * 16u;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t c = 0;
+        if (at < bytes) {
+            v = w[at >> 4];
+            w[at >> 4] = make_uint4(0u, 0u, 0u, 0u);       // the stream is zero again for the next call
+            c = enc_count_ff(v.x) + enc_count_ff(v.y) + enc_count_ff(v.z) + enc_count_ff(v.w);
+        }
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan<256>(c, scratch, &total);
+        if (fits && at < bytes) {
+            uint8_t* d = out + a.header_len + at + a.ff[static_cast<size_t>(img) * a.max_chunks + chunk] + ex;
+            const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t nb = bytes - at < 16u ? bytes - at : 16u;
+#pragma unroll
+            for (uint32_t j = 0; j < 16u; ++j) {
+                if (j < nb) {
+                    const uint32_t b = (ws[j >> 2] >> (8u * (j & 3u))) & 255u;
+                    *d++ = static_cast<uint8_t>(b);
+                    if (b == 255u) *d++ = 0u;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace ifhip
+
+using namespace ifhip;
+
+struct ifhip_jpeg_enc_stage {
+    EncGeom g;
+    uint32_t width = 0, height = 0;
+    uint8_t hs[3] = {1, 1, 1}, vs[3] = {1, 1, 1};
+    size_t plane_blocks[3] = {0, 0, 0};
+    uint32_t max_images = 0, n_wg = 0, max_chunks = 0;
+    size_t cap_words = 0;
+    int device = -1;
+    int header_quality = -1;
+    uint32_t header_len = 0;
+    // device buffers
+    uint32_t* d_tabs = nullptr;
+    uint16_t* d_nbits = nullptr;
+    uint32_t *d_wg_bits = nullptr, *d_tot_bits = nullptr, *d_words = nullptr, *d_ff = nullptr, *d_tot_ff = nullptr, *d_status = nullptr;
+    uint8_t* d_header = nullptr;
+    uint8_t* h_header = nullptr;    // pinned
+    ~ifhip_jpeg_enc_stage() {
+        (void)hipFree(d_tabs); (void)hipFree(d_nbits); (void)hipFree(d_wg_bits); (void)hipFree(d_tot_bits); (void)hipFree(d_words);
+        (void)hipFree(d_ff); (void)hipFree(d_tot_ff); (void)hipFree(d_status); (void)hipFree(d_header);
+        if (h_header) (void)hipHostFree(h_header);
+    }
+};
+
+namespace {
+constexpr uint32_t kHeaderCap = 1024;
+
+int make_enc_geom(uint32_t width, uint32_t height, int ncomp, const uint8_t* hs, const uint8_t* vs, const uint32_t* bw, const uint32_t* bh,
+                  EncGeom* g) {
+    switch (enc_make_geom(width, height, ncomp, hs, vs, bw, bh, g)) {
+    case 0: return IFHIP_OK;
+    case 1: return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: 1 or 3 components, sampling factors 1..2, 1..65535 pixels per side");
+    case 2: return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: a coefficient plane is smaller than the MCU grid");
+    default: return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: more than %llu blocks per image (32-bit bit positions)",
+                         static_cast<unsigned long long>((1ull << 32) / kEncMaxBitsPerBlock));
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int ifhip_jpeg_enc_stage_create(ifhip_jpeg_enc_stage** stage, uint32_t width, uint32_t height, int n_components, const uint8_t* h_samp,
+                                const uint8_t* v_samp, const uint32_t* blocks_w3, const uint32_t* blocks_h3, uint32_t max_images,
+                                size_t scan_capacity) {
+    if (!stage) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null stage out-pointer");
+    *stage = nullptr;
+    if (!h_samp || !v_samp || !blocks_w3 || !blocks_h3) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
+    if (max_images == 0 || max_images > 65535u) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: 1..65535 images per stage");
+    std::unique_ptr<ifhip_jpeg_enc_stage> s(new ifhip_jpeg_enc_stage);
+    int rc = make_enc_geom(width, height, n_components, h_samp, v_samp, blocks_w3, blocks_h3, &s->g);
+    if (rc) return rc;
+    s->width = width; s->height = height;
+    for (int c = 0; c < n_components; ++c) {
+        s->hs[c] = static_cast<uint8_t>(s->g.H[c]); s->vs[c] = static_cast<uint8_t>(s->g.V[c]);
+        s->plane_blocks[c] = static_cast<size_t>(blocks_w3[c]) * blocks_h3[c];
+    }
+    s->n_wg = (s->g.nblocks + kEncBlocksPerWg - 1u) / kEncBlocksPerWg;
+    // the unstuffed stream of an image: the caller's bound, or the most the geometry can produce (1 665 bits per block)
+    const uint64_t worst = (static_cast<uint64_t>(s->g.nblocks) * kEncMaxBitsPerBlock + 7u) / 8u;
+    uint64_t cap = scan_capacity ? std::min<uint64_t>(scan_capacity, worst) : worst;
+    cap = (cap + kEncChunkBytes - 1u) / kEncChunkBytes * kEncChunkBytes + kEncChunkBytes;      // whole chunks, one to spare
+    s->cap_words = static_cast<size_t>(cap / 4u);
+    s->max_chunks = static_cast<uint32_t>(cap / kEncChunkBytes);
+    if (hipGetDevice(&s->device) != hipSuccess)
+        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device; this library has no CPU path");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: device %d is %s, this library is built for gfx950 only", s->device, prop.gcnArchName);
+    s->max_images = max_images;
+    const size_t n = max_images;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_tabs), 4096));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_nbits), n * s->g.nblocks * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_wg_bits), n * s->n_wg * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_tot_bits), n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_words), n * s->cap_words * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_ff), n * s->max_chunks * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_tot_ff), n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_status), n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_header), kHeaderCap));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_header), kHeaderCap, hipHostMallocDefault));
+    uint32_t tabs[4][256];
+    jpeg_std_encode_tables(tabs);
+    HIP_TRY(hipMemcpy(s->d_tabs, tabs, sizeof tabs, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(s->d_words, 0, n * s->cap_words * sizeof(uint32_t)));       // the stuffing pass keeps it zero from here on
+    *stage = s.release();
+    return IFHIP_OK;
+}
+
+void ifhip_jpeg_enc_stage_destroy(ifhip_jpeg_enc_stage* stage) { delete stage; }
+
+size_t ifhip_jpeg_enc_stage_max_file_bytes(const ifhip_jpeg_enc_stage* stage) {
+    // marker segments + the stream with every byte stuffed + EOI
+    return stage ? static_cast<size_t>(kHeaderCap) + 2u * (stage->cap_words * 4u - kEncChunkBytes) + 2u : 0u;
+}
+
+int ifhip_jpeg_encode_batch_device(ifhip_jpeg_enc_stage* stage, const int16_t* d_coef0, const int16_t* d_coef1, const int16_t* d_coef2,
+                                   int quality, uint32_t n_images, uint8_t* d_files, size_t file_pitch, uint32_t* d_lengths,
+                                   uint32_t* d_status, void* hip_stream) {
+    if (!stage) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null stage");
+    if (n_images == 0) return IFHIP_OK;
+    if (n_images > stage->max_images) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: %u images exceed the stage capacity %u", n_images, stage->max_images);
+    if (!d_coef0 || (stage->g.ncomp == 3 && (!d_coef1 || !d_coef2)) || !d_files || !d_lengths)
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
+    if ((reinterpret_cast<uintptr_t>(d_coef0) | reinterpret_cast<uintptr_t>(d_coef1) | reinterpret_cast<uintptr_t>(d_coef2)) & 15u)
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: coefficient planes must be 16-byte aligned");
+    if (file_pitch < kHeaderCap) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: file_pitch below %u bytes", kHeaderCap);
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != stage->device) return fail(IFHIP_INVALID_STATE, "InvalidState: stage belongs to device %d, current device is %d", stage->device, dev);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (quality != stage->header_quality) {
+        uint16_t qt[2][64];
+        jpeg_quality_tables(quality, qt);
+        std::vector<uint8_t> h;
+        int rc = jpeg_baseline_header(static_cast<int>(stage->g.ncomp), stage->hs, stage->vs, stage->width, stage->height, qt, &h);
+        if (rc) return rc;
+        if (h.size() > kHeaderCap) return fail(IFHIP_INVALID_STATE, "InvalidState: marker segments of %zu bytes", h.size());
+        HIP_TRY(hipStreamSynchronize(st));                 // (the pinned copy may still be on its way to the device from the previous call)
+        std::memcpy(stage->h_header, h.data(), h.size());
+        stage->header_len = static_cast<uint32_t>(h.size());
+        HIP_TRY(hipMemcpyAsync(stage->d_header, stage->h_header, h.size(), hipMemcpyHostToDevice, st));
+        stage->header_quality = quality;
+    }
+    EncArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.g = stage->g;
+    a.coef[0] = d_coef0; a.coef[1] = d_coef1; a.coef[2] = d_coef2;
+    for (int c = 0; c < 3; ++c) a.plane_blocks[c] = stage->plane_blocks[c];
+    a.n_images = n_images; a.n_wg = stage->n_wg; a.tabs = stage->d_tabs; a.nbits = stage->d_nbits; a.wg_bits = stage->d_wg_bits;
+    a.tot_bits = stage->d_tot_bits; a.words = stage->d_words; a.cap_words = stage->cap_words; a.max_chunks = stage->max_chunks;
+    a.ff = stage->d_ff; a.tot_ff = stage->d_tot_ff; a.status = stage->d_status; a.header = stage->d_header; a.header_len = stage->header_len;
+    a.files = d_files; a.file_pitch = file_pitch; a.lengths = d_lengths; a.status_out = d_status;
+    HIP_TRY(hipMemsetAsync(stage->d_status, 0, n_images * sizeof(uint32_t), st));
+    const dim3 blocks_grid(stage->n_wg, n_images);
+    const dim3 chunk_grid(std::min<uint32_t>(stage->max_chunks, 256u), n_images);
+    hipLaunchKernelGGL(enc_count_kernel, blocks_grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(enc_scan_kernel, dim3(n_images), dim3(1024), 0, st, a, 0);
+    hipLaunchKernelGGL(enc_write_kernel, blocks_grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(enc_ff_count_kernel, chunk_grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(enc_scan_kernel, dim3(n_images), dim3(1024), 0, st, a, 1);
+    hipLaunchKernelGGL(enc_stuff_kernel, chunk_grid, dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return IFHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// jpeg_encode_core.hpp -- the arithmetic of the device entropy coder (csrc/jpeg_encode.hip), written so that it compiles
+// for the gfx950 kernels AND for a plain host compiler: tests/enc_emulate.cpp runs the same block routine, the same scan
+// order and the same bit / byte placement rules lane by lane on the CPU and compares the file with the host writer's
+// (csrc/jpeg_write.cpp, byte-identical to libjpeg-turbo) -- test infrastructure; the product has one path, the kernels.
+//
+// What is coded: jchuff.c encode_one_block (sequential Huffman, baseline) for the interleaved single scan that
+// MozjpegEncoder::write_frame produces with Defaults::LibJPEGv6 (codecs/mozjpeg.rs:108-112: set_fastest_defaults --
+// Annex K tables, no optimisation, not progressive, no restart markers).
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define IFHIP_HD __host__ __device__ __forceinline__
+#else
+#define IFHIP_HD inline
+#endif
+
+namespace ifhip {
+
+// Geometry of one image's scan.  A block's scan index s = MCU index * blocks per MCU + position inside the MCU
+// (jccoefct.c compress_data: components in order, each H x V blocks row-major); planes are [rows][pitch][64] int16,
+// natural coefficient order, MCU padded (the layout ifhip_jpeg_forward_batch_device leaves).
+struct EncGeom {
+    uint32_t ncomp, bpm, mcus_w, mcus_h, nblocks;
+    uint32_t H[3], V[3], pitch[3], rows[3];
+    uint32_t first[3];          // position inside the MCU of the component's first block
+    uint64_t layout;            // four bits per position inside the MCU: component | dx << 2 | dy << 3
+};
+
+// (an index that differs from lane to lane selects among registers; it never addresses the argument block)
+IFHIP_HD uint32_t enc_sel3(const uint32_t (&v)[3], uint32_t c) { return c == 0u ? v[0] : c == 1u ? v[1] : v[2]; }
+
+struct EncBlockRef { uint32_t comp, offset; };      // offset in blocks inside the component's plane
+
+IFHIP_HD EncBlockRef enc_locate(const EncGeom& g, uint32_t s) {
+    const uint32_t m = s / g.bpm, j = s - m * g.bpm;
+    const uint32_t my = m / g.mcus_w, mx = m - my * g.mcus_w;
+    const uint32_t e = static_cast<uint32_t>(g.layout >> (4u * j)) & 15u, c = e & 3u, dx = (e >> 2) & 1u, dy = e >> 3;
+    return EncBlockRef{c, (my * enc_sel3(g.V, c) + dy) * enc_sel3(g.pitch, c) + mx * enc_sel3(g.H, c) + dx};
+}
+
+// scan index of the block whose DC value predicts block s (the component's previous block in scan order); 0xFFFFFFFF:
+// none, the predictor is 0 (first MCU; jchuff.c start_pass_huff: last_dc_val = 0)
+IFHIP_HD uint32_t enc_predecessor(const EncGeom& g, uint32_t s) {
+    const uint32_t m = s / g.bpm, j = s - m * g.bpm;
+    const uint32_t c = static_cast<uint32_t>(g.layout >> (4u * j)) & 3u;
+    if (j != enc_sel3(g.first, c)) return s - 1u;
+    if (m == 0u) return 0xFFFFFFFFu;
+    return s - g.bpm + enc_sel3(g.H, c) * enc_sel3(g.V, c) - 1u;
+}
+
+// Host: the geometry of a scan from the frame size, the sampling factors (1 or 2; a single component counts as 1x1,
+// jcmaster.c) and the planes' sizes in blocks.  0: fine; 1: unsupported factors / sizes; 2: a plane smaller than the MCU
+// grid; 3: too many blocks for 32-bit bit positions.
+constexpr uint32_t kEncMaxBitsPerBlock = 16 + 11 + 63 * (16 + 10);
+inline int enc_make_geom(uint32_t width, uint32_t height, int ncomp, const uint8_t* hs, const uint8_t* vs, const uint32_t* bw,
+                         const uint32_t* bh, EncGeom* g) {
+    if ((ncomp != 1 && ncomp != 3) || width == 0 || height == 0 || width > 65535u || height > 65535u) return 1;
+    *g = EncGeom{};
+    g->ncomp = static_cast<uint32_t>(ncomp);
+    uint32_t hmax = 1, vmax = 1;
+    for (int c = 0; c < ncomp; ++c) {
+        const uint32_t H = ncomp == 3 ? hs[c] : 1u, V = ncomp == 3 ? vs[c] : 1u;
+        if (H < 1 || H > 2 || V < 1 || V > 2) return 1;
+        g->H[c] = H; g->V[c] = V;
+        hmax = H > hmax ? H : hmax; vmax = V > vmax ? V : vmax;
+    }
+    g->mcus_w = (width + 8u * hmax - 1u) / (8u * hmax);
+    g->mcus_h = (height + 8u * vmax - 1u) / (8u * vmax);
+    uint32_t j = 0;
+    for (int c = 0; c < ncomp; ++c) {
+        g->first[c] = j;
+        for (uint32_t y = 0; y < g->V[c]; ++y)
+            for (uint32_t x = 0; x < g->H[c]; ++x, ++j)
+                g->layout |= static_cast<uint64_t>(static_cast<uint32_t>(c) | x << 2 | y << 3) << (4u * j);
+        g->pitch[c] = bw[c]; g->rows[c] = bh[c];
+        if (bw[c] < g->mcus_w * g->H[c] || bh[c] < g->mcus_h * g->V[c]) return 2;
+    }
+    g->bpm = j;
+    const uint64_t nb = static_cast<uint64_t>(g->mcus_w) * g->mcus_h * j;
+    if (nb * kEncMaxBitsPerBlock >= (1ull << 32)) return 3;
+    g->nblocks = static_cast<uint32_t>(nb);
+    return 0;
+}
+
+// jpeg_natural_order
+#define IFHIP_ZIGZAG_LIST                                                                                              \
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35,   \
+        42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63
+
+IFHIP_HD int enc_zigzag(int k) {
+    constexpr int t[64] = {IFHIP_ZIGZAG_LIST};
+    return t[k];
+}
+
+IFHIP_HD uint32_t enc_nbits(uint32_t t) { return t ? 32u - static_cast<uint32_t>(__builtin_clz(t)) : 0u; }
+
+// Sinks: put(code, length) with length <= 32 and `code` < 2^length.
+struct EncCountSink {
+    uint32_t bits = 0;
+    IFHIP_HD void put(uint32_t, uint32_t len) { bits += len; }
+};
+
+// Bits go into a stream of big-endian 32-bit words that starts zeroed.  A lane's first word and its last, partial word
+// are shared with its neighbours in the stream (OR into the word: Store::shared); the words between belong to it alone.
+template <class Store>
+struct EncWordSink {
+    uint64_t acc = 0;
+    uint32_t n;                 // bits waiting in acc (< 32 between calls); starts at the bit offset inside the first word
+    uint32_t* p;
+    bool first = true;
+    IFHIP_HD EncWordSink(uint32_t* words, uint32_t bit_offset) : n(bit_offset & 31u), p(words + (bit_offset >> 5)) {}
+    IFHIP_HD void put(uint32_t code, uint32_t len) {
+        acc = (acc << len) | code;
+        n += len;
+        if (n >= 32u) {
+            const uint32_t w = static_cast<uint32_t>(acc >> (n - 32u));
+            n -= 32u;
+            if (first) Store::shared(p, __builtin_bswap32(w));
+            else Store::owned(p, __builtin_bswap32(w));
+            first = false;
+            ++p;
+        }
+    }
+    IFHIP_HD void finish() {
+        if (n) Store::shared(p, __builtin_bswap32(static_cast<uint32_t>(acc << (32u - n))));
+    }
+};
+
+// jchuff.c encode_one_block.  coef(k): the coefficient at zigzag position k; dct / act: 256 entries `code | length << 16`
+// (jpeg_make_c_derived_tbl; a symbol the table does not have is 0).  Returns nonzero when a coefficient needs more
+// magnitude bits than 8-bit JPEG has (JERR_BAD_DCT_COEF: 11 for the DC difference, 10 for an AC coefficient) -- the
+// bits put are then meaningless but their count stays the same in every pass.
+template <class Coef, class Sink>
+IFHIP_HD uint32_t enc_block(const Coef& coef, int32_t pred, const uint32_t* dct, const uint32_t* act, Sink& sink) {
+    uint32_t bad = 0;
+    {
+        const int32_t diff = coef(0) - pred;
+        const uint32_t t = static_cast<uint32_t>(diff < 0 ? -diff : diff), t2 = static_cast<uint32_t>(diff < 0 ? diff - 1 : diff);
+        uint32_t nb = enc_nbits(t);
+        if (nb > 11u) { bad = 1u; nb = 11u; }
+        const uint32_t cs = dct[nb];
+        sink.put(((cs & 0xffffu) << nb) | (t2 & ((1u << nb) - 1u)), (cs >> 16) + nb);
+    }
+    const uint32_t zrl = act[0xF0], eob = act[0];
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 1; k < 64; ++k) {
+        const int32_t v = coef(k);
+        if (v != 0) {
+            for (; run > 15u; run -= 16u) sink.put(zrl & 0xffffu, zrl >> 16);
+            const uint32_t t = static_cast<uint32_t>(v < 0 ? -v : v), t2 = static_cast<uint32_t>(v < 0 ? v - 1 : v);
+            uint32_t nb = enc_nbits(t);
+            if (nb > 10u) { bad = 1u; nb = 10u; }
+            const uint32_t cs = act[(run << 4) + nb];
+            sink.put(((cs & 0xffffu) << nb) | (t2 & ((1u << nb) - 1u)), (cs >> 16) + nb);
+            run = 0;
+        } else {
+            ++run;
+        }
+    }
+    if (run) sink.put(eob & 0xffffu, eob >> 16);
+    return bad;
+}
+
+// number of 0xFF bytes in a word
+IFHIP_HD uint32_t enc_count_ff(uint32_t w) {
+    uint32_t m = w & (w >> 4);
+    m &= m >> 2;
+    m &= m >> 1;
+    return static_cast<uint32_t>(__builtin_popcount(m & 0x01010101u));
+}
+
+constexpr uint32_t kEncBlocksPerWg = 256;           // scan-order blocks per workgroup of the count / write passes
+constexpr uint32_t kEncChunkBytes = 4096;           // unstuffed stream bytes per workgroup step of the stuffing passes
+// status bits per image
+constexpr uint32_t kEncBadCoef = 1, kEncScanOverflow = 2, kEncFileOverflow = 4;
+
+}  // namespace ifhip

@@ -533,6 +533,54 @@ int jpeg_write(const int16_t* const coef[3], const uint32_t bw[3], const uint32_
     return IFHIP_OK;
 }
 
+// For the device coder (csrc/jpeg_encode.hip): the Annex K tables in encode form (dc0, ac0, dc1, ac1) and the marker
+// segments jpeg_write puts in front of a baseline file's scan -- SOI, JFIF APP0, DQT per table, SOF0, the DHT segments of the
+// scan's components in jcmarker.c's order, SOS (tests compare whole files of the two coders).
+void jpeg_std_encode_tables(uint32_t tabs[4][256]) {
+    EncTab t[4];
+    build(kDcLumaBits, kDcVals, &t[0]); build(kAcLumaBits, kAcLumaVals, &t[1]);
+    build(kDcChromaBits, kDcVals, &t[2]); build(kAcChromaBits, kAcChromaVals, &t[3]);
+    for (int i = 0; i < 4; ++i) std::memcpy(tabs[i], t[i].cs, sizeof t[i].cs);
+}
+
+int jpeg_baseline_header(int ncomp, const uint8_t hs[3], const uint8_t vs[3], uint32_t width, uint32_t height, const uint16_t qt[2][64],
+                         std::vector<uint8_t>* out) {
+    if (!out || (ncomp != 1 && ncomp != 3) || width == 0 || height == 0 || width > 65535u || height > 65535u)
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: jpeg header geometry");
+    std::vector<uint8_t>& o = *out;
+    o.clear();
+    o.push_back(0xFF); o.push_back(0xD8);
+    marker(o, 0xE0, {'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0});
+    for (int t = 0; t < (ncomp == 3 ? 2 : 1); ++t) {
+        std::vector<uint8_t> b(65);
+        b[0] = static_cast<uint8_t>(t);
+        for (int i = 0; i < 64; ++i) b[1 + i] = static_cast<uint8_t>(qt[t][kZigzag[i]]);
+        marker(o, 0xDB, b);
+    }
+    {
+        std::vector<uint8_t> b = {8, static_cast<uint8_t>(height >> 8), static_cast<uint8_t>(height), static_cast<uint8_t>(width >> 8),
+                                  static_cast<uint8_t>(width), static_cast<uint8_t>(ncomp)};
+        for (int c = 0; c < ncomp; ++c) { b.push_back(static_cast<uint8_t>(c + 1)); b.push_back(static_cast<uint8_t>((hs[c] << 4) | vs[c])); b.push_back(c ? 1 : 0); }
+        marker(o, 0xC0, b);
+    }
+    for (int t = 0; t < (ncomp == 3 ? 2 : 1); ++t) {
+        for (int cls = 0; cls < 2; ++cls) {
+            const uint8_t* bits = cls ? (t ? kAcChromaBits : kAcLumaBits) : (t ? kDcChromaBits : kDcLumaBits);
+            const uint8_t* vals = cls ? (t ? kAcChromaVals : kAcLumaVals) : kDcVals;
+            std::vector<uint8_t> b;
+            b.push_back(static_cast<uint8_t>((cls << 4) | t));
+            for (int l = 1; l <= 16; ++l) b.push_back(bits[l]);
+            b.insert(b.end(), vals, vals + (cls ? 162 : 12));
+            marker(o, 0xC4, b);
+        }
+    }
+    std::vector<uint8_t> b = {static_cast<uint8_t>(ncomp)};
+    for (int c = 0; c < ncomp; ++c) { b.push_back(static_cast<uint8_t>(c + 1)); b.push_back(static_cast<uint8_t>(c ? 0x11 : 0x00)); }
+    b.push_back(0); b.push_back(63); b.push_back(0);
+    marker(o, 0xDA, b);
+    return IFHIP_OK;
+}
+
 int jpeg_write_baseline(const int16_t* const coef[3], const uint32_t bw[3], const uint32_t bh[3], int ncomp, const uint8_t hs[3],
                         const uint8_t vs[3], uint32_t width, uint32_t height, const uint16_t qt[2][64], std::vector<uint8_t>* out) {
     return jpeg_write(coef, bw, bh, ncomp, hs, vs, width, height, qt, 0, out);
@@ -541,6 +589,21 @@ int jpeg_write_baseline(const int16_t* const coef[3], const uint32_t bw[3], cons
 }  // namespace ifhip
 
 extern "C" {
+int ifhip_jpeg_debug_encode_tables(uint32_t* tabs4x256, int n_components, const uint8_t* h_samp, const uint8_t* v_samp, uint32_t width,
+                                   uint32_t height, int quality, uint8_t* header, size_t capacity, size_t* header_len) {
+    if (!tabs4x256 || !header_len) return ifhip::fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
+    ifhip::jpeg_std_encode_tables(reinterpret_cast<uint32_t(*)[256]>(tabs4x256));
+    uint16_t qt[2][64];
+    ifhip::jpeg_quality_tables(quality, qt);
+    std::vector<uint8_t> h;
+    const uint8_t ones[3] = {1, 1, 1};
+    int rc = ifhip::jpeg_baseline_header(n_components, h_samp ? h_samp : ones, v_samp ? v_samp : ones, width, height, qt, &h);
+    if (rc) return rc;
+    *header_len = h.size();
+    if (header && capacity >= h.size()) std::memcpy(header, h.data(), h.size());
+    return IFHIP_OK;
+}
+
 int ifhip_jpeg_quality_tables(int quality, uint16_t* qt2x64) {
     if (!qt2x64) return ifhip::fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
     ifhip::jpeg_quality_tables(quality, reinterpret_cast<uint16_t(*)[64]>(qt2x64));

@@ -281,6 +281,37 @@ IFHIP_API int ifhip_jpeg_write_batch(const int16_t* coef0, const int16_t* coef1,
                                      int quality, int flags, uint32_t n_images, uint32_t threads,
                                      uint8_t* out, size_t capacity, size_t* offsets, size_t* lengths, size_t* total);
 
+/* Device entropy coder: the same baseline files without the host loop.  Replaces, for the classic preset's default
+ * (codecs/mozjpeg.rs:108-129 with neither progressive nor optimize_coding), what compressor.write_scanlines / finish
+ * (mozjpeg.rs:155-175) run behind the pixel stage: jchuff.c encode_mcu_huff / encode_one_block / emit_bits with byte
+ * stuffing, and jcmarker.c's segments around the scan.  Coefficient planes stay in HBM ([n_images][bh_c][bw_c][64], the
+ * layout ifhip_jpeg_forward_batch_device leaves); image i's file is written to d_files + i * file_pitch and its length to
+ * d_lengths[i] -- 0 when the image was dropped, with the reason in d_status[i] (nullable): IFHIP_ENC_BAD_COEFFICIENT (a
+ * coefficient with more magnitude bits than 8-bit JPEG codes: JERR_BAD_DCT_COEF), IFHIP_ENC_SCAN_OVERFLOW (the scan is
+ * longer than the stage's scan_capacity), IFHIP_ENC_FILE_OVERFLOW (the file is longer than file_pitch).  Asynchronous on
+ * hip_stream.  scan_capacity: bound of an image's entropy-coded bytes before stuffing, 0 = the most the geometry can
+ * produce (208 bytes per block), with which no image is ever dropped for the scan's length.  Files are byte-identical to
+ * ifhip_jpeg_write_baseline's for the same coefficients and quality. */
+#define IFHIP_ENC_BAD_COEFFICIENT 1
+#define IFHIP_ENC_SCAN_OVERFLOW 2
+#define IFHIP_ENC_FILE_OVERFLOW 4
+typedef struct ifhip_jpeg_enc_stage ifhip_jpeg_enc_stage;
+IFHIP_API int ifhip_jpeg_enc_stage_create(ifhip_jpeg_enc_stage** stage, uint32_t width, uint32_t height, int n_components,
+                                          const uint8_t* h_samp, const uint8_t* v_samp, const uint32_t* blocks_w3,
+                                          const uint32_t* blocks_h3, uint32_t max_images, size_t scan_capacity);
+IFHIP_API void ifhip_jpeg_enc_stage_destroy(ifhip_jpeg_enc_stage* stage);
+/* a file_pitch with which no file overflows (marker segments + every stream byte stuffed + EOI) */
+IFHIP_API size_t ifhip_jpeg_enc_stage_max_file_bytes(const ifhip_jpeg_enc_stage* stage);
+IFHIP_API int ifhip_jpeg_encode_batch_device(ifhip_jpeg_enc_stage* stage, const int16_t* d_coef0, const int16_t* d_coef1,
+                                             const int16_t* d_coef2, int quality, uint32_t n_images, uint8_t* d_files,
+                                             size_t file_pitch, uint32_t* d_lengths, uint32_t* d_status, void* hip_stream);
+
+/* Host, for tests: what the device coder works from -- the Annex K Huffman tables in encode form (dc0, ac0, dc1, ac1; 256
+ * entries `code | length << 16`) and the marker segments in front of the scan (SOI ... SOS). */
+IFHIP_API int ifhip_jpeg_debug_encode_tables(uint32_t* tabs4x256, int n_components, const uint8_t* h_samp, const uint8_t* v_samp,
+                                             uint32_t width, uint32_t height, int quality, uint8_t* header, size_t capacity,
+                                             size_t* header_len);
+
 /* imageflow's 8x8 -> NxN spatial block scalers for the luma plane of a scaled decode: replaces
  * flow_scale_spatial[_srgb]_{1..7}x{1..7} (c_components/lib/codecs_jpeg_idct_fast.c, .h:17-43), the functions the IDCT
  * method selector installs for component 1 (codec_jpeg_wrapper.c:274-343).  `srgb` selects the linear-light variants.
