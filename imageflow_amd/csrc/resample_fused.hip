@@ -145,9 +145,13 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     // number of loads in flight is known statically and the compiler can wait with vmcnt(D-1) instead of vmcnt(0)
     const uint32_t quad = lane_on ? tid : n_groups - 1u;
     // bytes per source pixel in the plane(s) read: 4 (BGRA) or 1 (one of three component planes)
-    const size_t src_off = static_cast<size_t>(img) * a.in_image_bytes
-                           + static_cast<size_t>(strip.cx0 + static_cast<uint32_t>(PX) * quad) * (YCC ? 1u : 4u);
-    const uint8_t* src = a.in + src_off;
+    // A row's address = (frame + strip + row), all wave-uniform (a frame slot is whole waves: block_for) and left to the
+    // scalar unit, + this lane's columns, a 32-bit offset: the load takes base and offset as they are, no vector
+    // instruction forms an address (the 64-bit multiply-add the compiler otherwise emits per row issues at a quarter rate).
+    constexpr uint32_t BPP = YCC ? 1u : 4u;
+    const uint32_t img_u = __builtin_amdgcn_readfirstlane(img);
+    const uint8_t* src = a.in + (static_cast<size_t>(img_u) * a.in_image_bytes + static_cast<size_t>(strip.cx0) * BPP);
+    const uint32_t lane_off0 = static_cast<uint32_t>(PX) * quad * BPP;
 
     // Ring accumulators and converted samples live as float2 pairs over the flattened (pixel, channel) index
     // f = p*C + c, so that the vertical pass issues v_pk_fma_f32 (two IEEE fmaf per instruction, the weight broadcast
@@ -192,17 +196,26 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     typedef std::conditional_t<YCC, YccRaw, bgra_raw_t> raw_t;
     auto fetch_row = [&](int y) -> raw_t {                               // y is wave-uniform; -1 = nothing needed
         const uint32_t yy = y < 0 ? 0u : static_cast<uint32_t>(y);      // (row 0 is re-read: stays in L2)
-        const size_t ro = static_cast<size_t>(yy) * a.in_stride;
+        // (pinned to scalar registers: otherwise the lane offset is folded into the base and the row term comes back as
+        // a vector 64-bit multiply-add)
+        uint64_t rowp = reinterpret_cast<uint64_t>(src) + static_cast<uint64_t>(yy) * a.in_stride;
+        asm("" : "+s"(rowp));
+        uint32_t lane_off = lane_off0;                                  // (re-made here, in the load's own basic block: instruction
+        asm("" : "+v"(lane_off));                                       // selection only then sees "scalar base + 32-bit lane offset")
         // source frames are streamed exactly once: non-temporal loads keep them from displacing the tables in L2
         // (measured -1.7% kernel time, profiles/r1_notes.md)
+        // (global address space spelled out: a pointer made from an integer is a flat one, and flat loads count on lgkmcnt too)
+        typedef __attribute__((address_space(1))) const uint8_t gbyte;
+        typedef __attribute__((address_space(1))) const uint32_t gword;
+        typedef __attribute__((address_space(1))) const bgra_raw_t graw;
+        gbyte* py = reinterpret_cast<gbyte*>(rowp);
         if constexpr (YCC) {
-            // one 64-bit multiply-add (quarter rate) for the row, the other two planes by their (wave-uniform) distance
-            const uint8_t* py = src + ro;
-            return YccRaw{__builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(py)),
-                          __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(py + (a.in_cb - a.in))),
-                          __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(py + (a.in_cr - a.in)))};
+            // (the other two planes by their wave-uniform distance)
+            return YccRaw{__builtin_nontemporal_load(reinterpret_cast<gword*>(py + lane_off)),
+                          __builtin_nontemporal_load(reinterpret_cast<gword*>(py + (a.in_cb - a.in) + lane_off)),
+                          __builtin_nontemporal_load(reinterpret_cast<gword*>(py + (a.in_cr - a.in) + lane_off))};
         } else {
-            return __builtin_nontemporal_load(reinterpret_cast<const bgra_raw_t*>(src + ro));
+            return __builtin_nontemporal_load(reinterpret_cast<graw*>(py + lane_off));
         }
     };
 
