@@ -342,6 +342,7 @@ struct imageflow_context {
     std::atomic<bool> cancel{false};
     std::atomic<int64_t> poll_countdown{INT64_MAX};
     std::atomic<int64_t> fused_decode_resamples{0};
+    std::atomic<int64_t> device_coded_files{0};          // JPEG outputs whose entropy coding ran on the device (diagnostic)
     bool cancellation_requested() {
         if (cancel.load(std::memory_order_relaxed)) return true;
         if (poll_countdown.load(std::memory_order_relaxed) == INT64_MAX) return false;
@@ -850,9 +851,38 @@ struct Job {
             d_qt = reinterpret_cast<uint16_t*>(d_coef + off[3]);
             hip_check(hipMemcpy(d_qt, qt3, 384, hipMemcpyHostToDevice), "upload(quant tables)");
             check(ifhip_jpeg_forward_batch_device(st, dev(f), f->bytes(), f->stride, d_qt, 1, d_coef + off[0], d_coef + off[1], d_coef + off[2], nullptr));
+            poll_cancel();
+            if (write_flags == 0) {
+                // the preset's default (baseline, Annex K tables): the device entropy coder -- only the file leaves the device.
+                // First with room for a scan half the size of its coefficients (what the host path assumes too), then, for an
+                // image that is denser than that, with the geometry's worst case.
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                    const size_t scan_cap = attempt == 0 ? std::max<size_t>(65536u, off[3]) : 0u;
+                    ifhip_jpeg_enc_stage* es = nullptr;
+                    check(ifhip_jpeg_enc_stage_create(&es, f->w, f->h, 3, hs, vs, bw, bh, 1, scan_cap));
+                    std::unique_ptr<ifhip_jpeg_enc_stage, void (*)(ifhip_jpeg_enc_stage*)> es_guard(es, ifhip_jpeg_enc_stage_destroy);
+                    const size_t pitch = ifhip_jpeg_enc_stage_max_file_bytes(es);
+                    uint8_t* d_file = nullptr;
+                    hip_check(hipMalloc(reinterpret_cast<void**>(&d_file), pitch + 16u), "hipMalloc(file)");
+                    std::unique_ptr<uint8_t, void (*)(uint8_t*)> file_guard(d_file, [](uint8_t* p) { (void)hipFree(p); });
+                    uint32_t* d_len = reinterpret_cast<uint32_t*>(d_file + ((pitch + 3u) & ~static_cast<size_t>(3u)));   // length, status behind the file
+                    check(ifhip_jpeg_encode_batch_device(es, d_coef + off[0], d_coef + off[1], d_coef + off[2], quality, 1, d_file, pitch, d_len, d_len + 1, nullptr));
+                    uint32_t len_status[2] = {0, 0};
+                    hip_check(hipMemcpy(len_status, d_len, 8, hipMemcpyDeviceToHost), "download(file length)");
+                    if (len_status[1] & IFHIP_ENC_BAD_COEFFICIENT)
+                        raise(kArgumentInvalid, "InvalidArgument: coefficient out of range for 8-bit JPEG (more than 11 DC / 10 AC magnitude bits)");
+                    if (len_status[1] != 0) continue;
+                    o.owned.assign(len_status[0], 0);
+                    hip_check(hipMemcpy(o.owned.data(), d_file, len_status[0], hipMemcpyDeviceToHost), "download(file)");
+                    o.written = true;
+                    encodes.push_back({io_id, f->w, f->h, "image/jpeg", "jpg"});
+                    c->device_coded_files.fetch_add(1, std::memory_order_relaxed);
+                    return;
+                }
+                raise(kInternalError, "InternalError: the device entropy coder dropped the image at its worst-case capacity");
+            }
             std::vector<int16_t> coef(off[3]);
             hip_check(hipMemcpy(coef.data(), d_coef, off[3] * 2u, hipMemcpyDeviceToHost), "download(coefficients)");
-            poll_cancel();
             size_t len = 0;
             o.owned.assign(std::max<size_t>(4096u, off[3]), 0);                          // a file is smaller than its coefficients: one pass
             int wrc = ifhip_jpeg_write(coef.data() + off[0], coef.data() + off[1], coef.data() + off[2], bw, bh, 3, hs, vs, f->w, f->h, quality, write_flags,
@@ -1364,6 +1394,10 @@ int64_t ifhip_shim_cancellation_polls_remaining(struct imageflow_context* c) {
 int64_t ifhip_shim_fused_decode_resamples(struct imageflow_context* c) {
     CTX_OR_ABORT(c);
     return c->fused_decode_resamples.load(std::memory_order_relaxed);
+}
+int64_t ifhip_shim_device_coded_files(struct imageflow_context* c) {
+    CTX_OR_ABORT(c);
+    return c->device_coded_files.load(std::memory_order_relaxed);
 }
 bool imageflow_context_error_write_to_buffer(struct imageflow_context* c, char* buffer, size_t buffer_length, size_t* bytes_written) {   // lib.rs:684
     CTX_OR_ABORT(c);

@@ -10,7 +10,8 @@
 //   * the byte position after stuffing = position + the number of 0xFF bytes before it   -> count pass, scan, write pass;
 //   * the DC predictor is the previous block's DC value, which lies in the plane (no running state at all).
 // Launches per batch (all images of a batch in each): count (blocks), scan (per-workgroup bit sums), write (bits into a
-// zeroed big-endian word stream: a lane ORs its first and last word, owns the ones between), count 0xFF (per 4 KiB of the
+// zeroed big-endian word stream: a lane ORs its first and last word, owns the ones between -- assembled in an LDS window
+// per workgroup and copied out coalesced when the workgroup's piece fits it), count 0xFF (per 4 KiB of the
 // stream), scan, write bytes (stuffed, behind the marker segments; the same pass zeroes the word stream for the next call
 // and writes EOI and the file's length).  Bound by instruction issue of the block walk, not by HBM (coefficients are
 // read twice, 256 B per block; the files are a tenth of that).
@@ -71,9 +72,10 @@ struct DeviceStore {
     __device__ __forceinline__ static void owned(uint32_t* p, uint32_t v) { *p = v; }
 };
 
-struct LdsCoef {                    // a lane's block in LDS, natural order
-    const int16_t* b;
-    __device__ __forceinline__ int32_t operator()(int k) const { return b[enc_zigzag(k)]; }
+struct LdsCoef {                    // a lane's block in LDS, zigzag order (4-byte aligned)
+    const uint32_t* w;
+    __device__ __forceinline__ int32_t operator()(int k) const { return reinterpret_cast<const int16_t*>(w)[k]; }
+    __device__ __forceinline__ uint32_t pair(int j) const { return w[j]; }
 };
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
@@ -104,36 +106,61 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     return before + incl - v;
 }
 
-// Stage the workgroup's 256 scan-order blocks into LDS with coalesced 16-byte loads (eight lanes per block), tables too.
+// Stage the workgroup's 256 scan-order blocks into LDS -- coalesced 16-byte loads (eight lanes per block), stored in
+// ZIGZAG order so that the walk reads position k at base + 2k -- and the tables.
 // Returns this lane's DC predictor.
 __device__ __forceinline__ int32_t stage_blocks(const EncArgs& a, uint32_t img, uint32_t s0, uint32_t* blk, const int16_t** addr,
                                                 uint32_t* tabs) {
     const uint32_t tid = threadIdx.x, s = s0 + tid;
-    for (uint32_t i = tid; i < 1024u; i += kEncBlocksPerWg) tabs[i] = a.tabs[i];
-    int32_t pred = 0;
     const int16_t* mine = nullptr;
+    const int16_t* before = nullptr;                       // the DC value that predicts this lane's block
     if (s < a.g.nblocks) {
         const EncBlockRef r = enc_locate(a.g, s);
-        mine = (r.comp == 0u ? a.coef[0] : r.comp == 1u ? a.coef[1] : a.coef[2])
-               + (static_cast<size_t>(img) * (r.comp == 0u ? a.plane_blocks[0] : r.comp == 1u ? a.plane_blocks[1] : a.plane_blocks[2]) + r.offset) * 64u;
+        const uint64_t planes[3] = {reinterpret_cast<uint64_t>(a.coef[0]), reinterpret_cast<uint64_t>(a.coef[1]), reinterpret_cast<uint64_t>(a.coef[2])};
+        const uint64_t per_image[3] = {a.plane_blocks[0], a.plane_blocks[1], a.plane_blocks[2]};
+        mine = reinterpret_cast<const int16_t*>(enc_sel3(planes, r.comp)) + (img * enc_sel3(per_image, r.comp) + r.offset) * 64u;
         const uint32_t ps = enc_predecessor(a.g, s);
         if (ps != 0xFFFFFFFFu) {
             const EncBlockRef q = enc_locate(a.g, ps);     // (same component)
-            pred = mine[(static_cast<ptrdiff_t>(q.offset) - static_cast<ptrdiff_t>(r.offset)) * 64];
+            before = mine + (static_cast<ptrdiff_t>(q.offset) - static_cast<ptrdiff_t>(r.offset)) * 64;
         }
     }
+    // (a lane behind the image's last block names the workgroup's first block: every load below is unconditional, so all
+    // eight are in flight together -- with a test around each they went out one HBM round trip after the other, and that,
+    // not the walk, was what a workgroup spent its time on)
     addr[tid] = mine;
     __syncthreads();
+    // A lane carries the same piece (row of the block, natural order) in all eight steps: its eight coefficients go to
+    // fixed zigzag positions of whatever block the step names.
+    const uint32_t piece = tid & 7u;
+    uint32_t pos[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pos[i] = static_cast<uint32_t>(enc_zigzag_position(static_cast<int>(piece) * 8 + i));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) const u32x4 global_u32x4;    // (a pointer that went through LDS is a generic one to the compiler)
+    const int16_t* first = addr[0];
+    u32x4 v[8];
 #pragma unroll
     for (uint32_t it = 0; it < 8u; ++it) {
-        const uint32_t idx = it * kEncBlocksPerWg + tid, b = idx >> 3, piece = idx & 7u;
-        const int16_t* p = addr[b];
-        if (p) {
-            const uint4 v = *reinterpret_cast<const uint4*>(p + piece * 8u);
-            uint32_t* d = blk + b * kBlkPitch + piece * 4u;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
+        const int16_t* p = addr[(it * kEncBlocksPerWg + tid) >> 3];
+        p = p ? p : first;
+        v[it] = *reinterpret_cast<global_u32x4*>(reinterpret_cast<uintptr_t>(p + piece * 8u));
     }
+    // (tables and predictor behind the blocks: one round trip to memory for everything the workgroup stages)
+    uint32_t tv[1024u / kEncBlocksPerWg];
+#pragma unroll
+    for (uint32_t i = 0; i < 1024u / kEncBlocksPerWg; ++i) tv[i] = a.tabs[i * kEncBlocksPerWg + tid];
+    const int32_t pred = before ? *before : 0;
+#pragma unroll
+    for (uint32_t it = 0; it < 8u; ++it) {
+        uint16_t* d = reinterpret_cast<uint16_t*>(blk + ((it * kEncBlocksPerWg + tid) >> 3) * kBlkPitch);
+        d[pos[0]] = static_cast<uint16_t>(v[it].x); d[pos[1]] = static_cast<uint16_t>(v[it].x >> 16);
+        d[pos[2]] = static_cast<uint16_t>(v[it].y); d[pos[3]] = static_cast<uint16_t>(v[it].y >> 16);
+        d[pos[4]] = static_cast<uint16_t>(v[it].z); d[pos[5]] = static_cast<uint16_t>(v[it].z >> 16);
+        d[pos[6]] = static_cast<uint16_t>(v[it].w); d[pos[7]] = static_cast<uint16_t>(v[it].w >> 16);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < 1024u / kEncBlocksPerWg; ++i) tabs[i * kEncBlocksPerWg + tid] = tv[i];
     __syncthreads();
     return pred;
 }
@@ -149,7 +176,7 @@ __global__ __launch_bounds__(256) void enc_count_kernel(const EncArgs a) {
     if (s < a.g.nblocks) {
         const uint32_t t = enc_locate(a.g, s).comp ? 512u : 0u;
         EncCountSink sink;
-        bad = enc_block(LdsCoef{reinterpret_cast<const int16_t*>(blk + tid * kBlkPitch)}, pred, tabs + t, tabs + t + 256u, sink);
+        bad = enc_block(LdsCoef{blk + tid * kBlkPitch}, pred, tabs + t, tabs + t + 256u, sink);
         bits = sink.bits;
         a.nbits[static_cast<size_t>(img) * a.g.nblocks + s] = static_cast<uint16_t>(bits);
     }
@@ -194,27 +221,64 @@ __global__ __launch_bounds__(1024) void enc_scan_kernel(const EncArgs a, const i
     }
 }
 
+struct LdsStore {                   // the window: same ownership rule as the stream, LDS operations
+    __device__ __forceinline__ static void shared(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+    __device__ __forceinline__ static void owned(uint32_t* p, uint32_t v) { *p = v; }
+};
+
 __global__ __launch_bounds__(256) void enc_write_kernel(const EncArgs a) {
     __shared__ uint32_t blk[kEncBlocksPerWg * kBlkPitch];
-    __shared__ const int16_t* addr[kEncBlocksPerWg];
+    __shared__ uint32_t win[kEncWindowWords];              // (its head holds the blocks' addresses while they are staged)
     __shared__ uint32_t tabs[1024];
     __shared__ uint32_t scratch[8];
+    static_assert(kEncWindowWords * sizeof(uint32_t) >= kEncBlocksPerWg * sizeof(const int16_t*), "the address list must fit the window");
     const uint32_t tid = threadIdx.x, img = blockIdx.y, s0 = blockIdx.x * kEncBlocksPerWg, s = s0 + tid;
     if (a.status[img]) return;                             // (uniform: out-of-range coefficient or stream capacity; nothing is written)
-    const int32_t pred = stage_blocks(a, img, s0, blk, addr, tabs);
+    const int32_t pred = stage_blocks(a, img, s0, blk, reinterpret_cast<const int16_t**>(win), tabs);
     const bool valid = s < a.g.nblocks;
     const uint32_t mine = valid ? a.nbits[static_cast<size_t>(img) * a.g.nblocks + s] : 0u;
     uint32_t total;
-    const uint32_t off = a.wg_bits[static_cast<size_t>(img) * a.n_wg + blockIdx.x] + block_exclusive_scan<256>(mine, scratch, &total);
-    if (!valid) return;
-    const uint32_t t = enc_locate(a.g, s).comp ? 512u : 0u;
-    EncWordSink<DeviceStore> sink(a.words + static_cast<size_t>(img) * a.cap_words, off);
-    enc_block(LdsCoef{reinterpret_cast<const int16_t*>(blk + tid * kBlkPitch)}, pred, tabs + t, tabs + t + 256u, sink);
-    if (s == a.g.nblocks - 1u) {                           // jchuff.c flush_bits: the last byte is filled with 1 bits
-        const uint32_t pad = (8u - (sink.n & 7u)) & 7u;
-        if (pad) sink.put((1u << pad) - 1u, pad);
+    const uint32_t base = a.wg_bits[static_cast<size_t>(img) * a.n_wg + blockIdx.x];
+    const uint32_t local = block_exclusive_scan<256>(mine, scratch, &total);
+    const bool last_wg = blockIdx.x == a.n_wg - 1u;
+    if (last_wg) total += enc_final_padding(base + total); // jchuff.c flush_bits: the last byte is filled with 1 bits
+    const uint32_t n_words = enc_window_words(base, total);
+    const bool windowed = n_words <= kEncWindowWords;      // (uniform)
+    uint32_t* stream = a.words + static_cast<size_t>(img) * a.cap_words;
+    if (windowed) {
+        for (uint32_t i = tid; i < n_words; i += kEncBlocksPerWg) win[i] = 0u;
+        __syncthreads();
     }
-    sink.finish();
+    if (valid) {
+        const uint32_t t = enc_locate(a.g, s).comp ? 512u : 0u;
+        const LdsCoef coef{blk + tid * kBlkPitch};
+        if (windowed) {
+            EncWordSink<LdsStore> sink(win, (base & 31u) + local);
+            enc_block(coef, pred, tabs + t, tabs + t + 256u, sink);
+            if (s == a.g.nblocks - 1u) {
+                const uint32_t pad = (8u - (sink.n & 7u)) & 7u;
+                if (pad) sink.put((1u << pad) - 1u, pad);
+            }
+            sink.finish();
+        } else {
+            EncWordSink<DeviceStore> sink(stream, base + local);
+            enc_block(coef, pred, tabs + t, tabs + t + 256u, sink);
+            if (s == a.g.nblocks - 1u) {
+                const uint32_t pad = (8u - (sink.n & 7u)) & 7u;
+                if (pad) sink.put((1u << pad) - 1u, pad);
+            }
+            sink.finish();
+        }
+    }
+    if (windowed) {                                        // the piece leaves the window with coalesced stores; its two ends are shared
+        __syncthreads();
+        uint32_t* dst = stream + (base >> 5);
+        for (uint32_t i = tid; i < n_words; i += kEncBlocksPerWg) {
+            const uint32_t v = win[i];
+            if (i == 0u || i == n_words - 1u) atomicOr(dst + i, v);
+            else dst[i] = v;
+        }
+    }
 }
 
 // the stream bytes of an image: 0 when the image is dropped

@@ -27,8 +27,24 @@ struct EncGeom {
     uint64_t layout;            // four bits per position inside the MCU: component | dx << 2 | dy << 3
 };
 
-// (an index that differs from lane to lane selects among registers; it never addresses the argument block)
-IFHIP_HD uint32_t enc_sel3(const uint32_t (&v)[3], uint32_t c) { return c == 0u ? v[0] : c == 1u ? v[1] : v[2]; }
+// An index that differs from lane to lane must select among REGISTERS: left alone, the compiler turns a select between
+// two fields of the argument block into a load from a selected address -- a memory round trip per field, one waiting for
+// the other, in front of every workgroup's real work.  The fields are pinned to scalar registers first.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define IFHIP_UNIFORM32(x) static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(x)))
+#else
+#define IFHIP_UNIFORM32(x) (x)
+#endif
+IFHIP_HD uint32_t enc_sel3(const uint32_t (&v)[3], uint32_t c) {
+    const uint32_t v0 = IFHIP_UNIFORM32(v[0]), v1 = IFHIP_UNIFORM32(v[1]), v2 = IFHIP_UNIFORM32(v[2]);
+    return c == 0u ? v0 : c == 1u ? v1 : v2;
+}
+IFHIP_HD uint64_t enc_sel3(const uint64_t (&v)[3], uint32_t c) {
+    const uint64_t v0 = static_cast<uint64_t>(IFHIP_UNIFORM32(v[0] >> 32)) << 32 | IFHIP_UNIFORM32(v[0] & 0xffffffffu);
+    const uint64_t v1 = static_cast<uint64_t>(IFHIP_UNIFORM32(v[1] >> 32)) << 32 | IFHIP_UNIFORM32(v[1] & 0xffffffffu);
+    const uint64_t v2 = static_cast<uint64_t>(IFHIP_UNIFORM32(v[2] >> 32)) << 32 | IFHIP_UNIFORM32(v[2] & 0xffffffffu);
+    return c == 0u ? v0 : c == 1u ? v1 : v2;
+}
 
 struct EncBlockRef { uint32_t comp, offset; };      // offset in blocks inside the component's plane
 
@@ -99,6 +115,7 @@ IFHIP_HD uint32_t enc_nbits(uint32_t t) { return t ? 32u - static_cast<uint32_t>
 struct EncCountSink {
     uint32_t bits = 0;
     IFHIP_HD void put(uint32_t, uint32_t len) { bits += len; }
+    IFHIP_HD void put_times(uint32_t, uint32_t len, uint32_t times) { bits += len * times; }
 };
 
 // Bits go into a stream of big-endian 32-bit words that starts zeroed.  A lane's first word and its last, partial word
@@ -122,18 +139,39 @@ struct EncWordSink {
             ++p;
         }
     }
+    IFHIP_HD void put_times(uint32_t code, uint32_t len, uint32_t times) {
+        for (; times; --times) put(code, len);
+    }
     IFHIP_HD void finish() {
         if (n) Store::shared(p, __builtin_bswap32(static_cast<uint32_t>(acc << (32u - n))));
     }
 };
 
-// jchuff.c encode_one_block.  coef(k): the coefficient at zigzag position k; dct / act: 256 entries `code | length << 16`
-// (jpeg_make_c_derived_tbl; a symbol the table does not have is 0).  Returns nonzero when a coefficient needs more
-// magnitude bits than 8-bit JPEG has (JERR_BAD_DCT_COEF: 11 for the DC difference, 10 for an AC coefficient) -- the
-// bits put are then meaningless but their count stays the same in every pass.
+// jchuff.c encode_one_block.  `coef` gives the block in ZIGZAG order: coef(k) the coefficient at position k (k may differ
+// from lane to lane), coef.pair(j) positions 2j (low half) and 2j + 1 (high half) as 16-bit patterns; dct / act: 256
+// entries `code | length << 16` (jpeg_make_c_derived_tbl; a symbol the table does not have is 0).  Returns nonzero when a
+// coefficient needs more magnitude bits than 8-bit JPEG has (JERR_BAD_DCT_COEF: 11 for the DC difference, 10 for an AC
+// coefficient) -- the bits put are then meaningless but their count stays the same in every pass.
+// The walk never looks at a zero coefficient twice: one pass over the 32 pairs collects a mask of the nonzero positions
+// (position k at bit 63 - k), the symbol loop then jumps from set bit to set bit -- its trip count in a wave is the
+// largest number of nonzero coefficients among the wave's 64 blocks, not 63.
 template <class Coef, class Sink>
 IFHIP_HD uint32_t enc_block(const Coef& coef, int32_t pred, const uint32_t* dct, const uint32_t* act, Sink& sink) {
     uint32_t bad = 0;
+    uint32_t hi = 0, lo = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t w = coef.pair(j);
+        hi = (hi << 1) | ((w & 0xffffu) != 0u ? 1u : 0u);
+        hi = (hi << 1) | ((w >> 16) != 0u ? 1u : 0u);
+    }
+#pragma unroll
+    for (int j = 16; j < 32; ++j) {
+        const uint32_t w = coef.pair(j);
+        lo = (lo << 1) | ((w & 0xffffu) != 0u ? 1u : 0u);
+        lo = (lo << 1) | ((w >> 16) != 0u ? 1u : 0u);
+    }
+    uint64_t m = (static_cast<uint64_t>(hi & 0x7fffffffu) << 32) | lo;      // (bit 63 would be the DC value)
     {
         const int32_t diff = coef(0) - pred;
         const uint32_t t = static_cast<uint32_t>(diff < 0 ? -diff : diff), t2 = static_cast<uint32_t>(diff < 0 ? diff - 1 : diff);
@@ -143,24 +181,32 @@ IFHIP_HD uint32_t enc_block(const Coef& coef, int32_t pred, const uint32_t* dct,
         sink.put(((cs & 0xffffu) << nb) | (t2 & ((1u << nb) - 1u)), (cs >> 16) + nb);
     }
     const uint32_t zrl = act[0xF0], eob = act[0];
-    uint32_t run = 0;
-#pragma unroll
-    for (int k = 1; k < 64; ++k) {
-        const int32_t v = coef(k);
-        if (v != 0) {
-            for (; run > 15u; run -= 16u) sink.put(zrl & 0xffffu, zrl >> 16);
-            const uint32_t t = static_cast<uint32_t>(v < 0 ? -v : v), t2 = static_cast<uint32_t>(v < 0 ? v - 1 : v);
-            uint32_t nb = enc_nbits(t);
-            if (nb > 10u) { bad = 1u; nb = 10u; }
-            const uint32_t cs = act[(run << 4) + nb];
-            sink.put(((cs & 0xffffu) << nb) | (t2 & ((1u << nb) - 1u)), (cs >> 16) + nb);
-            run = 0;
-        } else {
-            ++run;
+    uint32_t prev = 0;
+    while (m) {
+        const uint32_t k = static_cast<uint32_t>(__builtin_clzll(m));
+        m &= ~(0x8000000000000000ull >> k);
+        uint32_t run = k - prev - 1u;
+        prev = k;
+        if (run > 15u) {                                      // ZRL symbols for every 16 zeros of the run
+            sink.put_times(zrl & 0xffffu, zrl >> 16, run >> 4);
+            run &= 15u;
         }
+        const int32_t v = coef(static_cast<int>(k));
+        const uint32_t t = static_cast<uint32_t>(v < 0 ? -v : v), t2 = static_cast<uint32_t>(v < 0 ? v - 1 : v);
+        uint32_t nb = enc_nbits(t);
+        if (nb > 10u) { bad = 1u; nb = 10u; }
+        const uint32_t cs = act[(run << 4) + nb];
+        sink.put(((cs & 0xffffu) << nb) | (t2 & ((1u << nb) - 1u)), (cs >> 16) + nb);
     }
-    if (run) sink.put(eob & 0xffffu, eob >> 16);
+    if (prev != 63u) sink.put(eob & 0xffffu, eob >> 16);
     return bad;
+}
+
+// position in zigzag order of the coefficient at natural index n (the inverse of jpeg_natural_order)
+IFHIP_HD int enc_zigzag_position(int n) {
+    constexpr int t[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
+                           10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+    return t[n];
 }
 
 // number of 0xFF bytes in a word
@@ -173,6 +219,14 @@ IFHIP_HD uint32_t enc_count_ff(uint32_t w) {
 
 constexpr uint32_t kEncBlocksPerWg = 256;           // scan-order blocks per workgroup of the count / write passes
 constexpr uint32_t kEncChunkBytes = 4096;           // unstuffed stream bytes per workgroup step of the stuffing passes
+// The write pass assembles a workgroup's piece of the stream in an LDS window of this many words when it fits (96 Kbit:
+// 384 bits per block on average) and copies it out with coalesced stores -- only the window's first and last word are
+// shared with the neighbouring workgroups; denser pieces are written to the stream directly, word by word.
+constexpr uint32_t kEncWindowWords = 3072;
+// words of the stream a workgroup's piece touches: `base` its first bit, `bits` its length (with the stream's final padding)
+IFHIP_HD uint32_t enc_window_words(uint32_t base, uint32_t bits) { return bits ? ((base & 31u) + bits + 31u) >> 5 : 0u; }
+// jchuff.c flush_bits: 1 bits up to the next byte boundary behind the stream's last bit
+IFHIP_HD uint32_t enc_final_padding(uint32_t end_bit) { return (8u - (end_bit & 7u)) & 7u; }
 // status bits per image
 constexpr uint32_t kEncBadCoef = 1, kEncScanOverflow = 2, kEncFileOverflow = 4;
 

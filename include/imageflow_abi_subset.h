@@ -103,6 +103,9 @@ IMAGEFLOW_SHIM_API int64_t ifhip_shim_cancellation_polls_remaining(struct imagef
 /* Diagnostic: how many decode -> resample pairs of this context's jobs ran as ONE device call without a decoded bitmap in
  * HBM (ifhip_jpeg_decode_resample_batch_device reporting fused = 1). */
 IMAGEFLOW_SHIM_API int64_t ifhip_shim_fused_decode_resamples(struct imageflow_context *context);
+/* Diagnostic: how many JPEG outputs of this context's jobs were entropy-coded on the device (libjpeg_turbo preset without
+ * progressive / optimize_huffman_coding: ifhip_jpeg_encode_batch_device; only the file is downloaded). */
+IMAGEFLOW_SHIM_API int64_t ifhip_shim_device_coded_files(struct imageflow_context *context);
 
 #ifdef __cplusplus
 }

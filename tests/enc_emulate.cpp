@@ -4,6 +4,7 @@
 // visits the blocks in a scrambled order and checks the ownership rule of the word stream: a word a lane stores plainly is
 // touched by nobody else.  Built by tests/test_jpeg_device_coder.py with g++.
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -32,16 +33,19 @@ struct HostStore {
     }
 };
 
-struct PlaneCoef {
+struct PlaneCoef {                            // a block of the plane (natural order) seen in zigzag order
     const int16_t* b;
     int32_t operator()(int k) const { return b[enc_zigzag(k)]; }
+    uint32_t pair(int j) const {
+        return static_cast<uint32_t>(static_cast<uint16_t>(b[enc_zigzag(2 * j)])) | static_cast<uint32_t>(static_cast<uint16_t>(b[enc_zigzag(2 * j + 1)])) << 16;
+    }
 };
 }  // namespace
 
 extern "C" int enc_emulate(const int16_t* c0, const int16_t* c1, const int16_t* c2, uint32_t width, uint32_t height, int ncomp,
                            const uint8_t* hs, const uint8_t* vs, const uint32_t* bw, const uint32_t* bh, const uint8_t* header,
                            uint32_t header_len, const uint32_t* tabs, uint8_t* out, size_t capacity, size_t* len, uint32_t* status,
-                           int* violations) {
+                           int* violations, int* window_paths) {
     EncGeom g;
     if (enc_make_geom(width, height, ncomp, hs, vs, bw, bh, &g)) return 1;
     const int16_t* planes[3] = {c0, c1, c2};
@@ -71,27 +75,56 @@ extern "C" int enc_emulate(const int16_t* c0, const int16_t* c1, const int16_t* 
     std::vector<uint32_t> words(cap_bytes / 4u, 0u);
     std::vector<uint8_t> mark(words.size(), 0);
     g_words = words.data(); g_mark = &mark; g_violations = 0;
-    // write pass, blocks in a scrambled order (any order must do)
-    std::vector<uint32_t> order(g.nblocks);
-    for (uint32_t i = 0; i < g.nblocks; ++i) order[i] = i;
+    // write pass: workgroups and the blocks inside each in a scrambled order (any order must do).  A workgroup whose piece of
+    // the stream fits the window assembles it there (window words follow the same ownership rule) and copies it out: first
+    // and last word ORed into the stream, the words between stored; a denser piece goes to the stream word by word.
     uint64_t rng = 0x9E3779B97F4A7C15ull;
-    for (uint32_t i = g.nblocks; i > 1; --i) {
-        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
-        std::swap(order[i - 1], order[static_cast<uint32_t>((rng >> 33) % i)]);
-    }
-    for (uint32_t s : order) {
-        const uint32_t w = s / kEncBlocksPerWg;
-        uint32_t off = wg[w];
-        for (uint32_t q = w * kEncBlocksPerWg; q < s; ++q) off += nbits[q];
-        EncWordSink<HostStore> sink(words.data(), off);
-        const uint32_t* t = tab_of(s);
-        enc_block(PlaneCoef{block(s)}, pred_of(s), t, t + 256, sink);
-        if (s == g.nblocks - 1u) {
-            const uint32_t pad = (8u - (sink.n & 7u)) & 7u;
-            if (pad) sink.put((1u << pad) - 1u, pad);
+    auto scramble = [&](std::vector<uint32_t>& v) {
+        for (size_t i = v.size(); i > 1; --i) {
+            rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(v[i - 1], v[static_cast<size_t>((rng >> 33) % i)]);
         }
-        sink.finish();
+    };
+    std::vector<uint32_t> wgs(n_wg);
+    for (uint32_t i = 0; i < n_wg; ++i) wgs[i] = i;
+    scramble(wgs);
+    int window_wgs = 0;
+    for (uint32_t w : wgs) {
+        const uint32_t s0 = w * kEncBlocksPerWg, s1 = std::min(g.nblocks, s0 + kEncBlocksPerWg);
+        uint32_t total = 0;
+        for (uint32_t q = s0; q < s1; ++q) total += nbits[q];
+        if (s1 == g.nblocks) total += enc_final_padding(wg[w] + total);
+        const uint32_t n_words = enc_window_words(wg[w], total);
+        const bool windowed = n_words <= kEncWindowWords;
+        std::vector<uint32_t> win(windowed ? n_words : 0u, 0u);
+        std::vector<uint8_t> win_mark(win.size(), 0);
+        if (windowed) { g_words = win.data(); g_mark = &win_mark; ++window_wgs; }
+        else { g_words = words.data(); g_mark = &mark; }
+        std::vector<uint32_t> order(s1 - s0);
+        for (uint32_t i = 0; i < s1 - s0; ++i) order[i] = s0 + i;
+        scramble(order);
+        for (uint32_t s : order) {
+            uint32_t off = windowed ? (wg[w] & 31u) : wg[w];
+            for (uint32_t q = s0; q < s; ++q) off += nbits[q];
+            EncWordSink<HostStore> sink(g_words, off);
+            const uint32_t* t = tab_of(s);
+            enc_block(PlaneCoef{block(s)}, pred_of(s), t, t + 256, sink);
+            if (s == g.nblocks - 1u) {
+                const uint32_t pad = (8u - (sink.n & 7u)) & 7u;
+                if (pad) sink.put((1u << pad) - 1u, pad);
+            }
+            sink.finish();
+        }
+        if (windowed) {
+            g_words = words.data(); g_mark = &mark;
+            uint32_t* dst = words.data() + (wg[w] >> 5);
+            for (uint32_t i = 0; i < n_words; ++i) {
+                if (i == 0 || i == n_words - 1u) HostStore::shared(dst + i, win[i]);
+                else HostStore::owned(dst + i, win[i]);
+            }
+        }
     }
+    if (window_paths) *window_paths = window_wgs;
     *violations = g_violations;
     // 0xFF counts per chunk, scan, stuffed bytes
     const uint32_t chunks = (bytes + kEncChunkBytes - 1u) / kEncChunkBytes;

@@ -166,7 +166,7 @@ def test_progressive_jpeg_is_refused_not_mis_decoded():
 @pytest.mark.parametrize("size,quality", [((1, 1), 75), ((17, 9), 90), ((203, 131), None), ((640, 427), 60)])
 def test_libjpeg_turbo_preset_writes_the_file_libjpeg_turbo_writes(size, quality):
     """decode(raw frame) -> encode(libjpeg_turbo): matte, colour conversion, down-sampling, DCT and quantisation on the GPU,
-    markers + Huffman coding on the host -- byte for byte the file libjpeg-turbo (Pillow, same 4:2:0 sampling, standard
+    Huffman coding and markers on the GPU too (the preset's default: baseline, Annex K tables) -- byte for byte the file libjpeg-turbo (Pillow, same 4:2:0 sampling, standard
     tables) writes from the same pixels.  Default quality is the reference's 75 (codecs/mozjpeg.rs:32)."""
     Image = pytest.importorskip("PIL.Image")
     w, h = size
@@ -182,6 +182,7 @@ def test_libjpeg_turbo_preset_writes_the_file_libjpeg_turbo_writes(size, quality
         c.add_output_buffer(1)
         r = _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"encode": {"io_id": 1, "preset": preset}}]}})
         got = bytes(c.get_output_buffer(1))
+        assert c.L.ifhip_shim_device_coded_files(c.p) == 1          # the Huffman coder ran on the device: only the file was downloaded
     enc = r["data"]["job_result"]["encodes"][0]
     assert (enc["preferred_mime_type"], enc["preferred_extension"], enc["w"], enc["h"]) == ("image/jpeg", "jpg", w, h)
     buf = io.BytesIO()
@@ -234,6 +235,7 @@ def test_libjpeg_turbo_preset_progressive_and_optimised_tables(extra, pillow):
         _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}},
                                                         {"encode": {"io_id": 1, "preset": {"libjpeg_turbo": dict(quality=88, **extra)}}}]}})
         got = bytes(c.get_output_buffer(1))
+        assert c.L.ifhip_shim_device_coded_files(c.p) == 0          # these options stay with the host writer
     buf = io.BytesIO()
     PIL.fromarray(rgb).save(buf, "JPEG", quality=88, subsampling="4:2:0", **pillow)
     assert got == buf.getvalue()

@@ -30,7 +30,7 @@ def emulator():
         subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", os.path.join(HERE, "enc_emulate.cpp"), "-o", so], check=True)
         lib = C.CDLL(so)
         lib.enc_emulate.argtypes = [C.c_void_p] * 3 + [C.c_uint32, C.c_uint32, C.c_int] + [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p,
-                                    C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+                                    C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _EMU["lib"] = lib
     return _EMU["lib"]
 
@@ -56,11 +56,12 @@ def emulate(j, quality, capacity=None):
     h, v = np.array(hs, np.uint8), np.array(vs, np.uint8)
     planes = [np.ascontiguousarray(j["coef"][c], np.int16) if c < ncomp else None for c in range(3)]
     cap = capacity if capacity is not None else 1024 + 4 * sum(p.size for p in planes if p is not None) + 8192
-    out, n, st, viol = np.zeros(cap, np.uint8), C.c_size_t(0), C.c_uint32(0), C.c_int(0)
+    out, n, st, viol, win = np.zeros(cap, np.uint8), C.c_size_t(0), C.c_uint32(0), C.c_int(0), C.c_int(0)
     rc = lib.enc_emulate(*[p.ctypes.data if p is not None else None for p in planes], j["width"], j["height"], ncomp, h.ctypes.data,
                          v.ctypes.data, bw.ctypes.data, bh.ctypes.data, header.ctypes.data, header.size, tabs.ctypes.data, out.ctypes.data,
-                         out.size, C.byref(n), C.byref(st), C.byref(viol))
+                         out.size, C.byref(n), C.byref(st), C.byref(viol), C.byref(win))
     assert rc == 0
+    emulate.window_paths = win.value
     return (out[:n.value].tobytes() if n.value else None), st.value, viol.value
 
 
@@ -108,6 +109,7 @@ def test_noise_at_q100_stuffs_bytes_across_chunks_and_workgroups():
     assert j["bw"][0] * j["bh"][0] > 4 * 256
     out, status, violations = emulate(j, 100)
     assert (status, violations) == (0, 0) and out == data
+    assert emulate.window_paths <= 1                      # too dense for the LDS window: written to the stream word by word
 
 
 def test_flat_image_has_blocks_of_a_few_bits():
@@ -116,6 +118,7 @@ def test_flat_image_has_blocks_of_a_few_bits():
     j = O.jpeg_read_coefficients(data)
     out, status, violations = emulate(j, 90)
     assert (status, violations) == (0, 0) and out == data
+    assert emulate.window_paths == (16 * 16 * 6 // 4 + 255) // 256
 
 
 def test_out_of_range_coefficient_drops_the_file():
