@@ -72,9 +72,9 @@ struct DeviceStore {
     __device__ __forceinline__ static void owned(uint32_t* p, uint32_t v) { *p = v; }
 };
 
-struct LdsCoef {                    // a lane's block in LDS, zigzag order (4-byte aligned)
+struct LdsCoef {                    // a lane's block in LDS, slot order (jpeg_encode_core.hpp enc_slot)
     const uint32_t* w;
-    __device__ __forceinline__ int32_t operator()(int k) const { return reinterpret_cast<const int16_t*>(w)[k]; }
+    __device__ __forceinline__ int32_t operator()(int k) const { return reinterpret_cast<const int16_t*>(w)[enc_slot(static_cast<uint32_t>(k))]; }
     __device__ __forceinline__ uint32_t pair(int j) const { return w[j]; }
 };
 
@@ -106,11 +106,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     return before + incl - v;
 }
 
-// Stage the workgroup's 256 scan-order blocks into LDS -- coalesced 16-byte loads (eight lanes per block), stored in
-// ZIGZAG order so that the walk reads position k at base + 2k -- and the tables.
-// Returns this lane's DC predictor.
+// Stage the workgroup's 256 scan-order blocks into LDS -- coalesced 16-byte loads (eight lanes per block), stored in the
+// walk's slot order (zigzag positions, paired for the nonzero mask: enc_slot) -- and the tables.
+// Returns this lane's DC predictor; *table: where its component's tables start in `tabs`.
 __device__ __forceinline__ int32_t stage_blocks(const EncArgs& a, uint32_t img, uint32_t s0, uint32_t* blk, const int16_t** addr,
-                                                uint32_t* tabs) {
+                                                uint32_t* tabs, uint32_t* table) {
     const uint32_t tid = threadIdx.x, s = s0 + tid;
     const int16_t* mine = nullptr;
     const int16_t* before = nullptr;                       // the DC value that predicts this lane's block
@@ -119,11 +119,8 @@ __device__ __forceinline__ int32_t stage_blocks(const EncArgs& a, uint32_t img, 
         const uint64_t planes[3] = {reinterpret_cast<uint64_t>(a.coef[0]), reinterpret_cast<uint64_t>(a.coef[1]), reinterpret_cast<uint64_t>(a.coef[2])};
         const uint64_t per_image[3] = {a.plane_blocks[0], a.plane_blocks[1], a.plane_blocks[2]};
         mine = reinterpret_cast<const int16_t*>(enc_sel3(planes, r.comp)) + (img * enc_sel3(per_image, r.comp) + r.offset) * 64u;
-        const uint32_t ps = enc_predecessor(a.g, s);
-        if (ps != 0xFFFFFFFFu) {
-            const EncBlockRef q = enc_locate(a.g, ps);     // (same component)
-            before = mine + (static_cast<ptrdiff_t>(q.offset) - static_cast<ptrdiff_t>(r.offset)) * 64;
-        }
+        if (r.pred_offset != 0xFFFFFFFFu) before = mine + (static_cast<ptrdiff_t>(r.pred_offset) - static_cast<ptrdiff_t>(r.offset)) * 64;
+        *table = r.comp ? 512u : 0u;
     }
     // (a lane behind the image's last block names the workgroup's first block: every load below is unconditional, so all
     // eight are in flight together -- with a test around each they went out one HBM round trip after the other, and that,
@@ -131,11 +128,11 @@ __device__ __forceinline__ int32_t stage_blocks(const EncArgs& a, uint32_t img, 
     addr[tid] = mine;
     __syncthreads();
     // A lane carries the same piece (row of the block, natural order) in all eight steps: its eight coefficients go to
-    // fixed zigzag positions of whatever block the step names.
+    // fixed slots of whatever block the step names.
     const uint32_t piece = tid & 7u;
     uint32_t pos[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) pos[i] = static_cast<uint32_t>(enc_zigzag_position(static_cast<int>(piece) * 8 + i));
+    for (int i = 0; i < 8; ++i) pos[i] = enc_slot(static_cast<uint32_t>(enc_zigzag_position(static_cast<int>(piece) * 8 + i)));
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(1))) const u32x4 global_u32x4;    // (a pointer that went through LDS is a generic one to the compiler)
     const int16_t* first = addr[0];
@@ -171,10 +168,10 @@ __global__ __launch_bounds__(256) void enc_count_kernel(const EncArgs a) {
     __shared__ uint32_t tabs[1024];
     __shared__ uint32_t scratch[8];
     const uint32_t tid = threadIdx.x, img = blockIdx.y, s0 = blockIdx.x * kEncBlocksPerWg, s = s0 + tid;
-    const int32_t pred = stage_blocks(a, img, s0, blk, addr, tabs);
+    uint32_t t = 0;
+    const int32_t pred = stage_blocks(a, img, s0, blk, addr, tabs, &t);
     uint32_t bits = 0, bad = 0;
     if (s < a.g.nblocks) {
-        const uint32_t t = enc_locate(a.g, s).comp ? 512u : 0u;
         EncCountSink sink;
         bad = enc_block(LdsCoef{blk + tid * kBlkPitch}, pred, tabs + t, tabs + t + 256u, sink);
         bits = sink.bits;
@@ -221,9 +218,9 @@ __global__ __launch_bounds__(1024) void enc_scan_kernel(const EncArgs a, const i
     }
 }
 
-struct LdsStore {                   // the window: same ownership rule as the stream, LDS operations
-    __device__ __forceinline__ static void shared(uint32_t* p, uint32_t v) { atomicOr(p, v); }
-    __device__ __forceinline__ static void owned(uint32_t* p, uint32_t v) { *p = v; }
+struct LdsStore {                   // the window: every word is ORed in (an LDS atomic costs what a store costs, and the
+    __device__ __forceinline__ static void shared(uint32_t* p, uint32_t v) { atomicOr(p, v); }   // walk carries no "first word" state)
+    __device__ __forceinline__ static void owned(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 };
 
 __global__ __launch_bounds__(256) void enc_write_kernel(const EncArgs a) {
@@ -234,7 +231,8 @@ __global__ __launch_bounds__(256) void enc_write_kernel(const EncArgs a) {
     static_assert(kEncWindowWords * sizeof(uint32_t) >= kEncBlocksPerWg * sizeof(const int16_t*), "the address list must fit the window");
     const uint32_t tid = threadIdx.x, img = blockIdx.y, s0 = blockIdx.x * kEncBlocksPerWg, s = s0 + tid;
     if (a.status[img]) return;                             // (uniform: out-of-range coefficient or stream capacity; nothing is written)
-    const int32_t pred = stage_blocks(a, img, s0, blk, reinterpret_cast<const int16_t**>(win), tabs);
+    uint32_t t = 0;
+    const int32_t pred = stage_blocks(a, img, s0, blk, reinterpret_cast<const int16_t**>(win), tabs, &t);
     const bool valid = s < a.g.nblocks;
     const uint32_t mine = valid ? a.nbits[static_cast<size_t>(img) * a.g.nblocks + s] : 0u;
     uint32_t total;
@@ -250,7 +248,6 @@ __global__ __launch_bounds__(256) void enc_write_kernel(const EncArgs a) {
         __syncthreads();
     }
     if (valid) {
-        const uint32_t t = enc_locate(a.g, s).comp ? 512u : 0u;
         const LdsCoef coef{blk + tid * kBlkPitch};
         if (windowed) {
             EncWordSink<LdsStore> sink(win, (base & 31u) + local);

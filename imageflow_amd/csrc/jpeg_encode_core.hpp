@@ -25,6 +25,7 @@ struct EncGeom {
     uint32_t H[3], V[3], pitch[3], rows[3];
     uint32_t first[3];          // position inside the MCU of the component's first block
     uint64_t layout;            // four bits per position inside the MCU: component | dx << 2 | dy << 3
+    float rcp_bpm, rcp_mcus_w;  // 1 / bpm, 1 / mcus_w (enc_div)
 };
 
 // An index that differs from lane to lane must select among REGISTERS: left alone, the compiler turns a select between
@@ -46,23 +47,35 @@ IFHIP_HD uint64_t enc_sel3(const uint64_t (&v)[3], uint32_t c) {
     return c == 0u ? v0 : c == 1u ? v1 : v2;
 }
 
-struct EncBlockRef { uint32_t comp, offset; };      // offset in blocks inside the component's plane
-
-IFHIP_HD EncBlockRef enc_locate(const EncGeom& g, uint32_t s) {
-    const uint32_t m = s / g.bpm, j = s - m * g.bpm;
-    const uint32_t my = m / g.mcus_w, mx = m - my * g.mcus_w;
-    const uint32_t e = static_cast<uint32_t>(g.layout >> (4u * j)) & 15u, c = e & 3u, dx = (e >> 2) & 1u, dy = e >> 3;
-    return EncBlockRef{c, (my * enc_sel3(g.V, c) + dy) * enc_sel3(g.pitch, c) + mx * enc_sel3(g.H, c) + dx};
+// n / d for n below 2^24 (scan indices are: enc_make_geom bounds the block count) without the 30-instruction integer
+// division: the float quotient is at most one off in either direction, the remainder says which.
+IFHIP_HD uint32_t enc_div(uint32_t n, uint32_t d, float rcp) {
+    uint32_t q = static_cast<uint32_t>(static_cast<float>(n) * rcp);
+    const int32_t r = static_cast<int32_t>(n - q * d);
+    if (r < 0) --q;
+    else if (static_cast<uint32_t>(r) >= d) ++q;
+    return q;
 }
 
-// scan index of the block whose DC value predicts block s (the component's previous block in scan order); 0xFFFFFFFF:
-// none, the predictor is 0 (first MCU; jchuff.c start_pass_huff: last_dc_val = 0)
-IFHIP_HD uint32_t enc_predecessor(const EncGeom& g, uint32_t s) {
-    const uint32_t m = s / g.bpm, j = s - m * g.bpm;
-    const uint32_t c = static_cast<uint32_t>(g.layout >> (4u * j)) & 3u;
-    if (j != enc_sel3(g.first, c)) return s - 1u;
-    if (m == 0u) return 0xFFFFFFFFu;
-    return s - g.bpm + enc_sel3(g.H, c) * enc_sel3(g.V, c) - 1u;
+// Where a block of the scan lies: component, offset in blocks inside the component's plane, and the same for the block
+// whose DC value predicts it -- the component's previous block in scan order (0xFFFFFFFF: none, the predictor is 0:
+// first MCU; jchuff.c start_pass_huff: last_dc_val = 0).
+struct EncBlockRef { uint32_t comp, offset, pred_offset; };
+
+IFHIP_HD EncBlockRef enc_locate(const EncGeom& g, uint32_t s) {
+    const uint32_t m = enc_div(s, g.bpm, g.rcp_bpm), j = s - m * g.bpm;
+    const uint32_t my = enc_div(m, g.mcus_w, g.rcp_mcus_w), mx = m - my * g.mcus_w;
+    const uint32_t e = static_cast<uint32_t>(g.layout >> (4u * j)) & 15u, c = e & 3u, dx = (e >> 2) & 1u, dy = e >> 3;
+    const uint32_t H = enc_sel3(g.H, c), V = enc_sel3(g.V, c), pitch = enc_sel3(g.pitch, c);
+    EncBlockRef r{c, (my * V + dy) * pitch + mx * H + dx, 0xFFFFFFFFu};
+    if (j != enc_sel3(g.first, c)) {                        // inside the MCU: the position before this one
+        const uint32_t pe = static_cast<uint32_t>(g.layout >> (4u * (j - 1u))) & 15u;
+        r.pred_offset = (my * V + (pe >> 3)) * pitch + mx * H + ((pe >> 2) & 1u);
+    } else if (m != 0u) {                                   // the component's last block of the MCU before
+        const uint32_t pmy = mx ? my : my - 1u, pmx = mx ? mx - 1u : g.mcus_w - 1u;
+        r.pred_offset = (pmy * V + V - 1u) * pitch + pmx * H + H - 1u;
+    }
+    return r;
 }
 
 // Host: the geometry of a scan from the frame size, the sampling factors (1 or 2; a single component counts as 1x1,
@@ -93,6 +106,8 @@ inline int enc_make_geom(uint32_t width, uint32_t height, int ncomp, const uint8
         if (bw[c] < g->mcus_w * g->H[c] || bh[c] < g->mcus_h * g->V[c]) return 2;
     }
     g->bpm = j;
+    g->rcp_bpm = 1.0f / static_cast<float>(j);
+    g->rcp_mcus_w = 1.0f / static_cast<float>(g->mcus_w);
     const uint64_t nb = static_cast<uint64_t>(g->mcus_w) * g->mcus_h * j;
     if (nb * kEncMaxBitsPerBlock >= (1ull << 32)) return 3;
     g->nblocks = static_cast<uint32_t>(nb);
@@ -147,12 +162,29 @@ struct EncWordSink {
     }
 };
 
-// jchuff.c encode_one_block.  `coef` gives the block in ZIGZAG order: coef(k) the coefficient at position k (k may differ
-// from lane to lane), coef.pair(j) positions 2j (low half) and 2j + 1 (high half) as 16-bit patterns; dct / act: 256
+// The order a staged block is kept in (16-bit slots, two per dword): dword j of the first 16 holds zigzag position j in its
+// HIGH half and position 16 + j in its low half, dword 16 + j positions 32 + j and 48 + j likewise.  With one flag per half
+// (coefficient != 0), shifting the dwords' flag pairs into one register one after the other leaves position p at bit
+// 31 - p: the nonzero mask of 32 positions costs two instructions per dword, and no bit ever has to be moved again.
+IFHIP_HD uint32_t enc_slot(uint32_t k) { return (k & 32u) | ((k & 15u) << 1) | (((k >> 4) & 1u) ^ 1u); }
+IFHIP_HD uint32_t enc_position_of_slot(uint32_t h) { return ((h >> 5) << 5) + ((h >> 1) & 15u) + ((h & 1u) ? 0u : 16u); }
+// 1 in bit 0 / bit 16 for a nonzero low / high half
+IFHIP_HD uint32_t enc_pair_flags(uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t f;                     // (spelled out: from the vector builtin the compiler makes two compares, two selects and a permute)
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(w), "s"(0x00010001u));
+    return f;
+#else
+    return ((w & 0xffffu) ? 1u : 0u) | ((w >> 16) ? 0x10000u : 0u);
+#endif
+}
+
+// jchuff.c encode_one_block.  `coef` gives the staged block: coef(k) the coefficient at zigzag position k (k may differ
+// from lane to lane), coef.pair(j) dword j of the slot order above; dct / act: 256
 // entries `code | length << 16` (jpeg_make_c_derived_tbl; a symbol the table does not have is 0).  Returns nonzero when a
 // coefficient needs more magnitude bits than 8-bit JPEG has (JERR_BAD_DCT_COEF: 11 for the DC difference, 10 for an AC
 // coefficient) -- the bits put are then meaningless but their count stays the same in every pass.
-// The walk never looks at a zero coefficient twice: one pass over the 32 pairs collects a mask of the nonzero positions
+// The walk never looks at a zero coefficient twice: one pass over the 32 dwords collects a mask of the nonzero positions
 // (position k at bit 63 - k), the symbol loop then jumps from set bit to set bit -- its trip count in a wave is the
 // largest number of nonzero coefficients among the wave's 64 blocks, not 63.
 template <class Coef, class Sink>
@@ -160,17 +192,9 @@ IFHIP_HD uint32_t enc_block(const Coef& coef, int32_t pred, const uint32_t* dct,
     uint32_t bad = 0;
     uint32_t hi = 0, lo = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint32_t w = coef.pair(j);
-        hi = (hi << 1) | ((w & 0xffffu) != 0u ? 1u : 0u);
-        hi = (hi << 1) | ((w >> 16) != 0u ? 1u : 0u);
-    }
+    for (int j = 0; j < 16; ++j) hi = (hi << 1) | enc_pair_flags(coef.pair(j));
 #pragma unroll
-    for (int j = 16; j < 32; ++j) {
-        const uint32_t w = coef.pair(j);
-        lo = (lo << 1) | ((w & 0xffffu) != 0u ? 1u : 0u);
-        lo = (lo << 1) | ((w >> 16) != 0u ? 1u : 0u);
-    }
+    for (int j = 16; j < 32; ++j) lo = (lo << 1) | enc_pair_flags(coef.pair(j));
     uint64_t m = (static_cast<uint64_t>(hi & 0x7fffffffu) << 32) | lo;      // (bit 63 would be the DC value)
     {
         const int32_t diff = coef(0) - pred;

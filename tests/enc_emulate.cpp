@@ -33,11 +33,13 @@ struct HostStore {
     }
 };
 
-struct PlaneCoef {                            // a block of the plane (natural order) seen in zigzag order
+struct PlaneCoef {                            // a block of the plane (natural order) seen as the kernels stage it
     const int16_t* b;
     int32_t operator()(int k) const { return b[enc_zigzag(k)]; }
     uint32_t pair(int j) const {
-        return static_cast<uint32_t>(static_cast<uint16_t>(b[enc_zigzag(2 * j)])) | static_cast<uint32_t>(static_cast<uint16_t>(b[enc_zigzag(2 * j + 1)])) << 16;
+        const uint16_t lo = static_cast<uint16_t>(b[enc_zigzag(static_cast<int>(enc_position_of_slot(2u * j)))]);
+        const uint16_t hi = static_cast<uint16_t>(b[enc_zigzag(static_cast<int>(enc_position_of_slot(2u * j + 1u)))]);
+        return static_cast<uint32_t>(lo) | static_cast<uint32_t>(hi) << 16;
     }
 };
 }  // namespace
@@ -50,7 +52,10 @@ extern "C" int enc_emulate(const int16_t* c0, const int16_t* c1, const int16_t* 
     if (enc_make_geom(width, height, ncomp, hs, vs, bw, bh, &g)) return 1;
     const int16_t* planes[3] = {c0, c1, c2};
     auto block = [&](uint32_t s) { const EncBlockRef r = enc_locate(g, s); return planes[r.comp] + static_cast<size_t>(r.offset) * 64u; };
-    auto pred_of = [&](uint32_t s) -> int32_t { const uint32_t p = enc_predecessor(g, s); return p == 0xFFFFFFFFu ? 0 : block(p)[0]; };
+    auto pred_of = [&](uint32_t s) -> int32_t {
+        const EncBlockRef r = enc_locate(g, s);
+        return r.pred_offset == 0xFFFFFFFFu ? 0 : planes[r.comp][static_cast<size_t>(r.pred_offset) * 64u];
+    };
     auto tab_of = [&](uint32_t s) { return tabs + (enc_locate(g, s).comp ? 512u : 0u); };
     // count pass + per-workgroup sums
     const uint32_t n_wg = (g.nblocks + kEncBlocksPerWg - 1u) / kEncBlocksPerWg;
