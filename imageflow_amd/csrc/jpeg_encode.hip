@@ -122,9 +122,8 @@ __device__ __forceinline__ int32_t stage_blocks(const EncArgs& a, uint32_t img, 
         if (r.pred_offset != 0xFFFFFFFFu) before = mine + (static_cast<ptrdiff_t>(r.pred_offset) - static_cast<ptrdiff_t>(r.offset)) * 64;
         *table = r.comp ? 512u : 0u;
     }
-    // (a lane behind the image's last block names the workgroup's first block: every load below is unconditional, so all
-    // eight are in flight together -- with a test around each they went out one HBM round trip after the other, and that,
-    // not the walk, was what a workgroup spent its time on)
+    // (every load below is unconditional, so all eight are in flight together -- with an "is this block inside the image"
+    // test around each they went out one HBM round trip after the other)
     addr[tid] = mine;
     __syncthreads();
     // A lane carries the same piece (row of the block, natural order) in all eight steps: its eight coefficients go to
@@ -135,12 +134,12 @@ __device__ __forceinline__ int32_t stage_blocks(const EncArgs& a, uint32_t img, 
     for (int i = 0; i < 8; ++i) pos[i] = enc_slot(static_cast<uint32_t>(enc_zigzag_position(static_cast<int>(piece) * 8 + i)));
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(1))) const u32x4 global_u32x4;    // (a pointer that went through LDS is a generic one to the compiler)
-    const int16_t* first = addr[0];
+    // (a step that names a block behind the image's last names the tile's last block instead: every load is unconditional)
+    const uint32_t last = min(kEncBlocksPerWg, a.g.nblocks - s0) - 1u;
     u32x4 v[8];
 #pragma unroll
     for (uint32_t it = 0; it < 8u; ++it) {
-        const int16_t* p = addr[(it * kEncBlocksPerWg + tid) >> 3];
-        p = p ? p : first;
+        const int16_t* p = addr[min((it * kEncBlocksPerWg + tid) >> 3, last)];
         v[it] = *reinterpret_cast<global_u32x4*>(reinterpret_cast<uintptr_t>(p + piece * 8u));
     }
     // (tables and predictor behind the blocks: one round trip to memory for everything the workgroup stages)
@@ -148,13 +147,17 @@ __device__ __forceinline__ int32_t stage_blocks(const EncArgs& a, uint32_t img, 
 #pragma unroll
     for (uint32_t i = 0; i < 1024u / kEncBlocksPerWg; ++i) tv[i] = a.tabs[i * kEncBlocksPerWg + tid];
     const int32_t pred = before ? *before : 0;
+    // (step `it` names the block 32 further on: a constant distance, so the eight addresses of a lane are computed once)
+    uint16_t* d[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = reinterpret_cast<uint16_t*>(blk + (tid >> 3) * kBlkPitch) + pos[i];
 #pragma unroll
     for (uint32_t it = 0; it < 8u; ++it) {
-        uint16_t* d = reinterpret_cast<uint16_t*>(blk + ((it * kEncBlocksPerWg + tid) >> 3) * kBlkPitch);
-        d[pos[0]] = static_cast<uint16_t>(v[it].x); d[pos[1]] = static_cast<uint16_t>(v[it].x >> 16);
-        d[pos[2]] = static_cast<uint16_t>(v[it].y); d[pos[3]] = static_cast<uint16_t>(v[it].y >> 16);
-        d[pos[4]] = static_cast<uint16_t>(v[it].z); d[pos[5]] = static_cast<uint16_t>(v[it].z >> 16);
-        d[pos[6]] = static_cast<uint16_t>(v[it].w); d[pos[7]] = static_cast<uint16_t>(v[it].w >> 16);
+        constexpr uint32_t kStep = (kEncBlocksPerWg / 8u) * kBlkPitch * 2u;      // halfwords between the blocks of two steps
+        d[0][it * kStep] = static_cast<uint16_t>(v[it].x); d[1][it * kStep] = static_cast<uint16_t>(v[it].x >> 16);
+        d[2][it * kStep] = static_cast<uint16_t>(v[it].y); d[3][it * kStep] = static_cast<uint16_t>(v[it].y >> 16);
+        d[4][it * kStep] = static_cast<uint16_t>(v[it].z); d[5][it * kStep] = static_cast<uint16_t>(v[it].z >> 16);
+        d[6][it * kStep] = static_cast<uint16_t>(v[it].w); d[7][it * kStep] = static_cast<uint16_t>(v[it].w >> 16);
     }
 #pragma unroll
     for (uint32_t i = 0; i < 1024u / kEncBlocksPerWg; ++i) tabs[i * kEncBlocksPerWg + tid] = tv[i];

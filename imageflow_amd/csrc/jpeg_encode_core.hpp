@@ -130,7 +130,7 @@ IFHIP_HD uint32_t enc_nbits(uint32_t t) { return t ? 32u - static_cast<uint32_t>
 struct EncCountSink {
     uint32_t bits = 0;
     IFHIP_HD void put(uint32_t, uint32_t len) { bits += len; }
-    IFHIP_HD void put_times(uint32_t, uint32_t len, uint32_t times) { bits += len * times; }
+    IFHIP_HD void put_times(uint32_t, uint32_t len, uint32_t times) { bits += (len & 0xffffu) * (times & 0xffu); }    // (a 24-bit multiply-add)
 };
 
 // Bits go into a stream of big-endian 32-bit words that starts zeroed.  A lane's first word and its last, partial word
@@ -163,11 +163,12 @@ struct EncWordSink {
 };
 
 // The order a staged block is kept in (16-bit slots, two per dword): dword j of the first 16 holds zigzag position j in its
-// HIGH half and position 16 + j in its low half, dword 16 + j positions 32 + j and 48 + j likewise.  With one flag per half
-// (coefficient != 0), shifting the dwords' flag pairs into one register one after the other leaves position p at bit
-// 31 - p: the nonzero mask of 32 positions costs two instructions per dword, and no bit ever has to be moved again.
-IFHIP_HD uint32_t enc_slot(uint32_t k) { return (k & 32u) | ((k & 15u) << 1) | (((k >> 4) & 1u) ^ 1u); }
-IFHIP_HD uint32_t enc_position_of_slot(uint32_t h) { return ((h >> 5) << 5) + ((h >> 1) & 15u) + ((h & 1u) ? 0u : 16u); }
+// low half and position 16 + j in its high half, dword 16 + j positions 32 + j and 48 + j likewise.  With one flag per half
+// (coefficient != 0), shifting the dwords' flag pairs into one register one after the other and swapping the register's
+// halves leaves position p at bit 31 - p: the nonzero mask of 32 positions costs two instructions per dword, and a
+// position's slot is its low five bits rotated left by one.
+IFHIP_HD uint32_t enc_slot(uint32_t k) { return (k & 32u) | ((k << 1) & 30u) | ((k >> 4) & 1u); }
+IFHIP_HD uint32_t enc_position_of_slot(uint32_t h) { return (h & 32u) + ((h >> 1) & 15u) + ((h & 1u) << 4); }
 // 1 in bit 0 / bit 16 for a nonzero low / high half
 IFHIP_HD uint32_t enc_pair_flags(uint32_t w) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -195,6 +196,8 @@ IFHIP_HD uint32_t enc_block(const Coef& coef, int32_t pred, const uint32_t* dct,
     for (int j = 0; j < 16; ++j) hi = (hi << 1) | enc_pair_flags(coef.pair(j));
 #pragma unroll
     for (int j = 16; j < 32; ++j) lo = (lo << 1) | enc_pair_flags(coef.pair(j));
+    hi = (hi << 16) | (hi >> 16);                             // positions 0 .. 15 were the low halves
+    lo = (lo << 16) | (lo >> 16);
     uint64_t m = (static_cast<uint64_t>(hi & 0x7fffffffu) << 32) | lo;      // (bit 63 would be the DC value)
     {
         const int32_t diff = coef(0) - pred;
@@ -205,23 +208,22 @@ IFHIP_HD uint32_t enc_block(const Coef& coef, int32_t pred, const uint32_t* dct,
         sink.put(((cs & 0xffffu) << nb) | (t2 & ((1u << nb) - 1u)), (cs >> 16) + nb);
     }
     const uint32_t zrl = act[0xF0], eob = act[0];
-    uint32_t prev = 0;
+    uint32_t prev = 0, widest = 0;
     while (m) {
         const uint32_t k = static_cast<uint32_t>(__builtin_clzll(m));
         m &= ~(0x8000000000000000ull >> k);
-        uint32_t run = k - prev - 1u;
+        const uint32_t run = k - prev - 1u;
         prev = k;
-        if (run > 15u) {                                      // ZRL symbols for every 16 zeros of the run
-            sink.put_times(zrl & 0xffffu, zrl >> 16, run >> 4);
-            run &= 15u;
-        }
-        const int32_t v = coef(static_cast<int>(k));
+        sink.put_times(zrl & 0xffffu, zrl >> 16, (run >> 4) & 3u);    // a ZRL symbol for every 16 zeros of the run (none: a no-op)
+        const int32_t v = coef(static_cast<int>(k));                  // (not zero: the mask says so)
         const uint32_t t = static_cast<uint32_t>(v < 0 ? -v : v), t2 = static_cast<uint32_t>(v < 0 ? v - 1 : v);
-        uint32_t nb = enc_nbits(t);
-        if (nb > 10u) { bad = 1u; nb = 10u; }
-        const uint32_t cs = act[(run << 4) + nb];
+        uint32_t nb = 32u - static_cast<uint32_t>(__builtin_clz(t));
+        widest = nb > widest ? nb : widest;
+        nb = nb > 10u ? 10u : nb;
+        const uint32_t cs = act[((run & 15u) << 4) + nb];
         sink.put(((cs & 0xffffu) << nb) | (t2 & ((1u << nb) - 1u)), (cs >> 16) + nb);
     }
+    bad |= widest > 10u ? 1u : 0u;
     if (prev != 63u) sink.put(eob & 0xffffu, eob >> 16);
     return bad;
 }

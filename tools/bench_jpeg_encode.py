@@ -42,6 +42,8 @@ def main():
     bm = Bitmap(smooth_frames(n, w, h, stride, dev), w, h, stride)
     res = {"frames": n, "w": w, "h": h, "quality": q, "device": torch.cuda.get_device_name(0)}
     for name, hs, vs in (("420", (2, 1, 1), (2, 1, 1)), ("444", (1, 1, 1), (1, 1, 1))):
+        if os.environ.get("ENC_ONLY", name) != name:       # (counter passes: one sampling per run)
+            continue
         fwd = M.JpegForwardStage(w, h, hs, vs, n, dev)
         qt = torch.from_numpy(np.stack([M.quant_tables_for_quality(q)] * n).view(np.int16)).to(dev)
         coef = fwd.write_frames(bm, qt)
