@@ -228,7 +228,7 @@ struct LdsStore {                   // the window: every word is ORed in (an LDS
 
 __global__ __launch_bounds__(256) void enc_write_kernel(const EncArgs a) {
     __shared__ uint32_t blk[kEncBlocksPerWg * kBlkPitch];
-    __shared__ uint32_t win[kEncWindowWords];              // (its head holds the blocks' addresses while they are staged)
+    __shared__ uint32_t win[kEncWindowWords + 1u];         // (+ the sink's spare word; the head holds the blocks' addresses while they are staged)
     __shared__ uint32_t tabs[1024];
     __shared__ uint32_t scratch[8];
     static_assert(kEncWindowWords * sizeof(uint32_t) >= kEncBlocksPerWg * sizeof(const int16_t*), "the address list must fit the window");
@@ -247,24 +247,23 @@ __global__ __launch_bounds__(256) void enc_write_kernel(const EncArgs a) {
     const bool windowed = n_words <= kEncWindowWords;      // (uniform)
     uint32_t* stream = a.words + static_cast<size_t>(img) * a.cap_words;
     if (windowed) {
-        for (uint32_t i = tid; i < n_words; i += kEncBlocksPerWg) win[i] = 0u;
+        for (uint32_t i = tid; i <= n_words; i += kEncBlocksPerWg) win[i] = 0u;
         __syncthreads();
     }
     if (valid) {
         const LdsCoef coef{blk + tid * kBlkPitch};
         if (windowed) {
-            EncWordSink<LdsStore> sink(win, (base & 31u) + local);
+            EncWindowSink<LdsStore> sink(win, (base & 31u) + local);
             enc_block(coef, pred, tabs + t, tabs + t + 256u, sink);
             if (s == a.g.nblocks - 1u) {
-                const uint32_t pad = (8u - (sink.n & 7u)) & 7u;
+                const uint32_t pad = (8u - sink.bits_in_last_byte()) & 7u;
                 if (pad) sink.put((1u << pad) - 1u, pad);
             }
-            sink.finish();
         } else {
             EncWordSink<DeviceStore> sink(stream, base + local);
             enc_block(coef, pred, tabs + t, tabs + t + 256u, sink);
             if (s == a.g.nblocks - 1u) {
-                const uint32_t pad = (8u - (sink.n & 7u)) & 7u;
+                const uint32_t pad = (8u - sink.bits_in_last_byte()) & 7u;
                 if (pad) sink.put((1u << pad) - 1u, pad);
             }
             sink.finish();
@@ -274,7 +273,7 @@ __global__ __launch_bounds__(256) void enc_write_kernel(const EncArgs a) {
         __syncthreads();
         uint32_t* dst = stream + (base >> 5);
         for (uint32_t i = tid; i < n_words; i += kEncBlocksPerWg) {
-            const uint32_t v = win[i];
+            const uint32_t v = __builtin_bswap32(win[i]);
             if (i == 0u || i == n_words - 1u) atomicOr(dst + i, v);
             else dst[i] = v;
         }
@@ -304,6 +303,7 @@ __global__ __launch_bounds__(256) void enc_ff_count_kernel(const EncArgs a) {
 
 __global__ __launch_bounds__(256) void enc_stuff_kernel(const EncArgs a) {
     __shared__ uint32_t scratch[8];
+    __shared__ uint8_t obuf[2u * kEncChunkBytes];          // a chunk's stuffed bytes (every byte 0xFF at worst)
     const uint32_t tid = threadIdx.x, img = blockIdx.y;
     const uint32_t st = a.status[img];
     // (a dropped image has written no word, its stream is still zero; nothing to clean)
@@ -333,8 +333,11 @@ __global__ __launch_bounds__(256) void enc_stuff_kernel(const EncArgs a) {
         }
         uint32_t total;
         const uint32_t ex = block_exclusive_scan<256>(c, scratch, &total);
-        if (fits && at < bytes) {
-            uint8_t* d = out + a.header_len + at + a.ff[static_cast<size_t>(img) * a.max_chunks + chunk] + ex;
+        if (!fits) continue;                               // (uniform)
+        // The lanes' bytes meet in LDS and leave as runs of consecutive bytes: stored straight from the lanes, every store
+        // instruction scattered its 64 bytes over a kilobyte of the file (sixteen partial cache lines each).
+        if (at < bytes) {
+            uint8_t* d = obuf + tid * 16u + ex;
             const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
             const uint32_t nb = bytes - at < 16u ? bytes - at : 16u;
 #pragma unroll
@@ -346,6 +349,11 @@ __global__ __launch_bounds__(256) void enc_stuff_kernel(const EncArgs a) {
                 }
             }
         }
+        __syncthreads();
+        const uint32_t n_in = bytes - chunk * kEncChunkBytes < kEncChunkBytes ? bytes - chunk * kEncChunkBytes : kEncChunkBytes;
+        uint8_t* dst = out + a.header_len + chunk * kEncChunkBytes + a.ff[static_cast<size_t>(img) * a.max_chunks + chunk];
+        for (uint32_t i = tid; i < n_in + total; i += 256u) dst[i] = obuf[i];
+        __syncthreads();                                   // (the buffer is reused by the next chunk)
     }
 }
 

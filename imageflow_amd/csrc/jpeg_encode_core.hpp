@@ -160,6 +160,30 @@ struct EncWordSink {
     IFHIP_HD void finish() {
         if (n) Store::shared(p, __builtin_bswap32(static_cast<uint32_t>(acc << (32u - n))));
     }
+    IFHIP_HD uint32_t bits_in_last_byte() const { return n & 7u; }
+};
+
+// The window form: no accumulator, no "is a word full" test in the symbol loop -- every field is shifted to its place in
+// the two words it may touch and ORed into both (the second OR is of zero when the field ends inside the first word; the
+// window carries one spare word for it).  Words are kept most-significant-bit-first as numbers; the copy-out turns them
+// into the stream's byte order.
+template <class Store>
+struct EncWindowSink {
+    uint32_t* w;
+    uint32_t pos;               // bit position in the window
+    IFHIP_HD EncWindowSink(uint32_t* window, uint32_t bit_offset) : w(window), pos(bit_offset) {}
+    IFHIP_HD void put(uint32_t code, uint32_t len) {
+        const uint64_t f = static_cast<uint64_t>(code) << ((64u - (pos & 31u) - len) & 63u);   // (64 only for an empty field at a word's start)
+        uint32_t* p = w + (pos >> 5);
+        Store::shared(p, static_cast<uint32_t>(f >> 32));
+        Store::shared(p + 1, static_cast<uint32_t>(f));
+        pos += len;
+    }
+    IFHIP_HD void put_times(uint32_t code, uint32_t len, uint32_t times) {
+        for (; times; --times) put(code, len);
+    }
+    IFHIP_HD void finish() {}
+    IFHIP_HD uint32_t bits_in_last_byte() const { return pos & 7u; }
 };
 
 // The order a staged block is kept in (16-bit slots, two per dword): dword j of the first 16 holds zigzag position j in its

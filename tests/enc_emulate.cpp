@@ -101,7 +101,7 @@ extern "C" int enc_emulate(const int16_t* c0, const int16_t* c1, const int16_t* 
         if (s1 == g.nblocks) total += enc_final_padding(wg[w] + total);
         const uint32_t n_words = enc_window_words(wg[w], total);
         const bool windowed = n_words <= kEncWindowWords;
-        std::vector<uint32_t> win(windowed ? n_words : 0u, 0u);
+        std::vector<uint32_t> win(windowed ? n_words + 1u : 0u, 0u);              // (one spare word: EncWindowSink)
         std::vector<uint8_t> win_mark(win.size(), 0);
         if (windowed) { g_words = win.data(); g_mark = &win_mark; ++window_wgs; }
         else { g_words = words.data(); g_mark = &mark; }
@@ -111,21 +111,25 @@ extern "C" int enc_emulate(const int16_t* c0, const int16_t* c1, const int16_t* 
         for (uint32_t s : order) {
             uint32_t off = windowed ? (wg[w] & 31u) : wg[w];
             for (uint32_t q = s0; q < s; ++q) off += nbits[q];
-            EncWordSink<HostStore> sink(g_words, off);
             const uint32_t* t = tab_of(s);
-            enc_block(PlaneCoef{block(s)}, pred_of(s), t, t + 256, sink);
-            if (s == g.nblocks - 1u) {
-                const uint32_t pad = (8u - (sink.n & 7u)) & 7u;
-                if (pad) sink.put((1u << pad) - 1u, pad);
-            }
-            sink.finish();
+            auto code = [&](auto& sink) {
+                enc_block(PlaneCoef{block(s)}, pred_of(s), t, t + 256, sink);
+                if (s == g.nblocks - 1u) {
+                    const uint32_t pad = (8u - sink.bits_in_last_byte()) & 7u;
+                    if (pad) sink.put((1u << pad) - 1u, pad);
+                }
+                sink.finish();
+            };
+            if (windowed) { EncWindowSink<HostStore> sink(g_words, off); code(sink); }
+            else { EncWordSink<HostStore> sink(g_words, off); code(sink); }
         }
         if (windowed) {
+            if (win[n_words] != 0u) ++g_violations;                                 // the spare word only ever takes zeros
             g_words = words.data(); g_mark = &mark;
             uint32_t* dst = words.data() + (wg[w] >> 5);
             for (uint32_t i = 0; i < n_words; ++i) {
-                if (i == 0 || i == n_words - 1u) HostStore::shared(dst + i, win[i]);
-                else HostStore::owned(dst + i, win[i]);
+                if (i == 0 || i == n_words - 1u) HostStore::shared(dst + i, __builtin_bswap32(win[i]));
+                else HostStore::owned(dst + i, __builtin_bswap32(win[i]));
             }
         }
     }

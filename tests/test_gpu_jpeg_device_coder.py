@@ -121,3 +121,29 @@ def test_encoder_mirror_uses_the_device_coder():
     on_device = enc.write_frames(Bitmap.from_numpy(frames.copy(), w, h, stride, "cuda:0"))
     on_host = enc.write_frames(Bitmap.from_numpy(frames.copy(), w, h, stride, "cuda:0"), device_entropy=False)
     assert on_device == on_host and all(f[:2] == b"\xff\xd8" and f[-2:] == b"\xff\xd9" for f in on_device)
+
+
+def test_full_size_frames_equal_the_host_writer_and_decode():
+    """BASELINE's frame size: two 3840x2160 frames (194 400 blocks each: 760 workgroups per pass, hundreds of chunks) ->
+    the device coder's files equal the host writer's and are files libjpeg reads back to the pixels within JPEG's error."""
+    import io
+    from PIL import Image
+    w, h, n, q = 3840, 2160, 2, 90
+    hs, vs = [2, 1, 1], [2, 1, 1]
+    stride = O.stride_for_width(w)
+    frames = np.zeros((n, h, stride), np.uint8)
+    rgbs = [photo(w, h, 77 + k, noise=6 + 30 * k) for k in range(n)]
+    for k, rgb in enumerate(rgbs):
+        px = frames[k, :, :4 * w].reshape(h, w, 4)
+        px[..., 0], px[..., 1], px[..., 2], px[..., 3] = rgb[..., 2], rgb[..., 1], rgb[..., 0], 255
+    stage = M.JpegForwardStage(w, h, hs, vs, n)
+    qt = torch.from_numpy(np.stack([M.quant_tables_for_quality(q)] * n).view(np.int16)).cuda()
+    coef = stage.write_frames(Bitmap.from_numpy(frames, w, h, stride, "cuda:0"), qt)
+    coder = M.JpegEntropyStage(w, h, hs, vs, stage.blocks_w, stage.blocks_h, n)
+    files, status = coder.encode(coef, q)
+    assert status == [0, 0]
+    assert files == M.write_jpeg_batch([c.cpu().numpy() for c in coef], w, h, hs, vs, q)
+    for f, rgb in zip(files, rgbs):
+        back = np.asarray(Image.open(io.BytesIO(f)).convert("RGB"), np.int32)
+        assert back.shape == (h, w, 3)
+        assert np.abs(back - rgb.astype(np.int32)).mean() < 6.0
