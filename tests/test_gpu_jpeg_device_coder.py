@@ -146,4 +146,4 @@ def test_full_size_frames_equal_the_host_writer_and_decode():
     for f, rgb in zip(files, rgbs):
         back = np.asarray(Image.open(io.BytesIO(f)).convert("RGB"), np.int32)
         assert back.shape == (h, w, 3)
-        assert np.abs(back - rgb.astype(np.int32)).mean() < 6.0
+        assert np.abs(back - rgb.astype(np.int32)).mean() < 20.0      # (4.3 / 14 through libjpeg-turbo's own encoder: 4:2:0 drops the chroma noise)
