@@ -1080,7 +1080,7 @@ struct Job {
         if (name == "watermark") return watermark(in, p);
         if (name == "encode") { encode(in, static_cast<int32_t>(want_int(p, "io_id", "encode")), p.get("preset"), in_shared); return in; }
         Timed t(this, name == "fill_rect" ? "fill_rect_mutate" : name == "crop" ? "crop_mutate" : name == "flip_v" ? "flip_vertical_mutate" : name == "flip_h" ? "flip_vertical_mutate" /* sic: rotate_flip_transpose.rs:206 */
-                      : name == "color_matrix_srgb" || name == "color_filter_srgb" ? "color_matrix_srgb_mut" : name == "expand_canvas" ? "expand_canvas" : name == "transpose" ? "transpose_mut"
+                      : name == "color_matrix_srgb" || name == "color_filter_srgb" ? "color_matrix_srgb_mut" : name == "expand_canvas" || name == "region" || name == "region_percent" ? "expand_canvas" : name == "transpose" ? "transpose_mut"
                       : name == "rotate_90" ? "rotate_90" : name == "rotate_180" ? "rotate_180" : name == "rotate_270" ? "rotate_270" : name == "apply_orientation" ? "apply_orientation" : "node");
         if (name == "fill_rect") {                                                    // clone_crop_fill_expand.rs:107-137
             in->compose = IFHIP_BLEND_WITH_SELF;                                      // :112: set before the fill, so matte canvases accept sub-rects
@@ -1102,6 +1102,54 @@ struct Job {
             if (x2 <= x1 || y2 <= y1 || x2 > in->w || y2 > in->h) raise(kArgumentInvalid, "InvalidNodeParams: Invalid crop bounds");
             FramePtr cv = new_frame(x2 - x1, y2 - y1, in->alpha, 0, true);
             return copy_into_canvas(in, cv, x1, y1, x2 - x1, y2 - y1, 0, 0);
+        }
+        if (name == "region" || name == "region_percent") {                            // :263-452
+            // RegionPercent rewrites itself into Region with pixel corners (get_coords :265-286: f32 arithmetic, round half
+            // away from zero, a side the percentages collapse gets one pixel), Region into Crop + ExpandCanvas -- or into a
+            // plain CreateCanvas of the parent's format when the rectangle misses the frame altogether (:409-421)
+            int64_t x1, y1, x2, y2;
+            const uint32_t color = parse_color(p.get("background_color"), "region.background_color");
+            if (name == "region_percent") {
+                auto pct = [&](const char* k) -> float {
+                    const JVal* v = p.get(k);
+                    if (!v || v->t != JVal::Num) raise(kInvalidJson, "InvalidJson: region_percent.%s is a number", k);
+                    return static_cast<float>(v->n);
+                };
+                const float l = pct("x1"), t2 = pct("y1"), r = pct("x2"), b = pct("y2");
+                if (b <= t2 || r <= l) raise(kArgumentInvalid, "InvalidNodeParams: Invalid coordinates: %g,%g %g,%g should describe the top-left and bottom-right corners of the region in percentages. Not a rectangle.", l, t2, r, b);
+                auto px = [](uint32_t side, float pc) -> int64_t {                    // `(side as f32 * pc / 100f32).round() as i32` (saturating)
+                    const float v = std::round(static_cast<float>(side) * pc / 100.0f);
+                    return v != v ? 0 : v >= 2147483648.0f ? INT32_MAX : v <= -2147483648.0f ? INT32_MIN : static_cast<int64_t>(v);
+                };
+                x1 = px(in->w, l); y1 = px(in->h, t2); x2 = px(in->w, r); y2 = px(in->h, b);
+                if (x2 < x1) x2 = x1 + 1;                                             // sic: `<`, equal corners fall through to Region's own check
+                if (y2 < y1) y2 = y1 + 1;
+            } else {
+                auto i32 = [&](const char* k) -> int64_t {
+                    const int64_t v = want_int(p, k, "region");
+                    if (v < INT32_MIN || v > INT32_MAX) raise(kInvalidJson, "InvalidJson: region.%s is a 32-bit integer", k);
+                    return v;
+                };
+                x1 = i32("x1"); y1 = i32("y1"); x2 = i32("x2"); y2 = i32("y2");
+            }
+            if (y2 <= y1 || x2 <= x1) raise(kArgumentInvalid, "InvalidNodeParams: Invalid coordinates: %lld,%lld %lld,%lld should describe the top-left and bottom-right corners of the region in pixels. Not a rectangle.",
+                                            static_cast<long long>(x1), static_cast<long long>(y1), static_cast<long long>(x2), static_cast<long long>(y2));
+            const int64_t iw = in->w, ih = in->h;
+            check_size(sec.max_frame_size, "max_frame_size", static_cast<uint64_t>(x2 - x1), static_cast<uint64_t>(y2 - y1));
+            if (x1 >= iw || y1 >= ih || x2 <= 0 || y2 <= 0)                           // nothing of the input inside: a canvas of the colour
+                return new_frame(static_cast<uint32_t>(x2 - x1), static_cast<uint32_t>(y2 - y1), in->alpha, color, true);
+            const uint32_t cx1 = static_cast<uint32_t>(std::min(iw, std::max<int64_t>(0, x1))), cy1 = static_cast<uint32_t>(std::min(ih, std::max<int64_t>(0, y1)));
+            const uint32_t cx2 = static_cast<uint32_t>(std::min(iw, std::max<int64_t>(0, x2))), cy2 = static_cast<uint32_t>(std::min(ih, std::max<int64_t>(0, y2)));
+            const uint32_t el = static_cast<uint32_t>(std::max<int64_t>(0, -x1)), et = static_cast<uint32_t>(std::max<int64_t>(0, -y1));
+            const uint32_t er = static_cast<uint32_t>(std::max<int64_t>(0, x2 - iw)), eb = static_cast<uint32_t>(std::max<int64_t>(0, y2 - ih));
+            FramePtr part = in;
+            if (cx1 != 0 || cy1 != 0 || cx2 != in->w || cy2 != in->h) {               // Crop (a full-frame crop is the frame)
+                part = new_frame(cx2 - cx1, cy2 - cy1, in->alpha, 0, true);
+                copy_into_canvas(in, part, cx1, cy1, cx2 - cx1, cy2 - cy1, 0, 0);
+            }
+            // ExpandCanvas, also by nothing: CreateCanvas of the colour + CopyRectToCanvas (:231-255)
+            FramePtr cv = new_frame(part->w + el + er, part->h + et + eb, (color >> 24) == 255 ? part->alpha : true, color, true);
+            return copy_into_canvas(part, cv, 0, 0, part->w, part->h, el, et);
         }
         if (name == "color_matrix_srgb") {                                            // s::Node::ColorMatrixSrgb {matrix: [[f32;5];5]}
             const JVal* mj = p.get("matrix");

@@ -27,7 +27,7 @@ def copy_rect_to_canvas(input: Bitmap, canvas: Bitmap, from_x, from_y, w, h, x, 
     """CopyRectNodeDef::render (:31-90)."""
     if (input.w <= from_x or input.h <= from_y or input.w < from_x + w or input.h < from_y + h
             or canvas.w < x + w or canvas.h < y + h):
-        raise FlowError(ErrorKind.InvalidNodeParams, f"Invalid coordinates. Canvas is {canvas.w}x{canvas.h}, Input is {input.w}x{input.h}")
+        raise FlowError(ErrorKind.InvalidArgument, f"InvalidNodeParams: Invalid coordinates. Canvas is {canvas.w}x{canvas.h}, Input is {input.w}x{input.h}")
     G.copy_rectangle(input, canvas, from_x, from_y, x, y, w, h)
     return canvas
 
@@ -52,3 +52,40 @@ def fill_rect(b: Bitmap, x1, y1, x2, y2, color32) -> Bitmap:
     b.compose = BitmapCompositing.BlendWithSelf
     G.fill_rectangle(b, color32, x1, y1, x2, y2)
     return b
+
+
+def region_percent_coords(w, h, left, top, right, bottom):
+    """RegionPercentDef::get_coords (:265-286): `(side as f32 * pct / 100f32).round() as i32` -- f32 arithmetic, half away
+    from zero -- and a side the percentages invert gets one pixel (`x2 < x1`; equal corners stay equal)."""
+    import numpy as np
+
+    def px(side, pct):
+        v = np.float32(side) * np.float32(pct) / np.float32(100)
+        r = float(np.copysign(np.floor(np.abs(v) + np.float32(0.5)), v))
+        return int(max(-2 ** 31, min(2 ** 31 - 1, r)))
+    x1, y1, x2, y2 = px(w, left), px(h, top), px(w, right), px(h, bottom)
+    if x2 < x1:
+        x2 = x1 + 1
+    if y2 < y1:
+        y2 = y1 + 1
+    return x1, y1, x2, y2
+
+
+def region(b: Bitmap, x1, y1, x2, y2, color32) -> Bitmap:
+    """RegionDef::expand (:390-452): Crop to the part of the rectangle inside the frame, then ExpandCanvas by the rest; a
+    rectangle that misses the frame is a canvas of the colour in the parent's format."""
+    if y2 <= y1 or x2 <= x1:
+        raise FlowError(ErrorKind.InvalidArgument, f"InvalidNodeParams: Invalid coordinates: {x1},{y1} {x2},{y2} should describe the top-left and "
+                        "bottom-right corners of the region in pixels. Not a rectangle.")
+    if x1 >= b.w or y1 >= b.h or x2 <= 0 or y2 <= 0:
+        return create_canvas(b.n, x2 - x1, y2 - y1, b.data.device, color32, b.alpha_meaningful)
+    part = crop(b, min(b.w, max(0, x1)), min(b.h, max(0, y1)), min(b.w, max(0, x2)), min(b.h, max(0, y2)))
+    return expand_canvas(part, max(0, -x1), max(0, -y1), max(0, x2 - b.w), max(0, y2 - b.h), color32)
+
+
+def region_percent(b: Bitmap, left, top, right, bottom, color32) -> Bitmap:
+    """RegionPercentDef::expand (:316-352)."""
+    if bottom <= top or right <= left:
+        raise FlowError(ErrorKind.InvalidArgument, f"InvalidNodeParams: Invalid coordinates: {left},{top} {right},{bottom} should describe the top-left "
+                        "and bottom-right corners of the region in percentages. Not a rectangle.")
+    return region(b, *region_percent_coords(b.w, b.h, left, top, right, bottom), color32)

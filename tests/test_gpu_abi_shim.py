@@ -579,3 +579,55 @@ def test_build_with_byte_array_input_and_base64_output():
         assert got == bytes(c.get_output_buffer(1)) and (enc["w"], enc["h"]) == (12, 8)
         rows = unpack_raw_bgra(got)[0]
     assert np.array_equal(rows, _oracle_resize(src, 24, 16, 12, 8, filter_id=2))
+
+
+def _bgra(hex_rgba):
+    r, g, b, a = (int(hex_rgba[i:i + 2], 16) for i in (0, 2, 4, 6))
+    return np.array([b, g, r, a], np.uint8)
+
+
+@pytest.mark.parametrize("node,corners,color,color_bgra", [
+    ({"region": {"x1": -5, "y1": 4, "x2": 40, "y2": 36}}, (-5, 4, 40, 36), {"srgb": {"hex": "2233AAFF"}}, "2233AAFF"),       # crop + expand left / bottom
+    ({"region": {"x1": 3, "y1": 2, "x2": 20, "y2": 11}}, (3, 2, 20, 11), "transparent", "00000000"),                        # inside: crop, expand by nothing
+    ({"region": {"x1": 60, "y1": 0, "x2": 70, "y2": 10}}, (60, 0, 70, 10), {"srgb": {"hex": "FF8000"}}, "FF8000FF"),         # misses the frame: a canvas
+    ({"region_percent": {"x1": 10, "y1": 20, "x2": 110, "y2": 60}}, (5, 6, 55, 18), "black", "000000FF"),                    # right edge beyond the frame
+    ({"region_percent": {"x1": 33, "y1": 0, "x2": 33.5, "y2": 100}}, (17, 0, 17 + 0, 30), "black", "000000FF"),              # 16.5 rounds away from zero; see below
+])
+def test_region_nodes_crop_then_expand_like_the_reference(node, corners, color, color_bgra):
+    """clone_crop_fill_expand.rs:263-452: RegionPercent -> Region (f32 percent arithmetic, half away from zero) -> Crop +
+    ExpandCanvas, or a plain canvas of the colour when the rectangle misses the frame.  Expected pixels by numpy."""
+    src = U.random_frames(1, 50, 30, seed0=83, alpha=True)[0]
+    name = next(iter(node))
+    node = {name: dict(node[name], background_color=color)}
+    x1, y1, x2, y2 = corners
+    if name == "region_percent" and x2 <= x1:
+        # get_coords :279-284 only widens `x2 < x1`; 16.75 rounds to 17 as well, so Region refuses the empty rectangle
+        with Context() as c:
+            c.add_input_buffer(0, pack_raw_bgra(src, 50, 30, alpha_meaningful=True))
+            c.add_output_buffer(1)
+            status, r = c.send_json("v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, node, {"encode": {"io_id": 1, "preset": "gif"}}]}})
+            assert status == 400 and "Not a rectangle" in r["message"], r
+        return
+    with Context() as c:
+        c.add_input_buffer(0, pack_raw_bgra(src, 50, 30, alpha_meaningful=True))
+        c.add_output_buffer(1)
+        _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, node, {"encode": {"io_id": 1, "preset": "gif"}}]}})
+        rows, w, h, alpha = unpack_raw_bgra(c.get_output_buffer(1))
+    assert (w, h) == (x2 - x1, y2 - y1)
+    exp = np.tile(_bgra(color_bgra), (h, w, 1))
+    sx1, sy1, sx2, sy2 = max(0, x1), max(0, y1), min(50, x2), min(30, y2)
+    if sx2 > sx1 and sy2 > sy1:
+        exp[sy1 - y1:sy2 - y1, sx1 - x1:sx2 - x1] = src[:, :200].reshape(30, 50, 4)[sy1:sy2, sx1:sx2]
+    assert np.array_equal(rows[:, :4 * w].reshape(h, w, 4), exp)
+    assert alpha                                                    # Bgra32 parent: the format survives an opaque colour (:237)
+
+
+def test_region_refuses_an_empty_rectangle():
+    src = U.random_frames(1, 16, 16, seed0=84, alpha=False)[0]
+    for node in ({"region": {"x1": 4, "y1": 4, "x2": 4, "y2": 9, "background_color": "black"}},
+                 {"region_percent": {"x1": 50, "y1": 10, "x2": 50, "y2": 90, "background_color": "black"}}):
+        with Context() as c:
+            c.add_input_buffer(0, pack_raw_bgra(src, 16, 16, alpha_meaningful=False))
+            c.add_output_buffer(1)
+            status, r = c.send_json("v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, node, {"encode": {"io_id": 1, "preset": "gif"}}]}})
+            assert status == 400 and c.error_code() != 0 and "Not a rectangle" in r["message"], r

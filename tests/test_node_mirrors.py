@@ -69,3 +69,27 @@ def test_orientation_sizes_and_quality_tables():
     assert q50[0, 0] == 16 and q50[1, 0] == 17 and np.array_equal(q50[1], q50[2])      # scale 100: the Annex K tables
     assert q75[0, 0] == 8 and q75[0, 1] == 6                                            # (16*50+50)/100, (11*50+50)/100
     assert MJ.sampling_factors((2, 2), (1, 1)) == ([2, 1, 2], [2, 1, 2])                # mixed chroma sizes, mozjpeg.rs:141-149
+
+
+def test_region_percent_coordinates_round_in_f32_away_from_zero():
+    """RegionPercentDef::get_coords (clone_crop_fill_expand.rs:265-286)."""
+    assert CC.region_percent_coords(50, 30, 10, 20, 110, 60) == (5, 6, 55, 18)
+    assert CC.region_percent_coords(50, 30, 33, 0, 33.5, 100) == (17, 0, 17, 30)      # 16.5 and 16.75 -> 17: equal corners stay (`<`, not `<=`)
+    assert CC.region_percent_coords(50, 30, -5, -50, 100, 100) == (-3, -15, 50, 30)   # -2.5 -> -3 (half away from zero)
+    assert CC.region_percent_coords(3, 3, 0, 0, 0.1, 0.1) == (0, 0, 0, 0)
+    assert CC.region_percent_coords(10, 10, 60, 0, 50, 100)[2] == 7                    # inverted side: one pixel
+    b = Bitmap(torch.zeros((1, 4 * 64), dtype=torch.uint8), 8, 4, 64)
+    for bad in ((2, 0, 2, 4), (0, 3, 8, 3), (5, 0, 1, 4)):
+        with pytest.raises(FlowError):
+            CC.region(b, *bad, 0)
+    with pytest.raises(FlowError):
+        CC.region_percent(b, 50, 0, 50, 100, 0)
+
+
+def test_copy_rect_to_canvas_refuses_rectangles_outside_either_bitmap():
+    """CopyRectNodeDef::render (clone_crop_fill_expand.rs:44-60): a FlowError, before any device call."""
+    a = Bitmap(torch.zeros((1, 4 * 64), dtype=torch.uint8), 8, 4, 64)
+    c = Bitmap(torch.zeros((1, 4 * 64), dtype=torch.uint8), 6, 4, 64)
+    for args in ((8, 0, 1, 1, 0, 0), (0, 4, 1, 1, 0, 0), (4, 0, 5, 1, 0, 0), (0, 0, 7, 1, 0, 0), (0, 0, 2, 2, 5, 0), (0, 0, 2, 2, 0, 3)):
+        with pytest.raises(FlowError, match="Invalid coordinates"):
+            CC.copy_rect_to_canvas(a, c, *args)
