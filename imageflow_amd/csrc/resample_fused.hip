@@ -31,6 +31,12 @@
 #ifndef IFHIP_DOT4_LUT
 #define IFHIP_DOT4_LUT 1     // table addresses of the vertical pass by v_dot4_u32_u8 (0: byte extract + shift-add, for A/B)
 #endif
+#ifndef IFHIP_REFILL_EARLY
+#define IFHIP_REFILL_EARLY 0     // BGRA sources: table addresses, THEN the row refill, then the next record and the gathers (see the step loop);
+#endif                           // bit 0: pipelined shapes, bit 1: the plain shape
+#ifndef IFHIP_ALPHA_PAIR_ONE
+#define IFHIP_ALPHA_PAIR_ONE 0   // premultiply: (c2, 1) * (af, af) as one v_pk_mul_f32 (exact: af * 1 == af) instead of v_mul + a copy of af
+#endif
 #ifndef IFHIP_H_UNROLL
 #define IFHIP_H_UNROLL 1     // measured: 1 beats 2 and 3 (-1.7%); the chain is not latency-bound per group, code size matters
 #endif
@@ -65,6 +71,8 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     constexpr int C = ALPHA ? 4 : 3;
     constexpr int D = fused_shape(K, C).rows_in_flight;
     constexpr bool PIPE = fused_shape(K, C).pipelined != 0;
+    constexpr bool RE = (IFHIP_REFILL_EARLY & (PIPE ? 1 : 2)) != 0 && IFHIP_DOT4_LUT != 0 && !YCC;   // step order, see the step loop
+    constexpr bool PAIR1 = IFHIP_ALPHA_PAIR_ONE != 0 && ALPHA && !YCC && !RE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // A workgroup works on F = a.frames_per_wg frames side by side (F > 1 only for sources narrower than half the
@@ -229,6 +237,17 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     typedef __attribute__((address_space(3))) const float lds_cfloat;
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     const uint32_t lut_lane = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(smem + L.lut))) + (lut.lane_off << 2);
+    // IFHIP_ALPHA_PAIR_ONE: the constant 1 next to every pixel's third table value, as a value the optimiser cannot see
+    // through: it then stays in the odd register of the pair the gather writes its even half of, instead of being
+    // re-made every step.  (Used by `convert`, i.e. wherever the step order is not IFHIP_REFILL_EARLY's.)
+    float one[PX];
+    if constexpr (PAIR1) {
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            one[p] = 1.0f;
+            asm volatile("" : "+v"(one[p]));
+        }
+    }
     auto convert = [&](const raw_t& q, f32x2 (&vv)[NP]) {
         float v[PX][C];
         if constexpr (YCC) {
@@ -276,6 +295,13 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             v[p][1] = lut[(px >> 8) & 255u];
             v[p][2] = lut[(px >> 16) & 255u];
 #endif
+            if constexpr (PAIR1) {
+                const float af = static_cast<float>(px >> 24) * (1.0f / 255.0f);
+                const f32x2 a2 = {af, af};
+                vv[2 * p] = f32x2{v[p][0], v[p][1]} * a2;
+                vv[2 * p + 1] = f32x2{v[p][2], one[p]} * a2;       // (c2 * af, af)
+                continue;
+            }
             if (ALPHA) {
                 const float af = static_cast<float>(px >> 24) * (1.0f / 255.0f);
                 v[p][0] = v[p][0] * af;
@@ -285,8 +311,42 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             }
         }
         }
+        if constexpr (PAIR1) return;                               // pairs written above
 #pragma unroll
         for (int i = 0; i < NP; ++i) vv[i] = f32x2{v[(2 * i) / C][(2 * i) % C], v[(2 * i + 1) / C][(2 * i + 1) % C]};
+    };
+
+    // The same conversion in three pieces, for the step order of IFHIP_REFILL_EARLY: what needs the row's bytes (table
+    // addresses, the alpha factor), the gathers, and the pairing / premultiply of what they return.
+    struct Gathered { float g[PX][3]; float af[PX]; };
+    auto conv_addresses = [&](const bgra_raw_t& q, uint32_t (&ad)[PX][3], Gathered& o) {
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ad[p][k] = __builtin_amdgcn_udot4(q[p], lut_mul << (8 * k), lut_lane, false);
+            if (ALPHA) o.af[p] = static_cast<float>(q[p] >> 24) * (1.0f / 255.0f);
+        }
+    };
+    auto conv_gather = [&](const uint32_t (&ad)[PX][3], Gathered& o) {
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o.g[p][k] = *reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(ad[p][k]));
+    };
+    auto conv_pack = [&](const Gathered& i, f32x2 (&vv)[NP]) {
+        if constexpr (ALPHA) {
+#pragma unroll
+            for (int p = 0; p < PX; ++p) {
+                const f32x2 a2 = {i.af[p], i.af[p]};
+                vv[2 * p] = f32x2{i.g[p][0], i.g[p][1]} * a2;
+                // (not the (c2, 1) pair of IFHIP_ALPHA_PAIR_ONE: with the gathers double buffered the constant would need
+                // two neighbours, and the register allocator answers with spills -- 112 .. 128 bytes of scratch per lane)
+                vv[2 * p + 1] = f32x2{i.g[p][2] * i.af[p], i.af[p]};
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NP; ++n) vv[n] = f32x2{i.g[(2 * n) / 3][(2 * n) % 3], i.g[(2 * n + 1) / 3][(2 * n + 1) % 3]};
+        }
     };
 
     // ---- horizontal pass of one output row (arithmetic contract step 3: per channel, the strictly ascending fmaf sum
@@ -408,9 +468,30 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
         raw[d] = fetch_row(steps[s0 + d].y);
         __builtin_amdgcn_sched_barrier(0);      // keep issue order raw[0..D-1]: the loop's vmcnt(D-1) relies on it
     }
+    // Step order RE (IFHIP_REFILL_EARLY, BGRA sources).  Scalar loads and LDS reads share lgkmcnt and return out of
+    // order, so the first use of a scalar-loaded value behind a batch of gathers is a wait for ALL of them.  In the order
+    // further down that use is the refill's row number, right behind the gathers: every lane sits out their round trip
+    // before its multiply-adds and before the row goes back in flight.  RE: the table addresses (the last readers of the
+    // row's registers), then the refill -- its wait finds only what was requested a step ago -- then the next step's
+    // record and the gathers, and the multiply-adds of the current step run under both.  The record is always loaded a
+    // step ahead (two sets of scalar registers, also on the plain shape).
+    static_assert(!RE || D % 2 == 0, "the record's double buffer alternates with the step's parity");
     f32x2 vbuf[PIPE ? 2 : 1][NP];
-    VStep rec[PIPE ? 2 : 1];
-    if (PIPE) {
+    Gathered gb[PIPE ? 2 : 1];
+    VStep rec[(PIPE || RE) ? 2 : 1];
+    if constexpr (RE) {
+        rec[0] = steps[s0];
+        if (PIPE) {
+            if constexpr (!YCC) {
+                uint32_t ad0[PX][3];
+                conv_addresses(raw[0], ad0, gb[0]);
+                conv_gather(ad0, gb[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            raw[0] = fetch_row((s0 + D < s1) ? steps[s0 + D].y : -1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (PIPE) {
         rec[0] = steps[s0];
         convert(raw[0], vbuf[0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -421,9 +502,24 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     for (uint32_t sb = s0; sb < s1; sb += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const int cur = PIPE ? (d & 1) : 0, nxt = PIPE ? (cur ^ 1) : 0;
+            const int cur = (PIPE || RE) ? (d & 1) : 0, nxt = (PIPE || RE) ? (cur ^ 1) : 0;
+            const int gcur = PIPE ? cur : 0, gnxt = PIPE ? nxt : 0;       // the plain shape gathers and uses within a step
             const uint32_t si = sb + d;
-            if (PIPE) {
+            f32x2 vloc[NP];
+            if constexpr (RE) {
+                if constexpr (!YCC) {
+                    const int slot = PIPE ? (d + 1) % D : d;               // the row this step converts: of step si + 1 / of step si
+                    uint32_t ad[PX][3];
+                    conv_addresses(raw[slot], ad, gb[gnxt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    raw[slot] = fetch_row(rec[cur].y_ahead);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rec[nxt] = steps[(si + 1 < s1) ? si + 1 : si];
+                    conv_gather(ad, gb[gnxt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    conv_pack(gb[gcur], vloc);
+                }
+            } else if (PIPE) {
                 // ---- stage A: start step si+1 (record, LUT gathers), refill its row slot for step si+1+D ----
                 const int slot_next = (d + 1) % D;
                 rec[nxt] = steps[(si + 1 < s1) ? si + 1 : si];
@@ -443,7 +539,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             }
             // ---- stage B: finish step si ----
             const VStep& st = rec[cur];
-            f32x2 (&v)[NP] = vbuf[cur];
+            f32x2 (&v)[NP] = RE ? vloc : vbuf[PIPE ? cur : 0];
 #if defined(IFHIP_EXP_LOAD_ONLY)   // experiment: stream rows, no arithmetic (NOT a product path)
             acc[0][0] += v[0] + v[1] + v[2] + v[NP - 1];   // (builds with IFHIP_MFMA_MODE=0 only)
 #else
