@@ -19,7 +19,7 @@ for v in vD vA vC; do
   IFHIP_LIB=$L/libimageflow_hip_$v.so timeout 90 python -m pytest $RT -m gpu -q -p no:cacheprovider > $O/suite_$v.log 2>&1
   echo "suite_$v rc=$? t=$(( $(date +%s) - $(cat $O/t0) ))" | tee -a $O/steps.log; tail -2 $O/suite_$v.log
 done
-timeout 100 python bench.py --steps 20 --warmup 5 > $O/bench_driver_like.json 2> $O/bench_err.log; echo "bench rc=$? t=$(( $(date +%s) - $(cat $O/t0) ))" | tee -a $O/steps.log
+timeout 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_like.json 2> $O/bench_err.log; echo "bench rc=$? t=$(( $(date +%s) - $(cat $O/t0) ))" | tee -a $O/steps.log
 timeout 60 python tools/bench_jpeg_encode.py > $O/bench_jpeg_encode.json 2>> $O/bench_err.log; echo "jpeg_encode rc=$? t=$(( $(date +%s) - $(cat $O/t0) ))" | tee -a $O/steps.log
-ab vD base vB vA vC
+ab vD base vB
 cat $O/ab.jsonl | tail -45
