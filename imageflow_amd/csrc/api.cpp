@@ -24,6 +24,8 @@ hipError_t launch_fused(const ResampleArgs& a, int slots, bool alpha, bool per_p
                         size_t lds, hipStream_t st);
 hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, uint32_t img0, uint32_t n_img,
                           hipStream_t st);
+hipError_t launch_banded(const ResampleArgs& a, bool alpha, uint32_t rows_per_band, uint32_t n_bands, uint32_t src_rows_cap,
+                         uint32_t flags, size_t lds, hipStream_t st);
 hipError_t launch_read_probe(const uint8_t* d, size_t bytes, uint32_t* sink, hipStream_t st);
 hipError_t launch_apply_matte(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w, uint32_t h,
                               uint32_t stride, uint32_t matte, float mb, float mg, float mr, float ma,
@@ -277,6 +279,46 @@ bool fused_usable(const ifhip_resample_plan* p, int alpha, const uint8_t* d_in, 
     return true;
 }
 
+// Banded two-pass kernel (resample_kernels.hip): R output rows per workgroup, their source rows and vertically filtered
+// rows in LDS.  R is the largest of a short list for which two workgroups share a CU; failing that, whatever fits one.
+struct BandPlan { uint32_t rows_per_band = 0, n_bands = 0, src_rows_cap = 0; size_t lds = 0; };
+constexpr size_t kBandedTables = 16384 + 1024;
+bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride, BandPlan* bp) {
+    if ((reinterpret_cast<uintptr_t>(d_in) | in_image_bytes | in_stride) & 3u) return false;      // 4-byte pixel reads
+    const AxisWeights& wv = p->wv;
+    const uint32_t out_h = p->out_h;
+    auto src_rows = [&](uint32_t R) {                       // widest source window of any band of R output rows
+        uint32_t worst = 0;
+        for (uint32_t j0 = 0; j0 < out_h; j0 += R) {
+            uint32_t lo = 0xffffffffu, hi = 0;
+            for (uint32_t j = j0; j < std::min(out_h, j0 + R); ++j) { lo = std::min(lo, wv.left[j]); hi = std::max(hi, wv.left[j] + wv.count[j]); }
+            worst = std::max(worst, hi - lo);
+        }
+        return worst;
+    };
+    const size_t row_bytes = static_cast<size_t>(p->in_w) * 16u;
+    static const uint32_t kRows[] = {64, 48, 32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
+    for (int pass = 0; pass < 2; ++pass) {
+        const size_t budget = pass == 0 ? kLdsLimit / 2 : kLdsLimit;
+        for (uint32_t R0 : kRows) {
+            const uint32_t R = std::min(R0, out_h);
+            if (pass == 0 && R < 4u && out_h >= 4u) break;
+            const uint32_t ns = src_rows(R);
+            const size_t lds = kBandedTables + static_cast<size_t>(ns + R) * row_bytes;
+            if (lds <= budget) {
+                bp->rows_per_band = R; bp->n_bands = (out_h + R - 1u) / R; bp->src_rows_cap = ns; bp->lds = lds;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+// IFHIP_BANDED: 0 = never, 1 = instead of the generic pair wherever it fits, 2 = also for up-scales the fused kernel could take
+int banded_mode() {
+    if (const char* e = std::getenv("IFHIP_BANDED")) return std::atoi(e);
+    return 0;
+}
+
 int validate_render(uint32_t in_w, uint32_t in_h, uint32_t in_stride, uint32_t cw, uint32_t ch, uint32_t c_stride,
                     uint32_t x, uint32_t y, uint32_t w, uint32_t h, int working_space, int compositing, uint32_t in_px_bytes = 4) {
     if (static_cast<uint64_t>(h) + y > ch || static_cast<uint64_t>(w) + x > cw)                 // scaling.rs:24-29
@@ -342,6 +384,29 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         return fail(IFHIP_INVALID_STATE, "InvalidState: fused kernel requested but its preconditions do not hold "
                     "(live rows %d > %d, or rows not 16-byte aligned / padded)", p->slots, kMaxSlots);
     if (force_kernel == 1) fused = false;
+
+    // banded two-pass kernel: asked for (force_kernel 2), or chosen in auto mode by IFHIP_BANDED
+    if (!ycc && (force_kernel == 2 || force_kernel == -1)) {
+        const int bm = force_kernel == 2 ? 2 : banded_mode();
+        const bool upscale = p->out_w >= p->in_w && p->out_h >= p->in_h;
+        const bool want = force_kernel == 2 || (bm >= 1 && !fused) || (bm >= 2 && upscale);
+        BandPlan bp;
+        if (want && banded_plan(p, d_in, in_image_bytes, in_stride, &bp)) {
+            const uint64_t grid = static_cast<uint64_t>(n_images) * bp.n_bands;
+            if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
+            if (std::getenv("IFHIP_TRACE_LAUNCH"))
+                std::fprintf(stderr, "ifhip banded launch: %ux%u -> %ux%u alpha=%d rows/band=%u bands=%u src rows=%u lds=%zu images=%u\n",
+                             p->in_w, p->in_h, p->out_w, p->out_h, alpha, bp.rows_per_band, bp.n_bands, bp.src_rows_cap, bp.lds, n_images);
+            // IFHIP_BANDED_FLAGS bit 0: horizontal weights of short windows in registers (experiment switch, default on)
+            const char* fe = std::getenv("IFHIP_BANDED_FLAGS");
+            const uint32_t flags = fe ? static_cast<uint32_t>(std::atoi(fe)) : 1u;
+            HIP_TRY(launch_banded(a, alpha != 0, bp.rows_per_band, bp.n_bands, bp.src_rows_cap, flags, bp.lds, st));
+            return IFHIP_OK;
+        }
+        if (force_kernel == 2)
+            return fail(IFHIP_INVALID_STATE, "InvalidState: banded kernel requested but a band's source rows do not fit the LDS "
+                        "(or the source pixels are not 4-byte aligned)");
+    }
 
     if (fused) {
         const ifhip_resample_plan::StripSet& ss = p->sets[alpha ? 1 : 0];

@@ -122,7 +122,8 @@ IFHIP_API int ifhip_resample_plan_kernel_kind(const ifhip_resample_plan* plan, i
  * n_images independent frames, image i at d_in + i*in_image_bytes / d_canvas + i*canvas_image_bytes.
  * d_f32_dump (nullable): [n_images][h][w][4] premultiplied working-space floats (the f32 working buffer,
  * what StreamingResize::next_output_row_f32 yields at scaling.rs:195).
- * force_kernel: -1 auto, 0 fused, 1 generic (tests cross-check the two).
+ * force_kernel: -1 auto, 0 fused, 1 generic, 2 banded (the generic pair fused through LDS: up-scales and small frames);
+ * tests cross-check them.
  */
 IFHIP_API int ifhip_scale_and_render_batch_device(const ifhip_resample_plan* plan,
                                                   const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride,

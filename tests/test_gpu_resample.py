@@ -313,3 +313,52 @@ def test_host_drop_in_from_several_threads():
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+# ---- banded two-pass kernel (force_kernel 2): the generic pair fused through LDS, for up-scales and small frames ------------
+BANDED_SHAPES = [
+    (100, 100, 300, 300),    # the reference's test_trim_then_resize shape: 15 live output rows per source row
+    (200, 200, 400, 400),    # test_fill_rect's shape
+    (20, 14, 57, 41), (64, 48, 128, 96), (10, 10, 10, 30), (37, 23, 111, 70),
+    (1, 1, 7, 5), (250, 3, 1000, 9),
+    (101, 67, 33, 21), (16, 16, 1, 1), (4, 4, 2, 2), (130, 90, 129, 91),      # small down-scales and ~1:1 fit as well
+]
+
+
+@pytest.mark.parametrize("shape", BANDED_SHAPES)
+@pytest.mark.parametrize("alpha", [False, True])
+def test_banded_kernel_equals_the_oracle(shape, alpha):
+    iw, ih, ow, oh = shape
+    run_case(iw, ih, ow, oh, alpha=alpha, force=2, n=3)
+
+
+@pytest.mark.parametrize("filt,sharpen", [(Filter.Lanczos, 15.0), (Filter.Ginseng, 0.0), (Filter.Hermite, 0.0), (Filter.Box, 0.0),
+                                          (Filter.Jinc, 0.0), (Filter.Robidoux, 50.0), (Filter.CatmullRom, 5.0)])
+def test_banded_kernel_filters(filt, sharpen, monkeypatch):
+    run_case(60, 40, 171, 113, filt=filt, sharpen=sharpen, alpha=True, force=2)           # short windows: weights in registers
+    run_case(150, 85, 31, 18, filt=filt, sharpen=sharpen, alpha=False, force=2)           # long windows: the tap loop
+    monkeypatch.setenv("IFHIP_BANDED_FLAGS", "0")                                         # the tap loop for every window
+    run_case(60, 40, 171, 113, filt=filt, sharpen=sharpen, alpha=True, force=2)
+
+
+@pytest.mark.parametrize("space", [WorkingFloatspace.StandardRGB, WorkingFloatspace.LinearRGB])
+@pytest.mark.parametrize("compose", list(BitmapCompositing))
+@pytest.mark.parametrize("alpha", [False, True])
+def test_banded_kernel_compositing_modes(space, compose, alpha):
+    for matte in (0xFFFFFFFF, 0x80FF2010):
+        run_case(40, 24, 93, 57, space=space, compose=compose, matte=matte, alpha=alpha, force=2, x=3, y=5, cw=100, ch=70)
+
+
+def test_banded_kernel_refuses_what_does_not_fit():
+    with pytest.raises(FlowError) as e:
+        run_case(3840, 216, 200, 20, n=1, force=2)            # 76 source rows x 3840 columns x 16 bytes per band of one row
+    assert e.value.kind == ErrorKind.InvalidState
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_auto_mode_with_the_banded_kernel_switched_on(mode, monkeypatch):
+    monkeypatch.setenv("IFHIP_BANDED", mode)
+    run_case(100, 100, 300, 300, alpha=True)                  # generic before: banded in both modes
+    run_case(200, 200, 400, 400, alpha=True, filt=Filter.Hermite)     # fused in mode 1, banded in mode 2
+    run_case(384, 216, 20, 20, alpha=False)                   # a down-scale the fused kernel takes in both modes
+    run_case(640, 360, 7, 4, alpha=True)                      # too many live rows for the fused kernel, too many source rows per band?
