@@ -24,8 +24,7 @@ hipError_t launch_fused(const ResampleArgs& a, int slots, bool alpha, bool per_p
                         size_t lds, hipStream_t st);
 hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, uint32_t img0, uint32_t n_img,
                           hipStream_t st);
-hipError_t launch_banded(const ResampleArgs& a, bool alpha, uint32_t rows_per_band, uint32_t n_bands, uint32_t src_rows_cap,
-                         uint32_t flags, size_t lds, hipStream_t st);
+hipError_t launch_banded(const ResampleArgs& a, bool alpha, const BandedArgs& b, uint32_t grid_x, size_t lds, hipStream_t st);
 hipError_t launch_read_probe(const uint8_t* d, size_t bytes, uint32_t* sink, hipStream_t st);
 hipError_t launch_apply_matte(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w, uint32_t h,
                               uint32_t stride, uint32_t matte, float mb, float mg, float mr, float ma,
@@ -280,11 +279,15 @@ bool fused_usable(const ifhip_resample_plan* p, int alpha, const uint8_t* d_in, 
 }
 
 // Banded two-pass kernel (resample_kernels.hip): R output rows per workgroup, their source rows and vertically filtered
-// rows in LDS.  R is the largest of a short list for which two workgroups share a CU; failing that, whatever fits one.
-struct BandPlan { uint32_t rows_per_band = 0, n_bands = 0, src_rows_cap = 0; size_t lds = 0; };
+// rows in LDS beside the tables.  R is the largest of a short list for which two workgroups share a CU; failing that,
+// whatever fits one.  A band's workgroups split the frames between them (frame_step), so that the tables are staged a few
+// times per CU and not once per frame and band.
+struct BandPlan { BandedArgs args{}; uint32_t grid = 0; size_t lds = 0; };
 constexpr size_t kBandedTables = 16384 + 1024;
-bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride, BandPlan* bp) {
+constexpr uint32_t kBandedWorkgroups = 2048;                 // about four rounds of two workgroups per CU
+bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride, uint32_t n_images, BandPlan* bp) {
     if ((reinterpret_cast<uintptr_t>(d_in) | in_image_bytes | in_stride) & 3u) return false;      // 4-byte pixel reads
+    if (in_image_bytes > 0xffffffffull) return false;                                              // 32-bit offsets inside a frame
     const AxisWeights& wv = p->wv;
     const uint32_t out_h = p->out_h;
     auto src_rows = [&](uint32_t R) {                       // widest source window of any band of R output rows
@@ -296,6 +299,13 @@ bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_im
         }
         return worst;
     };
+    bool ascending = true;                                  // window starts and ends never step back (they do not, but the kernel's
+    for (uint32_t j = 1; j < out_h; ++j)                    // shortcut rests on it, so it is checked, not assumed)
+        if (wv.left[j] < wv.left[j - 1] || wv.left[j] + wv.count[j] < wv.left[j - 1] + wv.count[j - 1]) ascending = false;
+    // horizontal tables in LDS when they are small (up-scales: ~5 taps per output column)
+    const size_t h_bytes = ((3u * static_cast<size_t>(p->out_w) + p->wh.w.size()) * 4u + 15u) & ~static_cast<size_t>(15u);
+    const bool h_lds = h_bytes <= 32u * 1024u;
+    const size_t tables = kBandedTables + (h_lds ? h_bytes : 0u);
     const size_t row_bytes = static_cast<size_t>(p->in_w) * 16u;
     static const uint32_t kRows[] = {64, 48, 32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
     for (int pass = 0; pass < 2; ++pass) {
@@ -304,9 +314,17 @@ bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_im
             const uint32_t R = std::min(R0, out_h);
             if (pass == 0 && R < 4u && out_h >= 4u) break;
             const uint32_t ns = src_rows(R);
-            const size_t lds = kBandedTables + static_cast<size_t>(ns + R) * row_bytes;
+            const size_t lds = tables + static_cast<size_t>(ns + R) * row_bytes;
             if (lds <= budget) {
-                bp->rows_per_band = R; bp->n_bands = (out_h + R - 1u) / R; bp->src_rows_cap = ns; bp->lds = lds;
+                BandedArgs& b = bp->args;
+                b.rows_per_band = R; b.n_bands = (out_h + R - 1u) / R; b.src_rows_cap = ns;
+                uint32_t wgs = kBandedWorkgroups;
+                if (const char* e = std::getenv("IFHIP_BANDED_WGS")) wgs = static_cast<uint32_t>(std::max(1, std::atoi(e)));   // experiment / test switch
+                b.frame_step = std::max<uint32_t>(1u, std::min<uint32_t>(n_images, wgs / b.n_bands));
+                b.h_w_floats = static_cast<uint32_t>(p->wh.w.size());
+                b.flags = 1u | (ascending ? 2u : 0u) | (h_lds ? 4u : 0u);
+                bp->grid = b.n_bands * b.frame_step;
+                bp->lds = lds;
                 return true;
             }
         }
@@ -316,7 +334,7 @@ bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_im
 // IFHIP_BANDED: 0 = never, 1 = instead of the generic pair wherever it fits, 2 = also for up-scales the fused kernel could take
 int banded_mode() {
     if (const char* e = std::getenv("IFHIP_BANDED")) return std::atoi(e);
-    return 0;
+    return 1;       // measured (MI355X): 3x up-scale 10.06 -> 3.7 ms with the first form of the kernel; the 2x up-scale the fused kernel takes is faster there (2.94 vs 4.4)
 }
 
 int validate_render(uint32_t in_w, uint32_t in_h, uint32_t in_stride, uint32_t cw, uint32_t ch, uint32_t c_stride,
@@ -391,16 +409,15 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         const bool upscale = p->out_w >= p->in_w && p->out_h >= p->in_h;
         const bool want = force_kernel == 2 || (bm >= 1 && !fused) || (bm >= 2 && upscale);
         BandPlan bp;
-        if (want && banded_plan(p, d_in, in_image_bytes, in_stride, &bp)) {
-            const uint64_t grid = static_cast<uint64_t>(n_images) * bp.n_bands;
-            if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
+        if (want && banded_plan(p, d_in, in_image_bytes, in_stride, n_images, &bp)) {
+            // IFHIP_BANDED_FLAGS: experiment switch, masks the plan's flags (1 weights of short horizontal windows in registers,
+            // 2 band rows from its first and last row, 4 horizontal tables in LDS)
+            if (const char* fe = std::getenv("IFHIP_BANDED_FLAGS")) bp.args.flags &= static_cast<uint32_t>(std::atoi(fe));
             if (std::getenv("IFHIP_TRACE_LAUNCH"))
-                std::fprintf(stderr, "ifhip banded launch: %ux%u -> %ux%u alpha=%d rows/band=%u bands=%u src rows=%u lds=%zu images=%u\n",
-                             p->in_w, p->in_h, p->out_w, p->out_h, alpha, bp.rows_per_band, bp.n_bands, bp.src_rows_cap, bp.lds, n_images);
-            // IFHIP_BANDED_FLAGS bit 0: horizontal weights of short windows in registers (experiment switch, default on)
-            const char* fe = std::getenv("IFHIP_BANDED_FLAGS");
-            const uint32_t flags = fe ? static_cast<uint32_t>(std::atoi(fe)) : 1u;
-            HIP_TRY(launch_banded(a, alpha != 0, bp.rows_per_band, bp.n_bands, bp.src_rows_cap, flags, bp.lds, st));
+                std::fprintf(stderr, "ifhip banded launch: %ux%u -> %ux%u alpha=%d rows/band=%u bands=%u src rows=%u frame step=%u flags=%u grid=%u lds=%zu images=%u\n",
+                             p->in_w, p->in_h, p->out_w, p->out_h, alpha, bp.args.rows_per_band, bp.args.n_bands, bp.args.src_rows_cap,
+                             bp.args.frame_step, bp.args.flags, bp.grid, bp.lds, n_images);
+            HIP_TRY(launch_banded(a, alpha != 0, bp.args, bp.grid, bp.lds, st));
             return IFHIP_OK;
         }
         if (force_kernel == 2)

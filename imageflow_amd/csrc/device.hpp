@@ -66,6 +66,15 @@ struct ResampleArgs {
     uint32_t n_images;
 };
 
+// Launch parameters of the banded two-pass kernel (resample_kernels.hip; planned in api.cpp)
+struct BandedArgs {
+    uint32_t rows_per_band, n_bands, src_rows_cap;
+    uint32_t frame_step;        // G: workgroup g of a band takes frames g, g + G, ...
+    uint32_t h_w_floats;        // size of the horizontal weight table (staged in LDS with flag 4)
+    uint32_t flags;             // 1: short horizontal windows in registers; 2: window starts and ends ascend with the row (the band's
+                                // source rows follow from its first and last row); 4: horizontal tables in LDS
+};
+
 // Shape of the fused kernel for a ring of K rows and C channels per pixel.  The vertical accumulators alone take
 // K*4*C registers per lane.  Three shapes, picked by a register estimate (checked against the compiler's report):
 //   wide + pipelined : 1024 lanes (128 registers), D = 4 rows in flight, converted samples double buffered

@@ -72,120 +72,167 @@ hpass_generic_kernel(const ResampleArgs a, const float4* scratch, uint32_t img0)
 // ------------------------------------------------------------------------------------------------------
 // Banded two-pass kernel: the generic pair fused through LDS, for shapes whose source window per band of output rows is
 // small -- up-scales (each output row reads 2 .. 6 source rows; the fused kernel's ring would need one slot per output
-// row a source row feeds: 3x Robidoux has 15, its limit is 8) and small frames.  One workgroup = (frame, band of R
-// output rows): the band's source rows are converted ONCE into LDS (working floats, premultiplied), every output row of
-// the band is filtered vertically from them into LDS, then horizontally into the output stage.  The f32 intermediate
-// the generic pair writes to and reads from HBM (out_h x in_w x 16 bytes per frame) never exists, every source byte is
-// converted once per band instead of once per tap, and the tables sit in LDS.  Same arithmetic as the generic kernels
-// term for term (vpass_generic_kernel / hpass_generic_kernel above: the same ascending fmaf chains on the same values),
-// hence bit-identical to them and to the oracle.  Rows run over waves, columns over lanes: the vertical weights of a
-// row are wave-uniform.
+// row a source row feeds: 3x Robidoux has 15, its limit is 8) and small frames.  One workgroup = (band of R output rows,
+// every G-th frame): tables once per workgroup, then per frame the band's source rows are converted ONCE into LDS
+// (working floats, premultiplied), every output row of the band is filtered vertically from them into LDS, then
+// horizontally into the output stage.  The f32 intermediate the generic pair writes to and reads from HBM
+// (out_h x in_w x 16 bytes per frame) never exists, every source byte is converted once per band instead of once per
+// tap, and the next frame's source pixels are requested while the current frame is filtered.  Same arithmetic as the
+// generic kernels term for term (vpass_generic_kernel / hpass_generic_kernel above: the same ascending fmaf chains on
+// the same values), hence bit-identical to them and to the oracle.  Vertical pass: rows over waves (their weights are
+// wave-uniform: scalar loads), columns over lanes.  Horizontal pass: a lane keeps its output column over the wave's rows.
 // ------------------------------------------------------------------------------------------------------
 constexpr uint32_t kBandedThreads = 512;
 constexpr uint32_t kBandedTableBytes = 16384 + 1024;        // linear -> sRGB table, sRGB -> float table
+constexpr uint32_t kBandedPrefetch = 8;                     // source pixels a lane keeps in flight for the next frame
+constexpr uint32_t kBandedRegTaps = 8;                      // horizontal windows up to this many taps keep their weights in registers
 template <bool ALPHA>
 __global__ void __launch_bounds__(kBandedThreads)
-banded_resample_kernel(const ResampleArgs a, uint32_t rows_per_band, uint32_t n_bands, uint32_t src_rows_cap, uint32_t flags) {
+banded_resample_kernel(const ResampleArgs a, const BandedArgs b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
     uint8_t* l2s_lds = bsm;
     float* s2f = reinterpret_cast<float*>(bsm + 16384);
-    float4* src = reinterpret_cast<float4*>(bsm + kBandedTableBytes);                  // [src_rows_cap][in_w]
-    float4* vband = src + static_cast<size_t>(src_rows_cap) * a.in_w;                  // [rows_per_band][in_w]
+    const bool h_lds = (b.flags & 4u) != 0u;
+    uint32_t* hl = reinterpret_cast<uint32_t*>(bsm + kBandedTableBytes);               // [out_w] left, count, weight offset; weights
+    uint32_t* hc = hl + a.out_w;
+    uint32_t* ho = hc + a.out_w;
+    float* hw = reinterpret_cast<float*>(ho + a.out_w);
+    const uint32_t h_bytes = h_lds ? ((3u * a.out_w + b.h_w_floats) * 4u + 15u) & ~15u : 0u;
+    float4* src = reinterpret_cast<float4*>(bsm + kBandedTableBytes + h_bytes);        // [src_rows_cap][in_w]
+    float4* vband = src + static_cast<size_t>(b.src_rows_cap) * a.in_w;                // [rows_per_band][in_w]
     const uint32_t tid = threadIdx.x, T = blockDim.x;
     const uint32_t lane = tid & 63u, nw = T >> 6;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);                   // wave-uniform: rows and their tables go the scalar way
-    const uint32_t band = blockIdx.x % n_bands, img = blockIdx.x / n_bands;
-    const uint32_t j0 = band * rows_per_band, j1 = min(j0 + rows_per_band, a.out_h), nrows = j1 - j0;
+    const uint32_t band = blockIdx.x % b.n_bands, g = blockIdx.x / b.n_bands;
+    const uint32_t j0 = band * b.rows_per_band, j1 = min(j0 + b.rows_per_band, a.out_h), nrows = j1 - j0;
     for (uint32_t i = tid; i < 1024u; i += T) reinterpret_cast<uint4*>(l2s_lds)[i] = reinterpret_cast<const uint4*>(a.l2s)[i];
     for (uint32_t i = tid; i < 256u; i += T) s2f[i] = a.lut_in[i];
-    uint32_t row0 = 0xffffffffu, row1 = 0u;                  // the band's source rows [row0, row1): at most src_rows_cap (host)
-    for (uint32_t j = j0; j < j1; ++j) {
-        const uint32_t l = a.v_left[j];
-        row0 = min(row0, l);
-        row1 = max(row1, l + a.v_count[j]);
+    if (h_lds) {
+        for (uint32_t i = tid; i < a.out_w; i += T) { hl[i] = a.h_left[i]; hc[i] = a.h_count[i]; ho[i] = a.h_off[i]; }
+        for (uint32_t i = tid; i < b.h_w_floats; i += T) hw[i] = a.h_w[i];
     }
-    __syncthreads();
-    // sample -> working float, once per source pixel of the band (arithmetic contract step 1, as vpass_generic_kernel)
-    const uint8_t* frame = a.in + static_cast<size_t>(img) * a.in_image_bytes;
-    for (uint32_t r = wave; r < row1 - row0; r += nw) {
-        const uint32_t* prow = reinterpret_cast<const uint32_t*>(frame + static_cast<size_t>(row0 + r) * a.in_stride);
-        for (uint32_t x = lane; x < a.in_w; x += 64u) {
-            const uint32_t px = prow[x];
-            float f0 = s2f[px & 255u], f1 = s2f[(px >> 8) & 255u], f2 = s2f[(px >> 16) & 255u], f3 = 1.0f;
-            if (ALPHA) {
-                f3 = static_cast<float>(px >> 24) * (1.0f / 255.0f);
-                f0 = f0 * f3; f1 = f1 * f3; f2 = f2 * f3;
-            }
-            src[r * a.in_w + x] = make_float4(f0, f1, f2, f3);
+    uint32_t row0, row1;                                     // the band's source rows [row0, row1): at most src_rows_cap (host)
+    if (b.flags & 2u) {
+        row0 = a.v_left[j0];
+        row1 = a.v_left[j1 - 1u] + a.v_count[j1 - 1u];
+    } else {
+        row0 = 0xffffffffu; row1 = 0u;
+        for (uint32_t j = j0; j < j1; ++j) {
+            const uint32_t l = a.v_left[j];
+            row0 = min(row0, l);
+            row1 = max(row1, l + a.v_count[j]);
         }
     }
-    __syncthreads();
-    // vertical pass of every output row of the band (step 2)
-    for (uint32_t jr = wave; jr < nrows; jr += nw) {
-        const uint32_t j = j0 + jr;
-        const uint32_t left = a.v_left[j] - row0, n = a.v_count[j];
-        const float* w = a.v_w + a.v_off[j];                 // (wave-uniform address: scalar loads)
-        for (uint32_t x = lane; x < a.in_w; x += 64u) {
-            const float4* col = src + left * a.in_w + x;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (uint32_t k = 0; k < n; ++k) {
-                const float4 v = col[k * a.in_w];
-                const float wk = w[k];
-                s0 = __builtin_fmaf(wk, v.x, s0);
-                s1 = __builtin_fmaf(wk, v.y, s1);
-                s2 = __builtin_fmaf(wk, v.z, s2);
-                if (ALPHA) s3 = __builtin_fmaf(wk, v.w, s3);
-            }
-            vband[jr * a.in_w + x] = make_float4(s0, s1, s2, ALPHA ? s3 : 1.0f);
-        }
+    const uint32_t npx = (row1 - row0) * a.in_w;             // source pixels of the band, LDS index r * in_w + x
+    // Source pixels this lane converts (LDS index tid + c * T): their byte offsets inside a frame, the same for every frame.
+    const bool prefetch = npx <= kBandedPrefetch * T;
+    uint32_t off[kBandedPrefetch], pre[kBandedPrefetch];
+#pragma unroll
+    for (uint32_t c = 0; c < kBandedPrefetch; ++c) {
+        const uint32_t i = tid + c * T;
+        const uint32_t r = i / a.in_w, x = i - r * a.in_w;
+        off[c] = (row0 + r) * a.in_stride + 4u * x;
+        pre[c] = 0u;
     }
-    __syncthreads();
-    // horizontal pass + output stage (step 3 and the compositing modes).  A lane keeps its output column over the wave's
-    // rows: its tap window and, when the window has at most kBandedRegTaps taps (every up-scale with a window-2 filter has
-    // 5), its weights stay in registers and the row's samples are requested together.  The padding taps carry weight +0
-    // on a clamped (finite) sample: fmaf(+0, x, h) == h exactly, h is never -0 (the fused kernel's argument).
+    auto request = [&](uint32_t img) {
+        const uint8_t* frame = a.in + static_cast<size_t>(img) * a.in_image_bytes;
+#pragma unroll
+        for (uint32_t c = 0; c < kBandedPrefetch; ++c)
+            if (tid + c * T < npx) pre[c] = *reinterpret_cast<const uint32_t*>(frame + off[c]);
+    };
+    auto to_float = [&](uint32_t px) -> float4 {             // arithmetic contract step 1, as vpass_generic_kernel
+        float f0 = s2f[px & 255u], f1 = s2f[(px >> 8) & 255u], f2 = s2f[(px >> 16) & 255u], f3 = 1.0f;
+        if (ALPHA) {
+            f3 = static_cast<float>(px >> 24) * (1.0f / 255.0f);
+            f0 = f0 * f3; f1 = f1 * f3; f2 = f2 * f3;
+        }
+        return make_float4(f0, f1, f2, f3);
+    };
+    uint32_t img = g;
+    if (prefetch && img < a.n_images) request(img);
+    __syncthreads();                                         // tables
     const OutTables<const float*, const uint8_t*> tb{s2f, l2s_lds};
-    constexpr uint32_t kBandedRegTaps = 8;
-    for (uint32_t u = lane; u < a.out_w; u += 64u) {
-        const uint32_t left = a.h_left[u], n = a.h_count[u];
-        const float* w = a.h_w + a.h_off[u];
-        if ((flags & 1u) && n <= kBandedRegTaps) {
-            float wr[kBandedRegTaps];
-            uint32_t col[kBandedRegTaps];
+    for (; img < a.n_images; img += b.frame_step) {
+        // ---- sample -> working float, once per source pixel of the band ----
+        if (prefetch) {
 #pragma unroll
-            for (uint32_t k = 0; k < kBandedRegTaps; ++k) {
-                const float wk = w[min(k, n - 1u)];          // (in bounds whatever the compiler makes of the select)
-                wr[k] = k < n ? wk : 0.0f;
-                col[k] = min(left + k, a.in_w - 1u);
-            }
-            for (uint32_t jr = wave; jr < nrows; jr += nw) {
-                const float4* row = vband + jr * a.in_w;
-                float4 v[kBandedRegTaps];
-#pragma unroll
-                for (uint32_t k = 0; k < kBandedRegTaps; ++k) v[k] = row[col[k]];
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-                for (uint32_t k = 0; k < kBandedRegTaps; ++k) {
-                    s0 = __builtin_fmaf(wr[k], v[k].x, s0);
-                    s1 = __builtin_fmaf(wr[k], v[k].y, s1);
-                    s2 = __builtin_fmaf(wr[k], v[k].z, s2);
-                    if (ALPHA) s3 = __builtin_fmaf(wr[k], v[k].w, s3);
-                }
-                store_pixel<ALPHA>(a, img, j0 + jr, u, s0, s1, s2, ALPHA ? s3 : 1.0f, tb);
-            }
+            for (uint32_t c = 0; c < kBandedPrefetch; ++c)
+                if (tid + c * T < npx) src[tid + c * T] = to_float(pre[c]);
+            if (img + b.frame_step < a.n_images) request(img + b.frame_step);      // in flight under both passes below
         } else {
-            for (uint32_t jr = wave; jr < nrows; jr += nw) {
-                const float4* row = vband + jr * a.in_w;
+            const uint8_t* frame = a.in + static_cast<size_t>(img) * a.in_image_bytes;
+            for (uint32_t r = wave; r < row1 - row0; r += nw) {
+                const uint32_t* prow = reinterpret_cast<const uint32_t*>(frame + static_cast<size_t>(row0 + r) * a.in_stride);
+                for (uint32_t x = lane; x < a.in_w; x += 64u) src[r * a.in_w + x] = to_float(prow[x]);
+            }
+        }
+        __syncthreads();     // src complete; every wave is also done with the previous frame's horizontal pass (vband is free)
+        // ---- vertical pass of every output row of the band (step 2) ----
+        for (uint32_t jr = wave; jr < nrows; jr += nw) {
+            const uint32_t j = j0 + jr;
+            const uint32_t left = a.v_left[j] - row0, n = a.v_count[j];
+            const float* w = a.v_w + a.v_off[j];             // (wave-uniform address: scalar loads)
+            for (uint32_t x = lane; x < a.in_w; x += 64u) {
+                const float4* col = src + left * a.in_w + x;
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
                 for (uint32_t k = 0; k < n; ++k) {
-                    const float4 v = row[left + k];
+                    const float4 v = col[k * a.in_w];
                     const float wk = w[k];
                     s0 = __builtin_fmaf(wk, v.x, s0);
                     s1 = __builtin_fmaf(wk, v.y, s1);
                     s2 = __builtin_fmaf(wk, v.z, s2);
                     if (ALPHA) s3 = __builtin_fmaf(wk, v.w, s3);
                 }
-                store_pixel<ALPHA>(a, img, j0 + jr, u, s0, s1, s2, ALPHA ? s3 : 1.0f, tb);
+                vband[jr * a.in_w + x] = make_float4(s0, s1, s2, ALPHA ? s3 : 1.0f);
+            }
+        }
+        __syncthreads();     // vband complete; src is free for the next frame
+        // ---- horizontal pass + output stage (step 3 and the compositing modes).  A lane keeps its output column over the
+        // wave's rows: its tap window and, when the window has at most kBandedRegTaps taps (every up-scale with a window-2
+        // filter has 5), its weights stay in registers and the row's samples are requested together.  The padding taps carry
+        // weight +0 on a clamped (finite) sample: fmaf(+0, x, h) == h exactly, h is never -0 (the fused kernel's argument).
+        for (uint32_t u = lane; u < a.out_w; u += 64u) {
+            const uint32_t left = h_lds ? hl[u] : a.h_left[u], n = h_lds ? hc[u] : a.h_count[u];
+            const uint32_t woff = h_lds ? ho[u] : a.h_off[u];
+            auto weight = [&](uint32_t k) -> float { return h_lds ? hw[woff + k] : a.h_w[woff + k]; };
+            if ((b.flags & 1u) && n <= kBandedRegTaps) {
+                float wr[kBandedRegTaps];
+                uint32_t col[kBandedRegTaps];
+#pragma unroll
+                for (uint32_t k = 0; k < kBandedRegTaps; ++k) {
+                    const float wk = weight(min(k, n - 1u));   // (in bounds whatever the compiler makes of the select)
+                    wr[k] = k < n ? wk : 0.0f;
+                    col[k] = min(left + k, a.in_w - 1u);
+                }
+                for (uint32_t jr = wave; jr < nrows; jr += nw) {
+                    const float4* row = vband + jr * a.in_w;
+                    float4 v[kBandedRegTaps];
+#pragma unroll
+                    for (uint32_t k = 0; k < kBandedRegTaps; ++k) v[k] = row[col[k]];
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+                    for (uint32_t k = 0; k < kBandedRegTaps; ++k) {
+                        s0 = __builtin_fmaf(wr[k], v[k].x, s0);
+                        s1 = __builtin_fmaf(wr[k], v[k].y, s1);
+                        s2 = __builtin_fmaf(wr[k], v[k].z, s2);
+                        if (ALPHA) s3 = __builtin_fmaf(wr[k], v[k].w, s3);
+                    }
+                    store_pixel<ALPHA>(a, img, j0 + jr, u, s0, s1, s2, ALPHA ? s3 : 1.0f, tb);
+                }
+            } else {
+                for (uint32_t jr = wave; jr < nrows; jr += nw) {
+                    const float4* row = vband + jr * a.in_w;
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                    for (uint32_t k = 0; k < n; ++k) {
+                        const float4 v = row[left + k];
+                        const float wk = weight(k);
+                        s0 = __builtin_fmaf(wk, v.x, s0);
+                        s1 = __builtin_fmaf(wk, v.y, s1);
+                        s2 = __builtin_fmaf(wk, v.z, s2);
+                        if (ALPHA) s3 = __builtin_fmaf(wk, v.w, s3);
+                    }
+                    store_pixel<ALPHA>(a, img, j0 + jr, u, s0, s1, s2, ALPHA ? s3 : 1.0f, tb);
+                }
             }
         }
     }
@@ -296,8 +343,7 @@ hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, ui
     return hipGetLastError();
 }
 
-hipError_t launch_banded(const ResampleArgs& a, bool alpha, uint32_t rows_per_band, uint32_t n_bands, uint32_t src_rows_cap,
-                         uint32_t flags, size_t lds, hipStream_t st) {
+hipError_t launch_banded(const ResampleArgs& a, bool alpha, const BandedArgs& b, uint32_t grid_x, size_t lds, hipStream_t st) {
     static std::atomic<int> raised[2][16];                     // the dynamic-LDS cap is sticky per kernel and device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -307,9 +353,9 @@ hipError_t launch_banded(const ResampleArgs& a, bool alpha, uint32_t rows_per_ba
         (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsCap));
         r.store(1, std::memory_order_relaxed);
     }
-    const dim3 grid(a.n_images * n_bands), block(kBandedThreads);
-    if (alpha) hipLaunchKernelGGL((banded_resample_kernel<true>), grid, block, lds, st, a, rows_per_band, n_bands, src_rows_cap, flags);
-    else hipLaunchKernelGGL((banded_resample_kernel<false>), grid, block, lds, st, a, rows_per_band, n_bands, src_rows_cap, flags);
+    const dim3 grid(grid_x), block(kBandedThreads);
+    if (alpha) hipLaunchKernelGGL((banded_resample_kernel<true>), grid, block, lds, st, a, b);
+    else hipLaunchKernelGGL((banded_resample_kernel<false>), grid, block, lds, st, a, b);
     return hipGetLastError();
 }
 

@@ -349,6 +349,15 @@ def test_banded_kernel_compositing_modes(space, compose, alpha):
         run_case(40, 24, 93, 57, space=space, compose=compose, matte=matte, alpha=alpha, force=2, x=3, y=5, cw=100, ch=70)
 
 
+def test_banded_kernel_frame_loop_and_wide_rows(monkeypatch):
+    run_case(600, 40, 1200, 80, alpha=True, force=2)           # 4 800 source pixels per band: no prefetch registers, tables from HBM
+    monkeypatch.setenv("IFHIP_BANDED_WGS", "1")                # one workgroup per band takes every frame: the prefetch of frame i + 1
+    run_case(100, 100, 300, 300, alpha=True, force=2, n=5)     # under the passes of frame i
+    run_case(600, 40, 1200, 80, alpha=False, force=2, n=3)
+    monkeypatch.setenv("IFHIP_BANDED_WGS", "30")               # 13 bands: two workgroups per band, frames 0 2 4 / 1 3
+    run_case(100, 100, 300, 300, alpha=False, force=2, n=5, compose=BitmapCompositing.BlendWithMatte, matte=0xFF405060)
+
+
 def test_banded_kernel_refuses_what_does_not_fit():
     with pytest.raises(FlowError) as e:
         run_case(3840, 216, 200, 20, n=1, force=2)            # 76 source rows x 3840 columns x 16 bytes per band of one row
