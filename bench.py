@@ -410,7 +410,7 @@ def main():
     else:
         kernel_ms = time_scale_and_render(inp, views[0], info, launches=launches, plan=plan)
         algo_bytes = n * (in_w * in_h * 4 + out_w * out_h * 4)
-        kernel_name = "fused_resample_kernel" if plan.kernel_kind(wl[6]) == 0 else "generic"
+        kernel_name = "fused_resample_kernel" if plan.kernel_kind(wl[6]) == 0 else "two-pass (banded_resample_kernel where a band's rows fit the LDS, else the generic pair)"
     torch.cuda.synchronize()
 
     if rank == 0:

@@ -284,7 +284,7 @@ bool fused_usable(const ifhip_resample_plan* p, int alpha, const uint8_t* d_in, 
 // times per CU and not once per frame and band.
 struct BandPlan { BandedArgs args{}; uint32_t grid = 0; size_t lds = 0; };
 constexpr size_t kBandedTables = 16384 + 1024;
-constexpr uint32_t kBandedWorkgroups = 2048;                 // about four rounds of two workgroups per CU
+constexpr uint32_t kBandedWorkgroups = 8192;                 // sixteen rounds of two workgroups per CU (measured: 512 4.09, 1 024 3.91, 2 048 3.76, 4 096 3.70, 8 192 3.66 ms on the 3x shape)
 bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride, uint32_t n_images, BandPlan* bp) {
     if ((reinterpret_cast<uintptr_t>(d_in) | in_image_bytes | in_stride) & 3u) return false;      // 4-byte pixel reads
     if (in_image_bytes > 0xffffffffull) return false;                                              // 32-bit offsets inside a frame
@@ -322,7 +322,10 @@ bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_im
                 if (const char* e = std::getenv("IFHIP_BANDED_WGS")) wgs = static_cast<uint32_t>(std::max(1, std::atoi(e)));   // experiment / test switch
                 b.frame_step = std::max<uint32_t>(1u, std::min<uint32_t>(n_images, wgs / b.n_bands));
                 b.h_w_floats = static_cast<uint32_t>(p->wh.w.size());
-                b.flags = 1u | (ascending ? 2u : 0u) | (h_lds ? 4u : 0u);
+                // (bit 0, weights of short horizontal windows in registers: padded to 8 taps it costs more multiply-adds than
+                // it saves reads -- 3.76 against 3.65 ms on the 3x shape -- so it is an experiment switch)
+                const char* rt = std::getenv("IFHIP_BANDED_REGTAPS");
+                b.flags = ((rt && std::atoi(rt) != 0) ? 1u : 0u) | (ascending ? 2u : 0u) | (h_lds ? 4u : 0u);
                 bp->grid = b.n_bands * b.frame_step;
                 bp->lds = lds;
                 return true;
@@ -334,7 +337,7 @@ bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_im
 // IFHIP_BANDED: 0 = never, 1 = instead of the generic pair wherever it fits, 2 = also for up-scales the fused kernel could take
 int banded_mode() {
     if (const char* e = std::getenv("IFHIP_BANDED")) return std::atoi(e);
-    return 1;       // measured (MI355X): 3x up-scale 10.06 -> 3.7 ms with the first form of the kernel; the 2x up-scale the fused kernel takes is faster there (2.94 vs 4.4)
+    return 1;       // measured (MI355X): 3x up-scale 9.97 -> 3.65 ms; the 2x up-scale the fused kernel takes is faster there (2.93 vs 4.43)
 }
 
 int validate_render(uint32_t in_w, uint32_t in_h, uint32_t in_stride, uint32_t cw, uint32_t ch, uint32_t c_stride,

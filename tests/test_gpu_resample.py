@@ -335,9 +335,12 @@ def test_banded_kernel_equals_the_oracle(shape, alpha):
 @pytest.mark.parametrize("filt,sharpen", [(Filter.Lanczos, 15.0), (Filter.Ginseng, 0.0), (Filter.Hermite, 0.0), (Filter.Box, 0.0),
                                           (Filter.Jinc, 0.0), (Filter.Robidoux, 50.0), (Filter.CatmullRom, 5.0)])
 def test_banded_kernel_filters(filt, sharpen, monkeypatch):
-    run_case(60, 40, 171, 113, filt=filt, sharpen=sharpen, alpha=True, force=2)           # short windows: weights in registers
-    run_case(150, 85, 31, 18, filt=filt, sharpen=sharpen, alpha=False, force=2)           # long windows: the tap loop
-    monkeypatch.setenv("IFHIP_BANDED_FLAGS", "0")                                         # the tap loop for every window
+    run_case(60, 40, 171, 113, filt=filt, sharpen=sharpen, alpha=True, force=2)
+    run_case(150, 85, 31, 18, filt=filt, sharpen=sharpen, alpha=False, force=2)
+    monkeypatch.setenv("IFHIP_BANDED_REGTAPS", "1")                                       # short windows: weights in registers, +0 padding taps
+    run_case(60, 40, 171, 113, filt=filt, sharpen=sharpen, alpha=True, force=2)
+    run_case(150, 85, 31, 18, filt=filt, sharpen=sharpen, alpha=False, force=2)           # long windows keep the tap loop
+    monkeypatch.setenv("IFHIP_BANDED_FLAGS", "0")                                         # no shortcut at all: tables from HBM, band rows by search
     run_case(60, 40, 171, 113, filt=filt, sharpen=sharpen, alpha=True, force=2)
 
 
