@@ -58,9 +58,16 @@ struct ThresholdL2S {
     }
 };
 
-template <typename LutB>
+// the whole 16 KiB table, known to be there (fused kernel, IFHIP_ENCODE_STATIC: no per-channel "is it staged" test)
+struct DirectL2S {
+    const uint8_t* table;   // LDS, 16384 entries
+    __device__ __forceinline__ uint8_t operator[](uint32_t idx) const { return table[idx]; }
+};
+
+// LIN: 1 = the working space is known to be linear at compile time, -1 = ask the argument block
+template <int LIN = -1, typename LutB>
 __device__ __forceinline__ uint8_t encode_channel(const ResampleArgs& a, LutB l2s, float v) {   // color.rs:61-71
-    if (a.linear) {                                                                            // lut.rs:4-8
+    if (LIN == 1 || (LIN < 0 && a.linear)) {                                                   // lut.rs:4-8
         // (v * 16383).clamp(0, 16383) as usize, NaN -> 0: max(NaN, 0) = 0 (maxNum), two instructions instead of three
         // compare/select pairs
         const float s = __builtin_fminf(__builtin_fmaxf(v * 16383.0f, 0.0f), 16383.0f);
@@ -71,11 +78,11 @@ __device__ __forceinline__ uint8_t encode_channel(const ResampleArgs& a, LutB l2
 
 // px: premultiplied working-space pixel (B,G,R,A).  Returns the BGRA8 word to store at the canvas pixel
 // whose current content is `dst` (only read for BlendWithSelf).
-template <bool ALPHA, typename LutF, typename LutB>
+template <bool ALPHA, int LIN = -1, typename LutF, typename LutB>
 __device__ __forceinline__ uint32_t render_pixel(const ResampleArgs& a, float p0, float p1, float p2, float pa,
                                                  uint32_t dst, const OutTables<LutF, LutB>& tb) {
     const LutF lut = tb.s2f;
-    auto encode_channel = [&](const ResampleArgs& aa, float v) -> uint32_t { return ifhip::encode_channel(aa, tb.l2s, v); };
+    auto encode_channel = [&](const ResampleArgs& aa, float v) -> uint32_t { return ifhip::encode_channel<LIN>(aa, tb.l2s, v); };
     uint32_t b, g, r, al;
     if (!ALPHA) {
         // scaling.rs:227-232 / :267-271: alpha is not meaningful -> straight encode, alpha = 255
@@ -136,7 +143,7 @@ __device__ __forceinline__ void store_f32x4_untracked(float4* p, float x, float 
 #endif
 }
 
-template <bool ALPHA, typename LutF, typename LutB>
+template <bool ALPHA, int LIN = -1, typename LutF, typename LutB>
 __device__ __forceinline__ void store_pixel(const ResampleArgs& a, uint32_t img, uint32_t j, uint32_t u,
                                             float p0, float p1, float p2, float pa, const OutTables<LutF, LutB>& tb) {
     uint8_t* cp = a.canvas + static_cast<size_t>(img) * a.canvas_image_bytes
@@ -148,7 +155,7 @@ __device__ __forceinline__ void store_pixel(const ResampleArgs& a, uint32_t img,
     // (other compositing modes) where no load was issued -- and each such wait drains the source rows in flight.
     if (ALPHA && a.mode == IFHIP_BLEND_WITH_SELF)
         asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(dst) : "v"(cw) : "memory");
-    store_u32_untracked(cw, render_pixel<ALPHA>(a, p0, p1, p2, pa, dst, tb));
+    store_u32_untracked(cw, render_pixel<ALPHA, LIN>(a, p0, p1, p2, pa, dst, tb));
     if (a.f32_dump) {
         float4* d = reinterpret_cast<float4*>(a.f32_dump) + (static_cast<size_t>(img) * a.out_h + j) * a.out_w + u;
         store_f32x4_untracked(d, p0, p1, p2, ALPHA ? pa : 1.0f);

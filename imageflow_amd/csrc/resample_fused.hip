@@ -31,6 +31,9 @@
 #ifndef IFHIP_DOT4_LUT
 #define IFHIP_DOT4_LUT 1     // table addresses of the vertical pass by v_dot4_u32_u8 (0: byte extract + shift-add, for A/B)
 #endif
+#ifndef IFHIP_ENCODE_STATIC
+#define IFHIP_ENCODE_STATIC 0    // fast horizontal pass: one test per output ROW for "linear working space, encode table staged", then a
+#endif                           // pixel loop without the per-channel tests (prepared in round 3, not yet measured)
 #ifndef IFHIP_REFILL_EARLY
 #define IFHIP_REFILL_EARLY 0     // BGRA sources: table addresses, THEN the row refill, then the next record and the gathers (see the step loop);
 #endif                           // bit 0: pipelined shapes, bit 1: the plain shape
@@ -416,7 +419,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
         }
     };
     // Mapping 2, fast form: two base addresses per output, everything else immediates.
-    auto h_run_row_pixels_fast = [&](uint32_t j, const float* vrow) {
+    auto h_run_row_pixels_fast = [&](uint32_t j, const float* vrow, auto static_encode) {
         constexpr uint32_t G = FG > 0 ? FG : 1;
         for (uint32_t ul = tid; ul < n_store; ul += T) {
             const uint32_t m = hmeta2[ul];
@@ -440,8 +443,13 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                 else asm volatile("" : "+v"(h2));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const OutTables<BankedLut, ThresholdL2S> tb{lut, ThresholdL2S{thr, l2s_lds}};
-            store_pixel<ALPHA>(a, img, j, strip.u0 + ul, h01.x, h01.y, ALPHA ? h23.x : h2, ALPHA ? h23.y : 1.0f, tb);
+            if constexpr (decltype(static_encode)::value) {
+                const OutTables<BankedLut, DirectL2S> tbs{lut, DirectL2S{l2s_lds}};
+                store_pixel<ALPHA, 1>(a, img, j, strip.u0 + ul, h01.x, h01.y, ALPHA ? h23.x : h2, ALPHA ? h23.y : 1.0f, tbs);
+            } else {
+                const OutTables<BankedLut, ThresholdL2S> tb{lut, ThresholdL2S{thr, l2s_lds}};
+                store_pixel<ALPHA>(a, img, j, strip.u0 + ul, h01.x, h01.y, ALPHA ? h23.x : h2, ALPHA ? h23.y : 1.0f, tb);
+            }
         }
     };
     int h_out_row = -1;              // output row whose horizontal result is waiting in obuf (uniform), -1: none
@@ -631,7 +639,13 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                 lds_barrier();
                 if constexpr (h_per_pixel) {
 #if !defined(IFHIP_EXP_NO_CHAIN)
-                    if constexpr (FG > 0) h_run_row_pixels_fast(j, dst_row);
+                    if constexpr (FG > 0) {
+#if IFHIP_ENCODE_STATIC
+                        if (a.linear && l2s_lds != nullptr) h_run_row_pixels_fast(j, dst_row, std::true_type{});
+                        else
+#endif
+                            h_run_row_pixels_fast(j, dst_row, std::false_type{});
+                    }
                     else h_run_row_pixels(j, dst_row);
 #endif
                 } else {

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 tag, wls = sys.argv[1], sys.argv[2:]
-for rep in range(2):
+for rep in range(int(os.environ.get('AB_REPS', '2'))):
     for wl in wls:
         sys.argv = ["bench.py", "--workload", wl, "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-strong-field", "--gather", "none"]
         buf = io.StringIO()
