@@ -32,8 +32,8 @@
 #define IFHIP_DOT4_LUT 1     // table addresses of the vertical pass by v_dot4_u32_u8 (0: byte extract + shift-add, for A/B)
 #endif
 #ifndef IFHIP_ENCODE_STATIC
-#define IFHIP_ENCODE_STATIC 0    // fast horizontal pass: one test per output ROW for "linear working space, encode table staged", then a
-#endif                           // pixel loop without the per-channel tests (prepared in round 3, not yet measured)
+#define IFHIP_ENCODE_STATIC 1    // fast horizontal pass: one test per output ROW for "linear working space, encode table staged", then a
+#endif                           // pixel loop without the per-channel tests, its three table reads in flight together (cfg3 level 1: 3.04 -> 2.91 ms; 0: A/B)
 #ifndef IFHIP_REFILL_EARLY
 #define IFHIP_REFILL_EARLY 0     // BGRA sources: table addresses, THEN the row refill, then the next record and the gathers (see the step loop);
 #endif                           // bit 0: pipelined shapes, bit 1: the plain shape
