@@ -50,8 +50,19 @@ def lib():
     L.ifhip_apply_matte.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
     L.ifhip_apply_matte_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  C.c_uint32, C.c_int, C.c_uint32, C.c_void_p]
+    L.ifhip_debug_set.argtypes = [C.c_char_p, C.c_char_p]
     _lib = L
+    # development convenience of THIS binding (the library itself reads no environment variable): IFHIP_<SWITCH>=v in the
+    # environment of a tools/ run becomes ifhip_debug_set("<switch>", v) once, at load
+    for k, v in os.environ.items():
+        if k.startswith("IFHIP_") and k not in ("IFHIP_LIB", "IFHIP_BUILD_IF_STALE"):
+            L.ifhip_debug_set(k[6:].lower().encode(), v.encode())
     return L
+
+
+def debug_set(key, value):
+    """ifhip_debug_set: a development switch of the library (tests, tools/); value None unsets."""
+    check(lib().ifhip_debug_set(key.encode(), None if value is None else str(value).encode()))
 
 
 def check(rc):

@@ -371,7 +371,7 @@ const imageflow_json_response* respond_error(imageflow_context* c, int cat, cons
     c->set_error(cat, msg);                                      // imageflow_abi/src/lib.rs:1001-1008
     const int code = http_code(cat);                             // JsonResponse::fail_with_message, json/mod.rs:170-181
     return respond(c, code, "{\n  \"code\": " + std::to_string(code) + ",\n  \"success\": false,\n  \"message\": \"" +
-                                json_escape(msg) + "\",\n  \"data\": {}\n}");                 // TellDecoderV1Response {} (v1.rs:177)
+                                json_escape(msg) + "\",\n  \"data\": \"none\"\n}");      // ResponsePayload::None, a unit variant renamed "none" (imageflow_types/src/lib.rs:2061-2062)
 }
 
 // ---- sizing: AspectRatio::proportional (imageflow_riapi/src/sizing.rs:118-185) ------------------------------------
@@ -482,10 +482,13 @@ struct Job {
     // the frame's pixels on the device; a pending JPEG gets its pixel stage now (IDCT + colour into a bitmap)
     uint8_t* dev(const FramePtr& f) {
         if (f->pending) {
-            hip_check(hipMalloc(reinterpret_cast<void**>(&f->d), f->bytes() + 64), "hipMalloc(frame)");
+            uint8_t* d = nullptr;                                    // the frame takes the bitmap only once it holds the pixels:
+            hip_check(hipMalloc(reinterpret_cast<void**>(&d), f->bytes() + 64), "hipMalloc(frame)");     // a failed stage leaves
+            struct Guard { uint8_t* p; ~Guard() { if (p) (void)hipFree(p); } } g{d};                     // `pending` and no buffer
             PendingJpeg& p = *f->pending;
-            check(ifhip_jpeg_idct_color_batch_device(p.st, p.coef[0], p.coef[1], p.coef[2], p.d_qt, 1, f->d, f->bytes(), f->stride, nullptr));
+            check(ifhip_jpeg_idct_color_batch_device(p.st, p.coef[0], p.coef[1], p.coef[2], p.d_qt, 1, d, f->bytes(), f->stride, nullptr));
             hip_check(hipStreamSynchronize(nullptr), "decode");
+            f->d = d; g.p = nullptr;
             f->pending.reset();
         }
         return f->d;
@@ -509,9 +512,22 @@ struct Job {
         return it->second;
     }
 
-    // header facts of an input (get_scaled_rotated_image_info's part that watermark / command_string need)
-    void image_size(int32_t io_id, uint32_t* w, uint32_t* h) {
+    // MzDec::get_exif_rotation_flag (mozjpeg_decoder.rs:290-292): the EXIF orientation tag of a JPEG input, -1 = none
+    static int exif_flag(const Io& in) {
+        int flag = -1;
+        if (in.in_len >= 4 && in.in[0] == 0xFF && in.in[1] == 0xD8) (void)ifhip_jpeg_exif_orientation(in.in, in.in_len, &flag);
+        return flag;
+    }
+    // header facts of an input (get_scaled_rotated_image_info's part that watermark / command_string need); `rotated`:
+    // Context::swap_dimensions_by_exif (context.rs:486-501) -- flags 5..8 swap width and height
+    void image_size(int32_t io_id, uint32_t* w, uint32_t* h, bool rotated = false) {
         Io& in = input(io_id);
+        if (rotated) {
+            image_size(io_id, w, h, false);
+            const int flag = exif_flag(in);
+            if (flag >= 5 && flag <= 8) std::swap(*w, *h);
+            return;
+        }
         if (in.in_len >= kRawHeader && std::memcmp(in.in, kRawMagic, 8) == 0) {
             uint32_t hdr[4];
             std::memcpy(hdr, in.in + 8, 16);
@@ -601,7 +617,11 @@ struct Job {
         f->w = ow; f->h = oh; f->stride = ifhip_stride_for_width(ow); f->alpha = false;
         f->pending = std::move(pend);
         if (!lazy_decode) (void)dev(f);                                               // several consumers: one bitmap for all of them
-        decodes.push_back({io_id, w, h, "image/jpeg", "jpg"});
+        {   // Context::get_image_decodes reports get_unscaled_rotated_image_info (context.rs:519-538)
+            const int flag = exif_flag(in);
+            const bool swap = flag >= 5 && flag <= 8;
+            decodes.push_back({io_id, swap ? h : w, swap ? w : h, "image/jpeg", "jpg"});
+        }
         return f;
     }
 
@@ -781,7 +801,9 @@ struct Job {
         const JVal* dec = p.get("decode");
         const JVal* enc = p.get("encode");
         uint32_t src_w = 0, src_h = 0;
-        if (dec && dec->t == JVal::Num) image_size(static_cast<int32_t>(want_int(p, "decode", "command_string")), &src_w, &src_h);
+        // (the layout sees the frame BEHIND the decoder's orientation step, and the decoder hints are worked out from those
+        // rotated sides and handed to the decoder as they are: command_string.rs:20-58, ir4/mod.rs:167-176)
+        if (dec && dec->t == JVal::Num) image_size(static_cast<int32_t>(want_int(p, "decode", "command_string")), &src_w, &src_h, true);
         else if (in) { src_w = in->w; src_h = in->h; }
         else raise(kGraphInvalid, "GraphInvalid: command_string has neither a decode io nor an input frame");
         auto target = [&](uint32_t sw, uint32_t sh, uint32_t* ow, uint32_t* oh) {        // mode=max: fit inside, never up-scale
@@ -796,7 +818,7 @@ struct Job {
                 const double preshrink = 2.1 / downscale;
                 if (preshrink < 1.0) { hint_w = static_cast<uint32_t>(std::floor(src_w * preshrink)); hint_h = static_cast<uint32_t>(std::floor(src_h * preshrink)); }
             }
-            in = decode(static_cast<int32_t>(dec->n), hint_w, hint_h, !srgb, !srgb);
+            in = decode_oriented(static_cast<int32_t>(dec->n), hint_w, hint_h, !srgb, !srgb);
             if (!src_w) { src_w = in->w; src_h = in->h; }
         }
         uint32_t ow, oh;
@@ -858,12 +880,14 @@ struct Job {
                 // image that is denser than that, with the geometry's worst case.
                 for (int attempt = 0; attempt < 2; ++attempt) {
                     const size_t scan_cap = attempt == 0 ? std::max<size_t>(65536u, off[3]) : 0u;
+                    // A geometry the coder does not take (more than 2.58 M blocks: a `security` override above ~110 MP) or a
+                    // stage that cannot be allocated is not the job's failure: the host writer below codes the same file.
                     ifhip_jpeg_enc_stage* es = nullptr;
-                    check(ifhip_jpeg_enc_stage_create(&es, f->w, f->h, 3, hs, vs, bw, bh, 1, scan_cap));
+                    if (ifhip_jpeg_enc_stage_create(&es, f->w, f->h, 3, hs, vs, bw, bh, 1, scan_cap) != IFHIP_OK) break;
                     std::unique_ptr<ifhip_jpeg_enc_stage, void (*)(ifhip_jpeg_enc_stage*)> es_guard(es, ifhip_jpeg_enc_stage_destroy);
                     const size_t pitch = ifhip_jpeg_enc_stage_max_file_bytes(es);
                     uint8_t* d_file = nullptr;
-                    hip_check(hipMalloc(reinterpret_cast<void**>(&d_file), pitch + 16u), "hipMalloc(file)");
+                    if (hipMalloc(reinterpret_cast<void**>(&d_file), pitch + 16u) != hipSuccess) { (void)hipGetLastError(); break; }
                     std::unique_ptr<uint8_t, void (*)(uint8_t*)> file_guard(d_file, [](uint8_t* p) { (void)hipFree(p); });
                     uint32_t* d_len = reinterpret_cast<uint32_t*>(d_file + ((pitch + 3u) & ~static_cast<size_t>(3u)));   // length, status behind the file
                     check(ifhip_jpeg_encode_batch_device(es, d_coef + off[0], d_coef + off[1], d_coef + off[2], quality, 1, d_file, pitch, d_len, d_len + 1, nullptr));
@@ -879,8 +903,7 @@ struct Job {
                     c->device_coded_files.fetch_add(1, std::memory_order_relaxed);
                     return;
                 }
-                raise(kInternalError, "InternalError: the device entropy coder dropped the image at its worst-case capacity");
-            }
+            }                                                                            // (not coded on the device: the host writer)
             std::vector<int16_t> coef(off[3]);
             hip_check(hipMemcpy(coef.data(), d_coef, off[3] * 2u, hipMemcpyDeviceToHost), "download(coefficients)");
             size_t len = 0;
@@ -930,6 +953,29 @@ struct Job {
         check(vertical ? ifhip_flip_vertical_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, nullptr)
                        : ifhip_flip_horizontal_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, nullptr));
         return in;
+    }
+    // ApplyOrientationDef::expand (flow/nodes/rotate_flip_transpose.rs:44-66): the EXIF flag as flips and a transpose
+    FramePtr apply_orientation(const FramePtr& in, int64_t flag) {
+        switch (flag) {
+        case 2: return flip(in, false);
+        case 3: return flip(flip(in, true), false);
+        case 4: return flip(in, true);
+        case 5: return transposed(in);
+        case 6: return flip(transposed(in), false);
+        case 7: return transposed(flip(flip(in, true), false));
+        case 8: return flip(transposed(in), true);
+        default: return in;
+        }
+    }
+    // DecoderDef::expand (flow/nodes/codecs_and_pointer.rs:94-107): a decode whose input carries an EXIF orientation
+    // above 0 is followed by ApplyOrientation {flag}.  Flag 1 is the identity -- the frame stays a pending JPEG, so that
+    // decode + resample remain one device call; the others need the bitmap.
+    FramePtr decode_oriented(int32_t io_id, uint32_t hint_w, uint32_t hint_h, bool luma_spatial, bool luma_srgb) {
+        FramePtr f = decode(io_id, hint_w, hint_h, luma_spatial, luma_srgb);
+        const int flag = exif_flag(input(io_id));
+        if (flag < 2) return f;
+        Timed t(this, "apply_orientation");
+        return apply_orientation(f, flag);
     }
     // ColorMatrixSrgbMutDef::mutate (flow/nodes/color.rs:20-38)
     FramePtr color_matrix(const FramePtr& in, const float m[25]) {
@@ -996,7 +1042,7 @@ struct Job {
         if (mode != "within" && mode != "fit" && mode != "distort")
             raise(kActionNotSupported, "ActionNotSupported: watermark fit_mode '%s' (this shim: within, fit, distort -- the crop / pad modes need imageflow_riapi's layout engine)", mode.c_str());
         uint32_t mw = 0, mh = 0;
-        image_size(io_id, &mw, &mh);
+        image_size(io_id, &mw, &mh, true);                                                                                // get_scaled_rotated_image_info (:128)
         uint32_t w, h;
         constrain_size(mode, mw, mh, true, true, bx2 - bx1, by2 - by1, &w, &h);
         float gx = 50.f, gy = 50.f;                                                                                       // obey_gravity (:69-86)
@@ -1014,7 +1060,7 @@ struct Job {
         };
         const int64_t x1 = gravity1d(gx, w, bx2 - bx1) + bx1, y1 = gravity1d(gy, h, by2 - by1) + by1;
         if (x1 < 0 || y1 < 0) raise(kArgumentInvalid, "InvalidNodeParams: Watermark fit_box does not work");
-        FramePtr mark = decode(io_id, 0, 0, false, false);
+        FramePtr mark = decode_oriented(io_id, 0, 0, false, false);
         float opacity = 1.f;
         if (const JVal* o = p.get("opacity")) if (o->t == JVal::Num) opacity = std::min(std::max(static_cast<float>(o->n), 0.f), 1.f);
         if (opacity < 1.f) {                                                                                             // :166-172
@@ -1064,7 +1110,7 @@ struct Job {
                             if (const JVal* b = j->get("scale_luma_spatially")) spatial = b->t == JVal::Bool && b->b;
                             if (const JVal* b = j->get("gamma_correct_for_srgb_during_spatial_luma_scaling")) gamma = b->t == JVal::Bool && b->b;
                         }
-            return decode(static_cast<int32_t>(want_int(p, "io_id", "decode")), hw, hh, spatial, gamma);
+            return decode_oriented(static_cast<int32_t>(want_int(p, "io_id", "decode")), hw, hh, spatial, gamma);
         }
         if (name == "create_canvas") {
             Timed t(this, "create_canvas");
@@ -1169,18 +1215,7 @@ struct Job {
         if (name == "rotate_90") return flip(transposed(in), false);                  // rotate_flip_transpose.rs:51-66
         if (name == "rotate_180") return flip(flip(in, true), false);
         if (name == "rotate_270") return flip(transposed(in), true);
-        if (name == "apply_orientation") {                                            // ApplyOrientationDef::expand (:44-66)
-            switch (want_int(p, "flag", "apply_orientation")) {
-            case 2: return flip(in, false);
-            case 3: return flip(flip(in, true), false);
-            case 4: return flip(in, true);
-            case 5: return transposed(in);
-            case 6: return flip(transposed(in), false);
-            case 7: return transposed(flip(flip(in, true), false));
-            case 8: return flip(transposed(in), true);
-            default: return in;
-            }
-        }
+        if (name == "apply_orientation") return apply_orientation(in, want_int(p, "flag", "apply_orientation"));
         raise(kActionNotSupported, "ActionNotSupported: node '%s' is outside the pixel hot path this library replaces", name.c_str());
     }
 
@@ -1582,6 +1617,10 @@ const struct imageflow_json_response* imageflow_context_send_json(struct imagefl
                     const uint32_t sw = static_cast<uint32_t>((static_cast<uint64_t>(w) * i + 7) / 8), sh = static_cast<uint32_t>((static_cast<uint64_t>(h) * i + 7) / 8);
                     if (sw >= in.told_w && sh >= in.told_h) { w = sw; h = sh; break; }
                 }
+            {   // get_unscaled_rotated_image_info / get_scaled_rotated_image_info (v1.rs:288,352 -> context.rs:486-501)
+                const int flag = Job::exif_flag(in);
+                if (flag >= 5 && flag <= 8) std::swap(w, h);
+            }
             return respond(c, 200, "{\n  \"code\": 200,\n  \"success\": true,\n  \"message\": \"OK\",\n  \"data\": {\n    \"image_info\": {\"preferred_mime_type\": \"image/jpeg\", "
                                    "\"preferred_extension\": \"jpg\", \"image_width\": " + std::to_string(w) + ", \"image_height\": " + std::to_string(h) +
                                    ", \"frame_decodes_into\": \"bgr_32\"}\n  }\n}");

@@ -173,14 +173,14 @@ size_t fused_lds_bytes(uint32_t n_u, uint32_t nquads, int channels, uint32_t wu_
 // way to spread the (long) chains over more lanes.
 bool use_per_pixel(uint32_t max_nu, int channels, uint32_t block) {
     bool per_pixel = max_nu >= 64u || static_cast<uint64_t>(max_nu) * static_cast<uint32_t>(channels) > block;
-    if (const char* e = std::getenv("IFHIP_PERPIXEL")) per_pixel = std::atoi(e) != 0;      // experiment switch
+    if (const char* e = debug_switch("perpixel")) per_pixel = std::atoi(e) != 0;      // experiment switch
     return per_pixel;
 }
 uint32_t block_for(uint32_t max_quads, int px) {          // lanes of a frame slot: one per px source pixels, whole waves
     return std::max<uint32_t>(64u, (max_quads * static_cast<uint32_t>(4 / px) + 63u) & ~63u);
 }
 size_t lds_limit() {                                   // experiment switch: cap the per-workgroup LDS (co-residency)
-    if (const char* e = std::getenv("IFHIP_LDS_LIMIT")) { const long v = std::atol(e); if (v >= 16384 && v <= 160 * 1024) return static_cast<size_t>(v); }
+    if (const char* e = debug_switch("lds_limit")) { const long v = std::atol(e); if (v >= 16384 && v <= 160 * 1024) return static_cast<size_t>(v); }
     return kLdsLimit;
 }
 constexpr uint32_t kMinLutCopiesLog2 = 4;      // never fewer than 16 copies of the sRGB->float table (2-way conflicts)
@@ -241,7 +241,7 @@ int get_schedule(const ifhip_resample_plan* p, uint32_t n_bands, int group, int 
 }
 
 uint32_t choose_bands(const ifhip_resample_plan* p, uint32_t n_images, size_t n_strips) {
-    if (const char* e = std::getenv("IFHIP_BANDS")) {
+    if (const char* e = debug_switch("bands")) {
         const int v = std::atoi(e);
         if (v >= 1) return std::min<uint32_t>(static_cast<uint32_t>(v), p->out_h);
     }
@@ -319,12 +319,12 @@ bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_im
                 BandedArgs& b = bp->args;
                 b.rows_per_band = R; b.n_bands = (out_h + R - 1u) / R; b.src_rows_cap = ns;
                 uint32_t wgs = kBandedWorkgroups;
-                if (const char* e = std::getenv("IFHIP_BANDED_WGS")) wgs = static_cast<uint32_t>(std::max(1, std::atoi(e)));   // experiment / test switch
+                if (const char* e = debug_switch("banded_wgs")) wgs = static_cast<uint32_t>(std::max(1, std::atoi(e)));   // experiment / test switch
                 b.frame_step = std::max<uint32_t>(1u, std::min<uint32_t>(n_images, wgs / b.n_bands));
                 b.h_w_floats = static_cast<uint32_t>(p->wh.w.size());
                 // (bit 0, weights of short horizontal windows in registers: padded to 8 taps it costs more multiply-adds than
                 // it saves reads -- 3.76 against 3.65 ms on the 3x shape -- so it is an experiment switch)
-                const char* rt = std::getenv("IFHIP_BANDED_REGTAPS");
+                const char* rt = debug_switch("banded_regtaps");
                 b.flags = ((rt && std::atoi(rt) != 0) ? 1u : 0u) | (ascending ? 2u : 0u) | (h_lds ? 4u : 0u);
                 bp->grid = b.n_bands * b.frame_step;
                 bp->lds = lds;
@@ -336,7 +336,7 @@ bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_im
 }
 // IFHIP_BANDED: 0 = never, 1 = instead of the generic pair wherever it fits, 2 = also for up-scales the fused kernel could take
 int banded_mode() {
-    if (const char* e = std::getenv("IFHIP_BANDED")) return std::atoi(e);
+    if (const char* e = debug_switch("banded")) return std::atoi(e);
     return 1;       // measured (MI355X): 3x up-scale 9.97 -> 3.65 ms; the 2x up-scale the fused kernel takes is faster there (2.93 vs 4.43)
 }
 
@@ -360,7 +360,9 @@ int validate_render(uint32_t in_w, uint32_t in_h, uint32_t in_stride, uint32_t c
 int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride,
                   int alpha, uint32_t n_images, uint8_t* d_canvas, size_t canvas_image_bytes, uint32_t cw, uint32_t ch,
                   uint32_t c_stride, uint32_t x, uint32_t y, int working_space, int compositing, uint32_t matte,
-                  float* d_f32, int force_kernel, hipStream_t st, const uint8_t* d_cb = nullptr, const uint8_t* d_cr = nullptr) {
+                  float* d_f32, int force_kernel, hipStream_t st, const uint8_t* d_cb = nullptr, const uint8_t* d_cr = nullptr,
+                  bool probe = false) {
+    // probe (planar source only): everything up to the launch -- IFHIP_OK means the real call will run the fused kernel
     // d_cb / d_cr: planar YCbCr source (d_in = the Y plane, in_stride = sample pitch, in_image_bytes = plane size).  That form
     // exists only on the fused kernel: kNotFusable tells the caller to go through a BGRA bitmap instead.
     if (!p) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null plan");
@@ -415,8 +417,8 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         if (want && banded_plan(p, d_in, in_image_bytes, in_stride, n_images, &bp)) {
             // IFHIP_BANDED_FLAGS: experiment switch, masks the plan's flags (1 weights of short horizontal windows in registers,
             // 2 band rows from its first and last row, 4 horizontal tables in LDS)
-            if (const char* fe = std::getenv("IFHIP_BANDED_FLAGS")) bp.args.flags &= static_cast<uint32_t>(std::atoi(fe));
-            if (std::getenv("IFHIP_TRACE_LAUNCH"))
+            if (const char* fe = debug_switch("banded_flags")) bp.args.flags &= static_cast<uint32_t>(std::atoi(fe));
+            if (debug_switch("trace_launch"))
                 std::fprintf(stderr, "ifhip banded launch: %ux%u -> %ux%u alpha=%d rows/band=%u bands=%u src rows=%u frame step=%u flags=%u grid=%u lds=%zu images=%u\n",
                              p->in_w, p->in_h, p->out_w, p->out_h, alpha, bp.args.rows_per_band, bp.args.n_bands, bp.args.src_rows_cap,
                              bp.args.frame_step, bp.args.flags, bp.grid, bp.lds, n_images);
@@ -448,7 +450,7 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
             // Frames per workgroup: a source narrower than half the workgroup would leave the CU with a handful of waves
             // (one workgroup per CU: the tables fill most of the LDS), so F frames share a workgroup and its tables.
             frames = 1;
-            if (ss.strips.size() == 1 && std::getenv("IFHIP_ONE_FRAME_PER_WG") == nullptr) {
+            if (ss.strips.size() == 1 && debug_switch("one_frame_per_wg") == nullptr) {
                 const uint32_t max_f = std::min<uint32_t>(static_cast<uint32_t>(fused_max_threads(p->slots, channels)) / block, n_images);
                 const Strip& s0 = ss.strips[0];
                 for (uint32_t f = max_f; f > 1; --f)
@@ -470,14 +472,14 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
                     if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, wu_floats, w, l2s, copies_log2, per_pixel, frames, fast_g) > limit) return false;
                 return true;
             };
-            w_in_lds = std::getenv("IFHIP_HW_GLOBAL") == nullptr && fits(true, false, kMinLutCopiesLog2);
+            w_in_lds = debug_switch("hw_global") == nullptr && fits(true, false, kMinLutCopiesLog2);
             // What goes next depends on where the lookups are: the 16 KiB linear->sRGB table saves an 8-step threshold
             // search (~40 instructions) per encoded channel, the second set of 16 table copies saves one LDS conflict cycle
             // per converted sample.  Per output row a strip encodes 3*n_u channels and converts 12*nquads*(in_h/out_h)
             // samples; thumbnail-sized outputs (cfg2) want the copies first, moderate ratios (cfg3) the encode table.
             const double enc_cost = 3.0 * max_nu * 40.0;
             const double conv_cost = 12.0 * ss.max_quads * (static_cast<double>(p->in_h) / std::max<uint32_t>(1u, p->out_h)) * 2.0;
-            const bool l2s_allowed = a.linear && std::getenv("IFHIP_L2S_SEARCH") == nullptr;
+            const bool l2s_allowed = a.linear && debug_switch("l2s_search") == nullptr;
             copies_log2 = kMinLutCopiesLog2;
             l2s_in_lds = false;
             if (enc_cost > conv_cost) {
@@ -503,12 +505,13 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         a.lanes_per_frame = block;
         const uint64_t grid = static_cast<uint64_t>((n_images + frames - 1u) / frames) * sd.n_bands * a.n_strips;
         if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
-        if (std::getenv("IFHIP_TRACE_LAUNCH"))                        // experiment aid: the shape this call launches
+        if (debug_switch("trace_launch"))                        // experiment aid: the shape this call launches
             std::fprintf(stderr, "ifhip fused launch: %ux%u -> %ux%u K=%d alpha=%d ycc=%d lanes/frame=%u frames/wg=%u bands=%u strips=%u "
                          "grid=%llu lds=%zu fast_g=%u w_in_lds=%d l2s_in_lds=%d lut_copies=%u per_pixel=%d images=%u\n",
                          p->in_w, p->in_h, p->out_w, p->out_h, p->slots, alpha, ycc ? 1 : 0, block, frames, sd.n_bands, a.n_strips,
                          static_cast<unsigned long long>(grid), lds, fast_g, w_in_lds ? 1 : 0, l2s_in_lds ? 1 : 0, 1u << copies_log2,
                          per_pixel ? 1 : 0, n_images);
+        if (probe) return IFHIP_OK;
         HIP_TRY(launch_fused(a, p->slots, alpha != 0, per_pixel, static_cast<uint32_t>(grid), block * frames, lds, st));
         return IFHIP_OK;
     }
@@ -541,9 +544,9 @@ namespace ifhip {
 int resample_from_ycc_planes_v(const ifhip_resample_plan* plan, const uint8_t* d_y, const uint8_t* d_cb, const uint8_t* d_cr,
                              size_t plane_bytes, uint32_t pitch, uint32_t n_images, uint8_t* d_canvas, size_t canvas_image_bytes,
                              uint32_t cw, uint32_t ch, uint32_t c_stride, uint32_t x, uint32_t y, int working_space, int compositing,
-                             uint32_t matte, void* hip_stream) {
+                             uint32_t matte, void* hip_stream, bool probe) {
     return enqueue_batch(plan, d_y, plane_bytes, pitch, 0, n_images, d_canvas, canvas_image_bytes, cw, ch, c_stride, x, y,
-                         working_space, compositing, matte, nullptr, -1, static_cast<hipStream_t>(hip_stream), d_cb, d_cr);
+                         working_space, compositing, matte, nullptr, -1, static_cast<hipStream_t>(hip_stream), d_cb, d_cr, probe);
 }
 void resample_plan_shape(const ifhip_resample_plan* plan, uint32_t* in_w, uint32_t* in_h, uint32_t* out_w, uint32_t* out_h) {
     *in_w = plan->in_w; *in_h = plan->in_h; *out_w = plan->out_w; *out_h = plan->out_h;
@@ -679,7 +682,7 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
     {
         uint32_t g_max = 0;
         for (uint32_t u = 0; u < w; ++u) g_max = std::max(g_max, hmeta[u].y);
-        if (g_max >= 2u && g_max <= 4u && std::getenv("IFHIP_NO_FAST_H") == nullptr) {
+        if (g_max >= 2u && g_max <= 4u && debug_switch("no_fast_h") == nullptr) {
             std::map<std::vector<uint32_t>, uint32_t> seen;        // padded row bits -> row id
             const uint32_t row_floats = g_max * 4u;
             bool ok = true;
@@ -715,7 +718,7 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
         const int channels = al ? 4 : 3;
         ifhip_resample_plan::StripSet& ss = p->sets[al];
         uint32_t max_lanes = static_cast<uint32_t>(fused_max_quads(p->slots, channels));      // in 4-pixel groups
-        if (const char* e = std::getenv("IFHIP_MAX_LANES")) {               // experiment switch: narrower strips
+        if (const char* e = debug_switch("max_lanes")) {               // experiment switch: narrower strips
             const int v = std::atoi(e);
             if (v >= 64) max_lanes = std::min<uint32_t>(max_lanes, static_cast<uint32_t>(v) & ~63u);
         }

@@ -12,6 +12,11 @@ namespace ifhip {
 int fail(int status, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 const char* last_error();
 
+// Development switches (tests and tools/ only).  The library never reads the environment: a switch exists only after
+// ifhip_debug_set(key, value) (include/imageflow_hip.h); unset -> nullptr.  One relaxed atomic load when none is set.
+const char* debug_switch(const char* key);
+inline bool debug_on(const char* key) { return debug_switch(key) != nullptr; }
+
 // ---------------------------------------------------------------------------------------------------
 // Interpolation kernels + per-axis contribution tables  (graphics/weights.rs)
 // ---------------------------------------------------------------------------------------------------
@@ -91,7 +96,7 @@ constexpr int kNotFusable = -1000;
 int resample_from_ycc_planes_v(const ifhip_resample_plan* plan, const uint8_t* d_y, const uint8_t* d_cb, const uint8_t* d_cr,
                                size_t plane_bytes, uint32_t pitch, uint32_t n_images, uint8_t* d_canvas, size_t canvas_image_bytes,
                                uint32_t cw, uint32_t ch, uint32_t c_stride, uint32_t x, uint32_t y, int working_space, int compositing,
-                               uint32_t matte, void* hip_stream);
+                               uint32_t matte, void* hip_stream, bool probe = false);   // probe: decide only, launch nothing
 void resample_plan_shape(const ifhip_resample_plan* plan, uint32_t* in_w, uint32_t* in_h, uint32_t* out_w, uint32_t* out_h);
 int max_live_rows(const AxisWeights& wv);
 

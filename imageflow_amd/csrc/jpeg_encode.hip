@@ -214,7 +214,9 @@ __global__ __launch_bounds__(1024) void enc_scan_kernel(const EncArgs a, const i
     if (tid == 0u) {
         if (mode == 0) {
             a.tot_bits[img] = carry;
-            if (overflow || (static_cast<uint64_t>(carry) + 7u) / 8u > a.cap_words * 4u) atomicOr(a.status + img, kEncScanOverflow);
+            // (the same bound ifhip_jpeg_enc_stage_max_file_bytes sizes a file for: the capacity minus its spare chunk -- a
+            // scan between the two passed this check and was then dropped as a file overflow)
+            if (overflow || (static_cast<uint64_t>(carry) + 7u) / 8u > a.cap_words * 4u - kEncChunkBytes) atomicOr(a.status + img, kEncScanOverflow);
         } else {
             a.tot_ff[img] = carry;
         }

@@ -692,7 +692,10 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
         // The DC predictors are touched when a block is stored, not per symbol; a coefficient goes into the row one symbol late: its natural-order index is an LDS lookup, and the wave would
         // sit out that round trip; this way it overlaps the next symbol's table read.
         constexpr uint32_t kNoStore = 64u;                   // a slot in the row's padding: "nothing to store" without a branch
-        uint32_t pend_nat = kNoStore;
+        // (the looked-up index is not even LOOKED AT in the step that requests it -- a select on it would wait for the read --
+        // but at the next step's row store: `pend_raw` is that read's destination, `pend_ok` whether it counts)
+        uint32_t pend_raw = kNoStore;
+        bool pend_ok = false;
         int32_t pend_val = 0;
 #ifdef IFHIP_ENT_TRACE
         const unsigned long long tw_0 = wall_clock64();
@@ -706,7 +709,7 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
                 const bool is_dc = z == 0u;
                 bits = rd.peek();
                 uint32_t e = tcur[bits >> (32u - kLutBits)];
-                row[pend_nat] = static_cast<int16_t>(pend_val);
+                row[pend_ok ? pend_raw : kNoStore] = static_cast<int16_t>(pend_val);
                 if ((e & 255u) == 0u) e = long_entry(T, S, static_cast<uint32_t>(tcur - lut0) / kLutEntries, e, bits);
                 p += e & 255u;
                 rd.skip(lds_words, e & 255u);
@@ -717,8 +720,8 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
                 const uint32_t pos = z + ((e >> 8) & 255u) - 1u;                // zigzag index of an AC coefficient (DC: 0)
                 const bool over = sz != 0u && pos > 63u;                         // a coefficient behind the block's end
                 err |= ((e >> 21) & 1u) | (over ? 4u : 0u);                      // (length field 32: no such code)
-                const uint32_t nat = lds_zz[pos & 63u];
-                pend_nat = (is_dc || (sz != 0u && !over)) ? nat : kNoStore;      // a DC entry holds the DIFFERENCE until the block is stored
+                pend_raw = lds_zz[pos & 63u];
+                pend_ok = is_dc || (sz != 0u && !over);                          // a DC entry holds the DIFFERENCE until the block is stored
                 waiting = advance(e);
             }
             const uint32_t n_wait = static_cast<uint32_t>(__popcll(__ballot(waiting)));
@@ -729,8 +732,8 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
             ++tw_fl;
 #endif
             if (waiting) {
-                row[pend_nat] = static_cast<int16_t>(pend_val);
-                pend_nat = kNoStore;
+                row[pend_ok ? pend_raw : kNoStore] = static_cast<int16_t>(pend_val);
+                pend_ok = false;
                 // every LDS read of the store (the row, where the block goes) is requested before the first is used
                 const BlockPlace pl = lds_place[k];
                 int16_t* plane = lds_plane[k];
@@ -1139,6 +1142,67 @@ int ifhip_jpeg_parse_headers(const uint8_t* jpeg, size_t len, uint32_t* width, u
     return IFHIP_OK;
 }
 
+// EXIF orientation of a JPEG as MozJpegDecoder reads it (codecs/mozjpeg_decoder_helpers.rs:107-202; the decoder saves
+// APP1 and APP2 markers up to 0xffff bytes, mozjpeg_decoder.rs:551-558): the FIRST saved marker whose data starts with
+// "Exif\0\0" decides -- shorter than 32 bytes: none; the TIFF header is looked for at offsets 0..15; IFD0's entries are
+// walked for tag 0x0112, rejected only if its type is not SHORT AND its count is not 1 (sic, `&&`), values above 8 are none.
+// Every read behind the data's end is the reference's io error, i.e. none.  *flag: -1 none, else 0..8.
+int ifhip_jpeg_exif_orientation(const uint8_t* d, size_t len, int* flag) {
+    if (!flag) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null out-pointer");
+    *flag = -1;
+    if (!d || len < 4 || d[0] != 0xFF || d[1] != 0xD8) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: not a JPEG (no SOI)");
+    size_t i = 2;
+    while (i + 4 <= len) {
+        if (d[i] != 0xFF) break;
+        while (i < len && d[i] == 0xFF) ++i;
+        if (i >= len) break;
+        const uint8_t m = d[i++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9 || m == 0xDA || i + 2 > len) break;                       // jpeg_read_header stops at SOS
+        const size_t seg = (static_cast<size_t>(d[i]) << 8) | d[i + 1];
+        if (seg < 2 || i + seg > len) break;
+        const uint8_t* q = d + i + 2;
+        const size_t n = seg - 2;
+        i += seg;
+        if ((m != 0xE1 && m != 0xE2) || n < 6 || std::memcmp(q, "Exif\0\0", 6) != 0) continue;
+        if (n < 32) return IFHIP_OK;                                             // "EXIF too short"
+        size_t tiff = 16;
+        bool little = false;
+        for (size_t t = 0; t < 16 && tiff == 16; ++t) {
+            if (std::memcmp(q + t, "II\x2a\0", 4) == 0) { tiff = t; little = true; }
+            else if (std::memcmp(q + t, "MM\0\x2a", 4) == 0) { tiff = t; little = false; }
+        }
+        if (tiff == 16) return IFHIP_OK;
+        const uint8_t* r = q + tiff + 4;
+        const uint64_t rn = n - tiff - 4;
+        uint64_t pos = 0;
+        bool eof = false;
+        auto rd = [&](uint32_t bytes) -> uint32_t {
+            if (eof || pos + bytes > rn) { eof = true; return 0; }
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < bytes; ++k) v |= static_cast<uint32_t>(r[pos + k]) << (little ? 8u * k : 8u * (bytes - 1u - k));
+            pos += bytes;
+            return v;
+        };
+        const uint32_t offset = rd(4);
+        if (eof) return IFHIP_OK;
+        pos = static_cast<uint64_t>(std::max<uint32_t>(4u, offset)) - 4u;
+        const uint32_t tags = rd(2);
+        for (uint32_t k = 0; k < tags && !eof; ++k) {
+            if (rd(2) == 0x112u && !eof) {
+                const uint32_t type = rd(2), count = rd(4);
+                if (eof || (type != 3u && count != 1u)) return IFHIP_OK;
+                const uint32_t v = rd(2);
+                if (!eof && v <= 8u) *flag = static_cast<int>(v);
+                return IFHIP_OK;
+            }
+            pos += 10;
+        }
+        return IFHIP_OK;
+    }
+    return IFHIP_OK;
+}
+
 static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* files, const size_t* lengths, uint32_t n_images) {
     if (!out) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null out-pointer");
     *out = nullptr;
@@ -1167,15 +1231,15 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
         std::vector<uint32_t> seg_mcu0, seg_mcus;
         uint32_t first_seg = 0;
     };
-    const bool timing = std::getenv("IFHIP_ENT_TIMING") != nullptr;        // development aid: phase times on stderr
+    const bool timing = debug_switch("ent_timing") != nullptr;        // development aid: phase times on stderr
     // test hooks: the rarely taken paths (serial code search for sub-tables that overflow the pool; further rounds after an
     // unsettled count pass) are forced by shrinking the pool / the iterations per launch
     auto env_u32 = [](const char* name, uint32_t dflt, uint32_t hi) {
-        const char* v = std::getenv(name);
+        const char* v = debug_switch(name);
         return v ? std::min<uint32_t>(static_cast<uint32_t>(std::strtoul(v, nullptr, 10)), hi) : dflt;
     };
-    const uint32_t pool_limit = env_u32("IFHIP_ENT_TEST_POOL", kPoolEntries, kPoolEntries);
-    const uint32_t inner_rounds = std::max<uint32_t>(1u, env_u32("IFHIP_ENT_TEST_INNER", kInnerRounds, kInnerRounds));
+    const uint32_t pool_limit = env_u32("ent_test_pool", kPoolEntries, kPoolEntries);
+    const uint32_t inner_rounds = std::max<uint32_t>(1u, env_u32("ent_test_inner", kInnerRounds, kInnerRounds));
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
     const auto t_start = now();
@@ -1408,7 +1472,7 @@ int ifhip_jpeg_debug_scan_report(const uint8_t* jpeg, size_t len, ifhip_jpeg_sca
         if (int rc = parse_jpeg(jpeg, len, &P)) return rc;
         auto F = std::make_unique<FastTabs>(), Pt = std::make_unique<FastTabs>(), Ct = std::make_unique<FastTabs>();
         SearchTab S6[6];
-        const char* lim = std::getenv("IFHIP_ENT_TEST_POOL");
+        const char* lim = debug_switch("ent_test_pool");
         const uint32_t pool_limit = lim ? std::min<uint32_t>(static_cast<uint32_t>(std::strtoul(lim, nullptr, 10)), kPoolEntries) : kPoolEntries;
         derive_image_tables(P, F.get(), S6, pool_limit, &out->pool_entries_used);
         derive_pair_tables(*F, P.ncomp, Pt.get());

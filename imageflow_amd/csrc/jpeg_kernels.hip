@@ -1211,7 +1211,7 @@ static int stage_args(ifhip_jpeg_stage* stage, const int16_t* d_coef0, const int
 
 // block-per-lane routine of component c: 0 islow 8x8, 1 jidctred 4x4, 2 islow + spatial scaler; -1: the eight-lanes kernel
 static int bpl_mode(const JpegGeom& g, int c) {
-    if (std::getenv("IFHIP_JPEG_IDCT8")) return -1;             // experiment switch: everything on the eight-lanes kernel
+    if (debug_switch("jpeg_idct8")) return -1;             // experiment switch: everything on the eight-lanes kernel
     const uint32_t n = g.idct_n[c];
     if (c == 0 && g.luma_mode != 0u && n < 8u) return 2;
     return n == 8u ? 0 : n == 4u ? 1 : -1;
@@ -1262,7 +1262,7 @@ int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d
     a.bgra = d_bgra; a.image_bytes = image_bytes; a.stride = stride;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     // full-size colour decode: the luma IDCT runs inside the colour kernel (no luma plane in HBM)
-    const bool fused_luma = a.g.ncomp == 3 && a.g.scale_num == 8u && a.g.luma_mode == 0u && std::getenv("IFHIP_JPEG_UNFUSED") == nullptr;
+    const bool fused_luma = a.g.ncomp == 3 && a.g.scale_num == 8u && a.g.luma_mode == 0u && debug_switch("jpeg_unfused") == nullptr;
     rc = launch_idct_planes(a, fused_luma ? 1 : 0, st);
     if (rc) return rc;
     const dim3 cgrid((a.g.out_w + 1023u) / 1024u, (a.g.out_h + kColorRows - 1u) / kColorRows, n_images);
@@ -1296,8 +1296,13 @@ int ifhip_jpeg_decode_resample_batch_device(ifhip_jpeg_stage* stage, const int16
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const JpegGeom& g = a.g;
     const bool planes_at_output = g.ncomp == 3 && g.upsample == 0u && g.pw[0] == g.pw[1] && g.pw[0] == g.pw[2] &&
-                                  g.ph[0] == g.ph[1] && g.ph[0] == g.ph[2] && std::getenv("IFHIP_JPEG_UNFUSED") == nullptr;
-    if (planes_at_output) {
+                                  g.ph[0] == g.ph[1] && g.ph[0] == g.ph[2] && debug_switch("jpeg_unfused") == nullptr;
+    // the resampler is asked FIRST whether it takes the planes (alignment, a shape of the planar-source instantiations):
+    // a refusal behind the plane IDCTs would run every IDCT twice
+    if (planes_at_output &&
+        resample_from_ycc_planes_v(plan, a.plane[0], a.plane[1], a.plane[2], static_cast<size_t>(g.pw[0]) * g.ph[0], g.pw[0], n_images,
+                                   d_canvas, canvas_image_bytes, canvas_w, canvas_h, canvas_stride, x, y, working_space, compositing,
+                                   matte_bgra, hip_stream, true) == IFHIP_OK) {
         rc = launch_idct_planes(a, 0, st);
         if (rc) return rc;
         rc = resample_from_ycc_planes_v(plan, a.plane[0], a.plane[1], a.plane[2], static_cast<size_t>(g.pw[0]) * g.ph[0], g.pw[0], n_images,

@@ -670,15 +670,18 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
 
 template <int K, bool ALPHA, bool WLDS, bool PERPIXEL, int FG = 0, bool YCC = false>
 static hipError_t launch_variant(const ResampleArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    // raise the dynamic-LDS cap once per kernel variant and device (it is sticky), not on every launch
-    static std::atomic<size_t> cap[16];      // (one per instantiation of this function template)
+    // raise the dynamic-LDS cap once per kernel variant and device (it is sticky), not on every launch: a bit per device
+    // ordinal (ordinals beyond the mask set the attribute on every launch); failing to raise it is the launch's error
+    static std::atomic<uint64_t> raised;     // (one per instantiation of this function template)
     int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::atomic<size_t>& c = cap[dev & 15];
-    if (c.load(std::memory_order_relaxed) < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_resample_kernel<K, ALPHA, WLDS, PERPIXEL, FG, YCC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsCap));
-        c.store(kFusedLdsCap, std::memory_order_relaxed);
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+    if (!(raised.load(std::memory_order_relaxed) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_resample_kernel<K, ALPHA, WLDS, PERPIXEL, FG, YCC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsCap));
+        if (e != hipSuccess) return e;
+        raised.fetch_or(bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((fused_resample_kernel<K, ALPHA, WLDS, PERPIXEL, FG, YCC>), grid, block, lds, st, a, a.steps);
     return hipGetLastError();

@@ -344,14 +344,19 @@ hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, ui
 }
 
 hipError_t launch_banded(const ResampleArgs& a, bool alpha, const BandedArgs& b, uint32_t grid_x, size_t lds, hipStream_t st) {
-    static std::atomic<int> raised[2][16];                     // the dynamic-LDS cap is sticky per kernel and device
+    // the dynamic-LDS cap is sticky per kernel and device: raised once for each (a bit per device ordinal; ordinals beyond
+    // the mask's width simply set the attribute again on every launch), and a failure to raise it is the launch's error
+    static std::atomic<uint64_t> raised[2];
     int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::atomic<int>& r = raised[alpha ? 1 : 0][dev & 15];
-    if (!r.load(std::memory_order_relaxed)) {
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::atomic<uint64_t>& r = raised[alpha ? 1 : 0];
+    const uint64_t bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+    if (!(r.load(std::memory_order_relaxed) & bit)) {
         const void* f = alpha ? reinterpret_cast<const void*>(&banded_resample_kernel<true>) : reinterpret_cast<const void*>(&banded_resample_kernel<false>);
-        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsCap));
-        r.store(1, std::memory_order_relaxed);
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsCap));
+        if (e != hipSuccess) return e;
+        r.fetch_or(bit, std::memory_order_relaxed);
     }
     const dim3 grid(grid_x), block(kBandedThreads);
     if (alpha) hipLaunchKernelGGL((banded_resample_kernel<true>), grid, block, lds, st, a, b);

@@ -7,6 +7,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <map>
+#include <mutex>
 
 #include "common.hpp"
 
@@ -22,6 +25,20 @@ int fail(int status, const char* fmt, ...) {
     return status;
 }
 const char* last_error() { return g_err; }
+
+// development switches: a small registry behind ifhip_debug_set; values live until the process ends (a changed value
+// leaves the old string in place, so a pointer handed out earlier stays readable)
+namespace {
+std::atomic<int> g_switches_set{0};
+std::mutex g_switch_mu;
+std::map<std::string, const std::string*>& switches() { static std::map<std::string, const std::string*> m; return m; }
+}  // namespace
+const char* debug_switch(const char* key) {
+    if (g_switches_set.load(std::memory_order_relaxed) == 0) return nullptr;
+    std::lock_guard<std::mutex> lk(g_switch_mu);
+    const auto it = switches().find(key);
+    return it == switches().end() || !it->second ? nullptr : it->second->c_str();
+}
 
 namespace {
 
@@ -335,3 +352,11 @@ bool build_vschedule(const AxisWeights& wv, int n_bands, int group, int ahead, V
 }
 
 }  // namespace ifhip
+
+extern "C" int ifhip_debug_set(const char* key, const char* value) {
+    if (!key || !*key) return ifhip::fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null switch name");
+    std::lock_guard<std::mutex> lk(ifhip::g_switch_mu);
+    ifhip::switches()[key] = value ? new std::string(value) : nullptr;
+    ifhip::g_switches_set.store(1, std::memory_order_relaxed);
+    return IFHIP_OK;
+}

@@ -68,6 +68,10 @@ typedef enum ifhip_lobe_mode { IFHIP_LOBE_NATURAL = 0, IFHIP_LOBE_EXACT = 1, IFH
 /* ---- library / device -------------------------------------------------------------------------------- */
 IFHIP_API const char* ifhip_last_error_message(void);
 IFHIP_API const char* ifhip_version(void);
+/* Development switches of tests and tools/ (kernel choice for A/B runs, rarely taken paths forced): the library reads NO
+ * environment variable -- what a call launches depends on its arguments only -- and a switch exists only after this call
+ * (value NULL: unset).  Not part of the drop-in surface. */
+IFHIP_API int ifhip_debug_set(const char* key, const char* value);
 IFHIP_API int ifhip_device_count(void);            /* number of usable gfx950 devices (0 if none)          */
 IFHIP_API int ifhip_set_device(int ordinal);       /* one process per GPU: call once with LOCAL_RANK       */
 
@@ -223,6 +227,9 @@ IFHIP_API int ifhip_jpeg_debug_scan_report(const uint8_t* jpeg, size_t len, ifhi
 IFHIP_API int ifhip_jpeg_parse_headers(const uint8_t* jpeg, size_t len, uint32_t* width, uint32_t* height,
                                        int* n_components, uint8_t* h_samp3, uint8_t* v_samp3, uint32_t* blocks_w3,
                                        uint32_t* blocks_h3, uint16_t* qt3x64, uint32_t* restart_interval);
+/* EXIF orientation as MozJpegDecoder::get_exif_rotation_flag reads it (codecs/mozjpeg_decoder.rs:290-292, :625-627 ->
+ * mozjpeg_decoder_helpers.rs:107-202): *flag = -1 when the file carries none, else the tag's value 0..8.  Host only. */
+IFHIP_API int ifhip_jpeg_exif_orientation(const uint8_t* jpeg, size_t len, int* flag);
 IFHIP_API int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* files, const size_t* lengths,
                                         uint32_t n_images);
 IFHIP_API void ifhip_jpeg_entropy_destroy(ifhip_jpeg_entropy* e);
@@ -292,7 +299,10 @@ IFHIP_API int ifhip_jpeg_write_batch(const int16_t* coef0, const int16_t* coef1,
  * longer than the stage's scan_capacity), IFHIP_ENC_FILE_OVERFLOW (the file is longer than file_pitch).  Asynchronous on
  * hip_stream.  scan_capacity: bound of an image's entropy-coded bytes before stuffing, 0 = the most the geometry can
  * produce (208 bytes per block), with which no image is ever dropped for the scan's length.  Files are byte-identical to
- * ifhip_jpeg_write_baseline's for the same coefficients and quality. */
+ * ifhip_jpeg_write_baseline's for the same coefficients and quality.
+ * A stage is bound to ONE stream at a time: it owns the scratch of a call in flight (bit counts, the word stream, the
+ * marker segments of the current quality), so a second call must be ordered behind the first -- same stream, or an
+ * event between them; use one stage per stream for concurrent batches. */
 #define IFHIP_ENC_BAD_COEFFICIENT 1
 #define IFHIP_ENC_SCAN_OVERFLOW 2
 #define IFHIP_ENC_FILE_OVERFLOW 4

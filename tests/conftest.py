@@ -15,3 +15,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def debug_switch():
+    """Sets development switches of the library (ifhip_debug_set) for one test and unsets them afterwards."""
+    from imageflow_amd import _native
+    used = []
+
+    def set_(key, value):
+        used.append(key)
+        _native.debug_set(key, value)
+    yield set_
+    for k in used:
+        _native.debug_set(k, None)

@@ -33,6 +33,9 @@ def test_invalid_json_is_category_3_http_400_exit_65(body):
     with Context() as c:
         status, r = c.send_json("v1/execute", body)
         assert status == 400 and r["success"] is False and r["message"].startswith("InvalidJson")
+        # JsonResponse::fail_with_message serialises ResponsePayload::None, a unit variant renamed "none" (json/mod.rs:169-180,
+        # imageflow_types/src/lib.rs:2061-2062): the reference's Response001 deserialises "none", not {}
+        assert r["code"] == 400 and r["data"] == "none"
         assert c.has_error() and c.error_code() == 3
         assert c.L.imageflow_context_error_as_http_code(c.p) == 400 and c.L.imageflow_context_error_as_exit_code(c.p) == 65
         # FlowError::recoverable() is `false` for every error (imageflow_core/src/errors.rs:656-658, 953-969): an error,

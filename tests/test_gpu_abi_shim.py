@@ -631,3 +631,85 @@ def test_region_refuses_an_empty_rectangle():
             c.add_output_buffer(1)
             status, r = c.send_json("v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, node, {"encode": {"io_id": 1, "preset": "gif"}}]}})
             assert status == 400 and c.error_code() != 0 and "Not a rectangle" in r["message"], r
+
+
+# ---- EXIF orientation behind decode (flow/nodes/codecs_and_pointer.rs:94-107) ---------------------------------------------
+def _exif_segment(value, little=True):
+    import struct
+    e = "<" if little else ">"
+    tiff = (b"II\x2a\x00" if little else b"MM\x00\x2a") + struct.pack(e + "I", 8) + struct.pack(e + "H", 1)
+    tiff += struct.pack(e + "HHI", 0x0112, 3, 1) + struct.pack(e + "H", value) + b"\0\0" + struct.pack(e + "I", 0)
+    data = b"Exif\0\0" + tiff + b"\0" * 8
+    return b"\xff\xe1" + struct.pack(">H", len(data) + 2) + data
+
+
+def _oracle_orient(rows, w, h, flag):
+    """ApplyOrientationDef::expand (rotate_flip_transpose.rs:44-66) with the primitives of :100-215 on the oracle's bitmaps:
+    rotate_90 = transpose + flip_h, rotate_180 = flip_v + flip_h, rotate_270 = transpose + flip_v."""
+    rows = np.ascontiguousarray(rows).copy()
+
+    def tr(a, aw, ah):
+        t = np.zeros((aw, U.stride_for(ah)), np.uint8)
+        O.transpose(a, aw, ah, a.shape[1], t, ah, aw, t.shape[1])
+        return t, ah, aw
+    if flag == 2: O.flip_horizontal(rows, w, h, rows.shape[1])
+    elif flag == 3: O.flip_vertical(rows, w, h, rows.shape[1]); O.flip_horizontal(rows, w, h, rows.shape[1])
+    elif flag == 4: O.flip_vertical(rows, w, h, rows.shape[1])
+    elif flag == 5: rows, w, h = tr(rows, w, h)
+    elif flag == 6: rows, w, h = tr(rows, w, h); O.flip_horizontal(rows, w, h, rows.shape[1])
+    elif flag == 7:
+        O.flip_vertical(rows, w, h, rows.shape[1]); O.flip_horizontal(rows, w, h, rows.shape[1])
+        rows, w, h = tr(rows, w, h)
+    elif flag == 8: rows, w, h = tr(rows, w, h); O.flip_vertical(rows, w, h, rows.shape[1])
+    return rows, w, h
+
+
+@pytest.mark.parametrize("flag", list(range(0, 9)) + [9])
+def test_exif_orientation_is_applied_behind_every_decode(flag):
+    """Eight 4:2:0 files that differ only in their EXIF orientation tag (+ tag 0 and an out-of-range 9): decode ->
+    resample_2d -> encode equals oracle decode + oracle orientation + oracle resize; the job's decode record and
+    v1/get_image_info report the rotated size (context.rs:486-538); flags 0, 1 and 9 keep decode + resample one call."""
+    base = _jpeg(176, 112, seed=flag)
+    data = base[:2] + _exif_segment(flag, little=flag % 2 == 0) + base[2:]
+    swap = 5 <= flag <= 8
+    ow, oh = (40, 66) if swap else (66, 40)
+    with Context() as c:
+        c.add_input_buffer(0, data)
+        c.add_output_buffer(1)
+        status, info = c.send_json("v1/get_image_info", {"io_id": 0})
+        assert status == 200
+        ii = info["data"]["image_info"]
+        assert (ii["image_width"], ii["image_height"]) == ((112, 176) if swap else (176, 112))
+        r = _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}},
+                                                           {"resample_2d": {"w": ow, "h": oh, "hints": {"down_filter": "robidoux"}}},
+                                                           {"encode": {"io_id": 1, "preset": "gif"}}]}})
+        d = r["data"]["job_result"]["decodes"][0]
+        assert (d["w"], d["h"]) == ((112, 176) if swap else (176, 112))
+        rows, w, h, alpha = unpack_raw_bgra(c.get_output_buffer(1))
+        assert c.L.ifhip_shim_fused_decode_resamples(c.p) == (1 if flag in (0, 1, 9) else 0)
+        names = [n["name"] for f in r["data"]["job_result"]["performance"]["frames"] for n in f["nodes"]]
+        assert ("apply_orientation" in names) == (2 <= flag <= 8)
+    j = O.jpeg_read_coefficients(data)                                     # (the oracle's parser skips APP1 like any APPn)
+    full = O.jpeg_idct_color(j)
+    rot, rw, rh = _oracle_orient(full, 176, 112, flag)
+    exp = _oracle_resize(rot, rw, rh, ow, oh, filter_id=2)
+    assert (w, h, alpha) == (ow, oh, False) and np.array_equal(rows, exp)
+
+
+def test_exif_orientation_in_a_command_string_job():
+    """command_string sizes its layout on the ROTATED frame and hands hints worked out from the rotated sides to the
+    decoder as they are (command_string.rs:20-58, ir4/mod.rs:167-176): a 1600x600 file tagged 6 is 600x1600 to the
+    querystring; width=100 -> 100x267; pre-shrink min(600/100, 1600/100) = 6 -> hints 210x560 against the decoder's
+    UNROTATED 1600x600 -> 8/8 (7/8 is skipped, 6/8 = 450 rows < 560), so the job decodes at full size."""
+    base = _jpeg(1600, 600, seed=5)
+    data = base[:2] + _exif_segment(6) + base[2:]
+    with Context() as c:
+        c.add_input_buffer(0, data)
+        c.add_output_buffer(1)
+        _run(c, "v1/execute", {"framewise": {"steps": [{"command_string": {"kind": "ir4", "value": "width=100", "decode": 0, "encode": 1}}]}})
+        rows, w, h, _ = unpack_raw_bgra(c.get_output_buffer(1))
+    assert (w, h) == (100, 267)
+    j = O.jpeg_read_coefficients(data)
+    rot, rw, rh = _oracle_orient(O.jpeg_idct_color(j), 1600, 600, 6)
+    assert (rw, rh) == (600, 1600)
+    assert np.array_equal(rows, _oracle_resize(rot, 600, 1600, 100, 267, filter_id=2))

@@ -249,6 +249,26 @@ def test_decode_resample_cfg4_shape():
     j = _random_case(rng, 3840, 2160, (2, 1, 1), (2, 1, 1), 3, 60)
     one, two, fused, _ = _decode_resample_case(j, 2, 4, 2, 800, 450)
     assert fused and np.array_equal(one, two)
+    # ... and against the ORACLE chain directly (frame 0 of the batch carries j's coefficients unchanged): scaled decode with
+    # the reference's compiled spatial luma scaler, then the CPU resize
+    exp_dec = O.jpeg_idct_color_scaled(j, 4, 2)
+    exp = np.zeros((1, 450, U.stride_for(800)), np.uint8)
+    U.oracle_render(exp_dec[None], 1920, 1080, exp, 800, 450, 0, 0, 800, 450)
+    assert np.array_equal(one[0], exp[0])
+
+
+@pytest.mark.parametrize("scale_num,ow,oh,tw,th", [(1, 480, 270, 200, 113), (2, 960, 540, 200, 113)])
+def test_decode_resample_one_call_at_4k_equals_the_oracle_chain(scale_num, ow, oh, tw, th):
+    """The 1/8 and 2/8 one-call shapes of a 3840x2160 file (what `width=200` asks its decoder for, BASELINE config 1) against
+    oracle decode + oracle resize, not only against the two-call form."""
+    rng = np.random.default_rng(50 + scale_num)
+    j = _random_case(rng, 3840, 2160, (2, 1, 1), (2, 1, 1), 3, 60)
+    one, two, fused, _ = _decode_resample_case(j, 2, scale_num, 2, tw, th)
+    assert fused and np.array_equal(one, two)
+    exp_dec = O.jpeg_idct_color_scaled(j, scale_num, 2)
+    exp = np.zeros((1, th, U.stride_for(tw)), np.uint8)
+    U.oracle_render(exp_dec[None], ow, oh, exp, tw, th, 0, 0, tw, th)
+    assert np.array_equal(one[0], exp[0])
 
 
 def test_decode_resample_rejects_a_plan_of_another_size():

@@ -114,14 +114,14 @@ def test_many_small_files_in_one_batch(golden_dir):
                 assert np.array_equal(coef[c][k].cpu().numpy(), j["coef"][c]), (k, c)
 
 
-@pytest.mark.parametrize("hook", [{"IFHIP_ENT_TEST_POOL": "0"}, {"IFHIP_ENT_TEST_POOL": "40"}, {"IFHIP_ENT_TEST_INNER": "1"},
-                                  {"IFHIP_ENT_TEST_INNER": "2", "IFHIP_ENT_TEST_POOL": "8"}])
-def test_rarely_taken_paths(golden_dir, monkeypatch, hook):
+@pytest.mark.parametrize("hook", [{"ent_test_pool": "0"}, {"ent_test_pool": "40"}, {"ent_test_inner": "1"},
+                                  {"ent_test_inner": "2", "ent_test_pool": "8"}])
+def test_rarely_taken_paths(golden_dir, debug_switch, hook):
     """The serial code search (sub-tables that overflow the second-level pool: forced by a pool of 0 / 40 / 8 entries) and the
     rounds after an unsettled count pass (forced by one or two fixpoint iterations per launch) decode the same
     coefficients as the normal path."""
     for k, v in hook.items():
-        monkeypatch.setenv(k, v)
+        debug_switch(k, v)
     checked, most_rounds = 0, 0
     for key, items in groups(golden_dir, "jpeg_entropy_cases.npz").items():
         files = [d for _, d in items]

@@ -334,13 +334,13 @@ def test_banded_kernel_equals_the_oracle(shape, alpha):
 
 @pytest.mark.parametrize("filt,sharpen", [(Filter.Lanczos, 15.0), (Filter.Ginseng, 0.0), (Filter.Hermite, 0.0), (Filter.Box, 0.0),
                                           (Filter.Jinc, 0.0), (Filter.Robidoux, 50.0), (Filter.CatmullRom, 5.0)])
-def test_banded_kernel_filters(filt, sharpen, monkeypatch):
+def test_banded_kernel_filters(filt, sharpen, debug_switch):
     run_case(60, 40, 171, 113, filt=filt, sharpen=sharpen, alpha=True, force=2)
     run_case(150, 85, 31, 18, filt=filt, sharpen=sharpen, alpha=False, force=2)
-    monkeypatch.setenv("IFHIP_BANDED_REGTAPS", "1")                                       # short windows: weights in registers, +0 padding taps
+    debug_switch("banded_regtaps", "1")                                             # short windows: weights in registers, +0 padding taps
     run_case(60, 40, 171, 113, filt=filt, sharpen=sharpen, alpha=True, force=2)
     run_case(150, 85, 31, 18, filt=filt, sharpen=sharpen, alpha=False, force=2)           # long windows keep the tap loop
-    monkeypatch.setenv("IFHIP_BANDED_FLAGS", "0")                                         # no shortcut at all: tables from HBM, band rows by search
+    debug_switch("banded_flags", "0")                                               # no shortcut at all: tables from HBM, band rows by search
     run_case(60, 40, 171, 113, filt=filt, sharpen=sharpen, alpha=True, force=2)
 
 
@@ -352,12 +352,12 @@ def test_banded_kernel_compositing_modes(space, compose, alpha):
         run_case(40, 24, 93, 57, space=space, compose=compose, matte=matte, alpha=alpha, force=2, x=3, y=5, cw=100, ch=70)
 
 
-def test_banded_kernel_frame_loop_and_wide_rows(monkeypatch):
+def test_banded_kernel_frame_loop_and_wide_rows(debug_switch):
     run_case(600, 40, 1200, 80, alpha=True, force=2)           # 4 800 source pixels per band: no prefetch registers, tables from HBM
-    monkeypatch.setenv("IFHIP_BANDED_WGS", "1")                # one workgroup per band takes every frame: the prefetch of frame i + 1
+    debug_switch("banded_wgs", "1")                      # one workgroup per band takes every frame: the prefetch of frame i + 1
     run_case(100, 100, 300, 300, alpha=True, force=2, n=5)     # under the passes of frame i
     run_case(600, 40, 1200, 80, alpha=False, force=2, n=3)
-    monkeypatch.setenv("IFHIP_BANDED_WGS", "30")               # 13 bands: two workgroups per band, frames 0 2 4 / 1 3
+    debug_switch("banded_wgs", "30")                     # 13 bands: two workgroups per band, frames 0 2 4 / 1 3
     run_case(100, 100, 300, 300, alpha=False, force=2, n=5, compose=BitmapCompositing.BlendWithMatte, matte=0xFF405060)
 
 
@@ -368,8 +368,8 @@ def test_banded_kernel_refuses_what_does_not_fit():
 
 
 @pytest.mark.parametrize("mode", ["1", "2"])
-def test_auto_mode_with_the_banded_kernel_switched_on(mode, monkeypatch):
-    monkeypatch.setenv("IFHIP_BANDED", mode)
+def test_auto_mode_with_the_banded_kernel_switched_on(mode, debug_switch):
+    debug_switch("banded", mode)
     run_case(100, 100, 300, 300, alpha=True)                  # generic before: banded in both modes
     run_case(200, 200, 400, 400, alpha=True, filt=Filter.Hermite)     # fused in mode 1, banded in mode 2
     run_case(384, 216, 20, 20, alpha=False)                   # a down-scale the fused kernel takes in both modes

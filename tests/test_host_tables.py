@@ -167,3 +167,20 @@ def test_header_is_plain_c_and_links_with_c_linkage(tmp_path):
                     f"-Wl,-rpath,{libdir}"], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "c abi ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_the_library_reads_no_environment_variable():
+    """A drop-in .so whose kernel choice depends on the host's environment is not a product: the development switches
+    exist only behind ifhip_debug_set (tests, tools/).  No IFHIP_* name is left in the binary, getenv is not imported, and
+    a switch set through the entry point is seen by the code that asks for it (the decode-table pool of the scan report)."""
+    import subprocess
+    from imageflow_amd import _native
+    path = _native.LIB_PATH
+    names = subprocess.run(["strings", path], capture_output=True, text=True, check=True).stdout
+    assert "IFHIP_" not in names
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    L = _native.lib()
+    assert L.ifhip_debug_set(None, b"1") != 0 and L.ifhip_debug_set(b"", b"1") != 0
+    _native.debug_set("no_such_switch", "1")
+    _native.debug_set("no_such_switch", None)

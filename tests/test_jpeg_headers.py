@@ -149,14 +149,14 @@ def _scan_report(data):
 
 
 @pytest.mark.parametrize("pool", [None, "0", "40"])
-def test_decode_tables_and_scan_layout_without_a_device(golden_dir, monkeypatch, pool):
+def test_decode_tables_and_scan_layout_without_a_device(golden_dir, debug_switch, pool):
     """What the entropy kernels rely on, checked on the host for every committed file (ifhip_jpeg_debug_scan_report):
     a serial walk with the two-level tables starts exactly the blocks the geometry asks for and ends on the DC values of
     the oracle's decode; walks with the pair tables (synchronisation rounds) and with the count tables pass through the
     same state at every sub-sequence boundary as the plain walk.  Also with a second-level pool of 0 / 40 entries, which
     leaves long prefixes to the serial code search."""
     if pool is not None:
-        monkeypatch.setenv("IFHIP_ENT_TEST_POOL", pool)
+        debug_switch("ent_test_pool", pool)
     files = searched = paired = 0
     reads = symbols = 0
     for name, data in all_files(golden_dir):
@@ -177,3 +177,76 @@ def test_decode_tables_and_scan_layout_without_a_device(golden_dir, monkeypatch,
     assert files == 206 and paired == files
     assert (searched > 0) == (pool is not None)          # the committed files fit the pool; the shrunken pools do not hold them
     assert reads < 0.8 * symbols                          # one read covers two symbols often enough
+
+
+# ---- EXIF orientation (ifhip_jpeg_exif_orientation; codecs/mozjpeg_decoder_helpers.rs:107-202) ----------------------------
+def _exif_app1(value=6, little=True, tag_type=3, count=1, lead=0, ifd_offset=8, pad_to=40, extra_tags=2):
+    """An APP1 "Exif" segment: header, `lead` junk bytes, TIFF header, IFD0 with `extra_tags` other tags and 0x0112."""
+    import struct
+    e = "<" if little else ">"
+    tiff = (b"II\x2a\x00" if little else b"MM\x00\x2a") + struct.pack(e + "I", ifd_offset)
+    tiff += b"\0" * (ifd_offset - 8)
+    tiff += struct.pack(e + "H", extra_tags + 1)
+    for k in range(extra_tags):
+        tiff += struct.pack(e + "HHI", 0x010F + k, 2, 4) + b"abc\0"
+    tiff += struct.pack(e + "HHI", 0x0112, tag_type, count) + struct.pack(e + "H", value) + b"\0\0"
+    tiff += struct.pack(e + "I", 0)
+    data = b"Exif\0\0" + b"\x01" * lead + tiff
+    data += b"\0" * max(0, pad_to - len(data))
+    return b"\xff\xe1" + struct.pack(">H", len(data) + 2) + data
+
+
+def _exif_flag(jpeg):
+    import ctypes as C
+    L = _native.lib()
+    L.ifhip_jpeg_exif_orientation.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    flag = C.c_int(-7)
+    assert L.ifhip_jpeg_exif_orientation(jpeg, len(jpeg), C.byref(flag)) == 0
+    return flag.value
+
+
+def _with_segments(jpeg, *segs):
+    return jpeg[:2] + b"".join(segs) + jpeg[2:]
+
+
+def test_exif_orientation_follows_the_reference_parser(golden_dir):
+    from imageflow_amd import _native
+    globals()["_native"] = _native
+    base = next(all_files(golden_dir))[1]
+    assert _exif_flag(base) == -1                                                    # no EXIF: None
+    for little in (True, False):
+        for v in range(0, 9):
+            assert _exif_flag(_with_segments(base, _exif_app1(v, little))) == v      # 0..8 are Some(v), 0 included (:191)
+        assert _exif_flag(_with_segments(base, _exif_app1(9, little))) == -1         # above 8: None
+        assert _exif_flag(_with_segments(base, _exif_app1(300, little))) == -1
+    # `tag_type != 3 && count != 1` is the only rejection (:187): one of the two may be off
+    assert _exif_flag(_with_segments(base, _exif_app1(6, tag_type=4, count=1))) == 6
+    assert _exif_flag(_with_segments(base, _exif_app1(6, tag_type=3, count=2))) == 6
+    assert _exif_flag(_with_segments(base, _exif_app1(6, tag_type=4, count=2))) == -1
+    # the TIFF header is searched at offsets 0..15 of the marker data (:136-145); "Exif\0\0" occupies 0..5
+    assert _exif_flag(_with_segments(base, _exif_app1(5, lead=9))) == 5               # header at offset 15
+    assert _exif_flag(_with_segments(base, _exif_app1(5, lead=10))) == -1             # at 16: not found
+    # shorter than 32 bytes: "EXIF too short" (:116-121) -- and the FIRST Exif marker decides
+    def cut(seg, n):                                                                  # the segment without its last n bytes
+        return seg[:2] + (len(seg) - 2 - n).to_bytes(2, "big") + seg[4:len(seg) - n]
+    full = _exif_app1(3, extra_tags=0, pad_to=0)
+    short = cut(full, 4)                                                              # (without the next-IFD pointer: 28 bytes)
+    assert len(full) - 4 == 32 and _exif_flag(_with_segments(base, full)) == 3 and _exif_flag(_with_segments(base, short)) == -1
+    assert _exif_flag(_with_segments(base, short, _exif_app1(6))) == -1
+    assert _exif_flag(_with_segments(base, _exif_app1(8), _exif_app1(6))) == 8
+    # other APP1 / APP2 content in front is skipped; an IFD offset below 4 reads from the start (max(4, offset) - 4, :173)
+    xmp = b"\xff\xe1\x00\x20" + b"http://ns.adobe.com/xap/1.0/\0x"
+    icc = b"\xff\xe2\x00\x12" + b"ICC_PROFILE\0\x01\x01ab"
+    assert _exif_flag(_with_segments(base, xmp, icc, _exif_app1(7))) == 7
+    # IFD that points behind the data, and a tag list that runs off the end: io errors are None (:150 unwrap_or(None))
+    assert _exif_flag(_with_segments(base, _exif_app1(6, ifd_offset=4000))) == 6     # IFD0 far behind the header
+    seg = bytearray(_exif_app1(6))
+    seg[14:18] = (4000).to_bytes(4, "little")                                          # ... and one that is not there
+    assert _exif_flag(_with_segments(base, bytes(seg))) == -1
+    seg[14:18] = (2).to_bytes(4, "little")                                             # max(4, offset) - 4: read as offset 4, i.e. the
+    assert _exif_flag(_with_segments(base, bytes(seg))) == -1                          # offset field's second half as the tag count
+    assert _exif_flag(_with_segments(base, cut(_exif_app1(6, extra_tags=1, pad_to=0), 8))) == -1   # ends inside the tag's value
+    # an Exif marker behind SOS is never seen (jpeg_read_header stops at the scan)
+    sos = base.index(b"\xff\xda")
+    assert _exif_flag(base[:sos] + base[sos:-2] + _exif_app1(6) + b"\xff\xd9") == -1
+
