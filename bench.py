@@ -20,7 +20,11 @@ ranks; under a launcher, WORLD_SIZE must equal --gpus (anything else is an error
 
 --workload cfg3 is BASELINE config 3 as a job: the export_4_sizes pyramid 3840x2160 -> 1600x900 -> {1200x675 -> 400x225,
 800x450} (imageflow_tool/src/self_test.rs:185-198), four chained launches per batch, 58 737 600 algorithmic bytes per
-image, 128 frames per GPU by default (1024 images over 8 GPUs).
+image, 128 frames per GPU by default (1024 images over 8 GPUs).  --outputs files (default): every output goes through the
+job's encoder as in the reference (`libjpeg_turbo` quality 90: forward pixel stage + entropy coder on the device) and
+the final gather ships the FILES -- ~0.26 bytes per pixel instead of 4 (1.38 GB of BGRA per rank became ~90 MB);
+--outputs bgra keeps the round-3 form (raw levels gathered).  `roofline` stays the four resample launches; the line
+also carries what a step costs without the encoders.
 
 Prints ONE JSON line (rank 0).  value = source megapixels resized per second over all ranks, inputs already in HBM.
 """
@@ -185,6 +189,9 @@ def parse_args(argv=None):
                          "buffered against the next step; none: results stay sharded")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--outputs", default="files", choices=["files", "bgra"],
+                    help="--workload cfg3: what the job leaves and its final gather ships -- the four JPEG files per image "
+                         "(libjpeg_turbo q90, coded on the device; the reference's export_4_sizes) or the raw BGRA levels")
     ap.add_argument("--no-strong-field", action="store_true",
                     help="skip the extra `strong_1024` measurement (the --total-frames job cut into N blocks) of a weak cfg2 run")
     return ap.parse_args(argv)
@@ -216,7 +223,7 @@ def main():
     from imageflow_amd.graphics.bitmaps import Bitmap, BitmapCompositing
     from imageflow_amd.graphics.scaling import ScaleAndRenderParams, plan_for, scale_and_render, time_scale_and_render
     from imageflow_amd.graphics.weights import Filter
-    from imageflow_amd.sharding import gather_to_root, max_over_ranks, shard_range
+    from imageflow_amd.sharding import gather_bytes_to_root, gather_to_root, max_over_ranks, shard_range
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: imageflow_amd has no CPU path")
@@ -250,7 +257,8 @@ def main():
         raise SystemExit(f"rank {rank} owns no frames ({total} frames over {world} ranks)")
     n_max = -(-total // world)                           # gather slots are sized by the largest block
     # the extra north_star measurement of a default run: --total-frames images cut into `world` blocks
-    strong_field = (args.scaling == "weak" and args.workload == "cfg2" and not args.no_strong_field and not pyramid)
+    strong_field = args.scaling == "weak" and args.workload in ("cfg2", "cfg3") and not args.no_strong_field
+    files_out = pyramid and args.outputs == "files"
     s_lo, s_hi = shard_range(args.total_frames, rank, world) if strong_field else (0, 0)
     n_strong = s_hi - s_lo
     if strong_field and n_strong < 1:
@@ -299,7 +307,25 @@ def main():
                     s = self.inp if a == "src" else self.levels[a]
                     self.chain.append((s, self.levels[b], ScaleAndRenderParams(0, 0, w, h), plan_for(s.w, s.h, w, h, Filter.Robidoux, 0.0, dev)))
                 self.out_bytes_per_frame = sum(b.image_bytes for b in self.levels.values())
-                self.packed = torch.empty((self.n_max, self.out_bytes_per_frame), dtype=torch.uint8, device=dev)   # the four outputs of a frame, side by side
+                self.enc = {}
+                if files_out:
+                    # MozjpegEncoder::write_frame behind every output (codecs/mozjpeg.rs:78-160, preset libjpeg_turbo q90,
+                    # self_test.rs:186): 4:2:0, forward pixel stage + baseline entropy coder, files stay in HBM
+                    import numpy as np
+                    from imageflow_amd.codecs import mozjpeg as M
+                    self.M = M
+                    hs, vs = M.sampling_factors((2, 2), (2, 2))
+                    self.qt = torch.from_numpy(np.stack([M.quant_tables_for_quality(90)] * nj).view(np.int16)).to(dev)
+                    for name, (w, h) in sizes.items():
+                        fwd = M.JpegForwardStage(w, h, hs, vs, nj, dev)
+                        coef = fwd.write_frames(self.levels[name], self.qt)
+                        coder = M.JpegEntropyStage(w, h, hs, vs, fwd.blocks_w, fwd.blocks_h, nj, dev)
+                        pitch = (3 * w * h + 4095) // 4096 * 4096 + 4096                 # three bytes per pixel: ten times a q90 photograph, room for noise
+                        self.enc[name] = [fwd, coef, coder, torch.empty((nj, pitch), dtype=torch.uint8, device=dev), None, None,
+                                          torch.empty(nj * pitch, dtype=torch.uint8, device=dev)]
+                    self.file_bytes = None
+                else:
+                    self.packed = torch.empty((self.n_max, self.out_bytes_per_frame), dtype=torch.uint8, device=dev)   # the four outputs of a frame, side by side
             else:
                 self.canv = [Bitmap.create_u8(self.n_max, out_w, out_h, dev, compose=BitmapCompositing[wl[7]], matte=wl[8]) for _ in range(2)]
                 self.views = [first_frames(c, nj) for c in self.canv]
@@ -307,16 +333,21 @@ def main():
                 self.plan = plan_for(in_w, in_h, out_w, out_h, self.info.interpolation_filter, wl[5], dev)
                 self.out_bytes_per_frame = self.canv[0].image_bytes
             self.gathered = None
-            if mode != "none" and rank == 0:
+            if mode != "none" and rank == 0 and not files_out:
                 self.gathered = [torch.empty((world, self.n_max, self.out_bytes_per_frame), dtype=torch.uint8, device="cpu" if dryrun else dev)
                                  for _ in range(2 if mode == "every" else 1)]
+            self.gathered_sizes = None
             self.pending = [None, None]
             self.note = gather_note
 
-        def step(self, i):
+        def step(self, i, encode=True):
             if pyramid:
                 for s, d, inf, pl in self.chain:
                     scale_and_render(s, d, inf, plan=pl)
+                if encode:
+                    for name, e in self.enc.items():                   # (outputs have no meaningful alpha: no matte pass)
+                        e[0].write_frames(self.levels[name], self.qt, e[1])
+                        _, e[4], e[5] = e[2].encode_device(e[1], 90, files=e[3])
                 return
             if mode == "every" and self.pending[i & 1] is not None:
                 self.pending[i & 1].wait()             # the buffer we are about to overwrite has been gathered
@@ -332,6 +363,18 @@ def main():
                     self.pending[k] = None
             torch.cuda.synchronize()
 
+        def packed_files(self):
+            """The job's outputs as one message: every level's files back to back (16-byte aligned starts), and the
+            table that finds them -- per level the n + 1 offsets inside the level's part."""
+            parts, meta = [], []
+            for name, e in self.enc.items():
+                parts.append(self.M.pack_files_device(e[3], e[4], out=e[6]))
+            used = [int(o[-1].item()) for _, o in parts]                 # (one look at the device: the message's size)
+            for (_, o) in parts:
+                meta.append(o)
+            self.file_bytes = sum(used)
+            return torch.cat([p[:u] for (p, _), u in zip(parts, used)]), torch.stack(meta)
+
         def final_payload(self, steps):
             if not pyramid:
                 return self.canv[(steps - 1) & 1].data
@@ -346,6 +389,14 @@ def main():
             # resample kernel would take CUs from a grid that is exactly one workgroup per CU, so the job's one exchange
             # happens after the last batch; a failure here is reported, it does not cost the measurement.
             try:
+                if files_out:
+                    msg, meta = self.packed_files()
+                    meta_pad = torch.zeros((len(self.enc), self.n_max + 1), dtype=torch.int64, device=meta.device)
+                    meta_pad[:, :meta.shape[1]] = meta
+                    gather_to_root(meta_pad.cpu() if dryrun else meta_pad, 0)
+                    self.gathered_sizes, _ = gather_bytes_to_root(msg.cpu() if dryrun else msg, 0)
+                    gather_calls[phase] += 1
+                    return
                 last = self.final_payload(steps)
                 gather_to_root(last.cpu() if dryrun else last, 0, async_op=False, out=self.gathered[0] if rank == 0 else None)
                 gather_calls[phase] += 1
@@ -379,6 +430,19 @@ def main():
 
     job = Job(n, total)
     elapsed, compute_s = job.measure(args.steps, args.warmup)
+    resize_only_ms = None
+    if files_out:                                   # what a step costs without the encoders, and what the job's files weigh
+        k = max(1, min(args.steps, 20))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k):
+            job.step(i, encode=False)
+        torch.cuda.synchronize()
+        resize_only_ms = (time.perf_counter() - t0) / k * 1e3
+        if job.file_bytes is None:
+            job.packed_files()
+        job_dropped = int(sum(int((e[5] != 0).sum().item()) for e in job.enc.values()))
+    job_file_bytes, job_gathered_sizes = (job.file_bytes, job.gathered_sizes) if files_out else (None, None)
     views, chain = (None, job.chain) if pyramid else (job.views, None)
     info, plan = (None, None) if pyramid else (job.info, job.plan)
     gather_note = job.note
@@ -396,6 +460,7 @@ def main():
                   "value_without_gather": round(args.total_frames * in_w * in_h / 1e6 * s_steps / s_compute, 1),
                   "gather_ms": round((s_elapsed - s_compute) * 1e3, 4), "unit": "MP/s", "scaling": "strong", "gather": sj.note,
                   "gathers": dict(gather_calls),
+                  **({"gathered_bytes_per_rank": sj.gathered_sizes} if files_out else {}),
                   "what": f"north_star job: {args.total_frames} images cut into {world} contiguous blocks, same kernel, same timing rule; "
                           f"speed-up over 1 GPU = this value at N divided by this value at N = 1"}
         del sj
@@ -460,6 +525,17 @@ def main():
                          "measured_read_GBps": round(measured_read / 1e9, 1) if measured_read else None,
                          "frac_of_measured_read": round(achieved / measured_read, 4) if measured_read else None},
         }
+        if pyramid:
+            out["config"]["outputs"] = ("four JPEG files per image (libjpeg_turbo q90 4:2:0: forward pixel stage + entropy coder on the device), "
+                                        "the final gather ships the files" if files_out else "four raw BGRA levels per image, gathered as they are")
+            if files_out:
+                out["config"]["file_bytes_per_image"] = int(job_file_bytes // max(n, 1)) if job_file_bytes else None
+                out["config"]["gathered_bytes_per_rank"] = job_gathered_sizes
+                out["config"]["dropped_files"] = job_dropped
+                out["config"]["bgra_bytes_per_rank_if_raw"] = n * job.out_bytes_per_frame
+                out["config"]["resize_only_ms_per_step"] = round(resize_only_ms, 4)
+                out["config"]["note"] = ("value counts source megapixels through the WHOLE job (resizes + encoders); roofline is the four "
+                                         "resample launches alone")
         if strong is not None:
             out["strong_1024"] = strong
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":

@@ -50,8 +50,10 @@ def lib():
     L.ifhip_apply_matte.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
     L.ifhip_apply_matte_batch_device.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  C.c_uint32, C.c_int, C.c_uint32, C.c_void_p]
-    L.ifhip_debug_set.argtypes = [C.c_char_p, C.c_char_p]
     _lib = L
+    if not hasattr(L, "ifhip_debug_set"):          # (a library build of an earlier round, loaded through IFHIP_LIB for an A/B run)
+        return L
+    L.ifhip_debug_set.argtypes = [C.c_char_p, C.c_char_p]
     # development convenience of THIS binding (the library itself reads no environment variable): IFHIP_<SWITCH>=v in the
     # environment of a tools/ run becomes ifhip_debug_set("<switch>", v) once, at load
     for k, v in os.environ.items():

@@ -161,6 +161,24 @@ class JpegEntropyStage:
             pass
 
 
+def pack_files_device(files, lengths, out=None):
+    """ifhip_pack_files_device: files [n, pitch] uint8 + lengths [n] int32 (as JpegEntropyStage.encode_device leaves them) ->
+    (packed uint8 [capacity], offsets int64 [n + 1]): the files back to back, 16-byte aligned starts -- ONE message for the
+    job's final gather.  `out`: a buffer to reuse (its size is the capacity; default n * pitch, which always fits).
+    Asynchronous on the current stream; offsets[n] is the number of bytes used."""
+    L = _bind()
+    L.ifhip_pack_files_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    n, pitch = files.shape
+    if out is None:
+        out = torch.empty(n * pitch, dtype=torch.uint8, device=files.device)
+    offsets = torch.empty(n + 1, dtype=torch.int64, device=files.device)
+    stream = torch.cuda.current_stream(files.device).cuda_stream
+    with torch.cuda.device(files.device):
+        _native.check(L.ifhip_pack_files_device(files.data_ptr(), pitch, lengths.data_ptr(), n, out.data_ptr(), out.numel(),
+                                                offsets.data_ptr(), C.c_void_p(stream)))
+    return out, offsets
+
+
 def jpeg_forward_host(bgra, width, height, stride, h_samp, v_samp, qt):
     """Host-buffer drop-in (numpy): BGRA rows -> list of int16 arrays [bh_c][bw_c][64]."""
     L = _bind()

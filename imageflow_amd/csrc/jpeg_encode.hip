@@ -401,6 +401,48 @@ int make_enc_geom(uint32_t width, uint32_t height, int ncomp, const uint8_t* hs,
 }
 }  // namespace
 
+// ---- a batch's files as ONE message (the job's only exchange is the gather of its outputs) -------------
+// ifhip_jpeg_encode_batch_device leaves image i's file at d_files + i * file_pitch: a pitch sized for the worst case, of which
+// a q90 file fills a sixth.  What a rank sends to the root is the files back to back, every file starting on a 16-byte
+// boundary (<= 15 bytes of padding per file, so that both sides of the copy are 16-byte aligned), and the n + 1 offsets.
+namespace ifhip {
+__global__ void __launch_bounds__(1024) pack_offsets_kernel(const uint32_t* __restrict__ lengths, uint32_t n, uint64_t* __restrict__ offsets) {
+    __shared__ uint64_t wave_tot[16];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t mine = i < n ? (static_cast<uint64_t>(lengths[i]) + 15u) & ~static_cast<uint64_t>(15u) : 0u;
+        uint64_t inc = mine;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint64_t o = __shfl_up(inc, d, 64);
+            if ((threadIdx.x & 63u) >= d) inc += o;
+        }
+        if ((threadIdx.x & 63u) == 63u) wave_tot[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint64_t before = carry;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wave_tot[w];
+        if (i < n) offsets[i] = before + inc - mine;
+        __syncthreads();
+        if (threadIdx.x == 1023u) carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[n] = carry;
+}
+__global__ void __launch_bounds__(256) pack_copy_kernel(const uint8_t* __restrict__ files, size_t pitch, const uint32_t* __restrict__ lengths,
+                                                        const uint64_t* __restrict__ offsets, uint8_t* __restrict__ out, uint64_t capacity) {
+    const uint32_t i = blockIdx.y;
+    const uint64_t at = offsets[i];
+    const uint32_t quads = (lengths[i] + 15u) >> 4;                   // (the tail's padding is whatever lies behind the file: inside its pitch)
+    if (at + static_cast<uint64_t>(quads) * 16u > capacity) return;   // does not fit: the caller sees offsets[n] > capacity
+    const uint4* src = reinterpret_cast<const uint4*>(files + static_cast<size_t>(i) * pitch);
+    uint4* dst = reinterpret_cast<uint4*>(out + at);
+    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < quads; q += gridDim.x * 256u) dst[q] = src[q];
+}
+}  // namespace ifhip
+
 extern "C" {
 
 int ifhip_jpeg_enc_stage_create(ifhip_jpeg_enc_stage** stage, uint32_t width, uint32_t height, int n_components, const uint8_t* h_samp,
@@ -504,6 +546,22 @@ int ifhip_jpeg_encode_batch_device(ifhip_jpeg_enc_stage* stage, const int16_t* d
     hipLaunchKernelGGL(enc_ff_count_kernel, chunk_grid, dim3(256), 0, st, a);
     hipLaunchKernelGGL(enc_scan_kernel, dim3(n_images), dim3(1024), 0, st, a, 1);
     hipLaunchKernelGGL(enc_stuff_kernel, chunk_grid, dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return IFHIP_OK;
+}
+
+
+int ifhip_pack_files_device(const uint8_t* d_files, size_t file_pitch, const uint32_t* d_lengths, uint32_t n_files, uint8_t* d_out,
+                            size_t out_capacity, uint64_t* d_offsets, void* hip_stream) {
+    if (!d_files || !d_lengths || !d_out || !d_offsets) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null pointer");
+    if ((file_pitch & 15u) || (reinterpret_cast<uintptr_t>(d_files) & 15u) || (reinterpret_cast<uintptr_t>(d_out) & 15u))
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: files, pitch and the packed buffer must be 16-byte aligned");
+    if (n_files == 0) return IFHIP_OK;
+    if (n_files > 65535u) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: at most 65535 files per call");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipLaunchKernelGGL(ifhip::pack_offsets_kernel, dim3(1), dim3(1024), 0, st, d_lengths, n_files, d_offsets);
+    hipLaunchKernelGGL(ifhip::pack_copy_kernel, dim3(16, n_files), dim3(256), 0, st, d_files, file_pitch, d_lengths, d_offsets, d_out,
+                       static_cast<uint64_t>(out_capacity));
     HIP_TRY(hipGetLastError());
     return IFHIP_OK;
 }

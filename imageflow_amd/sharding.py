@@ -65,6 +65,44 @@ def gather_to_root(local: torch.Tensor, root: int = 0, group=None, async_op=Fals
     return (work if async_op else None), (out if rank == root else None)
 
 
+def gather_bytes_to_root(local: torch.Tensor, root: int = 0, group=None, out=None):
+    """The final gather of a job whose outputs are FILES (export_4_sizes ends in four JPEGs per image,
+    imageflow_tool/src/self_test.rs:185-198): every rank holds one 1-D uint8 message of its own length (its files packed
+    back to back, codecs.mozjpeg.pack_files_device).  The lengths travel first (one small all_gather), then every peer
+    sends exactly its bytes to `root` -- grouped point-to-point transfers, over RCCL one direct xGMI link per peer.
+    Returns (sizes [world] as a list, received) where received is, on the root, the list of the ranks' messages (views
+    into `out` when given: a uint8 buffer of at least the sum of the sizes), elsewhere None."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    local = local.contiguous().view(-1)
+    mine = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    each = [torch.empty(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+    dist.all_gather(each, mine, group=group)
+    sizes = [int(v.item()) for v in each]
+    if rank != root:
+        if sizes[rank]:
+            dist.send(local, dst=root, group=group)
+        return sizes, None
+    total = sum(sizes)
+    if out is None:
+        out = torch.empty(total, dtype=torch.uint8, device=local.device)
+    if out.numel() < total:
+        raise ValueError(f"gather buffer of {out.numel()} bytes for {total} bytes of files")
+    parts, ops, at = [], [], 0
+    for r in range(world):
+        view = out[at:at + sizes[r]]
+        at += sizes[r]
+        parts.append(view)
+        if r == rank:
+            view.copy_(local)
+        elif sizes[r]:
+            ops.append(dist.P2POp(dist.irecv, view, r, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return sizes, parts
+
+
 def max_over_ranks(seconds: float, device) -> float:
     """bench.py's timing rule: the job takes as long as its slowest rank."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

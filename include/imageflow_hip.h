@@ -312,6 +312,13 @@ IFHIP_API int ifhip_jpeg_enc_stage_create(ifhip_jpeg_enc_stage** stage, uint32_t
                                           const uint32_t* blocks_h3, uint32_t max_images, size_t scan_capacity);
 IFHIP_API void ifhip_jpeg_enc_stage_destroy(ifhip_jpeg_enc_stage* stage);
 /* a file_pitch with which no file overflows (marker segments + every stream byte stuffed + EOI) */
+/* The files of a batch as ONE message for the job's final gather: image i's file (d_lengths[i] bytes
+ * at d_files + i * file_pitch, as ifhip_jpeg_encode_batch_device leaves it; a dropped image has length 0) is copied to
+ * d_out + d_offsets[i], every start rounded up to 16 bytes; d_offsets[n_files] = the bytes used.  When that exceeds
+ * out_capacity the files that do not fit are not copied (the caller compares).  file_pitch, d_files and d_out 16-byte
+ * aligned; a file's padding bytes are unspecified.  Asynchronous on hip_stream. */
+IFHIP_API int ifhip_pack_files_device(const uint8_t* d_files, size_t file_pitch, const uint32_t* d_lengths, uint32_t n_files,
+                                      uint8_t* d_out, size_t out_capacity, uint64_t* d_offsets, void* hip_stream);
 IFHIP_API size_t ifhip_jpeg_enc_stage_max_file_bytes(const ifhip_jpeg_enc_stage* stage);
 IFHIP_API int ifhip_jpeg_encode_batch_device(ifhip_jpeg_enc_stage* stage, const int16_t* d_coef0, const int16_t* d_coef1,
                                              const int16_t* d_coef2, int quality, uint32_t n_images, uint8_t* d_files,

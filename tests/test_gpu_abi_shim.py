@@ -664,12 +664,14 @@ def _oracle_orient(rows, w, h, flag):
     return rows, w, h
 
 
+@pytest.mark.parametrize("subsampling", ["4:2:0", "4:4:4"])
 @pytest.mark.parametrize("flag", list(range(0, 9)) + [9])
-def test_exif_orientation_is_applied_behind_every_decode(flag):
+def test_exif_orientation_is_applied_behind_every_decode(flag, subsampling):
     """Eight 4:2:0 files that differ only in their EXIF orientation tag (+ tag 0 and an out-of-range 9): decode ->
     resample_2d -> encode equals oracle decode + oracle orientation + oracle resize; the job's decode record and
-    v1/get_image_info report the rotated size (context.rs:486-538); flags 0, 1 and 9 keep decode + resample one call."""
-    base = _jpeg(176, 112, seed=flag)
+    v1/get_image_info report the rotated size (context.rs:486-538); flags 0, 1 and 9 keep decode + resample one call
+    where the decode can be fused at all (4:4:4 at full size; full-size 4:2:0 needs the fancy up-sampler's bitmap)."""
+    base = _jpeg(176, 112, seed=flag, subsampling=subsampling)
     data = base[:2] + _exif_segment(flag, little=flag % 2 == 0) + base[2:]
     swap = 5 <= flag <= 8
     ow, oh = (40, 66) if swap else (66, 40)
@@ -686,7 +688,7 @@ def test_exif_orientation_is_applied_behind_every_decode(flag):
         d = r["data"]["job_result"]["decodes"][0]
         assert (d["w"], d["h"]) == ((112, 176) if swap else (176, 112))
         rows, w, h, alpha = unpack_raw_bgra(c.get_output_buffer(1))
-        assert c.L.ifhip_shim_fused_decode_resamples(c.p) == (1 if flag in (0, 1, 9) else 0)
+        assert c.L.ifhip_shim_fused_decode_resamples(c.p) == (1 if flag in (0, 1, 9) and subsampling == "4:4:4" else 0)
         names = [n["name"] for f in r["data"]["job_result"]["performance"]["frames"] for n in f["nodes"]]
         assert ("apply_orientation" in names) == (2 <= flag <= 8)
     j = O.jpeg_read_coefficients(data)                                     # (the oracle's parser skips APP1 like any APPn)

@@ -58,8 +58,44 @@ def test_sharded_hip_render_equals_single_process(tmp_path, world):
     assert np.array_equal(got.reshape(exp.shape), exp)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_export_job_gathers_the_same_files_as_one_process(tmp_path, world):
+    """The cfg3 form of the final gather: every rank resizes its block to each size, codes every output as a JPEG on the
+    device (libjpeg_turbo q90) and sends ONE packed message; rank 0 ends with exactly the files a single process writes --
+    which are the files libjpeg-turbo reads back as the oracle's pixels + encoder."""
+    import io
+    import pickle
+    from tests import pg_worker as W
+    n_frames = 5
+    out = str(tmp_path / "files.pkl")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "pg_worker.py"), "files", out, str(n_frames)]
+    r = subprocess.run(cmd, env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = pickle.load(open(out, "rb"))
+    in_w, in_h, sizes = 640, 360, [(400, 225), (200, 113)]
+    frames = np.concatenate([U.random_frames(1, in_w, in_h, seed0=7000 + i, alpha=False) for i in range(n_frames)])
+    msg, metas, part_sizes = W.export_files(frames, in_w, in_h, sizes)
+    single = W.unpack_files(msg, metas, part_sizes)
+    assert len(got["message_bytes"]) == world and sum(got["message_bytes"]) >= sum(len(f) for fs in single for f in fs)
+    PIL = pytest.importorskip("PIL.Image")
+    for k, (w, h) in enumerate(sizes):
+        assert len(got["files"][k]) == n_frames
+        for i in range(n_frames):
+            assert got["files"][k][i] == single[k][i], (k, i)
+            im = PIL.open(io.BytesIO(got["files"][k][i]))
+            assert im.size == (w, h) and im.format == "JPEG"
+    # ... and the pixels inside are the oracle's resize (through libjpeg-turbo's decoder: compare with its decode of the
+    # file the HOST path writes from the oracle's pixels is test_gpu_abi_shim's business; here: a plausible image)
+    exp = np.zeros((1, 225, U.stride_for(400)), np.uint8)
+    U.oracle_render(frames[:1], in_w, in_h, exp, 400, 225, 0, 0, 400, 225)
+    dec = np.asarray(PIL.open(io.BytesIO(got["files"][0][0])).convert("RGB"), np.int16)
+    ref = exp[0, :, :1600].reshape(225, 400, 4)[:, :, 2::-1].astype(np.int16)
+    assert np.abs(dec - ref).mean() < 12.0                              # q90 4:2:0 of noise-like content
+
+
 @pytest.mark.parametrize("extra,scaling,total", [(["--total-frames", "9"], "weak", 16), (["--scaling", "strong", "--total-frames", "9"], "strong", 9),
-                                                 (["--workload", "cfg3", "--frames", "3"], "weak", 6)])
+                                                 (["--workload", "cfg3", "--frames", "3", "--total-frames", "5"], "weak", 6)])
 def test_bench_launches_its_own_ranks(extra, scaling, total):
     env = _clean_env()
     env["IFHIP_BENCH_DRYRUN_ONE_GPU"] = "1"
@@ -80,6 +116,14 @@ def test_bench_launches_its_own_ranks(extra, scaling, total):
     if scaling == "weak" and "--workload" not in extra:              # the north_star job rides along with the default run
         st = j["strong_1024"]
         assert st["total_frames"] == 9 and st["frames_per_gpu"] == 5 and st["gathers"] == {"warmup": 1, "timed": 1} and st["value"] > 0
+    elif "--workload" in extra:                                      # cfg3: the job's outputs are FILES, and so is what the gather ships
+        c = j["config"]
+        assert "JPEG files" in c["outputs"] and c["dropped_files"] == 0
+        sent = c["gathered_bytes_per_rank"]
+        assert len(sent) == 2 and all(0 < b < c["bgra_bytes_per_rank_if_raw"] // 2 for b in sent), c
+        assert c["file_bytes_per_image"] > 0 and abs(sent[0] - 3 * c["file_bytes_per_image"]) <= 3 * 4 * 16 and c["resize_only_ms_per_step"] > 0
+        st = j["strong_1024"]                                        # (--total-frames defaults to 1024: too big for a test box? no: 512 per rank)
+        assert st["gathers"] == {"warmup": 1, "timed": 1} and len(st["gathered_bytes_per_rank"]) == 2
     else:
         assert "strong_1024" not in j
 

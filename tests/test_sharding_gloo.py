@@ -101,3 +101,43 @@ def test_two_rank_gloo_gather_equals_single_process(world, n_frames):
         assert np.array_equal(full.reshape(exp.shape), exp), rank     # every rank holds the whole job's output
         assert same
         assert abs(t - (0.5 + world - 1)) < 1e-9                      # max over ranks
+
+
+def _bytes_worker(rank, world, port, sizes, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from imageflow_amd.sharding import gather_bytes_to_root
+        mine = torch.from_numpy(np.random.default_rng(900 + rank).integers(0, 256, sizes[rank], dtype=np.uint8))
+        got_sizes, parts = gather_bytes_to_root(mine, 0)
+        out = torch.empty(sum(sizes) + 7, dtype=torch.uint8)             # ... and into a caller's buffer
+        got_sizes2, parts2 = gather_bytes_to_root(mine, 0, out=out if rank == 0 else None)
+        ok = got_sizes == list(sizes) == got_sizes2
+        if rank == 0:
+            for r in range(world):
+                exp = np.random.default_rng(900 + r).integers(0, 256, sizes[r], dtype=np.uint8)
+                ok = ok and np.array_equal(parts[r].numpy(), exp) and np.array_equal(parts2[r].numpy(), exp)
+            ok = ok and (sizes[0] == 0 or parts2[0].data_ptr() == out.data_ptr())
+        else:
+            ok = ok and parts is None and parts2 is None
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes", [(1000, 37), (0, 4096), (16, 0, 100001), (5, 5, 5)])
+def test_gather_of_variable_length_messages_to_the_root(sizes):
+    """The cfg3 job's final gather ships FILES: every rank one message of its own length (also an empty one)."""
+    world = len(sizes)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bytes_worker, args=(r, world, port, sizes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results), results
