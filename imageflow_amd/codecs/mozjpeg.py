@@ -133,7 +133,7 @@ class JpegEntropyStage:
         L = _bind()
         n = coef[0].shape[0]
         if file_pitch is None:
-            file_pitch = files.shape[1] if files is not None else self.max_file_bytes
+            file_pitch = files.shape[1] if files is not None else (self.max_file_bytes + 15) // 16 * 16
         if files is None:
             files = torch.empty((n, file_pitch), dtype=torch.uint8, device=self.device)
         lengths = torch.zeros(n, dtype=torch.int32, device=self.device)

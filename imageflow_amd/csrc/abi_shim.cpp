@@ -29,10 +29,12 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/imageflow_abi_subset.h"
 #include "../../include/imageflow_hip.h"
+#include "common.hpp"           // the library's per-job memory cache and thread stream (devmem.cpp)
 
 namespace {
 
@@ -263,14 +265,50 @@ int parse_filter(const JVal* v, int dflt) {                      // imageflow_ty
 // A decoded JPEG whose pixel stage has not run: when the frame's one consumer is a resample, decode and resample run as ONE
 // device call (ifhip_jpeg_decode_resample_batch_device: no decoded BGRA bitmap in HBM); any other consumer gets the bitmap
 // through Job::dev(), which runs the pixel stage then.
+// ---- the stream of a job ------------------------------------------------------------------------------------------------
+// One Context per thread (imageflow_abi/src/lib.rs:20-27): every job runs on a stream of its own (non-blocking: nothing a
+// job does waits for another thread's job), leased from a pool for the duration of one send_json; device memory comes from
+// the library's size-class cache (devmem.cpp) and goes back without a driver call.  Every node ends with a wait for the
+// job's stream, so whatever a job frees is idle (ifhip::QuiescedScope around the whole job).
+std::mutex g_stream_mu;
+std::vector<hipStream_t> g_stream_pool;
+thread_local hipStream_t t_job_stream = nullptr;          // the stream of the job this thread is running (null outside a job)
+struct StreamLease {
+    hipStream_t st = nullptr;
+    StreamLease() {
+        {
+            std::lock_guard<std::mutex> lk(g_stream_mu);
+            if (!g_stream_pool.empty()) { st = g_stream_pool.back(); g_stream_pool.pop_back(); }
+        }
+        if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }   // (no device: the null stream, the first GPU call reports)
+        t_job_stream = st;
+        ifhip_set_thread_stream(st);
+    }
+    ~StreamLease() {
+        t_job_stream = nullptr;
+        ifhip_set_thread_stream(nullptr);
+        if (!st) return;
+        (void)hipStreamSynchronize(st);
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        g_stream_pool.push_back(st);
+    }
+};
+// Before anything of a job goes back to the cache: the job's stream -- the only one its blocks were ever used on -- is idle.
+void quiesce() {
+    if (t_job_stream && hipStreamQuery(t_job_stream) != hipSuccess) (void)hipStreamSynchronize(t_job_stream);
+    (void)hipGetLastError();
+}
+hipError_t job_malloc(void** p, size_t bytes) { return static_cast<hipError_t>(ifhip::cached_malloc(p, bytes)); }
+void job_free(void* p) { if (p) { quiesce(); (void)ifhip::cached_free(p); } }
+
 struct PendingJpeg {
     ifhip_jpeg_stage* st = nullptr;
     int16_t* coef[3] = {nullptr, nullptr, nullptr};
     uint16_t* d_qt = nullptr;
     ~PendingJpeg() {
-        if (st) ifhip_jpeg_stage_destroy(st);
-        for (int16_t* p : coef) if (p) (void)hipFree(p);
-        if (d_qt) (void)hipFree(d_qt);
+        if (st) { quiesce(); ifhip_jpeg_stage_destroy(st); }
+        for (int16_t* p : coef) job_free(p);
+        job_free(d_qt);
     }
 };
 struct Frame {                                   // graphics/bitmaps.rs Bitmap: BGRA8, 64-byte row stride
@@ -281,7 +319,7 @@ struct Frame {                                   // graphics/bitmaps.rs Bitmap: 
     uint32_t matte = 0;
     std::unique_ptr<PendingJpeg> pending;
     size_t bytes() const { return static_cast<size_t>(h) * stride; }
-    ~Frame() { if (d) (void)hipFree(d); }
+    ~Frame() { job_free(d); }
 };
 using FramePtr = std::shared_ptr<Frame>;
 
@@ -426,6 +464,43 @@ struct ResampleHints {                                                        //
     enum SWhen { kSAlways, kSDown, kSUp, kSSizeDiffers } sharpen_when = kSAlways;
 };
 
+// Resample plans (contribution tables of one shape on the device, immutable, thread-safe) are shared by all jobs of the
+// process: a service resizes to a handful of sizes, and a plan costs a dozen uploads.  Least recently used of 256 goes.
+struct PlanKey {
+    int device; uint32_t in_w, in_h, w, h; int filter; uint32_t sharpen_bits;
+    bool operator<(const PlanKey& o) const {
+        return std::tie(device, in_w, in_h, w, h, filter, sharpen_bits) < std::tie(o.device, o.in_w, o.in_h, o.w, o.h, o.filter, o.sharpen_bits);
+    }
+};
+std::mutex g_plan_mu;
+std::map<PlanKey, std::pair<std::shared_ptr<ifhip_resample_plan>, uint64_t>> g_plans;
+uint64_t g_plan_clock = 0;
+std::shared_ptr<ifhip_resample_plan> shared_plan(uint32_t in_w, uint32_t in_h, uint32_t w, uint32_t h, int filter, float sharpen) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint32_t bits;
+    std::memcpy(&bits, &sharpen, 4);
+    const PlanKey key{dev, in_w, in_h, w, h, filter, bits};
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        auto it = g_plans.find(key);
+        if (it != g_plans.end()) { it->second.second = ++g_plan_clock; return it->second.first; }
+    }
+    ifhip_resample_plan* raw = nullptr;
+    check(ifhip_resample_plan_create(&raw, in_w, in_h, w, h, filter, sharpen));
+    // (a plan dropped from the cache while a job still holds it is destroyed by that job's thread, behind its stream's wait;
+    // one dropped with no holder was last used by a job that has ended: plain destroy)
+    std::shared_ptr<ifhip_resample_plan> sp(raw, [](ifhip_resample_plan* q) { quiesce(); ifhip_resample_plan_destroy(q); });
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (g_plans.size() >= 256) {
+        auto victim = g_plans.begin();
+        for (auto it = g_plans.begin(); it != g_plans.end(); ++it) if (it->second.second < victim->second.second) victim = it;
+        g_plans.erase(victim);
+    }
+    auto ins = g_plans.emplace(key, std::make_pair(sp, ++g_plan_clock));
+    return ins.first->second.first;
+}
+
 struct Job {
     imageflow_context* c;
     std::vector<EncodeRecord> encodes;
@@ -445,7 +520,7 @@ struct Job {
     struct Timed {
         Job* j; const char* name; std::chrono::steady_clock::time_point t0; hipEvent_t e0 = nullptr, e1 = nullptr;
         Timed(Job* job, const char* n) : j(job), name(n), t0(std::chrono::steady_clock::now()) {
-            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, nullptr) != hipSuccess) {
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, t_job_stream) != hipSuccess) {
                 (void)hipGetLastError();
                 if (e0) (void)hipEventDestroy(e0);
                 if (e1) (void)hipEventDestroy(e1);
@@ -455,7 +530,7 @@ struct Job {
         ~Timed() {
             float ms = 0.f;
             if (e0) {
-                if (hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+                if (hipEventRecord(e1, t_job_stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
                 (void)hipEventDestroy(e0);
                 (void)hipEventDestroy(e1);
             }
@@ -471,11 +546,11 @@ struct Job {
         auto f = std::make_shared<Frame>();
         f->w = w; f->h = h; f->stride = ifhip_stride_for_width(w); f->alpha = alpha;
         if (f->stride == 0) raise(kArgumentInvalid, "InvalidArgument: Bitmap width %u has no 32-bit stride", w);
-        hip_check(hipMalloc(reinterpret_cast<void**>(&f->d), f->bytes() + 64), "hipMalloc(frame)");
-        if (zero) hip_check(hipMemsetAsync(f->d, 0, f->bytes() + 64, nullptr), "hipMemset(frame)");
+        hip_check(job_malloc(reinterpret_cast<void**>(&f->d), f->bytes() + 64), "hipMalloc(frame)");
+        if (zero) hip_check(hipMemsetAsync(f->d, 0, f->bytes() + 64, t_job_stream), "hipMemset(frame)");
         if (fill_color32 >> 24) {                    // create_canvas.rs:77-103 / bitmaps.rs:829-837: matte canvases start filled
             f->compose = IFHIP_BLEND_WITH_MATTE; f->matte = fill_color32;
-            check(ifhip_fill_rect_batch_device(f->d, f->bytes(), 1, w, h, f->stride, IFHIP_REPLACE_SELF, 0, 0, w, h, fill_color32, nullptr));
+            check(ifhip_fill_rect_batch_device(f->d, f->bytes(), 1, w, h, f->stride, IFHIP_REPLACE_SELF, 0, 0, w, h, fill_color32, t_job_stream));
         }
         return f;
     }
@@ -483,11 +558,11 @@ struct Job {
     uint8_t* dev(const FramePtr& f) {
         if (f->pending) {
             uint8_t* d = nullptr;                                    // the frame takes the bitmap only once it holds the pixels:
-            hip_check(hipMalloc(reinterpret_cast<void**>(&d), f->bytes() + 64), "hipMalloc(frame)");     // a failed stage leaves
-            struct Guard { uint8_t* p; ~Guard() { if (p) (void)hipFree(p); } } g{d};                     // `pending` and no buffer
+            hip_check(job_malloc(reinterpret_cast<void**>(&d), f->bytes() + 64), "hipMalloc(frame)");     // a failed stage leaves
+            struct Guard { uint8_t* p; ~Guard() { job_free(p); } } g{d};                                  // `pending` and no buffer
             PendingJpeg& p = *f->pending;
-            check(ifhip_jpeg_idct_color_batch_device(p.st, p.coef[0], p.coef[1], p.coef[2], p.d_qt, 1, d, f->bytes(), f->stride, nullptr));
-            hip_check(hipStreamSynchronize(nullptr), "decode");
+            check(ifhip_jpeg_idct_color_batch_device(p.st, p.coef[0], p.coef[1], p.coef[2], p.d_qt, 1, d, f->bytes(), f->stride, t_job_stream));
+            hip_check(hipStreamSynchronize(t_job_stream), "decode");
             f->d = d; g.p = nullptr;
             f->pending.reset();
         }
@@ -496,7 +571,7 @@ struct Job {
     bool lazy_decode = false;                                        // the decode node being run has exactly one consumer
     FramePtr clone(const FramePtr& in) {                              // flow/nodes/clone_crop_fill_expand.rs:140-175
         FramePtr c2 = new_frame(in->w, in->h, in->alpha, 0, false);
-        hip_check(hipMemcpyAsync(c2->d, dev(in), in->bytes(), hipMemcpyDeviceToDevice, nullptr), "clone");
+        hip_check(hipMemcpyAsync(c2->d, dev(in), in->bytes(), hipMemcpyDeviceToDevice, t_job_stream), "clone");
         c2->compose = in->compose; c2->matte = in->matte;
         return c2;
     }
@@ -558,7 +633,8 @@ struct Job {
                 raise(kImageMalformed, "ImageMalformed: raw BGRA container header does not match its length");
             check_size(sec.max_decode_size, "max_decode_size", w, h);
             FramePtr f = new_frame(w, h, hdr[3] != 0, 0, true);
-            hip_check(hipMemcpy2D(f->d, f->stride, in.in + kRawHeader, stride, w * 4ull, h, hipMemcpyHostToDevice), "upload(raw frame)");
+            hip_check(hipMemcpy2DAsync(f->d, f->stride, in.in + kRawHeader, stride, w * 4ull, h, hipMemcpyHostToDevice, t_job_stream), "upload(raw frame)");
+            hip_check(hipStreamSynchronize(t_job_stream), "upload(raw frame)");
             decodes.push_back({io_id, w, h, "application/x-imageflow-bgra", "ifbgra"});
             return f;
         }
@@ -576,7 +652,7 @@ struct Job {
         if (rc == IFHIP_METHOD_NOT_IMPLEMENTED)
             raise(kImageTypeNotSupported, "ImageTypeNotSupported: %s (baseline sequential JPEG only; keep other files on libjpeg)", ifhip_last_error_message());
         check(rc);
-        struct EntGuard { ifhip_jpeg_entropy* e; ~EntGuard() { ifhip_jpeg_entropy_destroy(e); } } eg{ent};
+        struct EntGuard { ifhip_jpeg_entropy* e; ~EntGuard() { quiesce(); ifhip_jpeg_entropy_destroy(e); } } eg{ent};
         uint32_t w = 0, h = 0, bw[3] = {0, 0, 0}, bh[3] = {0, 0, 0}, nsub = 0, nseg = 0;
         int ncomp = 0;
         uint8_t hs[3] = {1, 1, 1}, vs[3] = {1, 1, 1};
@@ -589,18 +665,18 @@ struct Job {
                 if ((static_cast<uint64_t>(w) * i + 7) / 8 >= hint_w && (static_cast<uint64_t>(h) * i + 7) / 8 >= hint_h) { scale = i; break; }
             }
         int16_t* coef[3] = {nullptr, nullptr, nullptr};
-        struct CoefGuard { int16_t** p; ~CoefGuard() { for (int i = 0; i < 3; ++i) if (p[i]) (void)hipFree(p[i]); } } cg{coef};
+        struct CoefGuard { int16_t** p; ~CoefGuard() { for (int i = 0; i < 3; ++i) job_free(p[i]); } } cg{coef};
         for (int k = 0; k < 3; ++k)
-            hip_check(hipMalloc(reinterpret_cast<void**>(&coef[k]), std::max<size_t>(1, static_cast<size_t>(bw[k]) * bh[k]) * 128), "hipMalloc(coefficients)");
+            hip_check(job_malloc(reinterpret_cast<void**>(&coef[k]), std::max<size_t>(1, static_cast<size_t>(bw[k]) * bh[k]) * 128), "hipMalloc(coefficients)");
         poll_cancel();                                               // the decoder's cancellation point (mozjpeg_decoder.rs:346-362 loop)
         uint32_t rounds = 0;
-        check(ifhip_jpeg_entropy_decode_device(ent, coef[0], coef[1], coef[2], &rounds, nullptr));
+        check(ifhip_jpeg_entropy_decode_device(ent, coef[0], coef[1], coef[2], &rounds, t_job_stream));
         uint16_t qt[192];
         check(ifhip_jpeg_entropy_quant_tables(ent, qt));
         uint16_t* d_qt = nullptr;
-        hip_check(hipMalloc(reinterpret_cast<void**>(&d_qt), sizeof qt), "hipMalloc(qt)");
-        struct QtGuard { uint16_t* p; ~QtGuard() { if (p) (void)hipFree(p); } } qg{d_qt};
-        hip_check(hipMemcpy(d_qt, qt, static_cast<size_t>(ncomp) * 128, hipMemcpyHostToDevice), "upload(qt)");
+        hip_check(job_malloc(reinterpret_cast<void**>(&d_qt), sizeof qt), "hipMalloc(qt)");
+        struct QtGuard { uint16_t* p; ~QtGuard() { job_free(p); } } qg{d_qt};
+        hip_check(static_cast<hipError_t>(ifhip::copy_to_device(d_qt, qt, static_cast<size_t>(ncomp) * 128)), "upload(qt)");
         ifhip_jpeg_stage* st = nullptr;
         const bool spatial = scale < 8 && luma_spatial;
         check(ifhip_jpeg_stage_create(&st, w, h, ncomp, hs, vs, scale, spatial ? 1 : 0, spatial && luma_srgb ? 1 : 0, 1));
@@ -688,19 +764,18 @@ struct Job {
         if (canvas->compose == IFHIP_REPLACE_SELF && compose) canvas->compose = IFHIP_BLEND_WITH_SELF;                 // :284-286
         if (canvas->compose == IFHIP_BLEND_WITH_MATTE && !compose && canvas->alpha) canvas->compose = IFHIP_REPLACE_SELF;   // :287-292
         poll_cancel();
-        ifhip_resample_plan* plan = nullptr;
-        check(ifhip_resample_plan_create(&plan, in->w, in->h, w, h, filter, sharpen));
-        struct PlanGuard { ifhip_resample_plan* p; ~PlanGuard() { ifhip_resample_plan_destroy(p); } } pg{plan};
+        const std::shared_ptr<ifhip_resample_plan> plan_ref = shared_plan(in->w, in->h, w, h, filter, sharpen);
+        ifhip_resample_plan* plan = plan_ref.get();
         if (in->pending) {                            // MzDec::read_frame + scale_and_render as one device call (mozjpeg_decoder.rs:346-362 -> :304-313)
             PendingJpeg& pj = *in->pending;
             int fused_call = 0;
             check(ifhip_jpeg_decode_resample_batch_device(pj.st, pj.coef[0], pj.coef[1], pj.coef[2], pj.d_qt, 1, plan, dev(canvas), canvas->bytes(), canvas->w,
-                                                          canvas->h, canvas->stride, x, y, hi.space, canvas->compose, canvas->matte, &fused_call, nullptr));
+                                                          canvas->h, canvas->stride, x, y, hi.space, canvas->compose, canvas->matte, &fused_call, t_job_stream));
             if (fused_call) c->fused_decode_resamples.fetch_add(1, std::memory_order_relaxed);
         } else
         check(ifhip_scale_and_render_batch_device(plan, in->d, in->bytes(), in->stride, in->alpha ? 1 : 0, 1, dev(canvas), canvas->bytes(),
-                                                  canvas->w, canvas->h, canvas->stride, x, y, hi.space, canvas->compose, canvas->matte, nullptr, -1, nullptr));
-        hip_check(hipStreamSynchronize(nullptr), "draw_image_exact");
+                                                  canvas->w, canvas->h, canvas->stride, x, y, hi.space, canvas->compose, canvas->matte, nullptr, -1, t_job_stream));
+        hip_check(hipStreamSynchronize(t_job_stream), "draw_image_exact");
         canvas->compose = IFHIP_BLEND_WITH_SELF;                                                                       // :314
     }
 
@@ -853,7 +928,7 @@ struct Job {
             const JVal* m = classic->get("matte");
             const uint32_t matte = m && !m->is_null() ? parse_color(m, "encode.preset.libjpeg_turbo.matte") : 0xFFFFFFFFu;   // :88-92
             if (shared && f->alpha) f = clone(f);
-            check(ifhip_apply_matte_batch_device(dev(f), f->bytes(), 1, f->w, f->h, f->stride, f->alpha ? 1 : 0, matte, nullptr));
+            check(ifhip_apply_matte_batch_device(dev(f), f->bytes(), 1, f->w, f->h, f->stride, f->alpha ? 1 : 0, matte, t_job_stream));
             f->alpha = false;                                                            // :94 set_alpha_meaningful(false)
             const uint8_t hs[3] = {2, 1, 1}, vs[3] = {2, 1, 1};
             uint16_t qt2[2][64], qt3[3][64];
@@ -868,11 +943,11 @@ struct Job {
             for (int k = 0; k < 3; ++k) off[k + 1] = off[k] + static_cast<size_t>(bw[k]) * bh[k] * 64u;
             int16_t* d_coef = nullptr;
             uint16_t* d_qt = nullptr;
-            hip_check(hipMalloc(reinterpret_cast<void**>(&d_coef), off[3] * 2u + 384u), "hipMalloc(coefficients)");
-            std::unique_ptr<int16_t, void (*)(int16_t*)> coef_guard(d_coef, [](int16_t* p) { (void)hipFree(p); });
+            hip_check(job_malloc(reinterpret_cast<void**>(&d_coef), off[3] * 2u + 384u), "hipMalloc(coefficients)");
+            std::unique_ptr<int16_t, void (*)(int16_t*)> coef_guard(d_coef, [](int16_t* p) { job_free(p); });
             d_qt = reinterpret_cast<uint16_t*>(d_coef + off[3]);
-            hip_check(hipMemcpy(d_qt, qt3, 384, hipMemcpyHostToDevice), "upload(quant tables)");
-            check(ifhip_jpeg_forward_batch_device(st, dev(f), f->bytes(), f->stride, d_qt, 1, d_coef + off[0], d_coef + off[1], d_coef + off[2], nullptr));
+            hip_check(static_cast<hipError_t>(ifhip::copy_to_device(d_qt, qt3, 384)), "upload(quant tables)");
+            check(ifhip_jpeg_forward_batch_device(st, dev(f), f->bytes(), f->stride, d_qt, 1, d_coef + off[0], d_coef + off[1], d_coef + off[2], t_job_stream));
             poll_cancel();
             if (write_flags == 0) {
                 // the preset's default (baseline, Annex K tables): the device entropy coder -- only the file leaves the device.
@@ -884,20 +959,20 @@ struct Job {
                     // stage that cannot be allocated is not the job's failure: the host writer below codes the same file.
                     ifhip_jpeg_enc_stage* es = nullptr;
                     if (ifhip_jpeg_enc_stage_create(&es, f->w, f->h, 3, hs, vs, bw, bh, 1, scan_cap) != IFHIP_OK) break;
-                    std::unique_ptr<ifhip_jpeg_enc_stage, void (*)(ifhip_jpeg_enc_stage*)> es_guard(es, ifhip_jpeg_enc_stage_destroy);
+                    std::unique_ptr<ifhip_jpeg_enc_stage, void (*)(ifhip_jpeg_enc_stage*)> es_guard(es, [](ifhip_jpeg_enc_stage* q) { quiesce(); ifhip_jpeg_enc_stage_destroy(q); });
                     const size_t pitch = ifhip_jpeg_enc_stage_max_file_bytes(es);
                     uint8_t* d_file = nullptr;
-                    if (hipMalloc(reinterpret_cast<void**>(&d_file), pitch + 16u) != hipSuccess) { (void)hipGetLastError(); break; }
-                    std::unique_ptr<uint8_t, void (*)(uint8_t*)> file_guard(d_file, [](uint8_t* p) { (void)hipFree(p); });
+                    if (job_malloc(reinterpret_cast<void**>(&d_file), pitch + 16u) != hipSuccess) break;
+                    std::unique_ptr<uint8_t, void (*)(uint8_t*)> file_guard(d_file, [](uint8_t* p) { job_free(p); });
                     uint32_t* d_len = reinterpret_cast<uint32_t*>(d_file + ((pitch + 3u) & ~static_cast<size_t>(3u)));   // length, status behind the file
-                    check(ifhip_jpeg_encode_batch_device(es, d_coef + off[0], d_coef + off[1], d_coef + off[2], quality, 1, d_file, pitch, d_len, d_len + 1, nullptr));
+                    check(ifhip_jpeg_encode_batch_device(es, d_coef + off[0], d_coef + off[1], d_coef + off[2], quality, 1, d_file, pitch, d_len, d_len + 1, t_job_stream));
                     uint32_t len_status[2] = {0, 0};
-                    hip_check(hipMemcpy(len_status, d_len, 8, hipMemcpyDeviceToHost), "download(file length)");
+                    hip_check(static_cast<hipError_t>(ifhip::copy_to_host(len_status, d_len, 8)), "download(file length)");
                     if (len_status[1] & IFHIP_ENC_BAD_COEFFICIENT)
                         raise(kArgumentInvalid, "InvalidArgument: coefficient out of range for 8-bit JPEG (more than 11 DC / 10 AC magnitude bits)");
                     if (len_status[1] != 0) continue;
                     o.owned.assign(len_status[0], 0);
-                    hip_check(hipMemcpy(o.owned.data(), d_file, len_status[0], hipMemcpyDeviceToHost), "download(file)");
+                    hip_check(static_cast<hipError_t>(ifhip::copy_to_host(o.owned.data(), d_file, len_status[0])), "download(file)");
                     o.written = true;
                     encodes.push_back({io_id, f->w, f->h, "image/jpeg", "jpg"});
                     c->device_coded_files.fetch_add(1, std::memory_order_relaxed);
@@ -905,7 +980,7 @@ struct Job {
                 }
             }                                                                            // (not coded on the device: the host writer)
             std::vector<int16_t> coef(off[3]);
-            hip_check(hipMemcpy(coef.data(), d_coef, off[3] * 2u, hipMemcpyDeviceToHost), "download(coefficients)");
+            hip_check(static_cast<hipError_t>(ifhip::copy_to_host(coef.data(), d_coef, off[3] * 2u)), "download(coefficients)");
             size_t len = 0;
             o.owned.assign(std::max<size_t>(4096u, off[3]), 0);                          // a file is smaller than its coefficients: one pass
             int wrc = ifhip_jpeg_write(coef.data() + off[0], coef.data() + off[1], coef.data() + off[2], bw, bh, 3, hs, vs, f->w, f->h, quality, write_flags,
@@ -925,7 +1000,7 @@ struct Job {
         std::memcpy(o.owned.data(), kRawMagic, 8);
         const uint32_t hdr[4] = {f->w, f->h, f->stride, f->alpha ? 1u : 0u};
         std::memcpy(o.owned.data() + 8, hdr, 16);
-        hip_check(hipMemcpy(o.owned.data() + kRawHeader, dev(f), f->bytes(), hipMemcpyDeviceToHost), "download(frame)");
+        { uint8_t* src = dev(f); hip_check(static_cast<hipError_t>(ifhip::copy_to_host(o.owned.data() + kRawHeader, src, f->bytes())), "download(frame)"); }
         o.written = true;
         encodes.push_back({io_id, f->w, f->h, "application/x-imageflow-bgra", "ifbgra"});
     }
@@ -939,19 +1014,19 @@ struct Job {
                   canvas->w, canvas->h, in->w, in->h, fx, fy, w, h, x, y);
         int canvas_alpha = canvas->alpha ? 1 : 0;
         check(ifhip_copy_rect_batch_device(dev(in), in->bytes(), in->w, in->h, in->stride, in->alpha ? 1 : 0, dev(canvas), canvas->bytes(),
-                                           canvas->w, canvas->h, canvas->stride, &canvas_alpha, fx, fy, x, y, w, h, 1, nullptr));
+                                           canvas->w, canvas->h, canvas->stride, &canvas_alpha, fx, fy, x, y, w, h, 1, t_job_stream));
         canvas->alpha = canvas_alpha != 0;
-        hip_check(hipStreamSynchronize(nullptr), "copy_rect");
+        hip_check(hipStreamSynchronize(t_job_stream), "copy_rect");
         return canvas;
     }
     FramePtr transposed(const FramePtr& in) {
         FramePtr t = new_frame(in->h, in->w, in->alpha, 0, true);
-        check(ifhip_transpose_batch_device(dev(in), in->bytes(), in->w, in->h, in->stride, t->d, t->bytes(), t->w, t->h, t->stride, 1, nullptr));
+        check(ifhip_transpose_batch_device(dev(in), in->bytes(), in->w, in->h, in->stride, t->d, t->bytes(), t->w, t->h, t->stride, 1, t_job_stream));
         return t;
     }
     FramePtr flip(const FramePtr& in, bool vertical) {
-        check(vertical ? ifhip_flip_vertical_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, nullptr)
-                       : ifhip_flip_horizontal_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, nullptr));
+        check(vertical ? ifhip_flip_vertical_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, t_job_stream)
+                       : ifhip_flip_horizontal_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, t_job_stream));
         return in;
     }
     // ApplyOrientationDef::expand (flow/nodes/rotate_flip_transpose.rs:44-66): the EXIF flag as flips and a transpose
@@ -979,7 +1054,7 @@ struct Job {
     }
     // ColorMatrixSrgbMutDef::mutate (flow/nodes/color.rs:20-38)
     FramePtr color_matrix(const FramePtr& in, const float m[25]) {
-        check(ifhip_apply_color_matrix_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, m, nullptr));
+        check(ifhip_apply_color_matrix_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, m, t_job_stream));
         in->compose = IFHIP_BLEND_WITH_SELF;
         return in;
     }
@@ -1007,7 +1082,7 @@ struct Job {
             std::memcpy(m, v, sizeof v);
         } else raise(kInvalidJson, "InvalidJson: unknown color_filter_srgb '%s'", name.c_str());
         if (name == "alpha" && !in->alpha) {                                          // EnableTransparency (enable_transparency.rs:68-95)
-            check(ifhip_normalize_unused_alpha_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, 0, nullptr));
+            check(ifhip_normalize_unused_alpha_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, 0, t_job_stream));
             in->alpha = true;
         }
         return color_matrix(in, m);
@@ -1584,6 +1659,9 @@ const struct imageflow_json_response* imageflow_context_send_json(struct imagefl
         if (json_buffer_size > 64u * 1024u * 1024u) raise(kArgumentInvalid, "SizeLimitExceeded: JSON payload exceeds max_json_bytes");   // ExecutionSecurity::max_json_bytes
         const JVal root = parse_json(json_buffer, json_buffer_size);
         if (root.t != JVal::Obj) raise(kInvalidJson, "InvalidJson: the message must be an object");
+        // the job's stream and the promise its frees rest on (every release is preceded by quiesce())
+        StreamLease lease;
+        ifhip::QuiescedScope quiet;
         Job job{c};
         job.poll_cancel();
         if (tell) {                                                  // v1/tell_decoder {io_id, command} (json/endpoints/v1.rs:365-371)

@@ -12,6 +12,28 @@ namespace ifhip {
 int fail(int status, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 const char* last_error();
 
+// ---- memory and stream of one job's objects (devmem.cpp) ---------------------------------------------------------------
+// Size-class caches in front of hipMalloc / hipHostMalloc: plans, stages, entropy handles and frames are created and
+// destroyed once per JOB, and neither call may cost a driver round trip (or hipFree's wait for the whole device) there.
+// Return values are hipError_t as int (this header stays free of hip_runtime.h).  cached_free waits for the device like
+// hipFree unless the caller holds a QuiescedScope: "the stream my work ran on has been synchronised".
+int cached_malloc(void** out, size_t bytes);
+int cached_free(void* p);
+int cached_host_malloc(void** out, size_t bytes);       // pinned, portable
+int cached_host_free(void* p);
+void quiesced_enter();
+void quiesced_leave();
+struct QuiescedScope { QuiescedScope() { quiesced_enter(); } ~QuiescedScope() { quiesced_leave(); } };
+// The stream a thread's create paths upload / clear on (ifhip_set_thread_stream; default: the null stream), and copies on it
+// that are complete on return.
+void* thread_stream();
+int copy_to_device(void* dst, const void* src, size_t bytes);
+int copy_to_host(void* dst, const void* src, size_t bytes);
+int zero_device(void* dst, size_t bytes);
+int require_gfx950(int* device_out);                  // IFHIP_OK and the current device, or GpuUnavailable (asked of the driver once)
+#define IFHIP_DMALLOC(pp, n) static_cast<hipError_t>(::ifhip::cached_malloc(reinterpret_cast<void**>(pp), (n)))
+#define IFHIP_DFREE(p) static_cast<hipError_t>(::ifhip::cached_free(p))
+
 // Development switches (tests and tools/ only).  The library never reads the environment: a switch exists only after
 // ifhip_debug_set(key, value) (include/imageflow_hip.h); unset -> nullptr.  One relaxed atomic load when none is set.
 const char* debug_switch(const char* key);

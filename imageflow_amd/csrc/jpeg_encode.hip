@@ -380,9 +380,9 @@ struct ifhip_jpeg_enc_stage {
     uint8_t* d_header = nullptr;
     uint8_t* h_header = nullptr;    // pinned
     ~ifhip_jpeg_enc_stage() {
-        (void)hipFree(d_tabs); (void)hipFree(d_nbits); (void)hipFree(d_wg_bits); (void)hipFree(d_tot_bits); (void)hipFree(d_words);
-        (void)hipFree(d_ff); (void)hipFree(d_tot_ff); (void)hipFree(d_status); (void)hipFree(d_header);
-        if (h_header) (void)hipHostFree(h_header);
+        (void)IFHIP_DFREE(d_tabs); (void)IFHIP_DFREE(d_nbits); (void)IFHIP_DFREE(d_wg_bits); (void)IFHIP_DFREE(d_tot_bits); (void)IFHIP_DFREE(d_words);
+        (void)IFHIP_DFREE(d_ff); (void)IFHIP_DFREE(d_tot_ff); (void)IFHIP_DFREE(d_status); (void)IFHIP_DFREE(d_header);
+        if (h_header) (void)cached_host_free(h_header);
     }
 };
 
@@ -467,28 +467,23 @@ int ifhip_jpeg_enc_stage_create(ifhip_jpeg_enc_stage** stage, uint32_t width, ui
     cap = (cap + kEncChunkBytes - 1u) / kEncChunkBytes * kEncChunkBytes + kEncChunkBytes;      // whole chunks, one to spare
     s->cap_words = static_cast<size_t>(cap / 4u);
     s->max_chunks = static_cast<uint32_t>(cap / kEncChunkBytes);
-    if (hipGetDevice(&s->device) != hipSuccess)
-        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device; this library has no CPU path");
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: device %d is %s, this library is built for gfx950 only", s->device, prop.gcnArchName);
+    if (int arc = require_gfx950(&s->device)) return arc;
     s->max_images = max_images;
     const size_t n = max_images;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_tabs), 4096));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_nbits), n * s->g.nblocks * sizeof(uint16_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_wg_bits), n * s->n_wg * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_tot_bits), n * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_words), n * s->cap_words * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_ff), n * s->max_chunks * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_tot_ff), n * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_status), n * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_header), kHeaderCap));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_header), kHeaderCap, hipHostMallocDefault));
+    HIP_TRY(IFHIP_DMALLOC(&s->d_tabs, 4096));
+    HIP_TRY(IFHIP_DMALLOC(&s->d_nbits, n * s->g.nblocks * sizeof(uint16_t)));
+    HIP_TRY(IFHIP_DMALLOC(&s->d_wg_bits, n * s->n_wg * sizeof(uint32_t)));
+    HIP_TRY(IFHIP_DMALLOC(&s->d_tot_bits, n * sizeof(uint32_t)));
+    HIP_TRY(IFHIP_DMALLOC(&s->d_words, n * s->cap_words * sizeof(uint32_t)));
+    HIP_TRY(IFHIP_DMALLOC(&s->d_ff, n * s->max_chunks * sizeof(uint32_t)));
+    HIP_TRY(IFHIP_DMALLOC(&s->d_tot_ff, n * sizeof(uint32_t)));
+    HIP_TRY(IFHIP_DMALLOC(&s->d_status, n * sizeof(uint32_t)));
+    HIP_TRY(IFHIP_DMALLOC(&s->d_header, kHeaderCap));
+    HIP_TRY(static_cast<hipError_t>(cached_host_malloc(reinterpret_cast<void**>(&s->h_header), kHeaderCap)));
     uint32_t tabs[4][256];
     jpeg_std_encode_tables(tabs);
-    HIP_TRY(hipMemcpy(s->d_tabs, tabs, sizeof tabs, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(s->d_words, 0, n * s->cap_words * sizeof(uint32_t)));       // the stuffing pass keeps it zero from here on
+    HIP_TRY(static_cast<hipError_t>(copy_to_device(s->d_tabs, tabs, sizeof tabs)));
+    HIP_TRY(static_cast<hipError_t>(zero_device(s->d_words, n * s->cap_words * sizeof(uint32_t))));       // the stuffing pass keeps it zero from here on
     *stage = s.release();
     return IFHIP_OK;
 }

@@ -1061,36 +1061,13 @@ uint32_t unstuff_scan(const uint8_t* d, size_t len, const ParsedJpeg& P, std::ve
 // Pinned staging for the packed scans, kept between calls (a service decodes batch after batch): pageable memory costs a
 // page fault per 4 KiB on first touch and a bounce copy on upload -- together more than the GPU needs for the decode.
 namespace {
-struct PinnedPool {
-    std::mutex mu;
-    void* ptr = nullptr;
-    size_t cap = 0;
-    bool busy = false;
-} g_staging;
-
-struct StagingLease {                    // the pool's buffer if it is free, a private pinned allocation otherwise
-    void* ptr = nullptr;
-    bool pooled = false;
+struct StagingLease {                    // a pinned buffer from the library's cache (devmem.cpp): threads preparing batches at
+    void* ptr = nullptr;                 // the same time each get their own, none allocates in the steady state
     int acquire(size_t bytes) {
-        {
-            std::lock_guard<std::mutex> lk(g_staging.mu);
-            if (!g_staging.busy) {
-                if (g_staging.cap < bytes) {
-                    if (g_staging.ptr) (void)hipHostFree(g_staging.ptr);
-                    g_staging.ptr = nullptr; g_staging.cap = 0;
-                    const size_t want = bytes + bytes / 4;
-                    if (hipHostMalloc(&g_staging.ptr, want, hipHostMallocPortable) == hipSuccess) g_staging.cap = want;
-                }
-                if (g_staging.cap >= bytes) { g_staging.busy = true; ptr = g_staging.ptr; pooled = true; return IFHIP_OK; }
-            }
-        }
-        HIP_TRY(hipHostMalloc(&ptr, bytes, hipHostMallocPortable));
+        HIP_TRY(static_cast<hipError_t>(cached_host_malloc(&ptr, bytes)));
         return IFHIP_OK;
     }
-    ~StagingLease() {
-        if (pooled) { std::lock_guard<std::mutex> lk(g_staging.mu); g_staging.busy = false; }
-        else if (ptr) (void)hipHostFree(ptr);
-    }
+    ~StagingLease() { if (ptr) (void)cached_host_free(ptr); }
 };
 }  // namespace
 
@@ -1103,17 +1080,17 @@ struct ifhip_jpeg_entropy {
     std::vector<void*> owned;
     uint32_t* h_flags = nullptr;                     // pinned copy of changed[16] + errors
     ~ifhip_jpeg_entropy() {
-        for (void* p : owned) if (p) (void)hipFree(p);
-        if (h_flags) (void)hipHostFree(h_flags);
+        for (void* p : owned) if (p) (void)IFHIP_DFREE(p);
+        if (h_flags) (void)cached_host_free(h_flags);
     }
 };
 
 template <typename T>
 static int dev_alloc(ifhip_jpeg_entropy* e, T** out, size_t count, const T* init = nullptr) {
     *out = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(out), std::max<size_t>(count, 1) * sizeof(T)));
+    HIP_TRY(IFHIP_DMALLOC(out, std::max<size_t>(count, 1) * sizeof(T)));
     e->owned.push_back(*out);
-    if (init && count) HIP_TRY(hipMemcpy(*out, init, count * sizeof(T), hipMemcpyHostToDevice));
+    if (init && count) HIP_TRY(static_cast<hipError_t>(copy_to_device(*out, init, count * sizeof(T))));
     return IFHIP_OK;
 }
 
@@ -1208,12 +1185,7 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     *out = nullptr;
     if (!files || !lengths || n_images == 0) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: empty batch");
     std::unique_ptr<ifhip_jpeg_entropy> e(new ifhip_jpeg_entropy);
-    if (hipGetDevice(&e->device) != hipSuccess)
-        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device; this library has no CPU path");
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, e->device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: device %d is %s, this library is built for gfx950 only", e->device, prop.gcnArchName);
+    if (int arc = require_gfx950(&e->device)) return arc;
     e->n_images = n_images;
     std::vector<Segment> segs;
     std::vector<uint32_t> sub_seg;
@@ -1378,7 +1350,7 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     if ((rc = dev_alloc<uint32_t>(e.get(), &a.changed, kFlagWords))) return rc;
     a.errors = a.changed + 16;
     a.unsettled = a.changed + 17;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_flags), kFlagWords * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(static_cast<hipError_t>(cached_host_malloc(reinterpret_cast<void**>(&e->h_flags), kFlagWords * sizeof(uint32_t))));
     if (timing)
         std::fprintf(stderr, "[ifhip entropy create] threads %u (hw %u): parse+unstuff %.2f ms, +pack %.2f ms, +upload/alloc %.2f ms\n",
                      n_threads, hw, t_parse, t_pack, ms_since(t_start));

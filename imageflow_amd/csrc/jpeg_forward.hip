@@ -321,12 +321,7 @@ int ifhip_jpeg_fwd_stage_create(ifhip_jpeg_fwd_stage** stage, uint32_t width, ui
     int rc = make_fwd_geom(width, height, h_samp, v_samp, &s->g);
     if (rc) return rc;
     if (s->g.bh[0] > 65535u) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: more than 65535 block rows per launch");
-    if (hipGetDevice(&s->device) != hipSuccess)
-        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device; this library has no CPU path");
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: device %d is %s, this library is built for gfx950 only", s->device, prop.gcnArchName);
+    if (int arc = require_gfx950(&s->device)) return arc;
     s->max_images = max_images;
     *stage = s.release();
     return IFHIP_OK;

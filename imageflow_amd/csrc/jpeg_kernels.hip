@@ -1069,7 +1069,7 @@ struct ifhip_jpeg_stage {
     JpegGeom g;
     uint32_t max_images = 0;
     uint8_t* planes[3] = {nullptr, nullptr, nullptr};
-    ~ifhip_jpeg_stage() { for (auto* p : planes) if (p) (void)hipFree(p); }
+    ~ifhip_jpeg_stage() { for (auto* p : planes) if (p) (void)IFHIP_DFREE(p); }
 };
 
 
@@ -1145,15 +1145,10 @@ int ifhip_jpeg_stage_create(ifhip_jpeg_stage** stage, uint32_t width, uint32_t h
     int rc = make_geom(width, height, n_components, h_samp, v_samp, scale_num, luma_spatial, luma_srgb, &s->g);
     if (rc) return rc;
     if (s->g.height > 65535u || max_images > 65535u) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: more than 65535 rows/images per launch");
-    if (hipGetDevice(&s->device) != hipSuccess)
-        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: no HIP device; this library has no CPU path");
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(IFHIP_GPU_UNAVAILABLE, "GpuUnavailable: device %d is %s, this library is built for gfx950 only", s->device, prop.gcnArchName);
+    if (int arc = require_gfx950(&s->device)) return arc;
     s->max_images = max_images;
     for (int c = 0; c < n_components; ++c)
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->planes[c]), static_cast<size_t>(s->g.pw[c]) * s->g.ph[c] * max_images + 16));
+        HIP_TRY(IFHIP_DMALLOC(&s->planes[c], static_cast<size_t>(s->g.pw[c]) * s->g.ph[c] * max_images + 16));
     *stage = s.release();
     return IFHIP_OK;
 }

@@ -74,6 +74,10 @@ IFHIP_API const char* ifhip_version(void);
 IFHIP_API int ifhip_debug_set(const char* key, const char* value);
 IFHIP_API int ifhip_device_count(void);            /* number of usable gfx950 devices (0 if none)          */
 IFHIP_API int ifhip_set_device(int ordinal);       /* one process per GPU: call once with LOCAL_RANK       */
+/* The HIP stream on which THIS THREAD's create calls (plans, stages, entropy handles) upload and clear what they need;
+ * default: the null stream.  A host that runs one job per thread (one imageflow Context per thread, lib.rs:20-27) sets its
+ * own stream here and passes the same stream to the *_device calls, so that jobs of different threads overlap. */
+IFHIP_API void ifhip_set_thread_stream(void* hip_stream);
 
 /* ---- host-side tables (no GPU needed) ---------------------------------------------------------------- */
 /* graphics/bitmaps.rs:712-740 Bitmap::get_stride::<u8>(w, h, 4, 64); 0 when the row does not fit 32 bits. */

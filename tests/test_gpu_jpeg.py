@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 from imageflow_amd.codecs.mozjpeg_decoder import JpegPixelStage, jpeg_idct_color_host  # noqa: E402
 from imageflow_amd.errors import ErrorKind, FlowError  # noqa: E402
 from oracle import oracle as O  # noqa: E402
+from tests import util as U  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -268,7 +269,7 @@ def test_decode_resample_one_call_at_4k_equals_the_oracle_chain(scale_num, ow, o
     exp_dec = O.jpeg_idct_color_scaled(j, scale_num, 2)
     exp = np.zeros((1, th, U.stride_for(tw)), np.uint8)
     U.oracle_render(exp_dec[None], ow, oh, exp, tw, th, 0, 0, tw, th)
-    assert np.array_equal(one[0], exp[0])
+    assert np.array_equal(one[0][:, :4 * tw], exp[0][:, :4 * tw])       # (the row padding keeps the canvases' 0x5A fill)
 
 
 def test_decode_resample_rejects_a_plan_of_another_size():

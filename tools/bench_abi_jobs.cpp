@@ -1,0 +1,166 @@
+// bench_abi_jobs.cpp -- jobs per second through the OUTER boundary (libimageflow C ABI, include/imageflow_abi_subset.h):
+// T host threads, one imageflow_context per job as the reference's guidance has it ("separate contexts per thread",
+// imageflow_abi/src/lib.rs:20-27), every job = add_input_buffer + add_output_buffer + send_json("v1/execute") +
+// take_output_buffer + buffer_free + context_destroy on a file already in host memory.  Reference bench shape:
+// imageflow_core/benches/bench_graphics.rs:382-456 (one pipeline per iteration, wall clock over many).
+//
+//   bench_abi_jobs <libimageflow_hip.so> <file.jpg> <job.json> <threads> <seconds> [warmup_jobs_per_thread]
+//
+// Prints one JSON line: jobs/s, per-node means from the job results' `performance` block (wall and gpu microseconds),
+// output bytes per job.  Development tool (tools/), built by tools/bench_abi_jobs.py with g++.
+#include <dlfcn.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct Api {
+    void* (*context_create)(uint32_t, uint32_t);
+    void (*context_destroy)(void*);
+    bool (*add_input_buffer)(void*, int32_t, const uint8_t*, size_t, int);
+    bool (*add_output_buffer)(void*, int32_t);
+    const void* (*send_json)(void*, const char*, const uint8_t*, size_t);
+    bool (*response_read)(void*, const void*, int64_t*, const uint8_t**, size_t*);
+    bool (*response_destroy)(void*, const void*);
+    bool (*take_output_buffer)(void*, int32_t, const uint8_t**, size_t*);
+    bool (*buffer_free)(const uint8_t*, size_t);
+    bool (*error_write)(void*, char*, size_t, size_t*);
+};
+
+template <typename F>
+static void load(void* h, const char* name, F* f) {
+    *f = reinterpret_cast<F>(dlsym(h, name));
+    if (!*f) { std::fprintf(stderr, "missing symbol %s\n", name); std::exit(2); }
+}
+
+static std::vector<uint8_t> read_file(const char* path) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { std::fprintf(stderr, "cannot open %s\n", path); std::exit(2); }
+    std::vector<uint8_t> d;
+    uint8_t buf[1 << 16];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
+    std::fclose(f);
+    return d;
+}
+
+struct NodeSum { double wall_us = 0, gpu_us = 0; uint64_t n = 0; };
+
+// {"wall_microseconds": W, "name": "N", "gpu_microseconds": G} entries of performance.frames[].nodes[]
+static void scan_nodes(const char* s, size_t len, std::map<std::string, NodeSum>* sums) {
+    const std::string t(s, len);
+    size_t at = t.find("\"nodes\"");
+    if (at == std::string::npos) return;
+    const size_t end = t.find(']', at);
+    while (true) {
+        const size_t w = t.find("\"wall_microseconds\": ", at);
+        if (w == std::string::npos || w > end) break;
+        const size_t nm = t.find("\"name\": \"", w), g = t.find("\"gpu_microseconds\": ", w);
+        if (nm == std::string::npos || g == std::string::npos) break;
+        const size_t nq = t.find('"', nm + 9);
+        NodeSum& ns = (*sums)[t.substr(nm + 9, nq - nm - 9)];
+        ns.wall_us += std::atof(t.c_str() + w + 21);
+        ns.gpu_us += std::atof(t.c_str() + g + 20);
+        ns.n += 1;
+        at = g + 20;
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc < 6) { std::fprintf(stderr, "usage: %s lib file job.json threads seconds [warmup]\n", argv[0]); return 2; }
+    void* h = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { std::fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+    Api a;
+    load(h, "imageflow_context_create", &a.context_create);
+    load(h, "imageflow_context_destroy", &a.context_destroy);
+    load(h, "imageflow_context_add_input_buffer", &a.add_input_buffer);
+    load(h, "imageflow_context_add_output_buffer", &a.add_output_buffer);
+    load(h, "imageflow_context_send_json", &a.send_json);
+    load(h, "imageflow_json_response_read", &a.response_read);
+    load(h, "imageflow_json_response_destroy", &a.response_destroy);
+    load(h, "imageflow_context_take_output_buffer", &a.take_output_buffer);
+    load(h, "imageflow_buffer_free", &a.buffer_free);
+    load(h, "imageflow_context_error_write_to_buffer", &a.error_write);
+    const std::vector<uint8_t> file = read_file(argv[2]), job = read_file(argv[3]);
+    const int threads = std::atoi(argv[4]);
+    const double seconds = std::atof(argv[5]);
+    const int warmup = argc > 6 ? std::atoi(argv[6]) : 3;
+
+    std::atomic<bool> go{false}, stop{false};
+    std::atomic<uint64_t> jobs{0}, out_bytes{0}, failures{0};
+    std::mutex mu;
+    std::map<std::string, NodeSum> sums;
+    std::string first_error;
+
+    auto one_job = [&](std::map<std::string, NodeSum>* local, bool count) {
+        void* c = a.context_create(3, 2);
+        if (!c) { failures++; return; }
+        bool ok = a.add_input_buffer(c, 0, file.data(), file.size(), 1) && a.add_output_buffer(c, 1);
+        const void* r = ok ? a.send_json(c, "v1/execute", job.data(), job.size()) : nullptr;
+        int64_t status = 0;
+        const uint8_t* body = nullptr;
+        size_t blen = 0;
+        if (r && a.response_read(c, r, &status, &body, &blen) && status == 200) {
+            if (count) scan_nodes(reinterpret_cast<const char*>(body), blen, local);
+            const uint8_t* ob = nullptr;
+            size_t on = 0;
+            if (a.take_output_buffer(c, 1, &ob, &on)) {
+                if (count) { out_bytes += on; jobs++; }
+                a.buffer_free(ob, on);
+            } else failures++;
+        } else {
+            failures++;
+            std::lock_guard<std::mutex> lk(mu);
+            if (first_error.empty()) {
+                char buf[600];
+                size_t n = 0;
+                if (a.error_write(c, buf, sizeof buf, &n)) first_error.assign(buf, std::min(n, sizeof buf - 1));
+                else if (body) first_error.assign(reinterpret_cast<const char*>(body), std::min<size_t>(blen, 500));
+            }
+        }
+        if (r) a.response_destroy(c, r);
+        a.context_destroy(c);
+    };
+
+    std::vector<std::thread> pool;
+    std::atomic<int> ready{0};
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&] {
+            std::map<std::string, NodeSum> local;
+            for (int i = 0; i < warmup; ++i) one_job(&local, false);
+            ready++;
+            while (!go.load()) std::this_thread::yield();
+            while (!stop.load()) one_job(&local, true);
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto& kv : local) { NodeSum& s = sums[kv.first]; s.wall_us += kv.second.wall_us; s.gpu_us += kv.second.gpu_us; s.n += kv.second.n; }
+        });
+    while (ready.load() < threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    const auto t0 = std::chrono::steady_clock::now();
+    go = true;
+    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+    stop = true;
+    for (auto& th : pool) th.join();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const uint64_t n = jobs.load();
+    std::string nodes = "{";
+    for (auto& kv : sums)
+        nodes += (nodes.size() > 1 ? ", \"" : "\"") + kv.first + "\": {\"per_job\": " + std::to_string(static_cast<double>(kv.second.n) / std::max<uint64_t>(n, 1)) +
+                 ", \"wall_us\": " + std::to_string(kv.second.wall_us / std::max<uint64_t>(kv.second.n, 1)) +
+                 ", \"gpu_us\": " + std::to_string(kv.second.gpu_us / std::max<uint64_t>(kv.second.n, 1)) + "}";
+    nodes += "}";
+    for (char& ch : first_error) if (ch == '"' || ch == '\n' || ch == '\\') ch = ' ';
+    std::printf("{\"threads\": %d, \"seconds\": %.3f, \"jobs\": %llu, \"jobs_per_s\": %.1f, \"ms_per_job_per_thread\": %.3f, \"failures\": %llu, "
+                "\"output_bytes_per_job\": %llu, \"input_bytes\": %zu, \"nodes\": %s, \"first_error\": \"%s\"}\n",
+                threads, dt, static_cast<unsigned long long>(n), n / dt, n ? dt * threads / n * 1e3 : 0.0,
+                static_cast<unsigned long long>(failures.load()), static_cast<unsigned long long>(n ? out_bytes.load() / n : 0), file.size(),
+                nodes.c_str(), first_error.c_str());
+    return failures.load() ? 1 : 0;
+}
