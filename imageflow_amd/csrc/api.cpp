@@ -106,7 +106,7 @@ template <typename T>
 int upload(const std::vector<T>& v, T** out) {
     *out = nullptr;
     if (v.empty()) return IFHIP_OK;
-    HIP_TRY(IFHIP_DMALLOC(out, v.size() * sizeof(T)));
+    HIP_TRY(DEV_MALLOC(out, v.size() * sizeof(T)));
     HIP_TRY(static_cast<hipError_t>(copy_to_device(*out, v.data(), v.size() * sizeof(T))));
     return IFHIP_OK;
 }
@@ -153,10 +153,10 @@ struct ifhip_resample_plan {
         for (void* p : {(void*)d_v_left, (void*)d_v_count, (void*)d_v_off, (void*)d_h_left, (void*)d_h_count,
                         (void*)d_h_off, (void*)d_v_w, (void*)d_h_w, (void*)d_h_wu, (void*)d_h_meta, (void*)d_h_wg, (void*)d_h_meta2, (void*)sets[0].d_strips,
                         (void*)sets[1].d_strips})
-            if (p) (void)IFHIP_DFREE(p);
+            if (p) (void)DEV_FREE(p);
         for (auto& kv : schedules) {
-            if (kv.second.steps) (void)IFHIP_DFREE(kv.second.steps);
-            if (kv.second.band_begin) (void)IFHIP_DFREE(kv.second.band_begin);
+            if (kv.second.steps) (void)DEV_FREE(kv.second.steps);
+            if (kv.second.band_begin) (void)DEV_FREE(kv.second.band_begin);
         }
     }
 };
@@ -233,7 +233,7 @@ int get_schedule(const ifhip_resample_plan* p, uint32_t n_bands, int group, int 
         int rc = upload(s.steps, &d.steps);
         if (rc) return rc;
         rc = upload(s.band_begin, &d.band_begin);
-        if (rc) { (void)IFHIP_DFREE(d.steps); return rc; }
+        if (rc) { (void)DEV_FREE(d.steps); return rc; }
         it = p->schedules.emplace(key, d).first;
     }
     *out = it->second;

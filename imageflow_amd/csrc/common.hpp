@@ -31,8 +31,8 @@ int copy_to_device(void* dst, const void* src, size_t bytes);
 int copy_to_host(void* dst, const void* src, size_t bytes);
 int zero_device(void* dst, size_t bytes);
 int require_gfx950(int* device_out);                  // IFHIP_OK and the current device, or GpuUnavailable (asked of the driver once)
-#define IFHIP_DMALLOC(pp, n) static_cast<hipError_t>(::ifhip::cached_malloc(reinterpret_cast<void**>(pp), (n)))
-#define IFHIP_DFREE(p) static_cast<hipError_t>(::ifhip::cached_free(p))
+#define DEV_MALLOC(pp, n) static_cast<hipError_t>(::ifhip::cached_malloc(reinterpret_cast<void**>(pp), (n)))
+#define DEV_FREE(p) static_cast<hipError_t>(::ifhip::cached_free(p))
 
 // Development switches (tests and tools/ only).  The library never reads the environment: a switch exists only after
 // ifhip_debug_set(key, value) (include/imageflow_hip.h); unset -> nullptr.  One relaxed atomic load when none is set.

@@ -380,8 +380,8 @@ struct ifhip_jpeg_enc_stage {
     uint8_t* d_header = nullptr;
     uint8_t* h_header = nullptr;    // pinned
     ~ifhip_jpeg_enc_stage() {
-        (void)IFHIP_DFREE(d_tabs); (void)IFHIP_DFREE(d_nbits); (void)IFHIP_DFREE(d_wg_bits); (void)IFHIP_DFREE(d_tot_bits); (void)IFHIP_DFREE(d_words);
-        (void)IFHIP_DFREE(d_ff); (void)IFHIP_DFREE(d_tot_ff); (void)IFHIP_DFREE(d_status); (void)IFHIP_DFREE(d_header);
+        (void)DEV_FREE(d_tabs); (void)DEV_FREE(d_nbits); (void)DEV_FREE(d_wg_bits); (void)DEV_FREE(d_tot_bits); (void)DEV_FREE(d_words);
+        (void)DEV_FREE(d_ff); (void)DEV_FREE(d_tot_ff); (void)DEV_FREE(d_status); (void)DEV_FREE(d_header);
         if (h_header) (void)cached_host_free(h_header);
     }
 };
@@ -470,15 +470,15 @@ int ifhip_jpeg_enc_stage_create(ifhip_jpeg_enc_stage** stage, uint32_t width, ui
     if (int arc = require_gfx950(&s->device)) return arc;
     s->max_images = max_images;
     const size_t n = max_images;
-    HIP_TRY(IFHIP_DMALLOC(&s->d_tabs, 4096));
-    HIP_TRY(IFHIP_DMALLOC(&s->d_nbits, n * s->g.nblocks * sizeof(uint16_t)));
-    HIP_TRY(IFHIP_DMALLOC(&s->d_wg_bits, n * s->n_wg * sizeof(uint32_t)));
-    HIP_TRY(IFHIP_DMALLOC(&s->d_tot_bits, n * sizeof(uint32_t)));
-    HIP_TRY(IFHIP_DMALLOC(&s->d_words, n * s->cap_words * sizeof(uint32_t)));
-    HIP_TRY(IFHIP_DMALLOC(&s->d_ff, n * s->max_chunks * sizeof(uint32_t)));
-    HIP_TRY(IFHIP_DMALLOC(&s->d_tot_ff, n * sizeof(uint32_t)));
-    HIP_TRY(IFHIP_DMALLOC(&s->d_status, n * sizeof(uint32_t)));
-    HIP_TRY(IFHIP_DMALLOC(&s->d_header, kHeaderCap));
+    HIP_TRY(DEV_MALLOC(&s->d_tabs, 4096));
+    HIP_TRY(DEV_MALLOC(&s->d_nbits, n * s->g.nblocks * sizeof(uint16_t)));
+    HIP_TRY(DEV_MALLOC(&s->d_wg_bits, n * s->n_wg * sizeof(uint32_t)));
+    HIP_TRY(DEV_MALLOC(&s->d_tot_bits, n * sizeof(uint32_t)));
+    HIP_TRY(DEV_MALLOC(&s->d_words, n * s->cap_words * sizeof(uint32_t)));
+    HIP_TRY(DEV_MALLOC(&s->d_ff, n * s->max_chunks * sizeof(uint32_t)));
+    HIP_TRY(DEV_MALLOC(&s->d_tot_ff, n * sizeof(uint32_t)));
+    HIP_TRY(DEV_MALLOC(&s->d_status, n * sizeof(uint32_t)));
+    HIP_TRY(DEV_MALLOC(&s->d_header, kHeaderCap));
     HIP_TRY(static_cast<hipError_t>(cached_host_malloc(reinterpret_cast<void**>(&s->h_header), kHeaderCap)));
     uint32_t tabs[4][256];
     jpeg_std_encode_tables(tabs);

@@ -1080,7 +1080,7 @@ struct ifhip_jpeg_entropy {
     std::vector<void*> owned;
     uint32_t* h_flags = nullptr;                     // pinned copy of changed[16] + errors
     ~ifhip_jpeg_entropy() {
-        for (void* p : owned) if (p) (void)IFHIP_DFREE(p);
+        for (void* p : owned) if (p) (void)DEV_FREE(p);
         if (h_flags) (void)cached_host_free(h_flags);
     }
 };
@@ -1088,7 +1088,7 @@ struct ifhip_jpeg_entropy {
 template <typename T>
 static int dev_alloc(ifhip_jpeg_entropy* e, T** out, size_t count, const T* init = nullptr) {
     *out = nullptr;
-    HIP_TRY(IFHIP_DMALLOC(out, std::max<size_t>(count, 1) * sizeof(T)));
+    HIP_TRY(DEV_MALLOC(out, std::max<size_t>(count, 1) * sizeof(T)));
     e->owned.push_back(*out);
     if (init && count) HIP_TRY(static_cast<hipError_t>(copy_to_device(*out, init, count * sizeof(T))));
     return IFHIP_OK;

@@ -1069,7 +1069,7 @@ struct ifhip_jpeg_stage {
     JpegGeom g;
     uint32_t max_images = 0;
     uint8_t* planes[3] = {nullptr, nullptr, nullptr};
-    ~ifhip_jpeg_stage() { for (auto* p : planes) if (p) (void)IFHIP_DFREE(p); }
+    ~ifhip_jpeg_stage() { for (auto* p : planes) if (p) (void)DEV_FREE(p); }
 };
 
 
@@ -1148,7 +1148,7 @@ int ifhip_jpeg_stage_create(ifhip_jpeg_stage** stage, uint32_t width, uint32_t h
     if (int arc = require_gfx950(&s->device)) return arc;
     s->max_images = max_images;
     for (int c = 0; c < n_components; ++c)
-        HIP_TRY(IFHIP_DMALLOC(&s->planes[c], static_cast<size_t>(s->g.pw[c]) * s->g.ph[c] * max_images + 16));
+        HIP_TRY(DEV_MALLOC(&s->planes[c], static_cast<size_t>(s->g.pw[c]) * s->g.ph[c] * max_images + 16));
     *stage = s.release();
     return IFHIP_OK;
 }

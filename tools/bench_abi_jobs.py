@@ -87,10 +87,12 @@ def main():
     ap.add_argument("--jobs", default="cfg1,cfg4")
     ap.add_argument("--lib", default=os.environ.get("IFHIP_LIB") or os.path.join(ROOT, "imageflow_amd", "lib", "libimageflow_hip.so"))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--hw-queues", default="", help="GPU_MAX_HW_QUEUES for the harness process (the HIP runtime's own switch: how many "
+                                                      "hardware queues its streams are spread over; default 4)")
     args = ap.parse_args()
     data = make_file()
     out = {"file": {"w": 3840, "h": 2160, "bytes": len(data), "what": "4:2:0 q85 baseline, gradient + texture + noise (Pillow)"},
-           "host_cores": os.cpu_count(), "lib": os.path.basename(args.lib), "runs": []}
+           "host_cores": os.cpu_count(), "lib": os.path.basename(args.lib), "GPU_MAX_HW_QUEUES": args.hw_queues or "default", "runs": []}
     with tempfile.TemporaryDirectory() as tmp:
         exe = build_harness(tmp)
         fpath = os.path.join(tmp, "in.jpg")
@@ -99,7 +101,10 @@ def main():
             jpath = os.path.join(tmp, kind + ".json")
             open(jpath, "w").write(json.dumps(JOBS[kind]))
             for t in [int(v) for v in args.threads.split(",")]:
-                r = subprocess.run([exe, args.lib, fpath, jpath, str(t), str(args.seconds)], capture_output=True, text=True, timeout=600)
+                env = dict(os.environ)
+                if args.hw_queues:
+                    env["GPU_MAX_HW_QUEUES"] = args.hw_queues
+                r = subprocess.run([exe, args.lib, fpath, jpath, str(t), str(args.seconds)], capture_output=True, text=True, timeout=600, env=env)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 rec = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-500:]}
                 rec["job"] = kind
