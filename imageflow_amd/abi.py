@@ -62,6 +62,8 @@ def _bind():
     L.ifhip_shim_fused_decode_resamples.restype = C.c_int64
     L.ifhip_shim_device_coded_files.argtypes = [vp]
     L.ifhip_shim_device_coded_files.restype = C.c_int64
+    L.ifhip_shim_coalesced_decodes.argtypes = [vp]
+    L.ifhip_shim_coalesced_decodes.restype = C.c_int64
     L.imageflow_context_memory_allocate.argtypes = [vp, C.c_size_t, C.c_char_p, C.c_int32]
     L.imageflow_context_memory_allocate.restype = vp
     L.imageflow_context_memory_free.argtypes = [vp, vp, C.c_char_p, C.c_int32]

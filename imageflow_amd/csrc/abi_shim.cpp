@@ -19,6 +19,7 @@
 #include <atomic>
 #include <chrono>
 #include <climits>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -301,14 +302,32 @@ void quiesce() {
 hipError_t job_malloc(void** p, size_t bytes) { return static_cast<hipError_t>(ifhip::cached_malloc(p, bytes)); }
 void job_free(void* p) { if (p) { quiesce(); (void)ifhip::cached_free(p); } }
 
+// The coefficient planes and quantisation tables of one entropy-decoded BATCH of files (one geometry): jobs of different
+// threads whose decodes were coalesced into one device call each hold a share and read their own image's part.
+struct DecodedBatch {
+    int16_t* coef[3] = {nullptr, nullptr, nullptr};      // [n][bh_c][bw_c][64]
+    size_t per_image[3] = {0, 0, 0};                     // int16 elements per image and component
+    uint16_t* d_qt = nullptr;                            // [n][3][64]
+    uint32_t w = 0, h = 0, bw[3] = {0, 0, 0}, bh[3] = {0, 0, 0};
+    int ncomp = 0;
+    uint8_t hs[3] = {1, 1, 1}, vs[3] = {1, 1, 1};
+    // the last share goes when its job ends -- every job waits for its own stream before it lets go (quiesce), the
+    // batch's decode itself was complete before any share was handed out
+    ~DecodedBatch() {
+        for (int16_t* p : coef) if (p) (void)ifhip::cached_free(p);
+        if (d_qt) (void)ifhip::cached_free(d_qt);
+    }
+};
 struct PendingJpeg {
     ifhip_jpeg_stage* st = nullptr;
-    int16_t* coef[3] = {nullptr, nullptr, nullptr};
+    int16_t* coef[3] = {nullptr, nullptr, nullptr};      // this image's planes inside `batch`
     uint16_t* d_qt = nullptr;
+    std::shared_ptr<DecodedBatch> batch;
     ~PendingJpeg() {
-        if (st) { quiesce(); ifhip_jpeg_stage_destroy(st); }
-        for (int16_t* p : coef) job_free(p);
-        job_free(d_qt);
+        quiesce();
+        if (st) ifhip_jpeg_stage_destroy(st);
+        ifhip::QuiescedScope q;                          // (a job thread has one already; a share that dies elsewhere: see above)
+        batch.reset();
     }
 };
 struct Frame {                                   // graphics/bitmaps.rs Bitmap: BGRA8, 64-byte row stride
@@ -381,6 +400,7 @@ struct imageflow_context {
     std::atomic<int64_t> poll_countdown{INT64_MAX};
     std::atomic<int64_t> fused_decode_resamples{0};
     std::atomic<int64_t> device_coded_files{0};          // JPEG outputs whose entropy coding ran on the device (diagnostic)
+    std::atomic<int64_t> coalesced_decodes{0};           // decodes of this context that shared their device call with another thread's job
     bool cancellation_requested() {
         if (cancel.load(std::memory_order_relaxed)) return true;
         if (poll_countdown.load(std::memory_order_relaxed) == INT64_MAX) return false;
@@ -463,6 +483,112 @@ struct ResampleHints {                                                        //
     enum When { kDefault, kSizeDiffers, kSizeDiffersOrSharpen, kAlways } resample_when = kDefault;
     enum SWhen { kSAlways, kSDown, kSUp, kSSizeDiffers } sharpen_when = kSAlways;
 };
+
+// ---- decodes of different threads as ONE device call ---------------------------------------------------------------------
+// A job decodes one file: 14 workgroups of the entropy kernels for a 4K JPEG, on a chip of 256 CUs, and the HIP runtime
+// runs the streams of a process on a handful of hardware queues -- measured through this ABI (round 4): 5 300 jobs/s at 16
+// threads and FEWER beyond, the GPU a fifth busy.  The entropy stage takes a batch of files of one geometry as cheaply as
+// one (ifhip_jpeg_entropy_create / _decode_device), so concurrent decodes are coalesced: the first thread to arrive leads,
+// gives the others a moment (only while other jobs are in flight at all), decodes everybody's file of its geometry in one
+// call on its own stream and hands each job its image's planes; the rest wait on a condition variable.  A batch that fails
+// (one damaged file) sends every member back to decode alone, so errors stay with the job that owns them.
+constexpr uint32_t kMaxCoalesce = 32;
+std::atomic<int> g_jobs_in_flight{0};
+struct DecodeRequest {
+    const uint8_t* file = nullptr;
+    size_t len = 0;
+    uint32_t w = 0, h = 0;
+    int ncomp = 0;
+    uint8_t hs[3] = {0, 0, 0}, vs[3] = {0, 0, 0};
+    // result
+    std::shared_ptr<DecodedBatch> batch;
+    uint32_t index = 0, batch_size = 0;
+    bool done = false, retry_alone = false;
+    bool same_geometry(const DecodeRequest& o) const {
+        return w == o.w && h == o.h && ncomp == o.ncomp && std::memcmp(hs, o.hs, 3) == 0 && std::memcmp(vs, o.vs, 3) == 0;
+    }
+};
+// one batch on the calling thread's job stream; throws FlowErr
+std::shared_ptr<DecodedBatch> decode_files(const std::vector<DecodeRequest*>& reqs) {
+    const uint32_t n = static_cast<uint32_t>(reqs.size());
+    std::vector<const uint8_t*> files(n);
+    std::vector<size_t> lens(n);
+    for (uint32_t i = 0; i < n; ++i) { files[i] = reqs[i]->file; lens[i] = reqs[i]->len; }
+    ifhip_jpeg_entropy* ent = nullptr;
+    const int rc = ifhip_jpeg_entropy_create(&ent, files.data(), lens.data(), n);
+    if (rc == IFHIP_METHOD_NOT_IMPLEMENTED)
+        raise(kImageTypeNotSupported, "ImageTypeNotSupported: %s (baseline sequential JPEG only; keep other files on libjpeg)", ifhip_last_error_message());
+    check(rc);
+    struct EntGuard { ifhip_jpeg_entropy* e; ~EntGuard() { quiesce(); ifhip_jpeg_entropy_destroy(e); } } eg{ent};
+    auto b = std::make_shared<DecodedBatch>();
+    uint32_t nsub = 0, nseg = 0;
+    check(ifhip_jpeg_entropy_info(ent, &b->w, &b->h, &b->ncomp, b->hs, b->vs, b->bw, b->bh, &nsub, &nseg));
+    for (int k = 0; k < 3; ++k) {
+        b->per_image[k] = static_cast<size_t>(b->bw[k]) * b->bh[k] * 64u;
+        hip_check(job_malloc(reinterpret_cast<void**>(&b->coef[k]), std::max<size_t>(1, b->per_image[k] * n) * 2u), "hipMalloc(coefficients)");
+    }
+    uint32_t rounds = 0;
+    check(ifhip_jpeg_entropy_decode_device(ent, b->coef[0], b->coef[1], b->coef[2], &rounds, t_job_stream));
+    std::vector<uint16_t> qt(static_cast<size_t>(n) * 192u);
+    check(ifhip_jpeg_entropy_quant_tables(ent, qt.data()));
+    hip_check(job_malloc(reinterpret_cast<void**>(&b->d_qt), qt.size() * 2u), "hipMalloc(qt)");
+    hip_check(static_cast<hipError_t>(ifhip::copy_to_device(b->d_qt, qt.data(), qt.size() * 2u)), "upload(qt)");
+    return b;
+}
+struct DecodeCoalescer {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<DecodeRequest*> queue;
+    bool leader_active = false;
+    // -> r.batch / r.index set, or r.retry_alone
+    void submit(DecodeRequest& r) {
+        std::unique_lock<std::mutex> lk(mu);
+        queue.push_back(&r);
+        cv.notify_all();                                             // (a leader gathering its batch counts arrivals)
+        for (;;) {
+            while (leader_active && !r.done) cv.wait(lk);
+            if (r.done) return;
+            leader_active = true;                                    // nobody leads: this thread does, for one batch
+            // the moment given to the others: only while other jobs are in flight at all (a lone caller pays nothing)
+            long window_us = g_jobs_in_flight.load(std::memory_order_relaxed) > 1 ? 120 : 0;
+            size_t wait_for = kMaxCoalesce;
+            if (const char* e = ifhip::debug_switch("coalesce_window_us")) window_us = std::atol(e);
+            if (const char* e = ifhip::debug_switch("coalesce_wait_for")) wait_for = static_cast<size_t>(std::max(1L, std::atol(e)));
+            if (window_us > 0) {
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us);
+                while (queue.size() < wait_for && cv.wait_until(lk, until) != std::cv_status::timeout) {}
+            }
+            // this thread's own request first, then whoever shares its geometry, in arrival order
+            std::vector<DecodeRequest*> mine{&r}, rest;
+            for (DecodeRequest* q : queue)
+                if (q != &r) (mine.size() < kMaxCoalesce && q->same_geometry(r) ? mine : rest).push_back(q);
+            queue.swap(rest);
+            lk.unlock();
+            std::shared_ptr<DecodedBatch> b;
+            bool failed = false;
+            try { b = decode_files(mine); } catch (const FlowErr&) { failed = true; } catch (const std::exception&) { failed = true; }
+            lk.lock();
+            for (size_t i = 0; i < mine.size(); ++i) {
+                DecodeRequest* q = mine[i];
+                if (failed) q->retry_alone = true;
+                else { q->batch = b; q->index = static_cast<uint32_t>(i); q->batch_size = static_cast<uint32_t>(mine.size()); }
+                q->done = true;
+            }
+            leader_active = false;
+            cv.notify_all();
+        }
+    }
+};
+DecodeCoalescer& coalescer_for_device() {
+    static std::mutex mu;
+    static std::map<int, DecodeCoalescer*> per_device;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    DecodeCoalescer*& c = per_device[dev];
+    if (!c) c = new DecodeCoalescer;
+    return *c;
+}
 
 // Resample plans (contribution tables of one shape on the device, immutable, thread-safe) are shared by all jobs of the
 // process: a service resizes to a handful of sizes, and a plan costs a dozen uploads.  Least recently used of 256 goes.
@@ -645,18 +771,30 @@ struct Job {
             image_size(io_id, &hw, &hh);
             check_size(sec.max_decode_size, "max_decode_size", hw, hh);
         }
-        ifhip_jpeg_entropy* ent = nullptr;
-        const uint8_t* files[1] = {in.in};
-        const size_t lens[1] = {in.in_len};
-        int rc = ifhip_jpeg_entropy_create(&ent, files, lens, 1);
-        if (rc == IFHIP_METHOD_NOT_IMPLEMENTED)
-            raise(kImageTypeNotSupported, "ImageTypeNotSupported: %s (baseline sequential JPEG only; keep other files on libjpeg)", ifhip_last_error_message());
-        check(rc);
-        struct EntGuard { ifhip_jpeg_entropy* e; ~EntGuard() { quiesce(); ifhip_jpeg_entropy_destroy(e); } } eg{ent};
-        uint32_t w = 0, h = 0, bw[3] = {0, 0, 0}, bh[3] = {0, 0, 0}, nsub = 0, nseg = 0;
-        int ncomp = 0;
-        uint8_t hs[3] = {1, 1, 1}, vs[3] = {1, 1, 1};
-        check(ifhip_jpeg_entropy_info(ent, &w, &h, &ncomp, hs, vs, bw, bh, &nsub, &nseg));
+        // the entropy stage: this file, together with whatever other threads' jobs want decoded right now (DecodeCoalescer)
+        DecodeRequest rq;
+        rq.file = in.in; rq.len = in.in_len;
+        {
+            uint32_t bw0[3], bh0[3], ri = 0;
+            uint16_t qt0[192];
+            const int prc = ifhip_jpeg_parse_headers(in.in, in.in_len, &rq.w, &rq.h, &rq.ncomp, rq.hs, rq.vs, bw0, bh0, qt0, &ri);
+            if (prc == IFHIP_METHOD_NOT_IMPLEMENTED)
+                raise(kImageTypeNotSupported, "ImageTypeNotSupported: %s (baseline sequential JPEG only; keep other files on libjpeg)", ifhip_last_error_message());
+            check(prc);
+        }
+        poll_cancel();                                               // the decoder's cancellation point (mozjpeg_decoder.rs:346-362 loop)
+        coalescer_for_device().submit(rq);
+        if (rq.retry_alone) {                                        // the shared call failed (somebody's file, maybe this one): alone, errors are this job's
+            std::vector<DecodeRequest*> one{&rq};
+            rq.batch = decode_files(one);
+            rq.index = 0; rq.batch_size = 1;
+        }
+        if (rq.batch_size > 1) c->coalesced_decodes.fetch_add(1, std::memory_order_relaxed);
+        const std::shared_ptr<DecodedBatch> batch = rq.batch;
+        const uint32_t w = batch->w, h = batch->h;
+        const int ncomp = batch->ncomp;
+        const uint8_t* hs = batch->hs;
+        const uint8_t* vs = batch->vs;
         // MzDec::apply_downscaling (mozjpeg_decoder.rs:588-618): smallest i/8 (7 skipped) that still covers the hint
         int scale = 8;
         if (hint_w > 0 && hint_h > 0)
@@ -664,26 +802,14 @@ struct Job {
                 if (i == 7) continue;
                 if ((static_cast<uint64_t>(w) * i + 7) / 8 >= hint_w && (static_cast<uint64_t>(h) * i + 7) / 8 >= hint_h) { scale = i; break; }
             }
-        int16_t* coef[3] = {nullptr, nullptr, nullptr};
-        struct CoefGuard { int16_t** p; ~CoefGuard() { for (int i = 0; i < 3; ++i) job_free(p[i]); } } cg{coef};
-        for (int k = 0; k < 3; ++k)
-            hip_check(job_malloc(reinterpret_cast<void**>(&coef[k]), std::max<size_t>(1, static_cast<size_t>(bw[k]) * bh[k]) * 128), "hipMalloc(coefficients)");
-        poll_cancel();                                               // the decoder's cancellation point (mozjpeg_decoder.rs:346-362 loop)
-        uint32_t rounds = 0;
-        check(ifhip_jpeg_entropy_decode_device(ent, coef[0], coef[1], coef[2], &rounds, t_job_stream));
-        uint16_t qt[192];
-        check(ifhip_jpeg_entropy_quant_tables(ent, qt));
-        uint16_t* d_qt = nullptr;
-        hip_check(job_malloc(reinterpret_cast<void**>(&d_qt), sizeof qt), "hipMalloc(qt)");
-        struct QtGuard { uint16_t* p; ~QtGuard() { job_free(p); } } qg{d_qt};
-        hip_check(static_cast<hipError_t>(ifhip::copy_to_device(d_qt, qt, static_cast<size_t>(ncomp) * 128)), "upload(qt)");
         ifhip_jpeg_stage* st = nullptr;
         const bool spatial = scale < 8 && luma_spatial;
         check(ifhip_jpeg_stage_create(&st, w, h, ncomp, hs, vs, scale, spatial ? 1 : 0, spatial && luma_srgb ? 1 : 0, 1));
-        auto pend = std::make_unique<PendingJpeg>();                                  // owns stage, coefficients, tables from here
+        auto pend = std::make_unique<PendingJpeg>();                                  // owns the stage and a share of the decoded batch
         pend->st = st;
-        for (int k = 0; k < 3; ++k) { pend->coef[k] = coef[k]; coef[k] = nullptr; }
-        pend->d_qt = d_qt; qg.p = nullptr;
+        pend->batch = batch;
+        for (int k = 0; k < 3; ++k) pend->coef[k] = batch->coef[k] + static_cast<size_t>(rq.index) * batch->per_image[k];
+        pend->d_qt = batch->d_qt + static_cast<size_t>(rq.index) * 192u;
         uint32_t ow = 0, oh = 0;
         check(ifhip_jpeg_stage_output_size(st, &ow, &oh));
         if (ow == 0 || oh == 0) raise(kArgumentInvalid, "InvalidArgument: Bitmap dimensions cannot be zero");
@@ -1553,6 +1679,10 @@ int64_t ifhip_shim_fused_decode_resamples(struct imageflow_context* c) {
     CTX_OR_ABORT(c);
     return c->fused_decode_resamples.load(std::memory_order_relaxed);
 }
+int64_t ifhip_shim_coalesced_decodes(struct imageflow_context* c) {
+    CTX_OR_ABORT(c);
+    return c->coalesced_decodes.load(std::memory_order_relaxed);
+}
 int64_t ifhip_shim_device_coded_files(struct imageflow_context* c) {
     CTX_OR_ABORT(c);
     return c->device_coded_files.load(std::memory_order_relaxed);
@@ -1662,6 +1792,7 @@ const struct imageflow_json_response* imageflow_context_send_json(struct imagefl
         // the job's stream and the promise its frees rest on (every release is preceded by quiesce())
         StreamLease lease;
         ifhip::QuiescedScope quiet;
+        struct InFlight { InFlight() { g_jobs_in_flight.fetch_add(1, std::memory_order_relaxed); } ~InFlight() { g_jobs_in_flight.fetch_sub(1, std::memory_order_relaxed); } } in_flight;
         Job job{c};
         job.poll_cancel();
         if (tell) {                                                  // v1/tell_decoder {io_id, command} (json/endpoints/v1.rs:365-371)

@@ -106,6 +106,9 @@ IMAGEFLOW_SHIM_API int64_t ifhip_shim_fused_decode_resamples(struct imageflow_co
 /* Diagnostic: how many JPEG outputs of this context's jobs were entropy-coded on the device (libjpeg_turbo preset without
  * progressive / optimize_huffman_coding: ifhip_jpeg_encode_batch_device; only the file is downloaded). */
 IMAGEFLOW_SHIM_API int64_t ifhip_shim_device_coded_files(struct imageflow_context *context);
+/* Diagnostic: how many decodes of this context's jobs shared their entropy-decode device call with the job of another
+ * thread (concurrent decodes of one geometry are coalesced into one batch; one context per thread, lib.rs:20-27). */
+IMAGEFLOW_SHIM_API int64_t ifhip_shim_coalesced_decodes(struct imageflow_context *context);
 
 #ifdef __cplusplus
 }

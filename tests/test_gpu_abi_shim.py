@@ -715,3 +715,76 @@ def test_exif_orientation_in_a_command_string_job():
     rot, rw, rh = _oracle_orient(O.jpeg_idct_color(j), 1600, 600, 6)
     assert (rw, rh) == (600, 1600)
     assert np.array_equal(rows, _oracle_resize(rot, 600, 1600, 100, 267, filter_id=2))
+
+
+# ---- decodes of different threads' jobs coalesced into one device call -------------------------------------------------
+def test_concurrent_jobs_share_one_entropy_decode_and_keep_their_own_bytes(debug_switch):
+    """Six threads, one context each (lib.rs:20-27), each a different 640x400 file through `command_string width=100`, started
+    together; the coalescer is told to wait for all six (a development switch: the product waits ~0.1 ms).  Every job's
+    output equals ITS file's oracle chain, and at least one decode shared its device call with another thread's."""
+    import threading
+    n = 6
+    debug_switch("coalesce_window_us", "2000000")
+    debug_switch("coalesce_wait_for", str(n))
+    files = [_jpeg(640, 400, seed=300 + i, quality=60 + 5 * i) for i in range(n)]          # same geometry, own tables and content
+    outs, shared, errs = [None] * n, [0] * n, []
+    gate = threading.Barrier(n)
+
+    def run(i):
+        try:
+            with Context() as c:
+                c.add_input_buffer(0, files[i])
+                c.add_output_buffer(1)
+                gate.wait()
+                _run(c, "v1/execute", {"framewise": {"steps": [{"command_string": {"kind": "ir4", "value": "width=100", "decode": 0, "encode": 1}}]}})
+                outs[i] = unpack_raw_bgra(c.get_output_buffer(1))
+                shared[i] = c.L.ifhip_shim_coalesced_decodes(c.p)
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+    th = [threading.Thread(target=run, args=(i,)) for i in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert sum(shared) >= 2, shared                                       # a batch has at least two members
+    for i in range(n):
+        rows, w, h, _ = outs[i]
+        j = O.jpeg_read_coefficients(files[i])
+        # width=100 on 640x400: target 100x63 (62.5 rounds up); pre-shrink min(6.4, 4.0) = 4 -> 2.1 / 4 -> hints 336x210 -> 5/8 = 400x250
+        small = O.jpeg_idct_color_scaled(j, 5, 2, general=True)
+        assert (w, h) == (100, 63)
+        assert np.array_equal(rows[:, :400], _oracle_resize(small, 400, 250, 100, 63, filter_id=2)[:, :400]), i
+
+
+def test_a_damaged_file_in_a_coalesced_batch_fails_alone(debug_switch):
+    """One of three concurrent jobs carries a truncated scan: its job reports the malformed image, the other two finish with
+    their own (correct) outputs."""
+    import threading
+    n = 3
+    debug_switch("coalesce_window_us", "2000000")
+    debug_switch("coalesce_wait_for", str(n))
+    files = [_jpeg(320, 240, seed=400 + i) for i in range(n)]
+    files[1] = files[1][: len(files[1]) // 2]                              # scan ends early
+    res = [None] * n
+    gate = threading.Barrier(n)
+
+    def run(i):
+        with Context() as c:
+            c.add_input_buffer(0, files[i])
+            c.add_output_buffer(1)
+            gate.wait()
+            status, r = c.send_json("v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"resample_2d": {"w": 80, "h": 60}},
+                                                                             {"encode": {"io_id": 1, "preset": "gif"}}]}})
+            res[i] = (status, r["message"] if status != 200 else unpack_raw_bgra(c.get_output_buffer(1)))
+    th = [threading.Thread(target=run, args=(i,)) for i in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert res[1][0] != 200 and "ImageMalformed" in res[1][1], res[1]
+    for i in (0, 2):
+        assert res[i][0] == 200
+        rows, w, h, _ = res[i][1]
+        full = O.jpeg_idct_color(O.jpeg_read_coefficients(files[i]))
+        assert np.array_equal(rows[:, :320], _oracle_resize(full, 320, 240, 80, 60, filter_id=2)[:, :320]), i
