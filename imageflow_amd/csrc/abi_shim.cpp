@@ -503,7 +503,7 @@ struct DecodeRequest {
     // result
     std::shared_ptr<DecodedBatch> batch;
     uint32_t index = 0, batch_size = 0;
-    bool done = false, retry_alone = false;
+    bool done = false, retry_alone = false, taken = false;      // taken: a leader is decoding it
     bool same_geometry(const DecodeRequest& o) const {
         return w == o.w && h == o.h && ncomp == o.ncomp && std::memcmp(hs, o.hs, 3) == 0 && std::memcmp(vs, o.vs, 3) == 0;
     }
@@ -546,7 +546,7 @@ struct DecodeCoalescer {
         queue.push_back(&r);
         cv.notify_all();                                             // (a leader gathering its batch counts arrivals)
         for (;;) {
-            while (leader_active && !r.done) cv.wait(lk);
+            while (!r.done && (leader_active || r.taken)) cv.wait(lk);
             if (r.done) return;
             leader_active = true;                                    // nobody leads: this thread does, for one batch
             // the moment given to the others: only while other jobs are in flight at all (a lone caller pays nothing)
@@ -563,6 +563,9 @@ struct DecodeCoalescer {
             for (DecodeRequest* q : queue)
                 if (q != &r) (mine.size() < kMaxCoalesce && q->same_geometry(r) ? mine : rest).push_back(q);
             queue.swap(rest);
+            for (DecodeRequest* q : mine) q->taken = true;
+            leader_active = false;                                   // leading = gathering: the next batch forms while this one decodes
+            cv.notify_all();
             lk.unlock();
             std::shared_ptr<DecodedBatch> b;
             bool failed = false;
@@ -574,7 +577,6 @@ struct DecodeCoalescer {
                 else { q->batch = b; q->index = static_cast<uint32_t>(i); q->batch_size = static_cast<uint32_t>(mine.size()); }
                 q->done = true;
             }
-            leader_active = false;
             cv.notify_all();
         }
     }

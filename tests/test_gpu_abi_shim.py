@@ -494,10 +494,10 @@ def test_job_with_cancellation_at_every_point():
 def test_cancellation_from_another_thread_while_a_job_runs():
     import threading
     src = U.random_frames(1, 2000, 1500, seed0=72, alpha=False)[0]
-    steps = [{"decode": {"io_id": 0}}] + [{"resample_2d": {"w": 1000 + (i % 2), "h": 750, "hints": {"resample_when": "always"}}} for i in range(400)]
-    with Context() as c:
+    steps = [{"decode": {"io_id": 0}}] + [{"resample_2d": {"w": 1000 + (i % 2), "h": 750, "hints": {"resample_when": "always"}}} for i in range(6000)]
+    with Context() as c:                                                      # (a step takes ~60 us since plans and device memory are cached)
         c.add_input_buffer(0, pack_raw_bgra(src, 2000, 1500, alpha_meaningful=False))
-        t = threading.Timer(0.05, c.request_cancellation)
+        t = threading.Timer(0.03, c.request_cancellation)
         t.start()
         status, r = c.send_json("v1/execute", {"framewise": {"steps": steps}})
         t.join()
