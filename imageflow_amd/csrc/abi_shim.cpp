@@ -495,8 +495,7 @@ struct ResampleHints {                                                        //
 constexpr uint32_t kMaxCoalesce = 32;
 std::atomic<int> g_jobs_in_flight{0};
 struct DecodeRequest {
-    const uint8_t* file = nullptr;
-    size_t len = 0;
+    ifhip_jpeg_prepared* prepared = nullptr;             // the job's file, prepared on the job's own thread
     uint32_t w = 0, h = 0;
     int ncomp = 0;
     uint8_t hs[3] = {0, 0, 0}, vs[3] = {0, 0, 0};
@@ -511,21 +510,19 @@ struct DecodeRequest {
 // one batch on the calling thread's job stream; throws FlowErr
 std::shared_ptr<DecodedBatch> decode_files(const std::vector<DecodeRequest*>& reqs) {
     const uint32_t n = static_cast<uint32_t>(reqs.size());
-    std::vector<const uint8_t*> files(n);
-    std::vector<size_t> lens(n);
-    for (uint32_t i = 0; i < n; ++i) { files[i] = reqs[i]->file; lens[i] = reqs[i]->len; }
+    std::vector<ifhip_jpeg_prepared*> files(n);
+    for (uint32_t i = 0; i < n; ++i) files[i] = reqs[i]->prepared;
     ifhip_jpeg_entropy* ent = nullptr;
-    const int rc = ifhip_jpeg_entropy_create(&ent, files.data(), lens.data(), n);
-    if (rc == IFHIP_METHOD_NOT_IMPLEMENTED)
-        raise(kImageTypeNotSupported, "ImageTypeNotSupported: %s (baseline sequential JPEG only; keep other files on libjpeg)", ifhip_last_error_message());
-    check(rc);
+    check(ifhip_jpeg_entropy_create_prepared(&ent, files.data(), n));
     struct EntGuard { ifhip_jpeg_entropy* e; ~EntGuard() { quiesce(); ifhip_jpeg_entropy_destroy(e); } } eg{ent};
     auto b = std::make_shared<DecodedBatch>();
     uint32_t nsub = 0, nseg = 0;
     check(ifhip_jpeg_entropy_info(ent, &b->w, &b->h, &b->ncomp, b->hs, b->vs, b->bw, b->bh, &nsub, &nseg));
+    uint32_t n_cap = 1;                                          // (batch sizes as powers of two: six size classes in the cache, not thirty-two)
+    while (n_cap < n) n_cap *= 2;
     for (int k = 0; k < 3; ++k) {
         b->per_image[k] = static_cast<size_t>(b->bw[k]) * b->bh[k] * 64u;
-        hip_check(job_malloc(reinterpret_cast<void**>(&b->coef[k]), std::max<size_t>(1, b->per_image[k] * n) * 2u), "hipMalloc(coefficients)");
+        hip_check(job_malloc(reinterpret_cast<void**>(&b->coef[k]), std::max<size_t>(1, b->per_image[k] * n_cap) * 2u), "hipMalloc(coefficients)");
     }
     uint32_t rounds = 0;
     check(ifhip_jpeg_entropy_decode_device(ent, b->coef[0], b->coef[1], b->coef[2], &rounds, t_job_stream));
@@ -775,15 +772,14 @@ struct Job {
         }
         // the entropy stage: this file, together with whatever other threads' jobs want decoded right now (DecodeCoalescer)
         DecodeRequest rq;
-        rq.file = in.in; rq.len = in.in_len;
         {
-            uint32_t bw0[3], bh0[3], ri = 0;
-            uint16_t qt0[192];
-            const int prc = ifhip_jpeg_parse_headers(in.in, in.in_len, &rq.w, &rq.h, &rq.ncomp, rq.hs, rq.vs, bw0, bh0, qt0, &ri);
+            const int prc = ifhip_jpeg_entropy_prepare(&rq.prepared, in.in, in.in_len);      // parse, un-stuff, pack, tables: on this job's thread
             if (prc == IFHIP_METHOD_NOT_IMPLEMENTED)
                 raise(kImageTypeNotSupported, "ImageTypeNotSupported: %s (baseline sequential JPEG only; keep other files on libjpeg)", ifhip_last_error_message());
             check(prc);
         }
+        struct PreparedGuard { ifhip_jpeg_prepared* p; ~PreparedGuard() { ifhip_jpeg_prepared_destroy(p); } } prepared_guard{rq.prepared};
+        check(ifhip_jpeg_prepared_info(rq.prepared, &rq.w, &rq.h, &rq.ncomp, rq.hs, rq.vs));
         poll_cancel();                                               // the decoder's cancellation point (mozjpeg_decoder.rs:346-362 loop)
         coalescer_for_device().submit(rq);
         if (rq.retry_alone) {                                        // the shared call failed (somebody's file, maybe this one): alone, errors are this job's

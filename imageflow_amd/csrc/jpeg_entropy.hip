@@ -1058,19 +1058,6 @@ uint32_t unstuff_scan(const uint8_t* d, size_t len, const ParsedJpeg& P, std::ve
 
 }  // namespace
 
-// Pinned staging for the packed scans, kept between calls (a service decodes batch after batch): pageable memory costs a
-// page fault per 4 KiB on first touch and a bounce copy on upload -- together more than the GPU needs for the decode.
-namespace {
-struct StagingLease {                    // a pinned buffer from the library's cache (devmem.cpp): threads preparing batches at
-    void* ptr = nullptr;                 // the same time each get their own, none allocates in the steady state
-    int acquire(size_t bytes) {
-        HIP_TRY(static_cast<hipError_t>(cached_host_malloc(&ptr, bytes)));
-        return IFHIP_OK;
-    }
-    ~StagingLease() { if (ptr) (void)cached_host_free(ptr); }
-};
-}  // namespace
-
 struct ifhip_jpeg_entropy {
     int device = -1;
     uint32_t n_images = 0;
@@ -1180,86 +1167,90 @@ int ifhip_jpeg_exif_orientation(const uint8_t* d, size_t len, int* flag) {
     return IFHIP_OK;
 }
 
-static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* files, const size_t* lengths, uint32_t n_images) {
-    if (!out) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null out-pointer");
-    *out = nullptr;
-    if (!files || !lengths || n_images == 0) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: empty batch");
+}  // extern "C"  (reopened below)
+
+// One file, prepared on the host by whoever owns it: parsed, its scan un-stuffed, cut at the restart markers and packed as
+// big-endian words (every segment padded to 1 024 bits) in PINNED memory, its decode tables derived.  A batch is then
+// assembled from n of these with no further pass over the data: n asynchronous uploads.  (A service that runs one job per
+// thread prepares each job's file on that job's thread -- imageflow_abi/src/lib.rs:20-27 -- and hands the handles of
+// whatever is waiting to ONE device call.)
+struct ifhip_jpeg_prepared {
+    ParsedJpeg P;
+    uint16_t qt[192];
+    std::vector<uint32_t> seg_mcu0, seg_mcus, seg_nsub, seg_first_word;      // per restart segment
+    std::vector<uint64_t> seg_bits;
+    uint32_t* words = nullptr;                       // pinned (devmem cache)
+    size_t n_words = 0;
+    uint32_t n_sub = 0;
+    FastTabs ftabs, ptabs, ctabs;
+    SearchTab stabs[6];
+    uint32_t pool_limit = kPoolEntries;
+    ~ifhip_jpeg_prepared() { if (words) (void)cached_host_free(words); }
+};
+
+static uint32_t test_hook_u32(const char* name, uint32_t dflt, uint32_t hi) {
+    // test hooks: the rarely taken paths (serial code search for sub-tables that overflow the pool; further rounds after an
+    // unsettled count pass) are forced by shrinking the pool / the iterations per launch
+    const char* v = debug_switch(name);
+    return v ? std::min<uint32_t>(static_cast<uint32_t>(std::strtoul(v, nullptr, 10)), hi) : dflt;
+}
+
+static int prepare_impl(ifhip_jpeg_prepared** out, const uint8_t* file, size_t len, uint32_t index_for_messages) {
+    std::unique_ptr<ifhip_jpeg_prepared> R(new ifhip_jpeg_prepared);
+    ParsedJpeg& P = R->P;
+    if (int rc = parse_jpeg(file, len, &P)) return rc;
+    std::memset(R->qt, 0, sizeof R->qt);
+    for (int c = 0; c < P.ncomp; ++c) std::memcpy(&R->qt[c * 64], P.qt[P.tq[c]], 128);
+    R->pool_limit = test_hook_u32("ent_test_pool", kPoolEntries, kPoolEntries);
+    derive_image_tables(P, &R->ftabs, R->stabs, R->pool_limit);
+    derive_pair_tables(R->ftabs, P.ncomp, &R->ptabs);
+    derive_count_tables(R->ftabs, R->ptabs, &R->ctabs);
+    std::vector<std::vector<uint8_t>> seg_bytes;
+    const uint32_t total_mcus = P.mcus_w * P.mcus_h;
+    const uint32_t mcu0 = unstuff_scan(file, len, P, &seg_bytes, &R->seg_mcu0, &R->seg_mcus);
+    if (mcu0 < total_mcus)
+        return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: scan of image %u ends after %u of %u MCUs", index_for_messages, mcu0, total_mcus);
+    uint64_t subs = 0;
+    for (const auto& sb : seg_bytes) {
+        const uint64_t bits = static_cast<uint64_t>(sb.size()) * 8u;
+        const uint64_t ns = std::max<uint64_t>(1, (bits + kSubBits - 1) / kSubBits);
+        R->seg_bits.push_back(bits);
+        R->seg_nsub.push_back(static_cast<uint32_t>(ns));
+        R->seg_first_word.push_back(static_cast<uint32_t>(subs * kSubWords));
+        subs += ns;
+        if (subs * kSubBits + 4096 >= (1ull << 32)) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: more than 512 MB of scan data");
+    }
+    R->n_sub = static_cast<uint32_t>(subs);
+    R->n_words = static_cast<size_t>(subs) * kSubWords;
+    void* pinned = nullptr;
+    size_t pinned_bytes = 4096;                                          // powers of two: few size classes in the pinned cache, whatever the files
+    while (pinned_bytes < R->n_words * sizeof(uint32_t)) pinned_bytes *= 2;
+    if (cached_host_malloc(&pinned, pinned_bytes) != 0)
+        return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: %zu bytes of pinned staging", R->n_words * sizeof(uint32_t));
+    R->words = static_cast<uint32_t*>(pinned);
+    for (size_t k = 0; k < seg_bytes.size(); ++k) {                      // pack: stream order bytes -> big-endian words
+        uint32_t* w = R->words + R->seg_first_word[k];
+        const size_t nw = static_cast<size_t>(R->seg_nsub[k]) * kSubWords, nb = seg_bytes[k].size();
+        std::memcpy(w, seg_bytes[k].data(), nb);
+        std::memset(reinterpret_cast<uint8_t*>(w) + nb, 0, nw * sizeof(uint32_t) - nb);      // pad to the 1 024-bit boundary
+        for (size_t q = 0; q < nw; ++q) w[q] = __builtin_bswap32(w[q]);
+    }
+    *out = R.release();
+    return IFHIP_OK;
+}
+
+static int create_prepared_impl(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* const* prep, uint32_t n_images) {
     std::unique_ptr<ifhip_jpeg_entropy> e(new ifhip_jpeg_entropy);
     if (int arc = require_gfx950(&e->device)) return arc;
     e->n_images = n_images;
+    e->qt.assign(static_cast<size_t>(n_images) * 192u, 0);
     std::vector<Segment> segs;
-    std::vector<uint32_t> sub_seg;
     std::vector<FastTabs> ftabs(n_images), ptabs(n_images), ctabs(n_images);
     std::vector<SearchTab> stabs(static_cast<size_t>(n_images) * 6u);
-    e->qt.assign(static_cast<size_t>(n_images) * 192u, 0);
-
-    // Host preparation runs on a few threads, one file at a time each: parsing and un-stuffing are independent per file
-    // and would otherwise take several times longer than the GPU needs to decode the batch.
-    struct Prep {
-        ParsedJpeg P;
-        int rc = IFHIP_OK;
-        std::string message;
-        std::vector<std::vector<uint8_t>> seg_bytes;      // un-stuffed data of every restart segment
-        std::vector<uint32_t> seg_mcu0, seg_mcus;
-        uint32_t first_seg = 0;
-    };
-    const bool timing = debug_switch("ent_timing") != nullptr;        // development aid: phase times on stderr
-    // test hooks: the rarely taken paths (serial code search for sub-tables that overflow the pool; further rounds after an
-    // unsettled count pass) are forced by shrinking the pool / the iterations per launch
-    auto env_u32 = [](const char* name, uint32_t dflt, uint32_t hi) {
-        const char* v = debug_switch(name);
-        return v ? std::min<uint32_t>(static_cast<uint32_t>(std::strtoul(v, nullptr, 10)), hi) : dflt;
-    };
-    const uint32_t pool_limit = env_u32("ent_test_pool", kPoolEntries, kPoolEntries);
-    const uint32_t inner_rounds = std::max<uint32_t>(1u, env_u32("ent_test_inner", kInnerRounds, kInnerRounds));
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
-    const auto t_start = now();
-    std::vector<Prep> prep(n_images);
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(n_images, hw), 16u);
-    // Workers never let an exception escape (a bad_alloc on a huge scan becomes that file's error), and a thread that
-    // cannot be created (container thread limits) leaves its share of the files to the calling thread.
-    auto run_parallel = [&](auto&& body) {
-        auto guarded = [&](uint32_t i) {
-            try { body(i); }
-            catch (const std::bad_alloc&) { prep[i].rc = IFHIP_ALLOCATION_FAILED; prep[i].message = "AllocationFailed: host memory while preparing the scan"; }
-            catch (const std::exception& ex) { prep[i].rc = IFHIP_INVALID_STATE; prep[i].message = std::string("InvalidState: ") + ex.what(); }
-        };
-        std::vector<std::thread> pool;
-        std::vector<uint32_t> inline_lanes{0u};
-        for (uint32_t t = 1; t < n_threads; ++t) {
-            try { pool.emplace_back([&, t] { for (uint32_t i = t; i < n_images; i += n_threads) guarded(i); }); }
-            catch (const std::exception&) { inline_lanes.push_back(t); }
-        }
-        for (uint32_t t : inline_lanes)
-            for (uint32_t i = t; i < n_images; i += n_threads) guarded(i);
-        for (auto& th : pool) th.join();
-    };
-    run_parallel([&](uint32_t img) {
-        Prep& R = prep[img];
-        ParsedJpeg& P = R.P;
-        R.rc = parse_jpeg(files[img], lengths[img], &P);
-        if (R.rc) { R.message = last_error(); return; }
-        for (int c = 0; c < P.ncomp; ++c) std::memcpy(&e->qt[(static_cast<size_t>(img) * 3u + c) * 64u], P.qt[P.tq[c]], 128);
-        derive_image_tables(P, &ftabs[img], &stabs[static_cast<size_t>(img) * 6u], pool_limit);
-        derive_pair_tables(ftabs[img], P.ncomp, &ptabs[img]);
-        derive_count_tables(ftabs[img], ptabs[img], &ctabs[img]);
-        const uint32_t total_mcus = P.mcus_w * P.mcus_h;
-        const uint32_t mcu0 = unstuff_scan(files[img], lengths[img], P, &R.seg_bytes, &R.seg_mcu0, &R.seg_mcus);
-        if (mcu0 < total_mcus) {
-            R.rc = IFHIP_INVALID_ARGUMENT;
-            char buf[160];
-            std::snprintf(buf, sizeof buf, "ImageMalformed: scan of image %u ends after %u of %u MCUs", img, mcu0, total_mcus);
-            R.message = buf;
-        }
-    });
-    const double t_parse = ms_since(t_start);
-    // serial: errors in file order, geometry check, segment table and word offsets
+    std::vector<uint32_t> first_sub_of(n_images);
     uint64_t total_subs = 0;
     for (uint32_t img = 0; img < n_images; ++img) {
-        Prep& R = prep[img];
-        if (R.rc) return fail(R.rc, "%s", R.message.c_str());
+        const ifhip_jpeg_prepared& R = *prep[img];
         const ParsedJpeg& P = R.P;
         if (img == 0) e->first = P;
         else {
@@ -1268,44 +1259,28 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
             for (int c = 0; c < P.ncomp && same; ++c) same = P.hs[c] == F.hs[c] && P.vs[c] == F.vs[c];
             if (!same) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: image %u differs in size or sampling from image 0 (one batch = one geometry)", img);
         }
-        R.first_seg = static_cast<uint32_t>(segs.size());
-        for (size_t k = 0; k < R.seg_bytes.size(); ++k) {
+        std::memcpy(&e->qt[static_cast<size_t>(img) * 192u], R.qt, sizeof R.qt);
+        ftabs[img] = R.ftabs; ptabs[img] = R.ptabs; ctabs[img] = R.ctabs;
+        std::memcpy(&stabs[static_cast<size_t>(img) * 6u], R.stabs, sizeof R.stabs);
+        first_sub_of[img] = static_cast<uint32_t>(total_subs);
+        for (size_t k = 0; k < R.seg_nsub.size(); ++k) {
             Segment sg;
             sg.image = img;
             sg.first_mcu = R.seg_mcu0[k];
             sg.n_blocks = R.seg_mcus[k] * P.blocks_per_mcu;
             sg.first_sub = static_cast<uint32_t>(total_subs);
-            const size_t bits = R.seg_bytes[k].size() * 8u;
-            sg.n_sub = static_cast<uint32_t>(std::max<size_t>(1, (bits + kSubBits - 1) / kSubBits));
-            const uint64_t bit_end = total_subs * kSubBits + bits;
+            sg.n_sub = R.seg_nsub[k];
+            const uint64_t bit_end = total_subs * kSubBits + R.seg_bits[k];
             if (bit_end + 4096 >= (1ull << 32)) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch holds more than 512 MB of scan data");
             sg.bit_end = static_cast<uint32_t>(bit_end);
             total_subs += sg.n_sub;
             segs.push_back(sg);
         }
     }
+    std::vector<uint32_t> sub_seg(static_cast<size_t>(total_subs));
+    for (size_t k = 0; k < segs.size(); ++k)
+        for (uint32_t q = 0; q < segs[k].n_sub; ++q) sub_seg[segs[k].first_sub + q] = static_cast<uint32_t>(k);
     const size_t n_words = static_cast<size_t>(total_subs) * kSubWords + 64u;  // + lookahead slack behind the last segment
-    StagingLease staging;
-    {
-        const int src = staging.acquire(n_words * sizeof(uint32_t));
-        if (src) return src;
-    }
-    uint32_t* words = static_cast<uint32_t*>(staging.ptr);
-    std::memset(words + (n_words - 64u), 0, 64u * sizeof(uint32_t));
-    sub_seg.resize(static_cast<size_t>(total_subs));
-    run_parallel([&](uint32_t img) {                                            // pack: stream order bytes -> big-endian words
-        const Prep& R = prep[img];
-        for (size_t k = 0; k < R.seg_bytes.size(); ++k) {
-            const Segment& sg = segs[R.first_seg + k];
-            uint32_t* w = words + static_cast<size_t>(sg.first_sub) * kSubWords;
-            const size_t nw = static_cast<size_t>(sg.n_sub) * kSubWords, nb = R.seg_bytes[k].size();
-            std::memcpy(w, R.seg_bytes[k].data(), nb);
-            std::memset(reinterpret_cast<uint8_t*>(w) + nb, 0, nw * sizeof(uint32_t) - nb);      // pad to the 1 024-bit boundary
-            for (size_t q = 0; q < nw; ++q) w[q] = __builtin_bswap32(w[q]);
-            for (uint32_t q = 0; q < sg.n_sub; ++q) sub_seg[sg.first_sub + q] = R.first_seg + static_cast<uint32_t>(k);
-        }
-    });
-    const double t_pack = ms_since(t_start);
     const ParsedJpeg& F = e->first;
     EntropyArgs& a = e->a;
     std::memset(&a, 0, sizeof a);
@@ -1319,7 +1294,7 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
                 a.g.kcomp_packed |= static_cast<uint32_t>(c) << (2u * k);
             }
     }
-    a.inner_rounds = inner_rounds;
+    a.inner_rounds = std::max<uint32_t>(1u, test_hook_u32("ent_test_inner", kInnerRounds, kInnerRounds));
     a.n_sub = static_cast<uint32_t>(sub_seg.size());
     a.n_seg = static_cast<uint32_t>(segs.size());
     a.uniform_tables = 1u;                           // batches of small files put many images into one workgroup: with
@@ -1331,8 +1306,16 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     Segment* d_segs = nullptr;
     FastTabs *d_ftabs = nullptr, *d_ptabs = nullptr, *d_ctabs = nullptr;
     SearchTab* d_stabs = nullptr;
-    if ((rc = dev_alloc(e.get(), &d_words, n_words, words))) return rc;
-    if ((rc = dev_alloc(e.get(), &d_segs, segs.size(), segs.data()))) return rc;
+    if ((rc = dev_alloc<uint32_t>(e.get(), &d_words, n_words))) return rc;
+    {   // every file's words straight from its pinned buffer to its place: n asynchronous copies, one wait (below, with the tables')
+        hipStream_t st = static_cast<hipStream_t>(thread_stream());
+        for (uint32_t img = 0; img < n_images; ++img)
+            if (prep[img]->n_words)
+                HIP_TRY(hipMemcpyAsync(d_words + static_cast<size_t>(first_sub_of[img]) * kSubWords, prep[img]->words,
+                                       prep[img]->n_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(d_words + (n_words - 64u), 0, 64u * sizeof(uint32_t), st));
+    }
+    if ((rc = dev_alloc(e.get(), &d_segs, segs.size(), segs.data()))) return rc;         // (each of these waits for the stream: the words are in place)
     if ((rc = dev_alloc(e.get(), &d_sub, sub_seg.size(), sub_seg.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_ftabs, ftabs.size(), ftabs.data()))) return rc;
     if ((rc = dev_alloc(e.get(), &d_ptabs, ptabs.size(), ptabs.data()))) return rc;
@@ -1351,11 +1334,89 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     a.errors = a.changed + 16;
     a.unsettled = a.changed + 17;
     HIP_TRY(static_cast<hipError_t>(cached_host_malloc(reinterpret_cast<void**>(&e->h_flags), kFlagWords * sizeof(uint32_t))));
-    if (timing)
-        std::fprintf(stderr, "[ifhip entropy create] threads %u (hw %u): parse+unstuff %.2f ms, +pack %.2f ms, +upload/alloc %.2f ms\n",
-                     n_threads, hw, t_parse, t_pack, ms_since(t_start));
     *out = e.release();
     return IFHIP_OK;
+}
+
+static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* files, const size_t* lengths, uint32_t n_images) {
+    if (!out) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null out-pointer");
+    *out = nullptr;
+    if (!files || !lengths || n_images == 0) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: empty batch");
+    if (int arc = require_gfx950(nullptr)) return arc;
+    // Host preparation runs on a few threads, one file at a time each: parsing and un-stuffing are independent per file
+    // and would otherwise take several times longer than the GPU needs to decode the batch.
+    const bool timing = debug_switch("ent_timing") != nullptr;        // development aid: phase times on stderr
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    std::vector<std::unique_ptr<ifhip_jpeg_prepared>> prep(n_images);
+    std::vector<int> rcs(n_images, IFHIP_OK);
+    std::vector<std::string> messages(n_images);
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(n_images, hw), 16u);
+    // Workers never let an exception escape (a bad_alloc on a huge scan becomes that file's error), and a thread that
+    // cannot be created (container thread limits) leaves its share of the files to the calling thread.
+    auto guarded = [&](uint32_t i) {
+        try {
+            ifhip_jpeg_prepared* one = nullptr;
+            rcs[i] = prepare_impl(&one, files[i], lengths[i], i);
+            if (rcs[i]) messages[i] = last_error();
+            prep[i].reset(one);
+        }
+        catch (const std::bad_alloc&) { rcs[i] = IFHIP_ALLOCATION_FAILED; messages[i] = "AllocationFailed: host memory while preparing the scan"; }
+        catch (const std::exception& ex) { rcs[i] = IFHIP_INVALID_STATE; messages[i] = std::string("InvalidState: ") + ex.what(); }
+    };
+    {
+        std::vector<std::thread> pool;
+        std::vector<uint32_t> inline_lanes{0u};
+        for (uint32_t t = 1; t < n_threads; ++t) {
+            try { pool.emplace_back([&, t] { for (uint32_t i = t; i < n_images; i += n_threads) guarded(i); }); }
+            catch (const std::exception&) { inline_lanes.push_back(t); }
+        }
+        for (uint32_t t : inline_lanes)
+            for (uint32_t i = t; i < n_images; i += n_threads) guarded(i);
+        for (auto& th : pool) th.join();
+    }
+    const double t_prep = ms_since();
+    for (uint32_t img = 0; img < n_images; ++img)                              // errors in file order
+        if (rcs[img]) return fail(rcs[img], "%s", messages[img].c_str());
+    std::vector<ifhip_jpeg_prepared*> raw(n_images);
+    for (uint32_t img = 0; img < n_images; ++img) raw[img] = prep[img].get();
+    const int rc = create_prepared_impl(out, raw.data(), n_images);
+    if (timing)
+        std::fprintf(stderr, "[ifhip entropy create] threads %u (hw %u): parse + unstuff + pack %.2f ms, + upload / alloc %.2f ms\n", n_threads, hw, t_prep, ms_since());
+    return rc;
+}
+
+extern "C" {
+
+int ifhip_jpeg_entropy_prepare(ifhip_jpeg_prepared** out, const uint8_t* jpeg, size_t len) {
+    if (!out) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null out-pointer");
+    *out = nullptr;
+    if (!jpeg) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null file");
+    try { return prepare_impl(out, jpeg, len, 0); }
+    catch (const std::bad_alloc&) { return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: host memory while preparing the scan"); }
+    catch (const std::exception& ex) { return fail(IFHIP_INVALID_STATE, "InvalidState: %s", ex.what()); }
+}
+void ifhip_jpeg_prepared_destroy(ifhip_jpeg_prepared* p) { delete p; }
+int ifhip_jpeg_prepared_info(const ifhip_jpeg_prepared* p, uint32_t* width, uint32_t* height, int* n_components, uint8_t* h_samp3, uint8_t* v_samp3) {
+    if (!p) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null handle");
+    if (width) *width = p->P.width;
+    if (height) *height = p->P.height;
+    if (n_components) *n_components = p->P.ncomp;
+    for (int c = 0; c < 3; ++c) {
+        if (h_samp3) h_samp3[c] = c < p->P.ncomp ? p->P.hs[c] : 0;
+        if (v_samp3) v_samp3[c] = c < p->P.ncomp ? p->P.vs[c] : 0;
+    }
+    return IFHIP_OK;
+}
+int ifhip_jpeg_entropy_create_prepared(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* const* prepared, uint32_t n_images) {
+    if (!out) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null out-pointer");
+    *out = nullptr;
+    if (!prepared || n_images == 0) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: empty batch");
+    for (uint32_t i = 0; i < n_images; ++i) if (!prepared[i]) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null prepared file %u", i);
+    try { return create_prepared_impl(out, prepared, n_images); }
+    catch (const std::bad_alloc&) { return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: host memory while assembling the batch"); }
+    catch (const std::exception& ex) { return fail(IFHIP_INVALID_STATE, "InvalidState: %s", ex.what()); }
 }
 
 void ifhip_jpeg_entropy_destroy(ifhip_jpeg_entropy* e) { delete e; }

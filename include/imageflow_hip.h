@@ -237,6 +237,17 @@ IFHIP_API int ifhip_jpeg_exif_orientation(const uint8_t* jpeg, size_t len, int* 
 IFHIP_API int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* files, const size_t* lengths,
                                         uint32_t n_images);
 IFHIP_API void ifhip_jpeg_entropy_destroy(ifhip_jpeg_entropy* e);
+/* The same batch assembled from files that were PREPARED one by one (host only, any thread: parse, un-stuff, cut at the
+ * restart markers, pack into pinned memory, derive the decode tables -- everything ifhip_jpeg_entropy_create does per
+ * file).  A host that runs one job per thread prepares each job's file on that job's thread and hands whatever is waiting
+ * to one create + decode call; the prepared handles may be destroyed as soon as create_prepared returns.  Errors of a
+ * file (ImageMalformed, MethodNotImplemented) are reported by its prepare call. */
+typedef struct ifhip_jpeg_prepared ifhip_jpeg_prepared;
+IFHIP_API int ifhip_jpeg_entropy_prepare(ifhip_jpeg_prepared** out, const uint8_t* jpeg, size_t len);
+IFHIP_API void ifhip_jpeg_prepared_destroy(ifhip_jpeg_prepared* p);
+IFHIP_API int ifhip_jpeg_prepared_info(const ifhip_jpeg_prepared* p, uint32_t* width, uint32_t* height, int* n_components,
+                                       uint8_t* h_samp3, uint8_t* v_samp3);
+IFHIP_API int ifhip_jpeg_entropy_create_prepared(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* const* prepared, uint32_t n_images);
 IFHIP_API int ifhip_jpeg_entropy_info(const ifhip_jpeg_entropy* e, uint32_t* width, uint32_t* height, int* n_components,
                                       uint8_t* h_samp3, uint8_t* v_samp3, uint32_t* blocks_w3, uint32_t* blocks_h3,
                                       uint32_t* n_subsequences, uint32_t* n_segments);
