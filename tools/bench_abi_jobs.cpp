@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -89,6 +90,18 @@ int main(int argc, char** argv) {
     load(h, "imageflow_context_take_output_buffer", &a.take_output_buffer);
     load(h, "imageflow_buffer_free", &a.buffer_free);
     load(h, "imageflow_context_error_write_to_buffer", &a.error_write);
+    // development switches of the library, as tools/ pass them: IFHIP_<SWITCH>=value in the environment -> ifhip_debug_set
+    if (auto set = reinterpret_cast<int (*)(const char*, const char*)>(dlsym(h, "ifhip_debug_set"))) {
+        extern char** environ;
+        for (char** e = environ; *e; ++e) {
+            std::string kv(*e);
+            const size_t eq = kv.find('=');
+            if (kv.compare(0, 6, "IFHIP_") != 0 || eq == std::string::npos || kv.compare(0, 9, "IFHIP_LIB") == 0) continue;
+            std::string key = kv.substr(6, eq - 6);
+            for (char& ch : key) ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
+            set(key.c_str(), kv.c_str() + eq + 1);
+        }
+    }
     const std::vector<uint8_t> file = read_file(argv[2]), job = read_file(argv[3]);
     const int threads = std::atoi(argv[4]);
     const double seconds = std::atof(argv[5]);
