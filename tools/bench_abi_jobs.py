@@ -5,7 +5,8 @@
 
   cfg1  BASELINE config 1: `command_string width=200` on a 3840x2160 4:2:0 q85 JPEG (GPU Huffman decode -> 2/8 IDCT with the
         spatial sRGB luma scaler -> Robidoux to 200x113; the shim's command_string writes the raw BGRA container)
-  cfg4  BASELINE config 4: decode -> constrain within 800 -> encode libjpeg_turbo q85 (a real JPEG out)
+  cfg4  BASELINE config 4: decode -> constrain within 800 -> encode libjpeg_turbo q85 (a real JPEG out; full-size decode)
+  cfg4h the same with the reference's querystring decoder hints (4/8 IDCT + spatial luma scaler; decode + resample fused)
 
 For each job kind and thread count: tools/bench_abi_jobs.cpp (g++, std::thread, one imageflow_context per job) -> jobs/s,
 source megapixels/s, the per-node wall / GPU microseconds of the jobs' `performance` blocks.  Beside them, on ONE host core:
@@ -29,6 +30,12 @@ JOBS = {
     "cfg1": {"framewise": {"steps": [{"command_string": {"kind": "ir4", "value": "width=200", "decode": 0, "encode": 1}}]}},
     "cfg4": {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"constrain": {"mode": "within", "w": 800}},
                                      {"encode": {"io_id": 1, "preset": {"libjpeg_turbo": {"quality": 85}}}}]}},
+    # the same with the decoder hints the reference's querystring path sends for an 800 px target (ir4/mod.rs:167-198:
+    # 2.1 x the target, spatial luma scaling in linear light): 4/8 IDCT, decode + resample as one device call
+    "cfg4h": {"framewise": {"steps": [{"decode": {"io_id": 0, "commands": [{"jpeg_downscale_hints": {
+        "width": 1680, "height": 945, "scale_luma_spatially": True, "gamma_correct_for_srgb_during_spatial_luma_scaling": True}}]}},
+                                      {"constrain": {"mode": "within", "w": 800}},
+                                      {"encode": {"io_id": 1, "preset": {"libjpeg_turbo": {"quality": 85}}}}]}},
 }
 
 
@@ -59,7 +66,8 @@ def cpu_one_core(data, kind, seconds=3.0):
             im = im.convert("RGB").resize((200, 113), Image.BICUBIC)
             im.tobytes()
         else:
-            im.draft("RGB", (1920, 1080))
+            if kind == "cfg4h":
+                im.draft("RGB", (1920, 1080))
             im = im.convert("RGB").resize((800, 450), Image.BICUBIC)
             im.save(io.BytesIO(), "JPEG", quality=85)
         n += 1
@@ -82,9 +90,9 @@ def oracle_one_core(data, kind):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--threads", default="1,8,64")
+    ap.add_argument("--threads", default="1,16,64")
     ap.add_argument("--seconds", type=float, default=4.0)
-    ap.add_argument("--jobs", default="cfg1,cfg4")
+    ap.add_argument("--jobs", default="cfg1,cfg4,cfg4h")
     ap.add_argument("--lib", default=os.environ.get("IFHIP_LIB") or os.path.join(ROOT, "imageflow_amd", "lib", "libimageflow_hip.so"))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--hw-queues", default="", help="GPU_MAX_HW_QUEUES for the harness process (the HIP runtime's own switch: how many "
