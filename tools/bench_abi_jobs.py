@@ -81,6 +81,8 @@ def oracle_one_core(data, kind):
     j = O.jpeg_read_coefficients(data)
     if kind == "cfg1":
         small, (sw, sh, tw, th) = O.jpeg_idct_color_scaled(j, 2, 2), (960, 540, 200, 113)
+    elif kind == "cfg4":
+        small, (sw, sh, tw, th) = O.jpeg_idct_color(j), (3840, 2160, 800, 450)
     else:
         small, (sw, sh, tw, th) = O.jpeg_idct_color_scaled(j, 4, 2), (1920, 1080, 800, 450)
     can = np.zeros((th, U.stride_for(tw)), np.uint8)
