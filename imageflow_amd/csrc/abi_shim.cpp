@@ -753,10 +753,37 @@ struct Job {
         uint16_t qt[192];
         if (in.in_len < 3 || in.in[0] != 0xFF || in.in[1] != 0xD8)
             raise(kImageTypeNotSupported, "ImageTypeNotSupported: io_id %d is neither a JPEG nor the raw BGRA extension", io_id);
-        const int rc = ifhip_jpeg_parse_headers(in.in, in.in_len, w, h, &nc, hs, vs, bw, bh, qt, &ri);
+        int progressive = 0;
+        (void)ri;
+        const int rc = ifhip_jpeg_frame_info(in.in, in.in_len, w, h, &nc, hs, vs, bw, bh, qt, &progressive);
         if (rc == IFHIP_METHOD_NOT_IMPLEMENTED)
-            raise(kImageTypeNotSupported, "ImageTypeNotSupported: %s (baseline sequential JPEG only; keep other files on libjpeg)", ifhip_last_error_message());
+            raise(kImageTypeNotSupported, "ImageTypeNotSupported: %s (Huffman-coded 8-bit JPEG with 1 or 3 components only; keep other files on libjpeg)", ifhip_last_error_message());
         check(rc);
+    }
+
+    // Progressive / multi-scan files: entropy decoding on the host (csrc/jpeg_read.cpp), planes uploaded, everything else as usual
+    std::shared_ptr<DecodedBatch> decode_on_host(const Io& in) {
+        auto b = std::make_shared<DecodedBatch>();
+        uint16_t qt[192];
+        int progressive = 0;
+        const int frc = ifhip_jpeg_frame_info(in.in, in.in_len, &b->w, &b->h, &b->ncomp, b->hs, b->vs, b->bw, b->bh, qt, &progressive);
+        if (frc == IFHIP_METHOD_NOT_IMPLEMENTED)
+            raise(kImageTypeNotSupported, "ImageTypeNotSupported: %s (Huffman-coded 8-bit JPEG with 1 or 3 components only; keep other files on libjpeg)", ifhip_last_error_message());
+        check(frc);
+        std::vector<int16_t> host[3];
+        for (int k = 0; k < 3; ++k) {
+            b->per_image[k] = static_cast<size_t>(b->bw[k]) * b->bh[k] * 64u;
+            host[k].resize(std::max<size_t>(b->per_image[k], 64u));
+        }
+        poll_cancel();
+        check(ifhip_jpeg_read_coefficients_host(in.in, in.in_len, host[0].data(), host[1].data(), host[2].data(), qt));
+        for (int k = 0; k < 3; ++k) {
+            hip_check(job_malloc(reinterpret_cast<void**>(&b->coef[k]), host[k].size() * 2u), "hipMalloc(coefficients)");
+            hip_check(static_cast<hipError_t>(ifhip::copy_to_device(b->coef[k], host[k].data(), host[k].size() * 2u)), "upload(coefficients)");
+        }
+        hip_check(job_malloc(reinterpret_cast<void**>(&b->d_qt), sizeof qt), "hipMalloc(qt)");
+        hip_check(static_cast<hipError_t>(ifhip::copy_to_device(b->d_qt, qt, sizeof qt)), "upload(qt)");
+        return b;
     }
 
     // decode: MozJpegDecoder::read_frame (codecs/mozjpeg_decoder.rs:295-420) on the device, or the raw extension
@@ -785,20 +812,23 @@ struct Job {
         }
         // the entropy stage: this file, together with whatever other threads' jobs want decoded right now (DecodeCoalescer)
         DecodeRequest rq;
-        {
-            const int prc = ifhip_jpeg_entropy_prepare(&rq.prepared, in.in, in.in_len);      // parse, un-stuff, pack, tables: on this job's thread
-            if (prc == IFHIP_METHOD_NOT_IMPLEMENTED)
-                raise(kImageTypeNotSupported, "ImageTypeNotSupported: %s (baseline sequential JPEG only; keep other files on libjpeg)", ifhip_last_error_message());
-            check(prc);
-        }
+        const int prc = ifhip_jpeg_entropy_prepare(&rq.prepared, in.in, in.in_len);          // parse, un-stuff, pack, tables: on this job's thread
         struct PreparedGuard { ifhip_jpeg_prepared* p; ~PreparedGuard() { ifhip_jpeg_prepared_destroy(p); } } prepared_guard{rq.prepared};
-        check(ifhip_jpeg_prepared_info(rq.prepared, &rq.w, &rq.h, &rq.ncomp, rq.hs, rq.vs));
-        poll_cancel();                                               // the decoder's cancellation point (mozjpeg_decoder.rs:346-362 loop)
-        coalescer_for_device().submit(rq);
-        if (rq.retry_alone) {                                        // the shared call failed (somebody's file, maybe this one): alone, errors are this job's
-            std::vector<DecodeRequest*> one{&rq};
-            rq.batch = decode_files(one);
+        if (prc == IFHIP_METHOD_NOT_IMPLEMENTED) {
+            // not a single-scan baseline file: progressive (what the reference's mozjpeg preset writes) or multi-scan -- the scans
+            // are decoded on the host as MzDec does (libjpeg's jdphuff.c), the pixel stage behind them stays on the GPU
+            rq.batch = decode_on_host(in);
             rq.index = 0; rq.batch_size = 1;
+        } else {
+            check(prc);
+            check(ifhip_jpeg_prepared_info(rq.prepared, &rq.w, &rq.h, &rq.ncomp, rq.hs, rq.vs));
+            poll_cancel();                                           // the decoder's cancellation point (mozjpeg_decoder.rs:346-362 loop)
+            coalescer_for_device().submit(rq);
+            if (rq.retry_alone) {                                    // the shared call failed (somebody's file, maybe this one): alone, errors are this job's
+                std::vector<DecodeRequest*> one{&rq};
+                rq.batch = decode_files(one);
+                rq.index = 0; rq.batch_size = 1;
+            }
         }
         if (rq.batch_size > 1) c->coalesced_decodes.fetch_add(1, std::memory_order_relaxed);
         const std::shared_ptr<DecodedBatch> batch = rq.batch;
@@ -1830,7 +1860,9 @@ const struct imageflow_json_response* imageflow_context_send_json(struct imagefl
             int nc = 0;
             uint8_t hs[3], vs[3];
             uint16_t qt[192];
-            check(ifhip_jpeg_parse_headers(in.in, in.in_len, &w, &h, &nc, hs, vs, bw, bh, qt, &ri));
+            int progressive = 0;
+            (void)ri;
+            check(ifhip_jpeg_frame_info(in.in, in.in_len, &w, &h, &nc, hs, vs, bw, bh, qt, &progressive));
             if (scaled_info && in.told && in.told_w > 0 && in.told_h > 0)             // MzDec::apply_downscaling on the told hints (:588-618)
                 for (uint32_t i = 1; i < 8; ++i) {
                     if (i == 7) continue;

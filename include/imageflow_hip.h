@@ -234,6 +234,18 @@ IFHIP_API int ifhip_jpeg_parse_headers(const uint8_t* jpeg, size_t len, uint32_t
 /* EXIF orientation as MozJpegDecoder::get_exif_rotation_flag reads it (codecs/mozjpeg_decoder.rs:290-292, :625-627 ->
  * mozjpeg_decoder_helpers.rs:107-202): *flag = -1 when the file carries none, else the tag's value 0..8.  Host only. */
 IFHIP_API int ifhip_jpeg_exif_orientation(const uint8_t* jpeg, size_t len, int* flag);
+/* Host-side entropy decoding of the Huffman JPEGs the GPU entropy stage does not take -- progressive (SOF2: what the
+ * reference's own mozjpeg encoder preset writes, codecs/mozjpeg.rs:121-123) and sequential files with several / non-
+ * interleaved scans -- into the same coefficient planes ([blocks_h][blocks_w][64] int16, natural order, MCU-padded), so
+ * that the pixel stage behind it is the GPU path unchanged (csrc/jpeg_read.cpp; libjpeg's jdphuff.c / jdhuff.c scans).
+ * ifhip_jpeg_frame_info: the frame facts of any such file (and of baseline ones), *progressive = 1 for SOF2.
+ * ifhip_jpeg_read_coefficients_host: planes sized by those facts (blocks_w * blocks_h * 64 each), cleared and filled;
+ * qt3x64 (optional) receives each component's quantisation table. */
+IFHIP_API int ifhip_jpeg_frame_info(const uint8_t* jpeg, size_t len, uint32_t* width, uint32_t* height, int* n_components,
+                                    uint8_t* h_samp3, uint8_t* v_samp3, uint32_t* blocks_w3, uint32_t* blocks_h3,
+                                    uint16_t* qt3x64, int* progressive);
+IFHIP_API int ifhip_jpeg_read_coefficients_host(const uint8_t* jpeg, size_t len, int16_t* coef0, int16_t* coef1,
+                                                int16_t* coef2, uint16_t* qt3x64);
 IFHIP_API int ifhip_jpeg_entropy_create(ifhip_jpeg_entropy** out, const uint8_t* const* files, const size_t* lengths,
                                         uint32_t n_images);
 IFHIP_API void ifhip_jpeg_entropy_destroy(ifhip_jpeg_entropy* e);

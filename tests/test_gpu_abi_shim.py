@@ -153,12 +153,45 @@ def test_raw_container_round_trip_and_matte_hint():
     assert rc == 0 and (w2, h2, alpha2) == (40, 25, False) and np.array_equal(rows2, can)
 
 
-def test_progressive_jpeg_is_refused_not_mis_decoded():
+@pytest.mark.parametrize("subsampling", ["4:2:0", "4:4:4", "4:2:2"])
+@pytest.mark.parametrize("size", [(32, 32), (203, 131), (640, 427)])
+def test_progressive_jpeg_decodes_to_libjpeg_turbos_pixels(size, subsampling):
+    """What the reference's mozjpeg preset writes (codecs/mozjpeg.rs:121-123: progressive): the scans are decoded on the host
+    (csrc/jpeg_read.cpp, jdphuff.c's four block decoders), the pixel stage is the GPU's -- the job's decode equals
+    libjpeg-turbo's decode of the same file byte for byte, as for baseline files."""
+    PIL = pytest.importorskip("PIL.Image")
+    w, h = size
+    rng = np.random.default_rng(w + h)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.clip(np.stack([x * 255 // max(w - 1, 1), y * 255 // max(h - 1, 1), (x + y) * 255 // max(w + h - 2, 1)], -1) +
+                  (30 * np.sin(x / 3.0) * np.cos(y / 5.0))[..., None] + rng.integers(-20, 21, (h, w, 3)), 0, 255).astype(np.uint8)
+    b = io.BytesIO()
+    PIL.fromarray(img).save(b, "JPEG", quality=80, progressive=True, subsampling=subsampling)
+    data = b.getvalue()
+    assert b"\xff\xc2" in data
+    with Context() as c:
+        c.add_input_buffer(0, data)
+        c.add_output_buffer(1)
+        status, info = c.send_json("v1/get_image_info", {"io_id": 0})
+        assert status == 200 and (info["data"]["image_info"]["image_width"], info["data"]["image_info"]["image_height"]) == (w, h)
+        _run(c, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"encode": {"io_id": 1, "preset": "gif"}}]}})
+        rows, ow, oh, alpha = unpack_raw_bgra(c.get_output_buffer(1))
+    ref = np.asarray(PIL.open(io.BytesIO(data)).convert("RGB"))
+    assert (ow, oh, alpha) == (w, h, False)
+    got = rows[:, :4 * w].reshape(h, w, 4)
+    assert np.array_equal(got[:, :, 2::-1], ref)
+
+
+def test_arithmetic_coded_jpeg_is_refused_not_mis_decoded():
+    """SOF9 (arithmetic coding): ImageTypeNotSupported, category 5 -- never a wrong picture."""
     PIL = pytest.importorskip("PIL.Image")
     b = io.BytesIO()
-    PIL.fromarray(np.zeros((32, 32, 3), np.uint8)).save(b, "JPEG", progressive=True)
+    PIL.fromarray(np.zeros((32, 32, 3), np.uint8)).save(b, "JPEG")
+    data = bytearray(b.getvalue())
+    at = data.index(b"\xff\xc0")
+    data[at + 1] = 0xC9
     with Context() as c:
-        c.add_input_buffer(0, b.getvalue())
+        c.add_input_buffer(0, bytes(data))
         status, r = c.send_json("v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}]}})
         assert status == 400 and c.error_code() == 5 and "ImageTypeNotSupported" in r["message"]
 
