@@ -1,14 +1,14 @@
 #!/bin/bash
-# Round-3 evidence run (on the GPU box through gpurun).  Raw output under gpurun_out/prof3, the summaries kept under
-# gpurun_out/prof3_summary (copied to profiles/r3_* afterwards).  Counter passes are separate runs with --kernel-trace only.
+# Round-4 evidence run (on the GPU box through gpurun): every figure DESIGN.md section 6 quotes for this round, from one build on one box.
+# Raw output under gpurun_out/prof4, the summaries kept under gpurun_out/prof4_summary (copied to profiles/r4_* afterwards).  Counter passes are separate runs with --kernel-trace only.
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-OUT=gpurun_out/prof3
-SUM=gpurun_out/prof3_summary
+OUT=gpurun_out/prof4
+SUM=gpurun_out/prof4_summary
 rm -rf $OUT $SUM; mkdir -p $OUT $SUM
-# SECTIONS="5" tools/profile_r3.sh re-measures one part only (default: all five)
-SECTIONS=${SECTIONS:-"1 2 3 4 5"}
+# SECTIONS="5" tools/profile_r4.sh re-measures one part only (default: all)
+SECTIONS=${SECTIONS:-"0 1 2 3 4 5 6"}
 want() { case " $SECTIONS " in *" $1 "*) return 0;; esac; return 1; }
 
 pmc_pass() {   # pmc_pass <tag> <kernel substring> <counters> -- cmd...
@@ -31,6 +31,11 @@ PY
   else echo "($ctr): no counter csv: $(tail -1 $OUT/pmc_$tag.err)"; fi
   rm -rf $OUT/pmc_$tag
 }
+
+# 0. the whole GPU suite and smoke() on this build
+if want 0; then
+{ timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4; timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1; } > $SUM/gpu_tests_and_smoke.log
+fi
 
 # 1. headline: bench line, the same command under kernel-trace, HBM traffic + SQ counters
 if want 1; then
@@ -69,6 +74,10 @@ fi
 # 4. jobs: export_4_sizes, 1024-frame strong-scaling job on one GPU
 if want 4; then
 python bench.py --workload cfg3 --steps 50 --warmup 5 --no-cpu-baseline > $SUM/bench_cfg3_job.json 2>/dev/null
+python bench.py --workload cfg3 --outputs bgra --steps 50 --warmup 5 --no-cpu-baseline > $SUM/bench_cfg3_job_bgra.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg3job -- python bench.py --workload cfg3 --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $OUT/trace_cfg3job.err
+find $OUT/trace_cfg3job -name '*kernel_stats.csv' -exec sh -c "head -14 {} | cut -c1-220 > $SUM/cfg3_job_kernel_stats.csv" \;
+rm -rf $OUT/trace_cfg3job
 python bench.py --scaling strong --total-frames 1024 --steps 30 --warmup 5 --no-cpu-baseline > $SUM/bench_strong_1024_1gpu.json 2>/dev/null
 fi
 
@@ -93,6 +102,9 @@ find $OUT/trace_jpeg -name '*kernel_stats.csv' -exec sh -c "head -9 {} > $SUM/jp
   done; } > $SUM/entropy_pmc.txt
 fi
 
-want 1 && tools/probes/issue_rate_probe > $SUM/issue_rate_probe.txt 2>&1
+# 6. jobs through the libimageflow ABI (file in, file out): T threads x one context per job, cfg1 / cfg4 / cfg4h jobs
+if want 6; then
+timeout 600 python tools/bench_abi_jobs.py --threads 1,8,64 --seconds 2.5 > $SUM/abi_jobs.json 2> $SUM/abi_jobs.err
+fi
 rm -rf $OUT
 ls -la $SUM
