@@ -64,6 +64,12 @@ def _bind():
     L.ifhip_shim_device_coded_files.restype = C.c_int64
     L.ifhip_shim_coalesced_decodes.argtypes = [vp]
     L.ifhip_shim_coalesced_decodes.restype = C.c_int64
+    L.ifhip_shim_spread_contexts.argtypes = [C.c_int]
+    L.ifhip_shim_spread_contexts.restype = None
+    L.ifhip_shim_context_set_device.argtypes = [vp, C.c_int]
+    L.ifhip_shim_context_set_device.restype = C.c_bool
+    L.ifhip_shim_context_device.argtypes = [vp]
+    L.ifhip_shim_context_device.restype = C.c_int
     L.imageflow_context_memory_allocate.argtypes = [vp, C.c_size_t, C.c_char_p, C.c_int32]
     L.imageflow_context_memory_allocate.restype = vp
     L.imageflow_context_memory_free.argtypes = [vp, vp, C.c_char_p, C.c_int32]
@@ -141,6 +147,14 @@ class Context:
         data = C.string_at(buf, n.value)
         assert self.L.imageflow_buffer_free(buf, n.value)
         return data
+
+    def set_device(self, ordinal):
+        """Bind the context's jobs to a device ordinal (-1: the calling thread's current device); False + a context error otherwise."""
+        return self.L.ifhip_shim_context_set_device(self.p, ordinal)
+
+    @property
+    def device(self):
+        return self.L.ifhip_shim_context_device(self.p)
 
     def request_cancellation(self):
         self.L.imageflow_context_request_cancellation(self.p)

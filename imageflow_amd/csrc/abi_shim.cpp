@@ -272,24 +272,46 @@ int parse_filter(const JVal* v, int dflt) {                      // imageflow_ty
 // the library's size-class cache (devmem.cpp) and goes back without a driver call.  Every node ends with a wait for the
 // job's stream, so whatever a job frees is idle (ifhip::QuiescedScope around the whole job).
 std::mutex g_stream_mu;
-std::vector<hipStream_t> g_stream_pool;
+struct DeviceQueues { std::vector<hipStream_t> pool; int slots_taken = 0; };
+std::map<int, DeviceQueues> g_queues;                     // per device ordinal: a stream belongs to the device it was created on
 thread_local hipStream_t t_job_stream = nullptr;          // the stream of the job this thread is running (null outside a job)
 // Admission: the runtime spreads a process's streams over a handful of hardware queues, and a job waits for its stream a
 // dozen times; with 64 jobs in flight every small copy queues behind other jobs' long kernels and the job rate FALLS
-// (measured, round 4: 6 750 jobs/s at 16 threads, 1 850 at 64).  Jobs beyond kJobSlots wait for a slot on the host.
+// (measured, round 4: 6 750 jobs/s at 16 threads, 1 850 at 64).  Jobs beyond kJobSlots PER DEVICE wait for a slot on the host.
 constexpr int kJobSlots = 20;
 std::condition_variable g_slot_cv;
-int g_slots_taken = 0;
+// Contexts and devices.  The reference's guidance is one Context per thread (imageflow_abi/src/lib.rs:20-27) and jobs are
+// independent, so a node's GPUs are fed by giving every context a device: with ifhip_shim_spread_contexts(1) a new context
+// takes the next usable device round-robin and all its jobs run there, whichever thread calls (no collective: a job's
+// outputs are host buffers).  Without it (the default) a context follows the calling thread's current device, as before.
+std::atomic<int> g_spread_contexts{0};
+std::atomic<uint32_t> g_context_counter{0};
+struct DeviceScope {                                      // the calling thread on the context's device for one call
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int dev) {
+        if (dev < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != dev) {
+            if (hipSetDevice(dev) == hipSuccess) switched = true;
+            else (void)hipGetLastError();                 // (the first GPU call of the job reports)
+        }
+    }
+    ~DeviceScope() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+};
 struct StreamLease {
     hipStream_t st = nullptr;
+    int dev = 0;
     StreamLease() {
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
         {
             std::unique_lock<std::mutex> lk(g_stream_mu);
             int slots = kJobSlots;
             if (const char* e = ifhip::debug_switch("job_slots")) slots = std::max(1, std::atoi(e));
-            while (g_slots_taken >= slots) g_slot_cv.wait(lk);
-            ++g_slots_taken;
-            if (!g_stream_pool.empty()) { st = g_stream_pool.back(); g_stream_pool.pop_back(); }
+            DeviceQueues& q = g_queues[dev];              // (map nodes do not move: the reference survives the wait)
+            while (q.slots_taken >= slots) g_slot_cv.wait(lk);
+            ++q.slots_taken;
+            if (!q.pool.empty()) { st = q.pool.back(); q.pool.pop_back(); }
         }
         if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }   // (no device: the null stream, the first GPU call reports)
         t_job_stream = st;
@@ -301,10 +323,11 @@ struct StreamLease {
         if (st) (void)hipStreamSynchronize(st);
         {
             std::lock_guard<std::mutex> lk(g_stream_mu);
-            if (st) g_stream_pool.push_back(st);
-            --g_slots_taken;
+            DeviceQueues& q = g_queues[dev];
+            if (st) q.pool.push_back(st);
+            --q.slots_taken;
         }
-        g_slot_cv.notify_one();
+        g_slot_cv.notify_all();                           // (waiters of several devices share the condition variable)
     }
 };
 // Before anything of a job goes back to the cache: the job's stream -- the only one its blocks were ever used on -- is idle.
@@ -414,6 +437,7 @@ struct imageflow_context {
     std::atomic<int64_t> fused_decode_resamples{0};
     std::atomic<int64_t> device_coded_files{0};          // JPEG outputs whose entropy coding ran on the device (diagnostic)
     std::atomic<int64_t> coalesced_decodes{0};           // decodes of this context that shared their device call with another thread's job
+    std::atomic<int> device{-1};                         // device ordinal its jobs run on; -1: the calling thread's current device
     bool cancellation_requested() {
         if (cancel.load(std::memory_order_relaxed)) return true;
         if (poll_countdown.load(std::memory_order_relaxed) == INT64_MAX) return false;
@@ -1669,7 +1693,14 @@ uint32_t imageflow_abi_version_minor(void) { return IMAGEFLOW_ABI_VER_MINOR; }
 
 struct imageflow_context* imageflow_context_create(uint32_t major, uint32_t minor) {       // lib.rs:430
     if (!imageflow_abi_compatible(major, minor)) return nullptr;
-    try { return new imageflow_context; } catch (...) { return nullptr; }
+    try {
+        imageflow_context* c = new imageflow_context;
+        if (g_spread_contexts.load(std::memory_order_relaxed)) {
+            const int n = ifhip_device_count();
+            if (n > 0) c->device.store(static_cast<int>(g_context_counter.fetch_add(1, std::memory_order_relaxed) % static_cast<uint32_t>(n)), std::memory_order_relaxed);
+        }
+        return c;
+    } catch (...) { return nullptr; }
 }
 bool imageflow_context_begin_terminate(struct imageflow_context* c) { CTX_OR_ABORT(c); return true; }
 void imageflow_context_destroy(struct imageflow_context* c) { delete c; }
@@ -1723,6 +1754,24 @@ int64_t ifhip_shim_fused_decode_resamples(struct imageflow_context* c) {
 int64_t ifhip_shim_coalesced_decodes(struct imageflow_context* c) {
     CTX_OR_ABORT(c);
     return c->coalesced_decodes.load(std::memory_order_relaxed);
+}
+// Contexts over the node's GPUs (see DeviceScope): enable != 0 -> contexts created from now on take devices round-robin
+void ifhip_shim_spread_contexts(int enable) { g_spread_contexts.store(enable ? 1 : 0, std::memory_order_relaxed); }
+// bind one context to a device ordinal (-1: follow the calling thread again); false and an error on the context when the
+// ordinal is not a usable device
+bool ifhip_shim_context_set_device(struct imageflow_context* c, int ordinal) {
+    CTX_OR_ABORT(c);
+    if (ordinal >= ifhip_device_count() || ordinal < -1) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->set_error(kArgumentInvalid, "InvalidArgument: device ordinal " + std::to_string(ordinal) + " is not a usable gfx950 device");
+        return false;
+    }
+    c->device.store(ordinal, std::memory_order_relaxed);
+    return true;
+}
+int ifhip_shim_context_device(struct imageflow_context* c) {
+    CTX_OR_ABORT(c);
+    return c->device.load(std::memory_order_relaxed);
 }
 int64_t ifhip_shim_device_coded_files(struct imageflow_context* c) {
     CTX_OR_ABORT(c);
@@ -1830,7 +1879,8 @@ const struct imageflow_json_response* imageflow_context_send_json(struct imagefl
         if (json_buffer_size > 64u * 1024u * 1024u) raise(kArgumentInvalid, "SizeLimitExceeded: JSON payload exceeds max_json_bytes");   // ExecutionSecurity::max_json_bytes
         const JVal root = parse_json(json_buffer, json_buffer_size);
         if (root.t != JVal::Obj) raise(kInvalidJson, "InvalidJson: the message must be an object");
-        // the job's stream and the promise its frees rest on (every release is preceded by quiesce())
+        // the context's device, then the job's stream and the promise its frees rest on (every release is preceded by quiesce())
+        DeviceScope on_device(c->device.load(std::memory_order_relaxed));
         StreamLease lease;
         ifhip::QuiescedScope quiet;
         struct InFlight { InFlight() { g_jobs_in_flight.fetch_add(1, std::memory_order_relaxed); } ~InFlight() { g_jobs_in_flight.fetch_sub(1, std::memory_order_relaxed); } } in_flight;

@@ -109,6 +109,14 @@ IMAGEFLOW_SHIM_API int64_t ifhip_shim_device_coded_files(struct imageflow_contex
 /* Diagnostic: how many decodes of this context's jobs shared their entropy-decode device call with the job of another
  * thread (concurrent decodes of one geometry are coalesced into one batch; one context per thread, lib.rs:20-27). */
 IMAGEFLOW_SHIM_API int64_t ifhip_shim_coalesced_decodes(struct imageflow_context *context);
+/* Independent jobs over the GPUs of one node, without a process per GPU: a context may be bound to a device ordinal and
+ * every job it runs (whichever thread calls) runs there -- the reference's "one Context per thread"
+ * (imageflow_abi/src/lib.rs:20-27) then shards a batch of jobs by construction, with no collective (outputs are host
+ * buffers).  ifhip_shim_spread_contexts(1): contexts created from now on take the usable devices round-robin;
+ * _context_set_device binds one context (-1: follow the calling thread's current device, the default). */
+IMAGEFLOW_SHIM_API void ifhip_shim_spread_contexts(int enable);
+IMAGEFLOW_SHIM_API bool ifhip_shim_context_set_device(struct imageflow_context *context, int ordinal);
+IMAGEFLOW_SHIM_API int ifhip_shim_context_device(struct imageflow_context *context);
 
 #ifdef __cplusplus
 }

@@ -293,3 +293,23 @@ def test_byte_array_io_is_validated():
     with Context() as c:
         status, r = c.send_json("v1/build", {"io": [{"io_id": 0, "direction": "in", "io": "output_base_64"}], "framewise": {"steps": []}})
         assert status == 400 and c.error_code() == 3
+
+
+def test_contexts_and_devices_without_a_gpu():
+    """ifhip_shim_spread_contexts / _context_set_device (include/imageflow_abi_subset.h): with no usable device a context
+    stays on "the calling thread's device" (-1) whatever the policy says, and binding it to an ordinal is an InvalidArgument
+    on that context."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the GPU form is tests/test_gpu_abi_shim.py::test_contexts_bound_to_devices")
+    L = abi._bind()
+    L.ifhip_shim_spread_contexts(1)
+    try:
+        with Context() as c:
+            assert c.device == -1
+            assert not c.set_device(0)
+            assert c.has_error() and "device ordinal 0" in c.error_message()[0]
+        with Context() as c:
+            assert c.set_device(-1) and not c.has_error()
+    finally:
+        L.ifhip_shim_spread_contexts(0)

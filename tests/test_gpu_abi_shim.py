@@ -821,3 +821,59 @@ def test_a_damaged_file_in_a_coalesced_batch_fails_alone(debug_switch):
         rows, w, h, _ = res[i][1]
         full = O.jpeg_idct_color(O.jpeg_read_coefficients(files[i]))
         assert np.array_equal(rows[:, :320], _oracle_resize(full, 320, 240, 80, 60, filter_id=2)[:, :320]), i
+
+
+# ---- contexts bound to devices (include/imageflow_abi_subset.h: ifhip_shim_spread_contexts / _context_set_device) --------
+def test_contexts_bound_to_devices():
+    """With the spreading policy on, new contexts take the usable devices round-robin (one GPU here: all ordinal 0) and their
+    jobs run there whichever thread calls; an ordinal past the usable devices is refused on the context; the outputs are the
+    unbound context's bytes.  One context per thread, jobs started together (lib.rs:20-27)."""
+    import threading
+    from imageflow_amd import _native, abi
+    L = abi._bind()
+    n_dev = _native.lib().ifhip_device_count()
+    assert n_dev >= 1
+    files = [_jpeg(640, 400, seed=500 + i) for i in range(4)]
+    job = {"framewise": {"steps": [{"command_string": {"kind": "ir4", "value": "width=100", "decode": 0, "encode": 1}}]}}
+
+    def run_one(c, data):
+        c.add_input_buffer(0, data)
+        c.add_output_buffer(1)
+        _run(c, "v1/execute", job)
+        return c.get_output_buffer(1)
+    with Context() as c:
+        assert c.device == -1
+        want = [None] * 4
+        want[0] = run_one(c, files[0])
+    for i in range(1, 4):
+        with Context() as c:
+            want[i] = run_one(c, files[i])
+    L.ifhip_shim_spread_contexts(1)
+    try:
+        ctxs = [Context() for _ in range(4)]
+        devs = [c.device for c in ctxs]
+        assert all(0 <= d < n_dev for d in devs), devs
+        assert len(set(devs)) == min(4, n_dev), devs                  # round-robin over the usable devices
+        got, errs = [None] * 4, []
+
+        def work(i):
+            try:
+                got[i] = run_one(ctxs[i], files[i])
+            except Exception as e:  # noqa: BLE001
+                errs.append((i, repr(e)))
+        th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        assert got == want
+        assert not ctxs[0].set_device(n_dev) and ctxs[0].has_error()
+        for c in ctxs:
+            c.close()
+    finally:
+        L.ifhip_shim_spread_contexts(0)
+    with Context() as c:                                              # explicit binding, then back to "the caller's device"
+        assert c.set_device(0) and c.device == 0
+        assert run_one(c, files[1]) == want[1]
+        assert c.set_device(-1) and c.device == -1

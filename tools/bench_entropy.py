@@ -17,9 +17,7 @@ sys.path.insert(0, ROOT)
 from imageflow_amd.codecs import mozjpeg_decoder as D  # noqa: E402
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-    w, h = 3840, 2160
+def make_files(n, w, h):
     y, x = np.mgrid[0:h, 0:w]
     rng = np.random.default_rng(1)
     files = []
@@ -29,6 +27,65 @@ def main():
         buf = io.BytesIO()
         Image.fromarray(np.clip(base + tex, 0, 255).astype(np.uint8)).save(buf, "JPEG", quality=85, subsampling="4:2:0", optimize=False)
         files.append(buf.getvalue())
+    return files
+
+
+def streams_mode(n, streams, reps):
+    """Whole-job rate with several batches in flight: T host threads, each with its own batch of n files, its own HIP stream
+    and buffers, loop entropy decode -> 4/8 pixel stage -> 800x450 (the one-call chain).  The synchronisation kernel of one
+    batch leaves most CUs idle during its late iterations; a second batch fills them."""
+    import threading
+    from imageflow_amd.graphics.bitmaps import Bitmap
+    from imageflow_amd.graphics.scaling import ScaleAndRenderParams
+    w, h = 3840, 2160
+    files = make_files(n, w, h)
+    torch.zeros(1, device="cuda").item()
+    info = ScaleAndRenderParams(0, 0, 800, 450)
+    out = []
+    for T in streams:
+        ctx = []
+        for _ in range(T):
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                ent = D.JpegEntropyBatch(files)
+                coef = ent.read_coefficients()
+                stage4 = D.JpegPixelStage(w, h, 3, ent.h_samp, ent.v_samp, n, scale_num=4, luma_spatial=True, luma_srgb=True)
+                qt = torch.from_numpy(ent.qt.view(np.int16)).cuda()
+                small = Bitmap.create_u8(n, 800, 450, "cuda:0")
+                stage4.read_frames_into(coef, qt, small, info)
+            ctx.append((st, ent, coef, stage4, qt, small))
+        torch.cuda.synchronize()
+        start = threading.Barrier(T + 1)
+        def work(c):
+            st, ent, coef, stage4, qt, small = c
+            with torch.cuda.stream(st):
+                start.wait()
+                for _ in range(reps):
+                    ent.read_coefficients(coef)
+                    stage4.read_frames_into(coef, qt, small, info)
+                st.synchronize()
+        th = [threading.Thread(target=work, args=(c,)) for c in ctx]
+        for t in th: t.start()
+        start.wait()
+        t0 = time.perf_counter()
+        for t in th: t.join()
+        dt = time.perf_counter() - t0
+        out.append({"streams": T, "batches": T * reps, "files_per_batch": n, "ms_per_batch": round(dt / (T * reps) * 1e3, 3),
+                    "files_per_s": round(T * reps * n / dt, 1), "MPps": round(T * reps * n * w * h / 1e6 / dt, 1)})
+        del ctx
+    print(json.dumps({"workload": "file -> entropy decode -> 4/8 pixel stage -> 800x450, batches in flight on separate HIP streams (one host thread each)",
+                      "runs": out}, indent=1))
+
+
+def main():
+    if "--streams" in sys.argv:
+        i = sys.argv.index("--streams")
+        streams = [int(v) for v in sys.argv[i + 1].split(",")]
+        rest = [a for k, a in enumerate(sys.argv[1:], 1) if k not in (i, i + 1)]
+        return streams_mode(int(rest[0]) if rest else 16, streams, 40)
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    w, h = 3840, 2160
+    files = make_files(n, w, h)
     size = sum(len(f) for f in files)
     torch.zeros(1, device="cuda").item()                    # HIP context up before anything is timed
     D.JpegEntropyBatch(files[:1]).read_coefficients()       # code objects loaded
