@@ -134,6 +134,12 @@ struct ifhip_resample_plan {
     float* d_h_wg = nullptr;        // distinct weight rows, each zero-padded to G groups
     uint32_t h_wg_floats = 0;
     uint32_t* d_h_meta2 = nullptr;  // [out_w] first group | row id << 16
+    // ... and its two-column form: G2 groups of 2 taps where that computes at most 2/3 of the taps per output (windows of 5-6 taps
+    // aligned to 4 columns take 3 groups = 12 taps, aligned to 2 columns 4 groups = 8); no alpha, BGRA sources
+    uint32_t h_two_groups = 0;      // 0: not available / not worth it
+    float* d_h_wg2 = nullptr;       // distinct weight rows, each zero-padded to G2 groups of 2
+    uint32_t h_wg2_floats = 0;
+    uint32_t* d_h_meta3 = nullptr;  // [out_w] first 2-column group | row id << 16
     uint32_t h_wu_floats = 0;       // de-duplicated, 4-tap padded horizontal weight rows
     uint32_t h_avg_groups = 0;      // mean 4-tap groups per horizontal chain
     // fused-kernel geometry
@@ -151,7 +157,7 @@ struct ifhip_resample_plan {
 
     ~ifhip_resample_plan() {
         for (void* p : {(void*)d_v_left, (void*)d_v_count, (void*)d_v_off, (void*)d_h_left, (void*)d_h_count,
-                        (void*)d_h_off, (void*)d_v_w, (void*)d_h_w, (void*)d_h_wu, (void*)d_h_meta, (void*)d_h_wg, (void*)d_h_meta2, (void*)sets[0].d_strips,
+                        (void*)d_h_off, (void*)d_v_w, (void*)d_h_w, (void*)d_h_wu, (void*)d_h_meta, (void*)d_h_wg, (void*)d_h_meta2, (void*)d_h_wg2, (void*)d_h_meta3, (void*)sets[0].d_strips,
                         (void*)sets[1].d_strips})
             if (p) (void)DEV_FREE(p);
         for (auto& kv : schedules) {
@@ -444,9 +450,14 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         uint32_t frames = 1, copies_log2 = kMinLutCopiesLog2, fast_g = 0, wu_floats = p->h_wu_floats;
         bool w_in_lds = false, l2s_in_lds = false;
         ScheduleOnDevice sd;
-        for (int attempt = (per_pixel && p->h_fast_groups && fused_shape(p->slots, channels).px == 4) ? 0 : 1; attempt < 2; ++attempt) {
-            fast_g = attempt == 0 ? p->h_fast_groups : 0u;
-            wu_floats = fast_g ? p->h_wg_floats : p->h_wu_floats;
+        // forms of the horizontal pass, best first: two-column groups, four-column groups (both: the fast pass), general
+        const bool fast_ok = per_pixel && p->h_fast_groups && fused_shape(p->slots, channels).px == 4;
+        const bool two_ok = fast_ok && p->h_two_groups && !alpha && !ycc;
+        bool two = false;
+        for (int attempt = two_ok ? -1 : (fast_ok ? 0 : 1); attempt < 2; ++attempt) {
+            two = attempt < 0;
+            fast_g = two ? p->h_two_groups : (attempt == 0 ? p->h_fast_groups : 0u);
+            wu_floats = two ? p->h_wg2_floats : (fast_g ? p->h_wg_floats : p->h_wu_floats);
             // Frames per workgroup: a source narrower than half the workgroup would leave the CU with a handful of waves
             // (one workgroup per CU: the tables fill most of the LDS), so F frames share a workgroup and its tables.
             frames = 1;
@@ -492,8 +503,9 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
             if (!fast_g || w_in_lds) break;
         }
         if (ycc && !(w_in_lds && per_pixel)) return kNotFusable;     // the planar source is instantiated for that form only
-        a.h_groups = fast_g;
-        if (fast_g) { a.h_wu = p->d_h_wg; a.h_wu_floats = p->h_wg_floats; a.h_meta2 = p->d_h_meta2; }
+        a.h_groups = two ? 16u + fast_g : fast_g;                    // (16 + G2: the two-column form)
+        if (two) { a.h_wu = p->d_h_wg2; a.h_wu_floats = p->h_wg2_floats; a.h_meta2 = p->d_h_meta3; }
+        else if (fast_g) { a.h_wu = p->d_h_wg; a.h_wu_floats = p->h_wg_floats; a.h_meta2 = p->d_h_meta2; }
         a.lut_copies_log2 = copies_log2;
         a.h_w_in_lds = w_in_lds ? 1u : 0u;
         a.l2s_in_lds = l2s_in_lds ? 1u : 0u;
@@ -507,9 +519,9 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
         if (debug_switch("trace_launch"))                        // experiment aid: the shape this call launches
             std::fprintf(stderr, "ifhip fused launch: %ux%u -> %ux%u K=%d alpha=%d ycc=%d lanes/frame=%u frames/wg=%u bands=%u strips=%u "
-                         "grid=%llu lds=%zu fast_g=%u w_in_lds=%d l2s_in_lds=%d lut_copies=%u per_pixel=%d images=%u\n",
+                         "grid=%llu lds=%zu fast_g=%u two_col=%d w_in_lds=%d l2s_in_lds=%d lut_copies=%u per_pixel=%d images=%u\n",
                          p->in_w, p->in_h, p->out_w, p->out_h, p->slots, alpha, ycc ? 1 : 0, block, frames, sd.n_bands, a.n_strips,
-                         static_cast<unsigned long long>(grid), lds, fast_g, w_in_lds ? 1 : 0, l2s_in_lds ? 1 : 0, 1u << copies_log2,
+                         static_cast<unsigned long long>(grid), lds, fast_g, two ? 1 : 0, w_in_lds ? 1 : 0, l2s_in_lds ? 1 : 0, 1u << copies_log2,
                          per_pixel ? 1 : 0, n_images);
         if (probe) return IFHIP_OK;
         HIP_TRY(launch_fused(a, p->slots, alpha != 0, per_pixel, static_cast<uint32_t>(grid), block * frames, lds, st));
@@ -703,6 +715,39 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
             if (ok) { p->h_fast_groups = g_max; p->h_wg_floats = static_cast<uint32_t>(wg.size()); }
         }
     }
+    // The same with groups of TWO source columns (8-byte LDS reads): a row starts at the first tap rounded down to an even
+    // column.  Worth it where it computes a third fewer taps per output: 1600 -> 1200 Robidoux has 5-6 taps per output,
+    // 3 groups of 4 (12 taps) or 4 groups of 2 (8): cfg3 level 1 2.91 -> 2.70 ms; 1200 -> 400 (16 taps or 12) measured equal
+    // and stays with groups of four.  The taps keep their order and the padding is +0: same pixels.
+    std::vector<float> wg2;
+    std::vector<uint32_t> hmeta3(w);
+    if (p->h_fast_groups && debug_switch("no_two_col") == nullptr) {
+        uint32_t g2_max = 0;
+        for (uint32_t u = 0; u < w; ++u) g2_max = std::max(g2_max, ((p->wh.left[u] & 1u) + p->wh.count[u] + 1u) >> 1);
+        if (g2_max >= 2u && g2_max <= 6u && 3u * g2_max <= 4u * p->h_fast_groups) {     // at most 2/3 of the taps (measured: 3/4 gains nothing)
+            std::map<std::vector<uint32_t>, uint32_t> seen;
+            const uint32_t row_floats = g2_max * 2u;
+            bool ok = true;
+            for (uint32_t u = 0; u < w && ok; ++u) {
+                std::vector<uint32_t> bits(row_floats, 0u);
+                std::memcpy(bits.data() + (p->wh.left[u] & 1u), p->wh.w.data() + p->wh.offset[u], p->wh.count[u] * sizeof(float));
+                auto it = seen.find(bits);
+                if (it == seen.end()) {
+                    const uint32_t id = static_cast<uint32_t>(seen.size());
+                    if (id >= 65536u) { ok = false; break; }
+                    wg2.resize(wg2.size() + row_floats);
+                    std::memcpy(wg2.data() + static_cast<size_t>(id) * row_floats, bits.data(), row_floats * 4u);
+                    it = seen.emplace(std::move(bits), id).first;
+                }
+                if ((p->wh.left[u] >> 1) >= 65536u) { ok = false; break; }
+                hmeta3[u] = (p->wh.left[u] >> 1) | (it->second << 16);
+            }
+            if (ok) {
+                while (wg2.size() & 3u) wg2.push_back(0.0f);             // (staged into LDS in 16-byte pieces)
+                p->h_two_groups = g2_max; p->h_wg2_floats = static_cast<uint32_t>(wg2.size());
+            }
+        }
+    }
 
     if ((rc = upload(p->wv.left, &p->d_v_left)) || (rc = upload(p->wv.count, &p->d_v_count)) ||
         (rc = upload(p->wv.offset, &p->d_v_off)) || (rc = upload(p->wv.w, &p->d_v_w)) ||
@@ -710,6 +755,7 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
         (rc = upload(p->wh.offset, &p->d_h_off)) || (rc = upload(p->wh.w, &p->d_h_w)) || (rc = upload(wu, &p->d_h_wu)) || (rc = upload(hmeta, &p->d_h_meta)))
         return rc;
     if (p->h_fast_groups && ((rc = upload(wg, &p->d_h_wg)) || (rc = upload(hmeta2, &p->d_h_meta2)))) return rc;
+    if (p->h_two_groups && ((rc = upload(wg2, &p->d_h_wg2)) || (rc = upload(hmeta3, &p->d_h_meta3)))) return rc;
 
     p->slots = max_live_rows(p->wv);
     VSchedule probe;
@@ -733,6 +779,15 @@ void ifhip_resample_plan_destroy(ifhip_resample_plan* plan) { delete plan; }
 
 int ifhip_resample_plan_kernel_kind(const ifhip_resample_plan* plan, int in_alpha_meaningful) {
     return (plan && plan->fused_possible && plan->sets[in_alpha_meaningful ? 1 : 0].ok) ? 0 : 1;
+}
+
+// What the fast horizontal pass of the fused kernel would run for this plan: groups of four source columns per output
+// (0: not available) and groups of two (0: not available or not fewer taps); see ifhip_resample_plan_create.
+int ifhip_resample_plan_horizontal_groups(const ifhip_resample_plan* plan, uint32_t* four_column_groups, uint32_t* two_column_groups) {
+    if (!plan) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null plan");
+    if (four_column_groups) *four_column_groups = plan->h_fast_groups;
+    if (two_column_groups) *two_column_groups = plan->h_two_groups;
+    return IFHIP_OK;
 }
 
 int ifhip_scale_and_render_batch_device(const ifhip_resample_plan* plan, const uint8_t* d_in, size_t in_image_bytes,

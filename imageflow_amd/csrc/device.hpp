@@ -38,7 +38,8 @@ struct ResampleArgs {
     // horizontal tables (fused kernel): per output column {left, taps, first weight (float index into h_wu)}
     const uint32_t* h_meta2;         // fast horizontal pass (h_groups > 0): [out_w] first 4-column group | weight row id << 16
     uint32_t h_groups;               // G in 1..4: every output runs exactly G 4-tap groups (rows zero-padded to G groups,
-                                     // h_wu holds them at a fixed pitch of G*4 floats); 0: per-output group counts (h_meta)
+                                     // h_wu holds them at a fixed pitch of G*4 floats); 0: per-output group counts (h_meta);
+                                     // 16 + G2: G2 groups of TWO taps (h_meta2 counts 2-column groups, pitch G2*2 floats)
     const uint4* h_meta;             // [out_w] {first tap column rounded down to 4, 4-tap groups, weight row offset, taps valid in the last group}
     const float* h_wu;               // de-duplicated weight rows: (left & 3) leading zeros, taps, zero pad to 4; 16-B aligned
     uint32_t h_wu_floats;            // size of h_wu

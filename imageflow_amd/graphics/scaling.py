@@ -35,6 +35,13 @@ class ResamplePlan:
     def handle(self):
         return self._h
 
+    def horizontal_groups(self):
+        """(groups of four source columns, groups of two) of the fused kernel's fast horizontal pass; 0 = not available."""
+        import ctypes as C
+        four, two = C.c_uint32(), C.c_uint32()
+        _native.check(_native.lib().ifhip_resample_plan_horizontal_groups(self._h, C.byref(four), C.byref(two)))
+        return four.value, two.value
+
     def kernel_kind(self, alpha_meaningful=False):
         return _native.lib().ifhip_resample_plan_kernel_kind(self._h, int(alpha_meaningful))
 

@@ -125,6 +125,11 @@ IFHIP_API int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in
 IFHIP_API void ifhip_resample_plan_destroy(ifhip_resample_plan* plan);
 /* introspection for tests/bench: 0 = fused single-pass kernel, 1 = generic two-pass kernels */
 IFHIP_API int ifhip_resample_plan_kernel_kind(const ifhip_resample_plan* plan, int in_alpha_meaningful);
+/* Diagnostic: the fused kernel's fast horizontal pass for this plan -- groups of four source columns per output (0: some
+ * output needs more than four groups, the general pass runs) and groups of two (0: not available, or more than two thirds
+ * of the taps; used for BGRA sources without meaningful alpha). */
+IFHIP_API int ifhip_resample_plan_horizontal_groups(const ifhip_resample_plan* plan, uint32_t* four_column_groups,
+                                                    uint32_t* two_column_groups);
 
 /*
  * n_images independent frames, image i at d_in + i*in_image_bytes / d_canvas + i*canvas_image_bytes.

@@ -374,3 +374,33 @@ def test_auto_mode_with_the_banded_kernel_switched_on(mode, debug_switch):
     run_case(200, 200, 400, 400, alpha=True, filt=Filter.Hermite)     # fused in mode 1, banded in mode 2
     run_case(384, 216, 20, 20, alpha=False)                   # a down-scale the fused kernel takes in both modes
     run_case(640, 360, 7, 4, alpha=True)                      # too many live rows for the fused kernel, too many source rows per band?
+
+
+@pytest.mark.parametrize("case", [(1600, 90, 1200, 68, Filter.Robidoux, 4), (400, 300, 300, 225, Filter.Robidoux, 4),
+                                  (640, 48, 533, 40, Filter.Hermite, 2), (200, 120, 400, 240, Filter.Hermite, 2),
+                                  (8000, 24, 6000, 18, Filter.Robidoux, 4), (333, 100, 250, 75, Filter.CatmullRom, 4)])
+def test_two_column_groups_of_the_fast_horizontal_pass(case):
+    """Windows of a few taps (ratios below ~1.6, up-scales): the fast horizontal pass runs groups of TWO source columns where
+    that computes at most two thirds of the taps per output (csrc/api.cpp, resample_fused.hip FG >= 16) -- BGRA sources without
+    alpha; same taps in the same order, so the oracle's bytes and f32 values, also in a sub-rectangle of the canvas, over
+    several column strips (8000 wide) and with several frames per workgroup.  With alpha the four-column form runs."""
+    iw, ih, ow, oh, filt, g2 = case
+    p = run_case(iw, ih, ow, oh, filt=filt, alpha=False, n=3, seed=iw + ow)
+    four, two = p.horizontal_groups()
+    assert p.kernel_kind(False) == 0 and two == g2 and 3 * two <= 4 * four, (four, two)
+    run_case(iw, ih, ow, oh, filt=filt, alpha=False, n=2, seed=iw, x=3, y=2, cw=ow + 9, ch=oh + 5,
+             space=WorkingFloatspace.StandardRGB)
+    run_case(iw, ih, ow, oh, filt=filt, alpha=True, n=2, seed=ow, compose=BitmapCompositing.BlendWithSelf)
+
+
+def test_two_column_groups_can_be_switched_off(debug_switch):
+    """The development switch the A/B runs use (`no_two_col`): plans made under it have no two-column tables."""
+    debug_switch("no_two_col", "1")
+    p = ResamplePlan(1600, 90, 1200, 68, Filter.Robidoux, 0.0)
+    assert p.horizontal_groups() == (3, 0)
+
+
+def test_two_column_groups_only_where_they_save_a_third_of_the_taps():
+    assert ResamplePlan(1600, 90, 1200, 68, Filter.Robidoux, 0.0).horizontal_groups() == (3, 4)      # 12 taps or 8
+    assert ResamplePlan(1200, 68, 400, 23, Filter.Robidoux, 0.0).horizontal_groups() == (4, 0)       # 16 or 12: stays
+    assert ResamplePlan(3840, 216, 1600, 90, Filter.Robidoux, 0.0).horizontal_groups() == (3, 0)     # 12 or 12
