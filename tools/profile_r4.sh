@@ -62,12 +62,19 @@ for W in cfg5 cfg2-alpha; do
 done
 fi
 
-# 3. the other resample shapes (kernel unchanged since round 2 apart from the gather addresses): bench line + kernel stats
+# 3. the other resample shapes (this round: output columns dealt to the lane groups of ds_read_b128, two-column groups): bench line + kernel stats
 if want 3; then
 for W in cfg3-l0 cfg3-l1 cfg3-l2 cfg3-l3 cfg4-resize cfg1-resize up2-hermite up3-robidoux; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- python bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline > $SUM/bench_$W.json 2> $OUT/trace_$W.err
   find $OUT/trace_$W -name '*kernel_stats.csv' -exec sh -c "head -1 {} > $SUM/${W}_kernel_stats.csv; grep -E 'fused_resample|generic' {} >> $SUM/${W}_kernel_stats.csv" \;
   rm -rf $OUT/trace_$W
+done
+# counters of the two moderate-ratio shapes this round's changes aim at (LDS busy / bank conflicts / VALU)
+for W in cfg3-l0 cfg3-l1; do
+  { echo "# rocprofv3 --pmc passes, python bench.py --workload $W --steps 6 --warmup 2 --no-cpu-baseline, kernel fused_resample"
+    for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+      pmc_pass $W fused_resample "$C" -- python bench.py --workload $W --steps 6 --warmup 2 --no-cpu-baseline
+    done; } > $SUM/${W}_pmc.txt
 done
 fi
 
@@ -94,6 +101,7 @@ tools/profile_jpeg_kernels.sh > /dev/null 2>&1; cp gpurun_out/jpeg_kernels/kerne
     done
   done; } > $SUM/cfg4_chain_traffic.txt
 python tools/bench_entropy.py 16 > $SUM/bench_entropy.json 2> /dev/null
+timeout 300 python tools/bench_entropy.py 16 --streams 1,2,4 > $SUM/bench_entropy_streams.json 2> /dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_jpeg -- python tools/bench_entropy.py 16 > /dev/null 2> $OUT/trace_jpeg.err
 find $OUT/trace_jpeg -name '*kernel_stats.csv' -exec sh -c "head -9 {} > $SUM/jpeg_chain_kernel_stats.csv" \;
 { echo "# rocprofv3 --pmc passes on the entropy stage, python tools/bench_entropy.py 1 (one file)"
