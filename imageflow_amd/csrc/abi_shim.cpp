@@ -272,14 +272,13 @@ int parse_filter(const JVal* v, int dflt) {                      // imageflow_ty
 // the library's size-class cache (devmem.cpp) and goes back without a driver call.  Every node ends with a wait for the
 // job's stream, so whatever a job frees is idle (ifhip::QuiescedScope around the whole job).
 std::mutex g_stream_mu;
-struct DeviceQueues { std::vector<hipStream_t> pool; int slots_taken = 0; };
+struct DeviceQueues { std::vector<hipStream_t> pool; int slots_taken = 0; std::condition_variable slot_cv; };
 std::map<int, DeviceQueues> g_queues;                     // per device ordinal: a stream belongs to the device it was created on
 thread_local hipStream_t t_job_stream = nullptr;          // the stream of the job this thread is running (null outside a job)
 // Admission: the runtime spreads a process's streams over a handful of hardware queues, and a job waits for its stream a
 // dozen times; with 64 jobs in flight every small copy queues behind other jobs' long kernels and the job rate FALLS
 // (measured, round 4: 6 750 jobs/s at 16 threads, 1 850 at 64).  Jobs beyond kJobSlots PER DEVICE wait for a slot on the host.
 constexpr int kJobSlots = 20;
-std::condition_variable g_slot_cv;
 // Contexts and devices.  The reference's guidance is one Context per thread (imageflow_abi/src/lib.rs:20-27) and jobs are
 // independent, so a node's GPUs are fed by giving every context a device: with ifhip_shim_spread_contexts(1) a new context
 // takes the next usable device round-robin and all its jobs run there, whichever thread calls (no collective: a job's
@@ -309,7 +308,7 @@ struct StreamLease {
             int slots = kJobSlots;
             if (const char* e = ifhip::debug_switch("job_slots")) slots = std::max(1, std::atoi(e));
             DeviceQueues& q = g_queues[dev];              // (map nodes do not move: the reference survives the wait)
-            while (q.slots_taken >= slots) g_slot_cv.wait(lk);
+            while (q.slots_taken >= slots) q.slot_cv.wait(lk);
             ++q.slots_taken;
             if (!q.pool.empty()) { st = q.pool.back(); q.pool.pop_back(); }
         }
@@ -326,8 +325,8 @@ struct StreamLease {
             DeviceQueues& q = g_queues[dev];
             if (st) q.pool.push_back(st);
             --q.slots_taken;
+            q.slot_cv.notify_one();                       // (one waiter of THIS device; waking all of them cost a third of the job rate at 64 threads)
         }
-        g_slot_cv.notify_all();                           // (waiters of several devices share the condition variable)
     }
 };
 // Before anything of a job goes back to the cache: the job's stream -- the only one its blocks were ever used on -- is idle.

@@ -43,6 +43,9 @@
 #ifndef IFHIP_H_LANE_PERM
 #define IFHIP_H_LANE_PERM 1      // fast horizontal pass: output columns dealt to lanes so that every lane group of a 16-byte LDS read
 #endif                           // holds 16 CONSECUTIVE outputs (see tid_h; 0: lane = column, for A/B)
+#ifndef IFHIP_HP_LANE_PERM
+#define IFHIP_HP_LANE_PERM 1     // the same dealing for the general per-pixel horizontal pass (thumbnail shapes: windows 4.8 chunks apart
+#endif                           // collide three deep in a scattered lane group, two deep in 16 consecutive columns): cfg2 1.325 -> 1.309 ms
 #ifndef IFHIP_H_UNROLL
 #define IFHIP_H_UNROLL 1     // measured: 1 beats 2 and 3 (-1.7%); the chain is not latency-bound per group, code size matters
 #endif
@@ -400,11 +403,25 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             }
         }
     };
+    // Which lane takes which column: a ds_read_b128 is served in four lane groups, {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and
+    // the same +32, one LDS cycle each when the 16 lanes of a group hit 16 different 16-byte slots of the 256-byte bank row.
+    // With lane = column a group's columns span 28 outputs: at 2.4 source pixels per output (cfg3 level 0, cfg4, cfg1) that
+    // is 17 source groups, the first and the last 16 groups apart -- the same slot, an extra cycle on every other read
+    // (counters on cfg3 level 0: 31 % of the LDS cycles were bank conflicts, the LDS busy 67 % of the launch).  So the 32
+    // columns of a half wave are dealt out group-wise: each lane group gets 16 consecutive columns (a span of 9.6 source
+    // groups at that ratio).  A permutation inside aligned blocks of 32 columns: stores still cover whole 128-byte lines,
+    // the 4-byte reads (two groups of 32 consecutive lanes) see the same set of addresses; pixels are unchanged.
+    uint32_t tid_h = tid;
+    if constexpr ((IFHIP_H_LANE_PERM != 0 && FG > 0) || (IFHIP_HP_LANE_PERM != 0 && FG == 0 && PERPIXEL)) {
+        const uint32_t q = (tid >> 2) & 7u;                          // lanes 0-3, 4-7, ... 28-31 -> columns 0-3, 16-19, 20-23, 4-7, 24-27, 8-11, 12-15, 28-31
+        const uint32_t first4 = (0x7326'1540u >> (4u * q)) & 15u;    // column of the quad's first lane, in units of 4
+        tid_h = (tid & ~31u) | (first4 << 2) | (tid & 3u);
+    }
     // Mapping 2: one lane per output PIXEL (all its channels, then encode + store at once, no obuf round trip): used
     // whenever a strip has at least a wave of outputs.
     constexpr bool h_per_pixel = PERPIXEL;
     auto h_run_row_pixels = [&](uint32_t j, const float* vrow) {
-        for (uint32_t ul = tid; ul < n_store; ul += T) {
+        for (uint32_t ul = tid_h; ul < n_store; ul += T) {
             const uint4 m = hmeta[ul];
             const float4* wp = reinterpret_cast<const float4*>((WLDS ? hw_lds : a.h_wu) + m.z);
             const float4* sp = reinterpret_cast<const float4*>(vrow + m.x);       // sub-plane k at sp + k * (plane_pitch / 4)
@@ -426,20 +443,6 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
         }
     };
     // Mapping 2, fast form: two base addresses per output, everything else immediates.
-    // Which lane takes which column: a ds_read_b128 is served in four lane groups, {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and
-    // the same +32, one LDS cycle each when the 16 lanes of a group hit 16 different 16-byte slots of the 256-byte bank row.
-    // With lane = column a group's columns span 28 outputs: at 2.4 source pixels per output (cfg3 level 0, cfg4, cfg1) that
-    // is 17 source groups, the first and the last 16 groups apart -- the same slot, an extra cycle on every other read
-    // (counters on cfg3 level 0: 31 % of the LDS cycles were bank conflicts, the LDS busy 67 % of the launch).  So the 32
-    // columns of a half wave are dealt out group-wise: each lane group gets 16 consecutive columns (a span of 9.6 source
-    // groups at that ratio).  A permutation inside aligned blocks of 32 columns: stores still cover whole 128-byte lines,
-    // the 4-byte reads (two groups of 32 consecutive lanes) see the same set of addresses; pixels are unchanged.
-    uint32_t tid_h = tid;
-    if constexpr (IFHIP_H_LANE_PERM != 0 && FG > 0) {
-        const uint32_t q = (tid >> 2) & 7u;                          // lanes 0-3, 4-7, ... 28-31 -> columns 0-3, 16-19, 20-23, 4-7, 24-27, 8-11, 12-15, 28-31
-        const uint32_t first4 = (0x7326'1540u >> (4u * q)) & 15u;    // column of the quad's first lane, in units of 4
-        tid_h = (tid & ~31u) | (first4 << 2) | (tid & 3u);
-    }
     auto h_run_row_pixels_fast = [&](uint32_t j, const float* vrow, auto static_encode) {
         constexpr uint32_t G = fast_g > 0 ? fast_g : 1;
         for (uint32_t ul = tid_h; ul < n_store; ul += T) {
