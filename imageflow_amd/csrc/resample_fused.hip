@@ -43,6 +43,9 @@
 #ifndef IFHIP_H_LANE_PERM
 #define IFHIP_H_LANE_PERM 1      // fast horizontal pass: output columns dealt to lanes so that every lane group of a 16-byte LDS read
 #endif                           // holds 16 CONSECUTIVE outputs (see tid_h; 0: lane = column, for A/B)
+#ifndef IFHIP_H_META_REGS
+#define IFHIP_H_META_REGS 0      // fast pass: the records of a lane's first two columns in registers (they are the same for every row): experiment
+#endif
 #ifndef IFHIP_HP_LANE_PERM
 #define IFHIP_HP_LANE_PERM 1     // the same dealing for the general per-pixel horizontal pass (thumbnail shapes: windows 4.8 chunks apart
 #endif                           // collide three deep in a scattered lane group, two deep in 16 consecutive columns): cfg2 1.325 -> 1.309 ms
@@ -84,7 +87,8 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     constexpr int C = ALPHA ? 4 : 3;
     constexpr int D = fused_shape(K, C).rows_in_flight;
     constexpr bool PIPE = fused_shape(K, C).pipelined != 0;
-    constexpr bool RE = (IFHIP_REFILL_EARLY & (PIPE ? 1 : 2)) != 0 && IFHIP_DOT4_LUT != 0 && !YCC;   // step order, see the step loop
+    // (bit 2: only the fast-pass instantiations)
+    constexpr bool RE = (IFHIP_REFILL_EARLY & (PIPE ? 1 : 2)) != 0 && ((IFHIP_REFILL_EARLY & 4) == 0 || FG > 0) && IFHIP_DOT4_LUT != 0 && !YCC;   // step order, see the step loop
     constexpr bool PAIR1 = IFHIP_ALPHA_PAIR_ONE != 0 && ALPHA && !YCC && !RE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -443,10 +447,18 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
         }
     };
     // Mapping 2, fast form: two base addresses per output, everything else immediates.
+    uint32_t hm0 = 0u, hm1 = 0u;
+    if constexpr (IFHIP_H_META_REGS != 0 && FG > 0) {
+        hm0 = tid_h < n_u ? hmeta2[tid_h] : 0u;
+        hm1 = tid_h + T < n_u ? hmeta2[tid_h + T] : 0u;
+    }
     auto h_run_row_pixels_fast = [&](uint32_t j, const float* vrow, auto static_encode) {
         constexpr uint32_t G = fast_g > 0 ? fast_g : 1;
-        for (uint32_t ul = tid_h; ul < n_store; ul += T) {
-            const uint32_t m = hmeta2[ul];
+        uint32_t kcol = 0u;
+        for (uint32_t ul = tid_h; ul < n_store; ul += T, ++kcol) {
+            uint32_t m;
+            if constexpr (IFHIP_H_META_REGS != 0) m = kcol == 0u ? hm0 : (kcol == 1u ? hm1 : hmeta2[ul]);
+            else m = hmeta2[ul];
             f32x2 h01 = {0.0f, 0.0f}, h23 = {0.0f, 0.0f};
             float h2 = 0.0f;
             if constexpr (TWO) {
