@@ -285,6 +285,22 @@ constexpr int kJobSlots = 20;
 // outputs are host buffers).  Without it (the default) a context follows the calling thread's current device, as before.
 std::atomic<int> g_spread_contexts{0};
 std::atomic<uint32_t> g_context_counter{0};
+// HIP ordinals of the gfx950 devices, asked of the driver once (hipGetDeviceProperties fills a kilobyte struct per call, and
+// a service creates thousands of contexts a second)
+const std::vector<int>& usable_devices() {
+    static const std::vector<int> list = [] {
+        std::vector<int> v;
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return v; }
+        for (int i = 0; i < n; ++i) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, i) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) v.push_back(i);
+            else (void)hipGetLastError();
+        }
+        return v;
+    }();
+    return list;
+}
 struct DeviceScope {                                      // the calling thread on the context's device for one call
     int prev = -1;
     bool switched = false;
@@ -1695,8 +1711,8 @@ struct imageflow_context* imageflow_context_create(uint32_t major, uint32_t mino
     try {
         imageflow_context* c = new imageflow_context;
         if (g_spread_contexts.load(std::memory_order_relaxed)) {
-            const int n = ifhip_device_count();
-            if (n > 0) c->device.store(static_cast<int>(g_context_counter.fetch_add(1, std::memory_order_relaxed) % static_cast<uint32_t>(n)), std::memory_order_relaxed);
+            const std::vector<int>& devs = usable_devices();
+            if (!devs.empty()) c->device.store(devs[g_context_counter.fetch_add(1, std::memory_order_relaxed) % devs.size()], std::memory_order_relaxed);
         }
         return c;
     } catch (...) { return nullptr; }
@@ -1760,7 +1776,8 @@ void ifhip_shim_spread_contexts(int enable) { g_spread_contexts.store(enable ? 1
 // ordinal is not a usable device
 bool ifhip_shim_context_set_device(struct imageflow_context* c, int ordinal) {
     CTX_OR_ABORT(c);
-    if (ordinal >= ifhip_device_count() || ordinal < -1) {
+    const std::vector<int>& devs = usable_devices();
+    if (ordinal != -1 && std::find(devs.begin(), devs.end(), ordinal) == devs.end()) {
         std::lock_guard<std::mutex> lk(c->mu);
         c->set_error(kArgumentInvalid, "InvalidArgument: device ordinal " + std::to_string(ordinal) + " is not a usable gfx950 device");
         return false;
