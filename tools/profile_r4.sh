@@ -65,7 +65,7 @@ fi
 # 3. the other resample shapes (this round: output columns dealt to the lane groups of ds_read_b128, two-column groups): bench line + kernel stats
 if want 3; then
 for W in cfg3-l0 cfg3-l1 cfg3-l2 cfg3-l3 cfg4-resize cfg1-resize up2-hermite up3-robidoux; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- python bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline > $SUM/bench_$W.json 2> $OUT/trace_$W.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- python bench.py --workload $W --steps 60 --warmup 5 --no-cpu-baseline > $SUM/bench_$W.json 2> $OUT/trace_$W.err
   find $OUT/trace_$W -name '*kernel_stats.csv' -exec sh -c "head -1 {} > $SUM/${W}_kernel_stats.csv; grep -E 'fused_resample|generic' {} >> $SUM/${W}_kernel_stats.csv" \;
   rm -rf $OUT/trace_$W
 done
