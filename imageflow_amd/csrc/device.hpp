@@ -98,10 +98,16 @@ struct BandedArgs {
 #ifndef IFHIP_NARROW_PX
 #define IFHIP_NARROW_PX 4    // 2 = 1024 lanes x 2 pixels (8-byte loads): parity-tested, measured 1.3 % slower on cfg5 (instruction-bound)
 #endif
+#ifndef IFHIP_PIPE_D
+#define IFHIP_PIPE_D 4       // rows in flight of the pipelined 1024-lane shape
+#endif
+#ifndef IFHIP_PIPE_ON
+#define IFHIP_PIPE_ON 1      // 0: that shape without the conversion double buffer (frees 12 registers for rows in flight)
+#endif
 struct FusedShape { int threads, rows_in_flight, pipelined, px; };   // px: source pixels per lane (16- or 8-byte loads)
 constexpr FusedShape fused_shape(int K, int channels) {
     // thresholds read off the compiler's register report (python -m imageflow_amd.kernel_report): no variant spills
-    return (channels == 3 ? K <= 4 : K <= 2) ? FusedShape{1024, 4, 1, 4}
+    return (channels == 3 ? K <= 4 : K <= 2) ? FusedShape{1024, IFHIP_PIPE_D, IFHIP_PIPE_ON, 4}
          : (channels == 3 ? K <= 5 : K <= 4) ? FusedShape{1024, IFHIP_PLAIN_D, 0, 4}
                                              : FusedShape{IFHIP_NARROW_PX == 2 ? 1024 : 512, (IFHIP_NARROW_PX == 2 && K == 8) ? 6 : (K <= 6 ? IFHIP_NARROW_D : 8), 1, IFHIP_NARROW_PX};   // (K = 8: 6 rows, else the alpha variants spill)
 }
