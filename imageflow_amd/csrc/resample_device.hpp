@@ -155,7 +155,14 @@ __device__ __forceinline__ void store_pixel(const ResampleArgs& a, uint32_t img,
     // (other compositing modes) where no load was issued -- and each such wait drains the source rows in flight.
     if (ALPHA && a.mode == IFHIP_BLEND_WITH_SELF)
         asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(dst) : "v"(cw) : "memory");
+#if defined(IFHIP_EXP_PIXEL_NO_STORE)       // timing experiment: everything but the canvas store (NOT a product path)
+    const uint32_t word = render_pixel<ALPHA, LIN>(a, p0, p1, p2, pa, dst, tb);
+    if (word == 0x12345678u && p0 == 123.0f) store_u32_untracked(cw, word);
+#elif defined(IFHIP_EXP_PIXEL_NO_ENCODE)    // timing experiment: the chains' result stored unencoded (NOT a product path)
+    store_u32_untracked(cw, __float_as_uint(p0) ^ __float_as_uint(p1) ^ __float_as_uint(p2));
+#else
     store_u32_untracked(cw, render_pixel<ALPHA, LIN>(a, p0, p1, p2, pa, dst, tb));
+#endif
     if (a.f32_dump) {
         float4* d = reinterpret_cast<float4*>(a.f32_dump) + (static_cast<size_t>(img) * a.out_h + j) * a.out_w + u;
         store_f32x4_untracked(d, p0, p1, p2, ALPHA ? pa : 1.0f);
