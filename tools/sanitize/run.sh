@@ -16,7 +16,9 @@ printf '__attribute__((section(".hip_fatbin"))) const char %s[64] = {0};\n' "$SY
 gcc -c fatbin_stub.c -o fatbin_stub.o
 g++ $SAN $INC -c "$ROOT/tools/sanitize/parser_fuzz.cpp" -o parser_fuzz.o
 g++ $SAN -c "$ROOT/tools/sanitize/stubs.cpp" -o stubs.o
-/opt/rocm/lib/llvm/bin/clang++ -fsanitize=address,undefined -o parser_fuzz parser_fuzz.o entropy_host.o stubs.o fatbin_stub.o -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lpthread
+# (the handles' memory comes from the library's cache: devmem.cpp, host-only like the rest; debug_switch lives in weights.cpp)
+/opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 --cuda-host-only $SAN $INC -c "$ROOT/imageflow_amd/csrc/devmem.cpp" -o devmem_host.o 2>/dev/null
+/opt/rocm/lib/llvm/bin/clang++ -fsanitize=address,undefined -o parser_fuzz parser_fuzz.o entropy_host.o devmem_host.o stubs.o fatbin_stub.o -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lpthread
 python3 - "$ROOT" <<'PY'
 import sys, numpy as np
 z = np.load(sys.argv[1] + "/tests/golden/jpeg_entropy_cases.npz")
