@@ -26,6 +26,7 @@ hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, ui
                           hipStream_t st);
 hipError_t launch_banded(const ResampleArgs& a, bool alpha, const BandedArgs& b, uint32_t grid_x, size_t lds, hipStream_t st);
 hipError_t launch_read_probe(const uint8_t* d, size_t bytes, uint32_t* sink, hipStream_t st);
+hipError_t launch_mix_probe(const uint8_t* d, uint8_t* out, size_t bytes, uint32_t every, uint32_t* sink, hipStream_t st);
 hipError_t launch_apply_matte(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w, uint32_t h,
                               uint32_t stride, uint32_t matte, float mb, float mg, float mr, float ma,
                               const float* s2l, const uint8_t* l2s, hipStream_t st);
@@ -871,6 +872,37 @@ int ifhip_measure_read_bandwidth(size_t bytes, int iters, double* bytes_per_seco
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
     *bytes_per_second = static_cast<double>(bytes) * iters / (static_cast<double>(ms) * 1e-3);
+    return IFHIP_OK;
+}
+
+int ifhip_measure_mixed_bandwidth(size_t read_bytes, uint32_t read_vectors_per_write, int iters, double* bytes_per_second) {
+    if (!bytes_per_second || iters < 1 || read_bytes < (1u << 20) || read_vectors_per_write < 1u)
+        return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: mixed bandwidth probe");
+    DeviceTables tb;
+    int rc = device_tables(&tb);
+    if (rc) return rc;
+    read_bytes &= ~static_cast<size_t>(4095);
+    const size_t write_cap = read_bytes / read_vectors_per_write + (static_cast<size_t>(64) << 20);   // every workgroup's span keeps its own output span
+    DeviceBuffer a, out, sink;
+    HIP_TRY(a.alloc(read_bytes));
+    HIP_TRY(out.alloc(std::max(write_cap, read_bytes)));
+    HIP_TRY(sink.alloc(8192));
+    HIP_TRY(hipMemset(a.p, 1, read_bytes));
+    HIP_TRY(hipMemset(sink.p, 0, 8192));
+    HIP_TRY(launch_mix_probe(static_cast<const uint8_t*>(a.p), static_cast<uint8_t*>(out.p), read_bytes, read_vectors_per_write, static_cast<uint32_t*>(sink.p), nullptr));   // warm-up
+    EventPair ev;
+    HIP_TRY(ev.create());
+    HIP_TRY(hipEventRecord(ev.e0, nullptr));
+    for (int i = 0; i < iters; ++i)
+        HIP_TRY(launch_mix_probe(static_cast<const uint8_t*>(a.p), static_cast<uint8_t*>(out.p), read_bytes, read_vectors_per_write, static_cast<uint32_t*>(sink.p), nullptr));
+    HIP_TRY(hipEventRecord(ev.e1, nullptr));
+    HIP_TRY(hipEventSynchronize(ev.e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+    uint32_t stores_per_lane = 0;
+    HIP_TRY(hipMemcpy(&stores_per_lane, static_cast<const uint32_t*>(sink.p) + 1024, 4, hipMemcpyDeviceToHost));
+    const double written = static_cast<double>(stores_per_lane) * 16.0 * 1024.0 * (256.0 * 8.0);
+    *bytes_per_second = (static_cast<double>(read_bytes) + written) * iters / (static_cast<double>(ms) * 1e-3);
     return IFHIP_OK;
 }
 

@@ -410,6 +410,45 @@ __global__ __launch_bounds__(1024) void read_probe_kernel(const probe_vec_t* __r
     if (acc == 0x9e3779b9u) sink[threadIdx.x] = acc;          // practically never true: keeps the loads alive
 }
 
+// The same with writes mixed in: one 16-byte vector per lane stored for every `every` vectors it read (the resample
+// kernels of the moderate ratios write 15 - 36 % of their bytes).  The store goes through inline asm for the reason the
+// canvas stores do (resample_device.hpp): loads and stores share vmcnt, and a store the compiler tracks drains the loads
+// in flight.  sink[1024] receives the stores one lane of workgroup 0 made (every workgroup makes as many, give or take one).
+__global__ __launch_bounds__(1024) void mix_probe_kernel(const probe_vec_t* __restrict__ src, probe_vec_t* __restrict__ dst, size_t n_vec,
+                                                         uint32_t every, uint32_t* sink) {
+    const size_t per_wg = (n_vec + gridDim.x - 1) / gridDim.x;
+    const size_t lo = per_wg * blockIdx.x;
+    size_t hi = lo + per_wg;
+    if (hi > n_vec) hi = n_vec;
+    uint32_t acc = 0, since = 0, stores = 0;
+    size_t w = lo + threadIdx.x;
+    typedef __attribute__((address_space(1))) probe_vec_t gout;
+    for (size_t i = lo + threadIdx.x; i + 3u * 1024u < hi; i += 4u * 1024u) {
+        const probe_vec_t a = __builtin_nontemporal_load(src + i);
+        const probe_vec_t b = __builtin_nontemporal_load(src + i + 1024u);
+        const probe_vec_t c = __builtin_nontemporal_load(src + i + 2048u);
+        const probe_vec_t d = __builtin_nontemporal_load(src + i + 3072u);
+        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+        since += 4u;
+        while (since >= every) {                                 // (wave-uniform)
+            since -= every;
+            const probe_vec_t ov = {acc, acc, acc, acc};
+            gout* op = reinterpret_cast<gout*>(reinterpret_cast<uintptr_t>(dst + w));
+            asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(op), "v"(ov) : "memory");
+            w += 1024u;
+            ++stores;
+        }
+    }
+    if (acc == 0x9e3779b9u) sink[threadIdx.x] = acc;
+    if (blockIdx.x == 0u && threadIdx.x == 0u) sink[1024] = stores;
+}
+
+hipError_t launch_mix_probe(const uint8_t* d, uint8_t* out, size_t bytes, uint32_t every, uint32_t* sink, hipStream_t st) {
+    hipLaunchKernelGGL(mix_probe_kernel, dim3(256u * 8u), dim3(1024), 0, st, reinterpret_cast<const probe_vec_t*>(d),
+                       reinterpret_cast<probe_vec_t*>(out), bytes / 16u, every, sink);
+    return hipGetLastError();
+}
+
 hipError_t launch_read_probe(const uint8_t* d, size_t bytes, uint32_t* sink, hipStream_t st) {
     hipLaunchKernelGGL(read_probe_kernel, dim3(256u * 8u), dim3(1024), 0, st, reinterpret_cast<const probe_vec_t*>(d), bytes / 16u, sink);
     return hipGetLastError();

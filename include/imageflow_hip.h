@@ -450,6 +450,10 @@ IFHIP_API int ifhip_measure_copy_bandwidth(size_t bytes, int iters, double* byte
 /* read-only streaming probe (bytes read per second; 16-byte non-temporal loads, one XOR per load): the yardstick for
  * the resample kernel, whose traffic is 99.5 % reads */
 IFHIP_API int ifhip_measure_read_bandwidth(size_t bytes, int iters, double* bytes_per_second);
+/* the same with writes mixed in: one 16-byte vector stored per `read_vectors_per_write` vectors read (bytes read + written
+ * per second) -- the yardstick for the moderate ratios, whose canvas stores are 15 - 36 % of their bytes: reads and writes
+ * together run at 5.3 - 5.5 TB/s on MI355X where reads alone reach 7 */
+IFHIP_API int ifhip_measure_mixed_bandwidth(size_t read_bytes, uint32_t read_vectors_per_write, int iters, double* bytes_per_second);
 
 #ifdef __cplusplus
 }
