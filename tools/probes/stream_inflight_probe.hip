@@ -50,7 +50,13 @@ __global__ void __launch_bounds__(1024) stream_kernel(const u32x4* __restrict__ 
                 // compiler sees makes it drain the counter -- vmcnt(0) -- at the next use of a loaded value)
                 const u32x4 ov = {acc, acc, acc, acc};
                 gout* op = obase + wrow * pitch;
+#ifdef STORE4                                                     // the same 16 KiB as four 4-byte stores per lane (the product's canvas stores are 4 bytes per lane)
+                uint32_t* o4 = reinterpret_cast<uint32_t*>(dst + static_cast<size_t>(blockIdx.x) * rows_per_wg * pitch + wrow * pitch) + threadIdx.x;
+                asm volatile("global_store_dword %0, %1, off nt\n\tglobal_store_dword %2, %1, off nt\n\tglobal_store_dword %3, %1, off nt\n\tglobal_store_dword %4, %1, off nt"
+                             : : "v"(o4), "v"(acc), "v"(o4 + 1024), "v"(o4 + 2048), "v"(o4 + 3072) : "memory");
+#else
                 asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(op), "v"(ov) : "memory");
+#endif
                 ++wrow;
             }
             if (pause > 0 && ++since == period) {                // wave-uniform: the "pixel loop" -- no loads are issued in here
