@@ -26,7 +26,21 @@ the final gather ships the FILES -- ~0.26 bytes per pixel instead of 4 (1.38 GB 
 --outputs bgra keeps the round-3 form (raw levels gathered).  `roofline` stays the four resample launches; the line
 also carries what a step costs without the encoders.
 
+--workload cfg4 is BASELINE config 4: 3840x2160 4:2:0 q85 baseline JPEG files (SURVEY.md 8d's recipe: the gradient of
+bench_codecs.rs:24-41 and a noise variant, written once on the host with Pillow) -> GPU entropy decode -> 4/8 IDCT with the
+spatial sRGB luma scaler + YCbCr (what the reference's decoder is asked for when the job wants 800 px:
+codecs/mozjpeg_decoder.rs:295-420,588-618) -> 800x450 Robidoux (flow/nodes/scale_render.rs:304-313), 64 files per GPU in
+batches of 16 with --batches-in-flight host threads / HIP streams (default 4).  The compressed scans are resident in HBM
+(un-stuffed, as the entropy stage reads them) when the timed region starts.  value = source megapixels through the WHOLE
+chain per second; `roofline` is the pixel stage + resize call alone on SURVEY 8d's 26 323 584 bytes per image (the entropy
+walk is latency-bound bit-serial work: HBM is not its yardstick); cpu_baseline = libjpeg-turbo (Pillow) DCT-domain 1/2
+decode + resize on all host cores.  Images are sharded in contiguous blocks like every other workload and the finished
+800x450 outputs are gathered once, after the last step.
+
 Prints ONE JSON line (rank 0).  value = source megapixels resized per second over all ranks, inputs already in HBM.
+After the timed region (never inside it) rank 0 renders frames of the last step's output again on the CPU oracle and
+compares: `parity_checked` (BASELINE config 2: "... bit-exact check vs CPU").  --selfcheck (N > 1): every rank's first
+gathered frame is compared with one rendered locally on rank 0 -- catches a gather that lands at the wrong offset.
 """
 import argparse
 import json
@@ -64,6 +78,8 @@ WORKLOADS = {
     # the whole export_4_sizes job: the tuple describes level 0, PYRAMID the chain
     "cfg3": (3840, 2160, 1600, 900, "Robidoux", 0.0, False, "ReplaceSelf", 0, 128),
 }
+CFG4 = {"in_w": 3840, "in_h": 2160, "dec_w": 1920, "dec_h": 1080, "out_w": 800, "out_h": 450, "files_per_gpu": 64, "batch": 16,
+        "bytes_per_image": 26_323_584}                             # coefficients + quant tables in, 800x450 BGRA out
 PYRAMID = [("src", "1600", 1600, 900), ("1600", "1200", 1200, 675), ("1600", "800", 800, 450), ("1200", "400", 400, 225)]
 PYRAMID_BYTES_PER_IMAGE = 58_737_600
 PYRAMID_WRITE_BYTES_PER_IMAGE = 10_800_000                         # of which written: the four levels (1600x900 + 1200x675 + 800x450 + 400x225) x 4 B
@@ -165,6 +181,309 @@ def host_dropin_rate(torch, seconds=3.0):
                     "PCIe inclusive (persistent pinned staging + per-thread stream); never `value`"}
 
 
+def resample_parity(torch, wl, inp, canvas, frames):
+    """After the timed region: frames of the LAST step's canvas rendered again by the CPU oracle (oracle/if_oracle.c) from
+    the same device-resident inputs; BGRA8 must be equal byte for byte (BASELINE cfg2: "bit-exact check vs CPU")."""
+    import numpy as np
+    from imageflow_amd.graphics.bitmaps import BitmapCompositing
+    from imageflow_amd.graphics.weights import Filter
+    from tests import util as U
+    in_w, in_h, out_w, out_h = wl[:4]
+    got = canvas.to_numpy()
+    equal, checked = True, []
+    for i in sorted(set(frames)):
+        src = inp.data[i].cpu().numpy().reshape(1, in_h, inp.stride)
+        exp = np.zeros((1, out_h, got.shape[2]), np.uint8)
+        U.oracle_render(src, in_w, in_h, exp, out_w, out_h, 0, 0, out_w, out_h, filter_id=int(Filter[wl[4]]), sharpen=wl[5],
+                        compositing=int(BitmapCompositing[wl[7]]), matte_bgra=wl[8], alpha_meaningful=wl[6])
+        equal = equal and bool(np.array_equal(got[i][:, :4 * out_w], exp[0][:, :4 * out_w]))
+        checked.append(int(i))
+    return {"frames": len(checked), "which": checked, "equal": equal, "against": "oracle.scale_and_render (oracle/if_oracle.c), BGRA8 byte for byte"}
+
+
+def pyramid_parity(torch, inp, levels):
+    """The same for the export_4_sizes job: frame 0's four levels against the oracle's chain from the same source."""
+    import numpy as np
+    from tests import util as U
+    cur = {"src": (inp.data[0].cpu().numpy().reshape(1, inp.h, inp.stride), inp.w, inp.h)}
+    equal = True
+    for a, b, w, h in PYRAMID:
+        src, sw, sh = cur[a]
+        exp = np.zeros((1, h, U.stride_for(w)), np.uint8)
+        U.oracle_render(src, sw, sh, exp, w, h, 0, 0, w, h)
+        cur[b] = (exp, w, h)
+        equal = equal and bool(np.array_equal(levels[b].to_numpy()[0][:, :4 * w], exp[0][:, :4 * w]))
+    return {"frames": 1, "which": [0], "levels": len(PYRAMID), "equal": equal,
+            "against": "oracle.scale_and_render chained as the job chains its levels, BGRA8 byte for byte"}
+
+
+def cfg4_files(first_index, n):
+    """SURVEY.md 8d's cfg4 inputs: 3840x2160 baseline 4:2:0 q85 files of the gradient of bench_codecs.rs:24-41
+    (R = 255 x / w, G = 255 y / h, B = 3 (x + y) & 255, shifted per file) -- every second file with uniform noise of +-12
+    added -- written on the host with Pillow (libjpeg-turbo, optimize=False).  File k's content depends on k only."""
+    import io
+    import numpy as np
+    from PIL import Image
+    w, h = CFG4["in_w"], CFG4["in_h"]
+    y, x = np.mgrid[0:h, 0:w].astype(np.int32)
+    files = []
+    for k in range(first_index, first_index + n):
+        rgb = np.stack([((x + 7 * k) % w) * 255 // w, ((y + 5 * k) % h) * 255 // h, ((x + y + k) * 3) & 255], -1).astype(np.int16)
+        if k & 1:
+            rgb = rgb + np.random.default_rng(4000 + k).integers(-12, 13, size=rgb.shape, dtype=np.int16)
+        buf = io.BytesIO()
+        Image.fromarray(np.clip(rgb, 0, 255).astype(np.uint8)).save(buf, "JPEG", quality=85, subsampling="4:2:0", optimize=False)
+        files.append(buf.getvalue())
+    return files
+
+
+def _cfg4_cpu_one(data):
+    import io
+    from PIL import Image
+    im = Image.open(io.BytesIO(data))
+    im.draft("RGB", (CFG4["dec_w"], CFG4["dec_h"]))                # libjpeg-turbo's DCT-domain 1/2 decode, as the reference's decoder hint
+    im = im.convert("RGB").resize((CFG4["out_w"], CFG4["out_h"]), Image.BICUBIC)
+    return im.size[0]
+
+
+def cfg4_cpu_baseline(files, sample_seconds=12.0):
+    """libjpeg-turbo (Pillow) decode at 1/2 scale + bicubic resize to 800x450 on every host core, one file per process at a
+    time, on a bounded sample of the run's own files.  Not the reference's Rust / mozjpeg path (no cargo here) and not a
+    bit-exact stand-in for it: a yardstick for "what the host's cores do with these files", next to the 50.1 MP/s per core
+    the reference publishes for its own full decode (benchmarks/c-vs-zen-codecs-2026-04-15-singlethread.txt:17)."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    _cfg4_cpu_one(files[0])
+    t1 = time.perf_counter() - t0
+    procs = min(cores, 64)
+    per_pass = max(procs, len(files))
+    work = [files[i % len(files)] for i in range(per_pass)]
+    with mp.get_context("fork").Pool(procs) as pool:
+        pool.map(_cfg4_cpu_one, work[:procs])                      # workers up, libraries loaded
+        t0 = time.perf_counter()
+        passes = 0
+        while time.perf_counter() - t0 < sample_seconds and passes < 50:
+            pool.map(_cfg4_cpu_one, work, chunksize=1)
+            passes += 1
+        dt = time.perf_counter() - t0
+    mpix = passes * per_pass * CFG4["in_w"] * CFG4["in_h"] / 1e6
+    return {"value": round(mpix / dt, 1), "unit": "MP/s", "cores": procs, "kind": "port",
+            "single_thread_MPps": round(CFG4["in_w"] * CFG4["in_h"] / 1e6 / t1, 1),
+            "sample": f"{passes} passes over {per_pass} of the run's files (3840x2160 4:2:0 q85): Pillow/libjpeg-turbo draft decode to "
+                      f"1920x1080 + bicubic resize to 800x450, {procs} processes on {cores} cores, {dt:.1f} s wall",
+            "note": "libjpeg-turbo through Pillow, not imageflow_core's mozjpeg decoder + zenresize (no Rust toolchain on this box): a host "
+                    "yardstick, never a target; the reference's own published full decode is 50.1 MP/s on one core",
+            "published_reference_decode_MPps_one_core": 50.1}
+
+
+def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun):
+    """BASELINE config 4 (see the module docstring): files -> entropy decode -> 4/8 pixel stage -> 800x450, sharded."""
+    import threading
+
+    import numpy as np
+
+    from imageflow_amd.codecs import mozjpeg_decoder as D
+    from imageflow_amd.graphics.bitmaps import Bitmap
+    from imageflow_amd.graphics.scaling import ScaleAndRenderParams
+    from imageflow_amd.sharding import gather_to_root, max_over_ranks, shard_range
+    distributed = world > 1
+    w, h, ow, oh = CFG4["in_w"], CFG4["in_h"], CFG4["out_w"], CFG4["out_h"]
+    if args.scaling == "strong":
+        total = args.total_frames
+        lo, hi = shard_range(total, rank, world)
+    else:
+        per = args.frames or CFG4["files_per_gpu"]
+        total = per * world
+        lo, hi = rank * per, (rank + 1) * per
+    n = hi - lo
+    if n < 1:
+        raise SystemExit(f"rank {rank} owns no files ({total} files over {world} ranks)")
+    n_max = -(-total // world)
+    T = max(1, min(args.batches_in_flight, n))
+    ranks_info = [{"rank": rank, "device": torch.cuda.get_device_name(local_rank), "local_rank": local_rank}]
+    if distributed:
+        objs = [None] * world
+        dist.all_gather_object(objs, ranks_info[0])
+        ranks_info = objs
+    files = cfg4_files(lo, n)
+    torch.zeros(1, device=dev).item()
+    info = ScaleAndRenderParams(0, 0, ow, oh)
+    out_all = Bitmap.create_u8(n_max, ow, oh, dev)                 # this rank's outputs, gather-slot sized
+    # T host threads, each with its contiguous share of the rank's files as one entropy batch, its own HIP stream and
+    # buffers: while one batch's synchronisation tail leaves CUs idle, the next one's dense passes fill them
+    ctx = []
+    for t in range(T):
+        a, b = shard_range(n, t, T)
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            ent = D.JpegEntropyBatch(files[a:b], device=str(dev))
+            coef = ent.read_coefficients()
+            stage = D.JpegPixelStage(w, h, 3, ent.h_samp, ent.v_samp, b - a, device=str(dev), scale_num=4, luma_spatial=True, luma_srgb=True)
+            qt = torch.from_numpy(ent.qt.view(np.int16)).to(dev)
+            small = Bitmap(out_all.data[a:b], ow, oh, out_all.stride, False)
+            fused = stage.read_frames_into(coef, qt, small, info)
+        ctx.append({"stream": st, "ent": ent, "coef": coef, "stage": stage, "qt": qt, "small": small, "fused": fused, "n": b - a})
+    torch.cuda.synchronize()
+    compressed = sum(len(f) for f in files)
+
+    def chain(c, steps):
+        with torch.cuda.stream(c["stream"]):
+            for _ in range(steps):
+                c["ent"].read_coefficients(c["coef"])
+                c["stage"].read_frames_into(c["coef"], c["qt"], c["small"], info)
+            c["stream"].synchronize()
+
+    def run_steps(steps):
+        th = [threading.Thread(target=chain, args=(c, steps)) for c in ctx[1:]]
+        for t in th:
+            t.start()
+        chain(ctx[0], steps)
+        for t in th:
+            t.join()
+
+    mode = "none" if (not distributed or args.no_gather or args.gather == "none") else "final"
+    gathered = None
+    if mode == "final" and rank == 0:
+        gathered = torch.empty((world, n_max, out_all.image_bytes), dtype=torch.uint8, device="cpu" if dryrun else dev)
+    gather_note = "none" if mode == "none" else "rccl gather of the 800x450 outputs to rank 0 once, at the end of the timed region (the same gather ran once during warm-up)"
+    gathers = {"warmup": 0, "timed": 0}
+
+    def final_gather(phase):
+        nonlocal gather_note
+        try:
+            gather_to_root(out_all.data.cpu() if dryrun else out_all.data, 0, out=gathered if rank == 0 else None)
+            gathers[phase] += 1
+        except Exception as e:  # noqa: BLE001
+            gather_note = f"final rccl gather failed: {type(e).__name__}: {e}"
+
+    run_steps(args.warmup)
+    torch.cuda.synchronize()
+    if mode == "final":
+        final_gather("warmup")
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize()
+    t_compute = time.perf_counter() - t0
+    if mode == "final":
+        final_gather("timed")
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    compute_s = max_over_ranks(t_compute, dev)
+
+    # the pixel stage + resize call alone (SURVEY 8d's unit: coefficient planes in, 800x450 out), hipEvents on its stream,
+    # one batch at a time so that nothing else shares the device
+    launches = max(3, min(args.steps, 20))
+    px_ms, ent_ms = 0.0, 0.0
+    for c in ctx:
+        with torch.cuda.stream(c["stream"]):
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record(c["stream"])
+            for _ in range(launches):
+                c["stage"].read_frames_into(c["coef"], c["qt"], c["small"], info)
+            e1.record(c["stream"])
+            for _ in range(launches):
+                c["ent"].read_coefficients(c["coef"])
+            e2.record(c["stream"])
+            c["stream"].synchronize()
+            px_ms += e0.elapsed_time(e1) / launches
+            ent_ms += e1.elapsed_time(e2) / launches
+    torch.cuda.synchronize()
+
+    parity = None
+    selfcheck = None
+    if rank == 0:
+        parity = cfg4_parity(torch, files, out_all, [0, n - 1])
+        if args.selfcheck and gathered is not None:
+            selfcheck = cfg4_selfcheck(torch, gathered, total, world, dev, out_all)
+        mp_per_step = total * w * h / 1e6
+        algo = n * CFG4["bytes_per_image"]
+        achieved = algo / (px_ms * 1e-3)
+        out = {
+            "metric": "megapixels/sec JPEG decode + resize (4K 4:2:0 q85 -> 800px)", "value": round(mp_per_step * args.steps / elapsed, 1), "unit": "MP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "i32/f32", "data": "synthetic",
+            "gather_ms": round((elapsed - compute_s) * 1e3, 4),
+            "value_without_gather": round(mp_per_step * args.steps / compute_s, 1),
+            "files_per_s": round(total * args.steps / elapsed, 1),
+            "config": {"workload": f"BASELINE cfg4: {total} files ({n} on rank 0) 3840x2160 4:2:0 q85 baseline JPEG -> GPU entropy decode -> 4/8 IDCT "
+                                   f"(spatial sRGB luma scaler) + YCbCr -> 800x450 Robidoux, linear light; compressed scans device resident",
+                       "files_per_gpu": n, "total_files": total, "batches_in_flight": T, "files_per_batch": [c["n"] for c in ctx],
+                       "compressed_MB_per_gpu": round(compressed / 1e6, 2),
+                       "one_call_chain": bool(all(c["fused"] for c in ctx)),
+                       "kernel": "jpeg entropy passes + luma / chroma IDCT kernels + the resampler reading the component planes",
+                       "gather": gather_note, "gathers": gathers, "rccl_ranks": dist.get_world_size() if distributed else 1,
+                       "backend": (dist.get_backend() if distributed else "none"), "ranks": ranks_info,
+                       "entropy_decode_ms_per_step": round(ent_ms, 4), "pixel_stage_and_resize_ms_per_step": round(px_ms, 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK, 4),
+                         "frac_timed": round(algo / (compute_s / args.steps) / HBM_PEAK, 4),
+                         "traffic": None, "traffic_source": "profiles/ (rocprofv3 --pmc passes of tools/bench_jpeg.py --chain), not measured in this run",
+                         "kernel_ms": round(px_ms, 4), "algorithmic_bytes_per_launch": algo,
+                         "what": "the pixel stage + resize calls of one step (coefficient planes + quant tables in, 800x450 BGRA out: 26 323 584 B per image, "
+                                 "SURVEY 8d), batches one after the other, hipEvents on their streams; frac_timed puts the same bytes over the WHOLE "
+                                 "chain's step time, entropy decode included"},
+            "parity_checked": parity,
+        }
+        if selfcheck is not None:
+            out["selfcheck"] = selfcheck
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cfg4_cpu_baseline(files)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "MP/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+
+
+def cfg4_parity(torch, files, out_all, which):
+    """After the timed region: the oracle's chain on some of this rank's files -- file -> coefficients (oracle/jpeg_oracle.c)
+    -> 4/8 decode with the reference's compiled spatial luma scaler -> CPU resize -- against the bytes the last step left."""
+    import numpy as np
+    from oracle import oracle as O
+    from tests import util as U
+    ow, oh = CFG4["out_w"], CFG4["out_h"]
+    equal, checked = True, []
+    got_all = out_all.to_numpy()
+    for i in sorted(set(which)):
+        j = O.jpeg_read_coefficients(files[i])
+        dec = O.jpeg_idct_color_scaled(j, 4, 2)
+        exp = np.zeros((1, oh, U.stride_for(ow)), np.uint8)
+        U.oracle_render(dec[None], CFG4["dec_w"], CFG4["dec_h"], exp, ow, oh, 0, 0, ow, oh)
+        ok = bool(np.array_equal(got_all[i][:, :4 * ow], exp[0][:, :4 * ow]))
+        equal = equal and ok
+        checked.append(i)
+    return {"frames": len(checked), "which": checked, "equal": equal, "against": "oracle chain (jpeg_oracle.c entropy + scaled IDCT, if_oracle.c resize), rank 0's files"}
+
+
+def cfg4_selfcheck(torch, gathered, total, world, dev, out_all):
+    """--selfcheck: the first frame every rank sent must equal that frame decoded HERE (rank 0 makes the same file again)."""
+    import numpy as np
+    from imageflow_amd.codecs import mozjpeg_decoder as D
+    from imageflow_amd.graphics.bitmaps import Bitmap
+    from imageflow_amd.graphics.scaling import ScaleAndRenderParams
+    from imageflow_amd.sharding import shard_range
+    ow, oh = CFG4["out_w"], CFG4["out_h"]
+    bad = []
+    for r in range(world):
+        lo = shard_range(total, r, world)[0]
+        f = cfg4_files(lo, 1)
+        ent = D.JpegEntropyBatch(f, device=str(dev))
+        coef = ent.read_coefficients()
+        stage = D.JpegPixelStage(CFG4["in_w"], CFG4["in_h"], 3, ent.h_samp, ent.v_samp, 1, device=str(dev), scale_num=4, luma_spatial=True, luma_srgb=True)
+        qt = torch.from_numpy(ent.qt.view(np.int16)).to(dev)
+        one = Bitmap.create_u8(1, ow, oh, dev)
+        stage.read_frames_into(coef, qt, one, ScaleAndRenderParams(0, 0, ow, oh))
+        torch.cuda.synchronize()
+        if not bool(torch.equal(gathered[r, 0].to(one.data.device), one.data[0])):
+            bad.append(r)
+    return {"ranks": world, "first_frame_of_every_rank_equal": not bad, "ranks_that_differ": bad}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -189,7 +508,10 @@ def parse_args(argv=None):
                          "(the job's final gather, BASELINE north_star); every: one per step, asynchronous and double "
                          "buffered against the next step; none: results stay sharded")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["cfg4"])
+    ap.add_argument("--batches-in-flight", type=int, default=4, help="--workload cfg4: host threads / HIP streams, each with a batch of files")
+    ap.add_argument("--selfcheck", action="store_true",
+                    help="after the timed region rank 0 checks the first gathered frame of EVERY rank against one it renders itself")
     ap.add_argument("--outputs", default="files", choices=["files", "bgra"],
                     help="--workload cfg3: what the job leaves and its final gather ships -- the four JPEG files per image "
                          "(libjpeg_turbo q90, coded on the device; the reference's export_4_sizes) or the raw BGRA levels")
@@ -213,10 +535,6 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to "
                          f"measure a different job than the one asked for")
-
-    wl = WORKLOADS[args.workload]
-    in_w, in_h, out_w, out_h = wl[0], wl[1], wl[2], wl[3]
-    pyramid = args.workload == "cfg3"
 
     import torch
     import torch.distributed as dist
@@ -244,7 +562,15 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    if args.workload == "cfg4":
+        run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun)
+        if distributed:
+            dist.destroy_process_group()
+        return
 
+    wl = WORKLOADS[args.workload]
+    in_w, in_h, out_w, out_h = wl[0], wl[1], wl[2], wl[3]
+    pyramid = args.workload == "cfg3"
     # this rank's block of the job
     if args.scaling == "strong":
         total = args.total_frames
@@ -479,6 +805,29 @@ def main():
         kernel_name = "fused_resample_kernel" if plan.kernel_kind(wl[6]) == 0 else "two-pass (banded_resample_kernel where a band's rows fit the LDS, else the generic pair)"
     torch.cuda.synchronize()
 
+    parity, selfcheck = None, None
+    if rank == 0:
+        try:
+            # (the kernel-duration probe above rewrote views[0] / the levels with the same inputs: same bytes as the last step's)
+            parity = pyramid_parity(torch, job.inp, job.levels) if pyramid else resample_parity(torch, wl, job.inp, job.views[(args.steps - 1) & 1], [0, n - 1])
+        except Exception as e:  # noqa: BLE001
+            parity = {"frames": 0, "equal": None, "error": f"{type(e).__name__}: {e}"}
+        if args.selfcheck and job.gathered is not None and not pyramid:
+            # the first frame every rank sent must equal that frame made and rendered HERE: a gather that lands at a wrong
+            # offset, or a rank that rendered another block than shard_range gave it, shows the first time RCCL really runs
+            bad = []
+            for r in range(world):
+                r_lo = shard_range(total, r, world)[0] if args.scaling == "strong" else r * n
+                one_in = make_frames(torch, 1, r_lo, r, dev, "gradient", in_w, in_h)
+                one_in.alpha_meaningful = wl[6]
+                one_out = Bitmap.create_u8(1, out_w, out_h, dev, compose=BitmapCompositing[wl[7]], matte=wl[8])
+                scale_and_render(one_in, one_out, info, plan=plan)
+                torch.cuda.synchronize()
+                if not bool(torch.equal(job.gathered[0][r, 0].to(dev), one_out.data[0])):
+                    bad.append(r)
+            selfcheck = {"ranks": world, "first_frame_of_every_rank_equal": not bad, "ranks_that_differ": bad,
+                         "note": "needs --pattern gradient or mixed (frame 0 of a block is a gradient frame) and alpha not meaningful"}
+
     if rank == 0:
         mp_per_step = total * in_w * in_h / 1e6
         value = mp_per_step * args.steps / elapsed
@@ -554,6 +903,9 @@ def main():
                 out["config"]["resize_only_ms_per_step"] = round(resize_only_ms, 4)
                 out["config"]["note"] = ("value counts source megapixels through the WHOLE job (resizes + encoders); roofline is the four "
                                          "resample launches alone")
+        out["parity_checked"] = parity
+        if selfcheck is not None:
+            out["selfcheck"] = selfcheck
         if strong is not None:
             out["strong_1024"] = strong
         if world == 1 and not args.no_cpu_baseline and args.workload == "cfg2":

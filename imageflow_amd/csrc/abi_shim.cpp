@@ -262,6 +262,23 @@ int parse_filter(const JVal* v, int dflt) {                      // imageflow_ty
     raise(kInvalidJson, "InvalidJson: unknown filter");
 }
 
+// `down.filter` / `up.filter` of a querystring: FilterStrings (imageflow_riapi/src/ir4/parsing.rs:159-193) spells every filter with
+// and without underscores, any case; -> the JSON name parse_filter takes.  A value the reference would drop with a warning
+// is refused here: a drop-in that cannot say "warning" must not pick another filter silently.
+std::string querystring_filter_name(std::string v) {
+    static const char* names[] = {"robidoux_fast", "robidoux", "robidoux_sharp", "ginseng", "ginseng_sharp", "lanczos", "lanczos_sharp", "lanczos_2",
+                                  "lanczos_2_sharp", "cubic", "cubic_sharp", "catmull_rom", "mitchell", "cubic_b_spline", "hermite", "jinc", "triangle",
+                                  "linear", "box", "fastest", "n_cubic", "n_cubic_sharp"};
+    auto squash = [](std::string t) {
+        std::string o;
+        for (char ch : t) if (ch != '_') o.push_back(static_cast<char>(std::tolower(static_cast<unsigned char>(ch))));
+        return o;
+    };
+    const std::string want = squash(v);
+    for (const char* n : names) if (squash(n) == want) return n;
+    raise(kArgumentInvalid, "InvalidNodeParams: querystring filter '%s' is not one of imageflow's filters", v.c_str());
+}
+
 // ---- frames in HBM ---------------------------------------------------------------------------------------------
 // A decoded JPEG whose pixel stage has not run: when the frame's one consumer is a resample, decode and resample run as ONE
 // device call (ifhip_jpeg_decode_resample_batch_device: no decoded BGRA bitmap in HBM); any other consumer gets the bitmap
@@ -428,6 +445,7 @@ struct Io {
     bool told = false;
     uint32_t told_w = 0, told_h = 0;
     bool told_spatial = false, told_gamma = false;
+    bool told_discard_profile = false;           // DecoderCommand::DiscardColorProfile (mozjpeg_decoder.rs:88-91)
 };
 struct Response {
     int64_t status;
@@ -849,6 +867,16 @@ struct Job {
             image_size(io_id, &hw, &hh);
             check_size(sec.max_decode_size, "max_decode_size", hw, hh);
         }
+        {   // MzDec::read_frame transforms the frame to sRGB whenever the file carries an ICC profile (mozjpeg_decoder.rs:370-420)
+            // unless the decoder was told discard_color_profile (:88-91).  Colour management is not part of this library: a
+            // profile that is not sRGB itself would come out with other colours than the reference's, so the job is refused --
+            // loudly -- instead (a profile that IS sRGB: the reference's transform is the identity up to its rounding).
+            int kind = 0;
+            if (!in.told_discard_profile && ifhip_jpeg_icc_profile_kind(in.in, in.in_len, &kind) == IFHIP_OK && kind == 2)
+                raise(kActionNotSupported, "ActionNotSupported: io_id %d carries an embedded ICC profile that is not sRGB; this build has no colour "
+                      "management (the reference converts such frames to sRGB, codecs/mozjpeg_decoder.rs:409).  Tell the decoder "
+                      "\"discard_color_profile\" to decode the samples as they are, or keep the file on the reference.", io_id);
+        }
         // the entropy stage: this file, together with whatever other threads' jobs want decoded right now (DecodeCoalescer)
         DecodeRequest rq;
         const int prc = ifhip_jpeg_entropy_prepare(&rq.prepared, in.in, in.in_len);          // parse, un-stuff, pack, tables: on this job's thread
@@ -1060,6 +1088,9 @@ struct Job {
             raise(kInvalidJson, "InvalidJson: command_string needs kind \"ir4\" and a value");
         double qw = 0, qh = 0;
         bool srgb = false;
+        std::string down_filter;                 // `down.filter` (ir4/parsing.rs:580 -> layout.rs:527 ResampleHints::down_filter)
+        int quality = -1, jpeg_quality = -1;     // `quality` / `jpeg.quality` (ir4/encoder.rs:74: jpeg.quality, else quality)
+        bool jpeg_out = false;                   // `format=jpg|jpeg`
         size_t i = 0;
         const std::string& q = value->s;
         while (i < q.size()) {
@@ -1074,7 +1105,18 @@ struct Job {
             else if (k == "height" || k == "h" || k == "maxheight") qh = std::atof(v.c_str());
             else if (k == "down.colorspace") srgb = v == "srgb";
             else if (k == "mode") { if (v != "max") raise(kActionNotSupported, "ActionNotSupported: querystring mode=%s (this shim: max)", v.c_str()); }
-            else if (k == "format" || k == "quality" || k == "down.filter") {}           // encode-side / default keys
+            else if (k == "down.filter") down_filter = querystring_filter_name(v);
+            else if (k == "quality" || k == "jpeg.quality") {
+                char* end = nullptr;
+                const long q = std::strtol(v.c_str(), &end, 10);
+                if (end == v.c_str() || *end) raise(kArgumentInvalid, "InvalidNodeParams: querystring %s=%s is not an integer", k.c_str(), v.c_str());
+                (k == "quality" ? quality : jpeg_quality) = static_cast<int>(std::max(0l, std::min(100l, q)));
+            }
+            else if (k == "format") {
+                for (char& ch : v) ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
+                if (v != "jpg" && v != "jpeg") raise(kActionNotSupported, "ActionNotSupported: querystring format=%s (this shim writes JPEG; PNG / GIF / WebP coders are out of scope)", v.c_str());
+                jpeg_out = true;
+            }
             else raise(kActionNotSupported, "ActionNotSupported: querystring key '%s'", k.c_str());
         }
         if (!(qw >= 0 && qw <= 2147483647.0) || !(qh >= 0 && qh <= 2147483647.0)) raise(kArgumentInvalid, "InvalidNodeParams: querystring width/height out of range");
@@ -1107,8 +1149,24 @@ struct Job {
         JVal hints;
         hints.t = JVal::Obj;
         if (srgb) { JVal cs; cs.t = JVal::Str; cs.s = "srgb"; hints.o.emplace_back("scaling_colorspace", cs); }
+        if (!down_filter.empty()) { JVal f; f.t = JVal::Str; f.s = down_filter; hints.o.emplace_back("down_filter", f); }
         FramePtr out = resample(in, ow, oh, &hints);
-        if (enc && enc->t == JVal::Num) encode(out, static_cast<int32_t>(want_int(p, "encode", "command_string")), nullptr, false);
+        if (enc && enc->t == JVal::Num) {
+            // The reference keeps the source's format (a JPEG stays a JPEG, ir4/encoder.rs:30-37 OutputFormat::Keep) and hands
+            // `jpeg.quality`, else `quality`, to its JPEG encoder (encoder.rs:74; 90 when neither is given, codecs/auto.rs).  Here a
+            // querystring that names the format or a quality gets the classic JPEG writer with exactly that quality (the mozjpeg
+            // preset's trellis / scan search is not built: DESIGN "Encode"); one that names neither keeps this shim's labelled
+            // extension, the raw BGRA container -- no key is accepted and then dropped.
+            const int q = jpeg_quality >= 0 ? jpeg_quality : quality;
+            if (jpeg_out || q >= 0) {
+                JVal qv; qv.t = JVal::Num; qv.n = q >= 0 ? q : 90;
+                JVal classic; classic.t = JVal::Obj; classic.o.emplace_back("quality", qv);
+                JVal preset; preset.t = JVal::Obj; preset.o.emplace_back("libjpeg_turbo", classic);
+                encode(out, static_cast<int32_t>(want_int(p, "encode", "command_string")), &preset, false);
+            } else {
+                encode(out, static_cast<int32_t>(want_int(p, "encode", "command_string")), nullptr, false);
+            }
+        }
         return out;
     }
 
@@ -1386,7 +1444,9 @@ struct Job {
             if (const JVal* cmds = p.get("commands"))
                 if (cmds->t == JVal::Arr)
                     for (const JVal& cmd : cmds->a)
-                        if (const JVal* j = cmd.get("jpeg_downscale_hints")) {               // s::JpegIDCTDownscaleHints
+                        if (cmd.t == JVal::Str && cmd.s == "discard_color_profile") {
+                            input(static_cast<int32_t>(want_int(p, "io_id", "decode"))).told_discard_profile = true;
+                        } else if (const JVal* j = cmd.get("jpeg_downscale_hints")) {        // s::JpegIDCTDownscaleHints
                             hw = want_u32(*j, "width", "jpeg_downscale_hints"); hh = want_u32(*j, "height", "jpeg_downscale_hints");
                             if (const JVal* b = j->get("scale_luma_spatially")) spatial = b->t == JVal::Bool && b->b;
                             if (const JVal* b = j->get("gamma_correct_for_srgb_during_spatial_luma_scaling")) gamma = b->t == JVal::Bool && b->b;
@@ -1914,8 +1974,10 @@ const struct imageflow_json_response* imageflow_context_send_json(struct imagefl
                 in.told_spatial = b && b->t == JVal::Bool && b->b;
                 b = j.get("gamma_correct_for_srgb_during_spatial_luma_scaling");
                 in.told_gamma = b && b->t == JVal::Bool && b->b;
-            } else if (!(cmd->t == JVal::Str && (cmd->s == "discard_color_profile" || cmd->s == "ignore_color_profile_errors")) &&
-                       !(cmd->t == JVal::Obj && cmd->get("webp_decoder_hints"))) {   // colour profiles / WebP: nothing here acts on them
+            } else if (cmd->t == JVal::Str && cmd->s == "discard_color_profile") {
+                in.told_discard_profile = true;                                      // the samples as they are: what this library does anyway
+            } else if (!(cmd->t == JVal::Str && cmd->s == "ignore_color_profile_errors") &&
+                       !(cmd->t == JVal::Obj && cmd->get("webp_decoder_hints"))) {   // profile errors (there is no CMS to fail) / WebP: nothing to act on
                 raise(kInvalidJson, "InvalidJson: unknown decoder command");
             }
             return respond(c, 200, "{\n  \"code\": 200,\n  \"success\": true,\n  \"message\": \"OK\",\n  \"data\": {}\n}");                 // TellDecoderV1Response {} (v1.rs:177)

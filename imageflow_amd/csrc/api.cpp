@@ -25,6 +25,7 @@ hipError_t launch_fused(const ResampleArgs& a, int slots, bool alpha, bool per_p
 hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, uint32_t img0, uint32_t n_img,
                           hipStream_t st);
 hipError_t launch_banded(const ResampleArgs& a, bool alpha, const BandedArgs& b, uint32_t grid_x, size_t lds, hipStream_t st);
+hipError_t launch_ws(const ResampleArgs& a, int slots, uint32_t grid, uint32_t block, size_t lds, hipStream_t st);
 hipError_t launch_read_probe(const uint8_t* d, size_t bytes, uint32_t* sink, hipStream_t st);
 hipError_t launch_mix_probe(const uint8_t* d, uint8_t* out, size_t bytes, uint32_t every, uint32_t* sink, hipStream_t st);
 hipError_t launch_apply_matte(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w, uint32_t h,
@@ -152,6 +153,7 @@ struct ifhip_resample_plan {
         uint32_t max_quads = 0;
         bool ok = false;
     } sets[2];                       // [in_alpha_meaningful]
+    StripSet ws_set;                 // strips of the wave-specialised kernel (resample_ws.hip): 8 V waves x 64 lanes x 4 columns
     // lazily built, guarded by mu
     mutable std::mutex mu;
     mutable std::map<uint64_t, ScheduleOnDevice> schedules;     // key: bands | group << 32 | ahead << 40
@@ -159,7 +161,7 @@ struct ifhip_resample_plan {
     ~ifhip_resample_plan() {
         for (void* p : {(void*)d_v_left, (void*)d_v_count, (void*)d_v_off, (void*)d_h_left, (void*)d_h_count,
                         (void*)d_h_off, (void*)d_v_w, (void*)d_h_w, (void*)d_h_wu, (void*)d_h_meta, (void*)d_h_wg, (void*)d_h_meta2, (void*)d_h_wg2, (void*)d_h_meta3, (void*)sets[0].d_strips,
-                        (void*)sets[1].d_strips})
+                        (void*)sets[1].d_strips, (void*)ws_set.d_strips})
             if (p) (void)DEV_FREE(p);
         for (auto& kv : schedules) {
             if (kv.second.steps) (void)DEV_FREE(kv.second.steps);
@@ -223,6 +225,34 @@ bool plan_strips(const AxisWeights& wh, uint32_t max_lanes, int px, int channels
         }
         if (ok) { *out = std::move(s); *max_quads = mq; return true; }
         if (n > 4096) break;
+    }
+    return false;
+}
+
+// The same for the wave-specialised kernel: the fewest equal strips whose staged span fits `max_quads` V lanes (the LDS is
+// budgeted per launch: the row ring takes what the tables leave).
+bool plan_ws_strips(const AxisWeights& wh, uint32_t max_quads, std::vector<Strip>* out, uint32_t* max_quads_out) {
+    for (uint32_t n = 1; n <= wh.n_out && n <= 64u; ++n) {
+        std::vector<Strip> s;
+        bool ok = true;
+        uint32_t mq = 0;
+        for (uint32_t i = 0; i < n && ok; ++i) {
+            Strip t;
+            t.u0 = static_cast<uint32_t>(static_cast<uint64_t>(wh.n_out) * i / n);
+            t.u1 = static_cast<uint32_t>(static_cast<uint64_t>(wh.n_out) * (i + 1) / n);
+            if (t.u1 <= t.u0) { ok = false; break; }
+            uint32_t lo = wh.left[t.u0], hi = 0;
+            for (uint32_t u = t.u0; u < t.u1; ++u) {
+                lo = std::min(lo, wh.left[u]);
+                hi = std::max(hi, wh.left[u] + wh.count[u]);
+            }
+            t.cx0 = lo & ~3u;
+            t.nquads = (hi - t.cx0 + 3u) / 4u;
+            if (t.nquads > max_quads || (t.u1 - t.u0) > kMaxStripOutputs) ok = false;
+            mq = std::max(mq, t.nquads);
+            s.push_back(t);
+        }
+        if (ok) { *out = std::move(s); *max_quads_out = mq; return true; }
     }
     return false;
 }
@@ -364,6 +394,80 @@ int validate_render(uint32_t in_w, uint32_t in_h, uint32_t in_stride, uint32_t c
     return IFHIP_OK;
 }
 
+// The wave-specialised kernel (resample_ws.hip) where it applies: no alpha, the fast horizontal pass, rings up to 5, and an LDS
+// plan that holds the tables and a ring of at least two row slots per frame slot.  kNotFusable: not this launch (the caller
+// goes on to the one-role kernel).  `a` is the caller's argument block, completed here on a copy.
+int enqueue_ws(const ifhip_resample_plan* p, ResampleArgs a, uint32_t n_images, bool ycc, bool probe, hipStream_t st) {
+    const ifhip_resample_plan::StripSet& ss = p->ws_set;
+    if (!ss.ok) return kNotFusable;
+    // OFF unless asked for (`ws` = 1, tests and tools/ab_switches.py): measured slower than the one-role kernel on every BASELINE
+    // shape -- cfg3 level 0 2.47 ms against 2.14, level 1 3.56 against 2.72, level 2 1.95 against 1.93 (profiles/r5_ws_*.jsonl).
+    { const char* e = debug_switch("ws"); if (!e || std::atoi(e) == 0) return kNotFusable; }
+    // the strips were planned on the BGRA alignment rules; a planar source reads 4 samples per lane and plane
+    for (const Strip& s : ss.strips) {
+        if (ycc ? static_cast<uint64_t>(s.cx0) + 4u * s.nquads > a.in_stride
+                : static_cast<uint64_t>(s.cx0 + 4u * s.nquads) * 4u > a.in_stride) return kNotFusable;
+    }
+    const bool two = p->h_two_groups != 0 && !ycc;
+    const uint32_t fast_g = two ? p->h_two_groups : p->h_fast_groups;
+    const uint32_t wu_floats = two ? p->h_wg2_floats : p->h_wg_floats;
+    const bool l2s = a.linear != 0;                                  // the encode table is part of the form (no threshold search here)
+    const uint32_t T = block_for(ss.max_quads, 4), wpf = T / 64u;
+    uint32_t v_max = std::max(kWsMaxVWaves, wpf), total_waves = 16u;
+    if (const char* e = debug_switch("ws_v_waves")) v_max = std::max<uint32_t>(wpf, std::min<uint32_t>(14u, static_cast<uint32_t>(std::atoi(e))));
+    uint32_t max_nu = 0;
+    for (const Strip& s : ss.strips) max_nu = std::max(max_nu, s.u1 - s.u0);
+    auto lds_for = [&](uint32_t frames, uint32_t copies_log2, uint32_t ring) {
+        size_t worst = 0;
+        for (const Strip& s : ss.strips)
+            worst = std::max<size_t>(worst, ws_lds_layout(s.u1 - s.u0, s.nquads, wu_floats, l2s, copies_log2, frames, fast_g, ring).total);
+        return worst;
+    };
+    const size_t limit = lds_limit();
+    uint32_t frames = std::max<uint32_t>(1u, std::min<uint32_t>(v_max / wpf, n_images));
+    if (ss.strips.size() > 1) frames = 1;
+    while (frames > 1 && lds_for(frames, kMinLutCopiesLog2, 3) > limit) --frames;
+    uint32_t ring = 0, copies_log2 = kMinLutCopiesLog2;
+    for (uint32_t r = 4; r >= 2; --r)
+        if (lds_for(frames, kMinLutCopiesLog2, r) <= limit) { ring = r; break; }
+    if (!ring) return kNotFusable;
+    if (lds_for(frames, 5, ring) <= limit) copies_log2 = 5;
+    if (const char* e = debug_switch("ws_ring")) {
+        const uint32_t r = static_cast<uint32_t>(std::atoi(e));
+        if (r >= 1 && r <= 8 && lds_for(frames, copies_log2, r) <= limit) ring = r;
+    }
+    const uint32_t n_v = frames * wpf;
+    uint32_t n_h = total_waves - n_v;
+    if (const char* e = debug_switch("ws_h_waves")) n_h = std::max<uint32_t>(1u, std::min<uint32_t>(total_waves - n_v, static_cast<uint32_t>(std::atoi(e))));
+    const uint32_t wgs = (n_images + frames - 1u) / frames;
+    ScheduleOnDevice sd;
+    const uint32_t want_bands = choose_bands(p, wgs, ss.strips.size());
+    int rc = get_schedule(p, want_bands, kWsRowsInFlight, kWsRowsInFlight, &sd);
+    if (rc) return rc;
+    a.steps = sd.steps; a.band_begin = sd.band_begin; a.n_bands = sd.n_bands;
+    a.strips = ss.d_strips; a.n_strips = static_cast<uint32_t>(ss.strips.size());
+    a.h_groups = two ? 16u + fast_g : fast_g;
+    if (two) { a.h_wu = p->d_h_wg2; a.h_wu_floats = p->h_wg2_floats; a.h_meta2 = p->d_h_meta3; }
+    else { a.h_wu = p->d_h_wg; a.h_wu_floats = p->h_wg_floats; a.h_meta2 = p->d_h_meta2; }
+    a.lut_copies_log2 = copies_log2;
+    a.h_w_in_lds = 1u;
+    a.l2s_in_lds = l2s ? 1u : 0u;
+    a.frames_per_wg = frames;
+    a.lanes_per_frame = T;
+    a.ws_ring = ring;
+    const size_t lds = lds_for(frames, copies_log2, ring);
+    const uint64_t grid = static_cast<uint64_t>(wgs) * sd.n_bands * a.n_strips;
+    if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
+    if (debug_switch("trace_launch"))
+        std::fprintf(stderr, "ifhip ws launch: %ux%u -> %ux%u K=%d ycc=%d V lanes/frame=%u frames/wg=%u V waves=%u H waves=%u ring=%u bands=%u "
+                     "strips=%u grid=%llu lds=%zu fast_g=%u two_col=%d lut_copies=%u images=%u\n",
+                     p->in_w, p->in_h, p->out_w, p->out_h, p->slots, ycc ? 1 : 0, T, frames, n_v, n_h, ring, sd.n_bands, a.n_strips,
+                     static_cast<unsigned long long>(grid), lds, fast_g, two ? 1 : 0, 1u << copies_log2, n_images);
+    if (probe) return IFHIP_OK;
+    HIP_TRY(launch_ws(a, p->slots, static_cast<uint32_t>(grid), (n_v + n_h) * 64u, lds, st));
+    return IFHIP_OK;
+}
+
 int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride,
                   int alpha, uint32_t n_images, uint8_t* d_canvas, size_t canvas_image_bytes, uint32_t cw, uint32_t ch,
                   uint32_t c_stride, uint32_t x, uint32_t y, int working_space, int compositing, uint32_t matte,
@@ -437,6 +541,10 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
                         "(or the source pixels are not 4-byte aligned)");
     }
 
+    if (fused && !alpha) {
+        rc = enqueue_ws(p, a, n_images, ycc, probe, st);
+        if (rc != kNotFusable) return rc;          // launched (or failed for a reason of its own); else: the one-role kernel
+    }
     if (fused) {
         const ifhip_resample_plan::StripSet& ss = p->sets[alpha ? 1 : 0];
         a.strips = ss.d_strips; a.n_strips = static_cast<uint32_t>(ss.strips.size());
@@ -770,6 +878,15 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
             if (v >= 64) max_lanes = std::min<uint32_t>(max_lanes, static_cast<uint32_t>(v) & ~63u);
         }
         ss.ok = plan_strips(p->wh, max_lanes, fused_shape(p->slots, channels).px, channels, &ss.strips, &ss.max_quads);
+        if (ss.ok && (rc = upload(ss.strips, &ss.d_strips))) return rc;
+    }
+    // Strips of the wave-specialised kernel: moderate ratios (the fast horizontal pass exists), rings the 1024-lane shapes
+    // hold (K <= 5), three channels; a strip's source span is what its 8 V waves cover.
+    if (p->fused_possible && p->h_fast_groups && p->slots <= 5 && fused_shape(p->slots, 3).px == 4 && fused_shape(p->slots, 3).threads == 1024) {
+        ifhip_resample_plan::StripSet& ss = p->ws_set;
+        uint32_t v_waves = kWsMaxVWaves;
+        if (const char* e = debug_switch("ws_strip_waves")) v_waves = std::max(1u, std::min(14u, static_cast<uint32_t>(std::atoi(e))));   // experiment switch: narrower / wider strips
+        ss.ok = plan_ws_strips(p->wh, v_waves * 64u, &ss.strips, &ss.max_quads);
         if (ss.ok && (rc = upload(ss.strips, &ss.d_strips))) return rc;
     }
     *plan = p.release();

@@ -85,11 +85,6 @@ const ColorTables& color_tables();
 // Vertical schedule for the fused kernel (our own construct; DESIGN.md "vertical schedule")
 // ---------------------------------------------------------------------------------------------------
 constexpr int kMaxSlots = 8;
-#ifndef IFHIP_PREFETCH_ROWS
-#define IFHIP_PREFETCH_ROWS 4
-#endif
-static_assert(IFHIP_PREFETCH_ROWS % 2 == 0, "the step loop double-buffers by step parity");
-constexpr int kPrefetchRows = IFHIP_PREFETCH_ROWS;     // source rows kept in flight per lane by the fused kernel
 struct alignas(64) VStep {
     int32_t y;            // source row to load and accumulate, or -1
     uint32_t active;      // bit s set: ring slot s accumulates row y with weight w[s]

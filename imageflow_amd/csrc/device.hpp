@@ -48,6 +48,8 @@ struct ResampleArgs {
     uint32_t lut_copies_log2;        // the sRGB->float table is replicated 2^n times in LDS (5: one copy per bank)
     uint32_t frames_per_wg;          // F: frames one workgroup works on side by side (narrow sources; tables shared)
     uint32_t lanes_per_frame;        // multiple of 64; the workgroup has F * lanes_per_frame lanes
+    // wave-specialised kernel (resample_ws.hip): the workgroup has F * lanes_per_frame V lanes, the rest are H waves
+    uint32_t ws_ring;                // R: row slots per frame slot between the vertical and the horizontal waves
     // generic-kernel tables
     const uint32_t* h_left;
     const uint32_t* h_count;
@@ -80,47 +82,20 @@ struct BandedArgs {
 // K*4*C registers per lane.  Three shapes, picked by a register estimate (checked against the compiler's report):
 //   wide + pipelined : 1024 lanes (128 registers), D = 4 rows in flight, converted samples double buffered
 //   wide + plain     : 1024 lanes, D = 4, no double buffering (register-heavier rings, e.g. K = 4 with alpha)
-//   narrow           : big rings (K >= 6, or K >= 5 with alpha): 512 lanes (256 registers), D = 8, pipelined; strips get
-//                      narrower.  (IFHIP_NARROW_PX=2 builds the same strips as 1024 lanes x 2 pixels with 8-byte loads --
-//                      twice the waves, half the accumulators per lane; these shapes are instruction-bound, so the extra
-//                      per-lane overhead costs more than the occupancy buys.)
+//   narrow           : big rings (K >= 6, or K >= 5 with alpha): 512 lanes (256 registers), pipelined; strips get narrower.
+//                      (The same strips as 1024 lanes x 2 pixels with 8-byte loads -- twice the waves, half the accumulators
+//                      per lane -- measured 1.3 % slower on cfg5: these shapes are instruction-bound; profiles/NOTEBOOK.md.)
 // D is sized by bytes in flight: a CU needs ~46 KB outstanding to cover HBM latency at its share of the bandwidth
 // (1024 lanes x 4 rows x 16 B = 64 KB; 512 lanes need 8 rows for the same).  Measured: cfg5 2.78 -> 2.46 ms with
 // D = 8 on the narrow shape, cfg2 with alpha 2.05 -> 2.03 ms with D = 4 on the plain shape; round 3: 12 rows -1.3 %,
 // 16 rows -2.0 % on cfg5 (216 / 232 registers; the step loop must then be unrolled past clang's pragma threshold,
 // build.py passes -pragma-unroll-threshold) -- rings up to K = 6 take 16, the larger ones keep 8.
-#ifndef IFHIP_PLAIN_D
-#define IFHIP_PLAIN_D 4
-#endif
-#ifndef IFHIP_NARROW_D
-#define IFHIP_NARROW_D 16
-#endif
-#ifndef IFHIP_NARROW_PX
-#define IFHIP_NARROW_PX 4    // 2 = 1024 lanes x 2 pixels (8-byte loads): parity-tested, measured 1.3 % slower on cfg5 (instruction-bound)
-#endif
-#ifndef IFHIP_PIPE_D
-#define IFHIP_PIPE_D 4       // rows in flight of the pipelined 1024-lane shape
-#endif
-#ifndef IFHIP_PIPE_ON
-#define IFHIP_PIPE_ON 1      // 0: that shape without the conversion double buffer (frees 12 registers for rows in flight)
-#endif
 struct FusedShape { int threads, rows_in_flight, pipelined, px; };   // px: source pixels per lane (16- or 8-byte loads)
 constexpr FusedShape fused_shape(int K, int channels) {
     // thresholds read off the compiler's register report (python -m imageflow_amd.kernel_report): no variant spills
-    return (channels == 3 ? K <= 4 : K <= 2) ? FusedShape{1024, IFHIP_PIPE_D, IFHIP_PIPE_ON, 4}
-         : (channels == 3 ? K <= 5 : K <= 4) ? FusedShape{1024, IFHIP_PLAIN_D, 0, 4}
-                                             : FusedShape{IFHIP_NARROW_PX == 2 ? 1024 : 512, (IFHIP_NARROW_PX == 2 && K == 8) ? 6 : (K <= 6 ? IFHIP_NARROW_D : 8), 1, IFHIP_NARROW_PX};   // (K = 8: 6 rows, else the alpha variants spill)
-}
-// Ring slots whose vertical accumulation runs on the matrix pipe (v_mfma_f32_4x4x1: four slots per instruction, exact
-// fmaf -- see resample_fused.hip).  IFHIP_MFMA_MODE: 0 none, 1 every slot (rounded up to 4: unused slots carry weight +0),
-// 2 the whole groups of four only (the rest on v_pk_fma_f32), 3 the per-shape choice measured on MI355X.
-#ifndef IFHIP_MFMA_MODE
-#define IFHIP_MFMA_MODE 0
-#endif
-constexpr int fused_mfma_slots(int K, int channels) {
-    return IFHIP_MFMA_MODE == 1 ? 4 * ((K + 3) / 4)
-         : IFHIP_MFMA_MODE == 2 ? 4 * (K / 4)
-         : 0;
+    return (channels == 3 ? K <= 4 : K <= 2) ? FusedShape{1024, 4, 1, 4}
+         : (channels == 3 ? K <= 5 : K <= 4) ? FusedShape{1024, 4, 0, 4}
+                                             : FusedShape{512, K <= 6 ? 16 : 8, 1, 4};
 }
 constexpr int fused_max_threads(int K, int channels) { return fused_shape(K, channels).threads; }
 constexpr int fused_max_quads(int K, int channels) { return fused_shape(K, channels).threads * fused_shape(K, channels).px / 4; }
@@ -165,6 +140,33 @@ inline FusedLds fused_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t wu_floa
         l.inter_stride = ((nquads + fast_groups - 1u) * fused_group_pitch(channels) + 15u) & ~15u;
     }
     l.inter = off; off += frames * 2u * l.inter_stride;    // vertically filtered rows j / j+1, one pair per frame slot
+    l.total = off;
+    return l;
+}
+
+// ---- wave-specialised kernel (resample_ws.hip): moderate ratios, fast horizontal pass, three channels ----
+// Rows in flight per V lane: half the workgroup streams (8 waves where the one-role kernel has 15-16), so a lane keeps twice the
+// rows in flight for the same bytes outstanding per CU (8 waves x 64 lanes x 8 rows x 16 B = 64 KB).  Measured with 6 rows
+// and the conversion double buffer, and with 12 rows: the same time within 1 % (profiles/r5_ws_*.jsonl) -- the V waves are
+// not bound by bytes in flight.
+constexpr int kWsRowsInFlight = 8;
+constexpr uint32_t kWsUnitChunks = 4;       // 64-output chunks an H wave works on at a time (one output of each per lane)
+constexpr uint32_t kWsMaxVWaves = 8;        // V waves per workgroup (of 16): strips are planned for 8 x 64 x 4 source columns
+struct WsLds { uint32_t lut, l2s, hmeta, hw, sync, ring, row_stride, total; };
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline WsLds ws_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t wu_floats, bool l2s_in_lds, uint32_t lut_copies_log2,
+                           uint32_t frames, uint32_t fast_groups, uint32_t ring) {
+    WsLds l;
+    uint32_t off = 0;
+    l.lut = off;   off += (256u << lut_copies_log2) * 4u;
+    l.l2s = off;   off += l2s_in_lds ? 16384u : 0u;
+    l.hmeta = off; off += (n_u * 4u + 15u) & ~15u;
+    l.hw = off;    off += (wu_floats * 4u + 15u) & ~15u;
+    l.sync = off;  off += (2u * frames * ring * 4u + 63u) & ~63u;      // row counters: published [F][R], consumed [F][R]
+    l.row_stride = ((nquads + fast_groups - 1u) * fused_group_pitch(3) + 15u) & ~15u;   // as the fast pass of the one-role kernel
+    l.ring = off;  off += frames * ring * l.row_stride;
     l.total = off;
     return l;
 }

@@ -44,15 +44,9 @@
 
 namespace ifhip {
 
-#ifndef IFHIP_ENT_SUBBITS
-#define IFHIP_ENT_SUBBITS 1024
-#endif
-constexpr uint32_t kSubBits = IFHIP_ENT_SUBBITS;     // bits per sub-sequence (one lane)
+constexpr uint32_t kSubBits = 1024;     // bits per sub-sequence (one lane)
 constexpr uint32_t kSubWords = kSubBits / 32;
-#ifndef IFHIP_ENT_LUTBITS
-#define IFHIP_ENT_LUTBITS 9
-#endif
-constexpr uint32_t kLutBits = IFHIP_ENT_LUTBITS;
+constexpr uint32_t kLutBits = 9;
 
 // Huffman tables in the form every pass reads.  Everything a pass needs from a symbol sits in one 32-bit entry, found
 // with ONE lookup by the next kLutBits bits of the stream -- or two for the 2 % of the symbols whose code is longer:
@@ -64,10 +58,7 @@ constexpr uint32_t kLutBits = IFHIP_ENT_LUTBITS;
 // 32 - n.  jdhuff.c's slow path (the serial "first l with code_l <= maxcode[l]" search) survives only for sub-tables
 // that did not fit the pool (first-level entry 0): it reads SearchTab from global memory and no real file gets there.
 constexpr uint32_t kLutEntries = 1u << kLutBits;
-#ifndef IFHIP_ENT_POOL
-#define IFHIP_ENT_POOL 768
-#endif
-constexpr uint32_t kPoolEntries = IFHIP_ENT_POOL;
+constexpr uint32_t kPoolEntries = 768;
 static_assert(kLutBits >= 8u && kLutBits <= 11u, "first-level lookup: the pair entries assume a code + magnitude of < 32 bits behind it");
 static_assert(kPoolEntries >= 128u && kPoolEntries <= 65535u, "a first-level pointer holds the pool offset in 16 bits; one sub-table is up to 128 entries");
 struct FastTabs {                                    // one image: [comp][dc, ac] and their shared second level
@@ -337,10 +328,7 @@ __device__ __forceinline__ void stage_fast_tables(const FastTabs* gtabs, FastTab
 }
 
 
-#ifndef IFHIP_ENT_SYNC_LANES
-#define IFHIP_ENT_SYNC_LANES 1024
-#endif
-constexpr uint32_t kSyncLanes = IFHIP_ENT_SYNC_LANES;               // sub-sequences per workgroup in these passes
+constexpr uint32_t kSyncLanes = 1024;               // sub-sequences per workgroup in these passes
 constexpr uint32_t kSyncCols = kSyncLanes + 1u;                     // a walk stops within 31 bits of its end and looks 3 words ahead
 constexpr uint32_t kFastStageDwords = kSyncCols * kColPitch;
 
@@ -351,22 +339,13 @@ constexpr uint32_t kFastStageDwords = kSyncCols * kColPitch;
 // lane costs as much as a full one -- so the iteration COMPACTS them: sub-sequence states live in LDS (one packed word:
 // relative bit position | block-in-MCU << 21 | zigzag index << 25), the lanes that need a decode enter a work list
 // through a ballot / prefix count, and lane k decodes the k-th entry.  An iteration then costs what its dense waves cost.
-#ifndef IFHIP_ENT_INNER
-#define IFHIP_ENT_INNER 24
-#endif
-constexpr uint32_t kInnerRounds = IFHIP_ENT_INNER;
-#ifndef IFHIP_ENT_WAVEWALK
-#define IFHIP_ENT_WAVEWALK 16
-#endif
-constexpr uint32_t kWaveWalkMax = IFHIP_ENT_WAVEWALK;                          // at most this many pending sub-sequences: one wave per walk
+constexpr uint32_t kInnerRounds = 24;
+constexpr uint32_t kWaveWalkMax = 16;                          // at most this many pending sub-sequences: one wave per walk
 // The first kWarmLanes lanes of a workgroup decode the sub-sequences IN FRONT of its own range in round 0 and discard the
 // result: the workgroup's first own sub-sequence then starts from a state that has had kWarmLanes sub-sequences to
 // synchronise (one fails to with probability ~0.4), so corrections across workgroup boundaries -- a whole extra launch
 // of lone walks -- all but disappear.  Later rounds run without them.
-#ifndef IFHIP_ENT_WARM
-#define IFHIP_ENT_WARM 16
-#endif
-constexpr uint32_t kWarmLanes = IFHIP_ENT_WARM;
+constexpr uint32_t kWarmLanes = 16;
 constexpr uint32_t kOwnSubs = kSyncLanes - kWarmLanes;                         // sub-sequences a workgroup owns
 static_assert(kWarmLanes < kSyncLanes && kSyncLanes % 64u == 0u && kSyncLanes <= 1024u, "whole waves, one workgroup");
 constexpr uint32_t kNever = 0xffffffffu;
@@ -382,9 +361,6 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
     __shared__ uint2 st[kSyncLanes];                                 // .x exit state, .y the entry state it was decoded from (written as a pair)
     __shared__ uint16_t endinfo[kSyncLanes], work[kSyncLanes];       // end - t * 1024 (| kChase); sub-sequences to decode this iteration
     __shared__ uint32_t wave_cnt[kSyncLanes / 64u];
-#ifdef IFHIP_ENT_TRACE
-    const unsigned long long tr_enter = wall_clock64();
-#endif
     const uint32_t own_sub = blockIdx.x * kOwnSubs, first_sub = own_sub - kWarmLanes;     // (wraps for workgroup 0: those lanes are off)
     const uint32_t t = threadIdx.x, s = first_sub + t, lane = t & 63u, wave = t >> 6;
     if (a.round == 0u && blockIdx.x == 0u && t < kFlagWords) a.changed[t] = 0u;     // the flags of this decode (later launches set them)
@@ -421,10 +397,6 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
     endinfo[t] = static_cast<uint16_t>(on ? (min((s + 1u) * kSubBits, sg.bit_end) - s * kSubBits) | (first ? 0u : kChase) : 0u);
     __syncthreads();
     bool pending = false;
-#ifdef IFHIP_ENT_TRACE
-    unsigned long long tr_t[24]; uint32_t tr_n[24], tr_k = 0u;
-    const unsigned long long tr_0 = wall_clock64();
-#endif
     for (uint32_t it = 0; it < a.inner_rounds; ++it) {
         // speculative first decode of round 0: from the sub-sequence's own first bit; afterwards from the predecessor's exit
         const uint32_t entry = (fixed && !(a.round == 0u && it > 0u && !first && t > 0u)) ? fixed_entry : st[t ? t - 1u : 0u].x;
@@ -436,9 +408,6 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
 #pragma unroll
         for (uint32_t w = 0; w < kSyncLanes / 64u; ++w) { const uint32_t n = wave_cnt[w]; base += w < wave ? n : 0u; total += n; }
         pending = total != 0u;
-#ifdef IFHIP_ENT_TRACE
-        if (it < 24u) { tr_t[it] = wall_clock64(); tr_n[it] = total; tr_k = it + 1u; }
-#endif
         if (!pending) break;
         if (need) {
             st[t].y = entry;
@@ -470,12 +439,6 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
         }
         __syncthreads();
     }
-#ifdef IFHIP_ENT_TRACE
-    if (t == 0u && a.round == 0u)
-        printf("WG %u its %u staged_us %.2f done_us %.2f enter_tick %llu\n", blockIdx.x, tr_k, (double)(tr_0 - tr_enter) / 100.0, (double)(wall_clock64() - tr_enter) / 100.0, tr_enter);
-    if (t == 0u && ((blockIdx.x % 60u) == 7u || wall_clock64() - tr_enter > 60000ull))
-        for (uint32_t i = 0; i < tr_k; ++i) printf("wg %u round %u it %u total %u us %.2f\n", blockIdx.x, a.round, i, tr_n[i], (double)(tr_t[i] - tr_0) / 100.0);
-#endif
     if (!on || t < kWarmLanes) return;
     const uint32_t fin = st[t].x, fu = st[t].y;
     a.exit_p[cur][s] = (fin & 0x1fffffu) + bit0;
@@ -519,10 +482,7 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_count_kernel(const Entropy
     const uint32_t s = first_sub + threadIdx.x;
     const uint32_t wg_image = a.segs[a.sub_seg[first_sub]].image;
     stage_stream_columns<kSyncLanes, kSyncCols>(a, lds_words, first_sub);
-#ifndef IFHIP_ENT_COUNT_PAIRS
-#define IFHIP_ENT_COUNT_PAIRS 1
-#endif
-    constexpr int kCountPairs = IFHIP_ENT_COUNT_PAIRS ? 2 : 0;
+    constexpr int kCountPairs = 2;
     const FastTabs* gtabs = kCountPairs ? a.ctabs : a.ftabs;
     stage_fast_tables<kSyncLanes>(gtabs, &lds_tabs, wg_image);
     int32_t* dcs = lds_dc + threadIdx.x;                     // this lane's three sums, kSyncLanes apart (one bank per lane)
@@ -579,11 +539,8 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_count_kernel(const Entropy
 constexpr uint32_t kWriteLanes = kChunkSubs;
 constexpr uint32_t kWriteCols = kWriteLanes + kMarginSubs;
 constexpr uint32_t kBlkPitch = 36;                   // dwords per lane row (32 + 4: int16 slots 64..71 are padding)
-#ifndef IFHIP_ENT_FLUSH
-#define IFHIP_ENT_FLUSH 16
-#endif
 
-constexpr uint32_t kFlushLanes = IFHIP_ENT_FLUSH;
+constexpr uint32_t kFlushLanes = 16;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct BlockPlace { uint32_t hv, bw, bh, comp; };    // block k of an MCU: hs | vs << 8 | dx << 16 | dy << 24, plane dimensions in blocks
 
@@ -697,14 +654,7 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
         uint32_t pend_raw = kNoStore;
         bool pend_ok = false;
         int32_t pend_val = 0;
-#ifdef IFHIP_ENT_TRACE
-        const unsigned long long tw_0 = wall_clock64();
-        uint32_t tw_it = 0u, tw_fl = 0u, tw_sym = 0u;
-#endif
         for (;;) {
-#ifdef IFHIP_ENT_TRACE
-            ++tw_it; tw_sym += (run && !waiting) ? 1u : 0u;
-#endif
             if (run && !waiting) {
                 const bool is_dc = z == 0u;
                 bits = rd.peek();
@@ -728,9 +678,6 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
             const bool decoding = __ballot(run && !waiting) != 0ull;
             if (n_wait < kFlushLanes && decoding) continue;
             if (n_wait == 0u) break;                         // nobody decodes, nothing to store
-#ifdef IFHIP_ENT_TRACE
-            ++tw_fl;
-#endif
             if (waiting) {
                 row[pend_ok ? pend_raw : kNoStore] = static_cast<int16_t>(pend_val);
                 pend_ok = false;
@@ -749,12 +696,8 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
                 const uint32_t bx = mx * (pl.hv & 255u) + ((pl.hv >> 16) & 255u), by = my * ((pl.hv >> 8) & 255u) + (pl.hv >> 24);
                 auto* dst = reinterpret_cast<__attribute__((address_space(1))) u32x4*>(reinterpret_cast<uintptr_t>(       // (global, not flat, stores)
                     plane + (static_cast<size_t>(sg.image * pl.bh + by) * pl.bw + bx) * 64u));
-#ifndef IFHIP_ENT_DIAG_NOSTORE
 #pragma unroll
                 for (uint32_t i = 0; i < 8u; ++i) dst[i] = r[i];
-#else
-                if (r[0].x == 0x12345678u && r[3].y == 0x9abcdef0u) dst[0] = r[1];
-#endif
 #pragma unroll
                 for (uint32_t i = 0; i < 8u; ++i) row4[i] = u32x4{0u, 0u, 0u, 0u};
                 ++block;
@@ -764,11 +707,6 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
                 run = p < end && block < sg.n_blocks;
             }
         }
-#ifdef IFHIP_ENT_TRACE
-        if ((threadIdx.x & 63u) == 0u && (blockIdx.x % 50u) == 3u)
-            printf("WR wg %u wave %u iters %u flushes %u lane0_symbols %u blocks %u us %.2f\n", blockIdx.x, threadIdx.x >> 6, tw_it, tw_fl, tw_sym,
-                   block - static_cast<uint32_t>(pre.x), (double)(wall_clock64() - tw_0) / 100.0);
-#endif
     });
     const bool last = s + 1u == sg.first_sub + sg.n_sub;
     if (last && block < sg.n_blocks) err |= 8u;              // the segment ran out of data
@@ -1164,6 +1102,93 @@ int ifhip_jpeg_exif_orientation(const uint8_t* d, size_t len, int* flag) {
         }
         return IFHIP_OK;
     }
+    return IFHIP_OK;
+}
+
+// The embedded ICC profile (see include/imageflow_hip.h).  libjpeg's jpeg_read_icc_profile rule: APP2 markers whose data starts
+// with "ICC_PROFILE\0", then a 1-based sequence number and the marker count; every number must occur exactly once with the
+// same count.  Anything short of that is "a profile we cannot vouch for" = kind 2.
+int ifhip_jpeg_icc_profile_kind(const uint8_t* d, size_t len, int* kind) {
+    if (!kind) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null out-pointer");
+    *kind = 0;
+    if (!d || len < 4 || d[0] != 0xFF || d[1] != 0xD8) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: not a JPEG (no SOI)");
+    std::vector<std::pair<const uint8_t*, size_t>> chunk(256, {nullptr, 0});
+    uint32_t count = 0, seen = 0;
+    bool broken = false;
+    size_t i = 2;
+    while (i + 4 <= len) {
+        if (d[i] != 0xFF) break;
+        while (i < len && d[i] == 0xFF) ++i;
+        if (i >= len) break;
+        const uint8_t m = d[i++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9 || m == 0xDA || i + 2 > len) break;
+        const size_t seg = (static_cast<size_t>(d[i]) << 8) | d[i + 1];
+        if (seg < 2 || i + seg > len) break;
+        const uint8_t* q = d + i + 2;
+        const size_t n = seg - 2;
+        i += seg;
+        if (m != 0xE2 || n < 14 || std::memcmp(q, "ICC_PROFILE\0", 12) != 0) continue;
+        const uint32_t seq = q[12], num = q[13];
+        if (seq == 0 || num == 0 || seq > num || (count && num != count) || chunk[seq].first) { broken = true; continue; }
+        count = num;
+        chunk[seq] = {q + 14, n - 14};
+        ++seen;
+    }
+    if (!seen && !broken) return IFHIP_OK;
+    *kind = 2;
+    if (broken || seen != count) return IFHIP_OK;
+    std::vector<uint8_t> icc;
+    for (uint32_t k = 1; k <= count; ++k) icc.insert(icc.end(), chunk[k].first, chunk[k].first + chunk[k].second);
+    // ICC.1 header: size (0..3), colour space (16..19), PCS (20..23); tag table at 128: count, then {sig, offset, size}
+    auto be32 = [&](size_t o) { return (static_cast<uint32_t>(icc[o]) << 24) | (static_cast<uint32_t>(icc[o + 1]) << 16) | (static_cast<uint32_t>(icc[o + 2]) << 8) | icc[o + 3]; };
+    if (icc.size() < 132 || std::memcmp(&icc[16], "RGB ", 4) != 0 || std::memcmp(&icc[20], "XYZ ", 4) != 0) return IFHIP_OK;
+    const uint32_t tags = be32(128);
+    if (tags > 200 || 132 + static_cast<size_t>(tags) * 12 > icc.size()) return IFHIP_OK;
+    auto find = [&](const char* sig, size_t* off, size_t* size) {
+        for (uint32_t t = 0; t < tags; ++t) {
+            const size_t e = 132 + static_cast<size_t>(t) * 12;
+            if (std::memcmp(&icc[e], sig, 4) != 0) continue;
+            *off = be32(e + 4); *size = be32(e + 8);
+            return *off + *size <= icc.size() && *size >= 8;
+        }
+        return false;
+    };
+    // primaries, D50-adapted (IEC 61966-2-1 through Bradford, as every sRGB profile carries them)
+    static const double want[3][3] = {{0.4360, 0.2225, 0.0139}, {0.3851, 0.7169, 0.0971}, {0.1431, 0.0606, 0.7141}};
+    const char* xyz_sig[3] = {"rXYZ", "gXYZ", "bXYZ"};
+    for (int c = 0; c < 3; ++c) {
+        size_t off = 0, size = 0;
+        if (!find(xyz_sig[c], &off, &size) || size < 20 || std::memcmp(&icc[off], "XYZ ", 4) != 0) return IFHIP_OK;
+        for (int k = 0; k < 3; ++k) {
+            const double v = static_cast<int32_t>(be32(off + 8 + 4 * static_cast<size_t>(k))) / 65536.0;
+            if (std::fabs(v - want[c][k]) > 0.003) return IFHIP_OK;
+        }
+    }
+    // tone curves: the sRGB parametric form (type 3: g 2.4, a 1/1.055, b 0.055/1.055, c 1/12.92, d 0.04045) or a sampled curve
+    // whose entries follow the sRGB function (checked at every entry; 2 of 65535 is the 16-bit tables' own rounding)
+    const char* trc_sig[3] = {"rTRC", "gTRC", "bTRC"};
+    for (int c = 0; c < 3; ++c) {
+        size_t off = 0, size = 0;
+        if (!find(trc_sig[c], &off, &size) || size < 12) return IFHIP_OK;
+        if (std::memcmp(&icc[off], "para", 4) == 0) {
+            if (size < 12 + 20 || ((static_cast<uint32_t>(icc[off + 8]) << 8) | icc[off + 9]) != 3u) return IFHIP_OK;
+            static const double p[5] = {2.4, 1.0 / 1.055, 0.055 / 1.055, 1.0 / 12.92, 0.04045};
+            for (int k = 0; k < 5; ++k)
+                if (std::fabs(static_cast<int32_t>(be32(off + 12 + 4 * static_cast<size_t>(k))) / 65536.0 - p[k]) > 0.002) return IFHIP_OK;
+        } else if (std::memcmp(&icc[off], "curv", 4) == 0) {
+            const uint32_t n = be32(off + 8);
+            if (n < 256 || 12 + static_cast<size_t>(n) * 2 > size) return IFHIP_OK;      // (a single gamma value is not the sRGB curve)
+            for (uint32_t k = 0; k < n; ++k) {
+                const double x = static_cast<double>(k) / (n - 1), y = x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4);
+                const double got = ((static_cast<uint32_t>(icc[off + 12 + 2 * static_cast<size_t>(k)]) << 8) | icc[off + 13 + 2 * static_cast<size_t>(k)]) / 65535.0;
+                if (std::fabs(got - y) > 2.0 / 65535.0 + 1e-4) return IFHIP_OK;
+            }
+        } else {
+            return IFHIP_OK;
+        }
+    }
+    *kind = 1;
     return IFHIP_OK;
 }
 

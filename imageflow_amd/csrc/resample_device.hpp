@@ -58,7 +58,7 @@ struct ThresholdL2S {
     }
 };
 
-// the whole 16 KiB table, known to be there (fused kernel, IFHIP_ENCODE_STATIC: no per-channel "is it staged" test)
+// the whole 16 KiB table, known to be there (fused kernel, fast pass: asked once per output row, not per channel)
 struct DirectL2S {
     const uint8_t* table;   // LDS, 16384 entries
     __device__ __forceinline__ uint8_t operator[](uint32_t idx) const { return table[idx]; }
@@ -129,24 +129,13 @@ __device__ __forceinline__ uint32_t render_pixel(const ResampleArgs& a, float p0
 // Cache policy of the canvas stores: non-temporal.  A canvas pixel is written once and never read again by the launch, and in
 // a stream of reads mixed with 15 - 36 % of writes (the moderate ratios) the memory system moves 5.4 TB/s with `nt` stores
 // against 4.9 with plain ones (tools/probes/stream_inflight_probe.hip).
-#ifndef IFHIP_CANVAS_STORE_POLICY
-#define IFHIP_CANVAS_STORE_POLICY " nt"
-#endif
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_u32_untracked(uint32_t* p, uint32_t v) {
-#if defined(IFHIP_EXP_PLAIN_STORES)
-    *p = v;
-#else
-    asm volatile("global_store_dword %0, %1, off" IFHIP_CANVAS_STORE_POLICY : : "v"(p), "v"(v) : "memory");
-#endif
+    asm volatile("global_store_dword %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store_f32x4_untracked(float4* p, float x, float y, float z, float w) {
-#if defined(IFHIP_EXP_PLAIN_STORES)
-    *p = make_float4(x, y, z, w);
-#else
     f32x4_t v = {x, y, z, w};
     asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
-#endif
 }
 
 template <bool ALPHA, int LIN = -1, typename LutF, typename LutB>
@@ -161,14 +150,7 @@ __device__ __forceinline__ void store_pixel(const ResampleArgs& a, uint32_t img,
     // (other compositing modes) where no load was issued -- and each such wait drains the source rows in flight.
     if (ALPHA && a.mode == IFHIP_BLEND_WITH_SELF)
         asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(dst) : "v"(cw) : "memory");
-#if defined(IFHIP_EXP_PIXEL_NO_STORE)       // timing experiment: everything but the canvas store (NOT a product path)
-    const uint32_t word = render_pixel<ALPHA, LIN>(a, p0, p1, p2, pa, dst, tb);
-    if (word == 0x12345678u && p0 == 123.0f) store_u32_untracked(cw, word);
-#elif defined(IFHIP_EXP_PIXEL_NO_ENCODE)    // timing experiment: the chains' result stored unencoded (NOT a product path)
-    store_u32_untracked(cw, __float_as_uint(p0) ^ __float_as_uint(p1) ^ __float_as_uint(p2));
-#else
     store_u32_untracked(cw, render_pixel<ALPHA, LIN>(a, p0, p1, p2, pa, dst, tb));
-#endif
     if (a.f32_dump) {
         float4* d = reinterpret_cast<float4*>(a.f32_dump) + (static_cast<size_t>(img) * a.out_h + j) * a.out_w + u;
         store_f32x4_untracked(d, p0, p1, p2, ALPHA ? pa : 1.0f);

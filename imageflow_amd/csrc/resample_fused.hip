@@ -22,37 +22,6 @@
 #ifndef IFHIP_FUSED_K
 #error "compile with -DIFHIP_FUSED_K=<ring size 1..8>"
 #endif
-#ifndef IFHIP_PK_FMA
-#define IFHIP_PK_FMA 1       // vertical pass on v_pk_fma_f32 (0: scalar v_fma_f32, kept for A/B measurements)
-#endif
-#ifndef IFHIP_HP_UNROLL
-#define IFHIP_HP_UNROLL 1    // per-pixel horizontal loop
-#endif
-#ifndef IFHIP_DOT4_LUT
-#define IFHIP_DOT4_LUT 1     // table addresses of the vertical pass by v_dot4_u32_u8 (0: byte extract + shift-add, for A/B)
-#endif
-#ifndef IFHIP_ENCODE_STATIC
-#define IFHIP_ENCODE_STATIC 1    // fast horizontal pass: one test per output ROW for "linear working space, encode table staged", then a
-#endif                           // pixel loop without the per-channel tests, its three table reads in flight together (cfg3 level 1: 3.04 -> 2.91 ms; 0: A/B)
-#ifndef IFHIP_REFILL_EARLY
-#define IFHIP_REFILL_EARLY 0     // BGRA sources: table addresses, THEN the row refill, then the next record and the gathers (see the step loop);
-#endif                           // bit 0: pipelined shapes, bit 1: the plain shape
-#ifndef IFHIP_ALPHA_PAIR_ONE
-#define IFHIP_ALPHA_PAIR_ONE 0   // premultiply: (c2, 1) * (af, af) as one v_pk_mul_f32 (exact: af * 1 == af) instead of v_mul + a copy of af
-#endif
-#ifndef IFHIP_H_LANE_PERM
-#define IFHIP_H_LANE_PERM 1      // fast horizontal pass: output columns dealt to lanes so that every lane group of a 16-byte LDS read
-#endif                           // holds 16 CONSECUTIVE outputs (see tid_h; 0: lane = column, for A/B)
-#ifndef IFHIP_H_META_REGS
-#define IFHIP_H_META_REGS 0      // fast pass: the records of a lane's first two columns in registers (they are the same for every row): experiment
-#endif
-#ifndef IFHIP_HP_LANE_PERM
-#define IFHIP_HP_LANE_PERM 1     // the same dealing for the general per-pixel horizontal pass (thumbnail shapes: windows 4.8 chunks apart
-#endif                           // collide three deep in a scattered lane group, two deep in 16 consecutive columns): cfg2 1.325 -> 1.309 ms
-#ifndef IFHIP_H_UNROLL
-#define IFHIP_H_UNROLL 1     // measured: 1 beats 2 and 3 (-1.7%); the chain is not latency-bound per group, code size matters
-#endif
-
 namespace ifhip {
 
 // ------------------------------------------------------------------------------------------------------
@@ -87,9 +56,6 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     constexpr int C = ALPHA ? 4 : 3;
     constexpr int D = fused_shape(K, C).rows_in_flight;
     constexpr bool PIPE = fused_shape(K, C).pipelined != 0;
-    // (bit 2: only the fast-pass instantiations)
-    constexpr bool RE = (IFHIP_REFILL_EARLY & (PIPE ? 1 : 2)) != 0 && ((IFHIP_REFILL_EARLY & 4) == 0 || FG > 0) && IFHIP_DOT4_LUT != 0 && !YCC;   // step order, see the step loop
-    constexpr bool PAIR1 = IFHIP_ALPHA_PAIR_ONE != 0 && ALPHA && !YCC && !RE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // A workgroup works on F = a.frames_per_wg frames side by side (F > 1 only for sources narrower than half the
@@ -184,37 +150,15 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr int NP = PX * C / 2;                  // pairs per lane and ring slot (PX pixels x C channels)
-    // Ring slots [0, KM) accumulate on the MATRIX pipe: v_mfma_f32_4x4x1_16b_f32 with the step's four slot weights as the
-    // A operand (lane 4b+i holds w[i]) and one converted sample per lane as B computes d[i] = w[i] * v + c[i] for four
-    // slots -- a rank-1 update with k = 1, i.e. four single-rounding fmaf (bit for bit, tools/probes/mfma_fma_probe.hip:
-    // 16.7 M cases on MI355X).  Not a GEMM: no sums inside the instruction, the chains stay strictly ascending.  What it
-    // was meant to buy: the K x PX x C multiply-adds per source row leave the VALU, which keeps the table gathers, the
-    // premultiply and the horizontal pass.  MEASURED (MI355X, round 3, gpurun_out r3_c): bit-exact on the whole resample
-    // suite, and slower on every shape -- cfg5 2.32 -> 2.65 ms with all slots (32 MFMA per row), 2.54 ms with slots 0..3
-    // (16 MFMA + 16 v_pk_fma); cfg2 with alpha 1.85 -> 1.93; cfg2 1.36 -> 1.43.  A 4x4x1 MFMA retires 256 multiply-adds
-    // in 8 cycles of its SIMD's matrix pipe, exactly the rate of v_pk_fma_f32 on the VALU, and the two waves a SIMD holds
-    // here run the same phases at the same time (row barrier), so the pipes take turns instead of overlapping.  Kept as
-    // a build switch (IFHIP_MFMA_MODE, default 0 = off) like IFHIP_PK_FMA; slots [KM, K) stay on v_pk_fma_f32.
-    constexpr int KM = fused_mfma_slots(K, C);
-    constexpr int KQ = KM / 4;                      // MFMA slot groups
-    constexpr int KV = K > KM ? K - KM : 0;         // slots on the VALU
-    constexpr int NV = PX * C;                      // samples per lane and source row
-    f32x4 accm[KQ ? KQ : 1][NV];
-    f32x2 acc[KV ? KV : 1][NP];
+    f32x2 acc[K][NP];
 #pragma unroll
-    for (int s = 0; s < (KQ ? KQ : 1); ++s)
-#pragma unroll
-        for (int i = 0; i < NV; ++i) accm[s][i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int s = 0; s < (KV ? KV : 1); ++s)
+    for (int s = 0; s < K; ++s)
 #pragma unroll
         for (int i = 0; i < NP; ++i) acc[s][i] = f32x2{0.0f, 0.0f};
     auto acc_at = [&](int s, int p, int c) -> float {
         const int f = p * C + c;
-        if (s < KM) return accm[s >> 2][f][s & 3];
-        return (f & 1) ? acc[s - KM][f >> 1].y : acc[s - KM][f >> 1].x;
+        return (f & 1) ? acc[s][f >> 1].y : acc[s][f >> 1].x;
     };
-    const uint32_t lane4 = threadIdx.x & 3u;        // this lane's row of the A operand
 
     typedef uint32_t bgra_raw_t __attribute__((ext_vector_type(PX)));   // one lane's PX source pixels
     struct YccRaw { uint32_t y, cb, cr; };                              // 4 samples of each component plane
@@ -254,17 +198,6 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     typedef __attribute__((address_space(3))) const float lds_cfloat;
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     const uint32_t lut_lane = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(smem + L.lut))) + (lut.lane_off << 2);
-    // IFHIP_ALPHA_PAIR_ONE: the constant 1 next to every pixel's third table value, as a value the optimiser cannot see
-    // through: it then stays in the odd register of the pair the gather writes its even half of, instead of being
-    // re-made every step.  (Used by `convert`, i.e. wherever the step order is not IFHIP_REFILL_EARLY's.)
-    float one[PX];
-    if constexpr (PAIR1) {
-#pragma unroll
-        for (int p = 0; p < PX; ++p) {
-            one[p] = 1.0f;
-            asm volatile("" : "+v"(one[p]));
-        }
-    }
     auto convert = [&](const raw_t& q, f32x2 (&vv)[NP]) {
         float v[PX][C];
         if constexpr (YCC) {
@@ -292,7 +225,6 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) v[p][k] = *reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(ad[p][k]));
         } else {
-#if IFHIP_DOT4_LUT
         // all addresses first, then all reads: a gather issued right behind its own address costs wait states
         uint32_t ad[PX][3];
 #pragma unroll
@@ -300,25 +232,11 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) ad[p][k] = __builtin_amdgcn_udot4(q[p], lut_mul << (8 * k), lut_lane, false);
         __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int p = 0; p < PX; ++p) {
             const uint32_t px = q[p];
-#if IFHIP_DOT4_LUT
 #pragma unroll
             for (int k = 0; k < 3; ++k) v[p][k] = *reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(ad[p][k]));
-#else
-            v[p][0] = lut[px & 255u];
-            v[p][1] = lut[(px >> 8) & 255u];
-            v[p][2] = lut[(px >> 16) & 255u];
-#endif
-            if constexpr (PAIR1) {
-                const float af = static_cast<float>(px >> 24) * (1.0f / 255.0f);
-                const f32x2 a2 = {af, af};
-                vv[2 * p] = f32x2{v[p][0], v[p][1]} * a2;
-                vv[2 * p + 1] = f32x2{v[p][2], one[p]} * a2;       // (c2 * af, af)
-                continue;
-            }
             if (ALPHA) {
                 const float af = static_cast<float>(px >> 24) * (1.0f / 255.0f);
                 v[p][0] = v[p][0] * af;
@@ -328,42 +246,8 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             }
         }
         }
-        if constexpr (PAIR1) return;                               // pairs written above
 #pragma unroll
         for (int i = 0; i < NP; ++i) vv[i] = f32x2{v[(2 * i) / C][(2 * i) % C], v[(2 * i + 1) / C][(2 * i + 1) % C]};
-    };
-
-    // The same conversion in three pieces, for the step order of IFHIP_REFILL_EARLY: what needs the row's bytes (table
-    // addresses, the alpha factor), the gathers, and the pairing / premultiply of what they return.
-    struct Gathered { float g[PX][3]; float af[PX]; };
-    auto conv_addresses = [&](const bgra_raw_t& q, uint32_t (&ad)[PX][3], Gathered& o) {
-#pragma unroll
-        for (int p = 0; p < PX; ++p) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) ad[p][k] = __builtin_amdgcn_udot4(q[p], lut_mul << (8 * k), lut_lane, false);
-            if (ALPHA) o.af[p] = static_cast<float>(q[p] >> 24) * (1.0f / 255.0f);
-        }
-    };
-    auto conv_gather = [&](const uint32_t (&ad)[PX][3], Gathered& o) {
-#pragma unroll
-        for (int p = 0; p < PX; ++p)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) o.g[p][k] = *reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(ad[p][k]));
-    };
-    auto conv_pack = [&](const Gathered& i, f32x2 (&vv)[NP]) {
-        if constexpr (ALPHA) {
-#pragma unroll
-            for (int p = 0; p < PX; ++p) {
-                const f32x2 a2 = {i.af[p], i.af[p]};
-                vv[2 * p] = f32x2{i.g[p][0], i.g[p][1]} * a2;
-                // (not the (c2, 1) pair of IFHIP_ALPHA_PAIR_ONE: with the gathers double buffered the constant would need
-                // two neighbours, and the register allocator answers with spills -- 112 .. 128 bytes of scratch per lane)
-                vv[2 * p + 1] = f32x2{i.g[p][2] * i.af[p], i.af[p]};
-            }
-        } else {
-#pragma unroll
-            for (int n = 0; n < NP; ++n) vv[n] = f32x2{i.g[(2 * n) / 3][(2 * n) % 3], i.g[(2 * n + 1) / 3][(2 * n + 1) % 3]};
-        }
     };
 
     // ---- horizontal pass of one output row (arithmetic contract step 3: per channel, the strictly ascending fmaf sum
@@ -416,7 +300,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     // groups at that ratio).  A permutation inside aligned blocks of 32 columns: stores still cover whole 128-byte lines,
     // the 4-byte reads (two groups of 32 consecutive lanes) see the same set of addresses; pixels are unchanged.
     uint32_t tid_h = tid;
-    if constexpr ((IFHIP_H_LANE_PERM != 0 && FG > 0) || (IFHIP_HP_LANE_PERM != 0 && FG == 0 && PERPIXEL)) {
+    if constexpr (PERPIXEL) {
         const uint32_t q = (tid >> 2) & 7u;                          // lanes 0-3, 4-7, ... 28-31 -> columns 0-3, 16-19, 20-23, 4-7, 24-27, 8-11, 12-15, 28-31
         const uint32_t first4 = (0x7326'1540u >> (4u * q)) & 15u;    // column of the quad's first lane, in units of 4
         tid_h = (tid & ~31u) | (first4 << 2) | (tid & 3u);
@@ -434,7 +318,7 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             float h2 = 0.0f;
             // (narrow shapes, two waves per SIMD: the reads of group q + 1 under the chains of group q -- cfg5 2.27 -> 2.18 ms;
             // at four waves per SIMD the other waves cover that latency and the longer code costs: cfg2 1.416 -> 1.428)
-            constexpr int HPU = IFHIP_HP_UNROLL > 1 ? IFHIP_HP_UNROLL : (fused_shape(K, C).threads == 512 ? 2 : 1);
+            constexpr int HPU = fused_shape(K, C).threads == 512 ? 2 : 1;
 #pragma unroll HPU
             for (uint32_t q = 0; q < m.y; ++q) {
                 const float4 w = wp[q];
@@ -447,18 +331,10 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
         }
     };
     // Mapping 2, fast form: two base addresses per output, everything else immediates.
-    uint32_t hm0 = 0u, hm1 = 0u;
-    if constexpr (IFHIP_H_META_REGS != 0 && FG > 0) {
-        hm0 = tid_h < n_u ? hmeta2[tid_h] : 0u;
-        hm1 = tid_h + T < n_u ? hmeta2[tid_h + T] : 0u;
-    }
     auto h_run_row_pixels_fast = [&](uint32_t j, const float* vrow, auto static_encode) {
         constexpr uint32_t G = fast_g > 0 ? fast_g : 1;
-        uint32_t kcol = 0u;
-        for (uint32_t ul = tid_h; ul < n_store; ul += T, ++kcol) {
-            uint32_t m;
-            if constexpr (IFHIP_H_META_REGS != 0) m = kcol == 0u ? hm0 : (kcol == 1u ? hm1 : hmeta2[ul]);
-            else m = hmeta2[ul];
+        for (uint32_t ul = tid_h; ul < n_store; ul += T) {
+            const uint32_t m = hmeta2[ul];
             f32x2 h01 = {0.0f, 0.0f}, h23 = {0.0f, 0.0f};
             float h2 = 0.0f;
             if constexpr (TWO) {
@@ -537,30 +413,9 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
         raw[d] = fetch_row(steps[s0 + d].y);
         __builtin_amdgcn_sched_barrier(0);      // keep issue order raw[0..D-1]: the loop's vmcnt(D-1) relies on it
     }
-    // Step order RE (IFHIP_REFILL_EARLY, BGRA sources).  Scalar loads and LDS reads share lgkmcnt and return out of
-    // order, so the first use of a scalar-loaded value behind a batch of gathers is a wait for ALL of them.  In the order
-    // further down that use is the refill's row number, right behind the gathers: every lane sits out their round trip
-    // before its multiply-adds and before the row goes back in flight.  RE: the table addresses (the last readers of the
-    // row's registers), then the refill -- its wait finds only what was requested a step ago -- then the next step's
-    // record and the gathers, and the multiply-adds of the current step run under both.  The record is always loaded a
-    // step ahead (two sets of scalar registers, also on the plain shape).
-    static_assert(!RE || D % 2 == 0, "the record's double buffer alternates with the step's parity");
     f32x2 vbuf[PIPE ? 2 : 1][NP];
-    Gathered gb[PIPE ? 2 : 1];
-    VStep rec[(PIPE || RE) ? 2 : 1];
-    if constexpr (RE) {
-        rec[0] = steps[s0];
-        if (PIPE) {
-            if constexpr (!YCC) {
-                uint32_t ad0[PX][3];
-                conv_addresses(raw[0], ad0, gb[0]);
-                conv_gather(ad0, gb[0]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            raw[0] = fetch_row((s0 + D < s1) ? steps[s0 + D].y : -1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else if (PIPE) {
+    VStep rec[PIPE ? 2 : 1];
+    if (PIPE) {
         rec[0] = steps[s0];
         convert(raw[0], vbuf[0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -571,24 +426,9 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     for (uint32_t sb = s0; sb < s1; sb += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const int cur = (PIPE || RE) ? (d & 1) : 0, nxt = (PIPE || RE) ? (cur ^ 1) : 0;
-            const int gcur = PIPE ? cur : 0, gnxt = PIPE ? nxt : 0;       // the plain shape gathers and uses within a step
+            const int cur = PIPE ? (d & 1) : 0, nxt = PIPE ? (cur ^ 1) : 0;
             const uint32_t si = sb + d;
-            f32x2 vloc[NP];
-            if constexpr (RE) {
-                if constexpr (!YCC) {
-                    const int slot = PIPE ? (d + 1) % D : d;               // the row this step converts: of step si + 1 / of step si
-                    uint32_t ad[PX][3];
-                    conv_addresses(raw[slot], ad, gb[gnxt]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    raw[slot] = fetch_row(rec[cur].y_ahead);
-                    __builtin_amdgcn_sched_barrier(0);
-                    rec[nxt] = steps[(si + 1 < s1) ? si + 1 : si];
-                    conv_gather(ad, gb[gnxt]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    conv_pack(gb[gcur], vloc);
-                }
-            } else if (PIPE) {
+            if (PIPE) {
                 // ---- stage A: start step si+1 (record, LUT gathers), refill its row slot for step si+1+D ----
                 const int slot_next = (d + 1) % D;
                 rec[nxt] = steps[(si + 1 < s1) ? si + 1 : si];
@@ -608,44 +448,20 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             }
             // ---- stage B: finish step si ----
             const VStep& st = rec[cur];
-            f32x2 (&v)[NP] = RE ? vloc : vbuf[PIPE ? cur : 0];
-#if defined(IFHIP_EXP_LOAD_ONLY)   // experiment: stream rows, no arithmetic (NOT a product path)
-            acc[0][0] += v[0] + v[1] + v[2] + v[NP - 1];   // (builds with IFHIP_MFMA_MODE=0 only)
-#else
+            f32x2 (&v)[NP] = vbuf[PIPE ? cur : 0];
             // Every ring slot accumulates unconditionally: a slot outside its window holds exactly +0.0f (initial
             // value / reset at flush) and has weight +0.0f in the step record, and fmaf(+0, v, +0) == +0 for the
             // finite non-negative v we feed it, so the result is bit-identical to skipping the slot -- without
             // K scalar branches (and their instruction-fetch bubbles) per source row.
             if (st.y >= 0) {
 #pragma unroll
-                for (int q = 0; q < KQ; ++q) {
-                    const float w01 = (lane4 & 1u) ? st.w[4 * q + 1] : st.w[4 * q];
-                    const float w23 = (lane4 & 1u) ? st.w[4 * q + 3] : st.w[4 * q + 2];
-                    const float wa = (lane4 & 2u) ? w23 : w01;
+                for (int s = 0; s < K; ++s) {
+                    const float w = st.w[s];
 #pragma unroll
-                    for (int f = 0; f < NV; ++f)
-                        accm[q][f] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa, (f & 1) ? v[f >> 1].y : v[f >> 1].x, accm[q][f], 0, 0, 0);
-                }
-#pragma unroll
-                for (int s = 0; s < KV; ++s) {
-                    const float w = st.w[KM + s];
-#pragma unroll
-                    for (int i = 0; i < NP; ++i) {
-#if IFHIP_PK_FMA
-                        acc[s][i] = __builtin_elementwise_fma(f32x2{w, w}, v[i], acc[s][i]);
-#else
-                        acc[s][i].x = __builtin_fmaf(w, v[i].x, acc[s][i].x);
-                        acc[s][i].y = __builtin_fmaf(w, v[i].y, acc[s][i].y);
-#endif
-                    }
+                    for (int i = 0; i < NP; ++i) acc[s][i] = __builtin_elementwise_fma(f32x2{w, w}, v[i], acc[s][i]);
                 }
             }
-#endif
-#if defined(IFHIP_EXP_NO_H)        // experiment: vertical pass only (NOT a product path)
-            if (st.flush_slot >= 0 && st.out_row == 0x7fffffff) {
-#else
             if (st.flush_slot >= 0) {
-#endif
                 // ---- output row j's vertical pass is complete: hand its row to the horizontal pass ----
                 const uint32_t j = static_cast<uint32_t>(st.out_row);
                 float* dst_row = inter + (j & 1u) * inter_stride;
@@ -691,13 +507,8 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                                 else *reinterpret_cast<float2*>(dst_row + 2u * plane_pitch + 2u * tid) = make_float2(acc_at(s, 0, 2), acc_at(s, 1, 2));
                             }
                         }
-                        if (s < KM) {
 #pragma unroll
-                            for (int i = 0; i < NV; ++i) accm[s >> 2][i][s & 3] = 0.0f;
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < NP; ++i) acc[s - KM][i] = f32x2{0.0f, 0.0f};
-                        }
+                        for (int i = 0; i < NP; ++i) acc[s][i] = f32x2{0.0f, 0.0f};
                     }
                 }
                 // One barrier per output row.  After it: row j's vertical result (inter[j&1]) and row j-1's horizontal
@@ -706,24 +517,17 @@ fused_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                 // wave has finished reading them.
                 lds_barrier();
                 if constexpr (h_per_pixel) {
-#if !defined(IFHIP_EXP_NO_CHAIN)
                     if constexpr (FG > 0) {
-#if IFHIP_ENCODE_STATIC
+                        // one test per output ROW for "linear working space, encode table staged": that copy of the pixel loop
+                        // runs without the per-channel tests, its three table reads in flight together
                         if (a.linear && l2s_lds != nullptr) h_run_row_pixels_fast(j, dst_row, std::true_type{});
-                        else
-#endif
-                            h_run_row_pixels_fast(j, dst_row, std::false_type{});
+                        else h_run_row_pixels_fast(j, dst_row, std::false_type{});
                     }
                     else h_run_row_pixels(j, dst_row);
-#endif
                 } else {
-#if !defined(IFHIP_EXP_NO_STORE)
                     if (h_out_row >= 0) h_store_row(static_cast<uint32_t>(h_out_row), obuf + (static_cast<uint32_t>(h_out_row) & 1u) * obuf_stride);
-#endif
                     h_out_row = static_cast<int>(j);
-#if !defined(IFHIP_EXP_NO_CHAIN)
                     h_run_row(dst_row, obuf + (j & 1u) * obuf_stride);
-#endif
                 }
             }
         }

@@ -329,6 +329,22 @@ hipError_t launch_fused(const ResampleArgs& a, int slots, bool alpha, bool per_p
     }
 }
 
+// the wave-specialised form for moderate ratios (resample_ws.hip, one translation unit per ring size 1..5)
+#define IFHIP_DECL_WS(n) hipError_t launch_ws_k##n(const ResampleArgs&, dim3, dim3, size_t, hipStream_t);
+IFHIP_DECL_WS(1) IFHIP_DECL_WS(2) IFHIP_DECL_WS(3) IFHIP_DECL_WS(4) IFHIP_DECL_WS(5)
+
+hipError_t launch_ws(const ResampleArgs& a, int slots, uint32_t grid, uint32_t block, size_t lds, hipStream_t st) {
+    const dim3 g(grid), b(block);
+    switch (slots) {
+    case 1: return launch_ws_k1(a, g, b, lds, st);
+    case 2: return launch_ws_k2(a, g, b, lds, st);
+    case 3: return launch_ws_k3(a, g, b, lds, st);
+    case 4: return launch_ws_k4(a, g, b, lds, st);
+    case 5: return launch_ws_k5(a, g, b, lds, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, uint32_t img0, uint32_t n_img,
                           hipStream_t st) {
     const dim3 bv(256), gv((a.in_w + 255u) / 256u, a.out_h, n_img);

@@ -49,10 +49,16 @@ def gather_outputs(local: torch.Tensor, n_frames: int, group=None, async_op=Fals
     return finish()
 
 
+def _global_rank(group, group_rank: int) -> int:
+    """torch.distributed's point-to-point and rooted calls take GLOBAL ranks; inside a sub-group the two numberings differ."""
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
+
+
 def gather_to_root(local: torch.Tensor, root: int = 0, group=None, async_op=False, out=None):
-    """The job's final gather (BASELINE north_star): equally shaped shards [n_local, ...] -> rank `root` receives
-    [world, n_local, ...]; every other rank only sends.  Over RCCL this is one direct xGMI transfer per peer (7 links
-    into the root in parallel), 1/8 of an all_gather's traffic.  Returns (work_or_None, out_or_None)."""
+    """The job's final gather (BASELINE north_star): equally shaped shards [n_local, ...] -> the group's rank `root`
+    receives [world, n_local, ...]; every other rank only sends.  Over RCCL this is one direct xGMI transfer per peer (7
+    links into the root in parallel), 1/8 of an all_gather's traffic.  `root` is a rank OF THE GROUP (0 = its first
+    member).  Returns (work_or_None, out_or_None)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     local = local.contiguous()
@@ -61,27 +67,29 @@ def gather_to_root(local: torch.Tensor, root: int = 0, group=None, async_op=Fals
         if out is None:
             out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         gather_list = [out[r] for r in range(world)]
-    work = dist.gather(local, gather_list, dst=root, group=group, async_op=async_op)
+    work = dist.gather(local, gather_list, dst=_global_rank(group, root), group=group, async_op=async_op)
     return (work if async_op else None), (out if rank == root else None)
 
 
 def gather_bytes_to_root(local: torch.Tensor, root: int = 0, group=None, out=None):
     """The final gather of a job whose outputs are FILES (export_4_sizes ends in four JPEGs per image,
     imageflow_tool/src/self_test.rs:185-198): every rank holds one 1-D uint8 message of its own length (its files packed
-    back to back, codecs.mozjpeg.pack_files_device).  The lengths travel first (one small all_gather), then every peer
-    sends exactly its bytes to `root` -- grouped point-to-point transfers, over RCCL one direct xGMI link per peer.
+    back to back, codecs.mozjpeg.pack_files_device).  The lengths travel first (one small all_gather, read with ONE
+    device-to-host copy), then every peer sends exactly its bytes to the group's rank `root` -- grouped point-to-point
+    transfers (batch_isend_irecv on both sides), over RCCL one direct xGMI link per peer.
     Returns (sizes [world] as a list, received) where received is, on the root, the list of the ranks' messages (views
     into `out` when given: a uint8 buffer of at least the sum of the sizes), elsewhere None."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     local = local.contiguous().view(-1)
     mine = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
-    each = [torch.empty(1, dtype=torch.int64, device=local.device) for _ in range(world)]
-    dist.all_gather(each, mine, group=group)
-    sizes = [int(v.item()) for v in each]
+    each = torch.empty(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(each, mine, group=group)
+    sizes = [int(v) for v in each.tolist()]
     if rank != root:
         if sizes[rank]:
-            dist.send(local, dst=root, group=group)
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, _global_rank(group, root), group)]):
+                w.wait()
         return sizes, None
     total = sum(sizes)
     if out is None:
@@ -96,7 +104,7 @@ def gather_bytes_to_root(local: torch.Tensor, root: int = 0, group=None, out=Non
         if r == rank:
             view.copy_(local)
         elif sizes[r]:
-            ops.append(dist.P2POp(dist.irecv, view, r, group))
+            ops.append(dist.P2POp(dist.irecv, view, _global_rank(group, r), group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()

@@ -239,6 +239,15 @@ IFHIP_API int ifhip_jpeg_parse_headers(const uint8_t* jpeg, size_t len, uint32_t
 /* EXIF orientation as MozJpegDecoder::get_exif_rotation_flag reads it (codecs/mozjpeg_decoder.rs:290-292, :625-627 ->
  * mozjpeg_decoder_helpers.rs:107-202): *flag = -1 when the file carries none, else the tag's value 0..8.  Host only. */
 IFHIP_API int ifhip_jpeg_exif_orientation(const uint8_t* jpeg, size_t len, int* flag);
+/* The embedded colour profile as MozJpegDecoder sees it (APP2 "ICC_PROFILE" chunks, codecs/mozjpeg_decoder.rs:370-420):
+ * the reference transforms a frame to sRGB whenever the file carries ANY profile (:409, SourceProfile::is_srgb is true
+ * only for "no profile") unless the job told the decoder discard_color_profile (:88-95).  This library has no colour
+ * management (out of scope), so callers must know when a file needs it.  *kind = 0: no profile;
+ * 1: a profile that describes sRGB itself (RGB matrix profile, sRGB primaries within 0.003 after D50 adaptation, the sRGB
+ * tone curve) -- the reference's transform is the identity up to its own rounding; 2: any other profile (Display P3,
+ * Adobe RGB, CMYK, grey, malformed chunks ...) -- decoding the samples as they are gives other colours than the
+ * reference.  Host only. */
+IFHIP_API int ifhip_jpeg_icc_profile_kind(const uint8_t* jpeg, size_t len, int* kind);
 /* Host-side entropy decoding of the Huffman JPEGs the GPU entropy stage does not take -- progressive (SOF2: what the
  * reference's own mozjpeg encoder preset writes, codecs/mozjpeg.rs:121-123) and sequential files with several / non-
  * interleaved scans -- into the same coefficient planes ([blocks_h][blocks_w][64] int16, natural order, MCU-padded), so

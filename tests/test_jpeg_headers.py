@@ -250,3 +250,86 @@ def test_exif_orientation_follows_the_reference_parser(golden_dir):
     sos = base.index(b"\xff\xda")
     assert _exif_flag(base[:sos] + base[sos:-2] + _exif_app1(6) + b"\xff\xd9") == -1
 
+
+
+# ---- embedded ICC profile (ifhip_jpeg_icc_profile_kind; codecs/mozjpeg_decoder.rs:370-420) -----------------------------------
+SRGB_XYZ = ((0.4360, 0.2225, 0.0139), (0.3851, 0.7169, 0.0971), (0.1431, 0.0606, 0.7141))
+P3_XYZ = ((0.5151, 0.2412, -0.0011), (0.2920, 0.6922, 0.0419), (0.1571, 0.0666, 0.7841))
+
+
+def make_icc(xyz=SRGB_XYZ, trc="para", space=b"RGB ", pcs=b"XYZ "):
+    """A minimal matrix/TRC ICC profile: header, tag table, rXYZ gXYZ bXYZ, one tone-curve element shared by r/g/bTRC."""
+    import struct
+
+    def s15(v):
+        return struct.pack(">i", int(round(v * 65536)))
+    if trc == "para":
+        curve = b"para" + b"\0" * 4 + struct.pack(">HH", 3, 0) + b"".join(s15(v) for v in (2.4, 1 / 1.055, 0.055 / 1.055, 1 / 12.92, 0.04045))
+    elif trc == "curv1024":
+        n = 1024
+        xs = [k / (n - 1) for k in range(n)]
+        ys = [x / 12.92 if x <= 0.04045 else ((x + 0.055) / 1.055) ** 2.4 for x in xs]
+        curve = b"curv" + b"\0" * 4 + struct.pack(">I", n) + b"".join(struct.pack(">H", int(round(y * 65535))) for y in ys)
+    elif trc == "gamma22":
+        curve = b"curv" + b"\0" * 4 + struct.pack(">I", 1) + struct.pack(">H", int(2.2 * 256)) + b"\0\0"
+    else:
+        raise ValueError(trc)
+    elems = [b"XYZ " + b"\0" * 4 + b"".join(s15(v) for v in c) for c in xyz] + [curve]
+    sigs = [b"rXYZ", b"gXYZ", b"bXYZ", b"rTRC", b"gTRC", b"bTRC"]
+    which = [0, 1, 2, 3, 3, 3]
+    table_end = 128 + 4 + 12 * len(sigs)
+    offs, body = [], b""
+    for e in elems:
+        offs.append(table_end + len(body))
+        body += e + b"\0" * (-len(e) % 4)
+    table = struct.pack(">I", len(sigs)) + b"".join(sig + struct.pack(">II", offs[w], len(elems[w])) for sig, w in zip(sigs, which))
+    size = table_end + len(body)
+    header = struct.pack(">I", size) + b"test" + bytes([4, 0x30, 0, 0]) + b"mntr" + space + pcs + b"\0" * 12 + b"acsp" + b"\0" * (128 - 40)
+    assert len(header) == 128
+    return header + table + body
+
+
+def icc_app2(profile, pieces=1, drop=None, dup=False):
+    import struct
+    step = -(-len(profile) // pieces)
+    segs = []
+    for k in range(pieces):
+        part = profile[k * step:(k + 1) * step]
+        data = b"ICC_PROFILE\0" + bytes([k + 1, pieces]) + part
+        segs.append(b"\xff\xe2" + struct.pack(">H", len(data) + 2) + data)
+    if drop is not None:
+        del segs[drop]
+    if dup:
+        segs.append(segs[0])
+    return b"".join(segs)
+
+
+def icc_kind(jpeg):
+    import ctypes as C
+    from imageflow_amd import _native
+    L = _native.lib()
+    L.ifhip_jpeg_icc_profile_kind.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    kind = C.c_int(-7)
+    assert L.ifhip_jpeg_icc_profile_kind(jpeg, len(jpeg), C.byref(kind)) == 0
+    return kind.value
+
+
+def test_icc_profile_kind(golden_dir):
+    """0 = no profile (the only case the reference does not run its CMS for, mozjpeg_decoder.rs:409), 1 = a profile that IS
+    sRGB (matrix profile, sRGB primaries and tone curve), 2 = anything else, malformed chunk sets included."""
+    base = next(all_files(golden_dir))[1]
+    assert icc_kind(base) == 0
+    assert icc_kind(_with_segments(base, icc_app2(make_icc()))) == 1
+    assert icc_kind(_with_segments(base, icc_app2(make_icc(trc="curv1024")))) == 1
+    assert icc_kind(_with_segments(base, _exif_app1(6), icc_app2(make_icc(), pieces=3))) == 1          # reassembled from three markers
+    assert icc_kind(_with_segments(base, icc_app2(make_icc(xyz=P3_XYZ)))) == 2                          # Display P3 primaries
+    assert icc_kind(_with_segments(base, icc_app2(make_icc(trc="gamma22")))) == 2                       # sRGB primaries, plain gamma
+    assert icc_kind(_with_segments(base, icc_app2(make_icc(space=b"CMYK")))) == 2
+    assert icc_kind(_with_segments(base, icc_app2(make_icc(space=b"GRAY")))) == 2
+    assert icc_kind(_with_segments(base, icc_app2(make_icc(), pieces=3, drop=1))) == 2                  # a chunk is missing
+    assert icc_kind(_with_segments(base, icc_app2(make_icc(), pieces=2, dup=True))) == 2                # a chunk twice
+    assert icc_kind(_with_segments(base, icc_app2(make_icc()[:100]))) == 2                              # shorter than a header
+    nearly = make_icc(xyz=((0.4360 + 0.004, 0.2225, 0.0139),) + SRGB_XYZ[1:])                           # a primary off by 0.004
+    assert icc_kind(_with_segments(base, icc_app2(nearly))) == 2
+    sos = base.index(b"\xff\xda")                                                                       # behind SOS: never seen
+    assert icc_kind(base[:sos] + base[sos:-2] + icc_app2(make_icc(xyz=P3_XYZ)) + b"\xff\xd9") == 0
