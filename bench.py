@@ -29,8 +29,8 @@ also carries what a step costs without the encoders.
 --workload cfg4 is BASELINE config 4: 3840x2160 4:2:0 q85 baseline JPEG files (SURVEY.md 8d's recipe: the gradient of
 bench_codecs.rs:24-41 and a noise variant, written once on the host with Pillow) -> GPU entropy decode -> 4/8 IDCT with the
 spatial sRGB luma scaler + YCbCr (what the reference's decoder is asked for when the job wants 800 px:
-codecs/mozjpeg_decoder.rs:295-420,588-618) -> 800x450 Robidoux (flow/nodes/scale_render.rs:304-313), 64 files per GPU in
-batches of 16 with --batches-in-flight host threads / HIP streams (default 4).  The compressed scans are resident in HBM
+codecs/mozjpeg_decoder.rs:295-420,588-618) -> 800x450 Robidoux (flow/nodes/scale_render.rs:304-313), 128 files per GPU
+(1 024 over 8 GPUs) in --batches-in-flight batches (default 4 x 32), one host thread and HIP stream each.  The compressed scans are resident in HBM
 (un-stuffed, as the entropy stage reads them) when the timed region starts.  value = source megapixels through the WHOLE
 chain per second; `roofline` is the pixel stage + resize call alone on SURVEY 8d's 26 323 584 bytes per image (the entropy
 walk is latency-bound bit-serial work: HBM is not its yardstick); cpu_baseline = libjpeg-turbo (Pillow) DCT-domain 1/2
@@ -78,7 +78,7 @@ WORKLOADS = {
     # the whole export_4_sizes job: the tuple describes level 0, PYRAMID the chain
     "cfg3": (3840, 2160, 1600, 900, "Robidoux", 0.0, False, "ReplaceSelf", 0, 128),
 }
-CFG4 = {"in_w": 3840, "in_h": 2160, "dec_w": 1920, "dec_h": 1080, "out_w": 800, "out_h": 450, "files_per_gpu": 64, "batch": 16,
+CFG4 = {"in_w": 3840, "in_h": 2160, "dec_w": 1920, "dec_h": 1080, "out_w": 800, "out_h": 450, "files_per_gpu": 128, "batch": 32,
         "bytes_per_image": 26_323_584}                             # coefficients + quant tables in, 800x450 BGRA out
 PYRAMID = [("src", "1600", 1600, 900), ("1600", "1200", 1200, 675), ("1600", "800", 800, 450), ("1200", "400", 400, 225)]
 PYRAMID_BYTES_PER_IMAGE = 58_737_600

@@ -7,3 +7,10 @@ codecs::{mozjpeg_decoder, mozjpeg} and the flow nodes in front of them) used by 
 PyTorch supplies device memory, streams and torch.distributed only.
 """
 from .errors import ErrorKind, FlowError  # noqa: F401
+
+
+def trim_cache(keep_device_bytes=0, keep_host_bytes=0):
+    """Give the library's recycled device / pinned blocks back to the driver (ifhip_cache_trim): call it
+    next to torch.cuda.empty_cache() or after a torch out-of-memory error.  -> (device, host) bytes released."""
+    from . import _native
+    return _native.trim_cache(keep_device_bytes, keep_host_bytes)

@@ -67,6 +67,39 @@ def debug_set(key, value):
     check(lib().ifhip_debug_set(key.encode(), None if value is None else str(value).encode()))
 
 
+def trim_cache(keep_device_bytes=0, keep_host_bytes=0):
+    """ifhip_cache_trim: give the library's recycled device / pinned blocks back to the driver (what a torch program calls
+    next to torch.cuda.empty_cache() or after an out-of-memory error; blocks in use are not touched).  -> (device, host) bytes released."""
+    d, h = C.c_size_t(0), C.c_size_t(0)
+    L = lib()
+    L.ifhip_cache_trim.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    check(L.ifhip_cache_trim(keep_device_bytes, keep_host_bytes, C.byref(d), C.byref(h)))
+    return d.value, h.value
+
+
+class CacheStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "device_hits", "device_driver_allocs", "device_driver_frees", "device_oom_flushes", "device_wide_syncs",
+        "device_bytes_cached", "device_bytes_live", "device_blocks_live", "device_limit_bytes",
+        "host_hits", "host_driver_allocs", "host_driver_frees",
+        "host_bytes_cached", "host_bytes_live", "host_blocks_live", "host_limit_bytes")]
+
+
+def cache_stats():
+    """ifhip_cache_stats as a dict."""
+    st = CacheStats()
+    L = lib()
+    L.ifhip_cache_stats.argtypes = [C.POINTER(CacheStats)]
+    check(L.ifhip_cache_stats(C.byref(st)))
+    return {n: getattr(st, n) for n, _ in CacheStats._fields_}
+
+
+def set_cache_limits(device_bytes, host_bytes):
+    L = lib()
+    L.ifhip_cache_set_limits.argtypes = [C.c_size_t, C.c_size_t]
+    check(L.ifhip_cache_set_limits(device_bytes, host_bytes))
+
+
 def check(rc):
     if rc != 0:
         msg = lib().ifhip_last_error_message()

@@ -31,10 +31,10 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hip")) and f not in (FUSED, WS))
 
 
-def compile_jobs(extra_defines=()):
+def compile_jobs():
     """(command, object) pairs for every translation unit."""
     jobs = []
-    defs = [f"-D{d}" for d in extra_defines]
+    defs = []
     for src in sources():
         obj = os.path.join(HERE, "lib", os.path.basename(src) + ".o")
         jobs.append(([HIPCC, "-x", "hip", "--offload-arch=gfx950"] + COMMON + defs + ["-c", src, "-o", obj], obj))
@@ -72,18 +72,6 @@ def stale():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "imageflow_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
-
-
-def build_variant(name, defines):
-    """Experiment builds (tools/): same sources with extra -D flags into lib/libimageflow_hip_<name>.so."""
-    out = os.path.join(HERE, "lib", f"libimageflow_hip_{name}.so")
-    tmp = os.path.join(HERE, "lib", f"variant_{name}")
-    os.makedirs(tmp, exist_ok=True)
-    jobs = [(cmd[:-1] + [os.path.join(tmp, os.path.basename(obj))], os.path.join(tmp, os.path.basename(obj)))
-            for cmd, obj in compile_jobs(defines)]
-    objs = run_jobs(jobs)
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, check=True)
-    return out
 
 
 def build(force=False, verbose=False):

@@ -381,7 +381,10 @@ struct DecodedBatch {
     uint8_t hs[3] = {1, 1, 1}, vs[3] = {1, 1, 1};
     // the last share goes when its job ends -- every job waits for its own stream before it lets go (quiesce), the
     // batch's decode itself was complete before any share was handed out
+    // (... and on an error path between the decode's launch and its wait this destructor IS the wait: the planes may not
+    // go back to the cache with the decode still writing them)
     ~DecodedBatch() {
+        quiesce();
         for (int16_t* p : coef) if (p) (void)ifhip::cached_free(p);
         if (d_qt) (void)ifhip::cached_free(d_qt);
     }
@@ -668,7 +671,8 @@ struct PlanKey {
     }
 };
 std::mutex g_plan_mu;
-std::map<PlanKey, std::pair<std::shared_ptr<ifhip_resample_plan>, uint64_t>> g_plans;
+typedef std::map<PlanKey, std::pair<std::shared_ptr<ifhip_resample_plan>, uint64_t>> PlanMap;
+PlanMap& plan_map() { static PlanMap* m = new PlanMap; return *m; }        // never destroyed: no HIP calls from static destructors at exit
 uint64_t g_plan_clock = 0;
 std::shared_ptr<ifhip_resample_plan> shared_plan(uint32_t in_w, uint32_t in_h, uint32_t w, uint32_t h, int filter, float sharpen) {
     int dev = 0;
@@ -678,22 +682,32 @@ std::shared_ptr<ifhip_resample_plan> shared_plan(uint32_t in_w, uint32_t in_h, u
     const PlanKey key{dev, in_w, in_h, w, h, filter, bits};
     {
         std::lock_guard<std::mutex> lk(g_plan_mu);
-        auto it = g_plans.find(key);
-        if (it != g_plans.end()) { it->second.second = ++g_plan_clock; return it->second.first; }
+        auto it = plan_map().find(key);
+        if (it != plan_map().end()) { it->second.second = ++g_plan_clock; return it->second.first; }
     }
     ifhip_resample_plan* raw = nullptr;
     check(ifhip_resample_plan_create(&raw, in_w, in_h, w, h, filter, sharpen));
     // (a plan dropped from the cache while a job still holds it is destroyed by that job's thread, behind its stream's wait;
     // one dropped with no holder was last used by a job that has ended: plain destroy)
+    // A plan's tables are only ever READ by kernels, and every job waits for its stream before it drops its reference
+    // (PendingJpeg / Job teardown), so the last reference -- whoever holds it -- goes with nothing in flight on the plan; the
+    // deleter still waits for the releasing thread's stream and, outside a job, the whole device (cached_free).
     std::shared_ptr<ifhip_resample_plan> sp(raw, [](ifhip_resample_plan* q) { quiesce(); ifhip_resample_plan_destroy(q); });
-    std::lock_guard<std::mutex> lk(g_plan_mu);
-    if (g_plans.size() >= 256) {
-        auto victim = g_plans.begin();
-        for (auto it = g_plans.begin(); it != g_plans.end(); ++it) if (it->second.second < victim->second.second) victim = it;
-        g_plans.erase(victim);
+    std::shared_ptr<ifhip_resample_plan> evicted;                // released AFTER the lock: its deleter waits for a stream
+    std::shared_ptr<ifhip_resample_plan> result;
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        PlanMap& plans = plan_map();
+        if (plans.size() >= 256) {
+            auto victim = plans.begin();
+            for (auto it = plans.begin(); it != plans.end(); ++it) if (it->second.second < victim->second.second) victim = it;
+            evicted = std::move(victim->second.first);
+            plans.erase(victim);
+        }
+        auto ins = plans.emplace(key, std::make_pair(sp, ++g_plan_clock));
+        result = ins.first->second.first;
     }
-    auto ins = g_plans.emplace(key, std::make_pair(sp, ++g_plan_clock));
-    return ins.first->second.first;
+    return result;
 }
 
 struct Job {
@@ -1441,9 +1455,9 @@ struct Job {
                 const Io& told = input(static_cast<int32_t>(want_int(p, "io_id", "decode")));
                 if (told.told) { hw = told.told_w; hh = told.told_h; spatial = told.told_spatial; gamma = told.told_gamma; }
             }
-            if (const JVal* cmds = p.get("commands"))
-                if (cmds->t == JVal::Arr)
-                    for (const JVal& cmd : cmds->a)
+            if (const JVal* cmds = p.get("commands")) {
+                if (cmds->t == JVal::Arr) {
+                    for (const JVal& cmd : cmds->a) {
                         if (cmd.t == JVal::Str && cmd.s == "discard_color_profile") {
                             input(static_cast<int32_t>(want_int(p, "io_id", "decode"))).told_discard_profile = true;
                         } else if (const JVal* j = cmd.get("jpeg_downscale_hints")) {        // s::JpegIDCTDownscaleHints
@@ -1451,6 +1465,9 @@ struct Job {
                             if (const JVal* b = j->get("scale_luma_spatially")) spatial = b->t == JVal::Bool && b->b;
                             if (const JVal* b = j->get("gamma_correct_for_srgb_during_spatial_luma_scaling")) gamma = b->t == JVal::Bool && b->b;
                         }
+                    }
+                }
+            }
             return decode_oriented(static_cast<int32_t>(want_int(p, "io_id", "decode")), hw, hh, spatial, gamma);
         }
         if (name == "create_canvas") {

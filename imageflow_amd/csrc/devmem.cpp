@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -24,8 +25,12 @@ namespace ifhip {
 namespace {
 
 constexpr size_t kMinClass = 256;
-constexpr size_t kKeepDeviceBytes = size_t(24) << 30;      // per device (of 288 GB)
-constexpr size_t kKeepHostBytes = size_t(2) << 30;
+// What the free lists may hold (blocks handed out do not count).  The memory parked here is invisible to every other allocator
+// on the device -- torch's caching allocator, another process -- so the default is what a few hundred concurrent thumbnail jobs
+// recycle (a 4K decode job: 33 MB frame + 25 MB coefficient planes), not a share of the 288 GB; a service that runs nothing
+// else on the device raises it (ifhip_cache_set_limits), anybody can give the lists back (ifhip_cache_trim).
+std::atomic<size_t> g_keep_device_bytes{size_t(8) << 30};  // per device
+std::atomic<size_t> g_keep_host_bytes{size_t(1) << 30};
 
 // size classes: 2^k * {8..15} / 8 -- at most 12.5 % above the request
 size_t size_class(size_t bytes) {
@@ -40,7 +45,8 @@ struct Cache {
     std::mutex mu;
     std::map<size_t, std::vector<void*>> free_lists;                  // class -> blocks
     std::map<void*, size_t> live;                                     // block -> class (handed out)
-    size_t kept = 0;
+    size_t kept = 0, live_bytes = 0;
+    uint64_t hits = 0, driver_allocs = 0, driver_frees = 0, oom_flushes = 0, device_syncs = 0;   // (ifhip_cache_stats)
 };
 Cache& device_cache(int dev) {
     static std::mutex mu;
@@ -75,6 +81,8 @@ int cached_malloc(void** out, size_t bytes) {
             it->second.pop_back();
             c.kept -= cls;
             c.live[*out] = cls;
+            c.live_bytes += cls;
+            ++c.hits;
             return 0;
         }
     }
@@ -86,6 +94,8 @@ int cached_malloc(void** out, size_t bytes) {
             std::lock_guard<std::mutex> lk(c.mu);
             for (auto& kv : c.free_lists) { drop.insert(drop.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
             c.kept = 0;
+            ++c.oom_flushes;
+            c.driver_frees += drop.size();
         }
         for (void* p : drop) (void)hipFree(p);
         e = hipMalloc(out, cls);
@@ -93,6 +103,8 @@ int cached_malloc(void** out, size_t bytes) {
     }
     std::lock_guard<std::mutex> lk(c.mu);
     c.live[*out] = cls;
+    c.live_bytes += cls;
+    ++c.driver_allocs;
     return 0;
 }
 
@@ -101,22 +113,26 @@ int cached_free(void* p) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return static_cast<int>(hipFree(p));
     // the block may be handed to another thread at once: nothing of the previous owner's work may still touch it
-    if (t_quiesced == 0) (void)hipDeviceSynchronize();
+    const bool sync = t_quiesced == 0;
+    if (sync) (void)hipDeviceSynchronize();
     Cache& c = device_cache(dev);
     size_t cls = 0;
     {
         std::lock_guard<std::mutex> lk(c.mu);
+        if (sync) ++c.device_syncs;
         auto it = c.live.find(p);
         if (it == c.live.end()) cls = 0;                              // not ours (another device's block, or a foreign pointer)
         else {
             cls = it->second;
             c.live.erase(it);
-            if (c.kept + cls <= kKeepDeviceBytes) {
+            c.live_bytes -= cls;
+            if (c.kept + cls <= g_keep_device_bytes.load(std::memory_order_relaxed)) {
                 c.free_lists[cls].push_back(p);
                 c.kept += cls;
                 return 0;
             }
         }
+        ++c.driver_frees;
     }
     return static_cast<int>(hipFree(p));
 }
@@ -133,6 +149,8 @@ int cached_host_malloc(void** out, size_t bytes) {
             it->second.pop_back();
             c.kept -= cls;
             c.live[*out] = cls;
+            c.live_bytes += cls;
+            ++c.hits;
             return 0;
         }
     }
@@ -140,6 +158,8 @@ int cached_host_malloc(void** out, size_t bytes) {
     if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return static_cast<int>(e); }
     std::lock_guard<std::mutex> lk(c.mu);
     c.live[*out] = cls;
+    c.live_bytes += cls;
+    ++c.driver_allocs;
     return 0;
 }
 
@@ -152,15 +172,39 @@ int cached_host_free(void* p) {
         if (it != c.live.end()) {
             const size_t cls = it->second;
             c.live.erase(it);
-            if (c.kept + cls <= kKeepHostBytes) {
+            c.live_bytes -= cls;
+            if (c.kept + cls <= g_keep_host_bytes.load(std::memory_order_relaxed)) {
                 c.free_lists[cls].push_back(p);
                 c.kept += cls;
                 return 0;
             }
         }
+        ++c.driver_frees;
     }
     return static_cast<int>(hipHostFree(p));
 }
+
+namespace {
+// give free-listed blocks back to the driver until at most `keep` bytes stay parked; largest classes first
+template <typename FreeFn>
+size_t trim_cache(Cache& c, size_t keep, FreeFn release) {
+    std::vector<void*> drop;
+    size_t dropped = 0;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        for (auto it = c.free_lists.rbegin(); it != c.free_lists.rend() && c.kept > keep; ++it)
+            while (!it->second.empty() && c.kept > keep) {
+                drop.push_back(it->second.back());
+                it->second.pop_back();
+                c.kept -= it->first;
+                dropped += it->first;
+            }
+        c.driver_frees += drop.size();
+    }
+    for (void* p : drop) release(p);
+    return dropped;
+}
+}  // namespace
 
 // "is this device a gfx950?" -- hipGetDeviceProperties fills a kilobyte struct through the driver; asked once per device
 int require_gfx950(int* device_out) {
@@ -209,3 +253,43 @@ int zero_device(void* dst, size_t bytes) {                            // ordered
 }  // namespace ifhip
 
 extern "C" void ifhip_set_thread_stream(void* hip_stream) { ifhip::t_stream = static_cast<hipStream_t>(hip_stream); }
+
+extern "C" int ifhip_cache_set_limits(size_t device_bytes, size_t host_bytes) {
+    ifhip::g_keep_device_bytes.store(device_bytes, std::memory_order_relaxed);
+    ifhip::g_keep_host_bytes.store(host_bytes, std::memory_order_relaxed);
+    return IFHIP_OK;
+}
+
+extern "C" int ifhip_cache_trim(size_t keep_device_bytes, size_t keep_host_bytes, size_t* released_device_bytes, size_t* released_host_bytes) {
+    int dev = -1;
+    size_t d = 0;
+    // cached blocks are idle by construction (a block enters a list only behind a device-wide wait or a quiesced stream), so
+    // releasing them needs no further wait here
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0) d = ifhip::trim_cache(ifhip::device_cache(dev), keep_device_bytes, [](void* p) { (void)hipFree(p); });
+    const size_t h = ifhip::trim_cache(ifhip::host_cache(), keep_host_bytes, [](void* p) { (void)hipHostFree(p); });
+    if (released_device_bytes) *released_device_bytes = d;
+    if (released_host_bytes) *released_host_bytes = h;
+    return IFHIP_OK;
+}
+
+extern "C" int ifhip_cache_stats(ifhip_cache_stats_t* out) {
+    if (!out) return ifhip::fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null out-pointer");
+    std::memset(out, 0, sizeof *out);
+    int dev = -1;
+    auto fill = [](ifhip::Cache& c, uint64_t* v) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        v[0] = c.hits; v[1] = c.driver_allocs; v[2] = c.driver_frees; v[3] = c.kept; v[4] = c.live_bytes; v[5] = c.live.size(); v[6] = c.oom_flushes; v[7] = c.device_syncs;
+    };
+    uint64_t v[8];
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0) {
+        fill(ifhip::device_cache(dev), v);
+        out->device_hits = v[0]; out->device_driver_allocs = v[1]; out->device_driver_frees = v[2]; out->device_bytes_cached = v[3];
+        out->device_bytes_live = v[4]; out->device_blocks_live = v[5]; out->device_oom_flushes = v[6]; out->device_wide_syncs = v[7];
+    }
+    fill(ifhip::host_cache(), v);
+    out->host_hits = v[0]; out->host_driver_allocs = v[1]; out->host_driver_frees = v[2]; out->host_bytes_cached = v[3];
+    out->host_bytes_live = v[4]; out->host_blocks_live = v[5];
+    out->device_limit_bytes = ifhip::g_keep_device_bytes.load(std::memory_order_relaxed);
+    out->host_limit_bytes = ifhip::g_keep_host_bytes.load(std::memory_order_relaxed);
+    return IFHIP_OK;
+}

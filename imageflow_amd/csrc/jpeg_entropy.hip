@@ -1332,8 +1332,16 @@ static int create_prepared_impl(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* c
     FastTabs *d_ftabs = nullptr, *d_ptabs = nullptr, *d_ctabs = nullptr;
     SearchTab* d_stabs = nullptr;
     if ((rc = dev_alloc<uint32_t>(e.get(), &d_words, n_words))) return rc;
+    // From here on copies into `d_words` FROM the callers' pinned buffers may be queued on the thread's stream.  On any failure
+    // below `e` is destroyed and its blocks go back to the cache -- inside an ABI job without a device-wide wait (QuiescedScope)
+    // -- and the callers free their pinned sources: neither may happen with a copy still in flight, or the next owner of
+    // either block is written over.  Every exit path of this function therefore waits for the stream first.
+    struct StreamDrain {
+        hipStream_t st;
+        ~StreamDrain() { (void)hipStreamSynchronize(st); }
+    } drain{static_cast<hipStream_t>(thread_stream())};
     {   // every file's words straight from its pinned buffer to its place: n asynchronous copies, one wait (below, with the tables')
-        hipStream_t st = static_cast<hipStream_t>(thread_stream());
+        hipStream_t st = drain.st;
         for (uint32_t img = 0; img < n_images; ++img)
             if (prep[img]->n_words)
                 HIP_TRY(hipMemcpyAsync(d_words + static_cast<size_t>(first_sub_of[img]) * kSubWords, prep[img]->words,

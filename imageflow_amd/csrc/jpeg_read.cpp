@@ -60,6 +60,8 @@ struct Frame {
     uint32_t wb[3] = {0, 0, 0}, hb[3] = {0, 0, 0};            // jdinput.c width_in_blocks / height_in_blocks (what a non-interleaved scan covers)
     uint16_t qt[4][64];
     bool qt_present[4] = {false, false, false, false};
+    uint16_t qt_latched[3][64];                               // jdinput.c latch_quant_tables: a component's table as it stood at its FIRST scan
+    bool latched[3] = {false, false, false};
     int adobe_transform = -1;
 };
 
@@ -141,7 +143,8 @@ static int read_jpeg(const uint8_t* d, size_t len, Frame* out, int16_t* const co
     HuffTab dc[4], ac[4];
     uint32_t restart_interval = 0;
     bool have_sof = false, any_scan = false;
-    // progressive bookkeeping (jdphuff.c coef_bits): which bit of which coefficient has been sent, to validate the script
+    // (jdphuff.c's coef_bits bookkeeping only WARNS about scripts that send bits out of order -- JWRN_BOGUS_PROGRESSION -- and
+    // decodes them anyway; there is no warning channel here, so such scans are decoded as libjpeg decodes them)
     size_t i = 2;
     while (i + 4 <= len) {
         if (d[i] != 0xFF) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: marker expected at byte %zu", i);
@@ -225,6 +228,13 @@ static int read_jpeg(const uint8_t* d, size_t len, Frame* out, int16_t* const co
             } else if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) {
                 return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: bad sequential scan parameters");
             }
+            for (int s = 0; s < ns; ++s) {                                // jdinput.c latch_quant_tables (start of every scan's input pass)
+                const int c = sc[s].ci;
+                if (F.latched[c]) continue;                               // a DQT that redefines the table later does not reach this component
+                if (!F.qt_present[F.tq[c]]) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: missing quantisation table");
+                std::memcpy(F.qt_latched[c], F.qt[F.tq[c]], 128);
+                F.latched[c] = true;
+            }
             for (int s = 0; s < ns; ++s) {
                 const bool need_dc = !F.progressive || (Ss == 0 && Ah == 0), need_ac = !F.progressive || Ss != 0;
                 if ((need_dc && !dc[sc[s].td].present) || (need_ac && !ac[sc[s].ta].present))
@@ -272,8 +282,7 @@ static int read_jpeg(const uint8_t* d, size_t len, Frame* out, int16_t* const co
                                     if (sz) {
                                         k += r;
                                         const int32_t v = extend(br.get(sz), sz);
-                                        if (k > 63) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: corrupt entropy-coded data (run past the block)");
-                                        blk[kZig[k]] = static_cast<int16_t>(v);
+                                        blk[kZig[k > 63 ? 63 : k]] = static_cast<int16_t>(v);   // (jpeg_natural_order's 16 extra entries: a corrupt run lands on 63)
                                         ++k;
                                     } else { if (r != 15) break; k += 16; }
                                 }
@@ -293,8 +302,7 @@ static int read_jpeg(const uint8_t* d, size_t len, Frame* out, int16_t* const co
                                     if (sz) {
                                         k += r;
                                         const int32_t v = extend(br.get(sz), sz);
-                                        if (k > 63) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: corrupt entropy-coded data (run past the block)");
-                                        blk[kZig[k]] = static_cast<int16_t>(static_cast<uint32_t>(v) << Al);
+                                        blk[kZig[k > 63 ? 63 : k]] = static_cast<int16_t>(static_cast<uint32_t>(v) << Al);   // (likewise; jdphuff.c does not clamp to Se either)
                                     } else if (r == 15) k += 15;
                                     else {
                                         eobrun = 1u << r;
@@ -392,11 +400,11 @@ int ifhip_jpeg_read_coefficients_host(const uint8_t* jpeg, size_t len, int16_t* 
         }
         Frame G;
         if (int rc = read_jpeg(jpeg, len, &G, coef)) return rc;
-        // (quantisation tables may arrive between scans: the ones in force at the end are the frame's, as in libjpeg, which
-        // latches a component's table at its first scan -- files that redefine a table mid-image are refused)
+        // (quantisation tables may arrive between scans: a component's table is the one in force at its first scan, as libjpeg
+        // latches it; a later DQT with the same id only reaches components whose first scan is still to come)
         for (int c = 0; c < G.ncomp; ++c) {
-            if (!G.qt_present[G.tq[c]]) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: missing quantisation table");
-            if (qt3x64) std::memcpy(qt3x64 + 64 * c, G.qt[G.tq[c]], 128);
+            if (!G.latched[c]) return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: component %d has no scan", c);
+            if (qt3x64) std::memcpy(qt3x64 + 64 * c, G.qt_latched[c], 128);
         }
         return IFHIP_OK;
     } catch (const std::bad_alloc&) { return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: host memory");

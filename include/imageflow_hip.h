@@ -78,6 +78,24 @@ IFHIP_API int ifhip_set_device(int ordinal);       /* one process per GPU: call 
  * default: the null stream.  A host that runs one job per thread (one imageflow Context per thread, lib.rs:20-27) sets its
  * own stream here and passes the same stream to the *_device calls, so that jobs of different threads overlap. */
 IFHIP_API void ifhip_set_thread_stream(void* hip_stream);
+/* The library's block cache (csrc/devmem.cpp): plans, stages, entropy handles and the frames of ABI jobs are created and
+ * destroyed once per JOB, so their device and pinned blocks are recycled through size-class free lists instead of hipMalloc /
+ * hipFree (whose device-wide wait would serialise every thread's jobs).  What sits in the lists is invisible to every other
+ * allocator on the device (torch's caching allocator, other processes):
+ *   ifhip_cache_set_limits  bytes the lists may hold, per device / pinned (defaults 8 GiB / 1 GiB; 0 = recycle nothing);
+ *   ifhip_cache_trim        give listed blocks back to the driver until at most the given bytes stay (0, 0: everything) --
+ *                           what a torch user calls next to torch.cuda.empty_cache() or after an out-of-memory error;
+ *   ifhip_cache_stats       hits / driver calls / bytes cached and handed out, for capacity planning and the jobs bench.
+ * Blocks handed out are never touched.  Thread safe. */
+typedef struct ifhip_cache_stats_t {
+    uint64_t device_hits, device_driver_allocs, device_driver_frees, device_oom_flushes, device_wide_syncs;
+    uint64_t device_bytes_cached, device_bytes_live, device_blocks_live, device_limit_bytes;
+    uint64_t host_hits, host_driver_allocs, host_driver_frees;
+    uint64_t host_bytes_cached, host_bytes_live, host_blocks_live, host_limit_bytes;
+} ifhip_cache_stats_t;
+IFHIP_API int ifhip_cache_set_limits(size_t device_bytes, size_t host_bytes);
+IFHIP_API int ifhip_cache_trim(size_t keep_device_bytes, size_t keep_host_bytes, size_t* released_device_bytes, size_t* released_host_bytes);
+IFHIP_API int ifhip_cache_stats(ifhip_cache_stats_t* out);
 
 /* ---- host-side tables (no GPU needed) ---------------------------------------------------------------- */
 /* graphics/bitmaps.rs:712-740 Bitmap::get_stride::<u8>(w, h, 4, 64); 0 when the row does not fit 32 bits. */

@@ -877,3 +877,85 @@ def test_contexts_bound_to_devices():
         assert c.set_device(0) and c.device == 0
         assert run_one(c, files[1]) == want[1]
         assert c.set_device(-1) and c.device == -1
+
+
+# ---- where the drop-in is not equal it says so: embedded ICC profiles, querystring keys -----------------------------------------
+def _tagged(jpeg, profile):
+    from tests.test_jpeg_headers import icc_app2
+    return jpeg[:2] + icc_app2(profile) + jpeg[2:]
+
+
+def test_a_file_with_a_non_srgb_profile_is_refused_unless_the_decoder_is_told_to_discard_it():
+    """MzDec::read_frame converts a frame to sRGB whenever the file carries an ICC profile (mozjpeg_decoder.rs:370-420) unless
+    told discard_color_profile (:88-91).  No CMS here: a Display-P3-tagged file is refused with ActionNotSupported; told to
+    discard the profile (decode command or v1/tell_decoder) it decodes to the untagged file's bytes; a profile that IS sRGB
+    passes (the reference's transform is the identity up to its rounding)."""
+    from tests.test_jpeg_headers import P3_XYZ, make_icc
+    base = _jpeg(320, 200, seed=11)
+    p3, srgb = _tagged(base, make_icc(xyz=P3_XYZ)), _tagged(base, make_icc())
+    steps = [{"decode": {"io_id": 0}}, {"resample_2d": {"w": 80, "h": 50}}, {"encode": {"io_id": 1, "preset": "gif"}}]
+
+    def run(data, steps, tell=False, expect=200):
+        with Context() as c:
+            c.add_input_buffer(0, data)
+            c.add_output_buffer(1)
+            if tell:
+                assert c.send_json("v1/tell_decoder", {"io_id": 0, "command": "discard_color_profile"})[0] == 200
+            status, r = c.send_json("v1/execute", {"framewise": {"steps": steps}})
+            assert status == expect, (status, r)
+            if expect != 200:
+                assert c.error_code() == 8 and "ICC profile" in r["message"] and "discard_color_profile" in r["message"], r
+                return None
+            return unpack_raw_bgra(c.get_output_buffer(1))[0]
+    plain = run(base, steps)
+    assert run(p3, steps, expect=400) is None
+    assert np.array_equal(run(p3, steps, tell=True), plain)
+    with_cmd = [{"decode": {"io_id": 0, "commands": ["discard_color_profile"]}}] + steps[1:]
+    assert np.array_equal(run(p3, with_cmd), plain)
+    assert np.array_equal(run(srgb, steps), plain)
+    # the querystring path decodes through the same gate
+    qs = [{"command_string": {"kind": "ir4", "value": "width=80", "decode": 0, "encode": 1}}]
+    assert run(p3, qs, expect=400) is None
+    assert run(p3, qs, tell=True) is not None
+
+
+def test_querystring_keys_are_honoured_or_refused_never_dropped():
+    """`down.filter` reaches the resample (any spelling FilterStrings knows, ir4/parsing.rs:159-193), `quality` / `jpeg.quality`
+    and `format=jpg` reach the JPEG writer (ir4/encoder.rs:74), any other format and unknown filter names are refused."""
+    PIL = pytest.importorskip("PIL.Image")
+    data = _jpeg(640, 400, seed=21)
+    j = O.jpeg_read_coefficients(data)
+
+    def run(value, expect=200):
+        with Context() as c:
+            c.add_input_buffer(0, data)
+            c.add_output_buffer(1)
+            status, r = c.send_json("v1/execute", {"framewise": {"steps": [{"command_string": {"kind": "ir4", "value": value, "decode": 0, "encode": 1}}]}})
+            assert status == expect, (status, r)
+            return bytes(c.get_output_buffer(1)) if expect == 200 else r
+    # width=160: pre-shrink 2.1 / 4 -> hints 336x210 -> the 5/8 decode (400x250) is the first that covers them ... the oracle
+    # chain needs no decode guess: compare the two filters' outputs with each other and the default with robidoux
+    default = unpack_raw_bgra(run("width=160"))[0]
+    assert np.array_equal(unpack_raw_bgra(run("width=160&down.filter=robidoux"))[0], default)
+    lanczos = unpack_raw_bgra(run("width=160&down.filter=lanczos"))[0]
+    assert not np.array_equal(lanczos, default)
+    assert np.array_equal(unpack_raw_bgra(run("width=160&down.filter=Lanczos"))[0], lanczos)
+    assert np.array_equal(unpack_raw_bgra(run("width=160&down.filter=catmullrom"))[0], unpack_raw_bgra(run("width=160&down.filter=catmull_rom"))[0])
+    # against the oracle with filter 6 where the decode is known: half size is below the 2.1 pre-shrink threshold -> full decode
+    rows, w, h, _ = unpack_raw_bgra(run("width=320&down.filter=lanczos"))
+    assert (w, h) == (320, 200) and np.array_equal(rows, _oracle_resize(O.jpeg_idct_color(j), 640, 400, 320, 200, filter_id=6))
+    assert "InvalidNodeParams" in run("width=160&down.filter=sharpest", expect=400)["message"]
+    assert "ActionNotSupported" in run("width=160&format=png", expect=400)["message"]
+    assert "ActionNotSupported" in run("width=160&format=webp", expect=400)["message"]
+    # quality: a real JPEG whose tables are libjpeg's for that quality; jpeg.quality wins over quality; format=jpg alone -> 90
+    def tables(buf):
+        im = PIL.open(io.BytesIO(buf))
+        assert im.format == "JPEG" and im.size == (160, 100)
+        return im.quantization
+    def libjpeg_tables(q):
+        b = io.BytesIO()
+        PIL.new("RGB", (16, 16)).save(b, "JPEG", quality=q, subsampling="4:2:0")
+        return PIL.open(io.BytesIO(b.getvalue())).quantization
+    assert tables(run("width=160&quality=50")) == libjpeg_tables(50)
+    assert tables(run("width=160&format=jpg")) == libjpeg_tables(90)
+    assert tables(run("width=160&format=jpeg&quality=30&jpeg.quality=77")) == libjpeg_tables(77)

@@ -53,3 +53,32 @@ def test_apply_matte_full_4k_frame():
     blend.apply_matte(b, 0xFFEEDDCC)
     torch.cuda.synchronize()
     assert np.array_equal(b.to_numpy(), exp)
+
+
+def test_block_cache_stats_trim_and_limits():
+    """csrc/devmem.cpp through the C ABI: blocks of destroyed plans are recycled (hits grow, bytes stay cached),
+    ifhip_cache_trim gives them back to the driver, a zero limit stops recycling."""
+    import imageflow_amd
+    from imageflow_amd import _native
+    from imageflow_amd.graphics.scaling import ResamplePlan
+    from imageflow_amd.graphics.weights import Filter
+    torch.cuda.synchronize()
+    _native.trim_cache()
+    s0 = _native.cache_stats()
+    for _ in range(3):
+        p = ResamplePlan(1000, 700, 100, 70, Filter.Robidoux, 0.0)
+        del p
+    s1 = _native.cache_stats()
+    assert s1["device_hits"] > s0["device_hits"] and s1["device_bytes_cached"] > 0
+    assert s1["device_limit_bytes"] == 8 << 30 and s1["host_limit_bytes"] == 1 << 30
+    dev_freed, _ = imageflow_amd.trim_cache()
+    s2 = _native.cache_stats()
+    assert dev_freed == s1["device_bytes_cached"] and s2["device_bytes_cached"] == 0
+    assert s2["device_driver_frees"] > s1["device_driver_frees"]
+    try:
+        _native.set_cache_limits(0, 0)
+        p = ResamplePlan(1000, 700, 100, 70, Filter.Robidoux, 0.0)
+        del p
+        assert _native.cache_stats()["device_bytes_cached"] == 0
+    finally:
+        _native.set_cache_limits(8 << 30, 1 << 30)

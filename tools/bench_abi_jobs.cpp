@@ -4,7 +4,13 @@
 // take_output_buffer + buffer_free + context_destroy on a file already in host memory.  Reference bench shape:
 // imageflow_core/benches/bench_graphics.rs:382-456 (one pipeline per iteration, wall clock over many).
 //
-//   bench_abi_jobs <libimageflow_hip.so> <file.jpg> <job.json> <threads> <seconds> [warmup_jobs_per_thread]
+//   bench_abi_jobs <libimageflow_hip.so> <file.jpg> <job.json> <threads> <seconds> [warmup_jobs_per_thread] [--spread]
+//
+// --spread: ifhip_shim_spread_contexts(1) first -- new contexts take the usable devices round-robin; the
+// line then carries the jobs each device ran, and the run FAILS when a context lands on an ordinal that does not exist or,
+// with more than one device, some device never got a job.
+// The line also carries what the library's block cache did during the timed region (ifhip_cache_stats before / after):
+// driver calls and device-wide waits per job, bytes cached and handed out at the end.
 //
 // Prints one JSON line: jobs/s, per-node means from the job results' `performance` block (wall and gpu microseconds),
 // output bytes per job.  Development tool (tools/), built by tools/bench_abi_jobs.py with g++.
@@ -34,6 +40,16 @@ struct Api {
     bool (*take_output_buffer)(void*, int32_t, const uint8_t**, size_t*);
     bool (*buffer_free)(const uint8_t*, size_t);
     bool (*error_write)(void*, char*, size_t, size_t*);
+    void (*spread)(int) = nullptr;                       // ifhip_shim_* / ifhip_*: this library's extensions, optional
+    int (*context_device)(void*) = nullptr;
+    int (*device_count)() = nullptr;
+    int (*cache_stats)(void*) = nullptr;
+};
+struct CacheStats {                                      // include/imageflow_hip.h ifhip_cache_stats_t
+    uint64_t device_hits, device_driver_allocs, device_driver_frees, device_oom_flushes, device_wide_syncs;
+    uint64_t device_bytes_cached, device_bytes_live, device_blocks_live, device_limit_bytes;
+    uint64_t host_hits, host_driver_allocs, host_driver_frees;
+    uint64_t host_bytes_cached, host_bytes_live, host_blocks_live, host_limit_bytes;
 };
 
 template <typename F>
@@ -90,6 +106,19 @@ int main(int argc, char** argv) {
     load(h, "imageflow_context_take_output_buffer", &a.take_output_buffer);
     load(h, "imageflow_buffer_free", &a.buffer_free);
     load(h, "imageflow_context_error_write_to_buffer", &a.error_write);
+    a.spread = reinterpret_cast<void (*)(int)>(dlsym(h, "ifhip_shim_spread_contexts"));
+    a.context_device = reinterpret_cast<int (*)(void*)>(dlsym(h, "ifhip_shim_context_device"));
+    a.device_count = reinterpret_cast<int (*)()>(dlsym(h, "ifhip_device_count"));
+    a.cache_stats = reinterpret_cast<int (*)(void*)>(dlsym(h, "ifhip_cache_stats"));
+    bool spread = false;
+    for (int i = 6; i < argc; ++i) if (std::strcmp(argv[i], "--spread") == 0) spread = true;
+    if (spread) {
+        if (!a.spread || !a.context_device || !a.device_count) { std::fprintf(stderr, "--spread: the library has no ifhip_shim_spread_contexts\n"); return 2; }
+        a.spread(1);
+    }
+    const int n_devices = a.device_count ? a.device_count() : 1;
+    std::vector<std::atomic<uint64_t>> per_device(static_cast<size_t>(std::max(1, n_devices)));
+    std::atomic<uint64_t> bad_device{0};
     // development switches of the library, as tools/ pass them: IFHIP_<SWITCH>=value in the environment -> ifhip_debug_set
     if (auto set = reinterpret_cast<int (*)(const char*, const char*)>(dlsym(h, "ifhip_debug_set"))) {
         extern char** environ;
@@ -105,7 +134,7 @@ int main(int argc, char** argv) {
     const std::vector<uint8_t> file = read_file(argv[2]), job = read_file(argv[3]);
     const int threads = std::atoi(argv[4]);
     const double seconds = std::atof(argv[5]);
-    const int warmup = argc > 6 ? std::atoi(argv[6]) : 3;
+    const int warmup = argc > 6 && argv[6][0] != '-' ? std::atoi(argv[6]) : 3;
 
     std::atomic<bool> go{false}, stop{false};
     std::atomic<uint64_t> jobs{0}, out_bytes{0}, failures{0};
@@ -116,6 +145,11 @@ int main(int argc, char** argv) {
     auto one_job = [&](std::map<std::string, NodeSum>* local, bool count) {
         void* c = a.context_create(3, 2);
         if (!c) { failures++; return; }
+        if (spread && count) {
+            const int d = a.context_device(c);
+            if (d < 0 || d >= n_devices) bad_device++;
+            else per_device[static_cast<size_t>(d)]++;
+        }
         bool ok = a.add_input_buffer(c, 0, file.data(), file.size(), 1) && a.add_output_buffer(c, 1);
         const void* r = ok ? a.send_json(c, "v1/execute", job.data(), job.size()) : nullptr;
         int64_t status = 0;
@@ -156,13 +190,34 @@ int main(int argc, char** argv) {
             for (auto& kv : local) { NodeSum& s = sums[kv.first]; s.wall_us += kv.second.wall_us; s.gpu_us += kv.second.gpu_us; s.n += kv.second.n; }
         });
     while (ready.load() < threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    CacheStats cs0{}, cs1{};
+    if (a.cache_stats) a.cache_stats(&cs0);
     const auto t0 = std::chrono::steady_clock::now();
     go = true;
     std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
     stop = true;
     for (auto& th : pool) th.join();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (a.cache_stats) a.cache_stats(&cs1);
     const uint64_t n = jobs.load();
+    const double nj = static_cast<double>(std::max<uint64_t>(n, 1));
+    char cache[700];
+    std::snprintf(cache, sizeof cache,
+                  "{\"device_hits_per_job\": %.2f, \"device_driver_allocs_per_job\": %.3f, \"device_driver_frees_per_job\": %.3f, \"device_wide_syncs_per_job\": %.3f, "
+                  "\"device_oom_flushes\": %llu, \"device_MB_cached\": %.1f, \"device_MB_live\": %.1f, \"device_limit_MB\": %.0f, "
+                  "\"host_hits_per_job\": %.2f, \"host_driver_allocs_per_job\": %.3f, \"host_driver_frees_per_job\": %.3f, \"host_MB_cached\": %.1f, \"host_MB_live\": %.1f}",
+                  (cs1.device_hits - cs0.device_hits) / nj, (cs1.device_driver_allocs - cs0.device_driver_allocs) / nj, (cs1.device_driver_frees - cs0.device_driver_frees) / nj,
+                  (cs1.device_wide_syncs - cs0.device_wide_syncs) / nj, static_cast<unsigned long long>(cs1.device_oom_flushes - cs0.device_oom_flushes),
+                  cs1.device_bytes_cached / 1e6, cs1.device_bytes_live / 1e6, cs1.device_limit_bytes / 1e6,
+                  (cs1.host_hits - cs0.host_hits) / nj, (cs1.host_driver_allocs - cs0.host_driver_allocs) / nj, (cs1.host_driver_frees - cs0.host_driver_frees) / nj,
+                  cs1.host_bytes_cached / 1e6, cs1.host_bytes_live / 1e6);
+    std::string devs = "[";
+    bool unused_device = false;
+    for (size_t d = 0; d < per_device.size(); ++d) {
+        devs += (d ? ", " : "") + std::to_string(per_device[d].load());
+        if (spread && n_devices > 1 && per_device[d].load() == 0) unused_device = true;
+    }
+    devs += "]";
     std::string nodes = "{";
     for (auto& kv : sums)
         nodes += (nodes.size() > 1 ? ", \"" : "\"") + kv.first + "\": {\"per_job\": " + std::to_string(static_cast<double>(kv.second.n) / std::max<uint64_t>(n, 1)) +
@@ -171,9 +226,11 @@ int main(int argc, char** argv) {
     nodes += "}";
     for (char& ch : first_error) if (ch == '"' || ch == '\n' || ch == '\\') ch = ' ';
     std::printf("{\"threads\": %d, \"seconds\": %.3f, \"jobs\": %llu, \"jobs_per_s\": %.1f, \"ms_per_job_per_thread\": %.3f, \"failures\": %llu, "
-                "\"output_bytes_per_job\": %llu, \"input_bytes\": %zu, \"nodes\": %s, \"first_error\": \"%s\"}\n",
+                "\"output_bytes_per_job\": %llu, \"input_bytes\": %zu, \"devices\": %d, \"spread\": %s, \"jobs_per_device\": %s, \"contexts_on_unknown_devices\": %llu, "
+                "\"cache\": %s, \"nodes\": %s, \"first_error\": \"%s\"}\n",
                 threads, dt, static_cast<unsigned long long>(n), n / dt, n ? dt * threads / n * 1e3 : 0.0,
                 static_cast<unsigned long long>(failures.load()), static_cast<unsigned long long>(n ? out_bytes.load() / n : 0), file.size(),
-                nodes.c_str(), first_error.c_str());
-    return failures.load() ? 1 : 0;
+                n_devices, spread ? "true" : "false", spread ? devs.c_str() : "null", static_cast<unsigned long long>(bad_device.load()),
+                a.cache_stats ? cache : "null", nodes.c_str(), first_error.c_str());
+    return (failures.load() || bad_device.load() || unused_device) ? 1 : 0;
 }

@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--jobs", default="cfg1,cfg4,cfg4h")
     ap.add_argument("--lib", default=os.environ.get("IFHIP_LIB") or os.path.join(ROOT, "imageflow_amd", "lib", "libimageflow_hip.so"))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--spread", action="store_true",
+                    help="ifhip_shim_spread_contexts(1): contexts take the node's GPUs round-robin; every run reports jobs per device "
+                         "and fails if a device stays idle (on a one-GPU box: every context on ordinal 0)")
     ap.add_argument("--hw-queues", default="", help="GPU_MAX_HW_QUEUES for the harness process (the HIP runtime's own switch: how many "
                                                       "hardware queues its streams are spread over; default 4)")
     args = ap.parse_args()
@@ -114,7 +117,8 @@ def main():
                 env = dict(os.environ)
                 if args.hw_queues:
                     env["GPU_MAX_HW_QUEUES"] = args.hw_queues
-                r = subprocess.run([exe, args.lib, fpath, jpath, str(t), str(args.seconds)], capture_output=True, text=True, timeout=600, env=env)
+                r = subprocess.run([exe, args.lib, fpath, jpath, str(t), str(args.seconds), "3"] + (["--spread"] if args.spread else []),
+                                   capture_output=True, text=True, timeout=600, env=env)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 rec = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-500:]}
                 rec["job"] = kind
