@@ -352,7 +352,7 @@ struct StreamLease {
     ~StreamLease() {
         t_job_stream = nullptr;
         ifhip_set_thread_stream(nullptr);
-        if (st) (void)hipStreamSynchronize(st);
+        if (st) (void)static_cast<hipError_t>(ifhip::wait_stream(st));
         {
             std::lock_guard<std::mutex> lk(g_stream_mu);
             DeviceQueues& q = g_queues[dev];
@@ -364,7 +364,7 @@ struct StreamLease {
 };
 // Before anything of a job goes back to the cache: the job's stream -- the only one its blocks were ever used on -- is idle.
 void quiesce() {
-    if (t_job_stream && hipStreamQuery(t_job_stream) != hipSuccess) (void)hipStreamSynchronize(t_job_stream);
+    if (t_job_stream && hipStreamQuery(t_job_stream) != hipSuccess) (void)static_cast<hipError_t>(ifhip::wait_stream(t_job_stream));
     (void)hipGetLastError();
 }
 hipError_t job_malloc(void** p, size_t bytes) { return static_cast<hipError_t>(ifhip::cached_malloc(p, bytes)); }
@@ -610,17 +610,26 @@ struct DecodeCoalescer {
     std::condition_variable cv;
     std::vector<DecodeRequest*> queue;
     bool leader_active = false;
+    int decoding = 0;                                               // batches whose decode is on the device right now
     // -> r.batch / r.index set, or r.retry_alone
     void submit(DecodeRequest& r) {
         std::unique_lock<std::mutex> lk(mu);
         queue.push_back(&r);
         cv.notify_all();                                             // (a leader gathering its batch counts arrivals)
         for (;;) {
-            while (!r.done && (leader_active || r.taken)) cv.wait(lk);
+            // At most kDecodesInFlight batches decode at a time; whoever arrives meanwhile waits here, and the next leader takes
+            // ALL of them: the batch size follows the load by itself (group commit).  An entropy decode costs about the same
+            // half millisecond for 1 file or 16 (three latency-bound launches), so a batch of 8 is an eighth of
+            // the device time per job -- before, a new batch formed as soon as the last one had been gathered, 1.85 files per
+            // batch at 2 300 jobs/s (round 5, profiles/r5_abi_trace_cfg4_8_threads.txt).
+            int max_decoding = 2;
+            if (const char* e = ifhip::debug_switch("coalesce_decodes_in_flight")) max_decoding = std::max(1, std::atoi(e));
+            while (!r.done && (leader_active || r.taken || decoding >= max_decoding)) cv.wait(lk);
             if (r.done) return;
             leader_active = true;                                    // nobody leads: this thread does, for one batch
-            // the moment given to the others: only while other jobs are in flight at all (a lone caller pays nothing)
-            long window_us = g_jobs_in_flight.load(std::memory_order_relaxed) > 1 ? 120 : 0;
+            // the moment given to the others: only while other jobs are in flight at all (a lone caller pays nothing) and no
+            // decode is running (else the wait above was the moment)
+            long window_us = (g_jobs_in_flight.load(std::memory_order_relaxed) > 1 && decoding == 0) ? 120 : 0;
             size_t wait_for = kMaxCoalesce;
             if (const char* e = ifhip::debug_switch("coalesce_window_us")) window_us = std::atol(e);
             if (const char* e = ifhip::debug_switch("coalesce_wait_for")) wait_for = static_cast<size_t>(std::max(1L, std::atol(e)));
@@ -635,12 +644,14 @@ struct DecodeCoalescer {
             queue.swap(rest);
             for (DecodeRequest* q : mine) q->taken = true;
             leader_active = false;                                   // leading = gathering: the next batch forms while this one decodes
+            ++decoding;
             cv.notify_all();
             lk.unlock();
             std::shared_ptr<DecodedBatch> b;
             bool failed = false;
             try { b = decode_files(mine); } catch (const FlowErr&) { failed = true; } catch (const std::exception&) { failed = true; }
             lk.lock();
+            --decoding;
             for (size_t i = 0; i < mine.size(); ++i) {
                 DecodeRequest* q = mine[i];
                 if (failed) q->retry_alone = true;
@@ -771,7 +782,7 @@ struct Job {
             struct Guard { uint8_t* p; ~Guard() { job_free(p); } } g{d};                                  // `pending` and no buffer
             PendingJpeg& p = *f->pending;
             check(ifhip_jpeg_idct_color_batch_device(p.st, p.coef[0], p.coef[1], p.coef[2], p.d_qt, 1, d, f->bytes(), f->stride, t_job_stream));
-            hip_check(hipStreamSynchronize(t_job_stream), "decode");
+            hip_check(static_cast<hipError_t>(ifhip::wait_stream(t_job_stream)), "decode");
             f->d = d; g.p = nullptr;
             f->pending.reset();
         }
@@ -870,7 +881,7 @@ struct Job {
             check_size(sec.max_decode_size, "max_decode_size", w, h);
             FramePtr f = new_frame(w, h, hdr[3] != 0, 0, true);
             hip_check(hipMemcpy2DAsync(f->d, f->stride, in.in + kRawHeader, stride, w * 4ull, h, hipMemcpyHostToDevice, t_job_stream), "upload(raw frame)");
-            hip_check(hipStreamSynchronize(t_job_stream), "upload(raw frame)");
+            hip_check(static_cast<hipError_t>(ifhip::wait_stream(t_job_stream)), "upload(raw frame)");
             decodes.push_back({io_id, w, h, "application/x-imageflow-bgra", "ifbgra"});
             return f;
         }
@@ -1023,7 +1034,7 @@ struct Job {
         } else
         check(ifhip_scale_and_render_batch_device(plan, in->d, in->bytes(), in->stride, in->alpha ? 1 : 0, 1, dev(canvas), canvas->bytes(),
                                                   canvas->w, canvas->h, canvas->stride, x, y, hi.space, canvas->compose, canvas->matte, nullptr, -1, t_job_stream));
-        hip_check(hipStreamSynchronize(t_job_stream), "draw_image_exact");
+        hip_check(static_cast<hipError_t>(ifhip::wait_stream(t_job_stream)), "draw_image_exact");
         canvas->compose = IFHIP_BLEND_WITH_SELF;                                                                       // :314
     }
 
@@ -1294,7 +1305,7 @@ struct Job {
         check(ifhip_copy_rect_batch_device(dev(in), in->bytes(), in->w, in->h, in->stride, in->alpha ? 1 : 0, dev(canvas), canvas->bytes(),
                                            canvas->w, canvas->h, canvas->stride, &canvas_alpha, fx, fy, x, y, w, h, 1, t_job_stream));
         canvas->alpha = canvas_alpha != 0;
-        hip_check(hipStreamSynchronize(t_job_stream), "copy_rect");
+        hip_check(static_cast<hipError_t>(ifhip::wait_stream(t_job_stream)), "copy_rect");
         return canvas;
     }
     FramePtr transposed(const FramePtr& in) {

@@ -283,16 +283,19 @@ uint32_t choose_bands(const ifhip_resample_plan* p, uint32_t n_images, size_t n_
         if (v >= 1) return std::min<uint32_t>(static_cast<uint32_t>(v), p->out_h);
     }
     // One workgroup occupies a CU (LDS), so a launch runs in ceil(workgroups / 256) rounds.  Cutting frames into bands
-    // of output rows makes the rounds finer but every extra band re-reads its halo of source rows; pick the band count
-    // with the smallest estimated time.
+    // of output rows makes the rounds finer but every extra band re-reads its halo of source rows and stages the tables
+    // again (a few microseconds per workgroup: `setup`, as a share of one frame's time on one CU); pick the band count with
+    // the smallest estimated time.  Up to 64 bands: a launch of ONE frame (a job through the ABI) then spreads over 64 CUs
+    // instead of 16 -- 3840x2160 -> 800x450 as a single frame: 118 us with 16 bands (round 5, profiles/r5_abi_*).
     const double wgs = static_cast<double>(n_images) * static_cast<double>(n_strips);
     const double halo = p->out_h ? static_cast<double>(p->wv.max_taps) / std::max<double>(1.0, p->in_h) : 0.0;
-    const uint32_t max_bands = std::max<uint32_t>(1u, std::min<uint32_t>(16u, p->out_h / 4u));
+    const double setup = 0.01;
+    const uint32_t max_bands = std::max<uint32_t>(1u, std::min<uint32_t>(64u, p->out_h / 4u));
     uint32_t best = 1;
     double best_cost = 1e300;
     for (uint32_t b = 1; b <= max_bands; ++b) {
         const double rounds = std::ceil(wgs * b / 256.0);
-        const double cost = rounds / b * (1.0 + halo * (b - 1));
+        const double cost = rounds * ((1.0 + halo * (b - 1)) / b + setup);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = b; }
     }
     return best;
@@ -1189,7 +1192,7 @@ int ifhip_scale_and_render(const uint8_t* in, uint32_t in_w, uint32_t in_h, uint
                            canvas_w, h, canvas_stride, x, 0, working_space, compositing, matte_bgra, nullptr, -1, s->stream);
         if (rc == IFHIP_OK) {
             e = hipMemcpyAsync(s->pin_c, s->d_c, c_valid, hipMemcpyDeviceToHost, s->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+            if (e == hipSuccess) e = static_cast<hipError_t>(ifhip::wait_stream(s->stream));
             if (e == hipSuccess) {
                 if (canvas_needed) std::memcpy(crow0, s->pin_c, c_valid);
                 else                                      // whole rows were produced: leave the caller's row padding alone
@@ -1197,8 +1200,8 @@ int ifhip_scale_and_render(const uint8_t* in, uint32_t in_w, uint32_t in_h, uint
                         std::memcpy(crow0 + static_cast<size_t>(j) * canvas_stride, s->pin_c + static_cast<size_t>(j) * canvas_stride,
                                     static_cast<size_t>(canvas_w) * 4u);
             }
-        } else (void)hipStreamSynchronize(s->stream);
-    } else (void)hipStreamSynchronize(s->stream);
+        } else (void)static_cast<hipError_t>(ifhip::wait_stream(s->stream));
+    } else (void)static_cast<hipError_t>(ifhip::wait_stream(s->stream));
     if (rc) return rc;
     if (e != hipSuccess) return fail(IFHIP_GPU_ERROR, "GpuError: staging failed: %s", hipGetErrorString(e));
     return IFHIP_OK;
@@ -1239,10 +1242,10 @@ int ifhip_apply_matte(uint8_t* bgra, uint32_t w, uint32_t h, uint32_t stride, in
         rc = ifhip_apply_matte_batch_device(s->d_c, bytes, 1, w, h, stride, 1, matte_bgra, s->stream);
         if (rc == IFHIP_OK) {
             e = hipMemcpyAsync(s->pin_c, s->d_c, valid, hipMemcpyDeviceToHost, s->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+            if (e == hipSuccess) e = static_cast<hipError_t>(ifhip::wait_stream(s->stream));
             if (e == hipSuccess) std::memcpy(bgra, s->pin_c, valid);
-        } else (void)hipStreamSynchronize(s->stream);
-    } else (void)hipStreamSynchronize(s->stream);
+        } else (void)static_cast<hipError_t>(ifhip::wait_stream(s->stream));
+    } else (void)static_cast<hipError_t>(ifhip::wait_stream(s->stream));
     if (rc) return rc;
     if (e != hipSuccess) return fail(IFHIP_GPU_ERROR, "GpuError: staging failed: %s", hipGetErrorString(e));
     return IFHIP_OK;

@@ -13,10 +13,12 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -230,23 +232,37 @@ int require_gfx950(int* device_out) {
     return IFHIP_OK;
 }
 
+int wait_stream(void* hip_stream) {
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const char* mode = debug_switch("wait");
+    if (!st || !mode || std::strcmp(mode, "poll") != 0) return static_cast<int>(hipStreamSynchronize(st));
+    for (uint32_t i = 0;; ++i) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return static_cast<int>(e);
+        (void)hipGetLastError();                                      // (NotReady is recorded as the thread's last error)
+        if (i < 200u) __builtin_ia32_pause();
+        else if (i < 4000u) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(30));
+    }
+}
+
 // host <-> device copies of the create paths: on the calling thread's job stream, complete on return
 int copy_to_device(void* dst, const void* src, size_t bytes) {
     if (!bytes) return 0;
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, t_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(t_stream);
+    if (e == hipSuccess) e = static_cast<hipError_t>(wait_stream(t_stream));
     return static_cast<int>(e);
 }
 int copy_to_host(void* dst, const void* src, size_t bytes) {
     if (!bytes) return 0;
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, t_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(t_stream);
+    if (e == hipSuccess) e = static_cast<hipError_t>(wait_stream(t_stream));
     return static_cast<int>(e);
 }
 int zero_device(void* dst, size_t bytes) {                            // ordered on the job stream (the stage's first launch follows on it)
     if (!bytes) return 0;
     hipError_t e = hipMemsetAsync(dst, 0, bytes, t_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(t_stream);
+    if (e == hipSuccess) e = static_cast<hipError_t>(wait_stream(t_stream));
     return static_cast<int>(e);
 }
 

@@ -517,7 +517,7 @@ int ifhip_jpeg_encode_batch_device(ifhip_jpeg_enc_stage* stage, const int16_t* d
         int rc = jpeg_baseline_header(static_cast<int>(stage->g.ncomp), stage->hs, stage->vs, stage->width, stage->height, qt, &h);
         if (rc) return rc;
         if (h.size() > kHeaderCap) return fail(IFHIP_INVALID_STATE, "InvalidState: marker segments of %zu bytes", h.size());
-        HIP_TRY(hipStreamSynchronize(st));                 // (the pinned copy may still be on its way to the device from the previous call)
+        HIP_TRY(static_cast<hipError_t>(ifhip::wait_stream(st)));                 // (the pinned copy may still be on its way to the device from the previous call)
         std::memcpy(stage->h_header, h.data(), h.size());
         stage->header_len = static_cast<uint32_t>(h.size());
         HIP_TRY(hipMemcpyAsync(stage->d_header, stage->h_header, h.size(), hipMemcpyHostToDevice, st));

@@ -1338,7 +1338,7 @@ static int create_prepared_impl(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* c
     // either block is written over.  Every exit path of this function therefore waits for the stream first.
     struct StreamDrain {
         hipStream_t st;
-        ~StreamDrain() { (void)hipStreamSynchronize(st); }
+        ~StreamDrain() { (void)static_cast<hipError_t>(ifhip::wait_stream(st)); }
     } drain{static_cast<hipStream_t>(thread_stream())};
     {   // every file's words straight from its pinned buffer to its place: n asynchronous copies, one wait (below, with the tables')
         hipStream_t st = drain.st;
@@ -1655,7 +1655,7 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
         hipLaunchKernelGGL(entropy_write_kernel, dim3((a.n_sub + kWriteLanes - 1u) / kWriteLanes), dim3(kWriteLanes), 0, st, a);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(e->h_flags, a.changed, kFlagWords * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(static_cast<hipError_t>(ifhip::wait_stream(st)));
         if (e->h_flags[17] == 0u) break;                             // every sub-sequence starts where its predecessor ended
         for (;;) {                                                   // rare: corrections across workgroups
             ++r;
@@ -1665,7 +1665,7 @@ int ifhip_jpeg_entropy_decode_device(ifhip_jpeg_entropy* e, int16_t* d_coef0, in
             hipLaunchKernelGGL(entropy_round_kernel, round_grid, sync_block, 0, st, a);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(e->h_flags, a.changed, kFlagWords * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(static_cast<hipError_t>(ifhip::wait_stream(st)));
             if (e->h_flags[r & 15u] == 0u) break;
         }
         HIP_TRY(hipMemsetAsync(a.errors, 0, 2u * sizeof(uint32_t), st));     // flags of the discarded count and write passes

@@ -135,3 +135,36 @@ def test_bench_refuses_a_mismatched_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("world,extra,total", [(2, ["--frames", "5"], 10), (3, ["--scaling", "strong", "--total-frames", "10"], 10)])
+def test_bench_cfg4_shards_files_over_ranks_and_checks_itself(world, extra, total):
+    """BASELINE config 4 as `bench.py --workload cfg4 --gpus N` (files -> GPU entropy decode -> 4/8 pixel stage -> 800x450, sharded
+    by shard_range, the 800x450 outputs gathered once): 2 ranks weak and 3 ranks strong (blocks of 4 / 3 / 3 files) on the test
+    box's one GPU.  The line must carry the chain's parity stamp against the oracle and, with --selfcheck, rank 0's check of the
+    first gathered frame of EVERY rank against the same file decoded locally."""
+    env = _clean_env()
+    env["IFHIP_BENCH_DRYRUN_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg4", "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--batches-in-flight", "2", "--selfcheck", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == world and j["config"]["total_files"] == total and "cfg4" in j["config"]["workload"], j["config"]
+    assert j["config"]["gathers"] == {"warmup": 1, "timed": 1} and "failed" not in j["config"]["gather"]
+    assert j["config"]["one_call_chain"] is True and j["config"]["batches_in_flight"] == 2
+    assert j["parity_checked"]["equal"] is True and j["parity_checked"]["frames"] == 2
+    assert j["selfcheck"] == {"ranks": world, "first_frame_of_every_rank_equal": True, "ranks_that_differ": []}
+    assert j["value"] > 0 and j["files_per_s"] > 0 and 0 < j["roofline"]["frac"] < 1
+    assert j["roofline"]["algorithmic_bytes_per_launch"] == j["config"]["files_per_gpu"] * 26_323_584
+
+
+def test_bench_selfcheck_and_parity_stamp_of_the_default_workload():
+    env = _clean_env()
+    env["IFHIP_BENCH_DRYRUN_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "6", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-strong-field", "--selfcheck"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["parity_checked"]["equal"] is True and j["parity_checked"]["which"] == [0, 5]
+    assert j["selfcheck"]["first_frame_of_every_rank_equal"] is True and j["selfcheck"]["ranks"] == 2

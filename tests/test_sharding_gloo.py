@@ -141,3 +141,92 @@ def test_gather_of_variable_length_messages_to_the_root(sizes):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in results), results
+
+
+def _cfg4_gather_worker(rank, world, port, total, q):
+    """The cfg4 job's message protocol without a GPU: every rank holds its shard_range block of fixed-size 800x450 outputs
+    (here 8 x 6 stand-ins whose bytes name the file they belong to), padded to the largest block; ONE rooted gather."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(total, rank, world)
+        n_max = -(-total // world)
+        image_bytes = 8 * 6 * 4
+        out_all = torch.zeros((n_max, image_bytes), dtype=torch.uint8)
+        for i in range(lo, hi):
+            out_all[i - lo] = torch.full((image_bytes,), i % 251, dtype=torch.uint8)
+        gathered = torch.empty((world, n_max, image_bytes), dtype=torch.uint8) if rank == 0 else None
+        _, got = gather_to_root(out_all, 0, out=gathered)
+        ok = True
+        if rank == 0:
+            ok = got.data_ptr() == gathered.data_ptr()
+            for r in range(world):
+                a, b = shard_range(total, r, world)
+                for i in range(a, b):
+                    ok = ok and bool((got[r, i - a] == i % 251).all())                   # file i sits in rank owner_of(i)'s slot i - lo
+                    ok = ok and owner_of(i, total, world) == r
+        else:
+            ok = got is None
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total", [(2, 10), (3, 10), (3, 4)])
+def test_cfg4_final_gather_protocol(world, total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cfg4_gather_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results), results
+
+
+def _subgroup_worker(rank, world, port, q):
+    """Gathers inside a SUB-group whose ranks are not the global ones (global ranks 1 and 2 of 3): the group's rank 0 is global
+    rank 1 -- the rooted gather and the point-to-point file gather must translate group ranks to global ones."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from imageflow_amd.sharding import gather_bytes_to_root
+        group = dist.new_group([1, 2])
+        ok = True
+        if rank in (1, 2):
+            g_rank = dist.get_rank(group)
+            local = torch.full((2, 5), 10 + rank, dtype=torch.uint8)
+            _, got = gather_to_root(local, 0, group=group)
+            if g_rank == 0:
+                ok = ok and bool((got[0] == 11).all()) and bool((got[1] == 12).all())
+            else:
+                ok = ok and got is None
+            mine = torch.arange(3 + 4 * rank, dtype=torch.uint8) + rank
+            sizes, parts = gather_bytes_to_root(mine, 0, group=group)
+            ok = ok and sizes == [7, 11]
+            if g_rank == 0:
+                ok = ok and bool((parts[0] == torch.arange(7, dtype=torch.uint8) + 1).all()) and bool((parts[1] == torch.arange(11, dtype=torch.uint8) + 2).all())
+        q.put((rank, bool(ok)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gathers_inside_a_sub_group_use_global_ranks():
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results), results

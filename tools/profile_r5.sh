@@ -1,14 +1,14 @@
 #!/bin/bash
-# Round-4 evidence run (on the GPU box through gpurun): every figure DESIGN.md section 6 quotes for this round, from one build on one box.
-# Raw output under gpurun_out/prof4, the summaries kept under gpurun_out/prof4_summary (copied to profiles/r4_* afterwards).  Counter passes are separate runs with --kernel-trace only.
+# Round-5 evidence run (on the GPU box through gpurun): every figure DESIGN.md section 6 quotes for this round, from one build on one box.
+# Raw output under gpurun_out/prof5, the summaries kept under gpurun_out/prof5_summary (copied to profiles/r5_* afterwards).  Counter passes are separate runs with --kernel-trace only.
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-OUT=gpurun_out/prof4
-SUM=gpurun_out/prof4_summary
+OUT=gpurun_out/prof5
+SUM=gpurun_out/prof5_summary
 rm -rf $OUT $SUM; mkdir -p $OUT $SUM
 # SECTIONS="5" tools/profile_r4.sh re-measures one part only (default: all)
-SECTIONS=${SECTIONS:-"0 1 2 3 4 5 6"}
+SECTIONS=${SECTIONS:-"0 1 2 3 4 5 6 7"}
 want() { case " $SECTIONS " in *" $1 "*) return 0;; esac; return 1; }
 
 pmc_pass() {   # pmc_pass <tag> <kernel substring> <counters> -- cmd...
@@ -112,7 +112,15 @@ fi
 
 # 6. jobs through the libimageflow ABI (file in, file out): T threads x one context per job, cfg1 / cfg4 / cfg4h jobs
 if want 6; then
-timeout 600 python tools/bench_abi_jobs.py --threads 1,8,64 --seconds 2.5 > $SUM/abi_jobs.json 2> $SUM/abi_jobs.err
+timeout 900 python tools/bench_abi_jobs.py --threads 1,8,16,64,128 --seconds 2.5 --spread > $SUM/abi_jobs.json 2> $SUM/abi_jobs.err
+fi
+
+# 7. BASELINE config 4 as a bench.py workload (files -> entropy decode -> 4/8 pixel stage -> 800x450), line + kernel statistics
+if want 7; then
+python bench.py --workload cfg4 --steps 20 --warmup 5 > $SUM/bench_cfg4.json 2> $SUM/bench_cfg4.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg4 -- python bench.py --workload cfg4 --steps 10 --warmup 3 --no-cpu-baseline > $SUM/bench_cfg4_under_trace.json 2> $OUT/trace_cfg4.err
+find $OUT/trace_cfg4 -name '*kernel_stats.csv' -exec sh -c "head -14 {} | cut -c1-220 > $SUM/cfg4_kernel_stats.csv" \;
+rm -rf $OUT/trace_cfg4
 fi
 rm -rf $OUT
 ls -la $SUM
