@@ -37,6 +37,11 @@ for src in "$ROOT"/imageflow_amd/csrc/*.cpp "$ROOT"/imageflow_amd/csrc/*.hip; do
       /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 --cuda-host-only $SAN $INC -DIFHIP_FUSED_K=$k -c "$src" -o lib/fused_$k.o 2>/dev/null &
       OBJS="$OBJS lib/fused_$k.o"
     done
+  elif [ "$base" = "resample_ws.hip" ]; then
+    for k in 1 2 3 4 5; do
+      /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 --cuda-host-only $SAN $INC -DIFHIP_FUSED_K=$k -c "$src" -o lib/ws_$k.o 2>/dev/null &
+      OBJS="$OBJS lib/ws_$k.o"
+    done
   else
     /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 --cuda-host-only $SAN $INC -c "$src" -o lib/$base.o 2>/dev/null &
     OBJS="$OBJS lib/$base.o"
