@@ -30,7 +30,8 @@ also carries what a step costs without the encoders.
 bench_codecs.rs:24-41 and a noise variant, written once on the host with Pillow) -> GPU entropy decode -> 4/8 IDCT with the
 spatial sRGB luma scaler + YCbCr (what the reference's decoder is asked for when the job wants 800 px:
 codecs/mozjpeg_decoder.rs:295-420,588-618) -> 800x450 Robidoux (flow/nodes/scale_render.rs:304-313), 128 files per GPU
-(1 024 over 8 GPUs) in --batches-in-flight batches (default 4 x 32), one host thread and HIP stream each.  The compressed scans are resident in HBM
+(1 024 over 8 GPUs) in batches of 64, --batches-in-flight of them on the device at a time (default 2: one host thread and HIP
+stream each, a thread's batches one after the other).  The compressed scans are resident in HBM
 (un-stuffed, as the entropy stage reads them) when the timed region starts.  value = source megapixels through the WHOLE
 chain per second; `roofline` is the pixel stage + resize call alone on SURVEY 8d's 26 323 584 bytes per image (the entropy
 walk is latency-bound bit-serial work: HBM is not its yardstick); cpu_baseline = libjpeg-turbo (Pillow) DCT-domain 1/2
@@ -78,7 +79,7 @@ WORKLOADS = {
     # the whole export_4_sizes job: the tuple describes level 0, PYRAMID the chain
     "cfg3": (3840, 2160, 1600, 900, "Robidoux", 0.0, False, "ReplaceSelf", 0, 128),
 }
-CFG4 = {"in_w": 3840, "in_h": 2160, "dec_w": 1920, "dec_h": 1080, "out_w": 800, "out_h": 450, "files_per_gpu": 128, "batch": 32,
+CFG4 = {"in_w": 3840, "in_h": 2160, "dec_w": 1920, "dec_h": 1080, "out_w": 800, "out_h": 450, "files_per_gpu": 128, "batch": 64,
         "bytes_per_image": 26_323_584}                             # coefficients + quant tables in, 800x450 BGRA out
 PYRAMID = [("src", "1600", 1600, 900), ("1600", "1200", 1200, 675), ("1600", "800", 800, 450), ("1200", "400", 400, 225)]
 PYRAMID_BYTES_PER_IMAGE = 58_737_600
@@ -301,6 +302,7 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun):
         raise SystemExit(f"rank {rank} owns no files ({total} files over {world} ranks)")
     n_max = -(-total // world)
     T = max(1, min(args.batches_in_flight, n))
+    per_batch = max(1, args.files_per_batch or CFG4["batch"])
     ranks_info = [{"rank": rank, "device": torch.cuda.get_device_name(local_rank), "local_rank": local_rank}]
     if distributed:
         objs = [None] * world
@@ -310,28 +312,37 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun):
     torch.zeros(1, device=dev).item()
     info = ScaleAndRenderParams(0, 0, ow, oh)
     out_all = Bitmap.create_u8(n_max, ow, oh, dev)                 # this rank's outputs, gather-slot sized
-    # T host threads, each with its contiguous share of the rank's files as one entropy batch, its own HIP stream and
-    # buffers: while one batch's synchronisation tail leaves CUs idle, the next one's dense passes fill them
+    # T host threads, each with its contiguous share of the rank's files cut into batches of CFG4["batch"] files, its own HIP
+    # stream and buffers: a thread decodes its batches one after the other, T batches are in flight on the device -- while one
+    # batch's synchronisation tail leaves CUs idle, another one's dense passes fill them.  (Measured, 128 files per step,
+    # profiles/r5_bench_cfg4_batch_sweep.txt: 2 x 64 files in flight 21 400 files/s, 2 x 32 20 200, 4 x 32 18 900, 4 x 16 19 200,
+    # 4 x 8 15 000; the pixel stage + resize call runs at 0.30 of 8 TB/s on 64 frames, 0.27 on 16.)
     ctx = []
     for t in range(T):
         a, b = shard_range(n, t, T)
         st = torch.cuda.Stream(device=dev)
+        batches = []
         with torch.cuda.stream(st):
-            ent = D.JpegEntropyBatch(files[a:b], device=str(dev))
-            coef = ent.read_coefficients()
-            stage = D.JpegPixelStage(w, h, 3, ent.h_samp, ent.v_samp, b - a, device=str(dev), scale_num=4, luma_spatial=True, luma_srgb=True)
-            qt = torch.from_numpy(ent.qt.view(np.int16)).to(dev)
-            small = Bitmap(out_all.data[a:b], ow, oh, out_all.stride, False)
-            fused = stage.read_frames_into(coef, qt, small, info)
-        ctx.append({"stream": st, "ent": ent, "coef": coef, "stage": stage, "qt": qt, "small": small, "fused": fused, "n": b - a})
+            for a0 in range(a, b, per_batch):
+                b0 = min(b, a0 + per_batch)
+                ent = D.JpegEntropyBatch(files[a0:b0], device=str(dev))
+                coef = ent.read_coefficients()
+                stage = D.JpegPixelStage(w, h, 3, ent.h_samp, ent.v_samp, b0 - a0, device=str(dev), scale_num=4, luma_spatial=True, luma_srgb=True)
+                qt = torch.from_numpy(ent.qt.view(np.int16)).to(dev)
+                small = Bitmap(out_all.data[a0:b0], ow, oh, out_all.stride, False)
+                fused = stage.read_frames_into(coef, qt, small, info)
+                batches.append({"ent": ent, "coef": coef, "stage": stage, "qt": qt, "small": small, "fused": fused, "n": b0 - a0})
+        ctx.append({"stream": st, "batches": batches})
     torch.cuda.synchronize()
     compressed = sum(len(f) for f in files)
+    all_batches = [bt for c in ctx for bt in c["batches"]]
 
     def chain(c, steps):
         with torch.cuda.stream(c["stream"]):
             for _ in range(steps):
-                c["ent"].read_coefficients(c["coef"])
-                c["stage"].read_frames_into(c["coef"], c["qt"], c["small"], info)
+                for bt in c["batches"]:
+                    bt["ent"].read_coefficients(bt["coef"])
+                    bt["stage"].read_frames_into(bt["coef"], bt["qt"], bt["small"], info)
             c["stream"].synchronize()
 
     def run_steps(steps):
@@ -382,17 +393,18 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun):
     px_ms, ent_ms = 0.0, 0.0
     for c in ctx:
         with torch.cuda.stream(c["stream"]):
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            e0.record(c["stream"])
-            for _ in range(launches):
-                c["stage"].read_frames_into(c["coef"], c["qt"], c["small"], info)
-            e1.record(c["stream"])
-            for _ in range(launches):
-                c["ent"].read_coefficients(c["coef"])
-            e2.record(c["stream"])
-            c["stream"].synchronize()
-            px_ms += e0.elapsed_time(e1) / launches
-            ent_ms += e1.elapsed_time(e2) / launches
+            for bt in c["batches"]:
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record(c["stream"])
+                for _ in range(launches):
+                    bt["stage"].read_frames_into(bt["coef"], bt["qt"], bt["small"], info)
+                e1.record(c["stream"])
+                for _ in range(launches):
+                    bt["ent"].read_coefficients(bt["coef"])
+                e2.record(c["stream"])
+                c["stream"].synchronize()
+                px_ms += e0.elapsed_time(e1) / launches
+                ent_ms += e1.elapsed_time(e2) / launches
     torch.cuda.synchronize()
 
     parity = None
@@ -413,9 +425,9 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun):
             "files_per_s": round(total * args.steps / elapsed, 1),
             "config": {"workload": f"BASELINE cfg4: {total} files ({n} on rank 0) 3840x2160 4:2:0 q85 baseline JPEG -> GPU entropy decode -> 4/8 IDCT "
                                    f"(spatial sRGB luma scaler) + YCbCr -> 800x450 Robidoux, linear light; compressed scans device resident",
-                       "files_per_gpu": n, "total_files": total, "batches_in_flight": T, "files_per_batch": [c["n"] for c in ctx],
+                       "files_per_gpu": n, "total_files": total, "batches_in_flight": T, "files_per_batch": [bt["n"] for bt in all_batches],
                        "compressed_MB_per_gpu": round(compressed / 1e6, 2),
-                       "one_call_chain": bool(all(c["fused"] for c in ctx)),
+                       "one_call_chain": bool(all(bt["fused"] for bt in all_batches)),
                        "kernel": "jpeg entropy passes + luma / chroma IDCT kernels + the resampler reading the component planes",
                        "gather": gather_note, "gathers": gathers, "rccl_ranks": dist.get_world_size() if distributed else 1,
                        "backend": (dist.get_backend() if distributed else "none"), "ranks": ranks_info,
@@ -509,7 +521,8 @@ def parse_args(argv=None):
                          "buffered against the next step; none: results stay sharded")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["cfg4"])
-    ap.add_argument("--batches-in-flight", type=int, default=4, help="--workload cfg4: host threads / HIP streams, each with a batch of files")
+    ap.add_argument("--batches-in-flight", type=int, default=2, help="--workload cfg4: host threads / HIP streams, each decoding its batches of files one after the other")
+    ap.add_argument("--files-per-batch", type=int, default=None, help="--workload cfg4: files per entropy / pixel-stage batch (default 64)")
     ap.add_argument("--selfcheck", action="store_true",
                     help="after the timed region rank 0 checks the first gathered frame of EVERY rank against one it renders itself")
     ap.add_argument("--outputs", default="files", choices=["files", "bgra"],
