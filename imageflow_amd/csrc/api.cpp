@@ -401,15 +401,11 @@ int validate_render(uint32_t in_w, uint32_t in_h, uint32_t in_stride, uint32_t c
 // plan that holds the tables and a ring of at least two row slots per frame slot.  kNotFusable: not this launch (the caller
 // goes on to the one-role kernel).  `a` is the caller's argument block, completed here on a copy.
 int enqueue_ws(const ifhip_resample_plan* p, ResampleArgs a, uint32_t n_images, bool ycc, bool probe, hipStream_t st) {
-    // OFF unless asked for (`ws` = 1: V waves + H waves; 2: decoupled -- tests and tools/ab_switches.py): DESIGN 4.1b has what
-    // each form measured against the one-role kernel.
-    int mode = 0;
-    { const char* e = debug_switch("ws"); mode = e ? std::atoi(e) : 0; }
-    if (mode != 1 && mode != 2) return kNotFusable;
-    const bool dec = mode == 2;
-    // decoupled: the one-role kernel's geometry (a strip is the whole workgroup); specialised: strips of 8 V waves
-    const ifhip_resample_plan::StripSet& ss = dec ? p->sets[0] : p->ws_set;
-    if (!ss.ok || !p->h_fast_groups || p->slots > 5 || fused_shape(p->slots, 3).px != 4 || fused_shape(p->slots, 3).threads != 1024) return kNotFusable;
+    const ifhip_resample_plan::StripSet& ss = p->ws_set;
+    if (!ss.ok) return kNotFusable;
+    // OFF unless asked for (`ws` = 1, tests and tools/ab_switches.py): measured slower than the one-role kernel on every BASELINE
+    // shape -- cfg3 level 0 2.47 ms against 2.14, level 1 3.56 against 2.72, level 2 1.95 against 1.93 (profiles/r5_ws_*.jsonl).
+    { const char* e = debug_switch("ws"); if (!e || std::atoi(e) == 0) return kNotFusable; }
     // the strips were planned on the BGRA alignment rules; a planar source reads 4 samples per lane and plane
     for (const Strip& s : ss.strips) {
         if (ycc ? static_cast<uint64_t>(s.cx0) + 4u * s.nquads > a.in_stride
@@ -420,10 +416,8 @@ int enqueue_ws(const ifhip_resample_plan* p, ResampleArgs a, uint32_t n_images, 
     const uint32_t wu_floats = two ? p->h_wg2_floats : p->h_wg_floats;
     const bool l2s = a.linear != 0;                                  // the encode table is part of the form (no threshold search here)
     const uint32_t T = block_for(ss.max_quads, 4), wpf = T / 64u;
-    const uint32_t total_waves = 16u;
-    uint32_t v_max = dec ? total_waves : std::max(kWsMaxVWaves, wpf);
-    if (const char* e = debug_switch("ws_v_waves")) v_max = std::max<uint32_t>(wpf, std::min<uint32_t>(dec ? 16u : 14u, static_cast<uint32_t>(std::atoi(e))));
-    if (wpf > v_max || wpf > total_waves) return kNotFusable;
+    uint32_t v_max = std::max(kWsMaxVWaves, wpf), total_waves = 16u;
+    if (const char* e = debug_switch("ws_v_waves")) v_max = std::max<uint32_t>(wpf, std::min<uint32_t>(14u, static_cast<uint32_t>(std::atoi(e))));
     uint32_t max_nu = 0;
     for (const Strip& s : ss.strips) max_nu = std::max(max_nu, s.u1 - s.u0);
     auto lds_for = [&](uint32_t frames, uint32_t copies_log2, uint32_t ring) {
@@ -433,33 +427,25 @@ int enqueue_ws(const ifhip_resample_plan* p, ResampleArgs a, uint32_t n_images, 
         return worst;
     };
     const size_t limit = lds_limit();
-    const uint32_t min_ring = 2u;
     uint32_t frames = std::max<uint32_t>(1u, std::min<uint32_t>(v_max / wpf, n_images));
     if (ss.strips.size() > 1) frames = 1;
-    while (frames > 1 && lds_for(frames, kMinLutCopiesLog2, dec ? 2u : 3u) > limit) --frames;
+    while (frames > 1 && lds_for(frames, kMinLutCopiesLog2, 3) > limit) --frames;
     uint32_t ring = 0, copies_log2 = kMinLutCopiesLog2;
-    if (dec) {                                                       // 1, 2 or 4 slots (slot = row & (R - 1))
-        if (lds_for(frames, kMinLutCopiesLog2, 4) <= limit) ring = 4;
-        else if (lds_for(frames, kMinLutCopiesLog2, 2) <= limit) ring = 2;
-    } else {
-        for (uint32_t r = 4; r >= min_ring; --r)
-            if (lds_for(frames, kMinLutCopiesLog2, r) <= limit) { ring = r; break; }
-    }
+    for (uint32_t r = 4; r >= 2; --r)
+        if (lds_for(frames, kMinLutCopiesLog2, r) <= limit) { ring = r; break; }
     if (!ring) return kNotFusable;
     if (lds_for(frames, 5, ring) <= limit) copies_log2 = 5;
     if (const char* e = debug_switch("ws_ring")) {
         const uint32_t r = static_cast<uint32_t>(std::atoi(e));
-        const bool shape_ok = dec ? (r == 1 || r == 2 || r == 4) : (r >= 1 && r <= 8);
-        if (shape_ok && lds_for(frames, copies_log2, r) <= limit) ring = r;
+        if (r >= 1 && r <= 8 && lds_for(frames, copies_log2, r) <= limit) ring = r;
     }
     const uint32_t n_v = frames * wpf;
-    uint32_t n_h = dec ? 0u : total_waves - n_v;
-    if (!dec) if (const char* e = debug_switch("ws_h_waves")) n_h = std::max<uint32_t>(1u, std::min<uint32_t>(total_waves - n_v, static_cast<uint32_t>(std::atoi(e))));
+    uint32_t n_h = total_waves - n_v;
+    if (const char* e = debug_switch("ws_h_waves")) n_h = std::max<uint32_t>(1u, std::min<uint32_t>(total_waves - n_v, static_cast<uint32_t>(std::atoi(e))));
     const uint32_t wgs = (n_images + frames - 1u) / frames;
     ScheduleOnDevice sd;
     const uint32_t want_bands = choose_bands(p, wgs, ss.strips.size());
-    const int rows_in_flight = dec ? kDecRowsInFlight : kWsRowsInFlight;
-    int rc = get_schedule(p, want_bands, rows_in_flight, rows_in_flight, &sd);
+    int rc = get_schedule(p, want_bands, kWsRowsInFlight, kWsRowsInFlight, &sd);
     if (rc) return rc;
     a.steps = sd.steps; a.band_begin = sd.band_begin; a.n_bands = sd.n_bands;
     a.strips = ss.d_strips; a.n_strips = static_cast<uint32_t>(ss.strips.size());
@@ -472,13 +458,12 @@ int enqueue_ws(const ifhip_resample_plan* p, ResampleArgs a, uint32_t n_images, 
     a.frames_per_wg = frames;
     a.lanes_per_frame = T;
     a.ws_ring = ring;
-    a.ws_mode = dec ? 1u : 0u;
     const size_t lds = lds_for(frames, copies_log2, ring);
     const uint64_t grid = static_cast<uint64_t>(wgs) * sd.n_bands * a.n_strips;
     if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
     if (debug_switch("trace_launch"))
-        std::fprintf(stderr, "ifhip ws launch (%s): %ux%u -> %ux%u K=%d ycc=%d V lanes/frame=%u frames/wg=%u V waves=%u H waves=%u ring=%u bands=%u "
-                     "strips=%u grid=%llu lds=%zu fast_g=%u two_col=%d lut_copies=%u images=%u\n", dec ? "decoupled" : "specialised",
+        std::fprintf(stderr, "ifhip ws launch: %ux%u -> %ux%u K=%d ycc=%d V lanes/frame=%u frames/wg=%u V waves=%u H waves=%u ring=%u bands=%u "
+                     "strips=%u grid=%llu lds=%zu fast_g=%u two_col=%d lut_copies=%u images=%u\n",
                      p->in_w, p->in_h, p->out_w, p->out_h, p->slots, ycc ? 1 : 0, T, frames, n_v, n_h, ring, sd.n_bands, a.n_strips,
                      static_cast<unsigned long long>(grid), lds, fast_g, two ? 1 : 0, 1u << copies_log2, n_images);
     if (probe) return IFHIP_OK;

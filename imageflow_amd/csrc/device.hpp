@@ -50,7 +50,6 @@ struct ResampleArgs {
     uint32_t lanes_per_frame;        // multiple of 64; the workgroup has F * lanes_per_frame lanes
     // wave-specialised kernel (resample_ws.hip): the workgroup has F * lanes_per_frame V lanes, the rest are H waves
     uint32_t ws_ring;                // R: row slots per frame slot between the vertical and the horizontal waves
-    uint32_t ws_mode;                // 0: V waves + H waves; 1: decoupled (every wave streams AND takes horizontal units)
     // generic-kernel tables
     const uint32_t* h_left;
     const uint32_t* h_count;
@@ -151,7 +150,6 @@ inline FusedLds fused_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t wu_floa
 // and the conversion double buffer, and with 12 rows: the same time within 1 % (profiles/r5_ws_*.jsonl) -- the V waves are
 // not bound by bytes in flight.
 constexpr int kWsRowsInFlight = 8;
-constexpr int kDecRowsInFlight = 4;         // decoupled mode: every wave streams, as in the one-role kernel (4 rows, conversion double buffered)
 constexpr uint32_t kWsUnitChunks = 4;       // 64-output chunks an H wave works on at a time (one output of each per lane)
 constexpr uint32_t kWsMaxVWaves = 8;        // V waves per workgroup (of 16): strips are planned for 8 x 64 x 4 source columns
 struct WsLds { uint32_t lut, l2s, hmeta, hw, sync, ring, row_stride, total; };

@@ -59,16 +59,9 @@ __device__ __forceinline__ void ws_signal(uint32_t* p) {
 // groups of TWO source columns (BGRA sources).  YCC: planar source (the JPEG stage's component planes).
 // D source rows in flight per V lane; PIPE: converted samples double buffered (the table gathers of step i + 1 under the
 // multiply-adds of step i).
-// MODE 0: wave-specialised (V waves + H waves).  MODE 1: DECOUPLED -- every wave is a V wave (the one-role kernel's geometry:
-// a strip is the whole workgroup, 4 rows in flight per lane, conversion double buffered) and ALSO takes horizontal units, one
-// 64-output chunk at a time, whenever it has published a row, whenever it waits for a row slot, and at the end of its band:
-// the units of a row are dealt to the frame slot's waves statically (rotating with the row), so the pixel
-// loop runs whenever a wave gets to it instead of on all of them at once behind a workgroup barrier.
-template <int K, int FG, bool YCC, int D, bool PIPE, int MODE>
+template <int K, int FG, bool YCC, int D, bool PIPE>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)))
 ws_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
-    constexpr bool DEC = MODE == 1;
-    constexpr uint32_t UC = DEC ? 1u : kWsUnitChunks;      // 64-output chunks per horizontal unit
     constexpr bool TWO = FG >= 16;
     static_assert(!TWO || !YCC, "two-column groups: BGRA sources");
     static_assert(fused_shape(K, 3).px == 4 && fused_shape(K, 3).threads == 1024, "rings that leave room for 4 pixels per lane at 4 waves per SIMD");
@@ -95,7 +88,7 @@ ws_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     const Strip strip = a.strips[strip_i];
     const uint32_t n_u = strip.u1 - strip.u0;
     const uint32_t chunks = (n_u + 63u) >> 6;              // 64-output chunks per row
-    const uint32_t units = (chunks + UC - 1u) / UC;        // what a wave takes at a time (and a row hands back in)
+    const uint32_t units = (chunks + kWsUnitChunks - 1u) / kWsUnitChunks;   // what an H wave takes at a time (and a row hands back in)
     const uint32_t R = a.ws_ring;
 
     constexpr uint32_t fast_g = TWO ? FG - 16 : FG;
@@ -139,129 +132,125 @@ ws_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                                                         + static_cast<size_t>(a.y) * a.c_stride + static_cast<size_t>(a.x) * 4u), 0xDEADBEEFu);
     };
 
-    // ---- the horizontal unit: shared by the H waves (MODE 0) and by every wave's help calls (MODE 1) ----
-    const uint32_t lane = wtid & 63u;
-    // output columns dealt to the lane groups of the 16-byte LDS read (resample_fused.hip, "Which lane takes which column")
-    const uint32_t q8 = (lane >> 2) & 7u;
-    const uint32_t first4 = (0x7326'1540u >> (4u * q8)) & 15u;
-    const uint32_t lane_h = (lane & ~31u) | (first4 << 2) | (lane & 3u);
-    const BankedLut lut{lut_banked, wtid & ((1u << a.lut_copies_log2) - 1u), a.lut_copies_log2};
-    const bool static_encode = a.linear && l2s_lds != nullptr;
-    // A unit = NK <= UC chunks of 64 consecutive outputs of one row starting at chunk c0, one output of each chunk per lane: the
-    // chains' LDS round trips and multiply-adds of the NK outputs overlap inside the wave (MODE 0: one chunk at a time left an
-    // H wave waiting out its own latencies, 2 200 cycles per 64 outputs, the launch H-bound at any number of H waves).
-    auto run_unit = [&](auto nk_const, uint32_t c0, uint32_t img, uint32_t j, const unsigned char* vrow, uint32_t* done, const uint32_t (&m)[UC]) {
-        constexpr uint32_t NK = decltype(nk_const)::value;
-        constexpr uint32_t G = fast_g;
-        uint32_t ul[NK];
-        bool on[NK];
-#pragma unroll
-        for (uint32_t k = 0; k < NK; ++k) {
-            ul[k] = ((c0 + k) << 6) + lane_h;
-            on[k] = ul[k] < n_u;
-        }
-        f32x2 h01[NK];
-        float h2[NK];
-#pragma unroll
-        for (uint32_t k = 0; k < NK; ++k) { h01[k] = f32x2{0.0f, 0.0f}; h2[k] = 0.0f; }
-        if constexpr (TWO) {
-            // (three base addresses the compiler cannot relate: two 8-byte reads of one base would be fused into ds_read2_b64,
-            // 8 LDS cycles per wave where two ds_read_b64 take 2 + 2)
-            typedef __attribute__((address_space(3))) const f32x2 lds_f2;
-            uint32_t a0[NK], a1[NK], a2[NK];
-            const float2* wp[NK];
-#pragma unroll
-            for (uint32_t k = 0; k < NK; ++k) {
-                a0[k] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(vrow))) + (m[k] & 0xffffu) * (GP / 2u);
-                a1[k] = a0[k] + 8u; a2[k] = a0[k] + 16u;
-                asm volatile("" : "+v"(a0[k]), "+v"(a1[k]), "+v"(a2[k]));
-                wp[k] = reinterpret_cast<const float2*>(hw_lds) + (m[k] >> 16) * G;
-            }
-#pragma unroll
-            for (uint32_t q = 0; q < G; ++q) {
-                float2 w[NK];
-                f32x2 t0[NK], t1[NK], c2[NK];
-#pragma unroll
-                for (uint32_t k = 0; k < NK; ++k) {
-                    w[k] = wp[k][q];
-                    t0[k] = *reinterpret_cast<lds_f2*>(static_cast<uintptr_t>(a0[k] + q * (GP / 2u)));
-                    t1[k] = *reinterpret_cast<lds_f2*>(static_cast<uintptr_t>(a1[k] + q * (GP / 2u)));
-                    c2[k] = *reinterpret_cast<lds_f2*>(static_cast<uintptr_t>(a2[k] + q * (GP / 2u)));
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < NK; ++k) {
-                    h01[k] = __builtin_elementwise_fma(f32x2{w[k].x, w[k].x}, f32x2{t0[k].x, t0[k].y}, h01[k]);
-                    h01[k] = __builtin_elementwise_fma(f32x2{w[k].y, w[k].y}, f32x2{t1[k].x, t1[k].y}, h01[k]);
-                    h2[k] = __builtin_fmaf(w[k].x, c2[k].x, h2[k]);
-                    h2[k] = __builtin_fmaf(w[k].y, c2[k].y, h2[k]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (uint32_t q = 0; q < G; ++q) {
-                float4 w[NK], t01[NK], t23[NK], t2[NK];
-#pragma unroll
-                for (uint32_t k = 0; k < NK; ++k) {
-                    const float4* g = reinterpret_cast<const float4*>(vrow + (m[k] & 0xffffu) * GP + q * GP);
-                    w[k] = (reinterpret_cast<const float4*>(hw_lds) + (m[k] >> 16) * G)[q];
-                    t01[k] = g[0]; t23[k] = g[1]; t2[k] = g[2];
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < NK; ++k) {
-                    h01[k] = __builtin_elementwise_fma(f32x2{w[k].x, w[k].x}, f32x2{t01[k].x, t01[k].y}, h01[k]);
-                    h01[k] = __builtin_elementwise_fma(f32x2{w[k].y, w[k].y}, f32x2{t01[k].z, t01[k].w}, h01[k]);
-                    h01[k] = __builtin_elementwise_fma(f32x2{w[k].z, w[k].z}, f32x2{t23[k].x, t23[k].y}, h01[k]);
-                    h01[k] = __builtin_elementwise_fma(f32x2{w[k].w, w[k].w}, f32x2{t23[k].z, t23[k].w}, h01[k]);
-                    h2[k] = __builtin_fmaf(w[k].x, t2[k].x, h2[k]);
-                    h2[k] = __builtin_fmaf(w[k].y, t2[k].y, h2[k]);
-                    h2[k] = __builtin_fmaf(w[k].z, t2[k].z, h2[k]);
-                    h2[k] = __builtin_fmaf(w[k].w, t2[k].w, h2[k]);
-                }
-            }
-        }
-        // the row's samples are in registers: the slot may go back as soon as every unit says so
-#pragma unroll
-        for (uint32_t k = 0; k < NK; ++k) asm volatile("" : "+v"(h01[k]), "+v"(h2[k]));
-        ws_signal(done);
-#pragma unroll
-        for (uint32_t k = 0; k < NK; ++k) {
-            if (on[k]) {
-                if (static_encode) {
-                    const OutTables<BankedLut, DirectL2S> tbs{lut, DirectL2S{l2s_lds}};
-                    store_pixel<false, 1>(a, img, j, strip.u0 + ul[k], h01[k].x, h01[k].y, h2[k], 1.0f, tbs);
-                } else {
-                    const OutTables<BankedLut, ThresholdL2S> tb{lut, ThresholdL2S{nullptr, l2s_lds}};
-                    store_pixel<false>(a, img, j, strip.u0 + ul[k], h01[k].x, h01[k].y, h2[k], 1.0f, tb);
-                }
-            }
-        }
-    };
-    if (!DEC && wave >= n_v) {
+    if (wave >= n_v) {
         // =================================================== H waves ===================================================
-        const uint32_t h = wave - n_v;
+        const uint32_t h = wave - n_v, lane = wtid & 63u;
+        // output columns dealt to the lane groups of the 16-byte LDS read (resample_fused.hip, "Which lane takes which column")
+        const uint32_t q8 = (lane >> 2) & 7u;
+        const uint32_t first4 = (0x7326'1540u >> (4u * q8)) & 15u;
+        const uint32_t lane_h = (lane & ~31u) | (first4 << 2) | (lane & 3u);
+        const BankedLut lut{lut_banked, wtid & ((1u << a.lut_copies_log2) - 1u), a.lut_copies_log2};
+        const bool static_encode = a.linear && l2s_lds != nullptr;
+        // A unit = U chunks of 64 consecutive outputs of one row, one output of each chunk per lane: the U chains' LDS round
+        // trips and multiply-adds overlap inside the wave (one chunk at a time left an H wave waiting out its own latencies:
+        // 2 200 cycles per 64 outputs, the launch H-bound at any number of H waves).  `NK` <= U chunks of a row's last unit exist.
         uint32_t c = h, f = 0u, r = 0u, s = 0u, u = 0u;          // unit (row r of the band, frame slot f, unit c of the row); slot s = r % R, use u = r / R
         const uint32_t rows = j1 - j0;
+        auto run_unit = [&](auto nk_const, uint32_t img, uint32_t j, const unsigned char* vrow, uint32_t* done, const uint32_t (&m)[kWsUnitChunks]) {
+            constexpr uint32_t NK = decltype(nk_const)::value;
+            constexpr uint32_t G = fast_g;
+            uint32_t ul[NK];
+            bool on[NK];
+#pragma unroll
+            for (uint32_t k = 0; k < NK; ++k) {
+                ul[k] = ((c * kWsUnitChunks + k) << 6) + lane_h;
+                on[k] = ul[k] < n_u;
+            }
+            f32x2 h01[NK];
+            float h2[NK];
+#pragma unroll
+            for (uint32_t k = 0; k < NK; ++k) { h01[k] = f32x2{0.0f, 0.0f}; h2[k] = 0.0f; }
+            if constexpr (TWO) {
+                // (three base addresses the compiler cannot relate: two 8-byte reads of one base would be fused into ds_read2_b64,
+                // 8 LDS cycles per wave where two ds_read_b64 take 2 + 2)
+                typedef __attribute__((address_space(3))) const f32x2 lds_f2;
+                uint32_t a0[NK], a1[NK], a2[NK];
+                const float2* wp[NK];
+#pragma unroll
+                for (uint32_t k = 0; k < NK; ++k) {
+                    a0[k] = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(vrow))) + (m[k] & 0xffffu) * (GP / 2u);
+                    a1[k] = a0[k] + 8u; a2[k] = a0[k] + 16u;
+                    asm volatile("" : "+v"(a0[k]), "+v"(a1[k]), "+v"(a2[k]));
+                    wp[k] = reinterpret_cast<const float2*>(hw_lds) + (m[k] >> 16) * G;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < G; ++q) {
+                    float2 w[NK];
+                    f32x2 t0[NK], t1[NK], c2[NK];
+#pragma unroll
+                    for (uint32_t k = 0; k < NK; ++k) {
+                        w[k] = wp[k][q];
+                        t0[k] = *reinterpret_cast<lds_f2*>(static_cast<uintptr_t>(a0[k] + q * (GP / 2u)));
+                        t1[k] = *reinterpret_cast<lds_f2*>(static_cast<uintptr_t>(a1[k] + q * (GP / 2u)));
+                        c2[k] = *reinterpret_cast<lds_f2*>(static_cast<uintptr_t>(a2[k] + q * (GP / 2u)));
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < NK; ++k) {
+                        h01[k] = __builtin_elementwise_fma(f32x2{w[k].x, w[k].x}, f32x2{t0[k].x, t0[k].y}, h01[k]);
+                        h01[k] = __builtin_elementwise_fma(f32x2{w[k].y, w[k].y}, f32x2{t1[k].x, t1[k].y}, h01[k]);
+                        h2[k] = __builtin_fmaf(w[k].x, c2[k].x, h2[k]);
+                        h2[k] = __builtin_fmaf(w[k].y, c2[k].y, h2[k]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < G; ++q) {
+                    float4 w[NK], t01[NK], t23[NK], t2[NK];
+#pragma unroll
+                    for (uint32_t k = 0; k < NK; ++k) {
+                        const float4* g = reinterpret_cast<const float4*>(vrow + (m[k] & 0xffffu) * GP + q * GP);
+                        w[k] = (reinterpret_cast<const float4*>(hw_lds) + (m[k] >> 16) * G)[q];
+                        t01[k] = g[0]; t23[k] = g[1]; t2[k] = g[2];
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < NK; ++k) {
+                        h01[k] = __builtin_elementwise_fma(f32x2{w[k].x, w[k].x}, f32x2{t01[k].x, t01[k].y}, h01[k]);
+                        h01[k] = __builtin_elementwise_fma(f32x2{w[k].y, w[k].y}, f32x2{t01[k].z, t01[k].w}, h01[k]);
+                        h01[k] = __builtin_elementwise_fma(f32x2{w[k].z, w[k].z}, f32x2{t23[k].x, t23[k].y}, h01[k]);
+                        h01[k] = __builtin_elementwise_fma(f32x2{w[k].w, w[k].w}, f32x2{t23[k].z, t23[k].w}, h01[k]);
+                        h2[k] = __builtin_fmaf(w[k].x, t2[k].x, h2[k]);
+                        h2[k] = __builtin_fmaf(w[k].y, t2[k].y, h2[k]);
+                        h2[k] = __builtin_fmaf(w[k].z, t2[k].z, h2[k]);
+                        h2[k] = __builtin_fmaf(w[k].w, t2[k].w, h2[k]);
+                    }
+                }
+            }
+            // the row's samples are in registers: the slot may go back as soon as every unit says so
+#pragma unroll
+            for (uint32_t k = 0; k < NK; ++k) asm volatile("" : "+v"(h01[k]), "+v"(h2[k]));
+            ws_signal(done);
+#pragma unroll
+            for (uint32_t k = 0; k < NK; ++k) {
+                if (on[k]) {
+                    if (static_encode) {
+                        const OutTables<BankedLut, DirectL2S> tbs{lut, DirectL2S{l2s_lds}};
+                        store_pixel<false, 1>(a, img, j, strip.u0 + ul[k], h01[k].x, h01[k].y, h2[k], 1.0f, tbs);
+                    } else {
+                        const OutTables<BankedLut, ThresholdL2S> tb{lut, ThresholdL2S{nullptr, l2s_lds}};
+                        store_pixel<false>(a, img, j, strip.u0 + ul[k], h01[k].x, h01[k].y, h2[k], 1.0f, tb);
+                    }
+                }
+            }
+        };
         for (;;) {
             while (c >= units) { c -= units; if (++f == f_on) { f = 0u; ++r; if (++s == R) { s = 0u; ++u; } } }
             if (r >= rows) break;
             const uint32_t img = img0 + f, j = j0 + r;
-            uint32_t m[UC];                                      // the outputs' records do not depend on the row: requested before the wait
+            uint32_t m[kWsUnitChunks];                           // the outputs' records do not depend on the row: requested before the wait
 #pragma unroll
-            for (uint32_t k = 0; k < UC; ++k) {
-                const uint32_t ulk = ((c * UC + k) << 6) + lane_h;
+            for (uint32_t k = 0; k < kWsUnitChunks; ++k) {
+                const uint32_t ulk = ((c * kWsUnitChunks + k) << 6) + lane_h;
                 m[k] = hmeta2[ulk < n_u ? ulk : 0u];
             }
             if (!ws_wait_ge(vcnt + f * R + s, wpf * (u + 1u)) && lane == 0u) mark_stuck(img);
             const unsigned char* vrow = smem + L.ring + (f * R + s) * L.row_stride;
-            if constexpr (!DEC) {
-                const uint32_t nk = min(UC, chunks - c * UC);        // chunks of this unit (the row's last one may be short)
-                static_assert(kWsUnitChunks == 4, "one case per unit size");
-                switch (nk) {
-                case 4: run_unit(std::integral_constant<uint32_t, 4>{}, c * UC, img, j, vrow, hcnt + f * R + s, m); break;
-                case 3: run_unit(std::integral_constant<uint32_t, 3>{}, c * UC, img, j, vrow, hcnt + f * R + s, m); break;
-                case 2: run_unit(std::integral_constant<uint32_t, 2>{}, c * UC, img, j, vrow, hcnt + f * R + s, m); break;
-                default: run_unit(std::integral_constant<uint32_t, 1>{}, c * UC, img, j, vrow, hcnt + f * R + s, m); break;
-                }
+            const uint32_t nk = min(kWsUnitChunks, chunks - c * kWsUnitChunks);      // chunks of this unit (the row's last one may be short)
+            static_assert(kWsUnitChunks == 4, "one case per unit size");
+            switch (nk) {
+            case 4: run_unit(std::integral_constant<uint32_t, 4>{}, img, j, vrow, hcnt + f * R + s, m); break;
+            case 3: run_unit(std::integral_constant<uint32_t, 3>{}, img, j, vrow, hcnt + f * R + s, m); break;
+            case 2: run_unit(std::integral_constant<uint32_t, 2>{}, img, j, vrow, hcnt + f * R + s, m); break;
+            default: run_unit(std::integral_constant<uint32_t, 1>{}, img, j, vrow, hcnt + f * R + s, m); break;
             }
             c += n_h;
         }
@@ -372,33 +361,6 @@ ws_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
     uint32_t* vcnt_f = vcnt + slot * R;
     uint32_t* hcnt_f = hcnt + slot * R;
 
-    // ---- decoupled mode: this wave's horizontal units ----
-    // Static deal, no claiming (a compare-and-swap per unit on one LDS word serialised the workgroup: 3.7 ms on cfg3 level 0):
-    // unit c of row r belongs to wave (c + r) mod wpf of the frame slot -- rotating with the row, so that the waves' shares even
-    // out over rows -- and a wave works its rows off in order whenever it looks: `hrow` = the first row whose units it still owes.
-    const uint32_t rows_total = j1 - j0;
-    const uint32_t ring_shift = R > 2u ? 2u : (R > 1u ? 1u : 0u);          // (the host plans 1, 2 or 4 row slots in this mode)
-    const uint32_t my_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint32_t hrow = 0u;
-    // -> 1: ran this wave's units of one more row; 0: that row is not complete yet; 2: nothing left to do in this band
-    auto help_one = [&]() -> int {
-        if (hrow >= rows_total) return 2;
-        const uint32_t r = hrow, s = r & (R - 1u), u = r >> ring_shift;
-        const uint32_t pub = __builtin_amdgcn_readfirstlane(__hip_atomic_load(vcnt_f + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if (pub < wpf * (u + 1u)) return 0;
-        asm volatile("" ::: "memory");
-        uint32_t c = my_wave + wpf - (r % wpf);                           // first unit with (c + r) mod wpf == my_wave
-        if (c >= wpf) c -= wpf;
-        for (; c < units; c += wpf) {
-            uint32_t m[UC];
-            const uint32_t ulk = (c << 6) + lane_h;
-            m[0] = hmeta2[ulk < n_u ? ulk : 0u];
-            run_unit(std::integral_constant<uint32_t, 1>{}, c, img, j0 + r, ring_f + s * L.row_stride, hcnt_f + s, m);
-        }
-        ++hrow;
-        return 1;
-    };
-
     for (uint32_t sb = s0; sb < s1; sb += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -436,18 +398,7 @@ ws_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
             }
             if (st.flush_slot >= 0) {
                 // ---- an output row's vertical pass is complete: publish it ----
-                if constexpr (DEC) {
-                    // the slot must be free (every unit of the row it held consumed): whoever waits for that helps to make it so
-                    if (ring_u != 0u) {
-                        uint32_t spin = 0u;
-                        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(hcnt_f + ring_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < units * ring_u) {
-                            if (help_one() != 1) { __builtin_amdgcn_s_sleep(1); if (++spin > (1u << 20)) { if (tid == 0u) mark_stuck(img); break; } }
-                        }
-                        asm volatile("" ::: "memory");
-                    }
-                } else {
-                    if (ring_u != 0u && !ws_wait_ge(hcnt_f + ring_s, units * ring_u) && tid == 0u) mark_stuck(img);
-                }
+                if (ring_u != 0u && !ws_wait_ge(hcnt_f + ring_s, units * ring_u) && tid == 0u) mark_stuck(img);
                 unsigned char* dst_row = ring_f + ring_s * L.row_stride;
 #pragma unroll
                 for (int s = 0; s < K; ++s) {
@@ -471,24 +422,15 @@ ws_resample_kernel(const ResampleArgs a, const VStep* __restrict__ steps) {
                 }
                 ws_signal(vcnt_f + ring_s);
                 if (++ring_s == R) { ring_s = 0u; ++ring_u; }
-                if constexpr (DEC) (void)help_one();                       // (one row's share per published row keeps pace; the waits catch up)
             }
-        }
-    }
-    if constexpr (DEC) {
-        // the band's last rows: every wave stays until every unit is taken (the rows still to come are the other waves')
-        for (uint32_t spin = 0u;;) {
-            const int h = help_one();
-            if (h == 2) break;
-            if (h == 0) { __builtin_amdgcn_s_sleep(2); if (++spin > (1u << 20)) { if (tid == 0u) mark_stuck(img); break; } }
         }
     }
 }
 
 
-template <int K, int FG, bool YCC, int MODE>
-static hipError_t launch_ws_mode(const ResampleArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    constexpr int D = MODE == 1 ? kDecRowsInFlight : kWsRowsInFlight;
+template <int K, int FG, bool YCC>
+static hipError_t launch_ws_variant(const ResampleArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+    constexpr int D = kWsRowsInFlight;
     constexpr bool PIPE = false;
     static std::atomic<uint64_t> raised;     // the dynamic-LDS cap is sticky per kernel and device: raised once for each
     int dev = 0;
@@ -496,18 +438,13 @@ static hipError_t launch_ws_mode(const ResampleArgs& a, dim3 grid, dim3 block, s
     if (e != hipSuccess) return e;
     const uint64_t bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
     if (!(raised.load(std::memory_order_relaxed) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_resample_kernel<K, FG, YCC, D, PIPE, MODE>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ws_resample_kernel<K, FG, YCC, D, PIPE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kFusedLdsCap));
         if (e != hipSuccess) return e;
         raised.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((ws_resample_kernel<K, FG, YCC, D, PIPE, MODE>), grid, block, lds, st, a, a.steps);
+    hipLaunchKernelGGL((ws_resample_kernel<K, FG, YCC, D, PIPE>), grid, block, lds, st, a, a.steps);
     return hipGetLastError();
-}
-
-template <int K, int FG, bool YCC>
-static hipError_t launch_ws_variant(const ResampleArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-    return a.ws_mode == 1u ? launch_ws_mode<K, FG, YCC, 1>(a, grid, block, lds, st) : launch_ws_mode<K, FG, YCC, 0>(a, grid, block, lds, st);
 }
 
 #define IFHIP_CAT2(a, b) a##b

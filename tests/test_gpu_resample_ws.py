@@ -33,11 +33,10 @@ MODERATE = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])                      # 1: V waves + H waves; 2: decoupled (every wave streams and takes units)
 @pytest.mark.parametrize("case", MODERATE)
-def test_ws_equals_the_oracle(case, mode, debug_switch):
+def test_ws_equals_the_oracle(case, debug_switch):
     iw, ih, ow, oh, n = case
-    debug_switch("ws", mode)
+    debug_switch("ws", "1")
     p = run_case(iw, ih, ow, oh, n=n, seed=iw + oh)
     assert p.kernel_kind(False) == 0
     run_case(iw, ih, ow, oh, n=1, seed=ow, x=3, y=2, cw=ow + 9, ch=oh + 5, space=WorkingFloatspace.StandardRGB)
@@ -60,32 +59,17 @@ def test_ws_schedules(ring, h_waves, debug_switch):
     run_case(1600, 200, 1200, 150, n=2, seed=4)
 
 
-@pytest.mark.parametrize("ring", ["1", "2", "4"])
-def test_decoupled_schedules(ring, debug_switch):
-    """The decoupled form with 1 row slot (every publish waits for the previous row's units -- and helps with them), 2 and 4;
-    several bands; several frames per workgroup with an idle slot; a strip wider than a workgroup."""
-    debug_switch("ws", "2")
-    debug_switch("ws_ring", ring)
-    run_case(1920, 108, 800, 45, n=3, seed=int(ring))
-    run_case(480, 60, 200, 25, n=5, seed=3)
-    run_case(8000, 24, 6000, 18, n=2, seed=5)
-    debug_switch("bands", "7")
-    run_case(1600, 200, 1200, 150, n=2, seed=4)
-
-
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_ws_filters_and_rings(mode, debug_switch):
+def test_ws_filters_and_rings(debug_switch):
     """Ring sizes 1..5 (vertical ratio / filter window) behind the same horizontal geometry; K = 6 and up stay one-role."""
-    debug_switch("ws", mode)
+    debug_switch("ws", "1")
     for (ih, oh, filt) in ((64, 64, Filter.Box), (200, 100, Filter.Box), (120, 64, Filter.Triangle), (300, 100, Filter.Hermite),
                            (400, 180, Filter.Robidoux), (400, 90, Filter.Robidoux), (330, 200, Filter.Lanczos)):
         run_case(640, ih, 300, oh, filt=filt, n=2, seed=ih + oh)
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_ws_full_size_level0_frame(mode, debug_switch):
+def test_ws_full_size_level0_frame(debug_switch):
     """One full-size frame of cfg3 level 0 (3840x2160 -> 1600x900, 900 rows through the ring), gradient + noise."""
     from tests import util as U
-    debug_switch("ws", mode)
+    debug_switch("ws", "1")
     fr = np.concatenate([U.gradient_frames(1, 3840, 2160), U.random_frames(1, 3840, 2160, seed0=5, alpha=True)])
     run_case(3840, 2160, 1600, 900, frames=fr)
