@@ -286,10 +286,11 @@ std::string querystring_filter_name(std::string v) {
 // ---- the stream of a job ------------------------------------------------------------------------------------------------
 // One Context per thread (imageflow_abi/src/lib.rs:20-27): every job runs on a stream of its own (non-blocking: nothing a
 // job does waits for another thread's job), leased from a pool for the duration of one send_json; device memory comes from
-// the library's size-class cache (devmem.cpp) and goes back without a driver call.  Every node ends with a wait for the
-// job's stream, so whatever a job frees is idle (ifhip::QuiescedScope around the whole job).
+// the library's size-class cache (devmem.cpp) and goes back without a driver call.  Whatever a job frees it frees behind
+// quiesce() -- a look at the job's stream, a wait if it is still busy -- so the block is idle (ifhip::QuiescedScope around
+// the whole job); nodes themselves do not wait for the device.
 std::mutex g_stream_mu;
-struct DeviceQueues { std::vector<hipStream_t> pool; int slots_taken = 0; std::condition_variable slot_cv; };
+struct DeviceQueues { std::vector<hipStream_t> pool, shared; size_t next_shared = 0; int slots_taken = 0; std::condition_variable slot_cv; };
 std::map<int, DeviceQueues> g_queues;                     // per device ordinal: a stream belongs to the device it was created on
 thread_local hipStream_t t_job_stream = nullptr;          // the stream of the job this thread is running (null outside a job)
 // Admission: the runtime spreads a process's streams over a handful of hardware queues, and a job waits for its stream a
@@ -334,8 +335,12 @@ struct DeviceScope {                                      // the calling thread 
 struct StreamLease {
     hipStream_t st = nullptr;
     int dev = 0;
+    bool shared = false;                                  // development switch `stream_pool` = C: jobs share C streams round-robin
     StreamLease() {
         if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+        int share = 0;
+        if (const char* e = ifhip::debug_switch("stream_pool")) share = std::max(0, std::atoi(e));
+        bool create = false;
         {
             std::unique_lock<std::mutex> lk(g_stream_mu);
             int slots = kJobSlots;
@@ -343,9 +348,14 @@ struct StreamLease {
             DeviceQueues& q = g_queues[dev];              // (map nodes do not move: the reference survives the wait)
             while (q.slots_taken >= slots) q.slot_cv.wait(lk);
             ++q.slots_taken;
-            if (!q.pool.empty()) { st = q.pool.back(); q.pool.pop_back(); }
+            if (share > 0) {
+                shared = true;
+                if (static_cast<int>(q.shared.size()) < share) create = true;
+                else st = q.shared[q.next_shared++ % q.shared.size()];
+            } else if (!q.pool.empty()) { st = q.pool.back(); q.pool.pop_back(); }
         }
         if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }   // (no device: the null stream, the first GPU call reports)
+        if (create && st) { std::lock_guard<std::mutex> lk(g_stream_mu); g_queues[dev].shared.push_back(st); }
         t_job_stream = st;
         ifhip_set_thread_stream(st);
     }
@@ -356,7 +366,7 @@ struct StreamLease {
         {
             std::lock_guard<std::mutex> lk(g_stream_mu);
             DeviceQueues& q = g_queues[dev];
-            if (st) q.pool.push_back(st);
+            if (st && !shared) q.pool.push_back(st);
             --q.slots_taken;
             q.slot_cv.notify_one();                       // (one waiter of THIS device; waking all of them cost a third of the job rate at 64 threads)
         }
@@ -546,7 +556,29 @@ void inner_box(int64_t sw, int64_t sh, int64_t tw, int64_t th, int64_t* ow, int6
 // ---- the job interpreter ---------------------------------------------------------------------------------------
 struct EncodeRecord { int32_t io_id; uint32_t w, h; const char* mime; const char* ext; };
 struct DecodeRecord { int32_t io_id; uint32_t w, h; const char* mime; const char* ext; };
-struct NodePerf { const char* name; uint64_t wall_ns; float gpu_ms; };        // s::NodePerf (imageflow_types/src/lib.rs:1999-2002)
+struct NodePerf { const char* name; uint64_t wall_ns; float gpu_ms; hipEvent_t e0, e1; };   // s::NodePerf (imageflow_types/src/lib.rs:1999-2002); e0/e1: read at the job's end
+// The hipEvents behind a node's `gpu_microseconds`, kept between jobs (two driver calls per node saved) and per device.
+struct TimingEvents {
+    std::mutex mu;
+    std::map<int, std::vector<hipEvent_t>> spare;
+    hipEvent_t take(int device) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto& v = spare[device];
+            if (!v.empty()) { hipEvent_t e = v.back(); v.pop_back(); return e; }
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return e;
+    }
+    void give(int device, hipEvent_t e) {
+        if (!e) return;
+        std::lock_guard<std::mutex> lk(mu);
+        auto& v = spare[device];
+        if (v.size() < 256) v.push_back(e); else (void)hipEventDestroy(e);
+    }
+};
+TimingEvents& timing_events() { static TimingEvents* t = new TimingEvents; return *t; }   // (never destroyed: jobs may outlive static teardown)
 struct ResampleHints {                                                        // s::ResampleHints (lib.rs:925-933), parsed
     bool has_sharpen = false;
     float sharpen = 0.f;
@@ -565,7 +597,11 @@ struct ResampleHints {                                                        //
 // gives the others a moment (only while other jobs are in flight at all), decodes everybody's file of its geometry in one
 // call on its own stream and hands each job its image's planes; the rest wait on a condition variable.  A batch that fails
 // (one damaged file) sends every member back to decode alone, so errors stay with the job that owns them.
-constexpr uint32_t kMaxCoalesce = 32;
+// At most 16 files to a batch: the decode's cost per file is flat from 8 up (profiles/r5_abi_jobs_cliff_7_decode_batches.txt),
+// and batches of 17-32 -- a sixth size class of 130 MB coefficient planes, everybody's pixel stages released at once --
+// took 20-35 ms each where 16 take 3: the job rate fell from 6 500 to 800 whenever more than ~20 jobs were admitted
+// (round 5, profiles/r5_abi_jobs_cliff_6_batch_cap.txt).
+constexpr uint32_t kMaxCoalesce = 16;
 std::atomic<int> g_jobs_in_flight{0};
 struct DecodeRequest {
     ifhip_jpeg_prepared* prepared = nullptr;             // the job's file, prepared on the job's own thread
@@ -576,6 +612,7 @@ struct DecodeRequest {
     std::shared_ptr<DecodedBatch> batch;
     uint32_t index = 0, batch_size = 0;
     bool done = false, retry_alone = false, taken = false;      // taken: a leader is decoding it
+    std::condition_variable cv;                                 // this request's own wake-up (never a broadcast to every waiting job)
     bool same_geometry(const DecodeRequest& o) const {
         return w == o.w && h == o.h && ncomp == o.ncomp && std::memcmp(hs, o.hs, 3) == 0 && std::memcmp(vs, o.vs, 3) == 0;
     }
@@ -583,50 +620,68 @@ struct DecodeRequest {
 // one batch on the calling thread's job stream; throws FlowErr
 std::shared_ptr<DecodedBatch> decode_files(const std::vector<DecodeRequest*>& reqs) {
     const uint32_t n = static_cast<uint32_t>(reqs.size());
+    const bool trace = ifhip::debug_switch("trace_decode_batches") != nullptr;      // one stderr line per batch: where its time went
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     std::vector<ifhip_jpeg_prepared*> files(n);
     for (uint32_t i = 0; i < n; ++i) files[i] = reqs[i]->prepared;
     ifhip_jpeg_entropy* ent = nullptr;
     check(ifhip_jpeg_entropy_create_prepared(&ent, files.data(), n));
     struct EntGuard { ifhip_jpeg_entropy* e; ~EntGuard() { quiesce(); ifhip_jpeg_entropy_destroy(e); } } eg{ent};
+    const double ms_create = ms_since(t0);
     auto b = std::make_shared<DecodedBatch>();
     uint32_t nsub = 0, nseg = 0;
     check(ifhip_jpeg_entropy_info(ent, &b->w, &b->h, &b->ncomp, b->hs, b->vs, b->bw, b->bh, &nsub, &nseg));
     uint32_t n_cap = 1;                                          // (batch sizes as powers of two: six size classes in the cache, not thirty-two)
     while (n_cap < n) n_cap *= 2;
+    const auto t1 = std::chrono::steady_clock::now();
     for (int k = 0; k < 3; ++k) {
         b->per_image[k] = static_cast<size_t>(b->bw[k]) * b->bh[k] * 64u;
         hip_check(job_malloc(reinterpret_cast<void**>(&b->coef[k]), std::max<size_t>(1, b->per_image[k] * n_cap) * 2u), "hipMalloc(coefficients)");
     }
+    const double ms_alloc = ms_since(t1);
+    const auto t2 = std::chrono::steady_clock::now();
     uint32_t rounds = 0;
     check(ifhip_jpeg_entropy_decode_device(ent, b->coef[0], b->coef[1], b->coef[2], &rounds, t_job_stream));
+    const double ms_decode = ms_since(t2);
     std::vector<uint16_t> qt(static_cast<size_t>(n) * 192u);
     check(ifhip_jpeg_entropy_quant_tables(ent, qt.data()));
     hip_check(job_malloc(reinterpret_cast<void**>(&b->d_qt), qt.size() * 2u), "hipMalloc(qt)");
     hip_check(static_cast<hipError_t>(ifhip::copy_to_device(b->d_qt, qt.data(), qt.size() * 2u)), "upload(qt)");
+    if (trace)
+        std::fprintf(stderr, "decode_batch files %u sub_sequences %u rounds %u ms: create %.3f alloc %.3f decode %.3f total %.3f\n", n, nsub, rounds, ms_create, ms_alloc,
+                     ms_decode, ms_since(t0));
     return b;
 }
 struct DecodeCoalescer {
     std::mutex mu;
-    std::condition_variable cv;
-    std::vector<DecodeRequest*> queue;
+    std::condition_variable leader_cv;                              // the gathering leader: "somebody arrived"
+    std::vector<DecodeRequest*> queue;                              // requests nobody has taken yet, in arrival order
     bool leader_active = false;
     int decoding = 0;                                               // batches whose decode is on the device right now
+    // Wake-ups are targeted: a request sleeps on its OWN condition variable and is woken when its batch is done or when it
+    // is its turn to lead; arrivals wake only a leader that is counting them.  (One shared condition variable with
+    // notify_all woke every waiting job on every arrival and every hand-over -- with more than ~20 jobs in the system the
+    // job rate fell five-fold, profiles/r5_abi_jobs_inflight_and_slots_sweep.txt.)
+    void wake_next_leader() {                                       // (mu held) the oldest request nobody took: it may lead now
+        if (!leader_active && !queue.empty()) queue.front()->cv.notify_one();
+    }
     // -> r.batch / r.index set, or r.retry_alone
     void submit(DecodeRequest& r) {
         std::unique_lock<std::mutex> lk(mu);
         queue.push_back(&r);
-        cv.notify_all();                                             // (a leader gathering its batch counts arrivals)
+        if (leader_active) leader_cv.notify_one();
         for (;;) {
-            // At most kDecodesInFlight batches decode at a time; whoever arrives meanwhile waits here, and the next leader takes
+            // At most `max_decoding` batches decode at a time; whoever arrives meanwhile waits here, and the next leader takes
             // ALL of them: the batch size follows the load by itself (group commit).  An entropy decode costs about the same
             // half millisecond for 1 file or 16 (three latency-bound launches), so a batch of 8 is an eighth of
             // the device time per job -- before, a new batch formed as soon as the last one had been gathered, 1.85 files per
             // batch at 2 300 jobs/s (round 5, profiles/r5_abi_trace_cfg4_8_threads.txt).
             int max_decoding = 2;
             if (const char* e = ifhip::debug_switch("coalesce_decodes_in_flight")) max_decoding = std::max(1, std::atoi(e));
-            while (!r.done && (leader_active || r.taken || decoding >= max_decoding)) cv.wait(lk);
+            while (!r.done && (r.taken || leader_active || decoding >= max_decoding || queue.front() != &r)) r.cv.wait(lk);
             if (r.done) return;
-            leader_active = true;                                    // nobody leads: this thread does, for one batch
+            leader_active = true;                                    // the oldest untaken request leads, for one batch
             // the moment given to the others: only while other jobs are in flight at all (a lone caller pays nothing) and no
             // decode is running (else the wait above was the moment)
             long window_us = (g_jobs_in_flight.load(std::memory_order_relaxed) > 1 && decoding == 0) ? 120 : 0;
@@ -635,17 +690,19 @@ struct DecodeCoalescer {
             if (const char* e = ifhip::debug_switch("coalesce_wait_for")) wait_for = static_cast<size_t>(std::max(1L, std::atol(e)));
             if (window_us > 0) {
                 const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us);
-                while (queue.size() < wait_for && cv.wait_until(lk, until) != std::cv_status::timeout) {}
+                while (queue.size() < wait_for && leader_cv.wait_until(lk, until) != std::cv_status::timeout) {}
             }
             // this thread's own request first, then whoever shares its geometry, in arrival order
+            size_t max_files = kMaxCoalesce;
+            if (const char* e = ifhip::debug_switch("coalesce_max")) max_files = static_cast<size_t>(std::max(1L, std::atol(e)));
             std::vector<DecodeRequest*> mine{&r}, rest;
             for (DecodeRequest* q : queue)
-                if (q != &r) (mine.size() < kMaxCoalesce && q->same_geometry(r) ? mine : rest).push_back(q);
+                if (q != &r) (mine.size() < max_files && q->same_geometry(r) ? mine : rest).push_back(q);
             queue.swap(rest);
             for (DecodeRequest* q : mine) q->taken = true;
             leader_active = false;                                   // leading = gathering: the next batch forms while this one decodes
             ++decoding;
-            cv.notify_all();
+            if (decoding < max_decoding) wake_next_leader();
             lk.unlock();
             std::shared_ptr<DecodedBatch> b;
             bool failed = false;
@@ -657,8 +714,9 @@ struct DecodeCoalescer {
                 if (failed) q->retry_alone = true;
                 else { q->batch = b; q->index = static_cast<uint32_t>(i); q->batch_size = static_cast<uint32_t>(mine.size()); }
                 q->done = true;
+                if (q != &r) q->cv.notify_one();
             }
-            cv.notify_all();
+            wake_next_leader();
         }
     }
 };
@@ -737,27 +795,49 @@ struct Job {
 
     // one executed primitive: wall clock as the reference's per-node cost (execution_engine.rs:506-538) plus the time
     // the device spent on it (hipEvents on the stream every node of this interpreter launches on)
+    // A node's performance record: wall time on the host and, between two hipEvents on the job's stream, the device's time.
+    // The node does NOT wait for the device when it ends -- its launches stay in flight while the host prepares the next
+    // node's; the events are read once, at the job's end (settle_perf).  (Until round 5 every node ended in
+    // hipEventSynchronize: 4 host/device round trips per job and, under the runtime's default spinning wait, one busy host
+    // core per job in flight -- profiles/r5_abi_jobs_host_cpu.txt.)
     struct Timed {
         Job* j; const char* name; std::chrono::steady_clock::time_point t0; hipEvent_t e0 = nullptr, e1 = nullptr;
         Timed(Job* job, const char* n) : j(job), name(n), t0(std::chrono::steady_clock::now()) {
-            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, t_job_stream) != hipSuccess) {
+            const int dev = j->c->device.load(std::memory_order_relaxed);
+            e0 = timing_events().take(dev); e1 = timing_events().take(dev);
+            if (!e0 || !e1 || hipEventRecord(e0, t_job_stream) != hipSuccess) {
                 (void)hipGetLastError();
-                if (e0) (void)hipEventDestroy(e0);
-                if (e1) (void)hipEventDestroy(e1);
+                timing_events().give(dev, e0); timing_events().give(dev, e1);
                 e0 = e1 = nullptr;
             }
         }
         ~Timed() {
-            float ms = 0.f;
-            if (e0) {
-                if (hipEventRecord(e1, t_job_stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
-                (void)hipEventDestroy(e0);
-                (void)hipEventDestroy(e1);
+            if (e0 && hipEventRecord(e1, t_job_stream) != hipSuccess) {
+                (void)hipGetLastError();
+                const int dev = j->c->device.load(std::memory_order_relaxed);
+                timing_events().give(dev, e0); timing_events().give(dev, e1);
+                e0 = e1 = nullptr;
             }
             const auto ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-            j->perf.push_back({name, static_cast<uint64_t>(ns), ms});
+            try { j->perf.push_back({name, static_cast<uint64_t>(ns), 0.f, e0, e1}); }
+            catch (...) { const int dev = j->c->device.load(std::memory_order_relaxed); timing_events().give(dev, e0); timing_events().give(dev, e1); }
         }
     };
+    // the device times of the nodes, once the job's stream has drained; `read` false (a failed job): the events just go back
+    void settle_perf(bool read) {
+        bool any = false;
+        for (const NodePerf& n : perf) any = any || n.e0;
+        if (!any) return;
+        const bool drained = read && ifhip::wait_stream(t_job_stream) == 0;
+        const int dev = c->device.load(std::memory_order_relaxed);
+        for (NodePerf& n : perf) {
+            if (!n.e0) continue;
+            if (drained && hipEventElapsedTime(&n.gpu_ms, n.e0, n.e1) != hipSuccess) { (void)hipGetLastError(); n.gpu_ms = 0.f; }
+            timing_events().give(dev, n.e0); timing_events().give(dev, n.e1);
+            n.e0 = n.e1 = nullptr;
+        }
+    }
+    ~Job() { settle_perf(false); }
 
     FramePtr new_frame(uint32_t w, uint32_t h, bool alpha, uint32_t fill_color32 = 0, bool zero = true) {
         if (w == 0 || h == 0) raise(kArgumentInvalid, "InvalidArgument: Bitmap dimensions cannot be zero");
@@ -2039,6 +2119,7 @@ const struct imageflow_json_response* imageflow_context_send_json(struct imagefl
         const JVal* fw = root.get("framewise");
         if (!fw || fw->t != JVal::Obj) raise(kInvalidJson, "InvalidJson: missing framewise");
         job.run_framewise(*fw);
+        job.settle_perf(true);
         return respond(c, 200, job_result_json(job, build ? "build_result" : "job_result"));
     } catch (const FlowErr& e) {
         return respond_error(c, e.cat, e.msg);

@@ -646,16 +646,16 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
     const size_t budget = static_cast<size_t>(1) << 30;
     uint32_t chunk = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(n_images, budget / std::max<size_t>(per_image, 1))));
     chunk = std::min<uint32_t>(chunk, 65535u);
-    // stream-ordered scratch: nothing is shared between concurrent calls on the same plan, and the memory returns to
-    // the pool as soon as the last kernel of this call has run
+    // stream-ordered scratch from the block cache: nothing is shared between concurrent calls on the same plan, and the
+    // memory is reusable as soon as the last kernel of this call has run (no host wait here)
     float4* scratch = nullptr;
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), per_image * chunk, st));
+    HIP_TRY(static_cast<hipError_t>(cached_malloc_for_stream(reinterpret_cast<void**>(&scratch), per_image * chunk, st, true)));
     hipError_t le = hipSuccess;
     for (uint32_t i0 = 0; i0 < n_images && le == hipSuccess; i0 += chunk) {
         const uint32_t n = std::min(chunk, n_images - i0);
         le = launch_generic(a, alpha != 0, scratch, i0, n, st);
     }
-    const hipError_t fe = hipFreeAsync(scratch, st);
+    const hipError_t fe = static_cast<hipError_t>(cached_free_after(scratch, st));
     HIP_TRY(le);
     HIP_TRY(fe);
     return IFHIP_OK;

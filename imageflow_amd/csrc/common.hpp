@@ -19,6 +19,8 @@ const char* last_error();
 // hipFree unless the caller holds a QuiescedScope: "the stream my work ran on has been synchronised".
 int cached_malloc(void** out, size_t bytes);
 int cached_free(void* p);
+int cached_malloc_for_stream(void** out, size_t bytes, void* stream, bool for_stream);   // a block for work on `stream` only
+int cached_free_after(void* p, void* stream);           // back to the cache once the work queued on `stream` so far has run; no host wait
 int cached_host_malloc(void** out, size_t bytes);       // pinned, portable
 int cached_host_free(void* p);
 void quiesced_enter();

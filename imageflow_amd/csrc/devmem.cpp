@@ -11,6 +11,7 @@
 // is kept: a plain cached_free waits for the device exactly like hipFree; a caller that HAS synchronised the stream its
 // work ran on says so (QuiescedScope) and pays nothing.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <atomic>
 #include <chrono>
@@ -47,6 +48,11 @@ struct Cache {
     std::mutex mu;
     std::map<size_t, std::vector<void*>> free_lists;                  // class -> blocks
     std::map<void*, size_t> live;                                     // block -> class (handed out)
+    // blocks released "behind" a stream (cached_free_after): reusable at once by an allocation FOR THAT STREAM, by anybody
+    // once the event recorded at the release has completed.  Counted in `kept`.
+    struct Pending { void* p; size_t cls; hipEvent_t ev; hipStream_t st; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> spare_events;
     size_t kept = 0, live_bytes = 0;
     uint64_t hits = 0, driver_allocs = 0, driver_frees = 0, oom_flushes = 0, device_syncs = 0;   // (ifhip_cache_stats)
 };
@@ -69,7 +75,26 @@ void quiesced_enter() { ++t_quiesced; }
 void quiesced_leave() { --t_quiesced; }
 void* thread_stream() { return t_stream; }
 
-int cached_malloc(void** out, size_t bytes) {
+namespace {
+// (c.mu held) pending releases whose stream has passed the release point move to the free lists; at most `budget` queries
+void reap_pending(Cache& c, size_t budget) {
+    for (size_t i = 0; i < c.pending.size() && budget > 0; --budget) {
+        const hipError_t e = hipEventQuery(c.pending[i].ev);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); ++i; continue; }
+        (void)hipGetLastError();                                      // (an error here: the stream is gone; its work is over either way)
+        c.free_lists[c.pending[i].cls].push_back(c.pending[i].p);
+        c.spare_events.push_back(c.pending[i].ev);
+        c.pending[i] = c.pending.back();
+        c.pending.pop_back();
+    }
+}
+}  // namespace
+
+int cached_malloc(void** out, size_t bytes) { return cached_malloc_for_stream(out, bytes, nullptr, false); }
+
+// `for_stream`: the block will only be touched by work queued on `stream` from now on -- a block released behind that very
+// stream (cached_free_after) can be handed out again without waiting for anything: stream order is the guarantee.
+int cached_malloc_for_stream(void** out, size_t bytes, void* stream, bool for_stream) {
     *out = nullptr;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return static_cast<int>(hipErrorNoDevice);
@@ -77,10 +102,21 @@ int cached_malloc(void** out, size_t bytes) {
     Cache& c = device_cache(dev);
     {
         std::lock_guard<std::mutex> lk(c.mu);
-        auto it = c.free_lists.find(cls);
-        if (it != c.free_lists.end() && !it->second.empty()) {
-            *out = it->second.back();
-            it->second.pop_back();
+        if (for_stream)
+            for (size_t i = c.pending.size(); i-- > 0;)
+                if (c.pending[i].cls == cls && c.pending[i].st == static_cast<hipStream_t>(stream)) {
+                    *out = c.pending[i].p;
+                    c.spare_events.push_back(c.pending[i].ev);
+                    c.pending[i] = c.pending.back();
+                    c.pending.pop_back();
+                    break;
+                }
+        if (!*out) {
+            auto it = c.free_lists.find(cls);
+            if ((it == c.free_lists.end() || it->second.empty()) && !c.pending.empty()) { reap_pending(c, 16); it = c.free_lists.find(cls); }
+            if (it != c.free_lists.end() && !it->second.empty()) { *out = it->second.back(); it->second.pop_back(); }
+        }
+        if (*out) {
             c.kept -= cls;
             c.live[*out] = cls;
             c.live_bytes += cls;
@@ -96,6 +132,7 @@ int cached_malloc(void** out, size_t bytes) {
             std::lock_guard<std::mutex> lk(c.mu);
             for (auto& kv : c.free_lists) { drop.insert(drop.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
             c.kept = 0;
+            for (const Cache::Pending& q : c.pending) c.kept += q.cls;   // (still behind their streams: they stay)
             ++c.oom_flushes;
             c.driver_frees += drop.size();
         }
@@ -137,6 +174,45 @@ int cached_free(void* p) {
         ++c.driver_frees;
     }
     return static_cast<int>(hipFree(p));
+}
+
+// Release without a host wait: the block goes back once the work queued on `stream` so far has run (an event marks the
+// point).  What hipFreeAsync does, with this cache's accounting -- and without the runtime pool's habit of giving memory back
+// to the driver at every synchronisation (release threshold 0: the no-hint ABI job ran at 1 200 or 2 800 jobs/s depending on
+// which way the pool fell in a given process, profiles/r5_abi_jobs_cfg4_bimodal_by_process_not_threads.txt).
+int cached_free_after(void* p, void* stream) {
+    if (!p) return 0;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return static_cast<int>(hipFree(p));
+    Cache& c = device_cache(dev);
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (!c.spare_events.empty()) { ev = c.spare_events.back(); c.spare_events.pop_back(); }
+    }
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return cached_free(p); }
+    if (hipEventRecord(ev, static_cast<hipStream_t>(stream)) != hipSuccess) {
+        (void)hipGetLastError();
+        { std::lock_guard<std::mutex> lk(c.mu); c.spare_events.push_back(ev); }
+        return cached_free(p);
+    }
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            const size_t cls = it->second;
+            if (c.kept + cls <= g_keep_device_bytes.load(std::memory_order_relaxed)) {
+                c.live.erase(it);
+                c.live_bytes -= cls;
+                c.pending.push_back({p, cls, ev, static_cast<hipStream_t>(stream)});
+                c.kept += cls;
+                if (c.pending.size() > 64) reap_pending(c, 8);
+                return 0;
+            }
+        }
+        c.spare_events.push_back(ev);
+    }
+    return cached_free(p);                                            // over the cap, or not ours: the waiting way
 }
 
 int cached_host_malloc(void** out, size_t bytes) {
@@ -194,6 +270,13 @@ size_t trim_cache(Cache& c, size_t keep, FreeFn release) {
     size_t dropped = 0;
     {
         std::lock_guard<std::mutex> lk(c.mu);
+        for (const Cache::Pending& q : c.pending) {                   // releases still behind a stream: wait for them, they are cache like the rest
+            (void)hipEventSynchronize(q.ev);
+            (void)hipGetLastError();
+            c.free_lists[q.cls].push_back(q.p);
+            c.spare_events.push_back(q.ev);
+        }
+        c.pending.clear();
         for (auto it = c.free_lists.rbegin(); it != c.free_lists.rend() && c.kept > keep; ++it)
             while (!it->second.empty() && c.kept > keep) {
                 drop.push_back(it->second.back());
@@ -232,17 +315,57 @@ int require_gfx950(int* device_out) {
     return IFHIP_OK;
 }
 
+// The library's one host-side wait.  hipStreamSynchronize SPINS in user space until the stream drains (the runtime's default,
+// hipDeviceScheduleAuto; an event created with hipEventBlockingSync spins as well, ROCr polls ~200 us before it sleeps --
+// both measured, profiles/r5_abi_jobs_host_cpu.txt): one busy host core per waiting thread.  That is the lowest latency while
+// cores are idle, and a disaster when they are not: a server with 48 jobs in flight in a container with a 16-CPU quota spent
+// 15 of its 16 CPUs spinning, the cgroup was throttled, and the job rate fell from 6 500 to 550 jobs/s.  So the wait is
+// load-aware: the first few waiters (a quarter of the CPUs this process may use) spin in the runtime, the rest query the
+// stream and sleep in between.
+//   switch `wait`: "runtime" = always hipStreamSynchronize, "sleep" = always query + sleep; default = by load
+//   switch `wait_spinners`: how many threads may spin at a time;  `wait_sleep_us`: the sleep between two queries (default 20)
+namespace {
+std::atomic<int> g_waiters{0};
+int cpu_budget() {                                                    // CPUs this process may keep busy: affinity and cgroup quota
+    static const int n = [] {
+        int cpus = static_cast<int>(std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::min(cpus > 0 ? cpus : CPU_COUNT(&set), CPU_COUNT(&set));
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {              // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0}; long long period = 0;
+            if (std::fscanf(f, "%31s %lld", q, &period) == 2 && period > 0 && q[0] != 'm')
+                cpus = std::min<long long>(cpus, std::max<long long>(1, (std::atoll(q) + period - 1) / period));
+            std::fclose(f);
+        } else {
+            long long quota = -1, period = 0;                                    // cgroup v1
+            if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(g, "%lld", &quota) != 1) quota = -1; std::fclose(g); }
+            if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(g, "%lld", &period) != 1) period = 0; std::fclose(g); }
+            if (quota > 0 && period > 0) cpus = std::min<long long>(cpus, std::max<long long>(1, (quota + period - 1) / period));
+        }
+        return std::max(1, cpus);
+    }();
+    return n;
+}
+}  // namespace
+
 int wait_stream(void* hip_stream) {
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const char* mode = debug_switch("wait");
-    if (!st || !mode || std::strcmp(mode, "poll") != 0) return static_cast<int>(hipStreamSynchronize(st));
-    for (uint32_t i = 0;; ++i) {
-        const hipError_t e = hipStreamQuery(st);
+    if (!st || (mode && std::strcmp(mode, "runtime") == 0)) return static_cast<int>(hipStreamSynchronize(st));
+    hipError_t e = hipStreamQuery(st);                                // often idle already
+    if (e != hipErrorNotReady) return static_cast<int>(e);
+    (void)hipGetLastError();                                          // (NotReady is recorded as the thread's last error)
+    struct Waiting { int n; Waiting() : n(g_waiters.fetch_add(1, std::memory_order_relaxed) + 1) {} ~Waiting() { g_waiters.fetch_sub(1, std::memory_order_relaxed); } } me;
+    int spinners = std::max(1, cpu_budget() / 4);
+    if (const char* sw = debug_switch("wait_spinners")) spinners = std::atoi(sw);
+    if (!(mode && std::strcmp(mode, "sleep") == 0) && me.n <= spinners) return static_cast<int>(hipStreamSynchronize(st));
+    long sleep_us = 20;
+    if (const char* sw = debug_switch("wait_sleep_us")) sleep_us = std::max(0L, std::atol(sw));
+    for (;;) {
+        std::this_thread::sleep_for(std::chrono::microseconds(sleep_us));
+        e = hipStreamQuery(st);
         if (e != hipErrorNotReady) return static_cast<int>(e);
-        (void)hipGetLastError();                                      // (NotReady is recorded as the thread's last error)
-        if (i < 200u) __builtin_ia32_pause();
-        else if (i < 4000u) std::this_thread::yield();
-        else std::this_thread::sleep_for(std::chrono::microseconds(30));
+        (void)hipGetLastError();
     }
 }
 

@@ -1311,12 +1311,12 @@ int ifhip_jpeg_decode_resample_batch_device(ifhip_jpeg_stage* stage, const int16
     const uint32_t stride = ifhip_stride_for_width(g.out_w);
     const size_t image_bytes = static_cast<size_t>(stride) * g.out_h;
     uint8_t* scratch = nullptr;
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), image_bytes * n_images, st));
+    HIP_TRY(static_cast<hipError_t>(cached_malloc_for_stream(reinterpret_cast<void**>(&scratch), image_bytes * n_images, st, true)));
     rc = ifhip_jpeg_idct_color_batch_device(stage, d_coef0, d_coef1, d_coef2, d_qt, n_images, scratch, image_bytes, stride, hip_stream);
     if (rc == IFHIP_OK)
         rc = ifhip_scale_and_render_batch_device(plan, scratch, image_bytes, stride, 0, n_images, d_canvas, canvas_image_bytes, canvas_w,
                                                  canvas_h, canvas_stride, x, y, working_space, compositing, matte_bgra, nullptr, -1, hip_stream);
-    const hipError_t fe = hipFreeAsync(scratch, st);
+    const hipError_t fe = static_cast<hipError_t>(cached_free_after(scratch, st));
     if (rc) return rc;
     HIP_TRY(fe);
     return IFHIP_OK;

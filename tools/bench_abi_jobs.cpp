@@ -15,6 +15,10 @@
 // Prints one JSON line: jobs/s, per-node means from the job results' `performance` block (wall and gpu microseconds),
 // output bytes per job.  Development tool (tools/), built by tools/bench_abi_jobs.py with g++.
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/time.h>
+#include <sys/resource.h>
 
 #include <atomic>
 #include <cctype>
@@ -45,6 +49,66 @@ struct Api {
     int (*device_count)() = nullptr;
     int (*cache_stats)(void*) = nullptr;
 };
+// What the host spent: this process's CPU time (getrusage) and the container's CPU quota and throttling (cgroup v2 cpu.max /
+// cpu.stat).  A quota of 16 CPUs with more than 16 runnable threads stops the WHOLE cgroup for the rest of each 100 ms period:
+// the job rate then says nothing about the library (profiles/r5_abi_jobs_cpu_quota.txt).
+struct HostCpu { double user_s = 0, sys_s = 0, quota_cpus = 0; long long nr_throttled = 0, throttled_usec = 0; };
+static HostCpu host_cpu() {
+    HostCpu h;
+    rusage ru{};
+    getrusage(RUSAGE_SELF, &ru);
+    h.user_s = ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6;
+    h.sys_s = ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0}; long long period = 0;
+        if (std::fscanf(f, "%31s %lld", q, &period) == 2 && period > 0 && q[0] != 'm') h.quota_cpus = std::atof(q) / period;
+        std::fclose(f);
+    }
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.stat", "r")) {
+        char k[64]; long long v;
+        while (std::fscanf(f, "%63s %lld", k, &v) == 2) {
+            if (!std::strcmp(k, "nr_throttled")) h.nr_throttled = v;
+            if (!std::strcmp(k, "throttled_usec")) h.throttled_usec = v;
+        }
+        std::fclose(f);
+    }
+    return h;
+}
+// --- where the host CPU time goes: IFHIP_BENCH_SAMPLE=<file> samples the process on CPU time (ITIMER_PROF, 1 kHz: the signal lands on
+// a thread in proportion to the CPU it burns) and writes one call stack per line as module+offset frames, leaf first.
+// tools/sample_stacks.py symbolises and ranks them.
+static constexpr int kMaxSamples = 120000, kDepth = 24;
+static void* g_samples[kMaxSamples][kDepth];
+static std::atomic<int> g_n_samples{0};
+static std::atomic<bool> g_sampling{false};
+static void on_prof(int) {
+    if (!g_sampling.load(std::memory_order_relaxed)) return;
+    const int i = g_n_samples.fetch_add(1, std::memory_order_relaxed);
+    if (i >= kMaxSamples) return;
+    int n = backtrace(g_samples[i], kDepth);
+    for (; n < kDepth; ++n) g_samples[i][n] = nullptr;
+}
+static void start_sampling() {
+    void* warm[4]; (void)backtrace(warm, 4);                // loads libgcc's unwinder outside the handler
+    struct sigaction sa{}; sa.sa_handler = on_prof; sa.sa_flags = SA_RESTART; sigaction(SIGPROF, &sa, nullptr);
+    itimerval tv{{0, 1000}, {0, 1000}}; setitimer(ITIMER_PROF, &tv, nullptr);
+}
+static void write_samples(const char* path) {
+    itimerval off{}; setitimer(ITIMER_PROF, &off, nullptr);
+    FILE* f = std::fopen(path, "w");
+    if (!f) return;
+    const int n = std::min(g_n_samples.load(), kMaxSamples);
+    for (int i = 0; i < n; ++i) {
+        for (int d = 2; d < kDepth && g_samples[i][d]; ++d) {  // 0, 1: the handler and the signal trampoline
+            Dl_info di{};
+            if (dladdr(g_samples[i][d], &di) && di.dli_fname)
+                std::fprintf(f, "%s%s+0x%zx", d > 2 ? ";" : "", di.dli_fname, static_cast<size_t>(static_cast<char*>(g_samples[i][d]) - static_cast<char*>(di.dli_fbase)));
+            else std::fprintf(f, "%s?+0x0", d > 2 ? ";" : "");
+        }
+        std::fputc('\n', f);
+    }
+    std::fclose(f);
+}
 struct CacheStats {                                      // include/imageflow_hip.h ifhip_cache_stats_t
     uint64_t device_hits, device_driver_allocs, device_driver_frees, device_oom_flushes, device_wide_syncs;
     uint64_t device_bytes_cached, device_bytes_live, device_blocks_live, device_limit_bytes;
@@ -192,6 +256,9 @@ int main(int argc, char** argv) {
     while (ready.load() < threads) std::this_thread::sleep_for(std::chrono::milliseconds(1));
     CacheStats cs0{}, cs1{};
     if (a.cache_stats) a.cache_stats(&cs0);
+    const char* sample_path = std::getenv("IFHIP_BENCH_SAMPLE");
+    if (sample_path) { start_sampling(); g_sampling = true; }
+    const HostCpu hc0 = host_cpu();
     const auto t0 = std::chrono::steady_clock::now();
     go = true;
     std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
@@ -199,6 +266,8 @@ int main(int argc, char** argv) {
     for (auto& th : pool) th.join();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (a.cache_stats) a.cache_stats(&cs1);
+    const HostCpu hc1 = host_cpu();
+    if (sample_path) { g_sampling = false; write_samples(sample_path); }
     const uint64_t n = jobs.load();
     const double nj = static_cast<double>(std::max<uint64_t>(n, 1));
     char cache[700];
@@ -211,6 +280,12 @@ int main(int argc, char** argv) {
                   cs1.device_bytes_cached / 1e6, cs1.device_bytes_live / 1e6, cs1.device_limit_bytes / 1e6,
                   (cs1.host_hits - cs0.host_hits) / nj, (cs1.host_driver_allocs - cs0.host_driver_allocs) / nj, (cs1.host_driver_frees - cs0.host_driver_frees) / nj,
                   cs1.host_bytes_cached / 1e6, cs1.host_bytes_live / 1e6);
+    char host[300];
+    std::snprintf(host, sizeof host, "{\"cpus_busy\": %.2f, \"user_cpus\": %.2f, \"sys_cpus\": %.2f, \"cpu_ms_per_job\": %.3f, \"cgroup_cpu_quota\": %.2f, "
+                  "\"cgroup_throttled_periods\": %lld, \"cgroup_throttled_s\": %.3f}",
+                  (hc1.user_s + hc1.sys_s - hc0.user_s - hc0.sys_s) / dt, (hc1.user_s - hc0.user_s) / dt, (hc1.sys_s - hc0.sys_s) / dt,
+                  (hc1.user_s + hc1.sys_s - hc0.user_s - hc0.sys_s) / nj * 1e3, hc1.quota_cpus,
+                  static_cast<long long>(hc1.nr_throttled - hc0.nr_throttled), (hc1.throttled_usec - hc0.throttled_usec) / 1e6);
     std::string devs = "[";
     bool unused_device = false;
     for (size_t d = 0; d < per_device.size(); ++d) {
@@ -227,10 +302,10 @@ int main(int argc, char** argv) {
     for (char& ch : first_error) if (ch == '"' || ch == '\n' || ch == '\\') ch = ' ';
     std::printf("{\"threads\": %d, \"seconds\": %.3f, \"jobs\": %llu, \"jobs_per_s\": %.1f, \"ms_per_job_per_thread\": %.3f, \"failures\": %llu, "
                 "\"output_bytes_per_job\": %llu, \"input_bytes\": %zu, \"devices\": %d, \"spread\": %s, \"jobs_per_device\": %s, \"contexts_on_unknown_devices\": %llu, "
-                "\"cache\": %s, \"nodes\": %s, \"first_error\": \"%s\"}\n",
+                "\"host\": %s, \"cache\": %s, \"nodes\": %s, \"first_error\": \"%s\"}\n",
                 threads, dt, static_cast<unsigned long long>(n), n / dt, n ? dt * threads / n * 1e3 : 0.0,
                 static_cast<unsigned long long>(failures.load()), static_cast<unsigned long long>(n ? out_bytes.load() / n : 0), file.size(),
                 n_devices, spread ? "true" : "false", spread ? devs.c_str() : "null", static_cast<unsigned long long>(bad_device.load()),
-                a.cache_stats ? cache : "null", nodes.c_str(), first_error.c_str());
+                host, a.cache_stats ? cache : "null", nodes.c_str(), first_error.c_str());
     return (failures.load() || bad_device.load() || unused_device) ? 1 : 0;
 }

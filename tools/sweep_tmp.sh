@@ -1,0 +1,36 @@
+#!/bin/bash
+set -u
+cd /root/repo 2>/dev/null || cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+W=$(mktemp -d)
+python - "$W" <<'PY'
+import json, os, sys
+sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import bench_abi_jobs as B
+w = sys.argv[1]
+B.build_harness(w)
+open(os.path.join(w, "in.jpg"), "wb").write(B.make_file())
+for k in ("cfg4", "cfg1", "cfg4h"):
+    open(os.path.join(w, k + ".json"), "w").write(json.dumps(B.JOBS[k]))
+PY
+LIB=$PWD/imageflow_amd/lib/libimageflow_hip.so
+run() { tag=$1; job=$2; thr=$3; reps=$4; shift 4
+  for rep in $(seq 1 $reps); do
+    r=$(env "$@" $W/bench_abi_jobs $LIB $W/in.jpg $W/$job.json $thr 1.5 3 2>/dev/null | grep -o '"jobs_per_s": [0-9.]*\|"host": {[^}]*}' | tr '\n' ' ')
+    echo "$tag job=$job threads=$thr rep=$rep $r"
+  done; }
+mkdir -p gpurun_out/samples
+samp() { tag=$1; job=$2; thr=$3; shift 3
+  env "$@" IFHIP_BENCH_SAMPLE=$W/$tag.samples $W/bench_abi_jobs $LIB $W/in.jpg $W/$job.json $thr 2.0 3 2>/dev/null | grep -o '"jobs_per_s": [0-9.]*\|"host": {[^}]*}' | tr '\n' ' ' > gpurun_out/samples/$tag.txt
+  echo >> gpurun_out/samples/$tag.txt
+  python tools/sample_stacks.py $W/$tag.samples 16 >> gpurun_out/samples/$tag.txt 2>&1
+  echo "=== $tag"; cat gpurun_out/samples/$tag.txt; }
+for rep in 1 2 3 4 5; do run default cfg4 64 1 A=1; done
+for rep in 1 2 3; do run max4 cfg4 64 1 IFHIP_COALESCE_MAX=4; done
+for rep in 1 2 3; do run slots32_max16 cfg4 64 1 IFHIP_COALESCE_MAX=16 IFHIP_JOB_SLOTS=32; done
+for rep in 1 2; do run slots32_max16 cfg1 64 1 IFHIP_COALESCE_MAX=16 IFHIP_JOB_SLOTS=32; done
+for rep in 1 2; do run slots32_max16 cfg4h 64 1 IFHIP_COALESCE_MAX=16 IFHIP_JOB_SLOTS=32; done
+for rep in 1 2; do run slots32_max8 cfg4h 64 1 IFHIP_COALESCE_MAX=8 IFHIP_JOB_SLOTS=32; done
+for rep in 1 2; do run slots48_max16 cfg4h 64 1 IFHIP_COALESCE_MAX=16 IFHIP_JOB_SLOTS=48; done
+for rep in 1 2; do run t8 cfg4 8 1 A=1; done
+rm -rf $W
