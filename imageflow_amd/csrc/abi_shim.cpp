@@ -293,10 +293,13 @@ std::mutex g_stream_mu;
 struct DeviceQueues { std::vector<hipStream_t> pool, shared; size_t next_shared = 0; int slots_taken = 0; std::condition_variable slot_cv; };
 std::map<int, DeviceQueues> g_queues;                     // per device ordinal: a stream belongs to the device it was created on
 thread_local hipStream_t t_job_stream = nullptr;          // the stream of the job this thread is running (null outside a job)
-// Admission: the runtime spreads a process's streams over a handful of hardware queues, and a job waits for its stream a
-// dozen times; with 64 jobs in flight every small copy queues behind other jobs' long kernels and the job rate FALLS
-// (measured, round 4: 6 750 jobs/s at 16 threads, 1 850 at 64).  Jobs beyond kJobSlots PER DEVICE wait for a slot on the host.
-constexpr int kJobSlots = 20;
+// Admission: jobs beyond kJobSlots PER DEVICE wait for a slot on the host.  The rate grows with the jobs admitted -- batches
+// of the coalesced decode fill up, the device always has somebody's pixel stage to run -- until the host's CPUs are the
+// limit: 7 800 jobs/s at 20, 9 900 at 40, 11 100 at 48 for the thumbnail job on a 16-CPU container (round 5,
+// profiles/r5_abi_jobs_slots_after_host_fixes.txt); 40 leaves a quarter of that container's CPUs to the caller.  (Rounds 4
+// and 5 measured a FALL above 20 admitted jobs and blamed the runtime's hardware queues; it was the 17-32-file decode
+// batches, see kMaxCoalesce.)
+constexpr int kJobSlots = 40;
 // Contexts and devices.  The reference's guidance is one Context per thread (imageflow_abi/src/lib.rs:20-27) and jobs are
 // independent, so a node's GPUs are fed by giving every context a device: with ifhip_shim_spread_contexts(1) a new context
 // takes the next usable device round-robin and all its jobs run there, whichever thread calls (no collective: a job's

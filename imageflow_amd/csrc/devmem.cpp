@@ -369,18 +369,41 @@ int wait_stream(void* hip_stream) {
     }
 }
 
-// host <-> device copies of the create paths: on the calling thread's job stream, complete on return
+// host <-> device copies of the create paths: on the calling thread's job stream, complete on return.  The host side is the
+// caller's ordinary (pageable) memory, and for that hipMemcpyAsync is not asynchronous at all: the runtime stages the bytes
+// itself and SPINS inside the call until they have moved -- 42 % of the host CPU of an ABI job was that spin, out of reach of
+// wait_stream's load-aware policy (round 5, profiles/r5_abi_jobs_host_cpu_slots32.txt).  So the copies are staged here, through
+// a pinned block of the library's cache, and the wait is ours.
+namespace {
+constexpr size_t kStageLimit = size_t(64) << 20;                       // larger copies: the runtime's own chunked path
+}
 int copy_to_device(void* dst, const void* src, size_t bytes) {
     if (!bytes) return 0;
-    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, t_stream);
-    if (e == hipSuccess) e = static_cast<hipError_t>(wait_stream(t_stream));
-    return static_cast<int>(e);
+    void* pin = nullptr;
+    if (bytes > kStageLimit || cached_host_malloc(&pin, bytes) != 0) {
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, t_stream);
+        if (e == hipSuccess) e = static_cast<hipError_t>(wait_stream(t_stream));
+        return static_cast<int>(e);
+    }
+    std::memcpy(pin, src, bytes);
+    hipError_t e = hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, t_stream);
+    const hipError_t w = static_cast<hipError_t>(wait_stream(t_stream));  // (also after a failed launch: nothing may still read `pin`)
+    (void)cached_host_free(pin);
+    return static_cast<int>(e != hipSuccess ? e : w);
 }
 int copy_to_host(void* dst, const void* src, size_t bytes) {
     if (!bytes) return 0;
-    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, t_stream);
-    if (e == hipSuccess) e = static_cast<hipError_t>(wait_stream(t_stream));
-    return static_cast<int>(e);
+    void* pin = nullptr;
+    if (bytes > kStageLimit || cached_host_malloc(&pin, bytes) != 0) {
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, t_stream);
+        if (e == hipSuccess) e = static_cast<hipError_t>(wait_stream(t_stream));
+        return static_cast<int>(e);
+    }
+    hipError_t e = hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, t_stream);
+    const hipError_t w = static_cast<hipError_t>(wait_stream(t_stream));
+    if (e == hipSuccess && w == hipSuccess) std::memcpy(dst, pin, bytes);
+    (void)cached_host_free(pin);
+    return static_cast<int>(e != hipSuccess ? e : w);
 }
 int zero_device(void* dst, size_t bytes) {                            // ordered on the job stream (the stage's first launch follows on it)
     if (!bytes) return 0;

@@ -27,6 +27,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -994,6 +995,65 @@ uint32_t unstuff_scan(const uint8_t* d, size_t len, const ParsedJpeg& P, std::ve
     return mcu0;
 }
 
+// The same walk, straight into the staging buffer the device reads: every restart segment starts on a sub-sequence boundary
+// and is zero-padded to the next one (an empty segment still takes one sub-sequence).  No per-segment vectors: a prepared
+// file used to cost a 400 KB vector grown by doubling, a copy out of it and a free that glibc answered with madvise() -- 40 %
+// of the host CPU of an ABI job (round 5, profiles/r5_abi_jobs_host_cpu_slots32.txt).  `cap` bytes are available at dst
+// (packed_scan_bound); returns the MCUs covered, *n_sub the sub-sequences written.
+size_t packed_scan_bound(size_t len, const ParsedJpeg& P) {
+    const uint32_t total_mcus = P.mcus_w * P.mcus_h;
+    const uint32_t per_seg = P.restart_interval ? P.restart_interval : total_mcus;
+    const size_t max_segs = per_seg ? (static_cast<size_t>(total_mcus) + per_seg - 1) / per_seg : 1;
+    return (len > P.scan_begin ? len - P.scan_begin : 0) + (max_segs + 1) * (kSubBits / 8u);
+}
+uint32_t unstuff_scan_packed(const uint8_t* d, size_t len, const ParsedJpeg& P, uint8_t* dst, size_t cap, std::vector<uint32_t>* seg_mcu0,
+                             std::vector<uint32_t>* seg_mcus, std::vector<uint64_t>* seg_bits, std::vector<uint32_t>* seg_nsub,
+                             std::vector<uint32_t>* seg_first_word, uint64_t* n_sub) {
+    constexpr size_t kSubBytes = kSubBits / 8u;
+    const uint32_t total_mcus = P.mcus_w * P.mcus_h;
+    const uint32_t per_seg = P.restart_interval ? P.restart_interval : total_mcus;
+    uint32_t mcu0 = 0;
+    uint64_t subs = 0;
+    size_t i = P.scan_begin;
+    bool more = true;
+    while (more && mcu0 < total_mcus) {
+        uint8_t* out = dst + subs * kSubBytes;
+        size_t nb = 0;
+        const size_t room = cap - static_cast<size_t>(subs) * kSubBytes;          // (the bound leaves a sub-sequence per segment beyond the scan's bytes)
+        more = false;
+        while (i < len) {
+            const uint8_t* ff = static_cast<const uint8_t*>(std::memchr(d + i, 0xFF, len - i));
+            const size_t run_end = ff ? static_cast<size_t>(ff - d) : len;
+            if (nb + (run_end - i) + 1 + kSubBytes > room) throw std::length_error("scan staging bound exceeded");
+            std::memcpy(out + nb, d + i, run_end - i);
+            nb += run_end - i;
+            i = run_end;
+            if (i >= len) break;
+            ++i;                                                           // the 0xFF
+            while (i < len && d[i] == 0xFF) ++i;                           // fill bytes before a marker
+            if (i >= len) break;
+            const uint8_t m = d[i++];
+            if (m == 0x00) { out[nb++] = 0xFF; continue; }
+            if (m >= 0xD0 && m <= 0xD7) { more = true; break; }            // restart: next segment
+            break;                                                         // EOI or any other marker: scan ends
+        }
+        const uint64_t bits = static_cast<uint64_t>(nb) * 8u;
+        const uint64_t ns = std::max<uint64_t>(1, (bits + kSubBits - 1) / kSubBits);
+        std::memset(out + nb, 0, static_cast<size_t>(ns) * kSubBytes - nb);                   // pad to the 1 024-bit boundary
+        const uint32_t mcus = std::min(per_seg, total_mcus - mcu0);
+        seg_mcu0->push_back(mcu0);
+        seg_mcus->push_back(mcus);
+        seg_bits->push_back(bits);
+        seg_nsub->push_back(static_cast<uint32_t>(ns));
+        seg_first_word->push_back(static_cast<uint32_t>(subs * kSubWords));
+        subs += ns;
+        mcu0 += mcus;
+        if (subs * kSubBits + 4096 >= (1ull << 32)) break;                 // (the caller refuses: more than 512 MB of scan data)
+    }
+    *n_sub = subs;
+    return mcu0;
+}
+
 }  // namespace
 
 struct ifhip_jpeg_entropy {
@@ -1004,9 +1064,11 @@ struct ifhip_jpeg_entropy {
     EntropyArgs a;
     std::vector<void*> owned;
     uint32_t* h_flags = nullptr;                     // pinned copy of changed[16] + errors
+    uint8_t* h_tables = nullptr;                     // pinned staging of the batch's tables (create_prepared_impl)
     ~ifhip_jpeg_entropy() {
         for (void* p : owned) if (p) (void)DEV_FREE(p);
         if (h_flags) (void)cached_host_free(h_flags);
+        if (h_tables) (void)cached_host_free(h_tables);
     }
 };
 
@@ -1213,6 +1275,33 @@ struct ifhip_jpeg_prepared {
     ~ifhip_jpeg_prepared() { if (words) (void)cached_host_free(words); }
 };
 
+// Prepared handles are recycled: 50 KB of tables each, one per job through the libimageflow ABI.
+namespace {
+struct PreparedPool { std::mutex mu; std::vector<ifhip_jpeg_prepared*> spare; };
+PreparedPool& prepared_pool() { static PreparedPool* p = new PreparedPool; return *p; }   // (never destroyed: handles may outlive static teardown)
+ifhip_jpeg_prepared* take_prepared() {
+    {
+        PreparedPool& pool = prepared_pool();
+        std::lock_guard<std::mutex> lk(pool.mu);
+        if (!pool.spare.empty()) { ifhip_jpeg_prepared* p = pool.spare.back(); pool.spare.pop_back(); return p; }
+    }
+    return new ifhip_jpeg_prepared;
+}
+void give_prepared(ifhip_jpeg_prepared* p) {
+    if (!p) return;
+    if (p->words) { (void)cached_host_free(p->words); p->words = nullptr; }
+    p->n_words = 0; p->n_sub = 0;
+    p->seg_mcu0.clear(); p->seg_mcus.clear(); p->seg_nsub.clear(); p->seg_first_word.clear(); p->seg_bits.clear();
+    PreparedPool& pool = prepared_pool();
+    {
+        std::lock_guard<std::mutex> lk(pool.mu);
+        if (pool.spare.size() < 64) { pool.spare.push_back(p); return; }
+    }
+    delete p;
+}
+struct GivePrepared { void operator()(ifhip_jpeg_prepared* p) const { give_prepared(p); } };
+}  // namespace
+
 static uint32_t test_hook_u32(const char* name, uint32_t dflt, uint32_t hi) {
     // test hooks: the rarely taken paths (serial code search for sub-tables that overflow the pool; further rounds after an
     // unsettled count pass) are forced by shrinking the pool / the iterations per launch
@@ -1221,45 +1310,35 @@ static uint32_t test_hook_u32(const char* name, uint32_t dflt, uint32_t hi) {
 }
 
 static int prepare_impl(ifhip_jpeg_prepared** out, const uint8_t* file, size_t len, uint32_t index_for_messages) {
-    std::unique_ptr<ifhip_jpeg_prepared> R(new ifhip_jpeg_prepared);
+    std::unique_ptr<ifhip_jpeg_prepared, GivePrepared> R(take_prepared());
     ParsedJpeg& P = R->P;
+    P = ParsedJpeg();
     if (int rc = parse_jpeg(file, len, &P)) return rc;
     std::memset(R->qt, 0, sizeof R->qt);
+    std::memset(&R->ftabs, 0, sizeof R->ftabs); std::memset(&R->ptabs, 0, sizeof R->ptabs); std::memset(&R->ctabs, 0, sizeof R->ctabs);   // (a recycled handle)
+    std::memset(R->stabs, 0, sizeof R->stabs);
     for (int c = 0; c < P.ncomp; ++c) std::memcpy(&R->qt[c * 64], P.qt[P.tq[c]], 128);
     R->pool_limit = test_hook_u32("ent_test_pool", kPoolEntries, kPoolEntries);
     derive_image_tables(P, &R->ftabs, R->stabs, R->pool_limit);
     derive_pair_tables(R->ftabs, P.ncomp, &R->ptabs);
     derive_count_tables(R->ftabs, R->ptabs, &R->ctabs);
-    std::vector<std::vector<uint8_t>> seg_bytes;
     const uint32_t total_mcus = P.mcus_w * P.mcus_h;
-    const uint32_t mcu0 = unstuff_scan(file, len, P, &seg_bytes, &R->seg_mcu0, &R->seg_mcus);
-    if (mcu0 < total_mcus)
-        return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: scan of image %u ends after %u of %u MCUs", index_for_messages, mcu0, total_mcus);
-    uint64_t subs = 0;
-    for (const auto& sb : seg_bytes) {
-        const uint64_t bits = static_cast<uint64_t>(sb.size()) * 8u;
-        const uint64_t ns = std::max<uint64_t>(1, (bits + kSubBits - 1) / kSubBits);
-        R->seg_bits.push_back(bits);
-        R->seg_nsub.push_back(static_cast<uint32_t>(ns));
-        R->seg_first_word.push_back(static_cast<uint32_t>(subs * kSubWords));
-        subs += ns;
-        if (subs * kSubBits + 4096 >= (1ull << 32)) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: more than 512 MB of scan data");
-    }
-    R->n_sub = static_cast<uint32_t>(subs);
-    R->n_words = static_cast<size_t>(subs) * kSubWords;
     void* pinned = nullptr;
     size_t pinned_bytes = 4096;                                          // powers of two: few size classes in the pinned cache, whatever the files
-    while (pinned_bytes < R->n_words * sizeof(uint32_t)) pinned_bytes *= 2;
+    const size_t bound = packed_scan_bound(len, P);
+    while (pinned_bytes < bound) pinned_bytes *= 2;
     if (cached_host_malloc(&pinned, pinned_bytes) != 0)
-        return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: %zu bytes of pinned staging", R->n_words * sizeof(uint32_t));
-    R->words = static_cast<uint32_t*>(pinned);
-    for (size_t k = 0; k < seg_bytes.size(); ++k) {                      // pack: stream order bytes -> big-endian words
-        uint32_t* w = R->words + R->seg_first_word[k];
-        const size_t nw = static_cast<size_t>(R->seg_nsub[k]) * kSubWords, nb = seg_bytes[k].size();
-        std::memcpy(w, seg_bytes[k].data(), nb);
-        std::memset(reinterpret_cast<uint8_t*>(w) + nb, 0, nw * sizeof(uint32_t) - nb);      // pad to the 1 024-bit boundary
-        for (size_t q = 0; q < nw; ++q) w[q] = __builtin_bswap32(w[q]);
-    }
+        return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: %zu bytes of pinned staging", pinned_bytes);
+    R->words = static_cast<uint32_t*>(pinned);                           // (R owns it from here: every return below releases it)
+    uint64_t subs = 0;
+    const uint32_t mcu0 = unstuff_scan_packed(file, len, P, reinterpret_cast<uint8_t*>(pinned), pinned_bytes, &R->seg_mcu0, &R->seg_mcus, &R->seg_bits,
+                                              &R->seg_nsub, &R->seg_first_word, &subs);
+    if (subs * kSubBits + 4096 >= (1ull << 32)) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: more than 512 MB of scan data");
+    if (mcu0 < total_mcus)
+        return fail(IFHIP_INVALID_ARGUMENT, "ImageMalformed: scan of image %u ends after %u of %u MCUs", index_for_messages, mcu0, total_mcus);
+    R->n_sub = static_cast<uint32_t>(subs);
+    R->n_words = static_cast<size_t>(subs) * kSubWords;
+    for (size_t q = 0; q < R->n_words; ++q) R->words[q] = __builtin_bswap32(R->words[q]);   // stream order bytes -> big-endian words
     *out = R.release();
     return IFHIP_OK;
 }
@@ -1269,11 +1348,32 @@ static int create_prepared_impl(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* c
     if (int arc = require_gfx950(&e->device)) return arc;
     e->n_images = n_images;
     e->qt.assign(static_cast<size_t>(n_images) * 192u, 0);
-    std::vector<Segment> segs;
-    std::vector<FastTabs> ftabs(n_images), ptabs(n_images), ctabs(n_images);
-    std::vector<SearchTab> stabs(static_cast<size_t>(n_images) * 6u);
+    // The batch's tables -- segments, sub-sequence -> segment, three look-up tables and six search tables per image -- are laid
+    // out in ONE pinned staging block and go to ONE device block in one copy (they were six allocations and six uploads, each
+    // with its own wait for the stream: most of the 1.9 ms a 16-file batch spent here, profiles/r5_abi_jobs_cliff_7_decode_batches.txt).
+    size_t n_segs = 0;
+    uint64_t subs_in_batch = 0;
+    for (uint32_t img = 0; img < n_images; ++img) { n_segs += prep[img]->seg_nsub.size(); subs_in_batch += prep[img]->n_sub; }
+    if (subs_in_batch * kSubBits + 4096 >= (1ull << 32)) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch holds more than 512 MB of scan data");
+    auto aligned = [](size_t v) { return (v + 255u) & ~static_cast<size_t>(255u); };
+    const size_t o_segs = 0, o_sub = aligned(o_segs + std::max<size_t>(n_segs, 1) * sizeof(Segment)),
+                 o_ftabs = aligned(o_sub + std::max<size_t>(subs_in_batch, 1) * sizeof(uint32_t)), o_ptabs = aligned(o_ftabs + n_images * sizeof(FastTabs)),
+                 o_ctabs = aligned(o_ptabs + n_images * sizeof(FastTabs)), o_stabs = aligned(o_ctabs + n_images * sizeof(FastTabs)),
+                 table_bytes = aligned(o_stabs + static_cast<size_t>(n_images) * 6u * sizeof(SearchTab));
+    size_t stage_bytes = 4096;                                           // powers of two: few size classes in the pinned cache
+    while (stage_bytes < table_bytes) stage_bytes *= 2;
+    if (cached_host_malloc(reinterpret_cast<void**>(&e->h_tables), stage_bytes) != 0)
+        return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: %zu bytes of pinned staging", stage_bytes);
+    uint8_t* const stage = e->h_tables;
+    Segment* const segs = reinterpret_cast<Segment*>(stage + o_segs);
+    uint32_t* const sub_seg = reinterpret_cast<uint32_t*>(stage + o_sub);
+    FastTabs* const ftabs = reinterpret_cast<FastTabs*>(stage + o_ftabs);
+    FastTabs* const ptabs = reinterpret_cast<FastTabs*>(stage + o_ptabs);
+    FastTabs* const ctabs = reinterpret_cast<FastTabs*>(stage + o_ctabs);
+    SearchTab* const stabs = reinterpret_cast<SearchTab*>(stage + o_stabs);
     std::vector<uint32_t> first_sub_of(n_images);
     uint64_t total_subs = 0;
+    size_t seg_count = 0;
     for (uint32_t img = 0; img < n_images; ++img) {
         const ifhip_jpeg_prepared& R = *prep[img];
         const ParsedJpeg& P = R.P;
@@ -1285,26 +1385,23 @@ static int create_prepared_impl(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* c
             if (!same) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: image %u differs in size or sampling from image 0 (one batch = one geometry)", img);
         }
         std::memcpy(&e->qt[static_cast<size_t>(img) * 192u], R.qt, sizeof R.qt);
-        ftabs[img] = R.ftabs; ptabs[img] = R.ptabs; ctabs[img] = R.ctabs;
+        std::memcpy(&ftabs[img], &R.ftabs, sizeof(FastTabs)); std::memcpy(&ptabs[img], &R.ptabs, sizeof(FastTabs)); std::memcpy(&ctabs[img], &R.ctabs, sizeof(FastTabs));
         std::memcpy(&stabs[static_cast<size_t>(img) * 6u], R.stabs, sizeof R.stabs);
         first_sub_of[img] = static_cast<uint32_t>(total_subs);
         for (size_t k = 0; k < R.seg_nsub.size(); ++k) {
             Segment sg;
+            std::memset(&sg, 0, sizeof sg);
             sg.image = img;
             sg.first_mcu = R.seg_mcu0[k];
             sg.n_blocks = R.seg_mcus[k] * P.blocks_per_mcu;
             sg.first_sub = static_cast<uint32_t>(total_subs);
             sg.n_sub = R.seg_nsub[k];
-            const uint64_t bit_end = total_subs * kSubBits + R.seg_bits[k];
-            if (bit_end + 4096 >= (1ull << 32)) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch holds more than 512 MB of scan data");
-            sg.bit_end = static_cast<uint32_t>(bit_end);
+            sg.bit_end = static_cast<uint32_t>(total_subs * kSubBits + R.seg_bits[k]);
+            for (uint32_t q = 0; q < sg.n_sub; ++q) sub_seg[total_subs + q] = static_cast<uint32_t>(seg_count);
             total_subs += sg.n_sub;
-            segs.push_back(sg);
+            segs[seg_count++] = sg;
         }
     }
-    std::vector<uint32_t> sub_seg(static_cast<size_t>(total_subs));
-    for (size_t k = 0; k < segs.size(); ++k)
-        for (uint32_t q = 0; q < segs[k].n_sub; ++q) sub_seg[segs[k].first_sub + q] = static_cast<uint32_t>(k);
     const size_t n_words = static_cast<size_t>(total_subs) * kSubWords + 64u;  // + lookahead slack behind the last segment
     const ParsedJpeg& F = e->first;
     EntropyArgs& a = e->a;
@@ -1320,8 +1417,8 @@ static int create_prepared_impl(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* c
             }
     }
     a.inner_rounds = std::max<uint32_t>(1u, test_hook_u32("ent_test_inner", kInnerRounds, kInnerRounds));
-    a.n_sub = static_cast<uint32_t>(sub_seg.size());
-    a.n_seg = static_cast<uint32_t>(segs.size());
+    a.n_sub = static_cast<uint32_t>(total_subs);
+    a.n_seg = static_cast<uint32_t>(seg_count);
     a.uniform_tables = 1u;                           // batches of small files put many images into one workgroup: with
     for (uint32_t img = 1; img < n_images && a.uniform_tables; ++img)     // identical tables they all use the LDS copy
         if (std::memcmp(&ftabs[img], &ftabs[0], sizeof(FastTabs)) != 0 ||
@@ -1348,12 +1445,12 @@ static int create_prepared_impl(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* c
                                        prep[img]->n_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemsetAsync(d_words + (n_words - 64u), 0, 64u * sizeof(uint32_t), st));
     }
-    if ((rc = dev_alloc(e.get(), &d_segs, segs.size(), segs.data()))) return rc;         // (each of these waits for the stream: the words are in place)
-    if ((rc = dev_alloc(e.get(), &d_sub, sub_seg.size(), sub_seg.data()))) return rc;
-    if ((rc = dev_alloc(e.get(), &d_ftabs, ftabs.size(), ftabs.data()))) return rc;
-    if ((rc = dev_alloc(e.get(), &d_ptabs, ptabs.size(), ptabs.data()))) return rc;
-    if ((rc = dev_alloc(e.get(), &d_ctabs, ctabs.size(), ctabs.data()))) return rc;
-    if ((rc = dev_alloc(e.get(), &d_stabs, stabs.size(), stabs.data()))) return rc;
+    uint8_t* d_tables = nullptr;
+    if ((rc = dev_alloc<uint8_t>(e.get(), &d_tables, table_bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_tables, stage, table_bytes, hipMemcpyHostToDevice, drain.st));      // (the wait: StreamDrain, on every way out)
+    d_segs = reinterpret_cast<Segment*>(d_tables + o_segs); d_sub = reinterpret_cast<uint32_t*>(d_tables + o_sub);
+    d_ftabs = reinterpret_cast<FastTabs*>(d_tables + o_ftabs); d_ptabs = reinterpret_cast<FastTabs*>(d_tables + o_ptabs);
+    d_ctabs = reinterpret_cast<FastTabs*>(d_tables + o_ctabs); d_stabs = reinterpret_cast<SearchTab*>(d_tables + o_stabs);
     a.words = d_words; a.segs = d_segs; a.sub_seg = d_sub; a.ftabs = d_ftabs; a.ptabs = d_ptabs; a.ctabs = d_ctabs; a.stabs = d_stabs;
     for (int b = 0; b < 2; ++b) {
         if ((rc = dev_alloc<uint32_t>(e.get(), &a.exit_p[b], a.n_sub))) return rc;
@@ -1381,7 +1478,7 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     const bool timing = debug_switch("ent_timing") != nullptr;        // development aid: phase times on stderr
     const auto t_start = std::chrono::steady_clock::now();
     auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
-    std::vector<std::unique_ptr<ifhip_jpeg_prepared>> prep(n_images);
+    std::vector<std::unique_ptr<ifhip_jpeg_prepared, GivePrepared>> prep(n_images);
     std::vector<int> rcs(n_images, IFHIP_OK);
     std::vector<std::string> messages(n_images);
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -1430,7 +1527,7 @@ int ifhip_jpeg_entropy_prepare(ifhip_jpeg_prepared** out, const uint8_t* jpeg, s
     catch (const std::bad_alloc&) { return fail(IFHIP_ALLOCATION_FAILED, "AllocationFailed: host memory while preparing the scan"); }
     catch (const std::exception& ex) { return fail(IFHIP_INVALID_STATE, "InvalidState: %s", ex.what()); }
 }
-void ifhip_jpeg_prepared_destroy(ifhip_jpeg_prepared* p) { delete p; }
+void ifhip_jpeg_prepared_destroy(ifhip_jpeg_prepared* p) { give_prepared(p); }
 int ifhip_jpeg_prepared_info(const ifhip_jpeg_prepared* p, uint32_t* width, uint32_t* height, int* n_components, uint8_t* h_samp3, uint8_t* v_samp3) {
     if (!p) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null handle");
     if (width) *width = p->P.width;

@@ -25,12 +25,12 @@ samp() { tag=$1; job=$2; thr=$3; shift 3
   echo >> gpurun_out/samples/$tag.txt
   python tools/sample_stacks.py $W/$tag.samples 16 >> gpurun_out/samples/$tag.txt 2>&1
   echo "=== $tag"; cat gpurun_out/samples/$tag.txt; }
-for rep in 1 2 3 4 5; do run default cfg4 64 1 A=1; done
-for rep in 1 2 3; do run max4 cfg4 64 1 IFHIP_COALESCE_MAX=4; done
-for rep in 1 2 3; do run slots32_max16 cfg4 64 1 IFHIP_COALESCE_MAX=16 IFHIP_JOB_SLOTS=32; done
-for rep in 1 2; do run slots32_max16 cfg1 64 1 IFHIP_COALESCE_MAX=16 IFHIP_JOB_SLOTS=32; done
-for rep in 1 2; do run slots32_max16 cfg4h 64 1 IFHIP_COALESCE_MAX=16 IFHIP_JOB_SLOTS=32; done
-for rep in 1 2; do run slots32_max8 cfg4h 64 1 IFHIP_COALESCE_MAX=8 IFHIP_JOB_SLOTS=32; done
-for rep in 1 2; do run slots48_max16 cfg4h 64 1 IFHIP_COALESCE_MAX=16 IFHIP_JOB_SLOTS=48; done
-for rep in 1 2; do run t8 cfg4 8 1 A=1; done
+for job in cfg1 cfg4h cfg4; do
+  for sl in 32 40 48 64; do run slots$sl $job 64 2 IFHIP_JOB_SLOTS=$sl; done
+  run default_t128 $job 128 1 A=1
+  run default_t16 $job 16 1 A=1
+  run default_t8 $job 8 1 A=1
+  run default_t1 $job 1 1 A=1
+done
+samp cfg1_default cfg1 64 A=1 > /dev/null
 rm -rf $W
