@@ -244,6 +244,49 @@ def test_decode_resample_falls_back_where_planes_are_not_at_output_size():
     assert np.array_equal(one, two)
 
 
+def test_decode_resample_scratch_comes_from_the_block_cache_in_stream_order():
+    """The two-step chain's scratch bitmap is a block of the library's cache released BEHIND the stream (devmem.cpp
+    cached_free_after): no host wait, no driver call after the first, reused by the next call on the same stream while the
+    previous one may still be running, on another stream only once the first has passed the release point.  (Until round 5 it
+    was hipMallocAsync / hipFreeAsync, whose pool trimmed itself at synchronisations: the no-hint ABI job ran at 1 200 or
+    2 800 jobs/s depending on the process.)"""
+    from imageflow_amd import _native
+    from imageflow_amd.graphics.bitmaps import Bitmap
+    from imageflow_amd.graphics.scaling import ScaleAndRenderParams, scale_and_render
+    rng = np.random.default_rng(19)
+    j = _random_case(rng, 640, 400, (2, 1, 1), (2, 1, 1), 3, 200)
+    n = 2
+    st = JpegPixelStage(j["width"], j["height"], j["ncomp"], j["hs"], j["vs"], n, DEV, scale_num=8)
+    coef = [torch.from_numpy(np.stack([j["coef"][c]] * n)).to(DEV) for c in range(3)]
+    qt = torch.from_numpy(np.stack([j["qt"]] * n).astype(np.int16)).to(DEV)
+    info = ScaleAndRenderParams(0, 0, 160, 100)
+    want = Bitmap.create_u8(n, 160, 100, DEV)
+    scale_and_render(st.read_frames(coef, qt), want, info)
+    torch.cuda.synchronize()
+    want = want.to_numpy()
+    canv = [Bitmap.create_u8(n, 160, 100, DEV) for _ in range(12)]
+    assert not st.read_frames_into(coef, qt, canv[0], info)              # (warm: the plan, the first scratch block)
+    torch.cuda.synchronize()
+    import gc
+    gc.collect()                                                         # (earlier tests' stages and plans free their blocks now, not inside the window)
+    s0 = _native.cache_stats()
+    for c in canv[1:7]:                                                  # six calls queued back to back on one stream, no wait between
+        assert not st.read_frames_into(coef, qt, c, info)
+    side = torch.cuda.Stream(DEV)
+    with torch.cuda.stream(side):                                        # and six on another stream, concurrently
+        for c in canv[7:]:
+            assert not st.read_frames_into(coef, qt, c, info)
+    torch.cuda.synchronize()
+    s1 = _native.cache_stats()
+    assert s1["device_hits"] - s0["device_hits"] >= 10                   # the scratch came from the cache ...
+    assert s1["device_driver_allocs"] - s0["device_driver_allocs"] <= 2  # ... (the other stream may need a block of its own)
+    assert (s1["device_driver_frees"], s1["device_wide_syncs"]) == (s0["device_driver_frees"], s0["device_wide_syncs"]), (s0, s1)
+    for c in canv:
+        assert np.array_equal(c.to_numpy(), want)
+    _native.trim_cache()                                                 # blocks still parked behind a stream are cache like the rest
+    assert _native.cache_stats()["device_bytes_cached"] == 0
+
+
 def test_decode_resample_cfg4_shape():
     """BASELINE config 4 as the reference decodes it: 3840x2160 4:2:0 at 4/8 with the spatial sRGB luma scaler -> 800x450."""
     rng = np.random.default_rng(44)

@@ -26,11 +26,15 @@ samp() { tag=$1; job=$2; thr=$3; shift 3
   python tools/sample_stacks.py $W/$tag.samples 16 >> gpurun_out/samples/$tag.txt 2>&1
   echo "=== $tag"; cat gpurun_out/samples/$tag.txt; }
 for job in cfg1 cfg4h cfg4; do
-  for sl in 32 40 48 64; do run slots$sl $job 64 2 IFHIP_JOB_SLOTS=$sl; done
-  run default_t128 $job 128 1 A=1
-  run default_t16 $job 16 1 A=1
-  run default_t8 $job 8 1 A=1
-  run default_t1 $job 1 1 A=1
+  run base $job 64 2 A=1
+  run spin8 $job 64 2 IFHIP_WAIT_SPINNERS=8
+  run spin12 $job 64 1 IFHIP_WAIT_SPINNERS=12
+  run sleep5 $job 64 1 IFHIP_WAIT_SLEEP_US=5
+  run sleep50 $job 64 1 IFHIP_WAIT_SLEEP_US=50
+  run spin8_sleep5 $job 64 1 IFHIP_WAIT_SPINNERS=8 IFHIP_WAIT_SLEEP_US=5
+  run slots64_spin8 $job 64 1 IFHIP_WAIT_SPINNERS=8 IFHIP_JOB_SLOTS=64
+  run slots96_t128 $job 128 1 IFHIP_JOB_SLOTS=96
+  run inflight3 $job 64 1 IFHIP_COALESCE_DECODES_IN_FLIGHT=3
+  run runtime $job 64 1 IFHIP_WAIT=runtime
 done
-samp cfg1_default cfg1 64 A=1 > /dev/null
 rm -rf $W
