@@ -290,7 +290,7 @@ std::string querystring_filter_name(std::string v) {
 // quiesce() -- a look at the job's stream, a wait if it is still busy -- so the block is idle (ifhip::QuiescedScope around
 // the whole job); nodes themselves do not wait for the device.
 std::mutex g_stream_mu;
-struct DeviceQueues { std::vector<hipStream_t> pool, shared; size_t next_shared = 0; int slots_taken = 0; std::condition_variable slot_cv; };
+struct DeviceQueues { std::vector<hipStream_t> pool; int slots_taken = 0; std::condition_variable slot_cv; };
 std::map<int, DeviceQueues> g_queues;                     // per device ordinal: a stream belongs to the device it was created on
 thread_local hipStream_t t_job_stream = nullptr;          // the stream of the job this thread is running (null outside a job)
 // Admission: jobs beyond kJobSlots PER DEVICE wait for a slot on the host.  The rate grows with the jobs admitted -- batches
@@ -338,12 +338,8 @@ struct DeviceScope {                                      // the calling thread 
 struct StreamLease {
     hipStream_t st = nullptr;
     int dev = 0;
-    bool shared = false;                                  // development switch `stream_pool` = C: jobs share C streams round-robin
     StreamLease() {
         if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
-        int share = 0;
-        if (const char* e = ifhip::debug_switch("stream_pool")) share = std::max(0, std::atoi(e));
-        bool create = false;
         {
             std::unique_lock<std::mutex> lk(g_stream_mu);
             int slots = kJobSlots;
@@ -351,14 +347,9 @@ struct StreamLease {
             DeviceQueues& q = g_queues[dev];              // (map nodes do not move: the reference survives the wait)
             while (q.slots_taken >= slots) q.slot_cv.wait(lk);
             ++q.slots_taken;
-            if (share > 0) {
-                shared = true;
-                if (static_cast<int>(q.shared.size()) < share) create = true;
-                else st = q.shared[q.next_shared++ % q.shared.size()];
-            } else if (!q.pool.empty()) { st = q.pool.back(); q.pool.pop_back(); }
+            if (!q.pool.empty()) { st = q.pool.back(); q.pool.pop_back(); }
         }
         if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }   // (no device: the null stream, the first GPU call reports)
-        if (create && st) { std::lock_guard<std::mutex> lk(g_stream_mu); g_queues[dev].shared.push_back(st); }
         t_job_stream = st;
         ifhip_set_thread_stream(st);
     }
@@ -369,7 +360,7 @@ struct StreamLease {
         {
             std::lock_guard<std::mutex> lk(g_stream_mu);
             DeviceQueues& q = g_queues[dev];
-            if (st && !shared) q.pool.push_back(st);
+            if (st) q.pool.push_back(st);
             --q.slots_taken;
             q.slot_cv.notify_one();                       // (one waiter of THIS device; waking all of them cost a third of the job rate at 64 threads)
         }
