@@ -1655,6 +1655,20 @@ int ifhip_jpeg_debug_scan_report(const uint8_t* jpeg, size_t len, ifhip_jpeg_sca
         std::vector<std::vector<uint8_t>> seg_bytes;
         std::vector<uint32_t> seg_mcu0, seg_mcus;
         const uint32_t covered = unstuff_scan(jpeg, len, P, &seg_bytes, &seg_mcu0, &seg_mcus);
+        {   // the product's un-stuffer (straight into the staging block) against the walk above: same segments, same bytes, and
+            // -- under the sanitizer build, tools/sanitize -- never a byte beyond the bound the staging block is sized by
+            const size_t bound = packed_scan_bound(len, P);
+            std::unique_ptr<uint8_t[]> packed(new uint8_t[bound]);
+            std::vector<uint32_t> p_mcu0, p_mcus, p_nsub, p_first;
+            std::vector<uint64_t> p_bits;
+            uint64_t p_subs = 0;
+            const uint32_t p_covered = unstuff_scan_packed(jpeg, len, P, packed.get(), bound, &p_mcu0, &p_mcus, &p_bits, &p_nsub, &p_first, &p_subs);
+            bool same = p_covered == covered && p_mcu0 == seg_mcu0 && p_mcus == seg_mcus && p_bits.size() == seg_bytes.size();
+            for (size_t k = 0; same && k < seg_bytes.size(); ++k)
+                same = p_bits[k] == seg_bytes[k].size() * 8u &&
+                       std::memcmp(packed.get() + static_cast<size_t>(p_first[k]) * 4u, seg_bytes[k].data(), seg_bytes[k].size()) == 0;
+            if (!same) return fail(IFHIP_INVALID_STATE, "InvalidState: the packed un-stuffer disagrees with the per-segment walk");
+        }
         out->segments = static_cast<uint32_t>(seg_bytes.size());
         out->scan_complete = covered == P.mcus_w * P.mcus_h ? 1u : 0u;
         for (size_t sgi = 0; sgi < seg_bytes.size(); ++sgi) {
