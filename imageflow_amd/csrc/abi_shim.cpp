@@ -555,8 +555,12 @@ struct NodePerf { const char* name; uint64_t wall_ns; float gpu_ms; hipEvent_t e
 struct TimingEvents {
     std::mutex mu;
     std::map<int, std::vector<hipEvent_t>> spare;
+    // development switch `perf_events`: "fresh" = create / destroy per node (no reuse), "off" = none (gpu_microseconds 0)
+    static int mode() { const char* m = ifhip::debug_switch("perf_events"); return !m ? 0 : (std::strcmp(m, "fresh") == 0 ? 1 : (std::strcmp(m, "off") == 0 ? 2 : 0)); }
     hipEvent_t take(int device) {
-        {
+        const int md = mode();
+        if (md == 2) return nullptr;
+        if (md == 0) {
             std::lock_guard<std::mutex> lk(mu);
             auto& v = spare[device];
             if (!v.empty()) { hipEvent_t e = v.back(); v.pop_back(); return e; }
@@ -567,6 +571,7 @@ struct TimingEvents {
     }
     void give(int device, hipEvent_t e) {
         if (!e) return;
+        if (mode() == 1) { (void)hipEventDestroy(e); return; }
         std::lock_guard<std::mutex> lk(mu);
         auto& v = spare[device];
         if (v.size() < 256) v.push_back(e); else (void)hipEventDestroy(e);

@@ -18,6 +18,7 @@
 #include <execinfo.h>
 #include <signal.h>
 #include <sys/time.h>
+#include <unistd.h>
 #include <sys/resource.h>
 
 #include <atomic>
@@ -88,6 +89,22 @@ static void on_prof(int) {
     int n = backtrace(g_samples[i], kDepth);
     for (; n < kDepth; ++n) g_samples[i][n] = nullptr;
 }
+// a crash inside the library (or the runtime, or a profiler's interposer) says where: module+offset frames on stderr
+static void on_segv(int sig) {
+    void* fr[40];
+    const int n = backtrace(fr, 40);
+    char line[600];
+    for (int d = 0; d < n; ++d) {
+        Dl_info di{};
+        int m;
+        if (dladdr(fr[d], &di) && di.dli_fname)
+            m = std::snprintf(line, sizeof line, "crash frame %d: %s+0x%zx %s\n", d, di.dli_fname, static_cast<size_t>(static_cast<char*>(fr[d]) - static_cast<char*>(di.dli_fbase)), di.dli_sname ? di.dli_sname : "");
+        else m = std::snprintf(line, sizeof line, "crash frame %d: ?\n", d);
+        if (m > 0) (void)!write(2, line, static_cast<size_t>(m));
+    }
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
 static void start_sampling() {
     void* warm[4]; (void)backtrace(warm, 4);                // loads libgcc's unwinder outside the handler
     struct sigaction sa{}; sa.sa_handler = on_prof; sa.sa_flags = SA_RESTART; sigaction(SIGPROF, &sa, nullptr);
@@ -156,6 +173,9 @@ static void scan_nodes(const char* s, size_t len, std::map<std::string, NodeSum>
 }
 
 int main(int argc, char** argv) {
+    signal(SIGSEGV, on_segv);
+    signal(SIGBUS, on_segv);
+    signal(SIGABRT, on_segv);
     if (argc < 6) { std::fprintf(stderr, "usage: %s lib file job.json threads seconds [warmup]\n", argv[0]); return 2; }
     void* h = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL);
     if (!h) { std::fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }

@@ -17,7 +17,8 @@ B.build_harness(w)
 open(os.path.join(w, "in.jpg"), "wb").write(B.make_file())
 open(os.path.join(w, "job.json"), "w").write(json.dumps(B.JOBS[kind]))
 PY
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $W/t -- $W/bench_abi_jobs $PWD/imageflow_amd/lib/libimageflow_hip.so $W/in.jpg $W/job.json $T $SEC > $W/run.json 2> $W/err.txt
+timeout 60 rocprofv3 --kernel-trace --output-format csv -d $W/t -- $W/bench_abi_jobs $PWD/imageflow_amd/lib/libimageflow_hip.so $W/in.jpg $W/job.json $T $SEC > $W/run.json 2> $W/err.txt
+grep "crash frame" $W/err.txt | head -40
 f=$(find $W/t -name '*kernel_trace.csv' | head -1)
 { echo "# $KIND, $T threads, $SEC s under rocprofv3 --kernel-trace"; grep -o '"jobs_per_s": [0-9.]*' $W/run.json | head -1
 python - "$f" <<'PY'

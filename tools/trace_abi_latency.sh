@@ -22,7 +22,7 @@ B.build_harness(w)
 open(os.path.join(w, "in.jpg"), "wb").write(B.make_file())
 open(os.path.join(w, "job.json"), "w").write(json.dumps(B.JOBS[kind]))
 PY
-timeout 600 rocprofv3 --hip-runtime-trace --kernel-trace --memory-copy-trace --output-format csv -d $W/t -- \
+timeout 90 rocprofv3 --hip-runtime-trace --kernel-trace --memory-copy-trace --output-format csv -d $W/t -- \
     $W/bench_abi_jobs $PWD/imageflow_amd/lib/libimageflow_hip.so $W/in.jpg $W/job.json $T $SEC > $W/run.json 2> $W/err.txt
 { echo "# $KIND, $T threads, $SEC s under rocprofv3 --hip-runtime-trace --kernel-trace --memory-copy-trace"
   grep -o '"jobs_per_s": [0-9.]*' $W/run.json | head -1
