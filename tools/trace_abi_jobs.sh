@@ -2,10 +2,13 @@
 # Where the GPU's time goes while jobs run through the libimageflow ABI: rocprofv3 --kernel-trace of tools/bench_abi_jobs.cpp
 # (T threads, one job kind), then per kernel: launches, summed duration, and how much of the wall span any kernel was running.
 #   usage (on the GPU box): tools/trace_abi_jobs.sh <job kind> <threads> [seconds]      -> gpurun_out/trace_abi/<kind>_<threads>.txt
+# Keep the run SHORT (0.5 s): at this build's 9 000 jobs/s a 1.0 s run under --kernel-trace died inside librocprofiler-sdk
+# (SIGSEGV below an HSA hook, or a hang; the harness prints the frames) three times out of three, 0.5 s runs four out of four
+# fine, with any wait mode and slot count -- profiles/NOTEBOOK.md, round 5.
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-KIND=${1:-cfg1}; T=${2:-32}; SEC=${3:-1.0}
+KIND=${1:-cfg1}; T=${2:-32}; SEC=${3:-0.5}
 OUT=gpurun_out/trace_abi; mkdir -p $OUT
 W=$(mktemp -d)
 python - "$W" "$KIND" <<'PY'
