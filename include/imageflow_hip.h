@@ -135,7 +135,8 @@ IFHIP_API int ifhip_scale_and_render(const uint8_t* in, uint32_t in_w, uint32_t 
  * (PixelRowWeights for both axes, the vertical schedule) for (in_w, in_h) -> (w, h); its tables are immutable and it
  * may be shared by any number of launches on the device it was created on (internal lazily built caches are locked).
  * The generic two-pass kernels (up-scaling, > 8 live rows, unaligned rows) stage through stream-ordered scratch
- * (hipMallocAsync on the launch stream), so launches of one plan may run on any number of streams.
+ * (a block of the library's cache, released behind the launch stream: ifhip_cache_stats counts it), so launches of one plan
+ * may run on any number of streams.
  */
 typedef struct ifhip_resample_plan ifhip_resample_plan;
 IFHIP_API int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32_t in_h,
