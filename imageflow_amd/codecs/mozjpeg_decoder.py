@@ -153,6 +153,11 @@ def _bind_entropy():
     L.ifhip_jpeg_entropy_info.argtypes = [C.c_void_p] + [C.c_void_p] * 9
     L.ifhip_jpeg_entropy_quant_tables.argtypes = [C.c_void_p, C.c_void_p]
     L.ifhip_jpeg_entropy_decode_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ifhip_jpeg_entropy_prepare.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t]
+    L.ifhip_jpeg_prepared_destroy.argtypes = [C.c_void_p]
+    L.ifhip_jpeg_prepared_destroy.restype = None
+    L.ifhip_jpeg_prepared_upload.argtypes = [C.c_void_p, C.c_void_p]
+    L.ifhip_jpeg_entropy_create_prepared.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_uint32]
     L._jpeg_entropy_bound = True
     return L
 
@@ -178,16 +183,34 @@ class JpegEntropyBatch:
     """ifhip_jpeg_entropy: n baseline files of one geometry, parsed and un-stuffed on the host, Huffman-decoded on the
     GPU by the self-synchronising parallel decoder."""
 
-    def __init__(self, files, device="cuda:0"):
+    def __init__(self, files, device="cuda:0", prepared=False, upload_stream=None):
+        """prepared=True: the per-file form a host with one job per thread uses -- ifhip_jpeg_entropy_prepare for every file,
+        then (upload_stream: a torch stream, or None for no early upload) ifhip_jpeg_prepared_upload on that stream, then
+        ifhip_jpeg_entropy_create_prepared on the handles, which are destroyed as soon as it returns."""
         L = _bind_entropy()
         self.device = torch.device(device)
         self.n = len(files)
         self._keep = [np.frombuffer(f, np.uint8) for f in files]
-        ptrs = (C.c_void_p * self.n)(*[k.ctypes.data for k in self._keep])
-        lens = (C.c_size_t * self.n)(*[len(f) for f in files])
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _native.check(L.ifhip_jpeg_entropy_create(C.byref(self._h), ptrs, lens, self.n))
+            if not prepared:
+                ptrs = (C.c_void_p * self.n)(*[k.ctypes.data for k in self._keep])
+                lens = (C.c_size_t * self.n)(*[len(f) for f in files])
+                _native.check(L.ifhip_jpeg_entropy_create(C.byref(self._h), ptrs, lens, self.n))
+            else:
+                handles = []
+                try:
+                    for k in self._keep:
+                        h = C.c_void_p()
+                        _native.check(L.ifhip_jpeg_entropy_prepare(C.byref(h), k.ctypes.data, len(k)))
+                        handles.append(h)
+                        if upload_stream is not None:
+                            _native.check(L.ifhip_jpeg_prepared_upload(h, C.c_void_p(upload_stream.cuda_stream)))
+                    arr = (C.c_void_p * self.n)(*[h.value for h in handles])
+                    _native.check(L.ifhip_jpeg_entropy_create_prepared(C.byref(self._h), arr, self.n))
+                finally:
+                    for h in handles:
+                        L.ifhip_jpeg_prepared_destroy(h)
         w, h, n, ns, ng = C.c_uint32(), C.c_uint32(), C.c_int(), C.c_uint32(), C.c_uint32()
         hs, vs = np.zeros(3, np.uint8), np.zeros(3, np.uint8)
         bw, bh = np.zeros(3, np.uint32), np.zeros(3, np.uint32)

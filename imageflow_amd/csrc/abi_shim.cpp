@@ -639,14 +639,16 @@ std::shared_ptr<DecodedBatch> decode_files(const std::vector<DecodeRequest*>& re
         hip_check(job_malloc(reinterpret_cast<void**>(&b->coef[k]), std::max<size_t>(1, b->per_image[k] * n_cap) * 2u), "hipMalloc(coefficients)");
     }
     const double ms_alloc = ms_since(t1);
+    // the quantisation tables ride along: queued before the decode, whose own wait for the stream covers them
+    std::vector<uint16_t> qt(static_cast<size_t>(n) * 192u);
+    check(ifhip_jpeg_entropy_quant_tables(ent, qt.data()));
+    hip_check(job_malloc(reinterpret_cast<void**>(&b->d_qt), qt.size() * 2u), "hipMalloc(qt)");
+    struct PinGuard { void* p = nullptr; ~PinGuard() { if (p) { quiesce(); (void)ifhip::cached_host_free(p); } } } qt_pin;
+    hip_check(static_cast<hipError_t>(ifhip::stage_to_device(b->d_qt, qt.data(), qt.size() * 2u, &qt_pin.p)), "upload(qt)");
     const auto t2 = std::chrono::steady_clock::now();
     uint32_t rounds = 0;
     check(ifhip_jpeg_entropy_decode_device(ent, b->coef[0], b->coef[1], b->coef[2], &rounds, t_job_stream));
     const double ms_decode = ms_since(t2);
-    std::vector<uint16_t> qt(static_cast<size_t>(n) * 192u);
-    check(ifhip_jpeg_entropy_quant_tables(ent, qt.data()));
-    hip_check(job_malloc(reinterpret_cast<void**>(&b->d_qt), qt.size() * 2u), "hipMalloc(qt)");
-    hip_check(static_cast<hipError_t>(ifhip::copy_to_device(b->d_qt, qt.data(), qt.size() * 2u)), "upload(qt)");
     if (trace)
         std::fprintf(stderr, "decode_batch files %u sub_sequences %u rounds %u ms: create %.3f alloc %.3f decode %.3f total %.3f\n", n, nsub, rounds, ms_create, ms_alloc,
                      ms_decode, ms_since(t0));
@@ -993,6 +995,7 @@ struct Job {
         } else {
             check(prc);
             check(ifhip_jpeg_prepared_info(rq.prepared, &rq.w, &rq.h, &rq.ncomp, rq.hs, rq.vs));
+            check(ifhip_jpeg_prepared_upload(rq.prepared, t_job_stream));      // the file's PCIe transfer starts now, not when a batch leader gets to it
             poll_cancel();                                           // the decoder's cancellation point (mozjpeg_decoder.rs:346-362 loop)
             coalescer_for_device().submit(rq);
             if (rq.retry_alone) {                                    // the shared call failed (somebody's file, maybe this one): alone, errors are this job's

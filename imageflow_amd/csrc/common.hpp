@@ -29,14 +29,11 @@ struct QuiescedScope { QuiescedScope() { quiesced_enter(); } ~QuiescedScope() { 
 // The stream a thread's create paths upload / clear on (ifhip_set_thread_stream; default: the null stream), and copies on it
 // that are complete on return.
 void* thread_stream();
-// Every wait of a job for its stream goes through here.  Default: hipStreamSynchronize.  Development switch `wait` = poll:
-// hipStreamQuery in a short spin, then with the CPU yielded between polls, then with short sleeps -- no HSA interrupt in the
-// path.  Round 5 looked for the cause of the jobs bench's run-to-run modes (profiles/r5_abi_jobs_*.txt: on some boxes identical
-// runs make 2 700, 1 150 or -- GPU idle -- 7 to 700 jobs/s, whatever the thread count; with HSA_ENABLE_INTERRUPT=0 always
-// 1 150) and measured this form equal to the runtime's wait on the boxes it ran on; it stays as the tool to repeat that
-// measurement on a box that shows the modes.
+// Every wait of a job for its stream goes through here: load-aware -- the first few waiters (a quarter of the CPUs the process
+// may use) spin in the runtime, the rest query the stream and sleep in between (devmem.cpp).
 int wait_stream(void* hip_stream);
 int copy_to_device(void* dst, const void* src, size_t bytes);
+int stage_to_device(void* dst, const void* src, size_t bytes, void** pin_out);   // queued, NOT waited for; *pin_out: cached_host_free after the stream's next wait
 int copy_to_host(void* dst, const void* src, size_t bytes);
 int zero_device(void* dst, size_t bytes);
 int require_gfx950(int* device_out);                  // IFHIP_OK and the current device, or GpuUnavailable (asked of the driver once)

@@ -391,6 +391,19 @@ int copy_to_device(void* dst, const void* src, size_t bytes) {
     (void)cached_host_free(pin);
     return static_cast<int>(e != hipSuccess ? e : w);
 }
+// The same upload WITHOUT the wait: queued on the thread's stream from a pinned block that is the caller's to
+// cached_host_free once that stream has been waited for (the caller has a wait coming anyway and folds this copy into it).
+int stage_to_device(void* dst, const void* src, size_t bytes, void** pin_out) {
+    *pin_out = nullptr;
+    if (!bytes) return 0;
+    void* pin = nullptr;
+    if (bytes > kStageLimit || cached_host_malloc(&pin, bytes) != 0) return copy_to_device(dst, src, bytes);
+    std::memcpy(pin, src, bytes);
+    const hipError_t e = hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, t_stream);
+    if (e != hipSuccess) { (void)static_cast<hipError_t>(wait_stream(t_stream)); (void)cached_host_free(pin); return static_cast<int>(e); }
+    *pin_out = pin;
+    return 0;
+}
 int copy_to_host(void* dst, const void* src, size_t bytes) {
     if (!bytes) return 0;
     void* pin = nullptr;

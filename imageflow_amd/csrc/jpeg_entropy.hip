@@ -1272,7 +1272,23 @@ struct ifhip_jpeg_prepared {
     FastTabs ftabs, ptabs, ctabs;
     SearchTab stabs[6];
     uint32_t pool_limit = kPoolEntries;
-    ~ifhip_jpeg_prepared() { if (words) (void)cached_host_free(words); }
+    // ifhip_jpeg_prepared_upload: the words on the device already, queued on the owner's stream; `uploaded` marks the copy's end
+    // (the event stays with a recycled handle, the block does not)
+    uint32_t* d_words = nullptr;
+    hipEvent_t uploaded = nullptr;
+    int d_device = -1, event_device = -1;
+    void drop_device_copy() {                        // nothing may still write the block when it goes back to the cache
+        if (!d_words) return;
+        if (uploaded && hipEventQuery(uploaded) != hipSuccess) { (void)hipGetLastError(); (void)hipEventSynchronize(uploaded); }
+        (void)hipGetLastError();
+        (void)DEV_FREE(d_words);
+        d_words = nullptr; d_device = -1;
+    }
+    ~ifhip_jpeg_prepared() {
+        if (words) (void)cached_host_free(words);
+        drop_device_copy();
+        if (uploaded) (void)hipEventDestroy(uploaded);
+    }
 };
 
 // Prepared handles are recycled: 50 KB of tables each, one per job through the libimageflow ABI.
@@ -1289,6 +1305,7 @@ ifhip_jpeg_prepared* take_prepared() {
 }
 void give_prepared(ifhip_jpeg_prepared* p) {
     if (!p) return;
+    p->drop_device_copy();                                               // (before the pinned source goes: the copy reads it)
     if (p->words) { (void)cached_host_free(p->words); p->words = nullptr; }
     p->n_words = 0; p->n_sub = 0;
     p->seg_mcu0.clear(); p->seg_mcus.clear(); p->seg_nsub.clear(); p->seg_first_word.clear(); p->seg_bits.clear();
@@ -1439,10 +1456,17 @@ static int create_prepared_impl(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* c
     } drain{static_cast<hipStream_t>(thread_stream())};
     {   // every file's words straight from its pinned buffer to its place: n asynchronous copies, one wait (below, with the tables')
         hipStream_t st = drain.st;
-        for (uint32_t img = 0; img < n_images; ++img)
-            if (prep[img]->n_words)
-                HIP_TRY(hipMemcpyAsync(d_words + static_cast<size_t>(first_sub_of[img]) * kSubWords, prep[img]->words,
-                                       prep[img]->n_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        for (uint32_t img = 0; img < n_images; ++img) {
+            const ifhip_jpeg_prepared& R = *prep[img];
+            if (!R.n_words) continue;
+            uint32_t* const dst = d_words + static_cast<size_t>(first_sub_of[img]) * kSubWords;
+            if (R.d_words && R.d_device == e->device) {              // its owner queued the upload already (ifhip_jpeg_prepared_upload): behind that copy, device to device
+                HIP_TRY(hipStreamWaitEvent(st, R.uploaded, 0));
+                HIP_TRY(hipMemcpyAsync(dst, R.d_words, R.n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            } else {
+                HIP_TRY(hipMemcpyAsync(dst, R.words, R.n_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            }
+        }
         HIP_TRY(hipMemsetAsync(d_words + (n_words - 64u), 0, 64u * sizeof(uint32_t), st));
     }
     uint8_t* d_tables = nullptr;
@@ -1528,6 +1552,27 @@ int ifhip_jpeg_entropy_prepare(ifhip_jpeg_prepared** out, const uint8_t* jpeg, s
     catch (const std::exception& ex) { return fail(IFHIP_INVALID_STATE, "InvalidState: %s", ex.what()); }
 }
 void ifhip_jpeg_prepared_destroy(ifhip_jpeg_prepared* p) { give_prepared(p); }
+int ifhip_jpeg_prepared_upload(ifhip_jpeg_prepared* p, void* hip_stream) {
+    if (!p) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null handle");
+    if (p->d_words || !p->n_words) return IFHIP_OK;
+    int dev = -1;
+    if (int arc = require_gfx950(&dev)) return arc;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (p->uploaded && p->event_device != dev) { (void)hipEventDestroy(p->uploaded); p->uploaded = nullptr; }   // (a recycled handle, last used on another device)
+    if (!p->uploaded) { HIP_TRY(hipEventCreateWithFlags(&p->uploaded, hipEventDisableTiming)); p->event_device = dev; }
+    HIP_TRY(DEV_MALLOC(&p->d_words, p->n_words * sizeof(uint32_t)));
+    p->d_device = dev;
+    hipError_t er = hipMemcpyAsync(p->d_words, p->words, p->n_words * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (er == hipSuccess) er = hipEventRecord(p->uploaded, st);
+    if (er != hipSuccess) {
+        (void)hipGetLastError();
+        (void)static_cast<hipError_t>(ifhip::wait_stream(st));        // (whatever was queued is over before the block goes back)
+        (void)DEV_FREE(p->d_words);
+        p->d_words = nullptr; p->d_device = -1;
+        return fail(IFHIP_GPU_ERROR, "GpuError: %s while queueing the scan upload", hipGetErrorString(er));
+    }
+    return IFHIP_OK;
+}
 int ifhip_jpeg_prepared_info(const ifhip_jpeg_prepared* p, uint32_t* width, uint32_t* height, int* n_components, uint8_t* h_samp3, uint8_t* v_samp3) {
     if (!p) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null handle");
     if (width) *width = p->P.width;

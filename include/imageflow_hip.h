@@ -290,6 +290,12 @@ IFHIP_API void ifhip_jpeg_entropy_destroy(ifhip_jpeg_entropy* e);
 typedef struct ifhip_jpeg_prepared ifhip_jpeg_prepared;
 IFHIP_API int ifhip_jpeg_entropy_prepare(ifhip_jpeg_prepared** out, const uint8_t* jpeg, size_t len);
 IFHIP_API void ifhip_jpeg_prepared_destroy(ifhip_jpeg_prepared* p);
+/* Optional, on a thread with a HIP device: queue the prepared scan's copy to the device on `hip_stream` NOW (asynchronous; the
+ * call does not wait).  ifhip_jpeg_entropy_create_prepared then takes the words device to device behind that copy instead
+ * of uploading them itself: with one job per thread the PCIe transfer of a job's file overlaps its wait for the next
+ * coalesced batch instead of lengthening that batch.  A handle uploaded on one device and handed to a batch on another is
+ * uploaded again from its pinned copy.  Destroying the handle waits for the queued copy if it is still running. */
+IFHIP_API int ifhip_jpeg_prepared_upload(ifhip_jpeg_prepared* p, void* hip_stream);
 IFHIP_API int ifhip_jpeg_prepared_info(const ifhip_jpeg_prepared* p, uint32_t* width, uint32_t* height, int* n_components,
                                        uint8_t* h_samp3, uint8_t* v_samp3);
 IFHIP_API int ifhip_jpeg_entropy_create_prepared(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* const* prepared, uint32_t n_images);

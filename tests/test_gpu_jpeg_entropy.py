@@ -49,6 +49,35 @@ def test_batches_equal_the_serial_decoder(golden_dir, fixture):
     assert total in (36, 108, 62)
 
 
+def test_prepared_files_with_and_without_the_early_upload(golden_dir):
+    """The per-file form of the batch (ifhip_jpeg_entropy_prepare -> [ifhip_jpeg_prepared_upload on the owner's stream] ->
+    ifhip_jpeg_entropy_create_prepared), which the libimageflow ABI's decode coalescer uses: the same coefficients as the
+    one-call form, whether the scan went up early (device to device into the batch, behind the owner's copy) or not."""
+    side = torch.cuda.Stream(DEV)
+    checked = 0
+    for key, items in list(groups(golden_dir, "jpeg_entropy_cases.npz").items())[:8]:
+        files = [d for _, d in items]
+        want = D.JpegEntropyBatch(files, DEV).read_coefficients()
+        for stream in (None, side, torch.cuda.current_stream(DEV)):
+            ent = D.JpegEntropyBatch(files, DEV, prepared=True, upload_stream=stream)
+            got = ent.read_coefficients()
+            for c in range(ent.ncomp):
+                assert torch.equal(got[c], want[c]), (key, c, stream)
+            checked += 1
+    # a handle whose upload is still queued when it is destroyed: the destroy waits, nothing is written into a recycled block
+    big = [d for _, d in max(groups(golden_dir, "jpeg_entropy_cases.npz").values(), key=lambda it: len(it[0][1]))]
+    L = D._bind_entropy()
+    import ctypes as C
+    for _ in range(20):
+        h = C.c_void_p()
+        keep = np.frombuffer(big[0], np.uint8)
+        assert L.ifhip_jpeg_entropy_prepare(C.byref(h), keep.ctypes.data, len(keep)) == 0
+        assert L.ifhip_jpeg_prepared_upload(h, C.c_void_p(side.cuda_stream)) == 0
+        L.ifhip_jpeg_prepared_destroy(h)
+    torch.cuda.synchronize()
+    assert checked == 24
+
+
 def test_files_to_bgra_on_device(golden_dir):
     for key, items in list(groups(golden_dir, "jpeg_entropy_cases.npz").items())[:6]:
         files = [d for _, d in items]
