@@ -86,7 +86,9 @@ IFHIP_API void ifhip_set_thread_stream(void* hip_stream);
  *   ifhip_cache_trim        give listed blocks back to the driver until at most the given bytes stay (0, 0: everything) --
  *                           what a torch user calls next to torch.cuda.empty_cache() or after an out-of-memory error;
  *   ifhip_cache_stats       hits / driver calls / bytes cached and handed out, for capacity planning and the jobs bench.
- * Blocks handed out are never touched.  Thread safe. */
+ * Blocks handed out are never touched.  Scratch of the device calls is released BEHIND the launch stream (an event marks the
+ * point; no host wait): such blocks count as cached from that moment, are handed out again at once for work on the same
+ * stream, to anybody once the event has completed, and a trim waits for them.  Thread safe. */
 typedef struct ifhip_cache_stats_t {
     uint64_t device_hits, device_driver_allocs, device_driver_frees, device_oom_flushes, device_wide_syncs;
     uint64_t device_bytes_cached, device_bytes_live, device_blocks_live, device_limit_bytes;
