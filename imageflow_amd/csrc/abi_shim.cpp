@@ -662,8 +662,9 @@ struct DecodeCoalescer {
     int decoding = 0;                                               // batches whose decode is on the device right now
     // Wake-ups are targeted: a request sleeps on its OWN condition variable and is woken when its batch is done or when it
     // is its turn to lead; arrivals wake only a leader that is counting them.  (One shared condition variable with
-    // notify_all woke every waiting job on every arrival and every hand-over -- with more than ~20 jobs in the system the
-    // job rate fell five-fold, profiles/r5_abi_jobs_inflight_and_slots_sweep.txt.)
+    // notify_all woke every waiting job on every arrival and every hand-over.  It was NOT what made the job rate fall above
+    // 20 admitted jobs -- profiles/r5_abi_jobs_cliff_1_targeted_wakeups_no_effect.txt; that was the batch size, kMaxCoalesce --
+    // but forty sleepers woken for one hand-over is work nobody needs.)
     void wake_next_leader() {                                       // (mu held) the oldest request nobody took: it may lead now
         if (!leader_active && !queue.empty()) queue.front()->cv.notify_one();
     }
