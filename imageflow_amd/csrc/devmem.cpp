@@ -318,9 +318,9 @@ int require_gfx950(int* device_out) {
 // The library's one host-side wait.  hipStreamSynchronize SPINS in user space until the stream drains (the runtime's default,
 // hipDeviceScheduleAuto; an event created with hipEventBlockingSync spins as well, ROCr polls ~200 us before it sleeps --
 // both measured, profiles/r5_abi_jobs_host_cpu.txt): one busy host core per waiting thread.  That is the lowest latency while
-// cores are idle, and a disaster when they are not: a server with 48 jobs in flight in a container with a 16-CPU quota spent
-// 15 of its 16 CPUs spinning, the cgroup was throttled, and the job rate fell from 6 500 to 550 jobs/s.  So the wait is
-// load-aware: the first few waiters (a quarter of the CPUs this process may use) spin in the runtime, the rest query the
+// cores are idle, and a waste when they are not: with 40 jobs in flight in a container with a 16-CPU quota the runtime's wait
+// for everybody keeps all 16 CPUs busy and the cgroup throttled, for 11 % fewer jobs per second than this policy makes with 6
+// (profiles/r5_abi_jobs_wait_policy.txt).  So the wait is load-aware: the first few waiters (a quarter of the CPUs this process may use) spin in the runtime, the rest query the
 // stream and sleep in between.
 //   switch `wait`: "runtime" = always hipStreamSynchronize, "sleep" = always query + sleep; default = by load
 //   switch `wait_spinners`: how many threads may spin at a time;  `wait_sleep_us`: the sleep between two queries (default 20)
