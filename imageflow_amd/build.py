@@ -23,12 +23,10 @@ FUSED = "resample_fused.hip"          # compiled once per ring size K (-DIFHIP_F
 # its step loop is unrolled by hand-over depth (up to 16 rows): past clang's default size limit for `#pragma unroll`
 FUSED_FLAGS = ["-mllvm", "-pragma-unroll-threshold=131072"]
 FUSED_KS = range(1, 9)
-WS = "resample_ws.hip"                # the wave-specialised form for moderate ratios, likewise per ring size
-WS_KS = range(1, 6)
 
 
 def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hip")) and f not in (FUSED, WS))
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hip")) and f != FUSED)
 
 
 def compile_jobs():
@@ -42,10 +40,6 @@ def compile_jobs():
         obj = os.path.join(HERE, "lib", f"resample_fused_k{k}.o")
         jobs.append(([HIPCC, "-x", "hip", "--offload-arch=gfx950"] + COMMON + FUSED_FLAGS + defs + [f"-DIFHIP_FUSED_K={k}", "-c",
                      os.path.join(CSRC, FUSED), "-o", obj], obj))
-    for k in WS_KS:
-        obj = os.path.join(HERE, "lib", f"resample_ws_k{k}.o")
-        jobs.append(([HIPCC, "-x", "hip", "--offload-arch=gfx950"] + COMMON + FUSED_FLAGS + defs + [f"-DIFHIP_FUSED_K={k}", "-c",
-                     os.path.join(CSRC, WS), "-o", obj], obj))
     return jobs
 
 

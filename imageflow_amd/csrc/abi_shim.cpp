@@ -342,8 +342,7 @@ struct StreamLease {
         if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
         {
             std::unique_lock<std::mutex> lk(g_stream_mu);
-            int slots = kJobSlots;
-            if (const char* e = ifhip::debug_switch("job_slots")) slots = std::max(1, std::atoi(e));
+            constexpr int slots = kJobSlots;
             DeviceQueues& q = g_queues[dev];              // (map nodes do not move: the reference survives the wait)
             while (q.slots_taken >= slots) q.slot_cv.wait(lk);
             ++q.slots_taken;
@@ -555,12 +554,8 @@ struct NodePerf { const char* name; uint64_t wall_ns; float gpu_ms; hipEvent_t e
 struct TimingEvents {
     std::mutex mu;
     std::map<int, std::vector<hipEvent_t>> spare;
-    // development switch `perf_events`: "fresh" = create / destroy per node (no reuse), "off" = none (gpu_microseconds 0)
-    static int mode() { const char* m = ifhip::debug_switch("perf_events"); return !m ? 0 : (std::strcmp(m, "fresh") == 0 ? 1 : (std::strcmp(m, "off") == 0 ? 2 : 0)); }
     hipEvent_t take(int device) {
-        const int md = mode();
-        if (md == 2) return nullptr;
-        if (md == 0) {
+        {
             std::lock_guard<std::mutex> lk(mu);
             auto& v = spare[device];
             if (!v.empty()) { hipEvent_t e = v.back(); v.pop_back(); return e; }
@@ -571,7 +566,6 @@ struct TimingEvents {
     }
     void give(int device, hipEvent_t e) {
         if (!e) return;
-        if (mode() == 1) { (void)hipEventDestroy(e); return; }
         std::lock_guard<std::mutex> lk(mu);
         auto& v = spare[device];
         if (v.size() < 256) v.push_back(e); else (void)hipEventDestroy(e);
@@ -619,39 +613,28 @@ struct DecodeRequest {
 // one batch on the calling thread's job stream; throws FlowErr
 std::shared_ptr<DecodedBatch> decode_files(const std::vector<DecodeRequest*>& reqs) {
     const uint32_t n = static_cast<uint32_t>(reqs.size());
-    const bool trace = ifhip::debug_switch("trace_decode_batches") != nullptr;      // one stderr line per batch: where its time went
-    const auto t0 = std::chrono::steady_clock::now();
-    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     std::vector<ifhip_jpeg_prepared*> files(n);
     for (uint32_t i = 0; i < n; ++i) files[i] = reqs[i]->prepared;
     ifhip_jpeg_entropy* ent = nullptr;
     check(ifhip_jpeg_entropy_create_prepared(&ent, files.data(), n));
     struct EntGuard { ifhip_jpeg_entropy* e; ~EntGuard() { quiesce(); ifhip_jpeg_entropy_destroy(e); } } eg{ent};
-    const double ms_create = ms_since(t0);
     auto b = std::make_shared<DecodedBatch>();
     uint32_t nsub = 0, nseg = 0;
     check(ifhip_jpeg_entropy_info(ent, &b->w, &b->h, &b->ncomp, b->hs, b->vs, b->bw, b->bh, &nsub, &nseg));
     uint32_t n_cap = 1;                                          // (batch sizes as powers of two: six size classes in the cache, not thirty-two)
     while (n_cap < n) n_cap *= 2;
-    const auto t1 = std::chrono::steady_clock::now();
     for (int k = 0; k < 3; ++k) {
         b->per_image[k] = static_cast<size_t>(b->bw[k]) * b->bh[k] * 64u;
         hip_check(job_malloc(reinterpret_cast<void**>(&b->coef[k]), std::max<size_t>(1, b->per_image[k] * n_cap) * 2u), "hipMalloc(coefficients)");
     }
-    const double ms_alloc = ms_since(t1);
     // the quantisation tables ride along: queued before the decode, whose own wait for the stream covers them
     std::vector<uint16_t> qt(static_cast<size_t>(n) * 192u);
     check(ifhip_jpeg_entropy_quant_tables(ent, qt.data()));
     hip_check(job_malloc(reinterpret_cast<void**>(&b->d_qt), qt.size() * 2u), "hipMalloc(qt)");
     struct PinGuard { void* p = nullptr; ~PinGuard() { if (p) { quiesce(); (void)ifhip::cached_host_free(p); } } } qt_pin;
     hip_check(static_cast<hipError_t>(ifhip::stage_to_device(b->d_qt, qt.data(), qt.size() * 2u, &qt_pin.p)), "upload(qt)");
-    const auto t2 = std::chrono::steady_clock::now();
     uint32_t rounds = 0;
     check(ifhip_jpeg_entropy_decode_device(ent, b->coef[0], b->coef[1], b->coef[2], &rounds, t_job_stream));
-    const double ms_decode = ms_since(t2);
-    if (trace)
-        std::fprintf(stderr, "decode_batch files %u sub_sequences %u rounds %u ms: create %.3f alloc %.3f decode %.3f total %.3f\n", n, nsub, rounds, ms_create, ms_alloc,
-                     ms_decode, ms_since(t0));
     return b;
 }
 struct DecodeCoalescer {
@@ -679,8 +662,7 @@ struct DecodeCoalescer {
             // half millisecond for 1 file or 16 (three latency-bound launches), so a batch of 8 is an eighth of
             // the device time per job -- before, a new batch formed as soon as the last one had been gathered, 1.85 files per
             // batch at 2 300 jobs/s (round 5, profiles/r5_abi_trace_cfg4_8_threads.txt).
-            int max_decoding = 2;
-            if (const char* e = ifhip::debug_switch("coalesce_decodes_in_flight")) max_decoding = std::max(1, std::atoi(e));
+            constexpr int max_decoding = 2;
             while (!r.done && (r.taken || leader_active || decoding >= max_decoding || queue.front() != &r)) r.cv.wait(lk);
             if (r.done) return;
             leader_active = true;                                    // the oldest untaken request leads, for one batch
@@ -695,20 +677,25 @@ struct DecodeCoalescer {
                 while (queue.size() < wait_for && leader_cv.wait_until(lk, until) != std::cv_status::timeout) {}
             }
             // this thread's own request first, then whoever shares its geometry, in arrival order
-            size_t max_files = kMaxCoalesce;
-            if (const char* e = ifhip::debug_switch("coalesce_max")) max_files = static_cast<size_t>(std::max(1L, std::atol(e)));
+            // Whatever leaves this block early (a bad_alloc while the lists are built) hands the leadership on: a leader
+            // flag left set would park every later job of the device on its own condition variable for good.
+            struct Leading {
+                DecodeCoalescer& c; bool armed = true;
+                ~Leading() { if (armed) { c.leader_active = false; c.wake_next_leader(); } }      // (mu held on every path that gets here armed)
+            } leading{*this};
             std::vector<DecodeRequest*> mine{&r}, rest;
             for (DecodeRequest* q : queue)
-                if (q != &r) (mine.size() < max_files && q->same_geometry(r) ? mine : rest).push_back(q);
+                if (q != &r) (mine.size() < kMaxCoalesce && q->same_geometry(r) ? mine : rest).push_back(q);
             queue.swap(rest);
             for (DecodeRequest* q : mine) q->taken = true;
+            leading.armed = false;
             leader_active = false;                                   // leading = gathering: the next batch forms while this one decodes
             ++decoding;
             if (decoding < max_decoding) wake_next_leader();
             lk.unlock();
             std::shared_ptr<DecodedBatch> b;
             bool failed = false;
-            try { b = decode_files(mine); } catch (const FlowErr&) { failed = true; } catch (const std::exception&) { failed = true; }
+            try { b = decode_files(mine); } catch (...) { failed = true; }      // (anything at all: the batch's members retry alone and report their own error)
             lk.lock();
             --decoding;
             for (size_t i = 0; i < mine.size(); ++i) {
@@ -1217,8 +1204,10 @@ struct Job {
             else if (k == "quality" || k == "jpeg.quality") {
                 char* end = nullptr;
                 const long q = std::strtol(v.c_str(), &end, 10);
-                if (end == v.c_str() || *end) raise(kArgumentInvalid, "InvalidNodeParams: querystring %s=%s is not an integer", k.c_str(), v.c_str());
-                (k == "quality" ? quality : jpeg_quality) = static_cast<int>(std::max(0l, std::min(100l, q)));
+                // a value that is no integer is ignored with a warning by the reference (ir4/parsing.rs parse_i32): the encoder's
+                // default quality then applies -- the key still says "a JPEG comes out"
+                if (end == v.c_str() || *end) jpeg_out = true;
+                else (k == "quality" ? quality : jpeg_quality) = static_cast<int>(std::max(0l, std::min(100l, q)));
             }
             else if (k == "format") {
                 for (char& ch : v) ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
@@ -1262,9 +1251,11 @@ struct Job {
         if (enc && enc->t == JVal::Num) {
             // The reference keeps the source's format (a JPEG stays a JPEG, ir4/encoder.rs:30-37 OutputFormat::Keep) and hands
             // `jpeg.quality`, else `quality`, to its JPEG encoder (encoder.rs:74; 90 when neither is given, codecs/auto.rs).  Here a
-            // querystring that names the format or a quality gets the classic JPEG writer with exactly that quality (the mozjpeg
-            // preset's trellis / scan search is not built: DESIGN "Encode"); one that names neither keeps this shim's labelled
-            // extension, the raw BGRA container -- no key is accepted and then dropped.
+            // querystring that names the format or a quality gets the classic JPEG writer with exactly that quality -- the
+            // LIBJPEG-TURBO STYLE file (what the reference writes under jpeg.turbo=true); its default mozjpeg-style encoder
+            // (trellis / scan search) is not built, so bytes and sizes differ from the reference's default for the same string
+            // (README "Known differences", DESIGN "Encode").  One that names neither keeps this shim's labelled extension, the raw
+            // BGRA container -- no key is accepted and then dropped.
             const int q = jpeg_quality >= 0 ? jpeg_quality : quality;
             if (jpeg_out || q >= 0) {
                 JVal qv; qv.t = JVal::Num; qv.n = q >= 0 ? q : 90;

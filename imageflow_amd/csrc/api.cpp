@@ -25,7 +25,6 @@ hipError_t launch_fused(const ResampleArgs& a, int slots, bool alpha, bool per_p
 hipError_t launch_generic(const ResampleArgs& a, bool alpha, float4* scratch, uint32_t img0, uint32_t n_img,
                           hipStream_t st);
 hipError_t launch_banded(const ResampleArgs& a, bool alpha, const BandedArgs& b, uint32_t grid_x, size_t lds, hipStream_t st);
-hipError_t launch_ws(const ResampleArgs& a, int slots, uint32_t grid, uint32_t block, size_t lds, hipStream_t st);
 hipError_t launch_read_probe(const uint8_t* d, size_t bytes, uint32_t* sink, hipStream_t st);
 hipError_t launch_mix_probe(const uint8_t* d, uint8_t* out, size_t bytes, uint32_t every, uint32_t* sink, hipStream_t st);
 hipError_t launch_apply_matte(uint8_t* d_bgra, size_t image_bytes, uint32_t n_images, uint32_t w, uint32_t h,
@@ -153,7 +152,6 @@ struct ifhip_resample_plan {
         uint32_t max_quads = 0;
         bool ok = false;
     } sets[2];                       // [in_alpha_meaningful]
-    StripSet ws_set;                 // strips of the wave-specialised kernel (resample_ws.hip): 8 V waves x 64 lanes x 4 columns
     // lazily built, guarded by mu
     mutable std::mutex mu;
     mutable std::map<uint64_t, ScheduleOnDevice> schedules;     // key: bands | group << 32 | ahead << 40
@@ -161,7 +159,7 @@ struct ifhip_resample_plan {
     ~ifhip_resample_plan() {
         for (void* p : {(void*)d_v_left, (void*)d_v_count, (void*)d_v_off, (void*)d_h_left, (void*)d_h_count,
                         (void*)d_h_off, (void*)d_v_w, (void*)d_h_w, (void*)d_h_wu, (void*)d_h_meta, (void*)d_h_wg, (void*)d_h_meta2, (void*)d_h_wg2, (void*)d_h_meta3, (void*)sets[0].d_strips,
-                        (void*)sets[1].d_strips, (void*)ws_set.d_strips})
+                        (void*)sets[1].d_strips})
             if (p) (void)DEV_FREE(p);
         for (auto& kv : schedules) {
             if (kv.second.steps) (void)DEV_FREE(kv.second.steps);
@@ -181,17 +179,12 @@ size_t fused_lds_bytes(uint32_t n_u, uint32_t nquads, int channels, uint32_t wu_
 // -10 %, cfg3 -27 %); the per-channel form is kept for strips with less than one wave of outputs, where it is the only
 // way to spread the (long) chains over more lanes.
 bool use_per_pixel(uint32_t max_nu, int channels, uint32_t block) {
-    bool per_pixel = max_nu >= 64u || static_cast<uint64_t>(max_nu) * static_cast<uint32_t>(channels) > block;
-    if (const char* e = debug_switch("perpixel")) per_pixel = std::atoi(e) != 0;      // experiment switch
-    return per_pixel;
+    return max_nu >= 64u || static_cast<uint64_t>(max_nu) * static_cast<uint32_t>(channels) > block;
 }
 uint32_t block_for(uint32_t max_quads, int px) {          // lanes of a frame slot: one per px source pixels, whole waves
     return std::max<uint32_t>(64u, (max_quads * static_cast<uint32_t>(4 / px) + 63u) & ~63u);
 }
-size_t lds_limit() {                                   // experiment switch: cap the per-workgroup LDS (co-residency)
-    if (const char* e = debug_switch("lds_limit")) { const long v = std::atol(e); if (v >= 16384 && v <= 160 * 1024) return static_cast<size_t>(v); }
-    return kLdsLimit;
-}
+bool trace_launch() { return debug_switch("trace_launch") != nullptr; }      // one stderr line per launch: its geometry (tools/)
 constexpr uint32_t kMinLutCopiesLog2 = 4;      // never fewer than 16 copies of the sRGB->float table (2-way conflicts)
 
 // Split the output columns into strips whose staged source span fits one workgroup (max_lanes lanes x 4 px)
@@ -221,38 +214,10 @@ bool plan_strips(const AxisWeights& wh, uint32_t max_lanes, int px, int channels
         if (ok) {
             const bool pp = use_per_pixel(mu, channels, block_for(mq, px));
             for (const Strip& t : s)
-                if (fused_lds_bytes(t.u1 - t.u0, t.nquads, channels, 0, false, false, kMinLutCopiesLog2, pp) > lds_limit()) ok = false;
+                if (fused_lds_bytes(t.u1 - t.u0, t.nquads, channels, 0, false, false, kMinLutCopiesLog2, pp) > kLdsLimit) ok = false;
         }
         if (ok) { *out = std::move(s); *max_quads = mq; return true; }
         if (n > 4096) break;
-    }
-    return false;
-}
-
-// The same for the wave-specialised kernel: the fewest equal strips whose staged span fits `max_quads` V lanes (the LDS is
-// budgeted per launch: the row ring takes what the tables leave).
-bool plan_ws_strips(const AxisWeights& wh, uint32_t max_quads, std::vector<Strip>* out, uint32_t* max_quads_out) {
-    for (uint32_t n = 1; n <= wh.n_out && n <= 64u; ++n) {
-        std::vector<Strip> s;
-        bool ok = true;
-        uint32_t mq = 0;
-        for (uint32_t i = 0; i < n && ok; ++i) {
-            Strip t;
-            t.u0 = static_cast<uint32_t>(static_cast<uint64_t>(wh.n_out) * i / n);
-            t.u1 = static_cast<uint32_t>(static_cast<uint64_t>(wh.n_out) * (i + 1) / n);
-            if (t.u1 <= t.u0) { ok = false; break; }
-            uint32_t lo = wh.left[t.u0], hi = 0;
-            for (uint32_t u = t.u0; u < t.u1; ++u) {
-                lo = std::min(lo, wh.left[u]);
-                hi = std::max(hi, wh.left[u] + wh.count[u]);
-            }
-            t.cx0 = lo & ~3u;
-            t.nquads = (hi - t.cx0 + 3u) / 4u;
-            if (t.nquads > max_quads || (t.u1 - t.u0) > kMaxStripOutputs) ok = false;
-            mq = std::max(mq, t.nquads);
-            s.push_back(t);
-        }
-        if (ok) { *out = std::move(s); *max_quads_out = mq; return true; }
     }
     return false;
 }
@@ -278,10 +243,6 @@ int get_schedule(const ifhip_resample_plan* p, uint32_t n_bands, int group, int 
 }
 
 uint32_t choose_bands(const ifhip_resample_plan* p, uint32_t n_images, size_t n_strips) {
-    if (const char* e = debug_switch("bands")) {
-        const int v = std::atoi(e);
-        if (v >= 1) return std::min<uint32_t>(static_cast<uint32_t>(v), p->out_h);
-    }
     // One workgroup occupies a CU (LDS), so a launch runs in ceil(workgroups / 256) rounds.  Cutting frames into bands
     // of output rows makes the rounds finer but every extra band re-reads its halo of source rows and stages the tables
     // again (a few microseconds per workgroup: `setup`, as a share of one frame's time on one CU); pick the band count with
@@ -359,13 +320,10 @@ bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_im
                 BandedArgs& b = bp->args;
                 b.rows_per_band = R; b.n_bands = (out_h + R - 1u) / R; b.src_rows_cap = ns;
                 uint32_t wgs = kBandedWorkgroups;
-                if (const char* e = debug_switch("banded_wgs")) wgs = static_cast<uint32_t>(std::max(1, std::atoi(e)));   // experiment / test switch
+                if (const char* e = debug_switch("banded_wgs")) wgs = static_cast<uint32_t>(std::max(1, std::atoi(e)));   // test hook: the frame loop of a workgroup
                 b.frame_step = std::max<uint32_t>(1u, std::min<uint32_t>(n_images, wgs / b.n_bands));
                 b.h_w_floats = static_cast<uint32_t>(p->wh.w.size());
-                // (bit 0, weights of short horizontal windows in registers: padded to 8 taps it costs more multiply-adds than
-                // it saves reads -- 3.76 against 3.65 ms on the 3x shape -- so it is an experiment switch)
-                const char* rt = debug_switch("banded_regtaps");
-                b.flags = ((rt && std::atoi(rt) != 0) ? 1u : 0u) | (ascending ? 2u : 0u) | (h_lds ? 4u : 0u);
+                b.flags = (ascending ? 2u : 0u) | (h_lds ? 4u : 0u);
                 bp->grid = b.n_bands * b.frame_step;
                 bp->lds = lds;
                 return true;
@@ -374,11 +332,8 @@ bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_im
     }
     return false;
 }
-// IFHIP_BANDED: 0 = never, 1 = instead of the generic pair wherever it fits, 2 = also for up-scales the fused kernel could take
-int banded_mode() {
-    if (const char* e = debug_switch("banded")) return std::atoi(e);
-    return 1;       // measured (MI355X): 3x up-scale 9.97 -> 3.65 ms; the 2x up-scale the fused kernel takes is faster there (2.93 vs 4.43)
-}
+// The banded kernel stands in for the generic pair wherever it fits (measured, MI355X: 3x up-scale 9.97 -> 3.65 ms), never for
+// the fused kernel (the 2x up-scale the fused kernel takes is faster there: 2.93 vs 4.43 ms).
 
 int validate_render(uint32_t in_w, uint32_t in_h, uint32_t in_stride, uint32_t cw, uint32_t ch, uint32_t c_stride,
                     uint32_t x, uint32_t y, uint32_t w, uint32_t h, int working_space, int compositing, uint32_t in_px_bytes = 4) {
@@ -394,80 +349,6 @@ int validate_render(uint32_t in_w, uint32_t in_h, uint32_t in_stride, uint32_t c
         return fail(IFHIP_METHOD_NOT_IMPLEMENTED, "MethodNotImplemented: working floatspace %d", working_space);
     if (compositing < IFHIP_REPLACE_SELF || compositing > IFHIP_BLEND_WITH_MATTE)
         return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: compositing mode %d", compositing);
-    return IFHIP_OK;
-}
-
-// The wave-specialised kernel (resample_ws.hip) where it applies: no alpha, the fast horizontal pass, rings up to 5, and an LDS
-// plan that holds the tables and a ring of at least two row slots per frame slot.  kNotFusable: not this launch (the caller
-// goes on to the one-role kernel).  `a` is the caller's argument block, completed here on a copy.
-int enqueue_ws(const ifhip_resample_plan* p, ResampleArgs a, uint32_t n_images, bool ycc, bool probe, hipStream_t st) {
-    const ifhip_resample_plan::StripSet& ss = p->ws_set;
-    if (!ss.ok) return kNotFusable;
-    // OFF unless asked for (`ws` = 1, tests and tools/ab_switches.py): measured slower than the one-role kernel on every BASELINE
-    // shape -- cfg3 level 0 2.47 ms against 2.14, level 1 3.56 against 2.72, level 2 1.95 against 1.93 (profiles/r5_ws_*.jsonl).
-    { const char* e = debug_switch("ws"); if (!e || std::atoi(e) == 0) return kNotFusable; }
-    // the strips were planned on the BGRA alignment rules; a planar source reads 4 samples per lane and plane
-    for (const Strip& s : ss.strips) {
-        if (ycc ? static_cast<uint64_t>(s.cx0) + 4u * s.nquads > a.in_stride
-                : static_cast<uint64_t>(s.cx0 + 4u * s.nquads) * 4u > a.in_stride) return kNotFusable;
-    }
-    const bool two = p->h_two_groups != 0 && !ycc;
-    const uint32_t fast_g = two ? p->h_two_groups : p->h_fast_groups;
-    const uint32_t wu_floats = two ? p->h_wg2_floats : p->h_wg_floats;
-    const bool l2s = a.linear != 0;                                  // the encode table is part of the form (no threshold search here)
-    const uint32_t T = block_for(ss.max_quads, 4), wpf = T / 64u;
-    uint32_t v_max = std::max(kWsMaxVWaves, wpf), total_waves = 16u;
-    if (const char* e = debug_switch("ws_v_waves")) v_max = std::max<uint32_t>(wpf, std::min<uint32_t>(14u, static_cast<uint32_t>(std::atoi(e))));
-    uint32_t max_nu = 0;
-    for (const Strip& s : ss.strips) max_nu = std::max(max_nu, s.u1 - s.u0);
-    auto lds_for = [&](uint32_t frames, uint32_t copies_log2, uint32_t ring) {
-        size_t worst = 0;
-        for (const Strip& s : ss.strips)
-            worst = std::max<size_t>(worst, ws_lds_layout(s.u1 - s.u0, s.nquads, wu_floats, l2s, copies_log2, frames, fast_g, ring).total);
-        return worst;
-    };
-    const size_t limit = lds_limit();
-    uint32_t frames = std::max<uint32_t>(1u, std::min<uint32_t>(v_max / wpf, n_images));
-    if (ss.strips.size() > 1) frames = 1;
-    while (frames > 1 && lds_for(frames, kMinLutCopiesLog2, 3) > limit) --frames;
-    uint32_t ring = 0, copies_log2 = kMinLutCopiesLog2;
-    for (uint32_t r = 4; r >= 2; --r)
-        if (lds_for(frames, kMinLutCopiesLog2, r) <= limit) { ring = r; break; }
-    if (!ring) return kNotFusable;
-    if (lds_for(frames, 5, ring) <= limit) copies_log2 = 5;
-    if (const char* e = debug_switch("ws_ring")) {
-        const uint32_t r = static_cast<uint32_t>(std::atoi(e));
-        if (r >= 1 && r <= 8 && lds_for(frames, copies_log2, r) <= limit) ring = r;
-    }
-    const uint32_t n_v = frames * wpf;
-    uint32_t n_h = total_waves - n_v;
-    if (const char* e = debug_switch("ws_h_waves")) n_h = std::max<uint32_t>(1u, std::min<uint32_t>(total_waves - n_v, static_cast<uint32_t>(std::atoi(e))));
-    const uint32_t wgs = (n_images + frames - 1u) / frames;
-    ScheduleOnDevice sd;
-    const uint32_t want_bands = choose_bands(p, wgs, ss.strips.size());
-    int rc = get_schedule(p, want_bands, kWsRowsInFlight, kWsRowsInFlight, &sd);
-    if (rc) return rc;
-    a.steps = sd.steps; a.band_begin = sd.band_begin; a.n_bands = sd.n_bands;
-    a.strips = ss.d_strips; a.n_strips = static_cast<uint32_t>(ss.strips.size());
-    a.h_groups = two ? 16u + fast_g : fast_g;
-    if (two) { a.h_wu = p->d_h_wg2; a.h_wu_floats = p->h_wg2_floats; a.h_meta2 = p->d_h_meta3; }
-    else { a.h_wu = p->d_h_wg; a.h_wu_floats = p->h_wg_floats; a.h_meta2 = p->d_h_meta2; }
-    a.lut_copies_log2 = copies_log2;
-    a.h_w_in_lds = 1u;
-    a.l2s_in_lds = l2s ? 1u : 0u;
-    a.frames_per_wg = frames;
-    a.lanes_per_frame = T;
-    a.ws_ring = ring;
-    const size_t lds = lds_for(frames, copies_log2, ring);
-    const uint64_t grid = static_cast<uint64_t>(wgs) * sd.n_bands * a.n_strips;
-    if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
-    if (debug_switch("trace_launch"))
-        std::fprintf(stderr, "ifhip ws launch: %ux%u -> %ux%u K=%d ycc=%d V lanes/frame=%u frames/wg=%u V waves=%u H waves=%u ring=%u bands=%u "
-                     "strips=%u grid=%llu lds=%zu fast_g=%u two_col=%d lut_copies=%u images=%u\n",
-                     p->in_w, p->in_h, p->out_w, p->out_h, p->slots, ycc ? 1 : 0, T, frames, n_v, n_h, ring, sd.n_bands, a.n_strips,
-                     static_cast<unsigned long long>(grid), lds, fast_g, two ? 1 : 0, 1u << copies_log2, n_images);
-    if (probe) return IFHIP_OK;
-    HIP_TRY(launch_ws(a, p->slots, static_cast<uint32_t>(grid), (n_v + n_h) * 64u, lds, st));
     return IFHIP_OK;
 }
 
@@ -522,17 +403,15 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
                     "(live rows %d > %d, or rows not 16-byte aligned / padded)", p->slots, kMaxSlots);
     if (force_kernel == 1) fused = false;
 
-    // banded two-pass kernel: asked for (force_kernel 2), or chosen in auto mode by IFHIP_BANDED
+    // banded two-pass kernel: asked for (force_kernel 2), or in auto mode where the fused kernel does not apply
     if (!ycc && (force_kernel == 2 || force_kernel == -1)) {
-        const int bm = force_kernel == 2 ? 2 : banded_mode();
-        const bool upscale = p->out_w >= p->in_w && p->out_h >= p->in_h;
-        const bool want = force_kernel == 2 || (bm >= 1 && !fused) || (bm >= 2 && upscale);
+        const bool want = force_kernel == 2 || !fused;
         BandPlan bp;
         if (want && banded_plan(p, d_in, in_image_bytes, in_stride, n_images, &bp)) {
-            // IFHIP_BANDED_FLAGS: experiment switch, masks the plan's flags (1 weights of short horizontal windows in registers,
-            // 2 band rows from its first and last row, 4 horizontal tables in LDS)
+            // test hook: masks the plan's flags (2 band rows from its first and last row, 4 horizontal tables in LDS) so that the
+            // kernel's table-free forms, which real weight tables reach only at very wide outputs, run in the suite
             if (const char* fe = debug_switch("banded_flags")) bp.args.flags &= static_cast<uint32_t>(std::atoi(fe));
-            if (debug_switch("trace_launch"))
+            if (trace_launch())
                 std::fprintf(stderr, "ifhip banded launch: %ux%u -> %ux%u alpha=%d rows/band=%u bands=%u src rows=%u frame step=%u flags=%u grid=%u lds=%zu images=%u\n",
                              p->in_w, p->in_h, p->out_w, p->out_h, alpha, bp.args.rows_per_band, bp.args.n_bands, bp.args.src_rows_cap,
                              bp.args.frame_step, bp.args.flags, bp.grid, bp.lds, n_images);
@@ -544,10 +423,6 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
                         "(or the source pixels are not 4-byte aligned)");
     }
 
-    if (fused && !alpha) {
-        rc = enqueue_ws(p, a, n_images, ycc, probe, st);
-        if (rc != kNotFusable) return rc;          // launched (or failed for a reason of its own); else: the one-role kernel
-    }
     if (fused) {
         const ifhip_resample_plan::StripSet& ss = p->sets[alpha ? 1 : 0];
         a.strips = ss.d_strips; a.n_strips = static_cast<uint32_t>(ss.strips.size());
@@ -556,7 +431,7 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         uint32_t max_nu = 0;
         for (const Strip& s : ss.strips) max_nu = std::max(max_nu, s.u1 - s.u0);
         const bool per_pixel = use_per_pixel(max_nu, channels, block);
-        const size_t limit = lds_limit();
+        const size_t limit = kLdsLimit;
         // The fast horizontal pass (same group count G for every output, rows padded with +0 weights) needs the padded
         // weight rows in LDS and the per-pixel mapping; when that does not fit, plan again for the general pass.
         uint32_t frames = 1, copies_log2 = kMinLutCopiesLog2, fast_g = 0, wu_floats = p->h_wu_floats;
@@ -573,7 +448,7 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
             // Frames per workgroup: a source narrower than half the workgroup would leave the CU with a handful of waves
             // (one workgroup per CU: the tables fill most of the LDS), so F frames share a workgroup and its tables.
             frames = 1;
-            if (ss.strips.size() == 1 && debug_switch("one_frame_per_wg") == nullptr) {
+            if (ss.strips.size() == 1) {
                 const uint32_t max_f = std::min<uint32_t>(static_cast<uint32_t>(fused_max_threads(p->slots, channels)) / block, n_images);
                 const Strip& s0 = ss.strips[0];
                 for (uint32_t f = max_f; f > 1; --f)
@@ -595,14 +470,14 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
                     if (fused_lds_bytes(s.u1 - s.u0, s.nquads, channels, wu_floats, w, l2s, copies_log2, per_pixel, frames, fast_g) > limit) return false;
                 return true;
             };
-            w_in_lds = debug_switch("hw_global") == nullptr && fits(true, false, kMinLutCopiesLog2);
+            w_in_lds = fits(true, false, kMinLutCopiesLog2);
             // What goes next depends on where the lookups are: the 16 KiB linear->sRGB table saves an 8-step threshold
             // search (~40 instructions) per encoded channel, the second set of 16 table copies saves one LDS conflict cycle
             // per converted sample.  Per output row a strip encodes 3*n_u channels and converts 12*nquads*(in_h/out_h)
             // samples; thumbnail-sized outputs (cfg2) want the copies first, moderate ratios (cfg3) the encode table.
             const double enc_cost = 3.0 * max_nu * 40.0;
             const double conv_cost = 12.0 * ss.max_quads * (static_cast<double>(p->in_h) / std::max<uint32_t>(1u, p->out_h)) * 2.0;
-            const bool l2s_allowed = a.linear && debug_switch("l2s_search") == nullptr;
+            const bool l2s_allowed = a.linear != 0;
             copies_log2 = kMinLutCopiesLog2;
             l2s_in_lds = false;
             if (enc_cost > conv_cost) {
@@ -629,7 +504,7 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         a.lanes_per_frame = block;
         const uint64_t grid = static_cast<uint64_t>((n_images + frames - 1u) / frames) * sd.n_bands * a.n_strips;
         if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
-        if (debug_switch("trace_launch"))                        // experiment aid: the shape this call launches
+        if (trace_launch())                                      // development aid: the shape this call launches
             std::fprintf(stderr, "ifhip fused launch: %ux%u -> %ux%u K=%d alpha=%d ycc=%d lanes/frame=%u frames/wg=%u bands=%u strips=%u "
                          "grid=%llu lds=%zu fast_g=%u two_col=%d w_in_lds=%d l2s_in_lds=%d lut_copies=%u per_pixel=%d images=%u\n",
                          p->in_w, p->in_h, p->out_w, p->out_h, p->slots, alpha, ycc ? 1 : 0, block, frames, sd.n_bands, a.n_strips,
@@ -806,7 +681,7 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
     {
         uint32_t g_max = 0;
         for (uint32_t u = 0; u < w; ++u) g_max = std::max(g_max, hmeta[u].y);
-        if (g_max >= 2u && g_max <= 4u && debug_switch("no_fast_h") == nullptr) {
+        if (g_max >= 2u && g_max <= 4u) {
             std::map<std::vector<uint32_t>, uint32_t> seen;        // padded row bits -> row id
             const uint32_t row_floats = g_max * 4u;
             bool ok = true;
@@ -833,7 +708,7 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
     // and stays with groups of four.  The taps keep their order and the padding is +0: same pixels.
     std::vector<float> wg2;
     std::vector<uint32_t> hmeta3(w);
-    if (p->h_fast_groups && debug_switch("no_two_col") == nullptr) {
+    if (p->h_fast_groups) {
         uint32_t g2_max = 0;
         for (uint32_t u = 0; u < w; ++u) g2_max = std::max(g2_max, ((p->wh.left[u] & 1u) + p->wh.count[u] + 1u) >> 1);
         if (g2_max >= 2u && g2_max <= 6u && 3u * g2_max <= 4u * p->h_fast_groups) {     // at most 2/3 of the taps (measured: 3/4 gains nothing)
@@ -875,21 +750,8 @@ int ifhip_resample_plan_create(ifhip_resample_plan** plan, uint32_t in_w, uint32
     for (int al = 0; al < 2 && p->fused_possible; ++al) {
         const int channels = al ? 4 : 3;
         ifhip_resample_plan::StripSet& ss = p->sets[al];
-        uint32_t max_lanes = static_cast<uint32_t>(fused_max_quads(p->slots, channels));      // in 4-pixel groups
-        if (const char* e = debug_switch("max_lanes")) {               // experiment switch: narrower strips
-            const int v = std::atoi(e);
-            if (v >= 64) max_lanes = std::min<uint32_t>(max_lanes, static_cast<uint32_t>(v) & ~63u);
-        }
+        const uint32_t max_lanes = static_cast<uint32_t>(fused_max_quads(p->slots, channels));      // in 4-pixel groups
         ss.ok = plan_strips(p->wh, max_lanes, fused_shape(p->slots, channels).px, channels, &ss.strips, &ss.max_quads);
-        if (ss.ok && (rc = upload(ss.strips, &ss.d_strips))) return rc;
-    }
-    // Strips of the wave-specialised kernel: moderate ratios (the fast horizontal pass exists), rings the 1024-lane shapes
-    // hold (K <= 5), three channels; a strip's source span is what its 8 V waves cover.
-    if (p->fused_possible && p->h_fast_groups && p->slots <= 5 && fused_shape(p->slots, 3).px == 4 && fused_shape(p->slots, 3).threads == 1024) {
-        ifhip_resample_plan::StripSet& ss = p->ws_set;
-        uint32_t v_waves = kWsMaxVWaves;
-        if (const char* e = debug_switch("ws_strip_waves")) v_waves = std::max(1u, std::min(14u, static_cast<uint32_t>(std::atoi(e))));   // experiment switch: narrower / wider strips
-        ss.ok = plan_ws_strips(p->wh, v_waves * 64u, &ss.strips, &ss.max_quads);
         if (ss.ok && (rc = upload(ss.strips, &ss.d_strips))) return rc;
     }
     *plan = p.release();

@@ -48,8 +48,6 @@ struct ResampleArgs {
     uint32_t lut_copies_log2;        // the sRGB->float table is replicated 2^n times in LDS (5: one copy per bank)
     uint32_t frames_per_wg;          // F: frames one workgroup works on side by side (narrow sources; tables shared)
     uint32_t lanes_per_frame;        // multiple of 64; the workgroup has F * lanes_per_frame lanes
-    // wave-specialised kernel (resample_ws.hip): the workgroup has F * lanes_per_frame V lanes, the rest are H waves
-    uint32_t ws_ring;                // R: row slots per frame slot between the vertical and the horizontal waves
     // generic-kernel tables
     const uint32_t* h_left;
     const uint32_t* h_count;
@@ -140,33 +138,6 @@ inline FusedLds fused_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t wu_floa
         l.inter_stride = ((nquads + fast_groups - 1u) * fused_group_pitch(channels) + 15u) & ~15u;
     }
     l.inter = off; off += frames * 2u * l.inter_stride;    // vertically filtered rows j / j+1, one pair per frame slot
-    l.total = off;
-    return l;
-}
-
-// ---- wave-specialised kernel (resample_ws.hip): moderate ratios, fast horizontal pass, three channels ----
-// Rows in flight per V lane: half the workgroup streams (8 waves where the one-role kernel has 15-16), so a lane keeps twice the
-// rows in flight for the same bytes outstanding per CU (8 waves x 64 lanes x 8 rows x 16 B = 64 KB).  Measured with 6 rows
-// and the conversion double buffer, and with 12 rows: the same time within 1 % (profiles/r5_ws_*.jsonl) -- the V waves are
-// not bound by bytes in flight.
-constexpr int kWsRowsInFlight = 8;
-constexpr uint32_t kWsUnitChunks = 4;       // 64-output chunks an H wave works on at a time (one output of each per lane)
-constexpr uint32_t kWsMaxVWaves = 8;        // V waves per workgroup (of 16): strips are planned for 8 x 64 x 4 source columns
-struct WsLds { uint32_t lut, l2s, hmeta, hw, sync, ring, row_stride, total; };
-#if defined(__HIPCC__)
-__host__ __device__
-#endif
-inline WsLds ws_lds_layout(uint32_t n_u, uint32_t nquads, uint32_t wu_floats, bool l2s_in_lds, uint32_t lut_copies_log2,
-                           uint32_t frames, uint32_t fast_groups, uint32_t ring) {
-    WsLds l;
-    uint32_t off = 0;
-    l.lut = off;   off += (256u << lut_copies_log2) * 4u;
-    l.l2s = off;   off += l2s_in_lds ? 16384u : 0u;
-    l.hmeta = off; off += (n_u * 4u + 15u) & ~15u;
-    l.hw = off;    off += (wu_floats * 4u + 15u) & ~15u;
-    l.sync = off;  off += (2u * frames * ring * 4u + 63u) & ~63u;      // row counters: published [F][R], consumed [F][R]
-    l.row_stride = ((nquads + fast_groups - 1u) * fused_group_pitch(3) + 15u) & ~15u;   // as the fast pass of the one-role kernel
-    l.ring = off;  off += frames * ring * l.row_stride;
     l.total = off;
     return l;
 }

@@ -127,16 +127,24 @@ int cached_malloc_for_stream(void** out, size_t bytes, void* stream, bool for_st
     hipError_t e = hipMalloc(out, cls);
     if (e != hipSuccess) {                                            // out of memory with blocks parked in the cache: give them back, once
         (void)hipGetLastError();
+        // ... the free lists and the blocks still behind a stream alike (up to the cache's cap of them): their release points
+        // are waited for OUTSIDE the lock, a short wait against an allocation that would otherwise fail
         std::vector<void*> drop;
+        std::vector<Cache::Pending> waiting;
         {
             std::lock_guard<std::mutex> lk(c.mu);
             for (auto& kv : c.free_lists) { drop.insert(drop.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
+            waiting.swap(c.pending);
             c.kept = 0;
-            for (const Cache::Pending& q : c.pending) c.kept += q.cls;   // (still behind their streams: they stay)
             ++c.oom_flushes;
-            c.driver_frees += drop.size();
+            c.driver_frees += drop.size() + waiting.size();
         }
+        for (const Cache::Pending& q : waiting) { (void)hipEventSynchronize(q.ev); (void)hipGetLastError(); drop.push_back(q.p); }
         for (void* p : drop) (void)hipFree(p);
+        if (!waiting.empty()) {
+            std::lock_guard<std::mutex> lk(c.mu);
+            for (const Cache::Pending& q : waiting) c.spare_events.push_back(q.ev);
+        }
         e = hipMalloc(out, cls);
         if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return static_cast<int>(e); }
     }
@@ -268,15 +276,20 @@ template <typename FreeFn>
 size_t trim_cache(Cache& c, size_t keep, FreeFn release) {
     std::vector<void*> drop;
     size_t dropped = 0;
+    // releases still behind a stream are cache like the rest: taken out under the lock, waited for WITHOUT it (every
+    // cached_malloc / cached_free of the device would stall behind the event waits otherwise), then free-listed
+    std::vector<Cache::Pending> waiting;
     {
         std::lock_guard<std::mutex> lk(c.mu);
-        for (const Cache::Pending& q : c.pending) {                   // releases still behind a stream: wait for them, they are cache like the rest
-            (void)hipEventSynchronize(q.ev);
-            (void)hipGetLastError();
+        waiting.swap(c.pending);
+    }
+    for (const Cache::Pending& q : waiting) { (void)hipEventSynchronize(q.ev); (void)hipGetLastError(); }
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        for (const Cache::Pending& q : waiting) {
             c.free_lists[q.cls].push_back(q.p);
             c.spare_events.push_back(q.ev);
         }
-        c.pending.clear();
         for (auto it = c.free_lists.rbegin(); it != c.free_lists.rend() && c.kept > keep; ++it)
             while (!it->second.empty() && c.kept > keep) {
                 drop.push_back(it->second.back());
@@ -350,17 +363,14 @@ int cpu_budget() {                                                    // CPUs th
 
 int wait_stream(void* hip_stream) {
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    const char* mode = debug_switch("wait");
-    if (!st || (mode && std::strcmp(mode, "runtime") == 0)) return static_cast<int>(hipStreamSynchronize(st));
+    if (!st) return static_cast<int>(hipStreamSynchronize(st));
     hipError_t e = hipStreamQuery(st);                                // often idle already
     if (e != hipErrorNotReady) return static_cast<int>(e);
     (void)hipGetLastError();                                          // (NotReady is recorded as the thread's last error)
     struct Waiting { int n; Waiting() : n(g_waiters.fetch_add(1, std::memory_order_relaxed) + 1) {} ~Waiting() { g_waiters.fetch_sub(1, std::memory_order_relaxed); } } me;
-    int spinners = std::max(1, cpu_budget() / 4);
-    if (const char* sw = debug_switch("wait_spinners")) spinners = std::atoi(sw);
-    if (!(mode && std::strcmp(mode, "sleep") == 0) && me.n <= spinners) return static_cast<int>(hipStreamSynchronize(st));
-    long sleep_us = 20;
-    if (const char* sw = debug_switch("wait_sleep_us")) sleep_us = std::max(0L, std::atol(sw));
+    const int spinners = std::max(1, cpu_budget() / 4);
+    if (me.n <= spinners) return static_cast<int>(hipStreamSynchronize(st));
+    constexpr long sleep_us = 20;
     for (;;) {
         std::this_thread::sleep_for(std::chrono::microseconds(sleep_us));
         e = hipStreamQuery(st);

@@ -1169,7 +1169,10 @@ int ifhip_jpeg_exif_orientation(const uint8_t* d, size_t len, int* flag) {
 
 // The embedded ICC profile (see include/imageflow_hip.h).  libjpeg's jpeg_read_icc_profile rule: APP2 markers whose data starts
 // with "ICC_PROFILE\0", then a 1-based sequence number and the marker count; every number must occur exactly once with the
-// same count.  Anything short of that is "a profile we cannot vouch for" = kind 2.
+// same count.  A chunk set that breaks the rule -- inconsistent counts, a sequence number out of range or twice, a missing
+// chunk, nothing but empty chunks -- is NO profile to the reference (read_icc_profile returns None,
+// mozjpeg_decoder_helpers.rs:42-83: the frame is decoded without a transform) and kind 0 here; so is a GRAY profile on a
+// colour frame (mozjpeg_decoder.rs:391-395 -> SourceProfile::Srgb).
 int ifhip_jpeg_icc_profile_kind(const uint8_t* d, size_t len, int* kind) {
     if (!kind) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: null out-pointer");
     *kind = 0;
@@ -1177,6 +1180,7 @@ int ifhip_jpeg_icc_profile_kind(const uint8_t* d, size_t len, int* kind) {
     std::vector<std::pair<const uint8_t*, size_t>> chunk(256, {nullptr, 0});
     uint32_t count = 0, seen = 0;
     bool broken = false;
+    int frame_components = 0;
     size_t i = 2;
     while (i + 4 <= len) {
         if (d[i] != 0xFF) break;
@@ -1190,6 +1194,7 @@ int ifhip_jpeg_icc_profile_kind(const uint8_t* d, size_t len, int* kind) {
         const uint8_t* q = d + i + 2;
         const size_t n = seg - 2;
         i += seg;
+        if (m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC && n >= 6) frame_components = q[5];     // SOFn: P, Y, X, Nf
         if (m != 0xE2 || n < 14 || std::memcmp(q, "ICC_PROFILE\0", 12) != 0) continue;
         const uint32_t seq = q[12], num = q[13];
         if (seq == 0 || num == 0 || seq > num || (count && num != count) || chunk[seq].first) { broken = true; continue; }
@@ -1197,11 +1202,12 @@ int ifhip_jpeg_icc_profile_kind(const uint8_t* d, size_t len, int* kind) {
         chunk[seq] = {q + 14, n - 14};
         ++seen;
     }
-    if (!seen && !broken) return IFHIP_OK;
-    *kind = 2;
-    if (broken || seen != count) return IFHIP_OK;
+    if (!seen || broken || seen != count) return IFHIP_OK;              // no profile, or a chunk set the reference drops
     std::vector<uint8_t> icc;
     for (uint32_t k = 1; k <= count; ++k) icc.insert(icc.end(), chunk[k].first, chunk[k].first + chunk[k].second);
+    if (icc.empty()) return IFHIP_OK;                                    // only empty markers: None
+    if (icc.size() >= 20 && std::memcmp(&icc[16], "GRAY", 4) == 0 && frame_components != 1) return IFHIP_OK;   // -> SourceProfile::Srgb
+    *kind = 2;
     // ICC.1 header: size (0..3), colour space (16..19), PCS (20..23); tag table at 128: count, then {sig, offset, size}
     auto be32 = [&](size_t o) { return (static_cast<uint32_t>(icc[o]) << 24) | (static_cast<uint32_t>(icc[o + 1]) << 16) | (static_cast<uint32_t>(icc[o + 2]) << 8) | icc[o + 3]; };
     if (icc.size() < 132 || std::memcmp(&icc[16], "RGB ", 4) != 0 || std::memcmp(&icc[20], "XYZ ", 4) != 0) return IFHIP_OK;
@@ -1499,9 +1505,6 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
     if (int arc = require_gfx950(nullptr)) return arc;
     // Host preparation runs on a few threads, one file at a time each: parsing and un-stuffing are independent per file
     // and would otherwise take several times longer than the GPU needs to decode the batch.
-    const bool timing = debug_switch("ent_timing") != nullptr;        // development aid: phase times on stderr
-    const auto t_start = std::chrono::steady_clock::now();
-    auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     std::vector<std::unique_ptr<ifhip_jpeg_prepared, GivePrepared>> prep(n_images);
     std::vector<int> rcs(n_images, IFHIP_OK);
     std::vector<std::string> messages(n_images);
@@ -1530,15 +1533,11 @@ static int entropy_create_impl(ifhip_jpeg_entropy** out, const uint8_t* const* f
             for (uint32_t i = t; i < n_images; i += n_threads) guarded(i);
         for (auto& th : pool) th.join();
     }
-    const double t_prep = ms_since();
     for (uint32_t img = 0; img < n_images; ++img)                              // errors in file order
         if (rcs[img]) return fail(rcs[img], "%s", messages[img].c_str());
     std::vector<ifhip_jpeg_prepared*> raw(n_images);
     for (uint32_t img = 0; img < n_images; ++img) raw[img] = prep[img].get();
-    const int rc = create_prepared_impl(out, raw.data(), n_images);
-    if (timing)
-        std::fprintf(stderr, "[ifhip entropy create] threads %u (hw %u): parse + unstuff + pack %.2f ms, + upload / alloc %.2f ms\n", n_threads, hw, t_prep, ms_since());
-    return rc;
+    return create_prepared_impl(out, raw.data(), n_images);
 }
 
 extern "C" {
@@ -1680,8 +1679,7 @@ int ifhip_jpeg_debug_scan_report(const uint8_t* jpeg, size_t len, ifhip_jpeg_sca
         if (int rc = parse_jpeg(jpeg, len, &P)) return rc;
         auto F = std::make_unique<FastTabs>(), Pt = std::make_unique<FastTabs>(), Ct = std::make_unique<FastTabs>();
         SearchTab S6[6];
-        const char* lim = debug_switch("ent_test_pool");
-        const uint32_t pool_limit = lim ? std::min<uint32_t>(static_cast<uint32_t>(std::strtoul(lim, nullptr, 10)), kPoolEntries) : kPoolEntries;
+        const uint32_t pool_limit = test_hook_u32("ent_test_pool", kPoolEntries, kPoolEntries);
         derive_image_tables(P, F.get(), S6, pool_limit, &out->pool_entries_used);
         derive_pair_tables(*F, P.ncomp, Pt.get());
         derive_count_tables(*F, *Pt, Ct.get());

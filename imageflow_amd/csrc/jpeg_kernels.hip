@@ -1206,7 +1206,6 @@ static int stage_args(ifhip_jpeg_stage* stage, const int16_t* d_coef0, const int
 
 // block-per-lane routine of component c: 0 islow 8x8, 1 jidctred 4x4, 2 islow + spatial scaler; -1: the eight-lanes kernel
 static int bpl_mode(const JpegGeom& g, int c) {
-    if (debug_switch("jpeg_idct8")) return -1;             // experiment switch: everything on the eight-lanes kernel
     const uint32_t n = g.idct_n[c];
     if (c == 0 && g.luma_mode != 0u && n < 8u) return 2;
     return n == 8u ? 0 : n == 4u ? 1 : -1;
@@ -1257,7 +1256,7 @@ int ifhip_jpeg_idct_color_batch_device(ifhip_jpeg_stage* stage, const int16_t* d
     a.bgra = d_bgra; a.image_bytes = image_bytes; a.stride = stride;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     // full-size colour decode: the luma IDCT runs inside the colour kernel (no luma plane in HBM)
-    const bool fused_luma = a.g.ncomp == 3 && a.g.scale_num == 8u && a.g.luma_mode == 0u && debug_switch("jpeg_unfused") == nullptr;
+    const bool fused_luma = a.g.ncomp == 3 && a.g.scale_num == 8u && a.g.luma_mode == 0u;
     rc = launch_idct_planes(a, fused_luma ? 1 : 0, st);
     if (rc) return rc;
     const dim3 cgrid((a.g.out_w + 1023u) / 1024u, (a.g.out_h + kColorRows - 1u) / kColorRows, n_images);
@@ -1291,7 +1290,7 @@ int ifhip_jpeg_decode_resample_batch_device(ifhip_jpeg_stage* stage, const int16
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const JpegGeom& g = a.g;
     const bool planes_at_output = g.ncomp == 3 && g.upsample == 0u && g.pw[0] == g.pw[1] && g.pw[0] == g.pw[2] &&
-                                  g.ph[0] == g.ph[1] && g.ph[0] == g.ph[2] && debug_switch("jpeg_unfused") == nullptr;
+                                  g.ph[0] == g.ph[1] && g.ph[0] == g.ph[2];
     // the resampler is asked FIRST whether it takes the planes (alignment, a shape of the planar-source instantiations):
     // a refusal behind the plane IDCTs would run every IDCT twice
     if (planes_at_output &&

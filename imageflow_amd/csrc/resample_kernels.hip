@@ -85,7 +85,6 @@ hpass_generic_kernel(const ResampleArgs a, const float4* scratch, uint32_t img0)
 constexpr uint32_t kBandedThreads = 512;
 constexpr uint32_t kBandedTableBytes = 16384 + 1024;        // linear -> sRGB table, sRGB -> float table
 constexpr uint32_t kBandedPrefetch = 8;                     // source pixels a lane keeps in flight for the next frame
-constexpr uint32_t kBandedRegTaps = 8;                      // horizontal windows up to this many taps keep their weights in registers
 template <bool ALPHA>
 __global__ void __launch_bounds__(kBandedThreads)
 banded_resample_kernel(const ResampleArgs a, const BandedArgs b) {
@@ -188,51 +187,24 @@ banded_resample_kernel(const ResampleArgs a, const BandedArgs b) {
         }
         __syncthreads();     // vband complete; src is free for the next frame
         // ---- horizontal pass + output stage (step 3 and the compositing modes).  A lane keeps its output column over the
-        // wave's rows: its tap window and, when the window has at most kBandedRegTaps taps (every up-scale with a window-2
-        // filter has 5), its weights stay in registers and the row's samples are requested together.  The padding taps carry
-        // weight +0 on a clamped (finite) sample: fmaf(+0, x, h) == h exactly, h is never -0 (the fused kernel's argument).
+        // wave's rows.  (Weights of short windows kept in registers, padded to 8 taps, measured slower -- 3.76 against 3.65 ms
+        // on the 3x shape -- and were removed.)
         for (uint32_t u = lane; u < a.out_w; u += 64u) {
             const uint32_t left = h_lds ? hl[u] : a.h_left[u], n = h_lds ? hc[u] : a.h_count[u];
             const uint32_t woff = h_lds ? ho[u] : a.h_off[u];
             auto weight = [&](uint32_t k) -> float { return h_lds ? hw[woff + k] : a.h_w[woff + k]; };
-            if ((b.flags & 1u) && n <= kBandedRegTaps) {
-                float wr[kBandedRegTaps];
-                uint32_t col[kBandedRegTaps];
-#pragma unroll
-                for (uint32_t k = 0; k < kBandedRegTaps; ++k) {
-                    const float wk = weight(min(k, n - 1u));   // (in bounds whatever the compiler makes of the select)
-                    wr[k] = k < n ? wk : 0.0f;
-                    col[k] = min(left + k, a.in_w - 1u);
+            for (uint32_t jr = wave; jr < nrows; jr += nw) {
+                const float4* row = vband + jr * a.in_w;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                for (uint32_t k = 0; k < n; ++k) {
+                    const float4 v = row[left + k];
+                    const float wk = weight(k);
+                    s0 = __builtin_fmaf(wk, v.x, s0);
+                    s1 = __builtin_fmaf(wk, v.y, s1);
+                    s2 = __builtin_fmaf(wk, v.z, s2);
+                    if (ALPHA) s3 = __builtin_fmaf(wk, v.w, s3);
                 }
-                for (uint32_t jr = wave; jr < nrows; jr += nw) {
-                    const float4* row = vband + jr * a.in_w;
-                    float4 v[kBandedRegTaps];
-#pragma unroll
-                    for (uint32_t k = 0; k < kBandedRegTaps; ++k) v[k] = row[col[k]];
-                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-                    for (uint32_t k = 0; k < kBandedRegTaps; ++k) {
-                        s0 = __builtin_fmaf(wr[k], v[k].x, s0);
-                        s1 = __builtin_fmaf(wr[k], v[k].y, s1);
-                        s2 = __builtin_fmaf(wr[k], v[k].z, s2);
-                        if (ALPHA) s3 = __builtin_fmaf(wr[k], v[k].w, s3);
-                    }
-                    store_pixel<ALPHA>(a, img, j0 + jr, u, s0, s1, s2, ALPHA ? s3 : 1.0f, tb);
-                }
-            } else {
-                for (uint32_t jr = wave; jr < nrows; jr += nw) {
-                    const float4* row = vband + jr * a.in_w;
-                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                    for (uint32_t k = 0; k < n; ++k) {
-                        const float4 v = row[left + k];
-                        const float wk = weight(k);
-                        s0 = __builtin_fmaf(wk, v.x, s0);
-                        s1 = __builtin_fmaf(wk, v.y, s1);
-                        s2 = __builtin_fmaf(wk, v.z, s2);
-                        if (ALPHA) s3 = __builtin_fmaf(wk, v.w, s3);
-                    }
-                    store_pixel<ALPHA>(a, img, j0 + jr, u, s0, s1, s2, ALPHA ? s3 : 1.0f, tb);
-                }
+                store_pixel<ALPHA>(a, img, j0 + jr, u, s0, s1, s2, ALPHA ? s3 : 1.0f, tb);
             }
         }
     }
@@ -325,22 +297,6 @@ hipError_t launch_fused(const ResampleArgs& a, int slots, bool alpha, bool per_p
     case 6: return launch_fused_k6(a, alpha, per_pixel, g, b, lds, st);
     case 7: return launch_fused_k7(a, alpha, per_pixel, g, b, lds, st);
     case 8: return launch_fused_k8(a, alpha, per_pixel, g, b, lds, st);
-    default: return hipErrorInvalidValue;
-    }
-}
-
-// the wave-specialised form for moderate ratios (resample_ws.hip, one translation unit per ring size 1..5)
-#define IFHIP_DECL_WS(n) hipError_t launch_ws_k##n(const ResampleArgs&, dim3, dim3, size_t, hipStream_t);
-IFHIP_DECL_WS(1) IFHIP_DECL_WS(2) IFHIP_DECL_WS(3) IFHIP_DECL_WS(4) IFHIP_DECL_WS(5)
-
-hipError_t launch_ws(const ResampleArgs& a, int slots, uint32_t grid, uint32_t block, size_t lds, hipStream_t st) {
-    const dim3 g(grid), b(block);
-    switch (slots) {
-    case 1: return launch_ws_k1(a, g, b, lds, st);
-    case 2: return launch_ws_k2(a, g, b, lds, st);
-    case 3: return launch_ws_k3(a, g, b, lds, st);
-    case 4: return launch_ws_k4(a, g, b, lds, st);
-    case 5: return launch_ws_k5(a, g, b, lds, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -264,9 +264,11 @@ IFHIP_API int ifhip_jpeg_exif_orientation(const uint8_t* jpeg, size_t len, int* 
  * the reference transforms a frame to sRGB whenever the file carries ANY profile (:409, SourceProfile::is_srgb is true
  * only for "no profile") unless the job told the decoder discard_color_profile (:88-95).  This library has no colour
  * management (out of scope), so callers must know when a file needs it.  *kind = 0: no profile;
+ * (also: a chunk set libjpeg's reassembly rule rejects -- mozjpeg_decoder_helpers.rs:42-83 returns None -- and a GRAY
+ * profile on a colour frame, which the reference maps to SourceProfile::Srgb, mozjpeg_decoder.rs:391-395);
  * 1: a profile that describes sRGB itself (RGB matrix profile, sRGB primaries within 0.003 after D50 adaptation, the sRGB
  * tone curve) -- the reference's transform is the identity up to its own rounding; 2: any other profile (Display P3,
- * Adobe RGB, CMYK, grey, malformed chunks ...) -- decoding the samples as they are gives other colours than the
+ * Adobe RGB, CMYK, grey on a grey frame, a profile too short to parse ...) -- decoding the samples as they are gives other colours than the
  * reference.  Host only. */
 IFHIP_API int ifhip_jpeg_icc_profile_kind(const uint8_t* jpeg, size_t len, int* kind);
 /* Host-side entropy decoding of the Huffman JPEGs the GPU entropy stage does not take -- progressive (SOF2: what the

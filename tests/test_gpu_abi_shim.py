@@ -913,6 +913,12 @@ def test_a_file_with_a_non_srgb_profile_is_refused_unless_the_decoder_is_told_to
     with_cmd = [{"decode": {"io_id": 0, "commands": ["discard_color_profile"]}}] + steps[1:]
     assert np.array_equal(run(p3, with_cmd), plain)
     assert np.array_equal(run(srgb, steps), plain)
+    # what the reference itself treats as "no profile": a chunk set its reassembly drops (mozjpeg_decoder_helpers.rs:42-83) and
+    # a GRAY profile on a colour frame (mozjpeg_decoder.rs:391-395 -> SourceProfile::Srgb) -- decoded, not refused
+    from tests.test_jpeg_headers import icc_app2
+    broken = base[:2] + icc_app2(make_icc(xyz=P3_XYZ), pieces=3, drop=1) + base[2:]
+    assert np.array_equal(run(broken, steps), plain)
+    assert np.array_equal(run(_tagged(base, make_icc(space=b"GRAY")), steps), plain)
     # the querystring path decodes through the same gate
     qs = [{"command_string": {"kind": "ir4", "value": "width=80", "decode": 0, "encode": 1}}]
     assert run(p3, qs, expect=400) is None
@@ -959,3 +965,4 @@ def test_querystring_keys_are_honoured_or_refused_never_dropped():
     assert tables(run("width=160&quality=50")) == libjpeg_tables(50)
     assert tables(run("width=160&format=jpg")) == libjpeg_tables(90)
     assert tables(run("width=160&format=jpeg&quality=30&jpeg.quality=77")) == libjpeg_tables(77)
+    assert tables(run("width=160&quality=high")) == libjpeg_tables(90)       # not an integer: ignored as the reference's parse_i32 does -> the default

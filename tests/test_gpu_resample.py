@@ -337,9 +337,6 @@ def test_banded_kernel_equals_the_oracle(shape, alpha):
 def test_banded_kernel_filters(filt, sharpen, debug_switch):
     run_case(60, 40, 171, 113, filt=filt, sharpen=sharpen, alpha=True, force=2)
     run_case(150, 85, 31, 18, filt=filt, sharpen=sharpen, alpha=False, force=2)
-    debug_switch("banded_regtaps", "1")                                             # short windows: weights in registers, +0 padding taps
-    run_case(60, 40, 171, 113, filt=filt, sharpen=sharpen, alpha=True, force=2)
-    run_case(150, 85, 31, 18, filt=filt, sharpen=sharpen, alpha=False, force=2)           # long windows keep the tap loop
     debug_switch("banded_flags", "0")                                               # no shortcut at all: tables from HBM, band rows by search
     run_case(60, 40, 171, 113, filt=filt, sharpen=sharpen, alpha=True, force=2)
 
@@ -367,13 +364,11 @@ def test_banded_kernel_refuses_what_does_not_fit():
     assert e.value.kind == ErrorKind.InvalidState
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_auto_mode_with_the_banded_kernel_switched_on(mode, debug_switch):
-    debug_switch("banded", mode)
-    run_case(100, 100, 300, 300, alpha=True)                  # generic before: banded in both modes
-    run_case(200, 200, 400, 400, alpha=True, filt=Filter.Hermite)     # fused in mode 1, banded in mode 2
-    run_case(384, 216, 20, 20, alpha=False)                   # a down-scale the fused kernel takes in both modes
-    run_case(640, 360, 7, 4, alpha=True)                      # too many live rows for the fused kernel, too many source rows per band?
+def test_auto_mode_picks_the_banded_kernel_where_the_fused_one_does_not_apply():
+    run_case(100, 100, 300, 300, alpha=True)                  # 3x up-scale: too many live rows for the fused kernel -> banded
+    run_case(200, 200, 400, 400, alpha=True, filt=Filter.Hermite)     # fused
+    run_case(384, 216, 20, 20, alpha=False)                   # a down-scale the fused kernel takes
+    run_case(640, 360, 7, 4, alpha=True)                      # too many live rows for the fused kernel, too many source rows per band: generic pair
 
 
 @pytest.mark.parametrize("case", [(1600, 90, 1200, 68, Filter.Robidoux, 4), (400, 300, 300, 225, Filter.Robidoux, 4),
@@ -391,13 +386,6 @@ def test_two_column_groups_of_the_fast_horizontal_pass(case):
     run_case(iw, ih, ow, oh, filt=filt, alpha=False, n=2, seed=iw, x=3, y=2, cw=ow + 9, ch=oh + 5,
              space=WorkingFloatspace.StandardRGB)
     run_case(iw, ih, ow, oh, filt=filt, alpha=True, n=2, seed=ow, compose=BitmapCompositing.BlendWithSelf)
-
-
-def test_two_column_groups_can_be_switched_off(debug_switch):
-    """The development switch the A/B runs use (`no_two_col`): plans made under it have no two-column tables."""
-    debug_switch("no_two_col", "1")
-    p = ResamplePlan(1600, 90, 1200, 68, Filter.Robidoux, 0.0)
-    assert p.horizontal_groups() == (3, 0)
 
 
 def test_two_column_groups_only_where_they_save_a_third_of_the_taps():

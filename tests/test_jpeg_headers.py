@@ -315,8 +315,9 @@ def icc_kind(jpeg):
 
 
 def test_icc_profile_kind(golden_dir):
-    """0 = no profile (the only case the reference does not run its CMS for, mozjpeg_decoder.rs:409), 1 = a profile that IS
-    sRGB (matrix profile, sRGB primaries and tone curve), 2 = anything else, malformed chunk sets included."""
+    """0 = no profile (the only case the reference does not run its CMS for, mozjpeg_decoder.rs:409) -- which includes chunk
+    sets its reassembly drops (mozjpeg_decoder_helpers.rs:42-83) and a GRAY profile on a colour frame (mozjpeg_decoder.rs:391-395);
+    1 = a profile that IS sRGB (matrix profile, sRGB primaries and tone curve); 2 = anything else."""
     base = next(all_files(golden_dir))[1]
     assert icc_kind(base) == 0
     assert icc_kind(_with_segments(base, icc_app2(make_icc()))) == 1
@@ -325,9 +326,16 @@ def test_icc_profile_kind(golden_dir):
     assert icc_kind(_with_segments(base, icc_app2(make_icc(xyz=P3_XYZ)))) == 2                          # Display P3 primaries
     assert icc_kind(_with_segments(base, icc_app2(make_icc(trc="gamma22")))) == 2                       # sRGB primaries, plain gamma
     assert icc_kind(_with_segments(base, icc_app2(make_icc(space=b"CMYK")))) == 2
-    assert icc_kind(_with_segments(base, icc_app2(make_icc(space=b"GRAY")))) == 2
-    assert icc_kind(_with_segments(base, icc_app2(make_icc(), pieces=3, drop=1))) == 2                  # a chunk is missing
-    assert icc_kind(_with_segments(base, icc_app2(make_icc(), pieces=2, dup=True))) == 2                # a chunk twice
+    assert icc_kind(_with_segments(base, icc_app2(make_icc(space=b"GRAY")))) == 0                       # grey profile, colour frame: Srgb
+    import io
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.new("L", (16, 16), 128).save(buf, "JPEG")
+    assert icc_kind(_with_segments(buf.getvalue(), icc_app2(make_icc(space=b"GRAY")))) == 2               # ... on a grey frame: IccProfileGray
+    assert icc_kind(_with_segments(base, icc_app2(make_icc(xyz=P3_XYZ), pieces=3, drop=1))) == 0        # a chunk is missing: None
+    assert icc_kind(_with_segments(base, icc_app2(make_icc(xyz=P3_XYZ), pieces=2, dup=True))) == 0      # a chunk twice: None
+    assert icc_kind(_with_segments(base, b"\xff\xe2\x00\x10ICC_PROFILE\0\x01\x01")) == 0                # only an empty marker: None
+    assert icc_kind(_with_segments(base, b"\xff\xe2\x00\x12ICC_PROFILE\0\x02\x01ab")) == 0              # sequence number past the count
     assert icc_kind(_with_segments(base, icc_app2(make_icc()[:100]))) == 2                              # shorter than a header
     nearly = make_icc(xyz=((0.4360 + 0.004, 0.2225, 0.0139),) + SRGB_XYZ[1:])                           # a primary off by 0.004
     assert icc_kind(_with_segments(base, icc_app2(nearly))) == 2

@@ -4,7 +4,7 @@ the settings are timed interleaved (hipEvents around back-to-back launches, as b
 setting's canvas is check-summed -- settings that claim the same pixels must print the same sum.
 
     tools/ab_switches.py [--reps 3] [--launches 30] --workloads cfg3-l0,cfg3-l1 \
-        --settings "base:ws=0" "ws:ws=1" "ws_prio:ws=1,ws_flags=1" ...
+        --settings "base:" "one_wg:banded_wgs=1" ...
 
 One JSON line per (workload, setting, repetition): {"workload", "setting", "rep", "kernel_ms", "frac", "checksum"} and a
 closing summary line per workload with the median of each setting."""
