@@ -111,7 +111,7 @@ def make_frames(torch, n, first_index, seed, device, pattern, in_w, in_h):
     return Bitmap(data.view(n, in_h * stride), in_w, in_h, stride, alpha_meaningful=False)
 
 
-def cpu_baseline(sample_seconds=15.0):
+def cpu_baseline(sample_seconds=8.0):
     """The oracle (our C port of the reference's CPU path) timed on the host cores on a bounded sample of cfg2.  The
     Rust reference itself (cargo bench -p imageflow_core --bench bench_graphics -- full_scale_pipeline,
     benches/bench_graphics.rs:382-456) needs a Rust toolchain AND the reference tree; both are probed and reported."""
@@ -218,24 +218,36 @@ def pyramid_parity(torch, inp, levels):
             "against": "oracle.scale_and_render chained as the job chains its levels, BGRA8 byte for byte"}
 
 
-def cfg4_files(first_index, n):
-    """SURVEY.md 8d's cfg4 inputs: 3840x2160 baseline 4:2:0 q85 files of the gradient of bench_codecs.rs:24-41
-    (R = 255 x / w, G = 255 y / h, B = 3 (x + y) & 255, shifted per file) -- every second file with uniform noise of +-12
-    added -- written on the host with Pillow (libjpeg-turbo, optimize=False).  File k's content depends on k only."""
+def _cfg4_one_file(k):
     import io
     import numpy as np
     from PIL import Image
     w, h = CFG4["in_w"], CFG4["in_h"]
     y, x = np.mgrid[0:h, 0:w].astype(np.int32)
-    files = []
-    for k in range(first_index, first_index + n):
-        rgb = np.stack([((x + 7 * k) % w) * 255 // w, ((y + 5 * k) % h) * 255 // h, ((x + y + k) * 3) & 255], -1).astype(np.int16)
-        if k & 1:
-            rgb = rgb + np.random.default_rng(4000 + k).integers(-12, 13, size=rgb.shape, dtype=np.int16)
-        buf = io.BytesIO()
-        Image.fromarray(np.clip(rgb, 0, 255).astype(np.uint8)).save(buf, "JPEG", quality=85, subsampling="4:2:0", optimize=False)
-        files.append(buf.getvalue())
-    return files
+    rgb = np.stack([((x + 7 * k) % w) * 255 // w, ((y + 5 * k) % h) * 255 // h, ((x + y + k) * 3) & 255], -1).astype(np.int16)
+    if k & 1:
+        rgb = rgb + np.random.default_rng(4000 + k).integers(-12, 13, size=rgb.shape, dtype=np.int16)
+    buf = io.BytesIO()
+    Image.fromarray(np.clip(rgb, 0, 255).astype(np.uint8)).save(buf, "JPEG", quality=85, subsampling="4:2:0", optimize=False)
+    return buf.getvalue()
+
+
+def cfg4_files(first_index, n):
+    """SURVEY.md 8d's cfg4 inputs: 3840x2160 baseline 4:2:0 q85 files of the gradient of bench_codecs.rs:24-41
+    (R = 255 x / w, G = 255 y / h, B = 3 (x + y) & 255, shifted per file) -- every second file with uniform noise of +-12
+    added -- written on the host with Pillow (libjpeg-turbo, optimize=False).  File k's content depends on k only.
+    (About half a second of one core per file: written by a pool of forked workers -- numpy and Pillow only, they never
+    touch HIP -- so that 128 files take seconds, not a minute; main() makes the files before it initialises the device.)"""
+    ks = list(range(first_index, first_index + n))
+    procs = min(len(ks), os.cpu_count() or 1, 32)
+    if procs >= 2 and len(ks) >= 4:
+        import multiprocessing as mp
+        try:
+            with mp.get_context("fork").Pool(procs) as pool:
+                return pool.map_async(_cfg4_one_file, ks, chunksize=1).get(timeout=300)
+        except Exception as e:  # noqa: BLE001 -- a pool that cannot start or stalls: the files are made here
+            print(f"bench.py: file pool failed ({type(e).__name__}: {e}); writing the files serially", file=sys.stderr, flush=True)
+    return [_cfg4_one_file(k) for k in ks]
 
 
 def _cfg4_cpu_one(data):
@@ -278,7 +290,7 @@ def cfg4_cpu_baseline(files, sample_seconds=12.0):
             "published_reference_decode_MPps_one_core": 50.1}
 
 
-def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun):
+def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun, inputs, rccl_env):
     """BASELINE config 4 (see the module docstring): files -> entropy decode -> 4/8 pixel stage -> 800x450, sharded."""
     import threading
 
@@ -308,7 +320,8 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun):
         objs = [None] * world
         dist.all_gather_object(objs, ranks_info[0])
         ranks_info = objs
-    files = cfg4_files(lo, n)
+    assert inputs[0] == lo and len(inputs[1]) == n, "main() wrote this rank's files before the device was initialised"
+    files = inputs[1]
     torch.zeros(1, device=dev).item()
     info = ScaleAndRenderParams(0, 0, ow, oh)
     out_all = Bitmap.create_u8(n_max, ow, oh, dev)                 # this rank's outputs, gather-slot sized
@@ -353,39 +366,59 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun):
         for t in th:
             t.join()
 
-    mode = "none" if (not distributed or args.no_gather or args.gather == "none") else "final"
+    mode = "none" if (not distributed or args.no_gather) else args.gather
     gathered = None
-    if mode == "final" and rank == 0:
+    if mode != "none" and rank == 0:
         gathered = torch.empty((world, n_max, out_all.image_bytes), dtype=torch.uint8, device="cpu" if dryrun else dev)
-    gather_note = "none" if mode == "none" else "rccl gather of the 800x450 outputs to rank 0 once, at the end of the timed region (the same gather ran once during warm-up)"
+    gather_note = {"none": "none",
+                   "every": "rccl gather of the batch's 800x450 outputs to rank 0 EVERY step (one per batch), in line: step, gather, next step",
+                   "final": "rccl gather of the 800x450 outputs to rank 0 once, at the end of the timed region (the same gather ran once during "
+                            "warm-up); amortised over the steps: not the per-batch figure"}[mode]
     gathers = {"warmup": 0, "timed": 0}
+    gather_ok = True
 
-    def final_gather(phase):
-        nonlocal gather_note
+    def gather_outputs(phase):
+        nonlocal gather_note, gather_ok
+        if not gather_ok:
+            return
         try:
             gather_to_root(out_all.data.cpu() if dryrun else out_all.data, 0, out=gathered if rank == 0 else None)
             gathers[phase] += 1
         except Exception as e:  # noqa: BLE001
-            gather_note = f"final rccl gather failed: {type(e).__name__}: {e}"
+            gather_ok = False
+            gather_note = f"rccl gather failed: {type(e).__name__}: {e}"
 
-    run_steps(args.warmup)
-    torch.cuda.synchronize()
-    if mode == "final":
-        final_gather("warmup")
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize()
-    t_compute = time.perf_counter() - t0
-    if mode == "final":
-        final_gather("timed")
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
-    compute_s = max_over_ranks(t_compute, dev)
+    def timed(steps, phase):
+        """-> seconds for `steps` batches; with phase and --gather every each batch is followed by its gather (the decode
+        threads of a step have joined: the outputs are complete), with --gather final the steps by one gather."""
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if phase is not None and mode == "every":
+            for _ in range(steps):
+                run_steps(1)
+                gather_outputs(phase)
+        else:
+            run_steps(steps)
+        torch.cuda.synchronize()
+        t_steps = time.perf_counter() - t0
+        if phase is not None and mode == "final":
+            gather_outputs(phase)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, t_steps
+
+    timed(args.warmup, "warmup")
+    if mode == "final" and gathers["warmup"] == 0:
+        gather_outputs("warmup")
+    el, t_steps = timed(args.steps, "timed")
+    elapsed = max_over_ranks(el, dev)
+    if mode == "every":
+        compute_s = max_over_ranks(timed(args.steps, None)[0], dev)
+    else:
+        compute_s = max_over_ranks(t_steps if mode == "final" else el, dev)
 
     # the pixel stage + resize call alone (SURVEY 8d's unit: coefficient planes in, 800x450 out), hipEvents on its stream,
     # one batch at a time so that nothing else shares the device
@@ -411,7 +444,7 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun):
     selfcheck = None
     if rank == 0:
         parity = cfg4_parity(torch, files, out_all, [0, n - 1])
-        if args.selfcheck and gathered is not None:
+        if args.selfcheck and gathered is not None and gather_ok:
             selfcheck = cfg4_selfcheck(torch, gathered, total, world, dev, out_all)
         mp_per_step = total * w * h / 1e6
         algo = n * CFG4["bytes_per_image"]
@@ -420,7 +453,7 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun):
             "metric": "megapixels/sec JPEG decode + resize (4K 4:2:0 q85 -> 800px)", "value": round(mp_per_step * args.steps / elapsed, 1), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "i32/f32", "data": "synthetic",
-            "gather_ms": round((elapsed - compute_s) * 1e3, 4),
+            "gather_ms": round((elapsed - compute_s) / (args.steps if mode == "every" else 1) * 1e3, 4),
             "value_without_gather": round(mp_per_step * args.steps / compute_s, 1),
             "files_per_s": round(total * args.steps / elapsed, 1),
             "config": {"workload": f"BASELINE cfg4: {total} files ({n} on rank 0) 3840x2160 4:2:0 q85 baseline JPEG -> GPU entropy decode -> 4/8 IDCT "
@@ -429,7 +462,8 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun):
                        "compressed_MB_per_gpu": round(compressed / 1e6, 2),
                        "one_call_chain": bool(all(bt["fused"] for bt in all_batches)),
                        "kernel": "jpeg entropy passes + luma / chroma IDCT kernels + the resampler reading the component planes",
-                       "gather": gather_note, "gathers": gathers, "rccl_ranks": dist.get_world_size() if distributed else 1,
+                       "gather": gather_note, "gathers": gathers, "gather_mode": mode, "rccl_channels": rccl_env,
+                       "rccl_ranks": dist.get_world_size() if distributed else 1,
                        "backend": (dist.get_backend() if distributed else "none"), "ranks": ranks_info,
                        "entropy_decode_ms_per_step": round(ent_ms, 4), "pixel_stage_and_resize_ms_per_step": round(px_ms, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -496,6 +530,52 @@ def cfg4_selfcheck(torch, gathered, total, world, dev, out_all):
     return {"ranks": world, "first_frame_of_every_rank_equal": not bad, "ranks_that_differ": bad}
 
 
+OTHER_CONFIGS = [        # name, what `bench.py` is asked for (reduced step counts; cfg4 on 64 generated files in batches of 32)
+    ("cfg5", ["--workload", "cfg5", "--steps", "10", "--warmup", "3"]),
+    ("cfg3_job", ["--workload", "cfg3", "--steps", "10", "--warmup", "3"]),
+    ("cfg4", ["--workload", "cfg4", "--frames", "64", "--files-per-batch", "32", "--steps", "6", "--warmup", "2"]),
+]
+
+
+def other_configs(budget_s):
+    """BASELINE configs 5, 3 and 4 beside the headline: each is THIS file run as a child process with `--workload ...`
+    (exactly what a user would type; a child that fails or stalls costs its own entry, not the line), its JSON line cut
+    down to what the driver needs to witness: time per step, the kernel-timed roofline fraction on SURVEY 8d's bytes, the
+    parity stamp against the CPU oracle, and the workload it ran."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_PORT")}
+    out, t_start = {}, time.perf_counter()
+    for name, extra in OTHER_CONFIGS:
+        left = budget_s - (time.perf_counter() - t_start)
+        if left < 20:
+            out[name] = {"skipped": f"time budget of {budget_s:.0f} s used up"}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--no-strong-field", "--no-other-configs"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=min(left, 100))
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": f"rc {r.returncode}: {r.stderr.strip()[-300:]}", "command": " ".join(cmd[1:])}
+                continue
+            j = json.loads(lines[-1])
+            rf, pc = j.get("roofline", {}), j.get("parity_checked") or {}
+            e = {"value": j.get("value"), "unit": j.get("unit"), "metric": j.get("metric"), "steps": j.get("steps"), "ms_per_step": j.get("ms_per_step"),
+                 "roofline": {k: rf.get(k) for k in ("bound", "frac", "frac_timed", "kernel_ms", "achieved", "peak", "unit", "algorithmic_bytes_per_launch")},
+                 "parity_checked": {"equal": pc.get("equal"), "frames": pc.get("frames"), "against": pc.get("against")},
+                 "config": {"workload": j.get("config", {}).get("workload"), "kernel": j.get("config", {}).get("kernel")},
+                 "command": "bench.py " + " ".join(extra), "wall_s": round(time.perf_counter() - t0, 1)}
+            for k in ("files_per_s", "roofline_entropy"):
+                if k in j:
+                    e[k] = j[k]
+            out[name] = e
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "timed out", "command": " ".join(cmd[1:])}
+        except Exception as ex:  # noqa: BLE001
+            out[name] = {"error": f"{type(ex).__name__}: {ex}", "command": " ".join(cmd[1:])}
+    return out
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -515,16 +595,30 @@ def parse_args(argv=None):
     ap.add_argument("--total-frames", type=int, default=1024, help="strong scaling: frames of the whole job")
     ap.add_argument("--pattern", default="mixed", choices=["mixed", "gradient", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", default="final", choices=["final", "every", "none"],
-                    help="N > 1 only.  final: one RCCL gather of the outputs to rank 0 at the end of the timed region "
-                         "(the job's final gather, BASELINE north_star); every: one per step, asynchronous and double "
-                         "buffered against the next step; none: results stay sharded")
+    ap.add_argument("--gather", default=None, choices=["every", "final", "none"],
+                    help="N > 1 only.  every (default): ONE RCCL gather of the batch's outputs to rank 0 PER STEP (a step is one "
+                         "batch: SURVEY 8e 'one per batch'), asynchronous and double buffered so that it overlaps the next "
+                         "batch's kernel; final: a single gather at the end of the timed region (amortised over the steps -- "
+                         "not the north_star batch time); none: results stay sharded")
+    ap.add_argument("--rccl-channels", type=int, default=8,
+                    help="N > 1: cap on RCCL's channels (= workgroups of its kernels; NCCL_MAX_NCHANNELS / NCCL_MAX_P2P_NCHANNELS, set "
+                         "before the process group is made unless the environment already names them).  7 peers x 20 MB per batch "
+                         "need one channel each; the default RCCL set-up would take tens of CUs from a grid that wants all 256")
+    ap.add_argument("--reserve-cus", type=int, default=None,
+                    help="N > 1 with --gather every: CUs the resample launches leave to the gather's workgroups "
+                         "(ifhip_set_cu_budget(256 - this); default: --rccl-channels)")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["cfg4"])
     ap.add_argument("--batches-in-flight", type=int, default=2, help="--workload cfg4: host threads / HIP streams, each decoding its batches of files one after the other")
     ap.add_argument("--files-per-batch", type=int, default=None, help="--workload cfg4: files per entropy / pixel-stage batch (default 64)")
-    ap.add_argument("--selfcheck", action="store_true",
-                    help="after the timed region rank 0 checks the first gathered frame of EVERY rank against one it renders itself")
+    ap.add_argument("--selfcheck", dest="selfcheck", action="store_true", default=None,
+                    help="after the timed region rank 0 checks the first gathered frame of EVERY rank against one it renders itself "
+                         "(default: on whenever N > 1 and the outputs are gathered)")
+    ap.add_argument("--no-selfcheck", dest="selfcheck", action="store_false")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="the default run (N = 1, cfg2) also measures BASELINE configs 5, 3 and 4 at reduced step counts, each as "
+                         "`bench.py --workload ...` in a child process, and reports them under `other_configs`; this skips them")
+    ap.add_argument("--other-configs-budget-s", type=float, default=150.0, help="wall-clock cap of that addition")
     ap.add_argument("--outputs", default="files", choices=["files", "bgra"],
                     help="--workload cfg3: what the job leaves and its final gather ships -- the four JPEG files per image "
                          "(libjpeg_turbo q90, coded on the device; the reference's export_4_sizes) or the raw BGRA levels")
@@ -548,10 +642,29 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to "
                          f"measure a different job than the one asked for")
+    if args.gather is None:
+        args.gather = "every" if world > 1 else "none"
+    if args.no_gather or world == 1:
+        args.gather = "none"
+    if args.selfcheck is None:
+        args.selfcheck = world > 1 and args.gather != "none"
+    # cfg4's input files are written on the host BEFORE the device is touched (the writers are forked workers)
+    cfg4_inputs = None
+    if args.workload == "cfg4":
+        from imageflow_amd.sharding import shard_range as _sr
+        if args.scaling == "strong":
+            lo4, hi4 = _sr(args.total_frames, rank, world)
+        else:
+            per4 = args.frames or CFG4["files_per_gpu"]
+            lo4, hi4 = rank * per4, (rank + 1) * per4
+        if hi4 - lo4 < 1:
+            raise SystemExit(f"rank {rank} owns no files")
+        cfg4_inputs = (lo4, cfg4_files(lo4, hi4 - lo4))
 
     import torch
     import torch.distributed as dist
 
+    from imageflow_amd import _native
     from imageflow_amd.graphics.bitmaps import Bitmap, BitmapCompositing
     from imageflow_amd.graphics.scaling import ScaleAndRenderParams, plan_for, scale_and_render, time_scale_and_render
     from imageflow_amd.graphics.weights import Filter
@@ -569,14 +682,27 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
+    rccl_env = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dryrun:
             dist.init_process_group("gloo")
         else:
+            # RCCL's kernels take one workgroup per channel; its default set-up on an xGMI node opens dozens.  The job's only
+            # collective is a gather of 20 MB per peer and batch: a handful of channels move that, and every CU RCCL does not
+            # take stays with the resample grid (one workgroup per CU).  Names the environment already sets are left alone.
+            ch = str(max(1, args.rccl_channels))
+            for k in ("NCCL_MAX_NCHANNELS", "NCCL_MAX_P2P_NCHANNELS"):
+                os.environ.setdefault(k, ch)
+            os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
+            os.environ.setdefault("NCCL_MIN_P2P_NCHANNELS", "1")
+            rccl_env = {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_MAX_P2P_NCHANNELS", "NCCL_MIN_P2P_NCHANNELS")}
             dist.init_process_group("nccl", device_id=dev)
+    reserve_cus = 0
+    if distributed and args.gather == "every":
+        reserve_cus = max(0, min(128, args.rccl_channels if args.reserve_cus is None else args.reserve_cus))
     if args.workload == "cfg4":
-        run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun)
+        run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun, cfg4_inputs, rccl_env)
         if distributed:
             dist.destroy_process_group()
         return
@@ -620,14 +746,13 @@ def main():
         return Bitmap(b.data[:k], b.w, b.h, b.stride, b.alpha_meaningful, b.compose, b.matte)
     inp = first_frames(inp_all, n)
     mode = "none" if (not distributed or args.no_gather or os.environ.get("IFHIP_BENCH_GATHER", "1") == "0") else args.gather
-    if pyramid and mode == "every":
-        raise SystemExit("--workload cfg3 gathers once per job: use --gather final or none")
-    if dryrun and mode == "every":  # gloo cannot gather device tensors; the dry run only walks the final gather (via the host)
-        raise SystemExit("dry run: pass --gather final or none")
+    overlapped = mode == "every" and not files_out       # (files: the message's size is read on the host first, so that gather runs in line)
     gather_note = {"none": "none",
-                   "every": "rccl gather of the outputs to rank 0 every step, asynchronous, double buffered",
-                   "final": "rccl gather of the outputs to rank 0 once, at the end of the timed region "
-                            "(the same gather ran once during warm-up)"}[mode]
+                   "every": ("rccl gather of the batch's outputs to rank 0 EVERY step (one per batch), asynchronous and double buffered: "
+                             "the gather of batch k runs beside the kernel of batch k + 1" if overlapped else
+                             "rccl gather of the batch's files to rank 0 EVERY step (one per batch), in line with the step (sizes first, then the bytes)"),
+                   "final": "rccl gather of the outputs to rank 0 once, at the end of the timed region (the same gather ran once "
+                            "during warm-up); amortised over the steps: not the per-batch figure"}[mode]
     gather_calls = {"warmup": 0, "timed": 0}
 
     class Job:
@@ -665,7 +790,8 @@ def main():
                                           torch.empty(nj * pitch, dtype=torch.uint8, device=dev)]
                     self.file_bytes = None
                 else:
-                    self.packed = torch.empty((self.n_max, self.out_bytes_per_frame), dtype=torch.uint8, device=dev)   # the four outputs of a frame, side by side
+                    # the four outputs of a frame, side by side; two of them when gathers overlap the next step
+                    self.packed = [torch.empty((self.n_max, self.out_bytes_per_frame), dtype=torch.uint8, device=dev) for _ in range(2 if overlapped else 1)]
             else:
                 self.canv = [Bitmap.create_u8(self.n_max, out_w, out_h, dev, compose=BitmapCompositing[wl[7]], matte=wl[8]) for _ in range(2)]
                 self.views = [first_frames(c, nj) for c in self.canv]
@@ -675,12 +801,63 @@ def main():
             self.gathered = None
             if mode != "none" and rank == 0 and not files_out:
                 self.gathered = [torch.empty((world, self.n_max, self.out_bytes_per_frame), dtype=torch.uint8, device="cpu" if dryrun else dev)
-                                 for _ in range(2 if mode == "every" else 1)]
+                                 for _ in range(2 if overlapped else 1)]
             self.gathered_sizes = None
             self.pending = [None, None]
+            self.host_copy = [None, None]                  # (dry run: the payload on the host while gloo gathers it)
             self.note = gather_note
+            self.gather_ok = True
+            self.last = 0                                   # parity of the last step run (which canvas / gather buffer holds its outputs)
 
-        def step(self, i, encode=True):
+        def payload(self, i):
+            """What step i's gather ships from this rank (device tensor, gather-slot sized)."""
+            if not pyramid:
+                return self.canv[i & 1].data
+            pk = self.packed[i & 1 if overlapped else 0]
+            off = 0
+            for b in self.levels.values():                             # device-side packing: one message per rank
+                pk[:self.n, off:off + b.image_bytes] = b.data
+                off += b.image_bytes
+            return pk
+
+        def wait_slot(self, k):
+            if self.pending[k] is not None:
+                self.pending[k].wait()                      # (RCCL: the current stream waits; gloo: the host does)
+                self.pending[k] = None
+
+        def gather_step(self, i, phase, blocking):
+            """The batch's one exchange: its finished outputs to rank 0.  The frames never meet before this point (no
+            data-path collective).  A failure is reported in the line; it does not cost the compute measurement."""
+            if not self.gather_ok:
+                return
+            try:
+                if files_out:
+                    msg, meta = self.packed_files()
+                    meta_pad = torch.zeros((len(self.enc), self.n_max + 1), dtype=torch.int64, device=meta.device)
+                    meta_pad[:, :meta.shape[1]] = meta
+                    gather_to_root(meta_pad.cpu() if dryrun else meta_pad, 0)
+                    self.gathered_sizes, _ = gather_bytes_to_root(msg.cpu() if dryrun else msg, 0)
+                else:
+                    k = (i & 1) if overlapped else 0
+                    pay = self.payload(i)
+                    if dryrun:
+                        self.host_copy[k] = pay.cpu()
+                        pay = self.host_copy[k]
+                    out = self.gathered[k] if rank == 0 else None
+                    if blocking:
+                        gather_to_root(pay, 0, async_op=False, out=out)
+                    else:
+                        self.pending[k], _ = gather_to_root(pay, 0, async_op=True, out=out)
+                gather_calls[phase] += 1
+            except Exception as e:  # noqa: BLE001
+                self.gather_ok = False
+                self.note = f"rccl gather failed: {type(e).__name__}: {e}"
+
+        def step(self, i, encode=True, phase=None):
+            """One batch: the rank's frames through the hot path; with `phase` (and --gather every) its gather behind it."""
+            gather = phase is not None and mode == "every"
+            if gather and overlapped:
+                self.wait_slot(i & 1)                      # the buffers step i is about to overwrite have been gathered (step i - 2)
             if pyramid:
                 for s, d, inf, pl in self.chain:
                     scale_and_render(s, d, inf, plan=pl)
@@ -688,19 +865,15 @@ def main():
                     for name, e in self.enc.items():                   # (outputs have no meaningful alpha: no matte pass)
                         e[0].write_frames(self.levels[name], self.qt, e[1])
                         _, e[4], e[5] = e[2].encode_device(e[1], 90, files=e[3])
-                return
-            if mode == "every" and self.pending[i & 1] is not None:
-                self.pending[i & 1].wait()             # the buffer we are about to overwrite has been gathered
-                self.pending[i & 1] = None
-            scale_and_render(self.inp, self.views[i & 1], self.info, plan=self.plan)
-            if mode == "every":
-                self.pending[i & 1], _ = gather_to_root(self.canv[i & 1].data, 0, async_op=True, out=self.gathered[i & 1] if rank == 0 else None)
+            else:
+                scale_and_render(self.inp, self.views[i & 1], self.info, plan=self.plan)
+            self.last = i & 1
+            if gather:
+                self.gather_step(i, phase, blocking=not overlapped)
 
         def sync_all(self):
             for k in range(2):
-                if self.pending[k] is not None:
-                    self.pending[k].wait()
-                    self.pending[k] = None
+                self.wait_slot(k)
             torch.cuda.synchronize()
 
         def packed_files(self):
@@ -715,58 +888,43 @@ def main():
             self.file_bytes = sum(used)
             return torch.cat([p[:u] for (p, _), u in zip(parts, used)]), torch.stack(meta)
 
-        def final_payload(self, steps):
-            if not pyramid:
-                return self.canv[(steps - 1) & 1].data
-            off = 0
-            for b in self.levels.values():                             # device-side packing: one message per rank
-                self.packed[:self.n, off:off + b.image_bytes] = b.data
-                off += b.image_bytes
-            return self.packed
-
-        def final_gather(self, steps, phase):
-            # The frames never meet before this point (no data-path collective).  A gather kernel running beside the
-            # resample kernel would take CUs from a grid that is exactly one workgroup per CU, so the job's one exchange
-            # happens after the last batch; a failure here is reported, it does not cost the measurement.
-            try:
-                if files_out:
-                    msg, meta = self.packed_files()
-                    meta_pad = torch.zeros((len(self.enc), self.n_max + 1), dtype=torch.int64, device=meta.device)
-                    meta_pad[:, :meta.shape[1]] = meta
-                    gather_to_root(meta_pad.cpu() if dryrun else meta_pad, 0)
-                    self.gathered_sizes, _ = gather_bytes_to_root(msg.cpu() if dryrun else msg, 0)
-                    gather_calls[phase] += 1
-                    return
-                last = self.final_payload(steps)
-                gather_to_root(last.cpu() if dryrun else last, 0, async_op=False, out=self.gathered[0] if rank == 0 else None)
-                gather_calls[phase] += 1
-            except Exception as e:  # noqa: BLE001
-                self.note = f"final rccl gather failed: {type(e).__name__}: {e}"
-
-        def measure(self, steps, warmup):
-            """-> (whole-job seconds, seconds without the final gather), both max over ranks."""
-            for i in range(warmup):
-                self.step(i)
-            self.sync_all()
-            if mode == "final":
-                # RCCL sets its peer-to-peer channels up lazily on the first send/recv between two ranks (tens of ms): the
-                # job's gather runs once here, on the tensors and through the call the timed region uses
-                self.final_gather(steps, "warmup")
+        def timed(self, steps, phase):
+            """`steps` batches between barriers -> seconds on this rank.  phase None: no gathers at all."""
+            # while gathers run beside the kernels the launches plan for the CUs RCCL's workgroups leave them
+            _native.set_cu_budget(256 - reserve_cus if (phase is not None and overlapped and reserve_cus) else 0)
             if distributed:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(steps):
-                self.step(i)
+                self.step(i, phase=phase)
             self.sync_all()
-            t_compute = time.perf_counter() - t0
-            if mode == "final":
-                self.final_gather(steps, "timed")
+            t_steps = time.perf_counter() - t0
+            if phase is not None and mode == "final":
+                self.gather_step(steps - 1, phase, blocking=True)
             if distributed:
                 dist.barrier()
             torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t0
-            return max_over_ranks(elapsed, dev), max_over_ranks(t_compute, dev)
+            dt = time.perf_counter() - t0
+            _native.set_cu_budget(0)
+            return dt, t_steps
+
+        def measure(self, steps, warmup):
+            """-> (whole-job seconds with the job's gathers, seconds of the same steps without any gather), both max over ranks.
+            With gathers: every step's batch is followed by ITS gather (mode every) -- the timed region ends when the last
+            batch's outputs are on rank 0 -- or the steps by one final gather (mode final).  Without: a second timed loop."""
+            for i in range(warmup):
+                self.step(i, phase="warmup")                # RCCL sets its peer-to-peer channels up lazily on the first send / recv
+            self.sync_all()                                 # between two ranks (tens of ms): the warm-up steps gather as the timed ones do
+            if mode == "final":
+                self.gather_step(max(warmup, 1) - 1, "warmup", blocking=True)
+            elapsed, t_steps = self.timed(steps, "timed")
+            if mode == "none":
+                return max_over_ranks(elapsed, dev), max_over_ranks(elapsed, dev)
+            if mode == "final":                              # the steps of the same loop, before its gather
+                return max_over_ranks(elapsed, dev), max_over_ranks(t_steps, dev)
+            plain, _ = self.timed(steps, None)
+            return max_over_ranks(elapsed, dev), max_over_ranks(plain, dev)
 
     job = Job(n, total)
     elapsed, compute_s = job.measure(args.steps, args.warmup)
@@ -798,11 +956,13 @@ def main():
                   "ms_per_step": round(s_elapsed / s_steps * 1e3, 4),
                   "value": round(args.total_frames * in_w * in_h / 1e6 * s_steps / s_elapsed, 1),
                   "value_without_gather": round(args.total_frames * in_w * in_h / 1e6 * s_steps / s_compute, 1),
-                  "gather_ms": round((s_elapsed - s_compute) * 1e3, 4), "unit": "MP/s", "scaling": "strong", "gather": sj.note,
+                  "gather_ms": round((s_elapsed - s_compute) / s_steps * 1e3, 4), "unit": "MP/s", "scaling": "strong", "gather": sj.note,
                   "gathers": dict(gather_calls),
                   **({"gathered_bytes_per_rank": sj.gathered_sizes} if files_out else {}),
-                  "what": f"north_star job: {args.total_frames} images cut into {world} contiguous blocks, same kernel, same timing rule; "
-                          f"speed-up over 1 GPU = this value at N divided by this value at N = 1"}
+                  "what": f"north_star job: a batch of {args.total_frames} images cut into {world} contiguous blocks, same kernel, same timing "
+                          f"rule: ms_per_step = one batch INCLUDING its gather to rank 0 (one gather per batch; `gathers.timed` = steps), "
+                          f"value_without_gather = the same batches with no gather at all, gather_ms = what the gather adds per batch "
+                          f"after overlap.  Speed-up of the batch over 1 GPU = this value at N / this value at N = 1 (no gather there)"}
         del sj
 
     # dominant-kernel duration: hipEvents on the launch stream around back-to-back launches of the same op
@@ -836,7 +996,7 @@ def main():
                 one_out = Bitmap.create_u8(1, out_w, out_h, dev, compose=BitmapCompositing[wl[7]], matte=wl[8])
                 scale_and_render(one_in, one_out, info, plan=plan)
                 torch.cuda.synchronize()
-                if not bool(torch.equal(job.gathered[0][r, 0].to(dev), one_out.data[0])):
+                if not bool(torch.equal(job.gathered[((args.steps - 1) & 1) if overlapped else 0][r, 0].to(dev), one_out.data[0])):
                     bad.append(r)
             selfcheck = {"ranks": world, "first_frame_of_every_rank_equal": not bad, "ranks_that_differ": bad,
                          "note": "needs --pattern gradient or mixed (frame 0 of a block is a gradient frame) and alpha not meaningful"}
@@ -885,13 +1045,17 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "gather_ms": round((elapsed - compute_s) * 1e3, 4),
+            "gather_ms": round((elapsed - compute_s) / (args.steps if mode == "every" else 1) * 1e3, 4),
             "value_without_gather": round(mp_per_step * args.steps / compute_s, 1),
             "config": {"workload": f"BASELINE {args.workload}: {total} frames ({n} on rank 0) {shape} {wl[4]}"
                                    f"{' sharpen ' + str(wl[5]) if wl[5] else ''}, linear light, {wl[7]}, "
                                    f"alpha {'meaningful' if wl[6] else 'not meaningful'}, device resident, pattern={args.pattern}",
                        "frames_per_gpu": n, "total_frames": total, "kernel": kernel_name, "gather": gather_note,
-                       "gathers": main_gather_calls, "rccl_ranks": dist.get_world_size() if distributed else 1,
+                       "gathers": main_gather_calls, "gather_mode": mode,
+                       "gather_ms_is": ("per step: (time of the steps with their gathers - time of the same steps without) / steps" if mode == "every"
+                                        else "the one gather at the end of the timed region"),
+                       "rccl_channels": rccl_env, "reserved_cus_while_gathering": reserve_cus if overlapped else 0,
+                       "rccl_ranks": dist.get_world_size() if distributed else 1,
                        "backend": (dist.get_backend() if distributed else "none"), "ranks": ranks_info},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK, 4),
@@ -928,9 +1092,11 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "MP/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e}"}
             try:
-                out["host_dropin"] = host_dropin_rate(torch)
+                out["host_dropin"] = host_dropin_rate(torch, seconds=2.0)
             except Exception as e:  # noqa: BLE001
                 out["host_dropin"] = {"images_per_s": None, "what": f"failed: {e}"}
+        if world == 1 and args.workload == "cfg2" and not args.no_other_configs and args.scaling == "weak" and args.frames is None:
+            out["other_configs"] = other_configs(args.other_configs_budget_s)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()

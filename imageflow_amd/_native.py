@@ -67,6 +67,14 @@ def debug_set(key, value):
     check(lib().ifhip_debug_set(key.encode(), None if value is None else str(value).encode()))
 
 
+def set_cu_budget(compute_units):
+    """ifhip_set_cu_budget: the CUs this process's resample launches plan for (0: all 256) -- what a host that overlaps a few
+    workgroups of other work (an RCCL gather) with them leaves."""
+    L = lib()
+    L.ifhip_set_cu_budget.argtypes = [C.c_uint32]
+    check(L.ifhip_set_cu_budget(int(compute_units)))
+
+
 def trim_cache(keep_device_bytes=0, keep_host_bytes=0):
     """ifhip_cache_trim: give the library's recycled device / pinned blocks back to the driver (what a torch program calls
     next to torch.cuda.empty_cache() or after an out-of-memory error; blocks in use are not touched).  -> (device, host) bytes released."""

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -242,6 +243,9 @@ int get_schedule(const ifhip_resample_plan* p, uint32_t n_bands, int group, int 
     return IFHIP_OK;
 }
 
+std::atomic<uint32_t> g_cu_budget{0};            // ifhip_set_cu_budget: CUs the launches plan for (0: all of them)
+constexpr uint32_t kComputeUnits = 256;          // MI355X
+
 uint32_t choose_bands(const ifhip_resample_plan* p, uint32_t n_images, size_t n_strips) {
     // One workgroup occupies a CU (LDS), so a launch runs in ceil(workgroups / 256) rounds.  Cutting frames into bands
     // of output rows makes the rounds finer but every extra band re-reads its halo of source rows and stages the tables
@@ -251,11 +255,13 @@ uint32_t choose_bands(const ifhip_resample_plan* p, uint32_t n_images, size_t n_
     const double wgs = static_cast<double>(n_images) * static_cast<double>(n_strips);
     const double halo = p->out_h ? static_cast<double>(p->wv.max_taps) / std::max<double>(1.0, p->in_h) : 0.0;
     const double setup = 0.01;
+    const uint32_t budget = g_cu_budget.load(std::memory_order_relaxed);
+    const double cus = budget ? static_cast<double>(budget) : static_cast<double>(kComputeUnits);
     const uint32_t max_bands = std::max<uint32_t>(1u, std::min<uint32_t>(64u, p->out_h / 4u));
     uint32_t best = 1;
     double best_cost = 1e300;
     for (uint32_t b = 1; b <= max_bands; ++b) {
-        const double rounds = std::ceil(wgs * b / 256.0);
+        const double rounds = std::ceil(wgs * b / cus);
         const double cost = rounds * ((1.0 + halo * (b - 1)) / b + setup);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = b; }
     }
@@ -569,6 +575,12 @@ int ifhip_device_count(void) {
         if (hipGetDeviceProperties(&prop, i) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++usable;
     }
     return usable;
+}
+
+int ifhip_set_cu_budget(uint32_t compute_units) {
+    if (compute_units > kComputeUnits) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: CU budget %u (the device has %u)", compute_units, kComputeUnits);
+    g_cu_budget.store(compute_units, std::memory_order_relaxed);
+    return IFHIP_OK;
 }
 
 int ifhip_set_device(int ordinal) {

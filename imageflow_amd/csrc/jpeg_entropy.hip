@@ -340,7 +340,11 @@ constexpr uint32_t kFastStageDwords = kSyncCols * kColPitch;
 // lane costs as much as a full one -- so the iteration COMPACTS them: sub-sequence states live in LDS (one packed word:
 // relative bit position | block-in-MCU << 21 | zigzag index << 25), the lanes that need a decode enter a work list
 // through a ballot / prefix count, and lane k decodes the k-th entry.  An iteration then costs what its dense waves cost.
-constexpr uint32_t kInnerRounds = 24;
+// (No cap below the workgroup's own length: the loop ends as soon as nothing is pending, and a chain of corrections that
+// is cut short costs a host round trip, more launches and a REPEATED count + write pass.  With a cap of 24 that was half of
+// all 64-file decodes of BASELINE cfg4's files -- noise files re-synchronise with p ~ 0.4 per sub-sequence, 430 000
+// sub-sequences: the longest chain of a batch is ~ ln 430 000 / ln (1 / 0.6) = 25 -- round 6, profiles/r6_entropy_rounds.txt.)
+constexpr uint32_t kInnerRounds = 1024;
 constexpr uint32_t kWaveWalkMax = 16;                          // at most this many pending sub-sequences: one wave per walk
 // The first kWarmLanes lanes of a workgroup decode the sub-sequences IN FRONT of its own range in round 0 and discard the
 // result: the workgroup's first own sub-sequence then starts from a state that has had kWarmLanes sub-sequences to

@@ -73,6 +73,12 @@ IFHIP_API const char* ifhip_version(void);
  * (value NULL: unset).  Not part of the drop-in surface. */
 IFHIP_API int ifhip_debug_set(const char* key, const char* value);
 IFHIP_API int ifhip_device_count(void);            /* number of usable gfx950 devices (0 if none)          */
+/* Compute units the resample launches of this PROCESS plan for (default and 0: all 256).  The fused kernel occupies a CU per
+ * workgroup (its tables fill the LDS) and cuts frames into bands so that a launch fills the chip in whole rounds; a host that
+ * runs something else beside it -- the batch harness overlaps the RCCL gather of batch k, a few workgroups, with the kernel
+ * of batch k + 1 -- says how many CUs that leaves, and the band count is chosen for THAT number (finer bands, a short last
+ * round) instead of a grid of exactly 256 workgroups whose last few wait a whole round for a CU.  Pixels do not depend on it. */
+IFHIP_API int ifhip_set_cu_budget(uint32_t compute_units);
 IFHIP_API int ifhip_set_device(int ordinal);       /* one process per GPU: call once with LOCAL_RANK       */
 /* The HIP stream on which THIS THREAD's create calls (plans, stages, entropy handles) upload and clear what they need;
  * default: the null stream.  A host that runs one job per thread (one imageflow Context per thread, lib.rs:20-27) sets its

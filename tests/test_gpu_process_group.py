@@ -96,11 +96,15 @@ def test_sharded_export_job_gathers_the_same_files_as_one_process(tmp_path, worl
 
 
 @pytest.mark.parametrize("extra,scaling,total", [(["--total-frames", "9"], "weak", 16), (["--scaling", "strong", "--total-frames", "9"], "strong", 9),
-                                                 (["--workload", "cfg3", "--frames", "3", "--total-frames", "5"], "weak", 6)])
+                                                 (["--workload", "cfg3", "--frames", "3", "--total-frames", "5"], "weak", 6),
+                                                 (["--total-frames", "9", "--gather", "final"], "weak", 16)])
 def test_bench_launches_its_own_ranks(extra, scaling, total):
+    """N > 1: ONE gather per batch (= per step) by default, SURVEY 8e -- `gathers.timed == steps` -- and the first gathered frame
+    of every rank is checked on rank 0 without being asked for; `--gather final` keeps the single amortised gather."""
     env = _clean_env()
     env["IFHIP_BENCH_DRYRUN_ONE_GPU"] = "1"
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    steps = 3
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline"]
     if "--frames" not in extra and scaling == "weak":
         cmd += ["--frames", "8"]
     r = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=900)
@@ -110,21 +114,26 @@ def test_bench_launches_its_own_ranks(extra, scaling, total):
     assert j["n_gpus"] == 2 and j["scaling"] == scaling and j["config"]["total_frames"] == total, j
     assert "failed" not in j["config"]["gather"], j["config"]["gather"]
     assert j["value"] > 0 and j["roofline"]["frac"] > 0 and j["roofline"]["frac_timed"] > 0
-    # the job's gather ran once during warm-up (RCCL's lazy channel set-up is not timed) and exactly once in the timed region
-    assert j["config"]["gathers"] == {"warmup": 1, "timed": 1}, j["config"]
+    final = "final" in extra
+    # every batch is followed by its gather (the warm-up steps too: RCCL's lazy channel set-up is not timed)
+    want = {"warmup": 1, "timed": 1 if final else steps}
+    assert j["config"]["gathers"] == want and j["config"]["gather_mode"] == ("final" if final else "every"), j["config"]
     assert j["config"]["rccl_ranks"] == 2 and len(j["config"]["ranks"]) == 2 and j["config"]["ranks"][1]["rank"] == 1
-    assert j["gather_ms"] >= 0 and j["value_without_gather"] >= j["value"]
+    assert j["value_without_gather"] > 0 and j["steps"] == steps
+    if "--workload" not in extra:                                    # checked without --selfcheck on the command line
+        assert j["selfcheck"]["first_frame_of_every_rank_equal"] is True and j["selfcheck"]["ranks"] == 2, j.get("selfcheck")
     if scaling == "weak" and "--workload" not in extra:              # the north_star job rides along with the default run
         st = j["strong_1024"]
-        assert st["total_frames"] == 9 and st["frames_per_gpu"] == 5 and st["gathers"] == {"warmup": 1, "timed": 1} and st["value"] > 0
+        assert st["total_frames"] == 9 and st["frames_per_gpu"] == 5 and st["gathers"] == want and st["value"] > 0
+        assert "one gather per batch" in st["what"]
     elif "--workload" in extra:                                      # cfg3: the job's outputs are FILES, and so is what the gather ships
         c = j["config"]
         assert "JPEG files" in c["outputs"] and c["dropped_files"] == 0
         sent = c["gathered_bytes_per_rank"]
         assert len(sent) == 2 and all(0 < b < c["bgra_bytes_per_rank_if_raw"] // 2 for b in sent), c
         assert c["file_bytes_per_image"] > 0 and abs(sent[0] - 3 * c["file_bytes_per_image"]) <= 3 * 4 * 16 and c["resize_only_ms_per_step"] > 0
-        st = j["strong_1024"]                                        # (--total-frames defaults to 1024: too big for a test box? no: 512 per rank)
-        assert st["gathers"] == {"warmup": 1, "timed": 1} and len(st["gathered_bytes_per_rank"]) == 2
+        st = j["strong_1024"]
+        assert st["gathers"] == want and len(st["gathered_bytes_per_rank"]) == 2
     else:
         assert "strong_1024" not in j
 
@@ -146,12 +155,12 @@ def test_bench_cfg4_shards_files_over_ranks_and_checks_itself(world, extra, tota
     env = _clean_env()
     env["IFHIP_BENCH_DRYRUN_ONE_GPU"] = "1"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg4", "--gpus", str(world), "--steps", "2", "--warmup", "1",
-           "--batches-in-flight", "2", "--selfcheck", "--no-cpu-baseline"] + extra
+           "--batches-in-flight", "2", "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == world and j["config"]["total_files"] == total and "cfg4" in j["config"]["workload"], j["config"]
-    assert j["config"]["gathers"] == {"warmup": 1, "timed": 1} and "failed" not in j["config"]["gather"]
+    assert j["config"]["gathers"] == {"warmup": 1, "timed": 2} and "failed" not in j["config"]["gather"]      # one per batch
     assert j["config"]["one_call_chain"] is True and j["config"]["batches_in_flight"] == 2
     assert j["parity_checked"]["equal"] is True and j["parity_checked"]["frames"] == 2
     assert j["selfcheck"] == {"ranks": world, "first_frame_of_every_rank_equal": True, "ranks_that_differ": []}
@@ -163,8 +172,8 @@ def test_bench_selfcheck_and_parity_stamp_of_the_default_workload():
     env = _clean_env()
     env["IFHIP_BENCH_DRYRUN_ONE_GPU"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "6", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-strong-field", "--selfcheck"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-strong-field", "--no-selfcheck"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["parity_checked"]["equal"] is True and j["parity_checked"]["which"] == [0, 5]
-    assert j["selfcheck"]["first_frame_of_every_rank_equal"] is True and j["selfcheck"]["ranks"] == 2
+    assert "selfcheck" not in j                                      # (--no-selfcheck skips what is otherwise on for N > 1)
