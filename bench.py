@@ -604,9 +604,12 @@ def parse_args(argv=None):
                     help="N > 1: cap on RCCL's channels (= workgroups of its kernels; NCCL_MAX_NCHANNELS / NCCL_MAX_P2P_NCHANNELS, set "
                          "before the process group is made unless the environment already names them).  7 peers x 20 MB per batch "
                          "need one channel each; the default RCCL set-up would take tens of CUs from a grid that wants all 256")
-    ap.add_argument("--reserve-cus", type=int, default=None,
+    ap.add_argument("--reserve-cus", default="auto",
                     help="N > 1 with --gather every: CUs the resample launches leave to the gather's workgroups "
-                         "(ifhip_set_cu_budget(256 - this); default: --rccl-channels)")
+                         "(ifhip_set_cu_budget(256 - this)).  auto (default): the warm-up measures a few batches WITH their gathers at 0 "
+                         "and at --rccl-channels reserved CUs and the timed region uses the faster (an RCCL workgroup cannot share a CU "
+                         "with a resample workgroup -- LDS and registers -- so an unreserved grid of exactly 256 workgroups waits for the "
+                         "gather's CUs; a reserved one runs finer bands: profiles/r6_gather_overlap_emulation.jsonl has both sides)")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS) + ["cfg4"])
     ap.add_argument("--batches-in-flight", type=int, default=2, help="--workload cfg4: host threads / HIP streams, each decoding its batches of files one after the other")
@@ -698,9 +701,12 @@ def main():
             os.environ.setdefault("NCCL_MIN_P2P_NCHANNELS", "1")
             rccl_env = {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_MAX_P2P_NCHANNELS", "NCCL_MIN_P2P_NCHANNELS")}
             dist.init_process_group("nccl", device_id=dev)
-    reserve_cus = 0
+    reserve_cus, reserve_candidates = 0, []
     if distributed and args.gather == "every":
-        reserve_cus = max(0, min(128, args.rccl_channels if args.reserve_cus is None else args.reserve_cus))
+        if args.reserve_cus == "auto":
+            reserve_candidates = [0, max(1, min(128, args.rccl_channels))]
+        else:
+            reserve_cus = max(0, min(128, int(args.reserve_cus)))
     if args.workload == "cfg4":
         run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun, cfg4_inputs, rccl_env)
         if distributed:
@@ -806,6 +812,7 @@ def main():
             self.pending = [None, None]
             self.host_copy = [None, None]                  # (dry run: the payload on the host while gloo gathers it)
             self.note = gather_note
+            self.reserve, self.tuned = reserve_cus, {}     # CUs left to the gather's workgroups; ms per batch measured at each candidate
             self.gather_ok = True
             self.last = 0                                   # parity of the last step run (which canvas / gather buffer holds its outputs)
 
@@ -891,7 +898,7 @@ def main():
         def timed(self, steps, phase):
             """`steps` batches between barriers -> seconds on this rank.  phase None: no gathers at all."""
             # while gathers run beside the kernels the launches plan for the CUs RCCL's workgroups leave them
-            _native.set_cu_budget(256 - reserve_cus if (phase is not None and overlapped and reserve_cus) else 0)
+            _native.set_cu_budget(256 - self.reserve if (phase is not None and overlapped and self.reserve) else 0)
             if distributed:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -916,6 +923,12 @@ def main():
             for i in range(warmup):
                 self.step(i, phase="warmup")                # RCCL sets its peer-to-peer channels up lazily on the first send / recv
             self.sync_all()                                 # between two ranks (tens of ms): the warm-up steps gather as the timed ones do
+            if overlapped and reserve_candidates:           # --reserve-cus auto: a few batches with their gathers at each setting
+                k = max(2, min(steps, 10))
+                for r in reserve_candidates:
+                    self.reserve = r
+                    self.tuned[r] = round(max_over_ranks(self.timed(k, "warmup")[0], dev) / k * 1e3, 4)
+                self.reserve = min(self.tuned, key=self.tuned.get)      # (the same on every rank: the times are maxima over the ranks)
             if mode == "final":
                 self.gather_step(max(warmup, 1) - 1, "warmup", blocking=True)
             elapsed, t_steps = self.timed(steps, "timed")
@@ -944,6 +957,7 @@ def main():
     views, chain = (None, job.chain) if pyramid else (job.views, None)
     info, plan = (None, None) if pyramid else (job.info, job.plan)
     gather_note = job.note
+    job_reserve, job_tuned = job.reserve, {str(k): v for k, v in job.tuned.items()}
     main_gather_calls = dict(gather_calls)
 
     strong = None
@@ -957,7 +971,8 @@ def main():
                   "value": round(args.total_frames * in_w * in_h / 1e6 * s_steps / s_elapsed, 1),
                   "value_without_gather": round(args.total_frames * in_w * in_h / 1e6 * s_steps / s_compute, 1),
                   "gather_ms": round((s_elapsed - s_compute) / s_steps * 1e3, 4), "unit": "MP/s", "scaling": "strong", "gather": sj.note,
-                  "gathers": dict(gather_calls),
+                  "gathers": dict(gather_calls), "reserved_cus_while_gathering": sj.reserve if overlapped else 0,
+                  "reserve_cus_tried_ms_per_batch": {str(k): v for k, v in sj.tuned.items()} or None,
                   **({"gathered_bytes_per_rank": sj.gathered_sizes} if files_out else {}),
                   "what": f"north_star job: a batch of {args.total_frames} images cut into {world} contiguous blocks, same kernel, same timing "
                           f"rule: ms_per_step = one batch INCLUDING its gather to rank 0 (one gather per batch; `gathers.timed` = steps), "
@@ -1054,7 +1069,8 @@ def main():
                        "gathers": main_gather_calls, "gather_mode": mode,
                        "gather_ms_is": ("per step: (time of the steps with their gathers - time of the same steps without) / steps" if mode == "every"
                                         else "the one gather at the end of the timed region"),
-                       "rccl_channels": rccl_env, "reserved_cus_while_gathering": reserve_cus if overlapped else 0,
+                       "rccl_channels": rccl_env, "reserved_cus_while_gathering": job_reserve if overlapped else 0,
+                       "reserve_cus_tried_ms_per_batch": job_tuned or None,
                        "rccl_ranks": dist.get_world_size() if distributed else 1,
                        "backend": (dist.get_backend() if distributed else "none"), "ranks": ranks_info},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",

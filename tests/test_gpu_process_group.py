@@ -116,8 +116,12 @@ def test_bench_launches_its_own_ranks(extra, scaling, total):
     assert j["value"] > 0 and j["roofline"]["frac"] > 0 and j["roofline"]["frac_timed"] > 0
     final = "final" in extra
     # every batch is followed by its gather (the warm-up steps too: RCCL's lazy channel set-up is not timed)
-    want = {"warmup": 1, "timed": 1 if final else steps}
+    tuned = not final and "--workload" not in extra                  # --reserve-cus auto: 3 more warm-up batches at each of its two settings
+    want = {"warmup": 1 + (6 if tuned else 0), "timed": 1 if final else steps}
     assert j["config"]["gathers"] == want and j["config"]["gather_mode"] == ("final" if final else "every"), j["config"]
+    if tuned:
+        tried = j["config"]["reserve_cus_tried_ms_per_batch"]
+        assert sorted(tried) == ["0", "8"] and j["config"]["reserved_cus_while_gathering"] == int(min(tried, key=tried.get)), j["config"]
     assert j["config"]["rccl_ranks"] == 2 and len(j["config"]["ranks"]) == 2 and j["config"]["ranks"][1]["rank"] == 1
     assert j["value_without_gather"] > 0 and j["steps"] == steps
     if "--workload" not in extra:                                    # checked without --selfcheck on the command line
