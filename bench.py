@@ -476,6 +476,10 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun, inputs, rc
                                  "chain's step time, entropy decode included"},
             "parity_checked": parity,
         }
+        try:
+            out["roofline_entropy"] = cfg4_entropy_roofline(files, n, ent_ms)
+        except Exception as e:  # noqa: BLE001
+            out["roofline_entropy"] = {"bound": "issue", "frac": None, "error": f"{type(e).__name__}: {e}"}
         if selfcheck is not None:
             out["selfcheck"] = selfcheck
         if world == 1 and not args.no_cpu_baseline:
@@ -484,6 +488,53 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun, inputs, rc
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "MP/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
+
+
+def cfg4_entropy_roofline(files, n_files, ent_ms):
+    """The yardstick of the entropy stage (92 % of a cfg4 step): instruction issue, not HBM.  Symbols and table reads of a sample
+    of the run's files (host walk, ifhip_jpeg_debug_scan_report) x the wave-instructions each pass issues per 64 lane-steps
+    (static: profiles/entropy_issue_model.json, SQ counters of this build's kernels) against what the chip's SIMDs can issue
+    in the measured time of the stage."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from imageflow_amd import _native
+
+    class Report(C.Structure):
+        _fields_ = ([(k, C.c_uint32) for k in ("segments", "sub_sequences", "scan_complete", "pool_entries", "pool_entries_used", "prefixes_left_to_search",
+                                               "pair_entries", "segments_with_wrong_block_count", "segments_with_invalid_codes", "pair_walk_mismatches",
+                                               "count_walk_mismatches")]
+                    + [("symbols", C.c_uint64), ("table_reads_with_pairs", C.c_uint64), ("blocks", C.c_uint64), ("dc_sum", C.c_int32 * 3), ("dc_last_segment", C.c_int32 * 3)])
+    L = _native.lib()
+    L.ifhip_jpeg_debug_scan_report.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Report)]
+    sample = files[:min(len(files), 16)]                 # gradient and noise files alternate: an even sample has the run's mix
+
+    def one(f):
+        r = Report()
+        _native.check(L.ifhip_jpeg_debug_scan_report(f, len(f), C.byref(r)))
+        return int(r.symbols), int(r.table_reads_with_pairs), int(r.sub_sequences)
+    with ThreadPoolExecutor(8) as ex:
+        rows = list(ex.map(one, sample))
+    scale = n_files / len(sample)
+    symbols, reads, subs = (sum(r[k] for r in rows) * scale for k in range(3))
+    model = json.load(open(os.path.join(ROOT, "profiles", "entropy_issue_model.json")))
+    per = model["per_64_lane_steps"]
+    steps = {"round": 2.0 * reads, "count": reads, "write": symbols}
+    simds, clock = 256 * 4, 2.4e9
+    valu_wave_instr = sum(per[k]["valu"] * steps[k] / 64.0 for k in steps)
+    lane_steps = sum(steps.values())
+    issue_s = valu_wave_instr * 2.0 / (simds * clock)                     # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles
+    achieved = lane_steps / (ent_ms * 1e-3)
+    return {"bound": "issue", "unit": "G lane-steps/s", "achieved": round(achieved / 1e9, 1), "peak": round(lane_steps / issue_s / 1e9, 1),
+            "frac": round(issue_s / (ent_ms * 1e-3), 4), "kernel_ms": round(ent_ms, 4),
+            "symbols": int(symbols), "sub_sequences": int(subs), "walks": 4, "table_reads_per_symbol_with_pair_entries": round(reads / symbols, 3),
+            "lane_steps": {k: int(v) for k, v in steps.items()},
+            "valu_wave_instructions_per_64_lane_steps": {k: per[k]["valu"] for k in steps},
+            "instr_per_symbol_all_walks": round(sum((per[k]["valu"] + per[k]["salu"] + per[k]["lds"]) * steps[k] for k in steps) / symbols, 1),
+            "sampled_files": len(sample), "model_source": "static: profiles/entropy_issue_model.json (" + model["source"] + ")",
+            "what": "the entropy decodes of one step, batches one after the other (hipEvents): four dense bit-serial walks of every sub-sequence "
+                    "(speculative, from the predecessor's exit, count, write; the first three read pair entries).  frac = VALU issue cycles the "
+                    "walks need on 1 024 SIMD-32s at 2.4 GHz / the measured time: what is left is dependent-chain latency (one table read per step), "
+                    "lanes idle in divergent waves (43 - 50 of 64 active) and the write pass's 2 waves per SIMD"}
 
 
 def cfg4_parity(torch, files, out_all, which):
