@@ -8,21 +8,27 @@ resident, each resized to 200x200 with Robidoux in linear light (ReplaceSelf can
 JPEG decode).  One "step" = one pass of the hot path over the rank's whole batch.
 
 Multi-GPU: images are independent, so frame i of a job belongs to rank floor(i * N / total)
-(imageflow_amd/sharding.py) and nothing is exchanged on the data path; the job's only collective is the RCCL gather of
-the finished outputs to rank 0, issued once inside the timed region -- after the same gather (same tensors, same call) ran
-once during warm-up, so that RCCL's lazy peer-to-peer set-up is not what gets timed.  The line carries `gather_ms`,
-`value_without_gather` and, for the default workload, `strong_1024`: the north_star job (1 024 images cut into N blocks)
-measured the same way in the same run, so one series of runs at N = 1, 2, 4, 8 gives both scaling curves.
+(imageflow_amd/sharding.py) and nothing is exchanged on the data path; the only collective is the RCCL gather of a batch's
+finished outputs to rank 0 -- ONE PER BATCH (= per step), asynchronous and double buffered so that the gather of batch k runs
+beside the kernel of batch k + 1 (--gather every, the N > 1 default; RCCL's channels are capped and the resample grid is sized
+for the CUs the gather leaves, or not: --reserve-cus auto measures both in the warm-up).  value = frames /
+time of the steps WITH their gathers; the line also carries `value_without_gather` (a second timed loop without any),
+`gather_ms` (what a gather adds per batch after overlap) and, for the default workload, `strong_1024`: the north_star job (a
+1 024-image batch cut into N blocks) measured the same way in the same run, so one series of runs at N = 1, 2, 4, 8 gives both
+scaling curves.  The warm-up steps gather as the timed ones do (RCCL's lazy peer-to-peer set-up is never timed).
   --scaling weak   (default) every rank owns --frames frames (256): per-GPU work fixed.
   --scaling strong the job is --total-frames frames (1024, the north_star batch) cut into N contiguous blocks.
 `--gpus N` with no torch.distributed environment re-executes this file under `python -m torch.distributed.run` with N
 ranks; under a launcher, WORLD_SIZE must equal --gpus (anything else is an error, never a silent 1-GPU run).
 
+The default run (N = 1, cfg2) also measures BASELINE configs 5, 3 and 4 -- child runs of this file with --workload, reduced step
+counts -- and reports them as `other_configs`: time per step, the kernel-timed roofline fraction, the parity stamp, the workload.
+
 --workload cfg3 is BASELINE config 3 as a job: the export_4_sizes pyramid 3840x2160 -> 1600x900 -> {1200x675 -> 400x225,
 800x450} (imageflow_tool/src/self_test.rs:185-198), four chained launches per batch, 58 737 600 algorithmic bytes per
 image, 128 frames per GPU by default (1024 images over 8 GPUs).  --outputs files (default): every output goes through the
 job's encoder as in the reference (`libjpeg_turbo` quality 90: forward pixel stage + entropy coder on the device) and
-the final gather ships the FILES -- ~0.26 bytes per pixel instead of 4 (1.38 GB of BGRA per rank became ~90 MB);
+the batch's gather ships the FILES -- ~0.26 bytes per pixel instead of 4 (1.38 GB of BGRA per rank became ~90 MB);
 --outputs bgra keeps the round-3 form (raw levels gathered).  `roofline` stays the four resample launches; the line
 also carries what a step costs without the encoders.
 
@@ -34,14 +40,14 @@ codecs/mozjpeg_decoder.rs:295-420,588-618) -> 800x450 Robidoux (flow/nodes/scale
 stream each, a thread's batches one after the other).  The compressed scans are resident in HBM
 (un-stuffed, as the entropy stage reads them) when the timed region starts.  value = source megapixels through the WHOLE
 chain per second; `roofline` is the pixel stage + resize call alone on SURVEY 8d's 26 323 584 bytes per image (the entropy
-walk is latency-bound bit-serial work: HBM is not its yardstick); cpu_baseline = libjpeg-turbo (Pillow) DCT-domain 1/2
-decode + resize on all host cores.  Images are sharded in contiguous blocks like every other workload and the finished
-800x450 outputs are gathered once, after the last step.
+walk is bit-serial work: its yardstick is instruction issue, `roofline_entropy`); cpu_baseline = libjpeg-turbo (Pillow)
+DCT-domain 1/2 decode + resize on all host cores.  Images are sharded in contiguous blocks like every other workload and the
+finished 800x450 outputs are gathered behind every step.
 
 Prints ONE JSON line (rank 0).  value = source megapixels resized per second over all ranks, inputs already in HBM.
 After the timed region (never inside it) rank 0 renders frames of the last step's output again on the CPU oracle and
-compares: `parity_checked` (BASELINE config 2: "... bit-exact check vs CPU").  --selfcheck (N > 1): every rank's first
-gathered frame is compared with one rendered locally on rank 0 -- catches a gather that lands at the wrong offset.
+compares: `parity_checked` (BASELINE config 2: "... bit-exact check vs CPU").  N > 1 (on unless --no-selfcheck): every rank's
+first gathered frame is compared with one rendered locally on rank 0 -- catches a gather that lands at the wrong offset.
 """
 import argparse
 import json
@@ -653,7 +659,7 @@ def parse_args(argv=None):
                          "not the north_star batch time); none: results stay sharded")
     ap.add_argument("--rccl-channels", type=int, default=8,
                     help="N > 1: cap on RCCL's channels (= workgroups of its kernels; NCCL_MAX_NCHANNELS / NCCL_MAX_P2P_NCHANNELS, set "
-                         "before the process group is made unless the environment already names them).  7 peers x 20 MB per batch "
+                         "before the process group is made unless the environment already names them; 0: leave RCCL alone).  7 peers x 20 MB per batch "
                          "need one channel each; the default RCCL set-up would take tens of CUs from a grid that wants all 256")
     ap.add_argument("--reserve-cus", default="auto",
                     help="N > 1 with --gather every: CUs the resample launches leave to the gather's workgroups "
@@ -745,17 +751,17 @@ def main():
             # RCCL's kernels take one workgroup per channel; its default set-up on an xGMI node opens dozens.  The job's only
             # collective is a gather of 20 MB per peer and batch: a handful of channels move that, and every CU RCCL does not
             # take stays with the resample grid (one workgroup per CU).  Names the environment already sets are left alone.
-            ch = str(max(1, args.rccl_channels))
-            for k in ("NCCL_MAX_NCHANNELS", "NCCL_MAX_P2P_NCHANNELS"):
-                os.environ.setdefault(k, ch)
-            os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
-            os.environ.setdefault("NCCL_MIN_P2P_NCHANNELS", "1")
+            if args.rccl_channels > 0:                       # (--rccl-channels 0: RCCL's own choice)
+                for k in ("NCCL_MAX_NCHANNELS", "NCCL_MAX_P2P_NCHANNELS"):
+                    os.environ.setdefault(k, str(args.rccl_channels))
+                os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
+                os.environ.setdefault("NCCL_MIN_P2P_NCHANNELS", "1")
             rccl_env = {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_MAX_P2P_NCHANNELS", "NCCL_MIN_P2P_NCHANNELS")}
             dist.init_process_group("nccl", device_id=dev)
     reserve_cus, reserve_candidates = 0, []
     if distributed and args.gather == "every":
         if args.reserve_cus == "auto":
-            reserve_candidates = [0, max(1, min(128, args.rccl_channels))]
+            reserve_candidates = [0, max(1, min(128, args.rccl_channels or 8))]
         else:
             reserve_cus = max(0, min(128, int(args.reserve_cus)))
     if args.workload == "cfg4":
