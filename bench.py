@@ -296,7 +296,7 @@ def cfg4_cpu_baseline(files, sample_seconds=12.0):
             "published_reference_decode_MPps_one_core": 50.1}
 
 
-def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun, inputs, rccl_env):
+def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun, inputs, rccl_env, grouped):
     """BASELINE config 4 (see the module docstring): files -> entropy decode -> 4/8 pixel stage -> 800x450, sharded."""
     import threading
 
@@ -306,7 +306,7 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun, inputs, rc
     from imageflow_amd.graphics.bitmaps import Bitmap
     from imageflow_amd.graphics.scaling import ScaleAndRenderParams
     from imageflow_amd.sharding import gather_to_root, max_over_ranks, shard_range
-    distributed = world > 1
+    distributed = grouped
     w, h, ow, oh = CFG4["in_w"], CFG4["in_h"], CFG4["out_w"], CFG4["out_h"]
     if args.scaling == "strong":
         total = args.total_frames
@@ -702,12 +702,17 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to "
                          f"measure a different job than the one asked for")
+    # IFHIP_BENCH_ONE_RANK_RCCL=1: development aid -- a process group of ONE rank over RCCL, so that the N > 1 code path (per-batch
+    # asynchronous gathers, their stream waits, the reserve tuning, the selfcheck) runs against the real backend on a box with one
+    # GPU (tests/test_gpu_process_group.py; the gather of a single rank moves nothing between devices: numbers mean nothing)
+    one_rank_rccl = world == 1 and os.environ.get("IFHIP_BENCH_ONE_RANK_RCCL") == "1" and "MASTER_PORT" in os.environ
+    grouped = world > 1 or one_rank_rccl
     if args.gather is None:
-        args.gather = "every" if world > 1 else "none"
-    if args.no_gather or world == 1:
+        args.gather = "every" if grouped else "none"
+    if args.no_gather or not grouped:
         args.gather = "none"
     if args.selfcheck is None:
-        args.selfcheck = world > 1 and args.gather != "none"
+        args.selfcheck = grouped and args.gather != "none"
     # cfg4's input files are written on the host BEFORE the device is touched (the writers are forked workers)
     cfg4_inputs = None
     if args.workload == "cfg4":
@@ -741,7 +746,7 @@ def main():
         raise SystemExit(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    distributed = grouped
     rccl_env = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -765,7 +770,7 @@ def main():
         else:
             reserve_cus = max(0, min(128, int(args.reserve_cus)))
     if args.workload == "cfg4":
-        run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun, cfg4_inputs, rccl_env)
+        run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun, cfg4_inputs, rccl_env, grouped)
         if distributed:
             dist.destroy_process_group()
         return

@@ -181,3 +181,64 @@ def test_bench_selfcheck_and_parity_stamp_of_the_default_workload():
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["parity_checked"]["equal"] is True and j["parity_checked"]["which"] == [0, 5]
     assert "selfcheck" not in j                                      # (--no-selfcheck skips what is otherwise on for N > 1)
+
+
+def test_rccl_itself_runs_the_gathers_on_a_one_rank_group():
+    """One GPU per test box: a group of ONE rank is the only way RCCL (backend "nccl") executes here at all.  The library loads,
+    a communicator is made under the channel caps bench.py sets, and the three calls of the N > 1 path -- the rooted gather of a
+    device canvas (blocking and asynchronous), the byte gather of a packed file message, the max over ranks -- run on device
+    tensors and deliver the bytes."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["IFHIP_ROOT"])
+from imageflow_amd.sharding import gather_bytes_to_root, gather_to_root, max_over_ranks
+for k in ("NCCL_MAX_NCHANNELS", "NCCL_MAX_P2P_NCHANNELS"):
+    os.environ.setdefault(k, "8")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+local = torch.arange(3 * 166400, dtype=torch.int64, device=dev).remainder(251).to(torch.uint8).view(3, 166400)
+_, out = gather_to_root(local, 0)
+assert out.shape == (1, 3, 166400) and torch.equal(out[0], local)
+buf = torch.zeros((1, 3, 166400), dtype=torch.uint8, device=dev)
+work, out2 = gather_to_root(local, 0, async_op=True, out=buf)
+work.wait()
+torch.cuda.synchronize()
+assert out2 is buf and torch.equal(buf[0], local)
+msg = local.view(-1)[:100003]
+sizes, parts = gather_bytes_to_root(msg, 0)
+assert sizes == [100003] and torch.equal(parts[0], msg)
+assert abs(max_over_ranks(1.25, dev) - 1.25) < 1e-12
+dist.barrier()
+dist.destroy_process_group()
+print("rccl one-rank ok")
+'''
+    env = _clean_env()
+    env.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_PORT": str(_free_port()), "IFHIP_ROOT": ROOT})
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("extra", [["--frames", "12", "--total-frames", "16"], ["--workload", "cfg3", "--frames", "3", "--total-frames", "4"]])
+def test_bench_runs_its_per_batch_gathers_over_rccl_on_a_one_rank_group(extra):
+    """bench.py's N > 1 code path against the REAL backend (IFHIP_BENCH_ONE_RANK_RCCL: a group of one rank over RCCL): every
+    step's batch followed by its asynchronous gather, the stream waits that let step i + 2 reuse a canvas, the reserve tuning,
+    the selfcheck on the gathered frame -- with device tensors and `dist.gather` on backend nccl."""
+    env = _clean_env()
+    env.update({"IFHIP_BENCH_ONE_RANK_RCCL": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_PORT": str(_free_port())})
+    steps = 4
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline",
+                        "--no-other-configs"] + extra, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = j["config"]
+    assert c["backend"] == "nccl" and c["rccl_ranks"] == 1 and c["gather_mode"] == "every" and "failed" not in c["gather"], c
+    assert c["gathers"]["timed"] == steps and c["rccl_channels"]["NCCL_MAX_NCHANNELS"] == "8", c
+    assert j["parity_checked"]["equal"] is True
+    if "--workload" not in extra:
+        assert j["selfcheck"]["first_frame_of_every_rank_equal"] is True
+        assert sorted(c["reserve_cus_tried_ms_per_batch"]) == ["0", "8"]
+        assert j["strong_1024"]["gathers"]["timed"] == j["strong_1024"]["steps"]
+    else:
+        assert len(c["gathered_bytes_per_rank"]) == 1 and c["gathered_bytes_per_rank"][0] > 0
