@@ -107,6 +107,7 @@ struct EntropyArgs {
     const uint32_t* words;                           // un-stuffed scan data, big-endian words, segments 1024-bit aligned
     const Segment* segs;
     const uint32_t* sub_seg;                         // segment of every sub-sequence
+    const uint32_t* wg_order;                        // synchronisation launch: workgroup blockIdx.x works on this block of kOwnSubs sub-sequences
     const FastTabs* ftabs;                           // [image]
     const FastTabs* ptabs;                           // [image] the same tables with pair entries, for the synchronisation rounds
     const FastTabs* ctabs;                           // [image] pair entries in the AC tables only, for the count pass (it reads the DC symbols)
@@ -366,7 +367,18 @@ __global__ void __launch_bounds__(kSyncLanes) entropy_round_kernel(const Entropy
     __shared__ uint2 st[kSyncLanes];                                 // .x exit state, .y the entry state it was decoded from (written as a pair)
     __shared__ uint16_t endinfo[kSyncLanes], work[kSyncLanes];       // end - t * 1024 (| kChase); sub-sequences to decode this iteration
     __shared__ uint32_t wave_cnt[kSyncLanes / 64u];
-    const uint32_t own_sub = blockIdx.x * kOwnSubs, first_sub = own_sub - kWarmLanes;     // (wraps for workgroup 0: those lanes are off)
+    // Workgroups are dispatched in blockIdx order and the launch lasts until its slowest one is done.  Their times differ by
+    // what the fixpoint needs -- typically 3 iterations on a smooth image and 8 on a noisy one, ~19 us each -- but the LONGEST
+    // correction chains of a batch (24 - 50 iterations on BASELINE cfg4's batches) sit in the SMOOTH images: where every block
+    // looks like its neighbour a decoder that is bit-synchronous but one block out of phase in the MCU stays out of phase,
+    // while noise throws it out and lets it re-synchronise.  One such chain that starts in the last dispatch round sets the
+    // launch's length (measured: 1 425 us with a 50-iteration workgroup dispatched at 506 us, where perfect packing is 575).  So
+    // the blocks of the images with the SMALLEST scans are dispatched first: their rare long chains run beside everybody else
+    // (the same two batches: 848 -> 724 and 1 425 -> 946 us per launch; largest-first made it 1 016 and 1 409;
+    // profiles/r6_entropy_dispatch_order.txt).  The true state crosses such a region one sub-sequence per iteration while
+    // everything behind the front is decoded again from entries that are still wrong, so these iterations are lane walks of many
+    // sub-sequences, not lone wave walks: letting a lone chain's wave follow it link by link (measured, round 6) met 3 of 50.
+    const uint32_t own_sub = a.wg_order[blockIdx.x] * kOwnSubs, first_sub = own_sub - kWarmLanes;     // (wraps for block 0: those lanes are off)
     const uint32_t t = threadIdx.x, s = first_sub + t, lane = t & 63u, wave = t >> 6;
     if (a.round == 0u && blockIdx.x == 0u && t < kFlagWords) a.changed[t] = 0u;     // the flags of this decode (later launches set them)
     const uint32_t t0 = a.round == 0u ? 0u : kWarmLanes;             // first lane at work
@@ -1386,7 +1398,8 @@ static int create_prepared_impl(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* c
     const size_t o_segs = 0, o_sub = aligned(o_segs + std::max<size_t>(n_segs, 1) * sizeof(Segment)),
                  o_ftabs = aligned(o_sub + std::max<size_t>(subs_in_batch, 1) * sizeof(uint32_t)), o_ptabs = aligned(o_ftabs + n_images * sizeof(FastTabs)),
                  o_ctabs = aligned(o_ptabs + n_images * sizeof(FastTabs)), o_stabs = aligned(o_ctabs + n_images * sizeof(FastTabs)),
-                 table_bytes = aligned(o_stabs + static_cast<size_t>(n_images) * 6u * sizeof(SearchTab));
+                 o_order = aligned(o_stabs + static_cast<size_t>(n_images) * 6u * sizeof(SearchTab)),
+                 table_bytes = aligned(o_order + ((subs_in_batch + kOwnSubs - 1u) / kOwnSubs + 1u) * sizeof(uint32_t));
     size_t stage_bytes = 4096;                                           // powers of two: few size classes in the pinned cache
     while (stage_bytes < table_bytes) stage_bytes *= 2;
     if (cached_host_malloc(reinterpret_cast<void**>(&e->h_tables), stage_bytes) != 0)
@@ -1398,6 +1411,7 @@ static int create_prepared_impl(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* c
     FastTabs* const ptabs = reinterpret_cast<FastTabs*>(stage + o_ptabs);
     FastTabs* const ctabs = reinterpret_cast<FastTabs*>(stage + o_ctabs);
     SearchTab* const stabs = reinterpret_cast<SearchTab*>(stage + o_stabs);
+    uint32_t* const wg_order = reinterpret_cast<uint32_t*>(stage + o_order);
     std::vector<uint32_t> first_sub_of(n_images);
     uint64_t total_subs = 0;
     size_t seg_count = 0;
@@ -1430,6 +1444,19 @@ static int create_prepared_impl(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* c
         }
     }
     const size_t n_words = static_cast<size_t>(total_subs) * kSubWords + 64u;  // + lookahead slack behind the last segment
+    {   // dispatch order of the synchronisation launch (see entropy_round_kernel): blocks of the smallest scans first, an image's
+        // blocks in their own order
+        const uint32_t n_wg = static_cast<uint32_t>((total_subs + kOwnSubs - 1u) / kOwnSubs);
+        std::vector<uint32_t> key(n_wg);
+        uint32_t img = 0;
+        for (uint32_t w = 0; w < n_wg; ++w) {
+            const uint64_t s0 = static_cast<uint64_t>(w) * kOwnSubs;
+            while (img + 1u < n_images && first_sub_of[img + 1u] <= s0) ++img;
+            key[w] = prep[img]->n_sub;
+            wg_order[w] = w;
+        }
+        std::stable_sort(wg_order, wg_order + n_wg, [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
+    }
     const ParsedJpeg& F = e->first;
     EntropyArgs& a = e->a;
     std::memset(&a, 0, sizeof a);
@@ -1485,6 +1512,7 @@ static int create_prepared_impl(ifhip_jpeg_entropy** out, ifhip_jpeg_prepared* c
     d_segs = reinterpret_cast<Segment*>(d_tables + o_segs); d_sub = reinterpret_cast<uint32_t*>(d_tables + o_sub);
     d_ftabs = reinterpret_cast<FastTabs*>(d_tables + o_ftabs); d_ptabs = reinterpret_cast<FastTabs*>(d_tables + o_ptabs);
     d_ctabs = reinterpret_cast<FastTabs*>(d_tables + o_ctabs); d_stabs = reinterpret_cast<SearchTab*>(d_tables + o_stabs);
+    a.wg_order = reinterpret_cast<const uint32_t*>(d_tables + o_order);
     a.words = d_words; a.segs = d_segs; a.sub_seg = d_sub; a.ftabs = d_ftabs; a.ptabs = d_ptabs; a.ctabs = d_ctabs; a.stabs = d_stabs;
     for (int b = 0; b < 2; ++b) {
         if ((rc = dev_alloc<uint32_t>(e.get(), &a.exit_p[b], a.n_sub))) return rc;

@@ -392,3 +392,17 @@ def test_two_column_groups_only_where_they_save_a_third_of_the_taps():
     assert ResamplePlan(1600, 90, 1200, 68, Filter.Robidoux, 0.0).horizontal_groups() == (3, 4)      # 12 taps or 8
     assert ResamplePlan(1200, 68, 400, 23, Filter.Robidoux, 0.0).horizontal_groups() == (4, 0)       # 16 or 12: stays
     assert ResamplePlan(3840, 216, 1600, 90, Filter.Robidoux, 0.0).horizontal_groups() == (3, 0)     # 12 or 12
+
+
+@pytest.mark.parametrize("budget", [248, 200, 17, 1])
+def test_cu_budget_changes_the_launch_geometry_not_the_pixels(budget):
+    """ifhip_set_cu_budget makes choose_bands plan for fewer CUs (finer bands, more halo rows re-read): BGRA8 and the f32 working
+    buffer stay the oracle's, for a thumbnail shape, a moderate ratio with several frames per workgroup and a strip-split source."""
+    from imageflow_amd import _native
+    _native.set_cu_budget(budget)
+    try:
+        run_case(960, 540, 50, 50, n=5, seed=budget)
+        run_case(400, 225, 300, 169, n=7, alpha=True, compose=BitmapCompositing.BlendWithMatte, matte=0xFF203040, seed=budget + 1)
+        run_case(4400, 120, 900, 25, n=2, seed=budget + 2)
+    finally:
+        _native.set_cu_budget(0)

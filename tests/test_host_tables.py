@@ -184,3 +184,16 @@ def test_the_library_reads_no_environment_variable():
     assert L.ifhip_debug_set(None, b"1") != 0 and L.ifhip_debug_set(b"", b"1") != 0
     _native.debug_set("no_such_switch", "1")
     _native.debug_set("no_such_switch", None)
+
+
+def test_cu_budget_is_validated_on_the_host():
+    """ifhip_set_cu_budget (the CUs the resample launches plan for while a host overlaps other work with them): host-side state,
+    0 = all, anything above the device's 256 CUs is refused with the reference's InvalidArgument kind."""
+    from imageflow_amd import _native
+    from imageflow_amd.errors import ErrorKind, FlowError
+    for ok in (0, 1, 248, 256, 0):
+        _native.set_cu_budget(ok)
+    with pytest.raises(FlowError) as e:
+        _native.set_cu_budget(257)
+    assert e.value.kind == ErrorKind.InvalidArgument
+    _native.set_cu_budget(0)
