@@ -677,12 +677,18 @@ struct DecodeCoalescer {
                 while (queue.size() < wait_for && leader_cv.wait_until(lk, until) != std::cv_status::timeout) {}
             }
             // this thread's own request first, then whoever shares its geometry, in arrival order
-            // Whatever leaves this block early (a bad_alloc while the lists are built) hands the leadership on: a leader
-            // flag left set would park every later job of the device on its own condition variable for good.
+            // Whatever leaves this block early (a bad_alloc while the lists are built) hands the leadership on and takes this
+            // request out of the queue: a leader flag left set would park every later job of the device on its own condition
+            // variable for good, and the request itself dies with its caller's frame.
             struct Leading {
-                DecodeCoalescer& c; bool armed = true;
-                ~Leading() { if (armed) { c.leader_active = false; c.wake_next_leader(); } }      // (mu held on every path that gets here armed)
-            } leading{*this};
+                DecodeCoalescer& c; DecodeRequest* me; bool armed = true;
+                ~Leading() {                                         // (mu held on every path that gets here armed)
+                    if (!armed) return;
+                    c.queue.erase(std::remove(c.queue.begin(), c.queue.end(), me), c.queue.end());
+                    c.leader_active = false;
+                    c.wake_next_leader();
+                }
+            } leading{*this, &r};
             std::vector<DecodeRequest*> mine{&r}, rest;
             for (DecodeRequest* q : queue)
                 if (q != &r) (mine.size() < kMaxCoalesce && q->same_geometry(r) ? mine : rest).push_back(q);
