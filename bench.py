@@ -428,7 +428,7 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun, inputs, rc
 
     # the pixel stage + resize call alone (SURVEY 8d's unit: coefficient planes in, 800x450 out), hipEvents on its stream,
     # one batch at a time so that nothing else shares the device
-    launches = max(3, min(args.steps, 20))
+    launches = max(10, min(args.steps, 20))
     px_ms, ent_ms = 0.0, 0.0
     for c in ctx:
         with torch.cuda.stream(c["stream"]):
@@ -588,9 +588,9 @@ def cfg4_selfcheck(torch, gathered, total, world, dev, out_all):
 
 
 OTHER_CONFIGS = [        # name, what `bench.py` is asked for (reduced step counts; cfg4 on 64 generated files in batches of 32)
-    ("cfg5", ["--workload", "cfg5", "--steps", "10", "--warmup", "3"]),
-    ("cfg3_job", ["--workload", "cfg3", "--steps", "10", "--warmup", "3"]),
-    ("cfg4", ["--workload", "cfg4", "--frames", "64", "--files-per-batch", "32", "--steps", "6", "--warmup", "2"]),
+    ("cfg5", ["--workload", "cfg5", "--steps", "30", "--warmup", "5"]),
+    ("cfg3_job", ["--workload", "cfg3", "--steps", "40", "--warmup", "5"]),        # (fewer steps: the kernel probe runs before the clocks are up)
+    ("cfg4", ["--workload", "cfg4", "--frames", "64", "--files-per-batch", "32", "--steps", "20", "--warmup", "4"]),
 ]
 
 
@@ -1043,7 +1043,7 @@ def main():
         del sj
 
     # dominant-kernel duration: hipEvents on the launch stream around back-to-back launches of the same op
-    launches = max(5, min(args.steps, 50))
+    launches = max(20, min(args.steps, 50))
     if pyramid:
         level_ms = [time_scale_and_render(s, d, inf, launches=launches, plan=pl) for s, d, inf, pl in chain]
         kernel_ms = sum(level_ms)
