@@ -117,6 +117,37 @@ def make_frames(torch, n, first_index, seed, device, pattern, in_w, in_h):
     return Bitmap(data.view(n, in_h * stride), in_w, in_h, stride, alpha_meaningful=False)
 
 
+def _usable_cpus_now():
+    """CPUs this process may really use: the affinity mask and the cgroup's CPU quota, not the host's logical CPU count (a GPU
+    box of this pool shows 256 logical CPUs to a container that is allowed 16: 256 threads on it measure the scheduler)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                    # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                  # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+_USABLE_CPUS = _usable_cpus_now()        # read at import: once an OpenMP runtime has bound the main thread to its place (OMP_PROC_BIND,
+                                         # set above for the baseline's threads) the affinity mask of this thread is one core
+
+
+def usable_cpus():
+    return _USABLE_CPUS
+
+
 def cpu_baseline(sample_seconds=8.0):
     """The oracle (our C port of the reference's CPU path) timed on the host cores on a bounded sample of cfg2.  The
     Rust reference itself (cargo bench -p imageflow_core --bench bench_graphics -- full_scale_pipeline,
@@ -125,7 +156,7 @@ def cpu_baseline(sample_seconds=8.0):
     from oracle import oracle as O
     from tests import util as U
     in_w, in_h, out_w, out_h = 3840, 2160, 200, 200
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     fr = U.gradient_frames(1, in_w, in_h)
     cst = U.stride_for(out_w)
     can = np.zeros((1, out_h, cst), np.uint8)
@@ -154,10 +185,11 @@ def cpu_baseline(sample_seconds=8.0):
     cargo = shutil.which("cargo")
     ref_tree = os.path.isdir("/root/reference/imageflow_core")
     return {"value": round(mp / total, 2), "unit": "MP/s", "cores": cores, "kind": "port",
-            "single_thread_MPps": round(in_w * in_h / 1e6 / t1, 2),
+            "host_logical_cpus": os.cpu_count(), "single_thread_MPps": round(in_w * in_h / 1e6 / t1, 2),
             "sample": f"{reps} passes over {n} frames 3840x2160->200x200 Robidoux linear (half gradient, half random), "
-                      f"{total:.1f} s wall, oracle/if_oracle.c -O3 x86-64-v3, {cores} OpenMP threads (one frame per thread, "
-                      f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')})",
+                      f"{total:.1f} s wall, oracle/if_oracle.c -O3 x86-64-v3, {cores} OpenMP threads = the CPUs this process may use "
+                      f"(affinity and cgroup quota; the host shows {os.cpu_count()}), one frame per thread, "
+                      f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}",
             "note": "a NAIVE scalar port of the reference's arithmetic (test infrastructure), not a tuned resizer: expect it "
                     ">= 10x below the reference's own SIMD (zenresize) path on the same cores; never a target, never credit",
             "reference_leg": ("cargo present but the reference tree is not on this box" if cargo and not ref_tree else
@@ -245,7 +277,7 @@ def cfg4_files(first_index, n):
     (About half a second of one core per file: written by a pool of forked workers -- numpy and Pillow only, they never
     touch HIP -- so that 128 files take seconds, not a minute; main() makes the files before it initialises the device.)"""
     ks = list(range(first_index, first_index + n))
-    procs = min(len(ks), os.cpu_count() or 1, 32)
+    procs = min(len(ks), usable_cpus(), 32)
     if procs >= 2 and len(ks) >= 4:
         import multiprocessing as mp
         try:
@@ -271,7 +303,7 @@ def cfg4_cpu_baseline(files, sample_seconds=12.0):
     bit-exact stand-in for it: a yardstick for "what the host's cores do with these files", next to the 50.1 MP/s per core
     the reference publishes for its own full decode (benchmarks/c-vs-zen-codecs-2026-04-15-singlethread.txt:17)."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     t0 = time.perf_counter()
     _cfg4_cpu_one(files[0])
     t1 = time.perf_counter() - t0
