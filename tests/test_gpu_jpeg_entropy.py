@@ -87,8 +87,10 @@ def test_files_to_bgra_on_device(golden_dir):
 
 
 def test_large_files_and_convergence():
-    """4K-class inputs (BASELINE cfg4 shape): 2 files of 3840x2160 4:2:0 q85, gradient + noise, no restart markers --
-    ~20 000 sub-sequences each; the decoder must converge in a handful of rounds and match the serial decode."""
+    """4K-class inputs (BASELINE cfg4 shape): files of 3840x2160 4:2:0 q85, gradient + noise, no restart markers -- 7 000 and
+    ~20 000 sub-sequences -- in the order noise, gradient, noise: the synchronisation launch dispatches the smallest scan's
+    blocks first (wg_order), so the dispatch order differs from the batch's; the decoder must converge in a handful of
+    rounds and every image must match the serial decode in ITS place."""
     PIL = pytest.importorskip("PIL.Image")
     w, h = 3840, 2160
     y, x = np.mgrid[0:h, 0:w]
@@ -97,10 +99,11 @@ def test_large_files_and_convergence():
             np.clip(np.stack([128 + 90 * np.sin(x / 9.0), 128 + 90 * np.cos(y / 7.0), 128 + 60 * np.sin((x + y) / 5.0)], -1)
                     + rng.integers(-30, 31, size=(h, w, 3)), 0, 255).astype(np.uint8)]
     files = []
-    for p in pics:
+    for p in (pics[1], pics[0], pics[1][::-1].copy()):
         buf = io.BytesIO()
         PIL.fromarray(p).save(buf, "JPEG", quality=85, subsampling="4:2:0", optimize=False)
         files.append(buf.getvalue())
+    assert len(files[1]) < len(files[0]) // 2
     ent = D.JpegEntropyBatch(files, DEV)
     coef = ent.read_coefficients()
     assert ent.rounds <= 16, ent.rounds                 # typical content re-synchronises within a few symbols
