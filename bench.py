@@ -461,6 +461,9 @@ def run_cfg4(args, torch, dist, world, rank, local_rank, dev, dryrun, inputs, rc
     # the pixel stage + resize call alone (SURVEY 8d's unit: coefficient planes in, 800x450 out), hipEvents on its stream,
     # one batch at a time so that nothing else shares the device
     launches = max(10, min(args.steps, 20))
+    if elapsed < 0.6 and args.steps > 0:               # a reduced run: bring the clocks up before the probe (see the resample workloads' probe)
+        run_steps(min(400, int((0.6 - elapsed) / max(elapsed / args.steps, 1e-4)) + 1))
+        torch.cuda.synchronize()
     px_ms, ent_ms = 0.0, 0.0
     for c in ctx:
         with torch.cuda.stream(c["stream"]):
@@ -619,10 +622,10 @@ def cfg4_selfcheck(torch, gathered, total, world, dev, out_all):
     return {"ranks": world, "first_frame_of_every_rank_equal": not bad, "ranks_that_differ": bad}
 
 
-OTHER_CONFIGS = [        # name, what `bench.py` is asked for (reduced step counts; cfg4 on 64 generated files in batches of 32)
+OTHER_CONFIGS = [        # name, what `bench.py` is asked for (the workloads' own sizes, reduced step counts)
     ("cfg5", ["--workload", "cfg5", "--steps", "30", "--warmup", "5"]),
     ("cfg3_job", ["--workload", "cfg3", "--steps", "40", "--warmup", "5"]),        # (fewer steps: the kernel probe runs before the clocks are up)
-    ("cfg4", ["--workload", "cfg4", "--frames", "64", "--files-per-batch", "32", "--steps", "20", "--warmup", "4"]),
+    ("cfg4", ["--workload", "cfg4", "--steps", "20", "--warmup", "4"]),
 ]
 
 
@@ -1076,13 +1079,25 @@ def main():
 
     # dominant-kernel duration: hipEvents on the launch stream around back-to-back launches of the same op
     launches = max(20, min(args.steps, 50))
+
+    def probe_once():
+        if pyramid:
+            return [time_scale_and_render(s, d, inf, launches=launches, plan=pl) for s, d, inf, pl in chain]
+        return [time_scale_and_render(inp, views[0], info, launches=launches, plan=plan)]
+    # The probe follows the timed job; when that job was short (a reduced run: the `other_configs` children, tests) the clocks
+    # are still ramping -- measured on cfg3: level 0, probed first, 1.18 ms behind a 150 ms job and 1.10 behind a 700 ms one -- so
+    # untimed passes of the same launches first bring the work done before the probe to ~0.6 s of GPU time.
+    warmed, probe_warm_passes = elapsed, 0
+    while warmed < 0.6 and probe_warm_passes < 50:
+        warmed += sum(probe_once()) * launches * 1e-3
+        probe_warm_passes += 1
     if pyramid:
-        level_ms = [time_scale_and_render(s, d, inf, launches=launches, plan=pl) for s, d, inf, pl in chain]
+        level_ms = probe_once()
         kernel_ms = sum(level_ms)
         algo_bytes = n * PYRAMID_BYTES_PER_IMAGE
         kernel_name = "fused_resample_kernel x4 (levels %s ms)" % "/".join(f"{m:.3f}" for m in level_ms)
     else:
-        kernel_ms = time_scale_and_render(inp, views[0], info, launches=launches, plan=plan)
+        kernel_ms = probe_once()[0]
         algo_bytes = n * (in_w * in_h * 4 + out_w * out_h * 4)
         kernel_name = "fused_resample_kernel" if plan.kernel_kind(wl[6]) == 0 else "two-pass (banded_resample_kernel where a band's rows fit the LDS, else the generic pair)"
     torch.cuda.synchronize()
@@ -1173,6 +1188,7 @@ def main():
                          "frac_timed": round(algo_bytes / (compute_s / args.steps) / HBM_PEAK, 4),
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
+                         "probe_launches": launches, "probe_warm_passes": probe_warm_passes,
                          "measured_read_GBps": round(measured_read / 1e9, 1) if measured_read else None,
                          "frac_of_measured_read": round(achieved / measured_read, 4) if measured_read else None,
                          "write_share": round(write_share, 4) if write_share is not None else None,
