@@ -32,7 +32,12 @@ def main():
     ap.add_argument("--reserve", default="0,8,16")
     ap.add_argument("--steps", type=int, default=100)
     args = ap.parse_args()
-    hog = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "libcu_hog.so"))
+    so = os.path.join(ROOT, "tools", "probes", "libcu_hog.so")
+    if not os.path.exists(so):                              # (built in-tree, git-ignored like every binary)
+        import subprocess
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so,
+                        os.path.join(ROOT, "tools", "probes", "cu_hog_probe.hip")], check=True)
+    hog = ctypes.CDLL(so)
     hog.cu_hog_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
