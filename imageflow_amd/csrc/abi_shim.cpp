@@ -250,6 +250,9 @@ uint32_t parse_color(const JVal* v, const char* node) {
     }
     return (ch[3] << 24) | (ch[0] << 16) | (ch[1] << 8) | ch[2];
 }
+// s::Color::Transparent, the enum value (a missing colour reads as it): the only colour create_canvas.rs:79-82 turns into a
+// ReplaceSelf canvas -- an srgb colour whose alpha is 0 still makes a BlendWithMatte canvas
+bool keyword_transparent(const JVal* v) { return !v || v->is_null() || (v->t == JVal::Str && v->s == "transparent"); }
 int parse_filter(const JVal* v, int dflt) {                      // imageflow_types/src/lib.rs:144-205
     if (!v || v->is_null()) return dflt;
     static const std::pair<const char*, int> names[] = {
@@ -834,7 +837,9 @@ struct Job {
     }
     ~Job() { settle_perf(false); }
 
-    FramePtr new_frame(uint32_t w, uint32_t h, bool alpha, uint32_t fill_color32 = 0, bool zero = true) {
+    // matte_canvas: the frame is CreateCanvas' result for a colour other than the enum value Transparent (-1: decide by the
+    // colour's alpha, for callers that have no JSON colour)
+    FramePtr new_frame(uint32_t w, uint32_t h, bool alpha, uint32_t fill_color32 = 0, bool zero = true, int matte_canvas = -1) {
         if (w == 0 || h == 0) raise(kArgumentInvalid, "InvalidArgument: Bitmap dimensions cannot be zero");
         check_size(sec.max_frame_size, "max_frame_size", w, h);
         poll_cancel();                                               // borrow_bitmaps_mut (context.rs:389)
@@ -843,8 +848,8 @@ struct Job {
         if (f->stride == 0) raise(kArgumentInvalid, "InvalidArgument: Bitmap width %u has no 32-bit stride", w);
         hip_check(job_malloc(reinterpret_cast<void**>(&f->d), f->bytes() + 64), "hipMalloc(frame)");
         if (zero) hip_check(hipMemsetAsync(f->d, 0, f->bytes() + 64, t_job_stream), "hipMemset(frame)");
-        if (fill_color32 >> 24) {                    // create_canvas.rs:77-103 / bitmaps.rs:829-837: matte canvases start filled
-            f->compose = IFHIP_BLEND_WITH_MATTE; f->matte = fill_color32;
+        if (matte_canvas < 0 ? (fill_color32 >> 24) != 0 : matte_canvas != 0) { f->compose = IFHIP_BLEND_WITH_MATTE; f->matte = fill_color32; }   // create_canvas.rs:77-103
+        if (fill_color32 >> 24) {                    // bitmaps.rs:829-837: canvases start filled unless the colour is transparent
             check(ifhip_fill_rect_batch_device(f->d, f->bytes(), 1, w, h, f->stride, IFHIP_REPLACE_SELF, 0, 0, w, h, fill_color32, t_job_stream));
         }
         return f;
@@ -1006,7 +1011,7 @@ struct Job {
         const uint8_t* vs = batch->vs;
         // MzDec::apply_downscaling (mozjpeg_decoder.rs:588-618): smallest i/8 (7 skipped) that still covers the hint
         int scale = 8;
-        if (hint_w > 0 && hint_h > 0)
+        if (hint_w > 0 && hint_h > 0 && (w > hint_w || h > hint_h))                   // downscale_if_wider_than = width, or_if_taller_than = height (:72-77)
             for (int i = 1; i < 8; ++i) {
                 if (i == 7) continue;
                 if ((static_cast<uint64_t>(w) * i + 7) / 8 >= hint_w && (static_cast<uint64_t>(h) * i + 7) / 8 >= hint_h) { scale = i; break; }
@@ -1137,10 +1142,11 @@ struct Job {
         FramePtr canvas;
         {
             Timed t(this, "create_canvas");
-            canvas = new_frame(w, h, in->alpha, bg, true);                                                             // format: parent.fmt (:96-105)
+            canvas = new_frame(w, h, in->alpha, bg, true, hi.has_bg && !hi.bg_keyword_transparent);                    // format: parent.fmt (:96-105)
         }
         draw_image_exact(canvas, in, 0, 0, w, h, (bg >> 24) != 0, hi);                                                 // blend Overwrite iff bgcolor.is_transparent() (:176-184)
-        if ((bg >> 24) == 255) canvas->alpha = false;                                 // an opaque matte leaves no meaningful alpha
+        // the canvas keeps parent.fmt: nothing in scaling.rs:50-90 or DrawImageDef::render clears alpha_meaningful after an
+        // opaque matte (only the encoder-side Bitmap::apply_matte does, bitmaps.rs:528-541), so a later node still sees Bgra32
         return canvas;
     }
 
@@ -1385,6 +1391,7 @@ struct Job {
         check(ifhip_copy_rect_batch_device(dev(in), in->bytes(), in->w, in->h, in->stride, in->alpha ? 1 : 0, dev(canvas), canvas->bytes(),
                                            canvas->w, canvas->h, canvas->stride, &canvas_alpha, fx, fy, x, y, w, h, 1, t_job_stream));
         canvas->alpha = canvas_alpha != 0;
+        canvas->compose = IFHIP_BLEND_WITH_SELF;                                       // copy_rect.rs:37
         hip_check(static_cast<hipError_t>(ifhip::wait_stream(t_job_stream)), "copy_rect");
         return canvas;
     }
@@ -1566,7 +1573,8 @@ struct Job {
             const JVal* fmt = p.get("format");
             const std::string f = fmt && fmt->t == JVal::Str ? fmt->s : "bgra_32";
             if (f != "bgra_32" && f != "bgr_32") raise(kActionNotSupported, "ActionNotSupported: create_canvas format %s", f.c_str());
-            return new_frame(want_u32(p, "w", "create_canvas"), want_u32(p, "h", "create_canvas"), f == "bgra_32", parse_color(p.get("color"), "create_canvas.color"), true);
+            return new_frame(want_u32(p, "w", "create_canvas"), want_u32(p, "h", "create_canvas"), f == "bgra_32", parse_color(p.get("color"), "create_canvas.color"), true,
+                             !keyword_transparent(p.get("color")));
         }
         if (name == "command_string") return command_string(p, in);
         need_input();
@@ -1581,7 +1589,7 @@ struct Job {
             in->compose = IFHIP_BLEND_WITH_SELF;                                      // :112: set before the fill, so matte canvases accept sub-rects
             check(ifhip_fill_rect_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, in->compose, want_u32(p, "x1", name.c_str()),
                                                want_u32(p, "y1", name.c_str()), want_u32(p, "x2", name.c_str()), want_u32(p, "y2", name.c_str()),
-                                               parse_color(p.get("color"), "fill_rect.color"), nullptr));
+                                               parse_color(p.get("color"), "fill_rect.color"), t_job_stream));
             return in;
         }
         if (name == "expand_canvas") {                                                // :224-262
@@ -1589,14 +1597,18 @@ struct Job {
                            b = want_u32(p, "bottom", "expand_canvas"), color = parse_color(p.get("color"), "expand_canvas.color");
             const uint64_t nw = static_cast<uint64_t>(in->w) + l + r, nh = static_cast<uint64_t>(in->h) + t2 + b;
             check_size(sec.max_frame_size, "max_frame_size", nw, nh);                 // before the 32-bit sums can wrap
-            FramePtr cv = new_frame(static_cast<uint32_t>(nw), static_cast<uint32_t>(nh), (color >> 24) == 255 ? in->alpha : true, color, true);
+            FramePtr cv = new_frame(static_cast<uint32_t>(nw), static_cast<uint32_t>(nh), (color >> 24) == 255 ? in->alpha : true, color, true, !keyword_transparent(p.get("color")));
             return copy_into_canvas(in, cv, 0, 0, in->w, in->h, l, t2);
         }
         if (name == "crop") {                                                         // :519-541 (materialised: a copy)
             const uint32_t x1 = want_u32(p, "x1", "crop"), y1 = want_u32(p, "y1", "crop"), x2 = want_u32(p, "x2", "crop"), y2 = want_u32(p, "y2", "crop");
             if (x2 <= x1 || y2 <= y1 || x2 > in->w || y2 > in->h) raise(kArgumentInvalid, "InvalidNodeParams: Invalid crop bounds");
             FramePtr cv = new_frame(x2 - x1, y2 - y1, in->alpha, 0, true);
-            return copy_into_canvas(in, cv, x1, y1, x2 - x1, y2 - y1, 0, 0);
+            const int compose = in->compose;                                          // Bitmap::crop is a window onto the same bitmap
+            const uint32_t matte = in->matte;                                         // (bitmaps.rs:841-859): its compositing mode stays
+            copy_into_canvas(in, cv, x1, y1, x2 - x1, y2 - y1, 0, 0);
+            cv->compose = compose; cv->matte = matte;
+            return cv;
         }
         if (name == "region" || name == "region_percent") {                            // :263-452
             // RegionPercent rewrites itself into Region with pixel corners (get_coords :265-286: f32 arithmetic, round half
@@ -1632,7 +1644,7 @@ struct Job {
             const int64_t iw = in->w, ih = in->h;
             check_size(sec.max_frame_size, "max_frame_size", static_cast<uint64_t>(x2 - x1), static_cast<uint64_t>(y2 - y1));
             if (x1 >= iw || y1 >= ih || x2 <= 0 || y2 <= 0)                           // nothing of the input inside: a canvas of the colour
-                return new_frame(static_cast<uint32_t>(x2 - x1), static_cast<uint32_t>(y2 - y1), in->alpha, color, true);
+                return new_frame(static_cast<uint32_t>(x2 - x1), static_cast<uint32_t>(y2 - y1), in->alpha, color, true, !keyword_transparent(p.get("background_color")));
             const uint32_t cx1 = static_cast<uint32_t>(std::min(iw, std::max<int64_t>(0, x1))), cy1 = static_cast<uint32_t>(std::min(ih, std::max<int64_t>(0, y1)));
             const uint32_t cx2 = static_cast<uint32_t>(std::min(iw, std::max<int64_t>(0, x2))), cy2 = static_cast<uint32_t>(std::min(ih, std::max<int64_t>(0, y2)));
             const uint32_t el = static_cast<uint32_t>(std::max<int64_t>(0, -x1)), et = static_cast<uint32_t>(std::max<int64_t>(0, -y1));
@@ -1643,7 +1655,7 @@ struct Job {
                 copy_into_canvas(in, part, cx1, cy1, cx2 - cx1, cy2 - cy1, 0, 0);
             }
             // ExpandCanvas, also by nothing: CreateCanvas of the colour + CopyRectToCanvas (:231-255)
-            FramePtr cv = new_frame(part->w + el + er, part->h + et + eb, (color >> 24) == 255 ? part->alpha : true, color, true);
+            FramePtr cv = new_frame(part->w + el + er, part->h + et + eb, (color >> 24) == 255 ? part->alpha : true, color, true, !keyword_transparent(p.get("background_color")));
             return copy_into_canvas(part, cv, 0, 0, part->w, part->h, el, et);
         }
         if (name == "color_matrix_srgb") {                                            // s::Node::ColorMatrixSrgb {matrix: [[f32;5];5]}
@@ -2099,7 +2111,7 @@ const struct imageflow_json_response* imageflow_context_send_json(struct imagefl
             int progressive = 0;
             (void)ri;
             check(ifhip_jpeg_frame_info(in.in, in.in_len, &w, &h, &nc, hs, vs, bw, bh, qt, &progressive));
-            if (scaled_info && in.told && in.told_w > 0 && in.told_h > 0)             // MzDec::apply_downscaling on the told hints (:588-618)
+            if (scaled_info && in.told && in.told_w > 0 && in.told_h > 0 && (w > in.told_w || h > in.told_h))   // MzDec::apply_downscaling on the told hints (:588-618)
                 for (uint32_t i = 1; i < 8; ++i) {
                     if (i == 7) continue;
                     const uint32_t sw = static_cast<uint32_t>((static_cast<uint64_t>(w) * i + 7) / 8), sh = static_cast<uint32_t>((static_cast<uint64_t>(h) * i + 7) / 8);

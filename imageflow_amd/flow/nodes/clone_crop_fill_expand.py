@@ -6,12 +6,15 @@ from ...graphics.bitmaps import Bitmap, BitmapCompositing
 from ...graphics import bitmap_ops as G
 
 
-def create_canvas(n, w, h, device, color32=0, bgra32=True) -> Bitmap:
-    """CreateCanvasDef::execute (create_canvas.rs:77-103): transparent -> ReplaceSelf and zero fill, any other colour
-    -> BlendWithMatte(colour), pre-filled with it (bitmaps.rs:829-837)."""
-    transparent = (color32 >> 24) == 0
-    compose = BitmapCompositing.ReplaceSelf if transparent else BitmapCompositing.BlendWithMatte
-    return Bitmap.create_u8(n, w, h, device, alpha_meaningful=bgra32, compose=compose, matte=0 if transparent else color32)
+def create_canvas(n, w, h, device, color32=0, bgra32=True, keyword_transparent=None) -> Bitmap:
+    """CreateCanvasDef::execute (create_canvas.rs:77-103): the enum value Color::Transparent -> ReplaceSelf and zero fill,
+    any other colour -- also an srgb colour whose alpha is 0 -- -> BlendWithMatte(colour), pre-filled with it unless it is
+    transparent (bitmaps.rs:829-837).  keyword_transparent: the JSON colour was the enum value (None: decide by the
+    colour's alpha, for callers that only hold a Color32)."""
+    if keyword_transparent is None:
+        keyword_transparent = (color32 >> 24) == 0
+    compose = BitmapCompositing.ReplaceSelf if keyword_transparent else BitmapCompositing.BlendWithMatte
+    return Bitmap.create_u8(n, w, h, device, alpha_meaningful=bgra32, compose=compose, matte=0 if keyword_transparent else color32)
 
 
 def crop(b: Bitmap, x1, y1, x2, y2) -> Bitmap:
@@ -38,11 +41,11 @@ def clone(b: Bitmap) -> Bitmap:
     return copy_rect_to_canvas(b, canvas, 0, 0, b.w, b.h, 0, 0)
 
 
-def expand_canvas(b: Bitmap, left, top, right, bottom, color32) -> Bitmap:
+def expand_canvas(b: Bitmap, left, top, right, bottom, color32, keyword_transparent=None) -> Bitmap:
     """ExpandCanvasDef::expand (:224-262): the canvas is Bgra32 unless the colour is opaque."""
     opaque = (color32 >> 24) == 255
     canvas = create_canvas(b.n, b.w + left + right, b.h + top + bottom, b.data.device, color32,
-                           b.alpha_meaningful if opaque else True)
+                           b.alpha_meaningful if opaque else True, keyword_transparent)
     return copy_rect_to_canvas(b, canvas, 0, 0, b.w, b.h, left, top)
 
 
@@ -71,21 +74,21 @@ def region_percent_coords(w, h, left, top, right, bottom):
     return x1, y1, x2, y2
 
 
-def region(b: Bitmap, x1, y1, x2, y2, color32) -> Bitmap:
+def region(b: Bitmap, x1, y1, x2, y2, color32, keyword_transparent=None) -> Bitmap:
     """RegionDef::expand (:390-452): Crop to the part of the rectangle inside the frame, then ExpandCanvas by the rest; a
     rectangle that misses the frame is a canvas of the colour in the parent's format."""
     if y2 <= y1 or x2 <= x1:
         raise FlowError(ErrorKind.InvalidArgument, f"InvalidNodeParams: Invalid coordinates: {x1},{y1} {x2},{y2} should describe the top-left and "
                         "bottom-right corners of the region in pixels. Not a rectangle.")
     if x1 >= b.w or y1 >= b.h or x2 <= 0 or y2 <= 0:
-        return create_canvas(b.n, x2 - x1, y2 - y1, b.data.device, color32, b.alpha_meaningful)
+        return create_canvas(b.n, x2 - x1, y2 - y1, b.data.device, color32, b.alpha_meaningful, keyword_transparent)
     part = crop(b, min(b.w, max(0, x1)), min(b.h, max(0, y1)), min(b.w, max(0, x2)), min(b.h, max(0, y2)))
-    return expand_canvas(part, max(0, -x1), max(0, -y1), max(0, x2 - b.w), max(0, y2 - b.h), color32)
+    return expand_canvas(part, max(0, -x1), max(0, -y1), max(0, x2 - b.w), max(0, y2 - b.h), color32, keyword_transparent)
 
 
-def region_percent(b: Bitmap, left, top, right, bottom, color32) -> Bitmap:
+def region_percent(b: Bitmap, left, top, right, bottom, color32, keyword_transparent=None) -> Bitmap:
     """RegionPercentDef::expand (:316-352)."""
     if bottom <= top or right <= left:
         raise FlowError(ErrorKind.InvalidArgument, f"InvalidNodeParams: Invalid coordinates: {left},{top} {right},{bottom} should describe the top-left "
                         "and bottom-right corners of the region in percentages. Not a rectangle.")
-    return region(b, *region_percent_coords(b.w, b.h, left, top, right, bottom), color32)
+    return region(b, *region_percent_coords(b.w, b.h, left, top, right, bottom), color32, keyword_transparent)

@@ -150,7 +150,8 @@ def test_raw_container_round_trip_and_matte_hint():
     can[:, :160] = 255                                                          # BlendWithMatte canvases start filled (bitmaps.rs:829-837)
     rc, _ = O.scale_and_render(np.ascontiguousarray(src), 333, 211, can, 40, 25, 0, 0, 40, 25, filter_id=6, sharpen=15.0,
                                compositing=O.BLEND_WITH_MATTE, matte_bgra=0xFFFFFFFF, alpha_meaningful=True)
-    assert rc == 0 and (w2, h2, alpha2) == (40, 25, False) and np.array_equal(rows2, can)
+    # the canvas keeps parent.fmt (Bgra32): an opaque matte does not clear alpha_meaningful on this path (scale_render.rs:96-105)
+    assert rc == 0 and (w2, h2, alpha2) == (40, 25, True) and np.array_equal(rows2, can)
 
 
 @pytest.mark.parametrize("subsampling", ["4:2:0", "4:4:4", "4:2:2"])
@@ -323,7 +324,9 @@ def test_same_size_matte_job_on_a_bgra_parent():
         rows, w, h, alpha = unpack_raw_bgra(c.get_output_buffer(1))
     can = _canvas_rows(64, 48, (0x99, 0x66, 0x33, 0xFF))
     rc, _ = O.scale_and_render(src, 64, 48, can, 64, 48, 0, 0, 64, 48, filter_id=2, compositing=O.BLEND_WITH_MATTE, matte_bgra=0xFF336699, alpha_meaningful=True)
-    assert rc == 0 and not alpha and np.array_equal(rows, can)
+    # the canvas keeps parent.fmt = Bgra32 (scale_render.rs:96-105); nothing on this path clears alpha_meaningful after
+    # an opaque matte (only the encoder-side Bitmap::apply_matte does, bitmaps.rs:528-541)
+    assert rc == 0 and alpha and np.array_equal(rows, can)
 
 
 def _graph(nodes, edges):
@@ -387,6 +390,77 @@ def test_graph_draw_image_exact_matches_the_oracle_chain():
         c.add_output_buffer(2)
         status, r = c.send_json("v1/execute", job)
         assert status == 400 and c.error_code() == 2 and "does not fit canvas size 400x400" in r["message"]
+
+
+def test_canvas_compositing_state_follows_the_reference_from_node_to_node():
+    """What a frame's compositing mode is when a later node draws on it (found by tools/fuzz_shim_chains.py, round 6; expected
+    pixels by the oracle):
+    * copy_rectangle leaves its canvas BlendWithSelf (copy_rect.rs:37), so a draw_image_exact with blend overwrite onto the
+      result of expand_canvas COMPOSES (scale_render.rs:284-292 rewrites only ReplaceSelf + compose and BlendWithMatte +
+      overwrite);
+    * create_canvas makes a ReplaceSelf canvas only for the enum value Transparent: an srgb colour whose alpha is 0 is a
+      BlendWithMatte canvas (create_canvas.rs:79-82), and draw_image_exact with blend compose then blends with THAT matte;
+    * crop is a window: the frame keeps the mode it had (bitmaps.rs:841-859)."""
+    overlay = U.random_frames(1, 55, 104, seed0=71, alpha=True)[0]
+    back = U.random_frames(1, 80, 89, seed0=72, alpha=True)[0]
+    hints = {"down_filter": "robidoux", "up_filter": "ginseng"}
+
+    def run(canvas_nodes, blend, canvas_input=True):
+        nodes = {0: {"decode": {"io_id": 0}}}
+        edges = []
+        first = 1
+        if canvas_input:
+            nodes[1] = {"decode": {"io_id": 1}}
+            first = 2
+        for k, n in enumerate(canvas_nodes):
+            nodes[first + k] = n
+            if k or canvas_input:
+                edges.append((first + k - 1, first + k, "input"))
+        last = first + len(canvas_nodes) - 1
+        d, e = last + 1, last + 2
+        nodes[d] = {"draw_image_exact": {"x": 4, "y": 21, "w": 70, "h": 60, "blend": blend, "hints": hints}}
+        nodes[e] = {"encode": {"io_id": 2, "preset": "gif"}}
+        edges += [(0, d, "input"), (last, d, "canvas"), (d, e, "input")]
+        with Context() as c:
+            c.add_input_buffer(0, pack_raw_bgra(overlay, 55, 104, alpha_meaningful=True))
+            c.add_input_buffer(1, pack_raw_bgra(back, 80, 89, alpha_meaningful=True))
+            c.add_output_buffer(2)
+            _run(c, "v1/execute", _graph(nodes, edges))
+            return unpack_raw_bgra(c.get_output_buffer(2))
+
+    def oracle_draw(can, cw, ch, mode, matte=0):
+        rc, _ = O.scale_and_render(overlay, 55, 104, can, cw, ch, 4, 21, 70, 60, filter_id=4, compositing=mode, matte_bgra=matte, alpha_meaningful=True)
+        assert rc == 0
+        return can
+    # expand_canvas, then overwrite: composes
+    rows, w, h, alpha = run([{"expand_canvas": {"left": 13, "top": 9, "right": 20, "bottom": 19, "color": "transparent"}}], "overwrite")
+    can = _canvas_rows(113, 117)
+    inp = back.copy()
+    rc, _ = O.copy_rect(inp, 80, 89, inp.shape[1], True, can, 113, 117, can.shape[1], True, 0, 0, 13, 9, 80, 89)
+    assert rc == 0 and (w, h, alpha) == (113, 117, True)
+    assert np.array_equal(rows[:, :4 * 113], oracle_draw(can.copy(), 113, 117, O.BLEND_WITH_SELF)[:, :4 * 113])
+    assert not np.array_equal(rows[:, :4 * 113], oracle_draw(can.copy(), 113, 117, O.REPLACE_SELF)[:, :4 * 113])
+    # a decoded frame, overwrite: replaces (the frame is ReplaceSelf)
+    rows, w, h, alpha = run([], "overwrite")
+    assert np.array_equal(rows[:, :320], oracle_draw(back.copy(), 80, 89, O.REPLACE_SELF)[:, :320])
+    # crop of the expanded frame keeps BlendWithSelf
+    rows, w, h, alpha = run([{"expand_canvas": {"left": 13, "top": 9, "right": 20, "bottom": 19, "color": "transparent"}},
+                             {"crop": {"x1": 3, "y1": 2, "x2": 100, "y2": 110}}], "overwrite")
+    win = np.zeros((108, U.stride_for(97)), np.uint8)
+    win[:, :4 * 97] = can[2:110, 12:400]
+    assert (w, h) == (97, 108) and np.array_equal(rows[:, :4 * 97], oracle_draw(win.copy(), 97, 108, O.BLEND_WITH_SELF)[:, :4 * 97])
+    # ... and a crop of the decoded frame keeps ReplaceSelf
+    rows, w, h, alpha = run([{"crop": {"x1": 2, "y1": 1, "x2": 80, "y2": 89}}], "overwrite")
+    win = np.zeros((88, U.stride_for(78)), np.uint8)
+    win[:, :4 * 78] = back[1:89, 8:320]
+    assert (w, h) == (78, 88) and np.array_equal(rows[:, :4 * 78], oracle_draw(win.copy(), 78, 88, O.REPLACE_SELF)[:, :4 * 78])
+    # create_canvas with an srgb colour of alpha 0: a matte canvas
+    for blend, mode in (("compose", O.BLEND_WITH_MATTE), ("overwrite", O.REPLACE_SELF)):
+        rows, w, h, alpha = run([{"create_canvas": {"w": 90, "h": 100, "format": "bgra_32", "color": {"srgb": {"hex": "19BD1200"}}}}], blend, canvas_input=False)
+        exp = oracle_draw(_canvas_rows(90, 100), 90, 100, mode, matte=0x0019BD12)
+        assert (w, h, alpha) == (90, 100, True) and np.array_equal(rows[:, :360], exp[:, :360]), blend
+    rows, w, h, alpha = run([{"create_canvas": {"w": 90, "h": 100, "format": "bgra_32", "color": "transparent"}}], "compose", canvas_input=False)
+    assert np.array_equal(rows[:, :360], oracle_draw(_canvas_rows(90, 100), 90, 100, O.BLEND_WITH_SELF)[:, :360])
 
 
 def test_graph_copy_rect_to_canvas_matches_the_oracle():

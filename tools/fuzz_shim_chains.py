@@ -1,0 +1,581 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the job interpreter behind the libimageflow C ABI (csrc/abi_shim.cpp) against the Python node mirrors
+(imageflow_amd/flow/nodes/*.py) on the GPU (round 6).
+
+Two independent statements of the reference's node semantics exist in this repository: the C++ interpreter a job's JSON
+reaches through `imageflow_context_send_json("v1/execute")`, and the Python mirrors of flow/nodes/*.rs that drive the same
+`ifhip_*` entry points from tests and bench (each cites the Rust lines it follows; tests/test_node_mirrors.py,
+test_gpu_bitmap_ops.py and test_gpu_abi_shim.py pin them to the oracle on hand-picked jobs).  This sweep sends random CHAINS of
+nodes -- flips, transpose, rotations, apply_orientation, crop, expand_canvas, fill_rect, region, region_percent, the
+colour filters, resample_2d with random hints (filters, sharpen + sharpen_when, resample_when, colour space, background
+colour) -- on a random raw frame (alpha meaningful or not) through both and compares the final pixels, size and alpha flag.
+A quarter of the cases are two-input GRAPHS: a canvas side (a decoded frame or a create_canvas node, followed by its own
+chain) and an input side joined by draw_image_exact (random rect, blend, hints) or copy_rect_to_canvas, then a tail chain;
+chains also draw color_matrix_srgb with a random matrix and watermark nodes (second input; fit box, fit mode, gravity,
+opacity; sizes by a Python restatement of imageflow_riapi's sizing.rs:118-197).  A third of the sources are baseline JPEG
+files (Pillow-written: quality, 4:4:4 / 4:2:2 / 4:2:0, grey) -- in a job they stay coefficients until a node needs pixels
+(or are decoded and resampled in one call); the mirror decodes them with codecs.mozjpeg_decoder.decode_frames first.
+What it can find: state that one side carries from node to node and the other does not (alpha_meaningful, the canvas'
+compositing mode, matte colours, windows with a foreign stride), and work queued on the wrong stream.  Found in round 6:
+fill_rect launched on the null stream behind a colour filter on the job's stream; resample_2d clearing alpha_meaningful
+after an opaque matte where the reference keeps the canvas Bgra32.
+
+    python tools/fuzz_shim_chains.py [--seconds 300] [--chains N] [--seed 1] [--out gpurun_out/fuzz_shim.jsonl]
+
+tests/test_gpu_shim_chain_fuzz.py runs a fixed number of chains of this sweep in the GPU suite."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FILTERS = ["robidoux", "robidoux_sharp", "robidoux_fast", "ginseng", "lanczos", "lanczos_2", "cubic", "catmull_rom", "mitchell", "hermite",
+           "triangle", "box", "n_cubic", "fastest", "jinc", "cubic_b_spline"]
+NAMED = ["sepia", "grayscale_ntsc", "grayscale_ry", "grayscale_flat", "grayscale_bt709", "invert"]
+PARAM = ["alpha", "contrast", "saturation", "brightness"]
+
+
+def rand_color(rng):
+    k = int(rng.integers(0, 5))
+    if k == 0:
+        return "transparent"
+    a = [0x00, 0xFF, 0xFF, int(rng.integers(1, 255)), 0x80][int(rng.integers(0, 5))]
+    return {"srgb": {"hex": "%02X%02X%02X%02X" % (int(rng.integers(0, 256)), int(rng.integers(0, 256)), int(rng.integers(0, 256)), a)}}
+
+
+def color32_of(c, color32):
+    if c == "transparent":
+        return 0
+    return color32(c["srgb"]["hex"])
+
+
+def rand_hints(rng, allow_when=True):
+    hints = {}
+    if rng.random() < 0.5:
+        hints["down_filter"] = FILTERS[int(rng.integers(0, len(FILTERS)))]
+    if rng.random() < 0.5:
+        hints["up_filter"] = FILTERS[int(rng.integers(0, len(FILTERS)))]
+    if rng.random() < 0.5:
+        hints["sharpen_percent"] = float(rng.choice([0.0, 10.0, 35.0, 100.0]))
+    if rng.random() < 0.4:
+        hints["sharpen_when"] = ["downscaling", "upscaling", "size_differs", "always"][int(rng.integers(0, 4))]
+    if allow_when and rng.random() < 0.4:
+        hints["resample_when"] = ["size_differs", "size_differs_or_sharpening_requested", "always"][int(rng.integers(0, 3))]
+    if rng.random() < 0.4:
+        hints["scaling_colorspace"] = ["srgb", "linear"][int(rng.integers(0, 2))]
+    if rng.random() < 0.4:
+        hints["background_color"] = rand_color(rng)
+    return hints
+
+
+def draw_node(rng, w, h, mark=None):
+    """-> (json node, new (w, h) estimate) for a frame of w x h; `mark` = (w, h) of the watermark input when the job has one"""
+    k = int(rng.integers(0, 17))
+    if k == 0:
+        return "flip_h", (w, h)
+    if k == 1:
+        return "flip_v", (w, h)
+    if k == 2:
+        return "transpose", (h, w)
+    if k == 3:
+        r = ["rotate_90", "rotate_180", "rotate_270"][int(rng.integers(0, 3))]
+        return r, ((w, h) if r == "rotate_180" else (h, w))
+    if k == 4:
+        f = int(rng.integers(0, 10))
+        return {"apply_orientation": {"flag": f}}, ((h, w) if 5 <= f <= 8 else (w, h))
+    if k == 5 and w > 1 and h > 1:
+        x1, y1 = int(rng.integers(0, w - 1)), int(rng.integers(0, h - 1))
+        x2, y2 = int(rng.integers(x1 + 1, w + 1)), int(rng.integers(y1 + 1, h + 1))
+        return {"crop": {"x1": x1, "y1": y1, "x2": x2, "y2": y2}}, (x2 - x1, y2 - y1)
+    if k == 6:
+        l, t, r, b = (int(v) for v in rng.integers(0, 24, 4))
+        return {"expand_canvas": {"left": l, "top": t, "right": r, "bottom": b, "color": rand_color(rng)}}, (w + l + r, h + t + b)
+    if k == 7:
+        x1, y1 = int(rng.integers(0, w)), int(rng.integers(0, h))
+        x2, y2 = int(rng.integers(x1 + 1, w + 1)), int(rng.integers(y1 + 1, h + 1))
+        return {"fill_rect": {"x1": x1, "y1": y1, "x2": x2, "y2": y2, "color": rand_color(rng)}}, (w, h)
+    if k == 8:
+        x1, y1 = int(rng.integers(-30, w + 10)), int(rng.integers(-30, h + 10))
+        x2, y2 = x1 + int(rng.integers(1, w + 40)), y1 + int(rng.integers(1, h + 40))
+        nw, nh = x2 - x1, y2 - y1
+        return {"region": {"x1": x1, "y1": y1, "x2": x2, "y2": y2, "background_color": rand_color(rng)}}, (nw, nh)
+    if k == 9:
+        x1, y1 = float(rng.integers(-20, 80)), float(rng.integers(-20, 80))
+        x2, y2 = x1 + float(rng.integers(5, 90)) + 0.5 * int(rng.integers(0, 2)), y1 + float(rng.integers(5, 90))
+        return {"region_percent": {"x1": x1, "y1": y1, "x2": x2, "y2": y2, "background_color": rand_color(rng)}}, None
+    if k == 10:
+        return {"color_filter_srgb": NAMED[int(rng.integers(0, len(NAMED)))]}, (w, h)
+    if k == 11:
+        name = PARAM[int(rng.integers(0, len(PARAM)))]
+        return {"color_filter_srgb": {name: float(np.float32(rng.uniform(-0.9, 0.9) if name != "alpha" else rng.uniform(0.05, 1.0)))}}, (w, h)
+    if k == 12:
+        m = np.eye(5, dtype=np.float32) + (rng.uniform(-0.6, 0.6, (5, 5)) * (rng.random((5, 5)) < 0.4)).astype(np.float32)
+        return {"color_matrix_srgb": {"matrix": [[float(v) for v in row] for row in m]}}, (w, h)
+    if k == 13 and mark is not None:
+        wm = {"io_id": 2}
+        fb = int(rng.integers(0, 3))
+        if fb == 1:
+            wm["fit_box"] = {"image_percentage": {"x1": float(rng.integers(-5, 60)), "y1": float(rng.integers(-5, 60)),
+                                                  "x2": float(rng.integers(40, 110)), "y2": float(rng.integers(40, 110))}}
+        elif fb == 2:
+            wm["fit_box"] = {"image_margins": {"left": int(rng.integers(0, 1 + w // 2)), "top": int(rng.integers(0, 1 + h // 2)),
+                                               "right": int(rng.integers(0, 1 + w // 2)), "bottom": int(rng.integers(0, 1 + h // 2))}}
+        if rng.random() < 0.7:
+            wm["fit_mode"] = ["within", "fit", "distort"][int(rng.integers(0, 3))]
+        if rng.random() < 0.6:
+            wm["gravity"] = {"percentage": {"x": float(rng.integers(-10, 120)), "y": float(rng.integers(-10, 120))}}
+        if rng.random() < 0.6:
+            wm["opacity"] = float(np.float32(rng.uniform(-0.1, 1.2)))
+        if rng.random() < 0.15:
+            wm["min_canvas_width"] = int(rng.integers(0, 200))
+        if rng.random() < 0.15:
+            wm["min_canvas_height"] = int(rng.integers(0, 150))
+        return {"watermark": wm}, (w, h)
+    # resample_2d (more likely than any other node)
+    same = rng.random() < 0.2
+    ow = w if same else max(1, int(w * rng.uniform(0.2, 2.2)))
+    oh = h if same else max(1, int(h * rng.uniform(0.2, 2.2)))
+    return {"resample_2d": {"w": ow, "h": oh, "hints": rand_hints(rng)}}, (ow, oh)
+
+
+def draw_chain(rng, w, h, max_nodes, mark=None):
+    nodes = []
+    for _ in range(max_nodes):
+        node, size = draw_node(rng, w, h, mark)
+        nodes.append(node)
+        if size is None or size[0] < 1 or size[1] < 1 or size[0] * size[1] > 400_000:
+            return nodes, None
+        w, h = size
+    return nodes, (w, h)
+
+
+# ---- imageflow_riapi/src/sizing.rs:70-197 restated for the watermark's constraint (Within / Fit / Distort with both sides given)
+def _rround(v):                                     # f64::round / f32::round: half away from zero
+    import math
+    return math.copysign(math.floor(abs(v) + 0.5), v)
+
+
+def _proportional(sw, sh, basis, basis_is_width, target):
+    ratio = sw / sh
+    if basis_is_width:                              # rounding_loss_based_on_target_height(target.h)  (:100-115)
+        rounded_x = _rround(sw * (target[1] / sh))
+        snap_amount = abs(target[1] - rounded_x / ratio)
+    else:                                           # rounding_loss_based_on_target_width(target.w)   (:81-97)
+        rounded_y = _rround(sh * (target[0] / sw))
+        snap_amount = abs(target[0] - rounded_y * ratio)
+    snap_a = sh if basis_is_width else sw
+    snap_b = target[1] if basis_is_width else target[0]
+    f = basis / ratio if basis_is_width else ratio * basis
+    da, db = f - snap_a, f - snap_b
+    if abs(da) <= snap_amount and abs(da) <= abs(db):
+        v = snap_a
+    elif abs(db) <= snap_amount:
+        v = snap_b
+    else:
+        v = int(_rround(f))
+    return max(v, 1)
+
+
+def _inner_box(sw, sh, tw, th):                     # box_of(target, Inner) (:184-192)
+    if sw / sh > tw / th:                           # target.aspect_wider_than(self) = self.ratio > target.ratio
+        return tw, _proportional(sw, sh, tw, True, (tw, th))
+    return _proportional(sw, sh, th, False, (tw, th)), th
+
+
+def watermark_placement(cw, ch, mw, mh, wm):
+    """-> None (the node disappears) or (x, y, w, h); flow/nodes/watermark.rs:11-86, :109-150"""
+    f32 = np.float32
+    if not (wm.get("min_canvas_width", 0) < cw and wm.get("min_canvas_height", 0) < ch):
+        return None
+    box = (0, 0, cw, ch)
+    fb = wm.get("fit_box")
+    if fb and "image_percentage" in fb:
+        p = fb["image_percentage"]
+        box = tuple(int(_rround(float(f32(min(max(p[k], 0.0), 100.0)) / f32(100) * f32(s)))) for k, s in (("x1", cw), ("y1", ch), ("x2", cw), ("y2", ch)))
+        if not (box[0] < box[2] and box[1] < box[3]):
+            return None
+    elif fb:
+        m = fb["image_margins"]
+        if not (m["left"] + m["right"] < cw and m["top"] + m["bottom"] < ch):
+            return None
+        box = (m["left"], m["top"], cw - m["right"], ch - m["bottom"])
+    bw, bh = box[2] - box[0], box[3] - box[1]
+    mode = wm.get("fit_mode", "within")
+    if mode == "distort":
+        tw, th = bw, bh
+    elif mode == "fit" or mw > bw or mh > bh:
+        tw, th = _inner_box(mw, mh, bw, bh)
+    else:
+        tw, th = mw, mh
+    g = wm.get("gravity", {"percentage": {"x": 50.0, "y": 50.0}})["percentage"]
+
+    def g1(pct, inner, outer):                      # gravity1d (:60-67)
+        if (outer < inner and inner < 1) or outer < 1:
+            raise ValueError("Watermark fit_box does not work")
+        return int(_rround(float(f32(outer - inner) * (f32(min(max(pct, 0.0), 100.0)) / f32(100)))))
+    return g1(g["x"], tw, bw) + box[0], g1(g["y"], th, bh) + box[1], tw, th
+
+
+def hints_of(hints, M):
+    CC, RF, SR, CO, Bm, color32, JSON_FILTER_NAMES, WorkingFloatspace = M[:8]
+    return SR.ResampleHints(sharpen_percent=hints.get("sharpen_percent"),
+                            down_filter=JSON_FILTER_NAMES[hints["down_filter"]] if "down_filter" in hints else None,
+                            up_filter=JSON_FILTER_NAMES[hints["up_filter"]] if "up_filter" in hints else None,
+                            scaling_colorspace=(WorkingFloatspace.StandardRGB if hints["scaling_colorspace"] == "srgb" else WorkingFloatspace.LinearRGB)
+                            if "scaling_colorspace" in hints else None,
+                            sharpen_when=SR.SharpenWhen(hints["sharpen_when"]) if "sharpen_when" in hints else None,
+                            resample_when=hints.get("resample_when"))
+
+
+def canvas_of(M, n, w, h, device, color, bgra32):
+    """CreateCanvasDef::execute (create_canvas.rs:77-103): only the enum value Transparent makes a ReplaceSelf canvas; any srgb
+    colour -- also one whose alpha is 0 -- is a BlendWithMatte canvas (pre-filled unless that colour is transparent,
+    bitmaps.rs:829-837)"""
+    Bm, color32 = M[4], M[5]
+    enum_transparent = color in (None, "transparent")
+    c32 = 0 if enum_transparent else color32(color["srgb"]["hex"])
+    return Bm.Bitmap.create_u8(n, w, h, device, alpha_meaningful=bgra32,
+                               compose=Bm.BitmapCompositing.ReplaceSelf if enum_transparent else Bm.BitmapCompositing.BlendWithMatte, matte=c32), c32
+
+
+def mirror_apply(b, node, M, mark=None):
+    """the node on the Python mirrors -> the resulting Bitmap"""
+    CC, RF, SR, CO, Bm, color32, JSON_FILTER_NAMES, WorkingFloatspace = M[:8]
+    if isinstance(node, str):
+        return getattr(RF, node)(b)
+    (name, p), = node.items()
+    if name == "apply_orientation":
+        return RF.apply_orientation(b, p["flag"])
+    if name == "crop":
+        return CC.crop(b, p["x1"], p["y1"], p["x2"], p["y2"])
+    if name == "expand_canvas":
+        return CC.expand_canvas(b, p["left"], p["top"], p["right"], p["bottom"], color32_of(p["color"], color32), p["color"] == "transparent")
+    if name == "fill_rect":
+        return CC.fill_rect(b, p["x1"], p["y1"], p["x2"], p["y2"], color32_of(p["color"], color32))
+    if name == "region":
+        return CC.region(b, p["x1"], p["y1"], p["x2"], p["y2"], color32_of(p["background_color"], color32), p["background_color"] == "transparent")
+    if name == "region_percent":
+        return CC.region_percent(b, p["x1"], p["y1"], p["x2"], p["y2"], color32_of(p["background_color"], color32), p["background_color"] == "transparent")
+    if name == "color_filter_srgb":
+        if isinstance(p, str):
+            CO.color_filter_srgb(b, p)
+        else:
+            (fname, v), = p.items()
+            CO.color_filter_srgb(b, fname, v)
+        return b
+    if name == "color_matrix_srgb":
+        CO.color_matrix_srgb(b, np.asarray(p["matrix"], dtype=np.float32))
+        return b
+    if name == "watermark":
+        WM = M[8]
+        mark_src, mw, mh = mark
+        place = watermark_placement(b.w, b.h, mw, mh, p)
+        if place is None:
+            return b
+        x, y, w, h = place
+        if x < 0 or y < 0:
+            raise M[9](M[10].InvalidArgument, "Watermark fit_box does not work")
+        m = Bm.Bitmap.from_numpy(mark_src[None].copy(), mw, mh, mark_src.shape[1], b.data.device, alpha_meaningful=True)
+        WM.draw_watermark(b, m, x, y, w, h, opacity=p.get("opacity"))
+        return b
+    if name == "resample_2d":
+        # Scale2dDef / the Resample2D expansion, scale_render.rs:30-120, then DrawImageExact :139-201
+        w, h, hints = p["w"], p["h"], p.get("hints") or {}
+        when = hints.get("resample_when", "size_differs_or_sharpening_requested")
+        size_differs = w != b.w or h != b.h
+        downscaling = w < b.w or h < b.h
+        upscaling = w > b.w or h > b.h
+        bg = hints.get("background_color")
+        apply_matte = b.alpha_meaningful and bg is not None and bg != "transparent"
+        raw = hints.get("sharpen_percent", 0.0) or 0.0
+        sw = hints.get("sharpen_when", "always")
+        sharpen = raw if (sw == "always" or (sw == "downscaling" and downscaling) or (sw == "upscaling" and upscaling)
+                          or (sw == "size_differs" and size_differs)) else 0.0
+        resample = when == "always" or (when == "size_differs" and size_differs) or \
+            (when == "size_differs_or_sharpening_requested" and (size_differs or sharpen != 0.0))
+        if not (resample or apply_matte):
+            return b
+        canvas, c32 = canvas_of(M, b.n, w, h, b.data.device, bg, b.alpha_meaningful)
+        rh = hints_of({k: v for k, v in hints.items() if k != "resample_when"}, M)
+        rh.sharpen_percent = sharpen
+        transparent_bg = (c32 >> 24) == 0                     # Color::is_transparent(): by the colour's alpha (imageflow_types lib.rs:852)
+        SR.render(canvas, b, 0, 0, w, h, rh, SR.CompositingMode.Overwrite if transparent_bg else None)
+        return canvas
+    raise ValueError(name)
+
+
+def mirror_join(canvas, inp, node, M):
+    CC, SR = M[0], M[2]
+    (name, p), = node.items()
+    if name == "draw_image_exact":
+        blend = {"compose": SR.CompositingMode.Compose, "overwrite": SR.CompositingMode.Overwrite, None: None}[p.get("blend")]
+        SR.render(canvas, inp, p["x"], p["y"], p["w"], p["h"], hints_of(p.get("hints") or {}, M), blend)
+        return canvas
+    if name == "copy_rect_to_canvas":
+        return CC.copy_rect_to_canvas(inp, canvas, p["from_x"], p["from_y"], p["w"], p["h"], p["x"], p["y"])
+    raise ValueError(name)
+
+
+def rand_jpeg(rng, w, h):
+    spec = {"quality": int(rng.integers(20, 98)), "subsampling": int(rng.integers(0, 3)), "grey": bool(rng.random() < 0.15),
+            "smooth": bool(rng.random() < 0.5)}
+    if rng.random() < 0.5:                              # s::DecoderCommand::JpegDownscaleHints on the decode node
+        spec["hints"] = {"width": max(1, int(w * rng.uniform(0.05, 1.2))), "height": max(1, int(h * rng.uniform(0.05, 1.2)))}
+        if rng.random() < 0.6:
+            spec["hints"]["scale_luma_spatially"] = bool(rng.integers(0, 2))
+        if rng.random() < 0.6:
+            spec["hints"]["gamma_correct_for_srgb_during_spatial_luma_scaling"] = bool(rng.integers(0, 2))
+    return spec
+
+
+def decode_node(io_id, spec):
+    if spec and "hints" in spec:
+        return {"decode": {"io_id": io_id, "commands": [{"jpeg_downscale_hints": spec["hints"]}]}}
+    return {"decode": {"io_id": io_id}}
+
+
+def hinted_size(w, h, spec):
+    """MzDec::apply_downscaling with the hints as tell_decoder maps them (mozjpeg_decoder.rs:72-77, :588-618) -> (scale_num, w, h)"""
+    hw, hh = (spec["hints"]["width"], spec["hints"]["height"]) if spec and "hints" in spec else (0, 0)
+    if hw > 0 and hh > 0 and (w > hw or h > hh):
+        for i in (1, 2, 3, 4, 5, 6):
+            nw, nh = -(-w * i // 8), -(-h * i // 8)
+            if nw >= hw and nh >= hh:
+                return i, nw, nh
+    return 8, w, h
+
+
+def jpeg_bytes(src, w, h, spec):
+    """the frame as a baseline JPEG file (Pillow = libjpeg-turbo); smooth: a low-pass of the noise, so that files with long
+    zero runs and small DC differences appear too"""
+    import io
+
+    from PIL import Image, ImageFilter
+    rgb = np.ascontiguousarray(src[:, :4 * w].reshape(h, w, 4)[:, :, 2::-1])
+    im = Image.fromarray(rgb, "RGB")
+    if spec["smooth"]:
+        im = im.filter(ImageFilter.GaussianBlur(2.0))
+    if spec["grey"]:
+        im = im.convert("L")
+    f = io.BytesIO()
+    im.save(f, "JPEG", quality=spec["quality"], subsampling=spec["subsampling"]) if not spec["grey"] else im.save(f, "JPEG", quality=spec["quality"])
+    return f.getvalue()
+
+
+def draw_case(rng):
+    """-> the case as plain JSON data: sizes, seeds, node lists"""
+    w, h = int(rng.integers(1, 180)), int(rng.integers(1, 130))
+    case = {"size": [w, h], "alpha": bool(rng.integers(0, 2)), "seed": int(rng.integers(0, 1 << 30)),
+            "mark": [int(rng.integers(1, 70)), int(rng.integers(1, 50)), int(rng.integers(0, 1 << 30))]}
+    if rng.random() < 0.33:
+        case["jpeg"] = rand_jpeg(rng, w, h)
+        case["alpha"] = False
+        _, w, h = hinted_size(w, h, case["jpeg"])
+    if rng.random() >= 0.25:
+        case["nodes"], _ = draw_chain(rng, w, h, int(rng.integers(1, 7)), mark=case["mark"][:2])
+        return case
+    # two inputs: the canvas side (decode of input 0 or create_canvas) and the input side (decode of input 1)
+    if rng.random() < 0.4:
+        cw, ch = int(rng.integers(1, 200)), int(rng.integers(1, 150))
+        case["canvas_node"] = {"create_canvas": {"w": cw, "h": ch, "format": ["bgra_32", "bgr_32"][int(rng.integers(0, 2))], "color": rand_color(rng)}}
+    else:
+        cw, ch = w, h
+    case["canvas_chain"], csize = draw_chain(rng, cw, ch, int(rng.integers(0, 3)))
+    iw, ih = int(rng.integers(1, 180)), int(rng.integers(1, 130))
+    case["input"] = {"size": [iw, ih], "alpha": bool(rng.integers(0, 2)), "seed": int(rng.integers(0, 1 << 30))}
+    if rng.random() < 0.33:
+        case["input"]["jpeg"] = rand_jpeg(rng, iw, ih)
+        case["input"]["alpha"] = False
+        _, iw, ih = hinted_size(iw, ih, case["input"]["jpeg"])
+    case["input_chain"], isize = draw_chain(rng, iw, ih, int(rng.integers(0, 3)))
+    cw, ch = csize or (cw, ch)
+    iw, ih = isize or (iw, ih)
+    if rng.random() < 0.6:
+        rw, rh = int(rng.integers(1, cw + 1 + (cw // 8))), int(rng.integers(1, ch + 1 + (ch // 8)))     # now and then too big
+        x, y = int(rng.integers(0, max(1, cw - rw + 2))), int(rng.integers(0, max(1, ch - rh + 2)))
+        d = {"x": x, "y": y, "w": rw, "h": rh, "hints": {k: v for k, v in rand_hints(rng, allow_when=rng.random() < 0.2).items() if k != "background_color"}}
+        if rng.random() < 0.7:
+            d["blend"] = ["compose", "overwrite"][int(rng.integers(0, 2))]
+        case["join"] = {"draw_image_exact": d}
+    else:
+        rw, rh = int(rng.integers(1, min(iw, cw) + 2)), int(rng.integers(1, min(ih, ch) + 2))
+        case["join"] = {"copy_rect_to_canvas": {"from_x": int(rng.integers(0, max(1, iw - rw + 2))), "from_y": int(rng.integers(0, max(1, ih - rh + 2))),
+                                                 "w": rw, "h": rh, "x": int(rng.integers(0, max(1, cw - rw + 2))), "y": int(rng.integers(0, max(1, ch - rh + 2)))}}
+    case["tail"], _ = draw_chain(rng, cw, ch, int(rng.integers(0, 3)))
+    return case
+
+
+def job_of(case):
+    """the JSON of v1/execute for a case"""
+    enc = {"encode": {"io_id": 9, "preset": "gif"}}
+    if "join" not in case:
+        return {"framewise": {"steps": [decode_node(0, case.get("jpeg"))] + case["nodes"] + [enc]}}
+    nodes, edges = {}, []
+
+    def chain(first, rest):
+        nodes[str(len(nodes))] = first
+        for n in rest:
+            nodes[str(len(nodes))] = n
+            edges.append({"from": len(nodes) - 2, "to": len(nodes) - 1, "kind": "input"})
+        return len(nodes) - 1
+    c_end = chain(case.get("canvas_node") or decode_node(0, case.get("jpeg")), case["canvas_chain"])
+    i_end = chain(decode_node(1, case["input"].get("jpeg")), case["input_chain"])
+    nodes[str(len(nodes))] = case["join"]
+    j = len(nodes) - 1
+    edges += [{"from": i_end, "to": j, "kind": "input"}, {"from": c_end, "to": j, "kind": "canvas"}]
+    for n in case["tail"] + [enc]:
+        nodes[str(len(nodes))] = n
+        edges.append({"from": len(nodes) - 2, "to": len(nodes) - 1, "kind": "input"})
+    return {"framewise": {"graph": {"nodes": nodes, "edges": edges}}}
+
+
+def run_case(case, E):
+    """-> the record of one case: both sides run, compared"""
+    torch, Context, pack_raw_bgra, unpack_raw_bgra, FlowError, U, M = E[:7]
+    Bm = M[4]
+    w, h = case["size"]
+    src = U.random_frames(1, w, h, seed0=case["seed"], alpha=True)[0]
+    mw, mh, mseed = case["mark"]
+    mark_src = U.random_frames(1, mw, mh, seed0=mseed, alpha=True)[0]
+    rec = dict(case)
+    shim_err, got = None, None
+    file0 = jpeg_bytes(src, w, h, case["jpeg"]) if "jpeg" in case else None
+    file1 = None
+    if "input" in case:
+        iw, ih = case["input"]["size"]
+        isrc = U.random_frames(1, iw, ih, seed0=case["input"]["seed"], alpha=True)[0]
+        file1 = jpeg_bytes(isrc, iw, ih, case["input"]["jpeg"]) if "jpeg" in case["input"] else None
+    with Context() as c:
+        c.add_input_buffer(0, file0 if file0 is not None else pack_raw_bgra(src, w, h, alpha_meaningful=case["alpha"]))
+        if "input" in case:
+            c.add_input_buffer(1, file1 if file1 is not None else pack_raw_bgra(isrc, iw, ih, alpha_meaningful=case["input"]["alpha"]))
+        c.add_input_buffer(2, pack_raw_bgra(mark_src, mw, mh, alpha_meaningful=True))
+        c.add_output_buffer(9)
+        status, r = c.send_json("v1/execute", job_of(case))
+        if status == 200:
+            rows, gw, gh, galpha = unpack_raw_bgra(c.get_output_buffer(9))
+            got = (rows[:, :4 * gw].copy(), gw, gh, galpha)
+        else:
+            shim_err = f"{status}: {c.error_message()[:160]}"
+    mir_err, exp = None, None
+    try:
+        def frame(s, fw, fh, alpha, file=None, spec=None):
+            if file is not None:
+                scale, _, _ = hinted_size(fw, fh, spec)
+                hi = spec.get("hints", {})
+                spatial = scale < 8 and hi.get("scale_luma_spatially", False)
+                return E[7].decode_frames([file], "cuda:0", scale_num=scale, luma_spatial=spatial,
+                                          luma_srgb=spatial and hi.get("gamma_correct_for_srgb_during_spatial_luma_scaling", False))
+            return Bm.Bitmap.from_numpy(s[None].copy(), fw, fh, s.shape[1], "cuda:0", alpha_meaningful=alpha)
+        if "join" not in case:
+            b = frame(src, w, h, case["alpha"], file0, case.get("jpeg"))
+            for node in case["nodes"]:
+                b = mirror_apply(b, node, M, (mark_src, mw, mh))
+        else:
+            if "canvas_node" in case:
+                p = case["canvas_node"]["create_canvas"]
+                cv, _ = canvas_of(M, 1, p["w"], p["h"], "cuda:0", p["color"], p["format"] == "bgra_32")
+            else:
+                cv = frame(src, w, h, case["alpha"], file0, case.get("jpeg"))
+            for node in case["canvas_chain"]:
+                cv = mirror_apply(cv, node, M)
+            ib = frame(isrc, iw, ih, case["input"]["alpha"], file1, case["input"].get("jpeg"))
+            for node in case["input_chain"]:
+                ib = mirror_apply(ib, node, M)
+            b = mirror_join(cv, ib, case["join"], M)
+            for node in case["tail"]:
+                b = mirror_apply(b, node, M)
+        torch.cuda.synchronize()
+        out = b.to_numpy()[0]
+        exp = (out[:, :4 * b.w], b.w, b.h, bool(b.alpha_meaningful))
+    except (FlowError, ValueError) as e:
+        mir_err = str(e)[:160]
+    if shim_err or mir_err:
+        rec["shim_error"], rec["mirror_error"] = shim_err, mir_err
+        rec["ok"] = bool(shim_err and mir_err)
+        rec["refused"] = True
+        return rec
+    same_meta = got[1:] == exp[1:]
+    same_px = same_meta and np.array_equal(got[0], exp[0])
+    rec["ok"] = bool(same_px)
+    if not same_px:
+        rec["shim"] = [got[1], got[2], got[3]]
+        rec["mirror"] = [exp[1], exp[2], exp[3]]
+        if same_meta:
+            d = np.argwhere(got[0] != exp[0])
+            rec["bytes_differ"] = int(len(d))
+            rec["first"] = [int(v) for v in d[0]] + [int(got[0][tuple(d[0])]), int(exp[0][tuple(d[0])])]
+    return rec
+
+
+def environment():
+    import torch
+    from imageflow_amd.abi import Context, pack_raw_bgra, unpack_raw_bgra
+    from imageflow_amd.errors import ErrorKind, FlowError
+    from imageflow_amd.flow.nodes import clone_crop_fill_expand as CC, color as CO, rotate_flip_transpose as RF, scale_render as SR, watermark as WM
+    from imageflow_amd.graphics import bitmaps as Bm
+    from imageflow_amd.graphics.bitmaps import color32
+    from imageflow_amd.graphics.color import WorkingFloatspace
+    from imageflow_amd.graphics.weights import JSON_FILTER_NAMES
+    from tests import util as U
+    M = (CC, RF, SR, CO, Bm, color32, JSON_FILTER_NAMES, WorkingFloatspace, WM, FlowError, ErrorKind)
+    from imageflow_amd.codecs import mozjpeg_decoder as MD
+    return (torch, Context, pack_raw_bgra, unpack_raw_bgra, FlowError, U, M, MD)
+
+
+def sweep(seed, seconds=None, chains=None, out=None):
+    """run cases until `seconds` have passed or `chains` cases are done -> (summary, the failing records)"""
+    E = environment()
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + (seconds if seconds is not None else 1e9)
+    done = bad = both_refuse = one_refuses = graphs = jpegs = 0
+    failing = []
+    f = open(out, "w") if out else None
+    while time.time() < t_end and (chains is None or done < chains):
+        case = draw_case(rng)
+        rec = run_case(case, E)
+        rec["case"] = done
+        graphs += "join" in case
+        jpegs += ("jpeg" in case) + ("jpeg" in case.get("input", {}))
+        if rec.get("refused"):
+            both_refuse += rec["ok"]
+            one_refuses += not rec["ok"]
+        if not rec["ok"]:
+            bad += 1
+            if len(failing) < 3000:
+                failing.append(rec)
+        if f and ((not rec["ok"] and bad <= 3000) or done % 500 == 0):       # every disagreement (the first 3 000), every 500th case
+            f.write(json.dumps(rec) + "\n")
+            f.flush()
+        done += 1
+    summary = {"summary": True, "seed": seed, "chains": done, "graphs": graphs, "jpeg_sources": jpegs, "disagreements": bad, "both_refuse": both_refuse,
+               "only_one_side_refuses": one_refuses}
+    if f:
+        f.write(json.dumps(summary) + "\n")
+        f.close()
+    return summary, failing
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--chains", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz_shim.jsonl"))
+    args = ap.parse_args()
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("needs a GPU")
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    summary, _ = sweep(args.seed, seconds=args.seconds, chains=args.chains, out=args.out)
+    print(json.dumps(summary))
+    sys.exit(1 if summary["disagreements"] else 0)
+
+
+if __name__ == "__main__":
+    main()
