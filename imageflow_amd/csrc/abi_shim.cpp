@@ -869,10 +869,14 @@ struct Job {
         return f->d;
     }
     bool lazy_decode = false;                                        // the decode node being run has exactly one consumer
-    FramePtr clone(const FramePtr& in) {                              // flow/nodes/clone_crop_fill_expand.rs:140-175
+    // clone_node: the Clone node MutProtect puts before a mutating node whose parent has other children (definitions.rs:
+    // 320-341) = CreateCanvas(Transparent, parent.fmt) + CopyRectToCanvas (clone_crop_fill_expand.rs:151-175), which leaves
+    // the copy in BlendWithSelf (copy_rect.rs:37); otherwise a private copy of this interpreter's that keeps the frame's state
+    FramePtr clone(const FramePtr& in, bool clone_node = false) {
         FramePtr c2 = new_frame(in->w, in->h, in->alpha, 0, false);
         hip_check(hipMemcpyAsync(c2->d, dev(in), in->bytes(), hipMemcpyDeviceToDevice, t_job_stream), "clone");
-        c2->compose = in->compose; c2->matte = in->matte;
+        if (clone_node) c2->compose = IFHIP_BLEND_WITH_SELF;
+        else { c2->compose = in->compose; c2->matte = in->matte; }
         return c2;
     }
 
@@ -1742,7 +1746,7 @@ struct Job {
             if (pit != parent.end()) {
                 in = eval(pit->second);
                 in_shared = consumers[pit->second] > 1;
-                if (in && in_shared && mutates_input(name)) in = clone(in);
+                if (in && in_shared && mutates_input(name)) in = clone(in, true);
             }
             auto cit = canvas_parent.find(id);
             if (cit != canvas_parent.end()) {

@@ -14,7 +14,10 @@ chain) and an input side joined by draw_image_exact (random rect, blend, hints) 
 chains also draw color_matrix_srgb with a random matrix and watermark nodes (second input; fit box, fit mode, gravity,
 opacity; sizes by a Python restatement of imageflow_riapi's sizing.rs:118-197).  A third of the sources are baseline JPEG
 files (Pillow-written: quality, 4:4:4 / 4:2:2 / 4:2:0, grey) -- in a job they stay coefficients until a node needs pixels
-(or are decoded and resampled in one call); the mirror decodes them with codecs.mozjpeg_decoder.decode_frames first.
+(or are decoded and resampled in one call, or decoded at i/8 under jpeg_downscale_hints); the mirror decodes them with
+codecs.mozjpeg_decoder.decode_frames first.  A quarter of the jobs end in a JPEG file (encode preset libjpeg_turbo: quality,
+progressive, optimised tables, matte) instead of the raw frame: the file must equal, byte for byte, the one libjpeg-turbo
+(Pillow) writes from the mirror's final pixels flattened onto the matte (codecs/mozjpeg.rs:88-94).
 What it can find: state that one side carries from node to node and the other does not (alpha_meaningful, the canvas'
 compositing mode, matte colours, windows with a foreign stride), and work queued on the wrong stream.  Found in round 6:
 fill_rect launched on the null stream behind a colour filter on the job's stream; resample_2d clearing alpha_meaningful
@@ -376,6 +379,17 @@ def draw_case(rng):
         case["jpeg"] = rand_jpeg(rng, w, h)
         case["alpha"] = False
         _, w, h = hinted_size(w, h, case["jpeg"])
+    if rng.random() < 0.25:
+        enc = {}
+        if rng.random() < 0.8:
+            enc["quality"] = int(rng.integers(1, 101))
+        if rng.random() < 0.3:
+            enc["progressive"] = bool(rng.integers(0, 2))
+        if rng.random() < 0.3:
+            enc["optimize_huffman_coding"] = bool(rng.integers(0, 2))
+        if rng.random() < 0.4:
+            enc["matte"] = rand_color(rng)
+        case["encode"] = enc
     if rng.random() >= 0.25:
         case["nodes"], _ = draw_chain(rng, w, h, int(rng.integers(1, 7)), mark=case["mark"][:2])
         return case
@@ -412,7 +426,7 @@ def draw_case(rng):
 
 def job_of(case):
     """the JSON of v1/execute for a case"""
-    enc = {"encode": {"io_id": 9, "preset": "gif"}}
+    enc = {"encode": {"io_id": 9, "preset": {"libjpeg_turbo": case["encode"]} if "encode" in case else "gif"}}
     if "join" not in case:
         return {"framewise": {"steps": [decode_node(0, case.get("jpeg"))] + case["nodes"] + [enc]}}
     nodes, edges = {}, []
@@ -457,7 +471,9 @@ def run_case(case, E):
         c.add_input_buffer(2, pack_raw_bgra(mark_src, mw, mh, alpha_meaningful=True))
         c.add_output_buffer(9)
         status, r = c.send_json("v1/execute", job_of(case))
-        if status == 200:
+        if status == 200 and "encode" in case:
+            got = bytes(c.get_output_buffer(9))
+        elif status == 200:
             rows, gw, gh, galpha = unpack_raw_bgra(c.get_output_buffer(9))
             got = (rows[:, :4 * gw].copy(), gw, gh, galpha)
         else:
@@ -490,15 +506,37 @@ def run_case(case, E):
             b = mirror_join(cv, ib, case["join"], M)
             for node in case["tail"]:
                 b = mirror_apply(b, node, M)
-        torch.cuda.synchronize()
-        out = b.to_numpy()[0]
-        exp = (out[:, :4 * b.w], b.w, b.h, bool(b.alpha_meaningful))
+        if "encode" in case:                                  # MozjpegEncoder::write_frame (mozjpeg.rs:88-94): matte (default white) first
+            import io
+
+            from PIL import Image, ImageFile
+            ImageFile.MAXBLOCK = 1 << 24
+            matte = case["encode"].get("matte")
+            E[8].apply_matte(b, 0xFFFFFFFF if matte is None else color32_of(matte, M[5]))
+            torch.cuda.synchronize()
+            out = b.to_numpy()[0]
+            rgb = np.ascontiguousarray(out[:, :4 * b.w].reshape(b.h, b.w, 4)[:, :, 2::-1])
+            f = io.BytesIO()
+            Image.fromarray(rgb).save(f, "JPEG", quality=case["encode"].get("quality", 75), subsampling="4:2:0",
+                                      optimize=bool(case["encode"].get("optimize_huffman_coding", False)),
+                                      progressive=bool(case["encode"].get("progressive", False)))
+            exp = f.getvalue()
+        else:
+            torch.cuda.synchronize()
+            out = b.to_numpy()[0]
+            exp = (out[:, :4 * b.w], b.w, b.h, bool(b.alpha_meaningful))
     except (FlowError, ValueError) as e:
         mir_err = str(e)[:160]
     if shim_err or mir_err:
         rec["shim_error"], rec["mirror_error"] = shim_err, mir_err
         rec["ok"] = bool(shim_err and mir_err)
         rec["refused"] = True
+        return rec
+    if "encode" in case:
+        rec["ok"] = got == exp
+        if not rec["ok"]:
+            rec["file_bytes"] = [len(got), len(exp)]
+            rec["first_differing_byte"] = next((i for i in range(min(len(got), len(exp))) if got[i] != exp[i]), min(len(got), len(exp)))
         return rec
     same_meta = got[1:] == exp[1:]
     same_px = same_meta and np.array_equal(got[0], exp[0])
@@ -525,7 +563,8 @@ def environment():
     from tests import util as U
     M = (CC, RF, SR, CO, Bm, color32, JSON_FILTER_NAMES, WorkingFloatspace, WM, FlowError, ErrorKind)
     from imageflow_amd.codecs import mozjpeg_decoder as MD
-    return (torch, Context, pack_raw_bgra, unpack_raw_bgra, FlowError, U, M, MD)
+    from imageflow_amd.graphics import blend as BL
+    return (torch, Context, pack_raw_bgra, unpack_raw_bgra, FlowError, U, M, MD, BL)
 
 
 def sweep(seed, seconds=None, chains=None, out=None):
@@ -533,7 +572,7 @@ def sweep(seed, seconds=None, chains=None, out=None):
     E = environment()
     rng = np.random.default_rng(seed)
     t_end = time.time() + (seconds if seconds is not None else 1e9)
-    done = bad = both_refuse = one_refuses = graphs = jpegs = 0
+    done = bad = both_refuse = one_refuses = graphs = jpegs = files = 0
     failing = []
     f = open(out, "w") if out else None
     while time.time() < t_end and (chains is None or done < chains):
@@ -542,6 +581,7 @@ def sweep(seed, seconds=None, chains=None, out=None):
         rec["case"] = done
         graphs += "join" in case
         jpegs += ("jpeg" in case) + ("jpeg" in case.get("input", {}))
+        files += "encode" in case
         if rec.get("refused"):
             both_refuse += rec["ok"]
             one_refuses += not rec["ok"]
@@ -553,7 +593,7 @@ def sweep(seed, seconds=None, chains=None, out=None):
             f.write(json.dumps(rec) + "\n")
             f.flush()
         done += 1
-    summary = {"summary": True, "seed": seed, "chains": done, "graphs": graphs, "jpeg_sources": jpegs, "disagreements": bad, "both_refuse": both_refuse,
+    summary = {"summary": True, "seed": seed, "chains": done, "graphs": graphs, "jpeg_sources": jpegs, "jpeg_outputs": files, "disagreements": bad, "both_refuse": both_refuse,
                "only_one_side_refuses": one_refuses}
     if f:
         f.write(json.dumps(summary) + "\n")
