@@ -21,6 +21,15 @@ def test_random_chains_and_graphs_agree_with_the_mirrors(seed):
     assert summary["disagreements"] == 0, json.dumps(failing[0])[:1500]
 
 
+def test_concurrent_jobs_agree_with_the_mirrors():
+    """the jobs of 32 cases at a time on 4 host threads (one context per job): per-thread streams, the block cache's stream-ordered
+    release, JPEG sources of four shared geometries through the decode coalescer"""
+    import fuzz_shim_chains as F
+    summary, failing = F.sweep(21, chains=2000, threads=4)
+    assert summary["chains"] == 2000 and summary["jpeg_sources"] > 500
+    assert summary["disagreements"] == 0, json.dumps(failing[0])[:1500]
+
+
 def test_fill_rect_runs_behind_the_colour_filter_of_the_same_job():
     """round 6: fill_rect was launched on the null stream while the colour filter before it ran on the job's stream -- the
     filter then ran over (part of) the filled rectangle"""

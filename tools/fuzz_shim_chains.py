@@ -23,7 +23,7 @@ compositing mode, matte colours, windows with a foreign stride), and work queued
 fill_rect launched on the null stream behind a colour filter on the job's stream; resample_2d clearing alpha_meaningful
 after an opaque matte where the reference keeps the canvas Bgra32.
 
-    python tools/fuzz_shim_chains.py [--seconds 300] [--chains N] [--seed 1] [--out gpurun_out/fuzz_shim.jsonl]
+    python tools/fuzz_shim_chains.py [--seconds 300] [--chains N] [--seed 1] [--threads T] [--out gpurun_out/fuzz_shim.jsonl]
 
 tests/test_gpu_shim_chain_fuzz.py runs a fixed number of chains of this sweep in the GPU suite."""
 import argparse
@@ -370,13 +370,25 @@ def jpeg_bytes(src, w, h, spec):
     return f.getvalue()
 
 
-def draw_case(rng):
-    """-> the case as plain JSON data: sizes, seeds, node lists"""
+JPEG_POOL = [(64, 48, 2), (97, 61, 2), (160, 120, 0), (33, 100, 1)]       # (w, h, subsampling): geometries concurrent jobs share
+
+
+def draw_case(rng, pool_jpeg=False):
+    """-> the case as plain JSON data: sizes, seeds, node lists.  pool_jpeg: most JPEG sources take one of four geometries,
+    so that the decode coalescer finds files of concurrent jobs it can put into one entropy batch"""
     w, h = int(rng.integers(1, 180)), int(rng.integers(1, 130))
+    pooled = None
+    if pool_jpeg and rng.random() < 0.7:
+        pooled = JPEG_POOL[int(rng.integers(0, len(JPEG_POOL)))]
     case = {"size": [w, h], "alpha": bool(rng.integers(0, 2)), "seed": int(rng.integers(0, 1 << 30)),
             "mark": [int(rng.integers(1, 70)), int(rng.integers(1, 50)), int(rng.integers(0, 1 << 30))]}
-    if rng.random() < 0.33:
+    if rng.random() < (0.6 if pool_jpeg else 0.33):
+        if pooled:
+            w, h = pooled[:2]
+            case["size"] = [w, h]
         case["jpeg"] = rand_jpeg(rng, w, h)
+        if pooled:
+            case["jpeg"]["subsampling"], case["jpeg"]["grey"] = pooled[2], False
         case["alpha"] = False
         _, w, h = hinted_size(w, h, case["jpeg"])
     if rng.random() < 0.25:
@@ -448,37 +460,53 @@ def job_of(case):
     return {"framewise": {"graph": {"nodes": nodes, "edges": edges}}}
 
 
-def run_case(case, E):
-    """-> the record of one case: both sides run, compared"""
-    torch, Context, pack_raw_bgra, unpack_raw_bgra, FlowError, U, M = E[:7]
-    Bm = M[4]
+def case_inputs(case, E):
+    """the source frames and files of a case"""
+    U = E[5]
     w, h = case["size"]
     src = U.random_frames(1, w, h, seed0=case["seed"], alpha=True)[0]
     mw, mh, mseed = case["mark"]
-    mark_src = U.random_frames(1, mw, mh, seed0=mseed, alpha=True)[0]
-    rec = dict(case)
-    shim_err, got = None, None
-    file0 = jpeg_bytes(src, w, h, case["jpeg"]) if "jpeg" in case else None
-    file1 = None
+    inp = {"src": src, "mark": (U.random_frames(1, mw, mh, seed0=mseed, alpha=True)[0], mw, mh),
+           "file0": jpeg_bytes(src, w, h, case["jpeg"]) if "jpeg" in case else None, "isrc": None, "file1": None}
     if "input" in case:
         iw, ih = case["input"]["size"]
-        isrc = U.random_frames(1, iw, ih, seed0=case["input"]["seed"], alpha=True)[0]
-        file1 = jpeg_bytes(isrc, iw, ih, case["input"]["jpeg"]) if "jpeg" in case["input"] else None
+        inp["isrc"] = U.random_frames(1, iw, ih, seed0=case["input"]["seed"], alpha=True)[0]
+        inp["file1"] = jpeg_bytes(inp["isrc"], iw, ih, case["input"]["jpeg"]) if "jpeg" in case["input"] else None
+    return inp
+
+
+COUNTS = {"coalesced_decodes": 0, "fused_decode_resamples": 0, "device_coded_files": 0}     # the contexts' diagnostics, summed
+
+
+def run_shim(case, inp, E):
+    """the job through the C ABI -> (error text or None, the output: file bytes, or (pixels, w, h, alpha flag))"""
+    Context, pack_raw_bgra, unpack_raw_bgra = E[1:4]
+    w, h = case["size"]
+    mark_src, mw, mh = inp["mark"]
     with Context() as c:
-        c.add_input_buffer(0, file0 if file0 is not None else pack_raw_bgra(src, w, h, alpha_meaningful=case["alpha"]))
+        c.add_input_buffer(0, inp["file0"] if inp["file0"] is not None else pack_raw_bgra(inp["src"], w, h, alpha_meaningful=case["alpha"]))
         if "input" in case:
-            c.add_input_buffer(1, file1 if file1 is not None else pack_raw_bgra(isrc, iw, ih, alpha_meaningful=case["input"]["alpha"]))
+            iw, ih = case["input"]["size"]
+            c.add_input_buffer(1, inp["file1"] if inp["file1"] is not None else pack_raw_bgra(inp["isrc"], iw, ih, alpha_meaningful=case["input"]["alpha"]))
         c.add_input_buffer(2, pack_raw_bgra(mark_src, mw, mh, alpha_meaningful=True))
         c.add_output_buffer(9)
         status, r = c.send_json("v1/execute", job_of(case))
-        if status == 200 and "encode" in case:
-            got = bytes(c.get_output_buffer(9))
-        elif status == 200:
-            rows, gw, gh, galpha = unpack_raw_bgra(c.get_output_buffer(9))
-            got = (rows[:, :4 * gw].copy(), gw, gh, galpha)
-        else:
-            shim_err = f"{status}: {c.error_message()[:160]}"
-    mir_err, exp = None, None
+        COUNTS["coalesced_decodes"] += int(c.L.ifhip_shim_coalesced_decodes(c.p))          # (+= of an int under the GIL)
+        COUNTS["fused_decode_resamples"] += int(c.L.ifhip_shim_fused_decode_resamples(c.p))
+        COUNTS["device_coded_files"] += int(c.L.ifhip_shim_device_coded_files(c.p))
+        if status != 200:
+            return f"{status}: {c.error_message()[:160]}", None
+        if "encode" in case:
+            return None, bytes(c.get_output_buffer(9))
+        rows, gw, gh, galpha = unpack_raw_bgra(c.get_output_buffer(9))
+        return None, (rows[:, :4 * gw].copy(), gw, gh, galpha)
+
+
+def run_mirror(case, inp, E):
+    """the same nodes on the Python mirrors -> (error text or None, the expected output)"""
+    torch, FlowError, M = E[0], E[4], E[6]
+    Bm = M[4]
+    w, h = case["size"]
     try:
         def frame(s, fw, fh, alpha, file=None, spec=None):
             if file is not None:
@@ -489,18 +517,19 @@ def run_case(case, E):
                                           luma_srgb=spatial and hi.get("gamma_correct_for_srgb_during_spatial_luma_scaling", False))
             return Bm.Bitmap.from_numpy(s[None].copy(), fw, fh, s.shape[1], "cuda:0", alpha_meaningful=alpha)
         if "join" not in case:
-            b = frame(src, w, h, case["alpha"], file0, case.get("jpeg"))
+            b = frame(inp["src"], w, h, case["alpha"], inp["file0"], case.get("jpeg"))
             for node in case["nodes"]:
-                b = mirror_apply(b, node, M, (mark_src, mw, mh))
+                b = mirror_apply(b, node, M, inp["mark"])
         else:
             if "canvas_node" in case:
                 p = case["canvas_node"]["create_canvas"]
                 cv, _ = canvas_of(M, 1, p["w"], p["h"], "cuda:0", p["color"], p["format"] == "bgra_32")
             else:
-                cv = frame(src, w, h, case["alpha"], file0, case.get("jpeg"))
+                cv = frame(inp["src"], w, h, case["alpha"], inp["file0"], case.get("jpeg"))
             for node in case["canvas_chain"]:
                 cv = mirror_apply(cv, node, M)
-            ib = frame(isrc, iw, ih, case["input"]["alpha"], file1, case["input"].get("jpeg"))
+            iw, ih = case["input"]["size"]
+            ib = frame(inp["isrc"], iw, ih, case["input"]["alpha"], inp["file1"], case["input"].get("jpeg"))
             for node in case["input_chain"]:
                 ib = mirror_apply(ib, node, M)
             b = mirror_join(cv, ib, case["join"], M)
@@ -520,13 +549,18 @@ def run_case(case, E):
             Image.fromarray(rgb).save(f, "JPEG", quality=case["encode"].get("quality", 75), subsampling="4:2:0",
                                       optimize=bool(case["encode"].get("optimize_huffman_coding", False)),
                                       progressive=bool(case["encode"].get("progressive", False)))
-            exp = f.getvalue()
-        else:
-            torch.cuda.synchronize()
-            out = b.to_numpy()[0]
-            exp = (out[:, :4 * b.w], b.w, b.h, bool(b.alpha_meaningful))
+            return None, f.getvalue()
+        torch.cuda.synchronize()
+        out = b.to_numpy()[0]
+        return None, (out[:, :4 * b.w], b.w, b.h, bool(b.alpha_meaningful))
     except (FlowError, ValueError) as e:
-        mir_err = str(e)[:160]
+        return str(e)[:160], None
+
+
+def compare(case, shim, mirror):
+    """-> the record of a case from the two sides' (error, output)"""
+    (shim_err, got), (mir_err, exp) = shim, mirror
+    rec = dict(case)
     if shim_err or mir_err:
         rec["shim_error"], rec["mirror_error"] = shim_err, mir_err
         rec["ok"] = bool(shim_err and mir_err)
@@ -551,6 +585,12 @@ def run_case(case, E):
     return rec
 
 
+def run_case(case, E):
+    """-> the record of one case: both sides run, compared"""
+    inp = case_inputs(case, E)
+    return compare(case, run_shim(case, inp, E), run_mirror(case, inp, E))
+
+
 def environment():
     import torch
     from imageflow_amd.abi import Context, pack_raw_bgra, unpack_raw_bgra
@@ -567,34 +607,53 @@ def environment():
     return (torch, Context, pack_raw_bgra, unpack_raw_bgra, FlowError, U, M, MD, BL)
 
 
-def sweep(seed, seconds=None, chains=None, out=None):
-    """run cases until `seconds` have passed or `chains` cases are done -> (summary, the failing records)"""
+def sweep(seed, seconds=None, chains=None, out=None, threads=1):
+    """run cases until `seconds` have passed or `chains` cases are done -> (summary, the failing records).  threads > 1: the
+    mirrors run one case after the other as before, the JOBS of a group of 8 x threads cases run concurrently on `threads`
+    host threads (one context per job, as imageflow_abi/src/lib.rs:20-27 prescribes) -- per-thread streams, the block cache's
+    stream-ordered release and the decode coalescer (JPEG sources of concurrent jobs share one entropy batch) under load."""
     E = environment()
     rng = np.random.default_rng(seed)
     t_end = time.time() + (seconds if seconds is not None else 1e9)
     done = bad = both_refuse = one_refuses = graphs = jpegs = files = 0
     failing = []
     f = open(out, "w") if out else None
+    pool = None
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(threads)
     while time.time() < t_end and (chains is None or done < chains):
-        case = draw_case(rng)
-        rec = run_case(case, E)
-        rec["case"] = done
-        graphs += "join" in case
-        jpegs += ("jpeg" in case) + ("jpeg" in case.get("input", {}))
-        files += "encode" in case
-        if rec.get("refused"):
-            both_refuse += rec["ok"]
-            one_refuses += not rec["ok"]
-        if not rec["ok"]:
-            bad += 1
-            if len(failing) < 3000:
-                failing.append(rec)
-        if f and ((not rec["ok"] and bad <= 3000) or done % 500 == 0):       # every disagreement (the first 3 000), every 500th case
-            f.write(json.dumps(rec) + "\n")
-            f.flush()
-        done += 1
-    summary = {"summary": True, "seed": seed, "chains": done, "graphs": graphs, "jpeg_sources": jpegs, "jpeg_outputs": files, "disagreements": bad, "both_refuse": both_refuse,
-               "only_one_side_refuses": one_refuses}
+        group = 1 if pool is None else 8 * threads
+        if chains is not None:
+            group = min(group, chains - done)
+        cases = [draw_case(rng, pool_jpeg=pool is not None) for _ in range(group)]
+        if pool is None:
+            recs = [run_case(cases[0], E)]
+        else:
+            inputs = [case_inputs(c, E) for c in cases]
+            jobs = [pool.submit(run_shim, c, i, E) for c, i in zip(cases, inputs)]      # the jobs run while the mirrors do
+            mirrors = [run_mirror(c, i, E) for c, i in zip(cases, inputs)]
+            recs = [compare(c, j.result(), m) for c, j, m in zip(cases, jobs, mirrors)]
+        for case, rec in zip(cases, recs):
+            rec["case"] = done
+            graphs += "join" in case
+            jpegs += ("jpeg" in case) + ("jpeg" in case.get("input", {}))
+            files += "encode" in case
+            if rec.get("refused"):
+                both_refuse += rec["ok"]
+                one_refuses += not rec["ok"]
+            if not rec["ok"]:
+                bad += 1
+                if len(failing) < 3000:
+                    failing.append(rec)
+            if f and ((not rec["ok"] and bad <= 3000) or done % 500 == 0):       # every disagreement (the first 3 000), every 500th case
+                f.write(json.dumps(rec) + "\n")
+                f.flush()
+            done += 1
+    if pool is not None:
+        pool.shutdown()
+    summary = {"summary": True, "seed": seed, "threads": threads, "chains": done, "graphs": graphs, "jpeg_sources": jpegs, "jpeg_outputs": files,
+               "disagreements": bad, "both_refuse": both_refuse, "only_one_side_refuses": one_refuses, **COUNTS}
     if f:
         f.write(json.dumps(summary) + "\n")
         f.close()
@@ -606,13 +665,14 @@ def main():
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--chains", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--threads", type=int, default=1, help="jobs of a group of cases run concurrently on this many host threads")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz_shim.jsonl"))
     args = ap.parse_args()
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("needs a GPU")
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
-    summary, _ = sweep(args.seed, seconds=args.seconds, chains=args.chains, out=args.out)
+    summary, _ = sweep(args.seed, seconds=args.seconds, chains=args.chains, out=args.out, threads=args.threads)
     print(json.dumps(summary))
     sys.exit(1 if summary["disagreements"] else 0)
 
