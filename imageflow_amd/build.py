@@ -68,11 +68,27 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def headers_mtime():
+    """newest header any translation unit may include (csrc/*.hpp|*.inc|*.h, include/*.h) and this file (the flags)"""
+    inc = os.path.join(HERE, "..", "include")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc", ".h"))]
+    deps += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")] + [os.path.abspath(__file__)]
+    return max(os.path.getmtime(d) for d in deps)
+
+
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    objs = run_jobs(compile_jobs(), verbose)
+    jobs = compile_jobs()
+    if not force:                                   # objects newer than their source and every header are kept
+        h = headers_mtime()
+        todo = [(cmd, obj) for cmd, obj in jobs
+                if not os.path.exists(obj) or os.path.getmtime(obj) <= max(h, os.path.getmtime(cmd[cmd.index("-c") + 1]))]
+        run_jobs(todo, verbose)
+        objs = [obj for _, obj in jobs]
+    else:
+        objs = run_jobs(jobs, verbose)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))

@@ -36,6 +36,7 @@
 #include "../../include/imageflow_abi_subset.h"
 #include "../../include/imageflow_hip.h"
 #include "common.hpp"           // the library's per-job memory cache and thread stream (devmem.cpp)
+#include "layout.hpp"           // imageflow_riapi's constraint layout (constrain / watermark)
 
 namespace {
 
@@ -1174,19 +1175,70 @@ struct Job {
         const JVal *jw = p.get("w"), *jh = p.get("h");
         *has_w = jw && jw->t == JVal::Num; *has_h = jh && jh->t == JVal::Num;
         *tw = *has_w ? want_u32(p, "w", node) : 0; *th = *has_h ? want_u32(p, "h", node) : 0;
-        if ((*has_w && *tw < 1) || (*has_h && *th < 1)) raise(kArgumentInvalid, "InvalidNodeParams: %s w/h must be >= 1", node);
     }
     FramePtr constrain(const FramePtr& in, const JVal& p) {
         std::string m;
         bool has_w, has_h;
         int64_t tw, th;
         constrain_params(p, "constrain", &m, &has_w, &has_h, &tw, &th);
-        if (m != "within" && m != "fit" && m != "distort")
-            raise(kActionNotSupported, "ActionNotSupported: constrain mode '%s' (this shim: within, fit, distort)", m.c_str());
-        if (!has_w && !has_h) return in;
-        uint32_t ow, oh;
-        constrain_size(m, in->w, in->h, has_w, has_h, tw, th, &ow, &oh);
-        return resample(in, ow, oh, p.get("hints"));
+        const int mode = ifhip::constraint_mode_from_name(m);
+        if (mode < 0) raise(kInvalidJson, "InvalidJson: unknown constrain mode '%s'", m.c_str());
+        float gx = 50.f, gy = 50.f;
+        const bool has_gravity = parse_gravity(p.get("gravity"), &gx, &gy);
+        ifhip::ConstraintLayout lay;
+        std::string err;
+        if (!ifhip::process_constraint(mode, static_cast<int32_t>(in->w), static_cast<int32_t>(in->h), has_w ? tw : -1, has_h ? th : -1, has_gravity, gx, gy, &lay, &err))
+            raise(kArgumentInvalid, "InvalidNodeParams: Constraint error: %s", err.c_str());                              // constrain.rs:50-52
+        FramePtr f = in;
+        if (lay.has_crop) {                                                                                                // :55-57
+            Timed t(this, "crop_mutate");
+            f = crop_frame(f, lay.crop[0], lay.crop[1], lay.crop[2], lay.crop[3]);
+        }
+        // canvas_color overrides the hints' background_color (:60-76)
+        const JVal* hints = p.get("hints");
+        const JVal* cc = p.get("canvas_color");
+        const bool has_cc = cc && !cc->is_null();
+        JVal merged;
+        if (has_cc) {
+            if (hints && hints->t == JVal::Obj) merged = *hints;
+            merged.t = JVal::Obj;
+            bool set = false;
+            for (auto& kv : merged.o) if (kv.first == "background_color") { kv.second = *cc; set = true; }
+            if (!set) merged.o.emplace_back("background_color", *cc);
+            hints = &merged;
+        }
+        f = resample(f, static_cast<uint32_t>(lay.scale_w), static_cast<uint32_t>(lay.scale_h), hints);                    // :78-82
+        if (lay.has_pad) {                                                                                                 // :84-92: canvas_color or Transparent
+            Timed t(this, "expand_canvas");
+            f = expand_frame(f, lay.pad[0], lay.pad[1], lay.pad[2], lay.pad[3], has_cc ? parse_color(cc, "constrain.canvas_color") : 0u, !has_cc || keyword_transparent(cc));
+        }
+        return f;
+    }
+    // ConstraintGravity (imageflow_types lib.rs:1054-1061): "center" | {"percentage": {x, y}} -> false for centre / absent
+    static bool parse_gravity(const JVal* g, float* gx, float* gy) {
+        if (!g || g->is_null() || (g->t == JVal::Str && g->s == "center")) return false;
+        const JVal* pc = g->get("percentage");
+        const JVal *jx = pc ? pc->get("x") : nullptr, *jy = pc ? pc->get("y") : nullptr;
+        if (!jx || !jy || jx->t != JVal::Num || jy->t != JVal::Num) raise(kInvalidJson, "InvalidJson: gravity is \"center\" or {\"percentage\":{x,y}}");
+        *gx = static_cast<float>(jx->n); *gy = static_cast<float>(jy->n);
+        return true;
+    }
+    // Crop (clone_crop_fill_expand.rs:519-541), materialised as a copy that keeps the parent's state
+    FramePtr crop_frame(const FramePtr& in, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2) {
+        if (x2 <= x1 || y2 <= y1 || x2 > in->w || y2 > in->h) raise(kArgumentInvalid, "InvalidNodeParams: Invalid crop bounds");
+        FramePtr cv = new_frame(x2 - x1, y2 - y1, in->alpha, 0, true);
+        const int compose = in->compose;                                              // Bitmap::crop is a window onto the same bitmap
+        const uint32_t matte = in->matte;                                             // (bitmaps.rs:841-859): its compositing mode stays
+        copy_into_canvas(in, cv, x1, y1, x2 - x1, y2 - y1, 0, 0);
+        cv->compose = compose; cv->matte = matte;
+        return cv;
+    }
+    // ExpandCanvas (:224-262): CreateCanvas of the colour (Bgra32 unless the colour is opaque) + CopyRectToCanvas
+    FramePtr expand_frame(const FramePtr& in, uint32_t l, uint32_t t2, uint32_t r, uint32_t b, uint32_t color, bool color_is_keyword_transparent) {
+        const uint64_t nw = static_cast<uint64_t>(in->w) + l + r, nh = static_cast<uint64_t>(in->h) + t2 + b;
+        check_size(sec.max_frame_size, "max_frame_size", nw, nh);                     // before the 32-bit sums can wrap
+        FramePtr cv = new_frame(static_cast<uint32_t>(nw), static_cast<uint32_t>(nh), (color >> 24) == 255 ? in->alpha : true, color, true, !color_is_keyword_transparent);
+        return copy_into_canvas(in, cv, 0, 0, in->w, in->h, l, t2);
     }
 
     // command_string {kind: "ir4", value: "width=200&..."}: the querystring form of BASELINE config 1.  Only the sizing
@@ -1494,20 +1546,19 @@ struct Job {
             }
         const JVal* fm = p.get("fit_mode");
         const std::string mode = fm && fm->t == JVal::Str ? fm->s : "within";                                            // :121
-        if (mode != "within" && mode != "fit" && mode != "distort")
-            raise(kActionNotSupported, "ActionNotSupported: watermark fit_mode '%s' (this shim: within, fit, distort -- the crop / pad modes need imageflow_riapi's layout engine)", mode.c_str());
+        if (mode != "within" && mode != "fit" && mode != "distort" && mode != "within_crop" && mode != "fit_crop")       // WatermarkConstraintMode (lib.rs:1022-1040)
+            raise(kInvalidJson, "InvalidJson: unknown watermark fit_mode '%s'", mode.c_str());
         uint32_t mw = 0, mh = 0;
         image_size(io_id, &mw, &mh, true);                                                                                // get_scaled_rotated_image_info (:128)
-        uint32_t w, h;
-        constrain_size(mode, mw, mh, true, true, bx2 - bx1, by2 - by1, &w, &h);
         float gx = 50.f, gy = 50.f;                                                                                       // obey_gravity (:69-86)
-        if (const JVal* g = p.get("gravity"))
-            if (!g->is_null() && !(g->t == JVal::Str && g->s == "center")) {
-                const JVal* pc = g->get("percentage");
-                const JVal *jx = pc ? pc->get("x") : nullptr, *jy = pc ? pc->get("y") : nullptr;
-                if (!jx || !jy || jx->t != JVal::Num || jy->t != JVal::Num) raise(kInvalidJson, "InvalidJson: gravity is \"center\" or {\"percentage\":{x,y}}");
-                gx = static_cast<float>(jx->n); gy = static_cast<float>(jy->n);
-            }
+        const bool has_gravity = parse_gravity(p.get("gravity"), &gx, &gy);
+        // Constraint {mode, w: box_w, h: box_h, hints: None, gravity, canvas_color: None} -> process_constraint (:121-139)
+        ifhip::ConstraintLayout lay;
+        std::string err;
+        if (!ifhip::process_constraint(ifhip::constraint_mode_from_name(mode), static_cast<int32_t>(mw), static_cast<int32_t>(mh), bx2 - bx1, by2 - by1,
+                                       has_gravity, gx, gy, &lay, &err))
+            raise(kArgumentInvalid, "InvalidNodeParams: Constraint error: %s", err.c_str());                              // (the reference unwraps: a panic)
+        const uint32_t w = static_cast<uint32_t>(lay.scale_w), h = static_cast<uint32_t>(lay.scale_h);
         auto gravity1d = [](float pct, int64_t inner, int64_t outer) -> int64_t {                                         // :60-67
             const float ratio = std::min(std::max(pct, 0.f), 100.f) / 100.f;
             if ((outer < inner && inner < 1) || outer < 1) raise(kArgumentInvalid, "InvalidNodeParams: Watermark fit_box does not work");
@@ -1516,6 +1567,10 @@ struct Job {
         const int64_t x1 = gravity1d(gx, w, bx2 - bx1) + bx1, y1 = gravity1d(gy, h, by2 - by1) + by1;
         if (x1 < 0 || y1 < 0) raise(kArgumentInvalid, "InvalidNodeParams: Watermark fit_box does not work");
         FramePtr mark = decode_oriented(io_id, 0, 0, false, false);
+        if (lay.has_crop) {                                                                                              // :157-164
+            Timed t(this, "crop_mutate");
+            mark = crop_frame(mark, lay.crop[0], lay.crop[1], lay.crop[2], lay.crop[3]);
+        }
         float opacity = 1.f;
         if (const JVal* o = p.get("opacity")) if (o->t == JVal::Num) opacity = std::min(std::max(static_cast<float>(o->n), 0.f), 1.f);
         if (opacity < 1.f) {                                                                                             // :166-172
@@ -1599,20 +1654,11 @@ struct Job {
         if (name == "expand_canvas") {                                                // :224-262
             const uint32_t l = want_u32(p, "left", "expand_canvas"), t2 = want_u32(p, "top", "expand_canvas"), r = want_u32(p, "right", "expand_canvas"),
                            b = want_u32(p, "bottom", "expand_canvas"), color = parse_color(p.get("color"), "expand_canvas.color");
-            const uint64_t nw = static_cast<uint64_t>(in->w) + l + r, nh = static_cast<uint64_t>(in->h) + t2 + b;
-            check_size(sec.max_frame_size, "max_frame_size", nw, nh);                 // before the 32-bit sums can wrap
-            FramePtr cv = new_frame(static_cast<uint32_t>(nw), static_cast<uint32_t>(nh), (color >> 24) == 255 ? in->alpha : true, color, true, !keyword_transparent(p.get("color")));
-            return copy_into_canvas(in, cv, 0, 0, in->w, in->h, l, t2);
+            return expand_frame(in, l, t2, r, b, color, keyword_transparent(p.get("color")));
         }
         if (name == "crop") {                                                         // :519-541 (materialised: a copy)
             const uint32_t x1 = want_u32(p, "x1", "crop"), y1 = want_u32(p, "y1", "crop"), x2 = want_u32(p, "x2", "crop"), y2 = want_u32(p, "y2", "crop");
-            if (x2 <= x1 || y2 <= y1 || x2 > in->w || y2 > in->h) raise(kArgumentInvalid, "InvalidNodeParams: Invalid crop bounds");
-            FramePtr cv = new_frame(x2 - x1, y2 - y1, in->alpha, 0, true);
-            const int compose = in->compose;                                          // Bitmap::crop is a window onto the same bitmap
-            const uint32_t matte = in->matte;                                         // (bitmaps.rs:841-859): its compositing mode stays
-            copy_into_canvas(in, cv, x1, y1, x2 - x1, y2 - y1, 0, 0);
-            cv->compose = compose; cv->matte = matte;
-            return cv;
+            return crop_frame(in, x1, y1, x2, y2);
         }
         if (name == "region" || name == "region_percent") {                            // :263-452
             // RegionPercent rewrites itself into Region with pixel corners (get_coords :265-286: f32 arithmetic, round half
@@ -1941,6 +1987,21 @@ void imageflow_context_request_cancellation(struct imageflow_context* c) {
 void ifhip_shim_request_cancellation_after_n_polls(struct imageflow_context* c, int64_t polls) {
     CTX_OR_ABORT(c);
     c->poll_countdown.store(polls, std::memory_order_seq_cst);
+}
+int ifhip_shim_process_constraint(const char* mode, int32_t source_w, int32_t source_h, int64_t w, int64_t h, int has_gravity, float gravity_x,
+                                  float gravity_y, uint32_t* crop, int32_t* scale_to, uint32_t* pad, int32_t* canvas, int* flags) {
+    if (!mode || !crop || !scale_to || !pad || !canvas || !flags) return 2;
+    const int m = ifhip::constraint_mode_from_name(mode);
+    if (m < 0) return 2;
+    ifhip::ConstraintLayout l;
+    std::string err;
+    if (!ifhip::process_constraint(m, source_w, source_h, w, h, has_gravity != 0, gravity_x, gravity_y, &l, &err)) return 1;
+    std::memcpy(crop, l.crop, sizeof l.crop);
+    std::memcpy(pad, l.pad, sizeof l.pad);
+    scale_to[0] = l.scale_w; scale_to[1] = l.scale_h;
+    canvas[0] = l.canvas_w; canvas[1] = l.canvas_h;
+    *flags = (l.has_crop ? 1 : 0) | (l.has_pad ? 2 : 0);
+    return 0;
 }
 int64_t ifhip_shim_cancellation_polls_remaining(struct imageflow_context* c) {
     CTX_OR_ABORT(c);

@@ -11,7 +11,7 @@
  * What a job may contain (anything else answers ActionNotSupported, HTTP 400): decode (baseline JPEG, or the raw
  * BGRA container EXTENSION), create_canvas, fill_rect, expand_canvas, crop, flip_h/flip_v, transpose, rotate_90/180/270,
  * apply_orientation, color_matrix_srgb, color_filter_srgb, resample_2d, draw_image_exact and copy_rect_to_canvas (graph
- * form, with a `canvas` edge), watermark (fit_mode within | fit | distort), constrain (within | fit | distort),
+ * form, with a `canvas` edge), watermark (all five fit modes), constrain (all nine modes, gravity, canvas_color),
  * command_string (ir4: width/height, mode=max), encode.
  * `encode` with the libjpeg_turbo preset writes a real JPEG (quality, matte, progressive, optimize_huffman_coding:
  * byte-identical to libjpeg-turbo's file for the same pixels at 4:2:0); every other preset writes the raw BGRA container
@@ -117,6 +117,17 @@ IMAGEFLOW_SHIM_API int64_t ifhip_shim_coalesced_decodes(struct imageflow_context
 IMAGEFLOW_SHIM_API void ifhip_shim_spread_contexts(int enable);
 IMAGEFLOW_SHIM_API bool ifhip_shim_context_set_device(struct imageflow_context *context, int ordinal);
 IMAGEFLOW_SHIM_API int ifhip_shim_context_device(struct imageflow_context *context);
+
+/* The layout arithmetic behind the `constrain` and `watermark` nodes, callable on its own (no GPU, no context):
+ * imageflow_riapi::ir4::process_constraint (imageflow_riapi/src/ir4/layout.rs:334-412) for a source of source_w x source_h
+ * and a Constraint {mode, w, h, gravity}.  mode: "distort" | "within" | "fit" | "larger_than" | "within_crop" | "fit_crop" |
+ * "aspect_crop" | "within_pad" | "fit_pad"; w / h < 0: not given; has_gravity 0: centre.  Out: crop_x1y1x2y2[4] (valid when
+ * bit 0 of *flags), scale_to_wh[2], pad_ltrb[4] (valid when bit 1 of *flags), canvas_wh[2].  Returns 0, 1 for a LayoutError
+ * (the reference's Err), 2 for an unknown mode or a null pointer. */
+IMAGEFLOW_SHIM_API int ifhip_shim_process_constraint(const char *mode, int32_t source_w, int32_t source_h, int64_t w, int64_t h,
+                                                     int has_gravity, float gravity_x, float gravity_y,
+                                                     uint32_t *crop_x1y1x2y2, int32_t *scale_to_wh, uint32_t *pad_ltrb,
+                                                     int32_t *canvas_wh, int *flags);
 
 #ifdef __cplusplus
 }

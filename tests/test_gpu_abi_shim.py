@@ -463,6 +463,40 @@ def test_canvas_compositing_state_follows_the_reference_from_node_to_node():
     assert np.array_equal(rows[:, :360], oracle_draw(_canvas_rows(90, 100), 90, 100, O.BLEND_WITH_SELF)[:, :360])
 
 
+def test_constrain_crop_and_pad_modes_equal_the_oracle_chain():
+    """flow/nodes/constrain.rs:41-98: [Crop] -> Resample2D (canvas_color over hints.background_color) -> [ExpandCanvas], sizes by
+    imageflow_riapi's process_constraint (csrc/layout.cpp; tests/test_constraint_layout.py pins the arithmetic).  Expected
+    pixels: the oracle on the cropped window, copied into a canvas of the colour."""
+    src = U.random_frames(1, 200, 100, seed0=81, alpha=False)[0]
+
+    def run(c):
+        with Context() as ctx:
+            ctx.add_input_buffer(0, pack_raw_bgra(src, 200, 100, alpha_meaningful=False))
+            ctx.add_output_buffer(1)
+            _run(ctx, "v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"constrain": c}, {"encode": {"io_id": 1, "preset": "gif"}}]}})
+            return unpack_raw_bgra(ctx.get_output_buffer(1))
+    # fit_crop to a square, gravity right: columns 100..200 of the source, scaled to 50x50
+    rows, w, h, alpha = run({"mode": "fit_crop", "w": 50, "h": 50, "gravity": {"percentage": {"x": 100, "y": 50}}, "hints": {"down_filter": "lanczos"}})
+    win = np.zeros((100, U.stride_for(100)), np.uint8)
+    win[:, :400] = src[:, 400:800]
+    assert (w, h, alpha) == (50, 50, False) and np.array_equal(rows, _oracle_resize(win, 100, 100, 50, 50, filter_id=6))
+    # fit_pad into 120x120 on an opaque colour: the 120x60 image in the middle of the canvas
+    rows, w, h, alpha = run({"mode": "fit_pad", "w": 120, "h": 120, "canvas_color": {"srgb": {"hex": "336699FF"}}})
+    img = _oracle_resize(src, 200, 100, 120, 60, filter_id=2)
+    can = _canvas_rows(120, 120, (0x99, 0x66, 0x33, 0xFF))
+    rc, can_alpha = O.copy_rect(img, 120, 60, img.shape[1], False, can, 120, 120, can.shape[1], False, 0, 0, 0, 30, 120, 60)
+    assert rc == 0 and (w, h, alpha) == (120, 120, False) and np.array_equal(rows[:, :480], can[:, :480])
+    # within_pad without a colour pads with Transparent: a Bgra32 canvas (clone_crop_fill_expand.rs:236)
+    rows, w, h, alpha = run({"mode": "within_pad", "w": 80, "h": 80})
+    img = _oracle_resize(src, 200, 100, 80, 40, filter_id=2)
+    can = _canvas_rows(80, 80)
+    rc, can_alpha = O.copy_rect(img, 80, 40, img.shape[1], False, can, 80, 80, can.shape[1], True, 0, 0, 0, 20, 80, 40)
+    assert rc == 0 and (w, h, alpha) == (80, 80, True) and np.array_equal(rows[:, :320], can[:, :320])
+    # aspect_crop changes no pixel: the middle 100 columns
+    rows, w, h, alpha = run({"mode": "aspect_crop", "w": 10, "h": 10})
+    assert (w, h) == (100, 100) and np.array_equal(rows[:, :400], src[:, 200:600])
+
+
 def test_graph_copy_rect_to_canvas_matches_the_oracle():
     """visuals/composition.rs:111-160 (test_graph_copy_rect_to_canvas): 100x100 of the input copied to (50,50) of a red
     300x300 Bgra32 canvas."""

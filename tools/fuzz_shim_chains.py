@@ -78,7 +78,7 @@ def rand_hints(rng, allow_when=True):
 
 def draw_node(rng, w, h, mark=None):
     """-> (json node, new (w, h) estimate) for a frame of w x h; `mark` = (w, h) of the watermark input when the job has one"""
-    k = int(rng.integers(0, 17))
+    k = int(rng.integers(0, 19))
     if k == 0:
         return "flip_h", (w, h)
     if k == 1:
@@ -129,7 +129,7 @@ def draw_node(rng, w, h, mark=None):
             wm["fit_box"] = {"image_margins": {"left": int(rng.integers(0, 1 + w // 2)), "top": int(rng.integers(0, 1 + h // 2)),
                                                "right": int(rng.integers(0, 1 + w // 2)), "bottom": int(rng.integers(0, 1 + h // 2))}}
         if rng.random() < 0.7:
-            wm["fit_mode"] = ["within", "fit", "distort"][int(rng.integers(0, 3))]
+            wm["fit_mode"] = ["within", "fit", "distort", "within_crop", "fit_crop"][int(rng.integers(0, 5))]
         if rng.random() < 0.6:
             wm["gravity"] = {"percentage": {"x": float(rng.integers(-10, 120)), "y": float(rng.integers(-10, 120))}}
         if rng.random() < 0.6:
@@ -139,6 +139,20 @@ def draw_node(rng, w, h, mark=None):
         if rng.random() < 0.15:
             wm["min_canvas_height"] = int(rng.integers(0, 150))
         return {"watermark": wm}, (w, h)
+    if k in (14, 15):
+        mode = ["distort", "within", "fit", "larger_than", "within_crop", "fit_crop", "aspect_crop", "within_pad", "fit_pad"][int(rng.integers(0, 9))]
+        c = {"mode": mode}
+        if rng.random() < 0.85:
+            c["w"] = max(1, int(w * rng.uniform(0.2, 2.0)))
+        if rng.random() < 0.85:
+            c["h"] = max(1, int(h * rng.uniform(0.2, 2.0)))
+        if rng.random() < 0.5:
+            c["hints"] = rand_hints(rng)
+        if rng.random() < 0.4:
+            c["gravity"] = {"percentage": {"x": float(rng.integers(-10, 120)), "y": float(rng.integers(-10, 120))}} if rng.random() < 0.8 else "center"
+        if rng.random() < 0.4:
+            c["canvas_color"] = rand_color(rng)
+        return {"constrain": c}, None               # (the size is the layout engine's: the chain ends here)
     # resample_2d (more likely than any other node)
     same = rng.random() < 0.2
     ow = w if same else max(1, int(w * rng.uniform(0.2, 2.2)))
@@ -157,22 +171,33 @@ def draw_chain(rng, w, h, max_nodes, mark=None):
     return nodes, (w, h)
 
 
-# ---- imageflow_riapi/src/sizing.rs:70-197 restated for the watermark's constraint (Within / Fit / Distort with both sides given)
+# ---- imageflow_riapi restated for the constrain / watermark nodes: sizing.rs (AspectRatio :35-222, Layout :304-450) and
+# ---- ir4/layout.rs (step programs :160-283, process_constraint :334-412, gravity :673-698)
+class LayoutError(ValueError):
+    pass
+
+
 def _rround(v):                                     # f64::round / f32::round: half away from zero
     import math
     return math.copysign(math.floor(abs(v) + 0.5), v)
 
 
-def _proportional(sw, sh, basis, basis_is_width, target):
+def _create(w, h):
+    if w < 1 or h < 1:
+        raise LayoutError(f"InvalidDimensions {w}x{h}")
+    return (int(w), int(h))
+
+
+def _proportional(sw, sh, basis, basis_is_width, target=None):
     ratio = sw / sh
-    if basis_is_width:                              # rounding_loss_based_on_target_height(target.h)  (:100-115)
-        rounded_x = _rround(sw * (target[1] / sh))
-        snap_amount = abs(target[1] - rounded_x / ratio)
-    else:                                           # rounding_loss_based_on_target_width(target.w)   (:81-97)
-        rounded_y = _rround(sh * (target[0] / sw))
-        snap_amount = abs(target[0] - rounded_y * ratio)
+    snap_amount = 1.0 - 2.220446049250313e-16
+    if target is not None:
+        if basis_is_width:                          # rounding_loss_based_on_target_height(target.h)  (:100-115)
+            snap_amount = abs(target[1] - _rround(sw * (target[1] / sh)) / ratio)
+        else:                                       # rounding_loss_based_on_target_width(target.w)   (:81-97)
+            snap_amount = abs(target[0] - _rround(sh * (target[0] / sw)) * ratio)
     snap_a = sh if basis_is_width else sw
-    snap_b = target[1] if basis_is_width else target[0]
+    snap_b = snap_a if target is None else (target[1] if basis_is_width else target[0])
     f = basis / ratio if basis_is_width else ratio * basis
     da, db = f - snap_a, f - snap_b
     if abs(da) <= snap_amount and abs(da) <= abs(db):
@@ -181,17 +206,107 @@ def _proportional(sw, sh, basis, basis_is_width, target):
         v = snap_b
     else:
         v = int(_rround(f))
+    if v < 0:
+        raise LayoutError("ValueScalingFailed")
     return max(v, 1)
 
 
-def _inner_box(sw, sh, tw, th):                     # box_of(target, Inner) (:184-192)
-    if sw / sh > tw / th:                           # target.aspect_wider_than(self) = self.ratio > target.ratio
-        return tw, _proportional(sw, sh, tw, True, (tw, th))
-    return _proportional(sw, sh, th, False, (tw, th)), th
+def _box_of(self, target, inner):                   # AspectRatio::box_of (:185-193)
+    self_wider = self[0] / self[1] > target[0] / target[1]          # target.aspect_wider_than(self)
+    if self_wider == inner:
+        return _create(target[0], _proportional(self[0], self[1], target[0], True, target))
+    return _create(_proportional(self[0], self[1], target[1], False, target), target[1])
+
+
+def _inner_box(sw, sh, tw, th):
+    return _box_of((sw, sh), (tw, th), True)
+
+
+def _gravity1d(pct, inner, outer):                  # ir4/layout.rs:673-683
+    f32 = np.float32
+    if (outer < inner and inner < 1) or outer < 1:
+        raise LayoutError("gravity")
+    v = int(_rround(float(f32(outer - inner) * (f32(min(max(pct, 0.0), 100.0)) / f32(100)))))
+    return max(0, min(v, outer - inner))
+
+
+def process_constraint(mode, sw, sh, w, h, gravity=None):
+    """-> (crop [x1, y1, x2, y2] or None, scale_to (w, h), pad [l, t, r, b] or None, canvas (w, h)); w / h None: not given"""
+    initial = _create(sw, sh)
+    some_w, some_h = w is not None and w >= 1, h is not None and h >= 1
+    if some_w and some_h:
+        target = _create(w, h)
+    elif some_w:
+        target = _create(w, _proportional(sw, sh, w, True))
+    elif some_h:
+        target = _create(_proportional(sw, sh, h, False), h)
+    else:
+        target = initial
+    fit, scale = {"distort": ("stretch", "both"), "within": ("max", "down"), "fit": ("max", "both"), "larger_than": ("max", "up"),
+                  "within_crop": ("crop", "down"), "fit_crop": ("crop", "both"), "aspect_crop": ("aspect", "down"),
+                  "within_pad": ("pad", "down"), "fit_pad": ("pad", "both")}[mode]
+    if w is None and h is None:
+        fit = "max"
+    L = {"source": initial, "canvas": initial, "image": initial}
+
+    def cmp():
+        return ((L["canvas"][0] > target[0]) - (L["canvas"][0] < target[0]), (L["canvas"][1] > target[1]) - (L["canvas"][1] < target[1]))
+
+    def distort_with(s, old, new):
+        return _create(s[0] * new[0] // old[0], s[1] * new[1] // old[1])
+
+    def scale_canvas(inner):
+        nc = _box_of(L["canvas"], target, inner)
+        L["image"] = distort_with(L["image"], L["canvas"], nc)
+        L["canvas"] = nc
+
+    def crop(t):
+        if t[0] > L["canvas"][0] or t[1] > L["canvas"][1]:
+            raise LayoutError("ImpossibleCrop")
+        ni = _create(min(L["image"][0], t[0]), min(L["image"][1], t[1]))
+        L["source"] = _box_of(ni, L["source"], True)
+        L["image"], L["canvas"] = ni, t
+    gate = scale == "both" or (scale == "down" and 1 in cmp()) or (scale == "up" and 1 not in cmp())
+    if fit == "max":
+        if gate:
+            scale_canvas(True)
+    elif fit == "pad":
+        if gate:
+            scale_canvas(True)
+            if L["canvas"][0] > target[0] or L["canvas"][1] > target[1]:
+                raise LayoutError("ImpossiblePad")
+            L["canvas"] = target
+    elif fit == "stretch":
+        if gate:
+            L["image"] = distort_with(L["image"], L["canvas"], target)
+            L["canvas"] = target
+    elif fit == "crop":
+        if scale == "both":
+            scale_canvas(False)
+            crop(target)
+        else:
+            if -1 not in cmp():
+                scale_canvas(False)
+                crop(target)
+            if cmp() in ((1, -1), (-1, 1)):
+                crop(_create(min(L["image"][0], target[0]), min(L["image"][1], target[1])))
+    else:
+        crop(_box_of(target, L["canvas"], True))
+    gx, gy = gravity if gravity is not None else (50.0, 50.0)
+    src = L["source"]
+    cx, cy = _gravity1d(gx, src[0], initial[0]), _gravity1d(gy, src[1], initial[1])
+    out_crop = [cx, cy, cx + src[0], cy + src[1]] if (cx > 0 or cy > 0 or src != initial) else None
+    img, cv = L["image"], L["canvas"]
+    left, top = _gravity1d(gx, img[0], cv[0]), _gravity1d(gy, img[1], cv[1])
+    right, bottom = cv[0] - img[0] - left, cv[1] - img[1] - top
+    pad = [left, top, right, bottom] if max(left, top, right, bottom) > 0 else None
+    if pad and min(pad) < 0:
+        raise LayoutError("negative padding")
+    return out_crop, img, pad, cv
 
 
 def watermark_placement(cw, ch, mw, mh, wm):
-    """-> None (the node disappears) or (x, y, w, h); flow/nodes/watermark.rs:11-86, :109-150"""
+    """-> None (the node disappears) or (x, y, w, h, crop of the mark or None); flow/nodes/watermark.rs:11-86, :109-150"""
     f32 = np.float32
     if not (wm.get("min_canvas_width", 0) < cw and wm.get("min_canvas_height", 0) < ch):
         return None
@@ -208,20 +323,14 @@ def watermark_placement(cw, ch, mw, mh, wm):
             return None
         box = (m["left"], m["top"], cw - m["right"], ch - m["bottom"])
     bw, bh = box[2] - box[0], box[3] - box[1]
-    mode = wm.get("fit_mode", "within")
-    if mode == "distort":
-        tw, th = bw, bh
-    elif mode == "fit" or mw > bw or mh > bh:
-        tw, th = _inner_box(mw, mh, bw, bh)
-    else:
-        tw, th = mw, mh
     g = wm.get("gravity", {"percentage": {"x": 50.0, "y": 50.0}})["percentage"]
+    crop, (tw, th), _, _ = process_constraint(wm.get("fit_mode", "within"), mw, mh, bw, bh, (g["x"], g["y"]) if "gravity" in wm else None)
 
-    def g1(pct, inner, outer):                      # gravity1d (:60-67)
+    def g1(pct, inner, outer):                      # WatermarkDef::gravity1d (:60-67): no clamp of the result
         if (outer < inner and inner < 1) or outer < 1:
-            raise ValueError("Watermark fit_box does not work")
+            raise LayoutError("Watermark fit_box does not work")
         return int(_rround(float(f32(outer - inner) * (f32(min(max(pct, 0.0), 100.0)) / f32(100)))))
-    return g1(g["x"], tw, bw) + box[0], g1(g["y"], th, bh) + box[1], tw, th
+    return g1(g["x"], tw, bw) + box[0], g1(g["y"], th, bh) + box[1], tw, th, crop
 
 
 def hints_of(hints, M):
@@ -280,11 +389,25 @@ def mirror_apply(b, node, M, mark=None):
         place = watermark_placement(b.w, b.h, mw, mh, p)
         if place is None:
             return b
-        x, y, w, h = place
+        x, y, w, h, mcrop = place
         if x < 0 or y < 0:
             raise M[9](M[10].InvalidArgument, "Watermark fit_box does not work")
         m = Bm.Bitmap.from_numpy(mark_src[None].copy(), mw, mh, mark_src.shape[1], b.data.device, alpha_meaningful=True)
-        WM.draw_watermark(b, m, x, y, w, h, opacity=p.get("opacity"))
+        WM.draw_watermark(b, m, x, y, w, h, opacity=p.get("opacity"), crop=mcrop)
+        return b
+    if name == "constrain":
+        # ConstrainDef::expand (constrain.rs:41-98): [Crop] -> Resample2D (canvas_color over hints.background_color) -> [ExpandCanvas]
+        g = p["gravity"]["percentage"] if isinstance(p.get("gravity"), dict) else None
+        crop, (sw, sh), pad, _ = process_constraint(p["mode"], b.w, b.h, p.get("w"), p.get("h"), (g["x"], g["y"]) if g else None)
+        if crop:
+            b = CC.crop(b, *crop)
+        hints = dict(p.get("hints") or {})
+        if p.get("canvas_color") is not None:
+            hints["background_color"] = p["canvas_color"]
+        b = mirror_apply(b, {"resample_2d": {"w": sw, "h": sh, "hints": hints}}, M)
+        if pad:
+            cc = p.get("canvas_color")
+            b = CC.expand_canvas(b, pad[0], pad[1], pad[2], pad[3], color32_of(cc, color32) if cc is not None else 0, cc is None or cc == "transparent")
         return b
     if name == "resample_2d":
         # Scale2dDef / the Resample2D expansion, scale_render.rs:30-120, then DrawImageExact :139-201
