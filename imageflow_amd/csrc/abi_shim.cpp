@@ -1658,7 +1658,9 @@ struct Job {
         }
         if (name == "crop") {                                                         // :519-541 (materialised: a copy)
             const uint32_t x1 = want_u32(p, "x1", "crop"), y1 = want_u32(p, "y1", "crop"), x2 = want_u32(p, "x2", "crop"), y2 = want_u32(p, "y2", "crop");
-            return crop_frame(in, x1, y1, x2, y2);
+            FramePtr cv = crop_frame(in, x1, y1, x2, y2);
+            if (in_shared) { cv->compose = IFHIP_BLEND_WITH_SELF; cv->matte = 0; }    // CROP is MutProtect (clone_crop_fill_expand.rs:6): a window onto the Clone
+            return cv;
         }
         if (name == "region" || name == "region_percent") {                            // :263-452
             // RegionPercent rewrites itself into Region with pixel corners (get_coords :265-286: f32 arithmetic, round half
@@ -1700,7 +1702,7 @@ struct Job {
             const uint32_t el = static_cast<uint32_t>(std::max<int64_t>(0, -x1)), et = static_cast<uint32_t>(std::max<int64_t>(0, -y1));
             const uint32_t er = static_cast<uint32_t>(std::max<int64_t>(0, x2 - iw)), eb = static_cast<uint32_t>(std::max<int64_t>(0, y2 - ih));
             FramePtr part = in;
-            if (cx1 != 0 || cy1 != 0 || cx2 != in->w || cy2 != in->h) {               // Crop (a full-frame crop is the frame)
+            if (in_shared || cx1 != 0 || cy1 != 0 || cx2 != in->w || cy2 != in->h) {  // Crop (a full-frame crop is the frame -- unless the frame has other readers: CROP is MutProtect, and copy_rectangle below normalises its input's unused alpha in place)
                 part = new_frame(cx2 - cx1, cy2 - cy1, in->alpha, 0, true);
                 copy_into_canvas(in, part, cx1, cy1, cx2 - cx1, cy2 - cy1, 0, 0);
             }
@@ -1778,6 +1780,10 @@ struct Job {
         std::map<int64_t, int> consumers;
         for (const auto& kv : parent) ++consumers[kv.second];
         for (const auto& kv : canvas_parent) ++consumers[kv.second];
+        // "shared" is a property of the FRAME, not of the edge: a node that disappears (a resample_2d that has nothing to do, a
+        // watermark on too small a canvas: delete_node_and_snap_together) hands its input on, and its consumer then reads a
+        // frame the disappeared node's siblings still need
+        std::map<const Frame*, bool> frame_shared;
         std::function<FramePtr(int64_t)> eval = [&](int64_t id) -> FramePtr {
             auto it = done.find(id);
             if (it != done.end()) return it->second;
@@ -1791,16 +1797,18 @@ struct Job {
             auto pit = parent.find(id);
             if (pit != parent.end()) {
                 in = eval(pit->second);
-                in_shared = consumers[pit->second] > 1;
-                if (in && in_shared && mutates_input(name)) in = clone(in, true);
+                in_shared = in && frame_shared[in.get()];
+                if (in && in_shared && mutates_input(name)) { in = clone(in, true); in_shared = false; }
             }
             auto cit = canvas_parent.find(id);
             if (cit != canvas_parent.end()) {
                 canvas = eval(cit->second);
-                if (canvas && consumers[cit->second] > 1) canvas = clone(canvas);
+                if (canvas && frame_shared[canvas.get()]) canvas = clone(canvas);
             }
+            const FramePtr given = in;
             lazy_decode = consumers[id] == 1;
             FramePtr out = run_node(name, *params, in, canvas, in_shared);
+            if (out) frame_shared[out.get()] = consumers[id] > 1 || (out == given && in_shared);
             state[id] = 2;
             done[id] = out;
             return out;

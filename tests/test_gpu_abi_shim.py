@@ -497,6 +497,32 @@ def test_constrain_crop_and_pad_modes_equal_the_oracle_chain():
     assert (w, h) == (100, 100) and np.array_equal(rows[:, :400], src[:, 200:600])
 
 
+def test_a_frame_with_several_readers_is_not_changed_through_a_node_that_disappeared():
+    """The reference deletes a node that has nothing to do and snaps its neighbours together (delete_node_and_snap_together), so
+    the mutating node behind it sees the SHARED parent and MutProtect gives it a Clone (definitions.rs:320-341).  The interpreter
+    hands the frame through such a node: whether a frame has other readers is a property of the frame, not of the edge it
+    arrived on (round 6; before, the flip below ran in place on the decoded frame and the second output came out flipped).
+    Likewise region: its Crop is a MutProtect node, and copy_rectangle normalises its INPUT's unused alpha in place."""
+    src = U.random_frames(1, 60, 40, seed0=91, alpha=True)[0]
+    job = _graph({0: {"decode": {"io_id": 0}}, 1: {"resample_2d": {"w": 60, "h": 40, "hints": {}}}, 2: "flip_h", 3: {"encode": {"io_id": 1, "preset": "gif"}},
+                  4: {"encode": {"io_id": 2, "preset": "gif"}},
+                  5: {"region": {"x1": 0, "y1": 0, "x2": 70, "y2": 40, "background_color": {"srgb": {"hex": "10203080"}}}}, 6: {"encode": {"io_id": 3, "preset": "gif"}}},
+                 [(0, 1, "input"), (1, 2, "input"), (2, 3, "input"), (0, 4, "input"), (0, 5, "input"), (5, 6, "input")])
+    for alpha in (True, False):
+        with Context() as c:
+            c.add_input_buffer(0, pack_raw_bgra(src, 60, 40, alpha_meaningful=alpha))
+            for o in (1, 2, 3):
+                c.add_output_buffer(o)
+            _run(c, "v1/execute", job)
+            flipped = unpack_raw_bgra(c.get_output_buffer(1))[0]
+            same = unpack_raw_bgra(c.get_output_buffer(2))[0]
+            padded, pw, ph, palpha = unpack_raw_bgra(c.get_output_buffer(3))
+        px = src[:, :240].reshape(40, 60, 4)
+        assert np.array_equal(same[:, :240], src[:, :240]), alpha                      # every byte, the unused alpha too
+        assert np.array_equal(flipped[:, :240].reshape(40, 60, 4)[:, :, :3], px[:, ::-1, :3]), alpha
+        assert (pw, ph, palpha) == (70, 40, True) and np.array_equal(padded[:, :240].reshape(40, 60, 4)[:, :, :3], px[:, :, :3])
+
+
 def test_graph_copy_rect_to_canvas_matches_the_oracle():
     """visuals/composition.rs:111-160 (test_graph_copy_rect_to_canvas): 100x100 of the input copied to (50,50) of a red
     300x300 Bgra32 canvas."""

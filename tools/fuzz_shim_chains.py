@@ -493,6 +493,19 @@ def jpeg_bytes(src, w, h, spec):
     return f.getvalue()
 
 
+def rand_encode(rng):
+    enc = {}
+    if rng.random() < 0.8:
+        enc["quality"] = int(rng.integers(1, 101))
+    if rng.random() < 0.3:
+        enc["progressive"] = bool(rng.integers(0, 2))
+    if rng.random() < 0.3:
+        enc["optimize_huffman_coding"] = bool(rng.integers(0, 2))
+    if rng.random() < 0.4:
+        enc["matte"] = rand_color(rng)
+    return enc
+
+
 JPEG_POOL = [(64, 48, 2), (97, 61, 2), (160, 120, 0), (33, 100, 1)]       # (w, h, subsampling): geometries concurrent jobs share
 
 
@@ -514,17 +527,34 @@ def draw_case(rng, pool_jpeg=False):
             case["jpeg"]["subsampling"], case["jpeg"]["grey"] = pooled[2], False
         case["alpha"] = False
         _, w, h = hinted_size(w, h, case["jpeg"])
+    if rng.random() < 0.12:
+        # a TREE (the shape of export_4_sizes): source -> trunk -> a parent several branches read, each with its own chain and
+        # output.  The parent is shared: MutProtect puts a Clone before a mutating first node (definitions.rs:320-341); the
+        # nodes that would change a shared parent in place in the reference (fill_rect, a watermark drawn onto it, a JPEG
+        # encoder's matte) are kept off the branches' first position / the parent's own output -- there the reference's result
+        # depends on the order the engine happens to run the siblings in.
+        case["tree"] = True
+        case["nodes"], size = draw_chain(rng, w, h, int(rng.integers(0, 3)))
+        while case["nodes"] and isinstance(case["nodes"][-1], dict) and "constrain" in case["nodes"][-1]:
+            case["nodes"].pop()                           # (a constrain ends a chain without a size estimate: keep the trunk sized)
+            size = None
+        if size is None:
+            case["nodes"], size = [], (w, h)
+        case["parent_output"] = bool(rng.random() < 0.5)
+        case["branches"] = []
+        for _ in range(int(rng.integers(2, 4))):
+            while True:
+                chain, _ = draw_chain(rng, size[0], size[1], int(rng.integers(0, 4)), mark=case["mark"][:2])
+                first = chain[0] if chain else None
+                if not (isinstance(first, dict) and ("fill_rect" in first or "watermark" in first)):
+                    break
+            br = {"chain": chain}
+            if chain and rng.random() < 0.4:
+                br["encode"] = rand_encode(rng)
+            case["branches"].append(br)
+        return case
     if rng.random() < 0.25:
-        enc = {}
-        if rng.random() < 0.8:
-            enc["quality"] = int(rng.integers(1, 101))
-        if rng.random() < 0.3:
-            enc["progressive"] = bool(rng.integers(0, 2))
-        if rng.random() < 0.3:
-            enc["optimize_huffman_coding"] = bool(rng.integers(0, 2))
-        if rng.random() < 0.4:
-            enc["matte"] = rand_color(rng)
-        case["encode"] = enc
+        case["encode"] = rand_encode(rng)
     if rng.random() >= 0.25:
         case["nodes"], _ = draw_chain(rng, w, h, int(rng.integers(1, 7)), mark=case["mark"][:2])
         return case
@@ -561,6 +591,22 @@ def draw_case(rng, pool_jpeg=False):
 
 def job_of(case):
     """the JSON of v1/execute for a case"""
+    if case.get("tree"):
+        nodes, edges = {"0": decode_node(0, case.get("jpeg"))}, []
+        for n in case["nodes"]:
+            nodes[str(len(nodes))] = n
+            edges.append({"from": len(nodes) - 2, "to": len(nodes) - 1, "kind": "input"})
+        parent = len(nodes) - 1
+        if case["parent_output"]:
+            nodes[str(len(nodes))] = {"encode": {"io_id": 9, "preset": "gif"}}
+            edges.append({"from": parent, "to": len(nodes) - 1, "kind": "input"})
+        for k, br in enumerate(case["branches"]):
+            prev = parent
+            for n in br["chain"] + [{"encode": {"io_id": 10 + k, "preset": {"libjpeg_turbo": br["encode"]} if "encode" in br else "gif"}}]:
+                nodes[str(len(nodes))] = n
+                edges.append({"from": prev, "to": len(nodes) - 1, "kind": "input"})
+                prev = len(nodes) - 1
+        return {"framewise": {"graph": {"nodes": nodes, "edges": edges}}}
     enc = {"encode": {"io_id": 9, "preset": {"libjpeg_turbo": case["encode"]} if "encode" in case else "gif"}}
     if "join" not in case:
         return {"framewise": {"steps": [decode_node(0, case.get("jpeg"))] + case["nodes"] + [enc]}}
@@ -612,17 +658,41 @@ def run_shim(case, inp, E):
             iw, ih = case["input"]["size"]
             c.add_input_buffer(1, inp["file1"] if inp["file1"] is not None else pack_raw_bgra(inp["isrc"], iw, ih, alpha_meaningful=case["input"]["alpha"]))
         c.add_input_buffer(2, pack_raw_bgra(mark_src, mw, mh, alpha_meaningful=True))
-        c.add_output_buffer(9)
+        outs = ([9] if case["parent_output"] else []) + [10 + k for k in range(len(case["branches"]))] if case.get("tree") else [9]
+        for o in outs:
+            c.add_output_buffer(o)
         status, r = c.send_json("v1/execute", job_of(case))
         COUNTS["coalesced_decodes"] += int(c.L.ifhip_shim_coalesced_decodes(c.p))          # (+= of an int under the GIL)
         COUNTS["fused_decode_resamples"] += int(c.L.ifhip_shim_fused_decode_resamples(c.p))
         COUNTS["device_coded_files"] += int(c.L.ifhip_shim_device_coded_files(c.p))
         if status != 200:
             return f"{status}: {c.error_message()[:160]}", None
-        if "encode" in case:
-            return None, bytes(c.get_output_buffer(9))
-        rows, gw, gh, galpha = unpack_raw_bgra(c.get_output_buffer(9))
-        return None, (rows[:, :4 * gw].copy(), gw, gh, galpha)
+        def out(o, is_file):
+            if is_file:
+                return bytes(c.get_output_buffer(o))
+            rows, gw, gh, galpha = unpack_raw_bgra(c.get_output_buffer(o))
+            return (rows[:, :4 * gw].copy(), gw, gh, galpha)
+        if case.get("tree"):
+            return None, [out(o, o >= 10 and "encode" in case["branches"][o - 10]) for o in outs]
+        return None, out(9, "encode" in case)
+
+
+def jpeg_file_of(b, enc, E):
+    """MozjpegEncoder::write_frame (mozjpeg.rs:88-94): the frame flattened onto the matte (default white), then the file
+    libjpeg-turbo (Pillow) writes from those pixels at 4:2:0"""
+    import io
+
+    from PIL import Image, ImageFile
+    ImageFile.MAXBLOCK = 1 << 24
+    matte = enc.get("matte")
+    E[8].apply_matte(b, 0xFFFFFFFF if matte is None else color32_of(matte, E[6][5]))
+    E[0].cuda.synchronize()
+    out = b.to_numpy()[0]
+    rgb = np.ascontiguousarray(out[:, :4 * b.w].reshape(b.h, b.w, 4)[:, :, 2::-1])
+    f = io.BytesIO()
+    Image.fromarray(rgb).save(f, "JPEG", quality=enc.get("quality", 75), subsampling="4:2:0", optimize=bool(enc.get("optimize_huffman_coding", False)),
+                              progressive=bool(enc.get("progressive", False)))
+    return f.getvalue()
 
 
 def run_mirror(case, inp, E):
@@ -639,6 +709,40 @@ def run_mirror(case, inp, E):
                 return E[7].decode_frames([file], "cuda:0", scale_num=scale, luma_spatial=spatial,
                                           luma_srgb=spatial and hi.get("gamma_correct_for_srgb_during_spatial_luma_scaling", False))
             return Bm.Bitmap.from_numpy(s[None].copy(), fw, fh, s.shape[1], "cuda:0", alpha_meaningful=alpha)
+        def finish(b, enc):
+            if enc is None:
+                torch.cuda.synchronize()
+                out = b.to_numpy()[0]
+                return (out[:, :4 * b.w].copy(), b.w, b.h, bool(b.alpha_meaningful))
+            return jpeg_file_of(b, enc, E)
+        if case.get("tree"):
+            parent = frame(inp["src"], w, h, case["alpha"], inp["file0"], case.get("jpeg"))
+            for node in case["nodes"]:
+                parent = mirror_apply(parent, node, M, inp["mark"])
+            results = [finish(parent, None)] if case["parent_output"] else []
+            for br in case["branches"]:
+                b = parent
+                for node in br["chain"]:
+                    name = node if isinstance(node, str) else next(iter(node))
+                    # the node reads the shared parent (it is the first, or the ones before it disappeared and were snapped
+                    # together): MutProtect puts a Clone before a mutating node whose parent has other children
+                    # (definitions.rs:334-337); fill_rect and watermark are not MutProtect nodes -- the interpreter copies for
+                    # them too, the reference would change the siblings' input
+                    if b is parent and name in ("flip_h", "flip_v", "rotate_90", "rotate_180", "apply_orientation", "color_filter_srgb", "color_matrix_srgb",
+                                                "crop", "region", "region_percent", "fill_rect", "watermark"):
+                        b = M[0].clone(parent)
+                    if b is parent and name == "constrain":              # its Crop, when the layout has one, is a MutProtect node too
+                        g = node["constrain"]["gravity"]["percentage"] if isinstance(node["constrain"].get("gravity"), dict) else None
+                        try:
+                            if process_constraint(node["constrain"]["mode"], b.w, b.h, node["constrain"].get("w"), node["constrain"].get("h"),
+                                                  (g["x"], g["y"]) if g else None)[0]:
+                                b = M[0].clone(parent)
+                        except LayoutError:
+                            pass
+                    b = mirror_apply(b, node, M, inp["mark"])
+                # (a JPEG encoder flattens the frame it is given in place: a shared one is copied first, as the interpreter does)
+                results.append(finish(M[0].clone(b) if "encode" in br and b is parent else b, br.get("encode")))
+            return None, results
         if "join" not in case:
             b = frame(inp["src"], w, h, case["alpha"], inp["file0"], case.get("jpeg"))
             for node in case["nodes"]:
@@ -658,24 +762,7 @@ def run_mirror(case, inp, E):
             b = mirror_join(cv, ib, case["join"], M)
             for node in case["tail"]:
                 b = mirror_apply(b, node, M)
-        if "encode" in case:                                  # MozjpegEncoder::write_frame (mozjpeg.rs:88-94): matte (default white) first
-            import io
-
-            from PIL import Image, ImageFile
-            ImageFile.MAXBLOCK = 1 << 24
-            matte = case["encode"].get("matte")
-            E[8].apply_matte(b, 0xFFFFFFFF if matte is None else color32_of(matte, M[5]))
-            torch.cuda.synchronize()
-            out = b.to_numpy()[0]
-            rgb = np.ascontiguousarray(out[:, :4 * b.w].reshape(b.h, b.w, 4)[:, :, 2::-1])
-            f = io.BytesIO()
-            Image.fromarray(rgb).save(f, "JPEG", quality=case["encode"].get("quality", 75), subsampling="4:2:0",
-                                      optimize=bool(case["encode"].get("optimize_huffman_coding", False)),
-                                      progressive=bool(case["encode"].get("progressive", False)))
-            return None, f.getvalue()
-        torch.cuda.synchronize()
-        out = b.to_numpy()[0]
-        return None, (out[:, :4 * b.w], b.w, b.h, bool(b.alpha_meaningful))
+        return None, finish(b, case.get("encode"))
     except (FlowError, ValueError) as e:
         return str(e)[:160], None
 
@@ -688,6 +775,14 @@ def compare(case, shim, mirror):
         rec["shim_error"], rec["mirror_error"] = shim_err, mir_err
         rec["ok"] = bool(shim_err and mir_err)
         rec["refused"] = True
+        return rec
+    if case.get("tree"):
+        rec["ok"] = True
+        for k, (g, e) in enumerate(zip(got, exp)):
+            same = g == e if isinstance(g, bytes) else (g[1:] == e[1:] and np.array_equal(g[0], e[0]))
+            if not same:
+                rec["ok"] = False
+                rec.setdefault("outputs_differ", []).append([k, "file" if isinstance(g, bytes) else [list(g[1:]), list(e[1:])]])
         return rec
     if "encode" in case:
         rec["ok"] = got == exp
@@ -738,7 +833,7 @@ def sweep(seed, seconds=None, chains=None, out=None, threads=1):
     E = environment()
     rng = np.random.default_rng(seed)
     t_end = time.time() + (seconds if seconds is not None else 1e9)
-    done = bad = both_refuse = one_refuses = graphs = jpegs = files = 0
+    done = bad = both_refuse = one_refuses = graphs = jpegs = files = trees = 0
     failing = []
     f = open(out, "w") if out else None
     pool = None
@@ -761,7 +856,8 @@ def sweep(seed, seconds=None, chains=None, out=None, threads=1):
             rec["case"] = done
             graphs += "join" in case
             jpegs += ("jpeg" in case) + ("jpeg" in case.get("input", {}))
-            files += "encode" in case
+            files += ("encode" in case) + sum("encode" in b for b in case.get("branches", []))
+            trees += bool(case.get("tree"))
             if rec.get("refused"):
                 both_refuse += rec["ok"]
                 one_refuses += not rec["ok"]
@@ -775,7 +871,7 @@ def sweep(seed, seconds=None, chains=None, out=None, threads=1):
             done += 1
     if pool is not None:
         pool.shutdown()
-    summary = {"summary": True, "seed": seed, "threads": threads, "chains": done, "graphs": graphs, "jpeg_sources": jpegs, "jpeg_outputs": files,
+    summary = {"summary": True, "seed": seed, "threads": threads, "chains": done, "graphs": graphs, "trees": trees, "jpeg_sources": jpegs, "jpeg_outputs": files,
                "disagreements": bad, "both_refuse": both_refuse, "only_one_side_refuses": one_refuses, **COUNTS}
     if f:
         f.write(json.dumps(summary) + "\n")
