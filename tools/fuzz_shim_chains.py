@@ -450,6 +450,10 @@ def mirror_join(canvas, inp, node, M):
 def rand_jpeg(rng, w, h):
     spec = {"quality": int(rng.integers(20, 98)), "subsampling": int(rng.integers(0, 3)), "grey": bool(rng.random() < 0.15),
             "smooth": bool(rng.random() < 0.5)}
+    if rng.random() < 0.2:
+        # a PROGRESSIVE file (what the reference's own mozjpeg preset writes): the job's scans are decoded on the host
+        # (csrc/jpeg_read.cpp); the mirror gets the baseline twin libjpeg-turbo writes from the same pixels -- the same coefficients
+        spec["progressive"] = True
     if rng.random() < 0.5:                              # s::DecoderCommand::JpegDownscaleHints on the decode node
         spec["hints"] = {"width": max(1, int(w * rng.uniform(0.05, 1.2))), "height": max(1, int(h * rng.uniform(0.05, 1.2)))}
         if rng.random() < 0.6:
@@ -476,9 +480,9 @@ def hinted_size(w, h, spec):
     return 8, w, h
 
 
-def jpeg_bytes(src, w, h, spec):
-    """the frame as a baseline JPEG file (Pillow = libjpeg-turbo); smooth: a low-pass of the noise, so that files with long
-    zero runs and small DC differences appear too"""
+def jpeg_bytes(src, w, h, spec, progressive=False):
+    """the frame as a baseline (or progressive) JPEG file (Pillow = libjpeg-turbo); smooth: a low-pass of the noise, so that
+    files with long zero runs and small DC differences appear too"""
     import io
 
     from PIL import Image, ImageFilter
@@ -489,7 +493,8 @@ def jpeg_bytes(src, w, h, spec):
     if spec["grey"]:
         im = im.convert("L")
     f = io.BytesIO()
-    im.save(f, "JPEG", quality=spec["quality"], subsampling=spec["subsampling"]) if not spec["grey"] else im.save(f, "JPEG", quality=spec["quality"])
+    kw = {} if spec["grey"] else {"subsampling": spec["subsampling"]}
+    im.save(f, "JPEG", quality=spec["quality"], progressive=progressive, **kw)
     return f.getvalue()
 
 
@@ -637,10 +642,12 @@ def case_inputs(case, E):
     mw, mh, mseed = case["mark"]
     inp = {"src": src, "mark": (U.random_frames(1, mw, mh, seed0=mseed, alpha=True)[0], mw, mh),
            "file0": jpeg_bytes(src, w, h, case["jpeg"]) if "jpeg" in case else None, "isrc": None, "file1": None}
+    inp["job_file0"] = jpeg_bytes(src, w, h, case["jpeg"], True) if case.get("jpeg", {}).get("progressive") else inp["file0"]
     if "input" in case:
         iw, ih = case["input"]["size"]
         inp["isrc"] = U.random_frames(1, iw, ih, seed0=case["input"]["seed"], alpha=True)[0]
         inp["file1"] = jpeg_bytes(inp["isrc"], iw, ih, case["input"]["jpeg"]) if "jpeg" in case["input"] else None
+    inp["job_file1"] = jpeg_bytes(inp["isrc"], iw, ih, case["input"]["jpeg"], True) if case.get("input", {}).get("jpeg", {}).get("progressive") else inp["file1"]
     return inp
 
 
@@ -653,10 +660,10 @@ def run_shim(case, inp, E):
     w, h = case["size"]
     mark_src, mw, mh = inp["mark"]
     with Context() as c:
-        c.add_input_buffer(0, inp["file0"] if inp["file0"] is not None else pack_raw_bgra(inp["src"], w, h, alpha_meaningful=case["alpha"]))
+        c.add_input_buffer(0, inp["job_file0"] if inp["file0"] is not None else pack_raw_bgra(inp["src"], w, h, alpha_meaningful=case["alpha"]))
         if "input" in case:
             iw, ih = case["input"]["size"]
-            c.add_input_buffer(1, inp["file1"] if inp["file1"] is not None else pack_raw_bgra(inp["isrc"], iw, ih, alpha_meaningful=case["input"]["alpha"]))
+            c.add_input_buffer(1, inp["job_file1"] if inp["file1"] is not None else pack_raw_bgra(inp["isrc"], iw, ih, alpha_meaningful=case["input"]["alpha"]))
         c.add_input_buffer(2, pack_raw_bgra(mark_src, mw, mh, alpha_meaningful=True))
         outs = ([9] if case["parent_output"] else []) + [10 + k for k in range(len(case["branches"]))] if case.get("tree") else [9]
         for o in outs:
@@ -833,7 +840,7 @@ def sweep(seed, seconds=None, chains=None, out=None, threads=1):
     E = environment()
     rng = np.random.default_rng(seed)
     t_end = time.time() + (seconds if seconds is not None else 1e9)
-    done = bad = both_refuse = one_refuses = graphs = jpegs = files = trees = 0
+    done = bad = both_refuse = one_refuses = graphs = jpegs = files = trees = progressive = 0
     failing = []
     f = open(out, "w") if out else None
     pool = None
@@ -858,6 +865,7 @@ def sweep(seed, seconds=None, chains=None, out=None, threads=1):
             jpegs += ("jpeg" in case) + ("jpeg" in case.get("input", {}))
             files += ("encode" in case) + sum("encode" in b for b in case.get("branches", []))
             trees += bool(case.get("tree"))
+            progressive += bool(case.get("jpeg", {}).get("progressive")) + bool(case.get("input", {}).get("jpeg", {}).get("progressive"))
             if rec.get("refused"):
                 both_refuse += rec["ok"]
                 one_refuses += not rec["ok"]
@@ -871,7 +879,7 @@ def sweep(seed, seconds=None, chains=None, out=None, threads=1):
             done += 1
     if pool is not None:
         pool.shutdown()
-    summary = {"summary": True, "seed": seed, "threads": threads, "chains": done, "graphs": graphs, "trees": trees, "jpeg_sources": jpegs, "jpeg_outputs": files,
+    summary = {"summary": True, "seed": seed, "threads": threads, "chains": done, "graphs": graphs, "trees": trees, "jpeg_sources": jpegs, "progressive_sources": progressive, "jpeg_outputs": files,
                "disagreements": bad, "both_refuse": both_refuse, "only_one_side_refuses": one_refuses, **COUNTS}
     if f:
         f.write(json.dumps(summary) + "\n")
