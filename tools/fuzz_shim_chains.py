@@ -450,7 +450,11 @@ def mirror_join(canvas, inp, node, M):
 def rand_jpeg(rng, w, h):
     spec = {"quality": int(rng.integers(20, 98)), "subsampling": int(rng.integers(0, 3)), "grey": bool(rng.random() < 0.15),
             "smooth": bool(rng.random() < 0.5)}
-    if rng.random() < 0.2:
+    if rng.random() < 0.08:
+        # a DAMAGED scan (a few bytes of the entropy-coded data overwritten): the file decodes to something or is refused -- the
+        # same way in a job (where it may sit in an entropy batch with other jobs' files, which must not notice) as alone
+        spec["damage"] = [int(rng.integers(0, 1 << 30)), int(rng.integers(1, 4))]
+    elif rng.random() < 0.2:
         # a PROGRESSIVE file (what the reference's own mozjpeg preset writes): the job's scans are decoded on the host
         # (csrc/jpeg_read.cpp); the mirror gets the baseline twin libjpeg-turbo writes from the same pixels -- the same coefficients
         spec["progressive"] = True
@@ -495,7 +499,17 @@ def jpeg_bytes(src, w, h, spec, progressive=False):
     f = io.BytesIO()
     kw = {} if spec["grey"] else {"subsampling": spec["subsampling"]}
     im.save(f, "JPEG", quality=spec["quality"], progressive=progressive, **kw)
-    return f.getvalue()
+    data = f.getvalue()
+    if "damage" in spec:
+        sos = data.find(b"\xff\xda")
+        first = sos + 2 + int.from_bytes(data[sos + 2:sos + 4], "big")          # the first byte of entropy-coded data
+        if first < len(data) - 3:
+            r = np.random.default_rng(spec["damage"][0])
+            b = bytearray(data)
+            for _ in range(spec["damage"][1]):
+                b[int(r.integers(first, len(data) - 2))] = int(r.integers(0, 256))
+            data = bytes(b)
+    return data
 
 
 def rand_encode(rng):
@@ -840,7 +854,7 @@ def sweep(seed, seconds=None, chains=None, out=None, threads=1):
     E = environment()
     rng = np.random.default_rng(seed)
     t_end = time.time() + (seconds if seconds is not None else 1e9)
-    done = bad = both_refuse = one_refuses = graphs = jpegs = files = trees = progressive = 0
+    done = bad = both_refuse = one_refuses = graphs = jpegs = files = trees = progressive = damaged = 0
     failing = []
     f = open(out, "w") if out else None
     pool = None
@@ -865,6 +879,7 @@ def sweep(seed, seconds=None, chains=None, out=None, threads=1):
             jpegs += ("jpeg" in case) + ("jpeg" in case.get("input", {}))
             files += ("encode" in case) + sum("encode" in b for b in case.get("branches", []))
             trees += bool(case.get("tree"))
+            damaged += ("damage" in case.get("jpeg", {})) + ("damage" in case.get("input", {}).get("jpeg", {}))
             progressive += bool(case.get("jpeg", {}).get("progressive")) + bool(case.get("input", {}).get("jpeg", {}).get("progressive"))
             if rec.get("refused"):
                 both_refuse += rec["ok"]
@@ -879,7 +894,7 @@ def sweep(seed, seconds=None, chains=None, out=None, threads=1):
             done += 1
     if pool is not None:
         pool.shutdown()
-    summary = {"summary": True, "seed": seed, "threads": threads, "chains": done, "graphs": graphs, "trees": trees, "jpeg_sources": jpegs, "progressive_sources": progressive, "jpeg_outputs": files,
+    summary = {"summary": True, "seed": seed, "threads": threads, "chains": done, "graphs": graphs, "trees": trees, "jpeg_sources": jpegs, "progressive_sources": progressive, "damaged_sources": damaged, "jpeg_outputs": files,
                "disagreements": bad, "both_refuse": both_refuse, "only_one_side_refuses": one_refuses, **COUNTS}
     if f:
         f.write(json.dumps(summary) + "\n")
