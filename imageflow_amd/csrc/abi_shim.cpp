@@ -1315,6 +1315,12 @@ struct Job {
         hints.t = JVal::Obj;
         if (srgb) { JVal cs; cs.t = JVal::Str; cs.s = "srgb"; hints.o.emplace_back("scaling_colorspace", cs); }
         if (!down_filter.empty()) { JVal f; f.t = JVal::Str; f.s = down_filter; hints.o.emplace_back("down_filter", f); }
+        {   // background_color: Some(bgcolor), Transparent unless the querystring names format=jpg, then white (ir4/layout.rs:492-503, :530)
+            JVal bg;
+            if (jpeg_out) { JVal hex; hex.t = JVal::Str; hex.s = "FFFFFFFF"; JVal srgb; srgb.t = JVal::Obj; srgb.o.emplace_back("hex", hex); bg.t = JVal::Obj; bg.o.emplace_back("srgb", srgb); }
+            else { bg.t = JVal::Str; bg.s = "transparent"; }
+            hints.o.emplace_back("background_color", bg);
+        }
         FramePtr out = resample(in, ow, oh, &hints);
         if (enc && enc->t == JVal::Num) {
             // The reference keeps the source's format (a JPEG stays a JPEG, ir4/encoder.rs:30-37 OutputFormat::Keep) and hands

@@ -1100,3 +1100,16 @@ def test_querystring_keys_are_honoured_or_refused_never_dropped():
     assert tables(run("width=160&format=jpg")) == libjpeg_tables(90)
     assert tables(run("width=160&format=jpeg&quality=30&jpeg.quality=77")) == libjpeg_tables(77)
     assert tables(run("width=160&quality=high")) == libjpeg_tables(90)       # not an integer: ignored as the reference's parse_i32 does -> the default
+    # an explicit format=jpg makes the querystring layer resample onto WHITE (ir4/layout.rs:492-503, :530): a Bgra32 source is
+    # flattened in the working space by the resampler, not by the encoder afterwards
+    src = U.random_frames(1, 120, 80, seed0=33, alpha=True)[0]
+    with Context() as c:
+        c.add_input_buffer(0, pack_raw_bgra(src, 120, 80, alpha_meaningful=True))
+        c.add_output_buffer(1)
+        _run(c, "v1/execute", {"framewise": {"steps": [{"command_string": {"kind": "ir4", "value": "width=60&format=jpg&quality=85", "decode": 0, "encode": 1}}]}})
+        got = bytes(c.get_output_buffer(1))
+    can = _canvas_rows(60, 40, (255, 255, 255, 255))
+    rc, _ = O.scale_and_render(src, 120, 80, can, 60, 40, 0, 0, 60, 40, filter_id=2, compositing=O.BLEND_WITH_MATTE, matte_bgra=0xFFFFFFFF, alpha_meaningful=True)
+    b = io.BytesIO()
+    PIL.fromarray(np.ascontiguousarray(can[:, :240].reshape(40, 60, 4)[:, :, 2::-1])).save(b, "JPEG", quality=85, subsampling="4:2:0")
+    assert rc == 0 and got == b.getvalue()
