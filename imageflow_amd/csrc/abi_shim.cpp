@@ -1652,6 +1652,11 @@ struct Job {
                       : name == "rotate_90" ? "rotate_90" : name == "rotate_180" ? "rotate_180" : name == "rotate_270" ? "rotate_270" : name == "apply_orientation" ? "apply_orientation" : "node");
         if (name == "fill_rect") {                                                    // clone_crop_fill_expand.rs:107-137
             in->compose = IFHIP_BLEND_WITH_SELF;                                      // :112: set before the fill, so matte canvases accept sub-rects
+            {   // the node's own check (:114-127): an empty rectangle is an error HERE (fill_rectangle itself lets one pass)
+                const uint32_t x1 = want_u32(p, "x1", name.c_str()), y1 = want_u32(p, "y1", name.c_str()), x2 = want_u32(p, "x2", name.c_str()), y2 = want_u32(p, "y2", name.c_str());
+                if (x2 <= x1 || y2 <= y1 || static_cast<int32_t>(x1) < 0 || static_cast<int32_t>(y1) < 0 || x2 > in->w || y2 > in->h)
+                    raise(kArgumentInvalid, "InvalidCoordinates: Invalid coordinates for %ux%u bitmap: fill_rect x1=%u y1=%u x2=%u y2=%u", in->w, in->h, x1, y1, x2, y2);
+            }
             check(ifhip_fill_rect_batch_device(dev(in), in->bytes(), 1, in->w, in->h, in->stride, in->compose, want_u32(p, "x1", name.c_str()),
                                                want_u32(p, "y1", name.c_str()), want_u32(p, "x2", name.c_str()), want_u32(p, "y2", name.c_str()),
                                                parse_color(p.get("color"), "fill_rect.color"), t_job_stream));

@@ -53,6 +53,8 @@ def fill_rect(b: Bitmap, x1, y1, x2, y2, color32) -> Bitmap:
     """FillRectNodeDef::mutate (:107-137): the bitmap becomes BlendWithSelf first (:112), so a matte canvas accepts a
     sub-rectangle."""
     b.compose = BitmapCompositing.BlendWithSelf
+    if x2 <= x1 or y2 <= y1 or x1 >= 1 << 31 or y1 >= 1 << 31 or x2 > b.w or y2 > b.h:      # the node's own check (:114-127): an empty
+        raise FlowError(ErrorKind.InvalidArgument, f"InvalidCoordinates: Invalid coordinates for {b.w}x{b.h} bitmap")     # rectangle is an error here
     G.fill_rectangle(b, color32, x1, y1, x2, y2)
     return b
 

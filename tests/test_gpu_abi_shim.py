@@ -523,6 +523,21 @@ def test_a_frame_with_several_readers_is_not_changed_through_a_node_that_disappe
         assert (pw, ph, palpha) == (70, 40, True) and np.array_equal(padded[:, :240].reshape(40, 60, 4)[:, :, :3], px[:, :, :3])
 
 
+def test_fill_rect_refuses_an_empty_rectangle_like_the_node_does():
+    """FillRectNodeDef::mutate checks `x2 <= x1 || y2 <= y1 || ... x2 > w || y2 > h` -> InvalidCoordinates before it fills
+    (clone_crop_fill_expand.rs:114-127); only fill_rectangle itself lets a zero-width rectangle pass (bitmaps.rs:1523)."""
+    src = U.random_frames(1, 20, 10, seed0=95, alpha=False)[0]
+    for rect, ok in (((3, 2, 3, 8), False), ((3, 2, 9, 2), False), ((3, 2, 21, 8), False), ((3, 2, 9, 8), True), ((0, 0, 20, 10), True)):
+        with Context() as c:
+            c.add_input_buffer(0, pack_raw_bgra(src, 20, 10, alpha_meaningful=False))
+            c.add_output_buffer(1)
+            status, r = c.send_json("v1/execute", {"framewise": {"steps": [{"decode": {"io_id": 0}}, {"fill_rect": {"x1": rect[0], "y1": rect[1], "x2": rect[2], "y2": rect[3], "color": "black"}},
+                                                                            {"encode": {"io_id": 1, "preset": "gif"}}]}})
+            assert (status == 200) == ok, (rect, status, r)
+            if not ok:
+                assert status == 400 and "InvalidCoordinates" in r["message"] and c.error_code() == 2
+
+
 def test_graph_copy_rect_to_canvas_matches_the_oracle():
     """visuals/composition.rs:111-160 (test_graph_copy_rect_to_canvas): 100x100 of the input copied to (50,50) of a red
     300x300 Bgra32 canvas."""

@@ -101,6 +101,10 @@ def draw_node(rng, w, h, mark=None):
     if k == 7:
         x1, y1 = int(rng.integers(0, w)), int(rng.integers(0, h))
         x2, y2 = int(rng.integers(x1 + 1, w + 1)), int(rng.integers(y1 + 1, h + 1))
+        if rng.random() < 0.04:
+            x2 = x1                                       # an empty rectangle: the node refuses it (clone_crop_fill_expand.rs:114-127)
+        if rng.random() < 0.03:
+            x2 = w + 1 + int(rng.integers(0, 5))          # outside the frame
         return {"fill_rect": {"x1": x1, "y1": y1, "x2": x2, "y2": y2, "color": rand_color(rng)}}, (w, h)
     if k == 8:
         x1, y1 = int(rng.integers(-30, w + 10)), int(rng.integers(-30, h + 10))
