@@ -1361,7 +1361,11 @@ struct Job {
             const int write_flags = (flag("progressive") ? IFHIP_JPEG_PROGRESSIVE : 0) | (flag("optimize_huffman_coding") ? IFHIP_JPEG_OPTIMIZE_HUFFMAN : 0);
             const JVal* q = classic->get("quality");
             int quality = 75;                                                            // mozjpeg.rs:32 DEFAULT_QUALITY
-            if (q && q->t == JVal::Num) quality = q->n > 100 ? 100 : (q->n < 0 ? 0 : static_cast<int>(q->n));
+            // Option<i32> -> `q as u8` (codecs/auto.rs:201: the value WRAPS, 300 is 44 and -5 is 251) -> u8::min(100, ..) (mozjpeg.rs:71)
+            if (q && q->t == JVal::Num) {
+                if (q->n != std::floor(q->n) || q->n < -2147483648.0 || q->n > 2147483647.0) raise(kInvalidJson, "InvalidJson: encode.preset.libjpeg_turbo.quality is a 32-bit integer");
+                quality = std::min(100, static_cast<int>(static_cast<uint8_t>(static_cast<int32_t>(q->n))));
+            }
             const JVal* m = classic->get("matte");
             const uint32_t matte = m && !m->is_null() ? parse_color(m, "encode.preset.libjpeg_turbo.matte") : 0xFFFFFFFFu;   // :88-92
             if (shared && f->alpha) f = clone(f);

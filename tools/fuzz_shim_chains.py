@@ -519,7 +519,7 @@ def jpeg_bytes(src, w, h, spec, progressive=False):
 def rand_encode(rng):
     enc = {}
     if rng.random() < 0.8:
-        enc["quality"] = int(rng.integers(1, 101))
+        enc["quality"] = int(rng.integers(1, 101)) if rng.random() < 0.93 else int(rng.choice([0, 101, 150, 255, 256, 300, -1, -5, -200]))
     if rng.random() < 0.3:
         enc["progressive"] = bool(rng.integers(0, 2))
     if rng.random() < 0.3:
@@ -715,7 +715,9 @@ def jpeg_file_of(b, enc, E):
     out = b.to_numpy()[0]
     rgb = np.ascontiguousarray(out[:, :4 * b.w].reshape(b.h, b.w, 4)[:, :, 2::-1])
     f = io.BytesIO()
-    Image.fromarray(rgb).save(f, "JPEG", quality=enc.get("quality", 75), subsampling="4:2:0", optimize=bool(enc.get("optimize_huffman_coding", False)),
+    # Option<i32> -> `q as u8` (codecs/auto.rs:201: wraps) -> min(100, ..) (mozjpeg.rs:71) -> jpeg_set_quality (<= 0 is 1)
+    quality = max(1, min(100, enc.get("quality", 75) & 0xFF))
+    Image.fromarray(rgb).save(f, "JPEG", quality=quality, subsampling="4:2:0", optimize=bool(enc.get("optimize_huffman_coding", False)),
                               progressive=bool(enc.get("progressive", False)))
     return f.getvalue()
 
