@@ -571,6 +571,12 @@ def cfg4_entropy_roofline(files, n_files, ent_ms):
             "lane_steps": {k: int(v) for k, v in steps.items()},
             "valu_wave_instructions_per_64_lane_steps": {k: per[k]["valu"] for k in steps},
             "instr_per_symbol_all_walks": round(sum((per[k]["valu"] + per[k]["salu"] + per[k]["lds"]) * steps[k] for k in steps) / symbols, 1),
+            # the stage's other yardstick: its compulsory HBM traffic -- the coefficient planes written once (zeros included) and the
+            # compressed scans read by each of the three kernels -- against 8 TB/s in the same measured time
+            "hbm": (lambda b: {"bytes": int(b), "unit": "GB/s", "achieved": round(b / (ent_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                               "frac": round(b / 8e12 / (ent_ms * 1e-3), 4),
+                               "what": "coefficient planes out (24 883 200 B per 4K 4:2:0 file, SURVEY 8a a14) + 3 x the un-stuffed scan bytes in"})(
+                n_files * 24_883_200.0 * (CFG4["in_w"] * CFG4["in_h"] / (3840.0 * 2160.0)) + 3.0 * subs * 128.0),
             "sampled_files": len(sample), "model_source": "static: profiles/entropy_issue_model.json (" + model["source"] + ")",
             "what": "the entropy decodes of one step, batches one after the other (hipEvents): four dense bit-serial walks of every sub-sequence "
                     "(speculative, from the predecessor's exit, count, write; the first three read pair entries).  frac = VALU issue cycles the "

@@ -28,6 +28,10 @@ def test_entropy_issue_yardstick_from_a_file_and_the_committed_model():
     cycles = sum(per[k]["valu"] * r["lane_steps"][k] / 64.0 for k in ("round", "count", "write")) * 2.0
     assert abs(r["frac"] - cycles / (1024 * 2.4e9) / 0.5e-3) < 2e-4
     assert abs(r["achieved"] / r["peak"] - r["frac"]) < 2e-3
+    # the stage's compulsory HBM traffic: the coefficient planes of 4 files + the scans read by three kernels, in the time given
+    h = r["hbm"]
+    assert 4 * 24_883_200 < h["bytes"] < 4 * 24_883_200 + 3 * 4 * len(f) * 1.1
+    assert abs(h["frac"] - h["bytes"] / 8e12 / 0.5e-3) < 2e-4 and abs(h["achieved"] / h["peak"] - h["frac"]) < 2e-3
 
 
 def test_no_cut_with_the_encode_table_adds_busy_lanes_at_twenty_waves_per_cu():
