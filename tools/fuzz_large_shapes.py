@@ -121,7 +121,7 @@ def main():
             f.flush()
             done += 1
         summary = {"summary": True, "seed": args.seed, "cases": done, "mismatches": bad, "rejected_by_the_reference_rule": rejected,
-                   "by_kind": kinds, "by_kernel_kind (0 fused, 1 generic, 2 banded)": kernels}
+                   "by_kind": kinds, "by_kernel_kind (0 fused, 1 the banded kernel where a band fits the LDS, else the generic pair)": kernels}
         f.write(json.dumps(summary) + "\n")
     print(json.dumps(summary))
     sys.exit(1 if bad else 0)
