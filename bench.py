@@ -82,6 +82,9 @@ WORKLOADS = {
     # trim.rs:131-158): 2x stays on the fused kernel, 3x has more than 8 live rows and takes the generic two-pass kernels
     "up2-hermite": (200, 200, 400, 400, "Hermite", 0.0, True, "ReplaceSelf", 0, 4096),
     "up3-robidoux": (100, 100, 300, 300, "Robidoux", 0.0, True, "ReplaceSelf", 0, 8192),
+    # the up-scales a decoded JPEG meets (no alpha, the node's default up filter, scale_render.rs:255-259): HD frames 2x and 1.5x
+    "up2-ginseng-hd": (960, 540, 1920, 1080, "Ginseng", 0.0, False, "ReplaceSelf", 0, 512),
+    "up1.5-ginseng-hd": (1280, 720, 1920, 1080, "Ginseng", 0.0, False, "ReplaceSelf", 0, 512),
     # the whole export_4_sizes job: the tuple describes level 0, PYRAMID the chain
     "cfg3": (3840, 2160, 1600, 900, "Robidoux", 0.0, False, "ReplaceSelf", 0, 128),
 }

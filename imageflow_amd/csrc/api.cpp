@@ -290,14 +290,14 @@ bool fused_usable(const ifhip_resample_plan* p, int alpha, const uint8_t* d_in, 
 // whatever fits one.  A band's workgroups split the frames between them (frame_step), so that the tables are staged a few
 // times per CU and not once per frame and band.
 struct BandPlan { BandedArgs args{}; uint32_t grid = 0; size_t lds = 0; };
-constexpr size_t kBandedTables = 16384 + 1024;
+constexpr size_t kBandedTables = 16384 + 1024 + 16;
 constexpr uint32_t kBandedWorkgroups = 8192;                 // sixteen rounds of two workgroups per CU (measured: 512 4.09, 1 024 3.91, 2 048 3.76, 4 096 3.70, 8 192 3.66 ms on the 3x shape)
 bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_image_bytes, uint32_t in_stride, uint32_t n_images, BandPlan* bp) {
     if ((reinterpret_cast<uintptr_t>(d_in) | in_image_bytes | in_stride) & 3u) return false;      // 4-byte pixel reads
     if (in_image_bytes > 0xffffffffull) return false;                                              // 32-bit offsets inside a frame
     const AxisWeights& wv = p->wv;
     const uint32_t out_h = p->out_h;
-    auto src_rows = [&](uint32_t R) {                       // widest source window of any band of R output rows
+    auto src_rows_of = [&](uint32_t R) {                    // widest source window of any band of R output rows
         uint32_t worst = 0;
         for (uint32_t j0 = 0; j0 < out_h; j0 += R) {
             uint32_t lo = 0xffffffffu, hi = 0;
@@ -306,37 +306,99 @@ bool banded_plan(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_im
         }
         return worst;
     };
+    uint32_t src_rows_memo[65] = {};                        // (asked for the same dozen R by every candidate strip width)
+    auto src_rows = [&](uint32_t R) { return R <= 64u ? (src_rows_memo[R] ? src_rows_memo[R] : (src_rows_memo[R] = src_rows_of(R))) : src_rows_of(R); };
     bool ascending = true;                                  // window starts and ends never step back (they do not, but the kernel's
     for (uint32_t j = 1; j < out_h; ++j)                    // shortcut rests on it, so it is checked, not assumed)
         if (wv.left[j] < wv.left[j - 1] || wv.left[j] + wv.count[j] < wv.left[j - 1] + wv.count[j - 1]) ascending = false;
+    const AxisWeights& wh = p->wh;
+    const uint32_t out_w = p->out_w;
+    static const uint32_t kRows[] = {64, 48, 32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
+    uint32_t wgs = kBandedWorkgroups;
+    if (const char* e = debug_switch("banded_wgs")) wgs = static_cast<uint32_t>(std::max(1, std::atoi(e)));   // test hook: the frame loop of a workgroup
+    auto commit = [&](uint32_t R, uint32_t ns, uint32_t strip_w, uint32_t hwf, bool h_lds, size_t lds) {
+        BandedArgs& b = bp->args;
+        b.rows_per_band = R; b.n_bands = (out_h + R - 1u) / R; b.src_rows_cap = ns;
+        b.strip_w = strip_w; b.n_strips = (out_w + strip_w - 1u) / strip_w;
+        b.frame_step = std::max<uint32_t>(1u, std::min<uint32_t>(n_images, wgs / std::max(1u, b.n_bands * b.n_strips)));
+        b.h_w_floats = hwf;
+        b.flags = (ascending ? 2u : 0u) | (h_lds ? 4u : 0u);
+        bp->grid = b.n_bands * b.n_strips * b.frame_step;
+        bp->lds = lds;
+    };
+    // ---- whole rows (small frames): R is the largest of the list for which two workgroups share a CU, else whatever fits one ----
     // horizontal tables in LDS when they are small (up-scales: ~5 taps per output column)
-    const size_t h_bytes = ((3u * static_cast<size_t>(p->out_w) + p->wh.w.size()) * 4u + 15u) & ~static_cast<size_t>(15u);
+    const size_t h_bytes = ((3u * static_cast<size_t>(out_w) + wh.w.size()) * 4u + 15u) & ~static_cast<size_t>(15u);
     const bool h_lds = h_bytes <= 32u * 1024u;
     const size_t tables = kBandedTables + (h_lds ? h_bytes : 0u);
     const size_t row_bytes = static_cast<size_t>(p->in_w) * 16u;
-    static const uint32_t kRows[] = {64, 48, 32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
-    for (int pass = 0; pass < 2; ++pass) {
+    uint32_t whole_R = 0, whole_ns = 0; size_t whole_lds = 0;
+    for (int pass = 0; pass < 2 && !whole_R; ++pass) {
         const size_t budget = pass == 0 ? kLdsLimit / 2 : kLdsLimit;
         for (uint32_t R0 : kRows) {
             const uint32_t R = std::min(R0, out_h);
             if (pass == 0 && R < 4u && out_h >= 4u) break;
             const uint32_t ns = src_rows(R);
             const size_t lds = tables + static_cast<size_t>(ns + R) * row_bytes;
-            if (lds <= budget) {
-                BandedArgs& b = bp->args;
-                b.rows_per_band = R; b.n_bands = (out_h + R - 1u) / R; b.src_rows_cap = ns;
-                uint32_t wgs = kBandedWorkgroups;
-                if (const char* e = debug_switch("banded_wgs")) wgs = static_cast<uint32_t>(std::max(1, std::atoi(e)));   // test hook: the frame loop of a workgroup
-                b.frame_step = std::max<uint32_t>(1u, std::min<uint32_t>(n_images, wgs / b.n_bands));
-                b.h_w_floats = static_cast<uint32_t>(p->wh.w.size());
-                b.flags = (ascending ? 2u : 0u) | (h_lds ? 4u : 0u);
-                bp->grid = b.n_bands * b.frame_step;
-                bp->lds = lds;
-                return true;
-            }
+            if (lds <= budget) { whole_R = R; whole_ns = ns; whole_lds = lds; break; }
         }
     }
-    return false;
+    // ---- column strips (wide frames): where whole rows leave a band of fewer than 16 rows (each band converts its own halo of
+    // source rows and stages the tables again) or do not fit at all, a workgroup takes a strip of S output columns of a band
+    // of R rows; its source columns and its slice of the weights are the union of its columns' windows. ----
+    uint32_t forced_strip = 0;
+    if (const char* e = debug_switch("banded_strip")) forced_strip = static_cast<uint32_t>(std::max(0, std::atoi(e)));   // test hook: strips on small frames
+    const bool whole_good = whole_R != 0 && (whole_R >= 16u || whole_R >= out_h);
+    if ((whole_good && !forced_strip) || out_w < 2u) {
+        if (!whole_R) return false;
+        commit(whole_R, whole_ns, out_w, static_cast<uint32_t>(wh.w.size()), h_lds, whole_lds);
+        return true;
+    }
+    auto pad64 = [](uint32_t v) { return (v + 63u) / 64u * 64u; };
+    const double nv = static_cast<double>(wv.w.size()) / std::max(1u, out_h);          // mean taps of the vertical windows
+    // cost per output pixel, in tap steps (one 16-byte LDS read + its multiply-adds): converting the tile's source pixels (three
+    // table reads each: 3), the vertical pass over the strip's source columns, both with their idle lanes; a tile that leaves no
+    // room for a second workgroup on the CU waits out its own barriers (x 1.25)
+    auto cost_of = [&](uint32_t R, uint32_t ns, uint32_t S, uint32_t sc, size_t lds) {
+        const double px = static_cast<double>(R) * S;
+        return (3.0 * ns * pad64(sc) + nv * R * pad64(sc) + 8.0 * R * pad64(S)) / px * (lds > kLdsLimit / 2 ? 1.25 : 1.0);
+    };
+    double best = 1e300;
+    struct { uint32_t R, ns, S, hwf; bool h_lds; size_t lds; } pick{};
+    if (whole_R && !forced_strip) {
+        best = cost_of(whole_R, whole_ns, out_w, p->in_w, whole_lds);
+        pick = {whole_R, whole_ns, out_w, static_cast<uint32_t>(wh.w.size()), h_lds, whole_lds};
+    }
+    static const uint32_t kStrips[] = {512, 384, 256, 192, 128, 112, 96, 64, 48, 32, 16};
+    for (uint32_t S0 : kStrips) {
+        const uint32_t S = forced_strip ? std::min(forced_strip, out_w) : S0;
+        if (S >= out_w && !forced_strip) continue;
+        uint32_t sc = 0, hwf = 0;                            // widest strip: source columns, floats of its weight slice
+        for (uint32_t u0 = 0; u0 < out_w; u0 += S) {
+            const uint32_t u1 = std::min(out_w, u0 + S);
+            uint32_t lo = 0xffffffffu, hi = 0, wlo = 0xffffffffu, whi = 0;       // (as the kernel finds them)
+            for (uint32_t u = u0; u < u1; ++u) {
+                lo = std::min(lo, wh.left[u]); hi = std::max(hi, wh.left[u] + wh.count[u]);
+                wlo = std::min(wlo, wh.offset[u]); whi = std::max(whi, wh.offset[u] + wh.count[u]);
+            }
+            sc = std::max(sc, hi - lo);
+            hwf = std::max(hwf, whi - wlo);
+        }
+        const size_t hb = ((3u * static_cast<size_t>(S) + hwf) * 4u + 15u) & ~static_cast<size_t>(15u);
+        const bool hl = hb <= 32u * 1024u;
+        for (uint32_t R0 : kRows) {
+            const uint32_t R = std::min(R0, out_h);
+            const uint32_t ns = src_rows(R);
+            const size_t lds = kBandedTables + (hl ? hb : 0u) + static_cast<size_t>(ns + R) * sc * 16u;
+            if (lds > kLdsLimit) continue;
+            const double c = cost_of(R, ns, S, sc, lds);
+            if (c < best) { best = c; pick = {R, ns, S, hwf, hl, lds}; }
+        }
+        if (forced_strip) break;
+    }
+    if (best == 1e300) return false;
+    commit(pick.R, pick.ns, pick.S, pick.hwf, pick.h_lds, pick.lds);
+    return true;
 }
 // The banded kernel stands in for the generic pair wherever it fits (measured, MI355X: 3x up-scale 9.97 -> 3.65 ms), never for
 // the fused kernel (the 2x up-scale the fused kernel takes is faster there: 2.93 vs 4.43 ms).
@@ -418,9 +480,9 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
             // kernel's table-free forms, which real weight tables reach only at very wide outputs, run in the suite
             if (const char* fe = debug_switch("banded_flags")) bp.args.flags &= static_cast<uint32_t>(std::atoi(fe));
             if (trace_launch())
-                std::fprintf(stderr, "ifhip banded launch: %ux%u -> %ux%u alpha=%d rows/band=%u bands=%u src rows=%u frame step=%u flags=%u grid=%u lds=%zu images=%u\n",
+                std::fprintf(stderr, "ifhip banded launch: %ux%u -> %ux%u alpha=%d rows/band=%u bands=%u src rows=%u strip=%u strips=%u frame step=%u flags=%u grid=%u lds=%zu images=%u\n",
                              p->in_w, p->in_h, p->out_w, p->out_h, alpha, bp.args.rows_per_band, bp.args.n_bands, bp.args.src_rows_cap,
-                             bp.args.frame_step, bp.args.flags, bp.grid, bp.lds, n_images);
+                             bp.args.strip_w, bp.args.n_strips, bp.args.frame_step, bp.args.flags, bp.grid, bp.lds, n_images);
             HIP_TRY(launch_banded(a, alpha != 0, bp.args, bp.grid, bp.lds, st));
             return IFHIP_OK;
         }

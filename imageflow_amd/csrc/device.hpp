@@ -71,9 +71,11 @@ struct ResampleArgs {
 struct BandedArgs {
     uint32_t rows_per_band, n_bands, src_rows_cap;
     uint32_t frame_step;        // G: workgroup g of a band takes frames g, g + G, ...
-    uint32_t h_w_floats;        // size of the horizontal weight table (staged in LDS with flag 4)
+    uint32_t h_w_floats;        // horizontal weights staged in LDS with flag 4: the whole table, or the widest strip's slice of it
     uint32_t flags;             // 1: short horizontal windows in registers; 2: window starts and ends ascend with the row (the band's
                                 // source rows follow from its first and last row); 4: horizontal tables in LDS
+    uint32_t n_strips, strip_w; // column strips of strip_w output columns each (wide frames: a band of whole rows would not fit
+                                // the LDS); 1, out_w: whole rows
 };
 
 // Shape of the fused kernel for a ring of K rows and C channels per pixel.  The vertical accumulators alone take

@@ -81,9 +81,11 @@ hpass_generic_kernel(const ResampleArgs a, const float4* scratch, uint32_t img0)
 // generic kernels term for term (vpass_generic_kernel / hpass_generic_kernel above: the same ascending fmaf chains on
 // the same values), hence bit-identical to them and to the oracle.  Vertical pass: rows over waves (their weights are
 // wave-uniform: scalar loads), columns over lanes.  Horizontal pass: a lane keeps its output column over the wave's rows.
+// Wide frames (a band of whole rows does not fit the LDS: 960 -> 1920 columns) are cut into COLUMN STRIPS as well: a workgroup
+// = (band, strip of strip_w output columns, every G-th frame), its LDS rows hold the strip's source columns only.
 // ------------------------------------------------------------------------------------------------------
 constexpr uint32_t kBandedThreads = 512;
-constexpr uint32_t kBandedTableBytes = 16384 + 1024;        // linear -> sRGB table, sRGB -> float table
+constexpr uint32_t kBandedTableBytes = 16384 + 1024 + 16;   // linear -> sRGB table, sRGB -> float table, a strip's ranges
 constexpr uint32_t kBandedPrefetch = 8;                     // source pixels a lane keeps in flight for the next frame
 template <bool ALPHA>
 __global__ void __launch_bounds__(kBandedThreads)
@@ -92,23 +94,42 @@ banded_resample_kernel(const ResampleArgs a, const BandedArgs b) {
     uint8_t* l2s_lds = bsm;
     float* s2f = reinterpret_cast<float*>(bsm + 16384);
     const bool h_lds = (b.flags & 4u) != 0u;
-    uint32_t* hl = reinterpret_cast<uint32_t*>(bsm + kBandedTableBytes);               // [out_w] left, count, weight offset; weights
-    uint32_t* hc = hl + a.out_w;
-    uint32_t* ho = hc + a.out_w;
-    float* hw = reinterpret_cast<float*>(ho + a.out_w);
-    const uint32_t h_bytes = h_lds ? ((3u * a.out_w + b.h_w_floats) * 4u + 15u) & ~15u : 0u;
-    float4* src = reinterpret_cast<float4*>(bsm + kBandedTableBytes + h_bytes);        // [src_rows_cap][in_w]
-    float4* vband = src + static_cast<size_t>(b.src_rows_cap) * a.in_w;                // [rows_per_band][in_w]
+    uint32_t* hl = reinterpret_cast<uint32_t*>(bsm + kBandedTableBytes);               // [strip_w] left, count, weight offset; weights
+    uint32_t* hc = hl + b.strip_w;
+    uint32_t* ho = hc + b.strip_w;
+    float* hw = reinterpret_cast<float*>(ho + b.strip_w);
+    const uint32_t h_bytes = h_lds ? ((3u * b.strip_w + b.h_w_floats) * 4u + 15u) & ~15u : 0u;
     const uint32_t tid = threadIdx.x, T = blockDim.x;
     const uint32_t lane = tid & 63u, nw = T >> 6;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);                   // wave-uniform: rows and their tables go the scalar way
-    const uint32_t band = blockIdx.x % b.n_bands, g = blockIdx.x / b.n_bands;
+    const uint32_t tiles = b.n_bands * b.n_strips;
+    const uint32_t tile = blockIdx.x % tiles, g = blockIdx.x / tiles;
+    const uint32_t band = tile % b.n_bands, strip = tile / b.n_bands;
     const uint32_t j0 = band * b.rows_per_band, j1 = min(j0 + b.rows_per_band, a.out_h), nrows = j1 - j0;
+    // the strip's output columns [u0, u1), its source columns [cx0, cx0 + sw) and its slice [wo0, wo0 + nwf) of the weights:
+    // the union of its columns' windows (trimmed zero weights move a window's ends: no column is taken for the first or last)
+    const uint32_t u0 = strip * b.strip_w, u1 = min(u0 + b.strip_w, a.out_w), nu = u1 - u0;
+    uint32_t cx0 = 0u, sw = a.in_w, wo0 = 0u, nwf = b.h_w_floats;
+    if (b.n_strips > 1u) {
+        uint32_t* rng = reinterpret_cast<uint32_t*>(bsm + 16384 + 1024);            // {min left, max right, min offset, max offset end}
+        if (tid < 4u) rng[tid] = (tid & 1u) ? 0u : 0xffffffffu;
+        __syncthreads();
+        uint32_t lo = 0xffffffffu, hi = 0u, wlo = 0xffffffffu, whi = 0u;
+        for (uint32_t i = tid; i < nu; i += T) {
+            const uint32_t l = a.h_left[u0 + i], c = a.h_count[u0 + i], o = a.h_off[u0 + i];
+            lo = min(lo, l); hi = max(hi, l + c); wlo = min(wlo, o); whi = max(whi, o + c);
+        }
+        if (tid < nu) { atomicMin(&rng[0], lo); atomicMax(&rng[1], hi); atomicMin(&rng[2], wlo); atomicMax(&rng[3], whi); }
+        __syncthreads();
+        cx0 = rng[0]; sw = rng[1] - cx0; wo0 = rng[2]; nwf = rng[3] - wo0;
+    }
+    float4* src = reinterpret_cast<float4*>(bsm + kBandedTableBytes + h_bytes);        // [src rows][sw]
+    float4* vband = src + static_cast<size_t>(b.src_rows_cap) * sw;                    // [rows_per_band][sw]
     for (uint32_t i = tid; i < 1024u; i += T) reinterpret_cast<uint4*>(l2s_lds)[i] = reinterpret_cast<const uint4*>(a.l2s)[i];
     for (uint32_t i = tid; i < 256u; i += T) s2f[i] = a.lut_in[i];
     if (h_lds) {
-        for (uint32_t i = tid; i < a.out_w; i += T) { hl[i] = a.h_left[i]; hc[i] = a.h_count[i]; ho[i] = a.h_off[i]; }
-        for (uint32_t i = tid; i < b.h_w_floats; i += T) hw[i] = a.h_w[i];
+        for (uint32_t i = tid; i < nu; i += T) { hl[i] = a.h_left[u0 + i] - cx0; hc[i] = a.h_count[u0 + i]; ho[i] = a.h_off[u0 + i] - wo0; }
+        for (uint32_t i = tid; i < nwf; i += T) hw[i] = a.h_w[wo0 + i];
     }
     uint32_t row0, row1;                                     // the band's source rows [row0, row1): at most src_rows_cap (host)
     if (b.flags & 2u) {
@@ -122,15 +143,15 @@ banded_resample_kernel(const ResampleArgs a, const BandedArgs b) {
             row1 = max(row1, l + a.v_count[j]);
         }
     }
-    const uint32_t npx = (row1 - row0) * a.in_w;             // source pixels of the band, LDS index r * in_w + x
+    const uint32_t npx = (row1 - row0) * sw;                 // source pixels of the tile, LDS index r * sw + x
     // Source pixels this lane converts (LDS index tid + c * T): their byte offsets inside a frame, the same for every frame.
     const bool prefetch = npx <= kBandedPrefetch * T;
     uint32_t off[kBandedPrefetch], pre[kBandedPrefetch];
 #pragma unroll
     for (uint32_t c = 0; c < kBandedPrefetch; ++c) {
         const uint32_t i = tid + c * T;
-        const uint32_t r = i / a.in_w, x = i - r * a.in_w;
-        off[c] = (row0 + r) * a.in_stride + 4u * x;
+        const uint32_t r = i / sw, x = i - r * sw;
+        off[c] = (row0 + r) * a.in_stride + 4u * (cx0 + x);
         pre[c] = 0u;
     }
     auto request = [&](uint32_t img) {
@@ -162,7 +183,7 @@ banded_resample_kernel(const ResampleArgs a, const BandedArgs b) {
             const uint8_t* frame = a.in + static_cast<size_t>(img) * a.in_image_bytes;
             for (uint32_t r = wave; r < row1 - row0; r += nw) {
                 const uint32_t* prow = reinterpret_cast<const uint32_t*>(frame + static_cast<size_t>(row0 + r) * a.in_stride);
-                for (uint32_t x = lane; x < a.in_w; x += 64u) src[r * a.in_w + x] = to_float(prow[x]);
+                for (uint32_t x = lane; x < sw; x += 64u) src[r * sw + x] = to_float(prow[cx0 + x]);
             }
         }
         __syncthreads();     // src complete; every wave is also done with the previous frame's horizontal pass (vband is free)
@@ -171,30 +192,31 @@ banded_resample_kernel(const ResampleArgs a, const BandedArgs b) {
             const uint32_t j = j0 + jr;
             const uint32_t left = a.v_left[j] - row0, n = a.v_count[j];
             const float* w = a.v_w + a.v_off[j];             // (wave-uniform address: scalar loads)
-            for (uint32_t x = lane; x < a.in_w; x += 64u) {
-                const float4* col = src + left * a.in_w + x;
+            for (uint32_t x = lane; x < sw; x += 64u) {
+                const float4* col = src + left * sw + x;
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
                 for (uint32_t k = 0; k < n; ++k) {
-                    const float4 v = col[k * a.in_w];
+                    const float4 v = col[k * sw];
                     const float wk = w[k];
                     s0 = __builtin_fmaf(wk, v.x, s0);
                     s1 = __builtin_fmaf(wk, v.y, s1);
                     s2 = __builtin_fmaf(wk, v.z, s2);
                     if (ALPHA) s3 = __builtin_fmaf(wk, v.w, s3);
                 }
-                vband[jr * a.in_w + x] = make_float4(s0, s1, s2, ALPHA ? s3 : 1.0f);
+                vband[jr * sw + x] = make_float4(s0, s1, s2, ALPHA ? s3 : 1.0f);
             }
         }
         __syncthreads();     // vband complete; src is free for the next frame
         // ---- horizontal pass + output stage (step 3 and the compositing modes).  A lane keeps its output column over the
         // wave's rows.  (Weights of short windows kept in registers, padded to 8 taps, measured slower -- 3.76 against 3.65 ms
         // on the 3x shape -- and were removed.)
-        for (uint32_t u = lane; u < a.out_w; u += 64u) {
-            const uint32_t left = h_lds ? hl[u] : a.h_left[u], n = h_lds ? hc[u] : a.h_count[u];
-            const uint32_t woff = h_lds ? ho[u] : a.h_off[u];
+        for (uint32_t ui = lane; ui < nu; ui += 64u) {
+            const uint32_t u = u0 + ui;
+            const uint32_t left = h_lds ? hl[ui] : a.h_left[u] - cx0, n = h_lds ? hc[ui] : a.h_count[u];
+            const uint32_t woff = h_lds ? ho[ui] : a.h_off[u];
             auto weight = [&](uint32_t k) -> float { return h_lds ? hw[woff + k] : a.h_w[woff + k]; };
             for (uint32_t jr = wave; jr < nrows; jr += nw) {
-                const float4* row = vband + jr * a.in_w;
+                const float4* row = vband + jr * sw;
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
                 for (uint32_t k = 0; k < n; ++k) {
                     const float4 v = row[left + k];

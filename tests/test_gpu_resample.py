@@ -358,6 +358,33 @@ def test_banded_kernel_frame_loop_and_wide_rows(debug_switch):
     run_case(100, 100, 300, 300, alpha=False, force=2, n=5, compose=BitmapCompositing.BlendWithMatte, matte=0xFF405060)
 
 
+@pytest.mark.parametrize("strip", [16, 50, 64])
+@pytest.mark.parametrize("shape", [(100, 100, 300, 300), (64, 48, 128, 96), (37, 23, 111, 70), (250, 3, 1000, 9), (130, 90, 129, 91),
+                                   (101, 67, 33, 21)])
+def test_banded_kernel_column_strips_forced_on_small_frames(shape, strip, debug_switch):
+    """Column strips (wide frames) on shapes the suite can afford: the hook forces a strip width, every strip stages its own
+    source columns and its slice of the horizontal tables."""
+    iw, ih, ow, oh = shape
+    debug_switch("banded_strip", str(strip))
+    run_case(iw, ih, ow, oh, alpha=True, force=2, n=3)
+    run_case(iw, ih, ow, oh, alpha=False, force=2, n=2, filt=Filter.Ginseng)
+    debug_switch("banded_flags", "0")                          # tables from HBM, band rows by search
+    run_case(iw, ih, ow, oh, alpha=True, force=2, n=2, filt=Filter.Lanczos, sharpen=15.0)
+
+
+@pytest.mark.parametrize("case", [(960, 54, 1920, 108, Filter.Ginseng), (1280, 40, 1920, 60, Filter.Ginseng), (700, 20, 2100, 60, Filter.Robidoux),
+                                  (1500, 30, 1700, 34, Filter.Lanczos), (1100, 16, 4400, 64, Filter.Hermite)])
+@pytest.mark.parametrize("alpha", [False, True])
+def test_wide_up_scales_take_the_banded_kernel_in_column_strips(case, alpha):
+    """An HD frame up-scaled with the node's default up filter (scale_render.rs:255-259): too many live rows for the fused
+    kernel, rows too wide for a band of whole rows -- auto mode cuts bands into column strips."""
+    iw, ih, ow, oh, filt = case
+    plan = run_case(iw, ih, ow, oh, alpha=alpha, filt=filt, n=2)
+    run_case(iw, ih, ow, oh, alpha=alpha, filt=filt, n=3, force=2, compose=BitmapCompositing.BlendWithSelf, x=5, y=3, cw=ow + 9, ch=oh + 4)
+    run_case(iw, ih, ow, oh, alpha=alpha, filt=filt, n=1, force=2, compose=BitmapCompositing.BlendWithMatte, matte=0x80FF2010,
+             space=WorkingFloatspace.StandardRGB)
+
+
 def test_banded_kernel_refuses_what_does_not_fit():
     with pytest.raises(FlowError) as e:
         run_case(3840, 216, 200, 20, n=1, force=2)            # 76 source rows x 3840 columns x 16 bytes per band of one row
