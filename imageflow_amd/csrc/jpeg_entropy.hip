@@ -713,8 +713,15 @@ __global__ void __launch_bounds__(kWriteLanes) entropy_write_kernel(const Entrop
                 const uint32_t bx = mx * (pl.hv & 255u) + ((pl.hv >> 16) & 255u), by = my * ((pl.hv >> 8) & 255u) + (pl.hv >> 24);
                 auto* dst = reinterpret_cast<__attribute__((address_space(1))) u32x4*>(reinterpret_cast<uintptr_t>(       // (global, not flat, stores)
                     plane + (static_cast<size_t>(sg.image * pl.bh + by) * pl.bw + bx) * 64u));
+                // The store is bounded by POSITION as well as by the segment's block count: this launch is enqueued behind the count
+                // pass before the host has seen whether the fixpoint settled, and on exit states that are not final a lane's first
+                // block and its block-in-MCU phase need not agree -- its MCU row can run past the frame (found by
+                // tools/scan_entropy_shapes.py: a fault behind the last image's plane; the decode is repeated after the next
+                // rounds, so the result was right, the transient stores were not).
+                if (my < a.g.mcus_h) {
 #pragma unroll
-                for (uint32_t i = 0; i < 8u; ++i) dst[i] = r[i];
+                    for (uint32_t i = 0; i < 8u; ++i) dst[i] = r[i];
+                }
 #pragma unroll
                 for (uint32_t i = 0; i < 8u; ++i) row4[i] = u32x4{0u, 0u, 0u, 0u};
                 ++block;
