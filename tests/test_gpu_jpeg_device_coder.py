@@ -91,6 +91,31 @@ def test_dropped_images_leave_the_others_alone():
     assert M.ENC_SCAN_OVERFLOW in status or all(len(d) < 9000 for d in datas)
 
 
+@pytest.mark.parametrize("pitch_of", [lambda longest: 1024, lambda longest: (longest // 2) & ~15, lambda longest: (longest - 16) & ~15,
+                                      lambda longest: (longest + 15) & ~15])
+def test_files_that_do_not_fit_never_write_behind_their_slot(pitch_of):
+    """Guard region behind the batch's slots, slots too short for some or all files: a file that overflows is dropped
+    (ENC_FILE_OVERFLOW), its neighbours are complete and nothing is stored behind the last slot."""
+    rng = np.random.default_rng(5)
+    w, h, q = 200, 152, 100
+    datas = [pillow_file(rng.integers(0, 256, (h, w, 3), dtype=np.uint8) if k % 2 else photo(w, h, k), q, "4:2:0") for k in range(6)]
+    js = [O.jpeg_read_coefficients(d) for d in datas]
+    longest = max(len(d) for d in datas)
+    pitch = pitch_of(longest)
+    coder = coder_for(js[0], 6)
+    guard = 1 << 20
+    buf = torch.full((6 * pitch + guard,), 0xA5, dtype=torch.uint8, device="cuda:0")
+    files, lengths, status = coder.encode_device(planes_of(js), q, file_pitch=pitch, files=buf[:6 * pitch].view(6, pitch))
+    torch.cuda.synchronize()
+    assert bool((buf[6 * pitch:] == 0xA5).all()), "a byte landed behind the last slot"
+    lengths, status, host = lengths.cpu().numpy(), status.cpu().numpy(), files.cpu().numpy()
+    for i, d in enumerate(datas):
+        if len(d) <= pitch:
+            assert status[i] == 0 and host[i, :lengths[i]].tobytes() == d, i
+        else:
+            assert status[i] == M.ENC_FILE_OVERFLOW and lengths[i] == 0, i
+
+
 @pytest.mark.parametrize("sub", ["420", "444"])
 def test_forward_stage_plus_device_coder_equals_host_writer(sub):
     """BGRA frames in HBM -> files in HBM: the pixel stage's planes never leave the device; same bytes as the host writer."""
