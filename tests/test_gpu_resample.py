@@ -38,11 +38,16 @@ def run_case(in_w, in_h, out_w, out_h, *, n=2, filt=Filter.Robidoux, sharpen=0.0
                               working_space=int(space), compositing=int(compose), matte_bgra=matte,
                               alpha_meaningful=alpha, want_f32=True)
     inp = Bitmap.from_numpy(frames, in_w, in_h, frames.shape[2], DEV, alpha_meaningful=alpha)
-    can = Bitmap.from_numpy(canvas0.copy(), cw, ch, cst, DEV, compose=compose, matte=matte)
-    f32 = torch.zeros((n, out_h, out_w, 4), dtype=torch.float32, device=DEV)
+    # canvases and the f32 dump are the first n frames of buffers with one guard frame behind them: no kernel may store there
+    can_all = torch.cat([torch.from_numpy(canvas0.reshape(n, -1)), torch.full((1, ch * cst), 0xA5, dtype=torch.uint8)]).to(DEV)
+    can = Bitmap(can_all[:n], cw, ch, cst, False, compose, matte)
+    f32_all = torch.zeros((n + 1, out_h, out_w, 4), dtype=torch.float32, device=DEV)
+    f32_all[n] = 12345.0
+    f32 = f32_all[:n]
     info = ScaleAndRenderParams(x, y, out_w, out_h, sharpen, filt, space)
     plan = scale_and_render(inp, can, info, f32_out=f32, force_kernel=force)
     torch.cuda.synchronize()
+    assert bool((can_all[n] == 0xA5).all()) and bool((f32_all[n] == 12345.0).all()), "a store landed behind the last frame"
     got = can.to_numpy()
     got_f32 = f32.cpu().numpy()
     assert np.array_equal(got_f32.view(np.uint32), exp_f32.view(np.uint32)), \
