@@ -100,13 +100,29 @@ def main():
                    "save": {k: (v if not isinstance(v, (np.integer,)) else int(v)) for k, v in kw.items()}}
             try:
                 ent = D.JpegEntropyBatch(files, "cuda:0")
-                coef = ent.read_coefficients()
+                # guard regions behind the coefficient planes and the decoded frames: no kernel may store there (the write pass did,
+                # on unsettled exit states, until round 6's position bound)
+                coef, guards = [], []
+                for c in range(3):                                   # (a grayscale batch carries two one-block dummies, as read_coefficients makes them)
+                    shape = (ent.n, max(ent.blocks_h[c], 1), max(ent.blocks_w[c], 1), 64)
+                    count = int(np.prod(shape))
+                    buf = torch.full((count + (1 << 18),), 0x5A5A, dtype=torch.int16, device="cuda:0")
+                    guards.append(buf[count:])
+                    coef.append(buf[:count].view(shape))
+                ent.read_coefficients(coef)
                 rec["rounds"], rec["subsequences"] = int(ent.rounds), int(ent.n_subsequences)
                 max_rounds = max(max_rounds, rec["rounds"])
                 stage = D.JpegPixelStage(ent.width, ent.height, ent.ncomp, ent.h_samp, ent.v_samp, ent.n, "cuda:0")
                 qt = torch.from_numpy(ent.qt[:, :ent.ncomp].copy().view(np.int16)).to("cuda:0")
-                frames = stage.read_frames(coef, qt).to_numpy()
+                from imageflow_amd.graphics.bitmaps import Bitmap, get_stride
+                fst = get_stride(stage.out_w)
+                fbuf = torch.full((ent.n + 1, stage.out_h * fst), 0xA5, dtype=torch.uint8, device="cuda:0")
+                frames = stage.read_frames(coef, qt, Bitmap(fbuf[:ent.n], stage.out_w, stage.out_h, fst)).to_numpy()
                 errs = []
+                if not all(bool((g == 0x5A5A).all()) for g in guards):
+                    errs.append("a store landed behind a coefficient plane")
+                if not bool((fbuf[ent.n] == 0xA5).all()):
+                    errs.append("a store landed behind the last decoded frame")
                 for k in range(n):
                     px = frames[k][:, :4 * w].reshape(h, w, 4)
                     if not np.array_equal(px[..., [2, 1, 0]], refs[k]):
