@@ -20,6 +20,9 @@ SHAPES = [(1920, 1080, 3840, 2160), (1920, 1080, 2560, 1440), (640, 480, 1280, 9
 
 def main():
     dev = torch.device("cuda:0")
+    global SHAPES
+    if len(sys.argv) > 1:                                    # shapes as iw,ih,ow,oh arguments
+        SHAPES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
     for (iw, ih, ow, oh) in SHAPES:
         for filt in (Filter.Robidoux, Filter.Box, Filter.Triangle, Filter.Hermite, Filter.Ginseng):
             for alpha in (False, True):
