@@ -572,6 +572,21 @@ int enqueue_batch(const ifhip_resample_plan* p, const uint8_t* d_in, size_t in_i
         a.lanes_per_frame = block;
         const uint64_t grid = static_cast<uint64_t>((n_images + frames - 1u) / frames) * sd.n_bands * a.n_strips;
         if (grid > 0x7fffffffull) return fail(IFHIP_INVALID_ARGUMENT, "InvalidArgument: batch too large for one launch");
+        // Up-scales with alpha whose geometry leaves the CU a workgroup of at most four waves (a 1 440 - 2 048 column source cut
+        // into two strips, the output rows of one frame filling the LDS so that no second frame shares the workgroup) run on the
+        // banded kernel's column strips instead: 0.34 - 0.89 of the fused kernel's time on every such shape and filter measured
+        // (profiles/r6_fused_vs_banded_upscales.jsonl); with five or more waves, and without alpha, the fused kernel stays ahead.
+        if (force_kernel == -1 && !ycc && !probe && alpha && block * frames <= 256u &&
+            4ull * p->out_w >= 5ull * p->in_w && 4ull * p->out_h >= 5ull * p->in_h) {
+            BandPlan bp;
+            if (banded_plan(p, d_in, in_image_bytes, in_stride, n_images, &bp)) {
+                if (trace_launch())
+                    std::fprintf(stderr, "ifhip banded launch (instead of a %u-lane fused workgroup): %ux%u -> %ux%u rows/band=%u strip=%u strips=%u grid=%u lds=%zu images=%u\n",
+                                 block * frames, p->in_w, p->in_h, p->out_w, p->out_h, bp.args.rows_per_band, bp.args.strip_w, bp.args.n_strips, bp.grid, bp.lds, n_images);
+                HIP_TRY(launch_banded(a, true, bp.args, bp.grid, bp.lds, st));
+                return IFHIP_OK;
+            }
+        }
         if (trace_launch())                                      // development aid: the shape this call launches
             std::fprintf(stderr, "ifhip fused launch: %ux%u -> %ux%u K=%d alpha=%d ycc=%d lanes/frame=%u frames/wg=%u bands=%u strips=%u "
                          "grid=%llu lds=%zu fast_g=%u two_col=%d w_in_lds=%d l2s_in_lds=%d lut_copies=%u per_pixel=%d images=%u\n",

@@ -390,6 +390,19 @@ def test_wide_up_scales_take_the_banded_kernel_in_column_strips(case, alpha):
              space=WorkingFloatspace.StandardRGB)
 
 
+@pytest.mark.parametrize("case", [(1440, 36, 2880, 72, Filter.Robidoux), (1920, 30, 2400, 38, Filter.Hermite), (1600, 28, 2400, 42, Filter.Box),
+                                  (1920, 24, 3840, 48, Filter.Triangle)])
+def test_wide_alpha_up_scales_the_fused_kernel_could_take_go_to_the_banded_kernel(case):
+    """Auto mode, alpha, a source of 1 440 - 2 048 columns up-scaled by 1.25 or more: the fused kernel's geometry would be one
+    workgroup of at most four waves per CU, the banded kernel's column strips are 1.1 - 2.9 x faster there (api.cpp); whichever
+    runs, the pixels are the oracle's -- in every compositing mode."""
+    iw, ih, ow, oh, filt = case
+    run_case(iw, ih, ow, oh, alpha=True, filt=filt, n=3)
+    run_case(iw, ih, ow, oh, alpha=True, filt=filt, n=2, compose=BitmapCompositing.BlendWithSelf, x=7, y=2, cw=ow + 8, ch=oh + 5)
+    run_case(iw, ih, ow, oh, alpha=True, filt=filt, n=2, compose=BitmapCompositing.BlendWithMatte, matte=0xFF102030, force=0)    # and the fused kernel still agrees
+    run_case(iw, ih, ow, oh, alpha=False, filt=filt, n=2)
+
+
 def test_banded_kernel_refuses_what_does_not_fit():
     with pytest.raises(FlowError) as e:
         run_case(3840, 216, 200, 20, n=1, force=2)            # 76 source rows x 3840 columns x 16 bytes per band of one row
